@@ -1,0 +1,77 @@
+"""In-tree builds: host library (g++), HIP library (hipcc, gfx950) and -- for the
+test/bench checker only -- the CPU oracle (gcc).  No JIT cache: the .so files
+land next to the sources so they travel to the GPU box with the snapshot."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(ROOT, "include")
+ORACLE = os.path.join(ROOT, "oracle")
+
+HOST_LIB = os.path.join(PKG, "libisph_host.so")
+HIP_LIB = os.path.join(PKG, "libisph_hip.so")
+ORACLE_LIB = os.path.join(ORACLE, "libisph_oracle.so")
+
+HOST_SRCS = ["workload.cpp"]
+HIP_SRCS = ["isph_capi.hip"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return r
+
+
+def _headers():
+    hs = [os.path.join(INC, f) for f in os.listdir(INC)]
+    hs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".cuh"))]
+    return hs
+
+
+def build_host(force=False):
+    srcs = [os.path.join(CSRC, s) for s in HOST_SRCS]
+    if force or _stale(HOST_LIB, srcs + _headers()):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INC, "-o", HOST_LIB] + srcs)
+    return HOST_LIB
+
+
+def hipcc_path():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP library cannot be built")
+
+
+def build_hip(force=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SRCS]
+    deps = srcs + _headers() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip")]
+    if force or _stale(HIP_LIB, deps):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-I", INC, "-I", CSRC, "-o", HIP_LIB] + srcs + ["-L/opt/rocm/lib", "-lrccl"])
+    return HIP_LIB
+
+
+def build_oracle(force=False):
+    """Compiles the CPU restatement used as the parity checker (tests, smoke,
+    bench cpu_baseline).  Building the checker is not using it."""
+    srcs = [os.path.join(ORACLE, "isph_oracle.c")]
+    deps = srcs + [os.path.join(ORACLE, "isph_oracle.h")]
+    if force or _stale(ORACLE_LIB, deps):
+        _run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
+              "-o", ORACLE_LIB] + srcs + ["-lm"])
+    return ORACLE_LIB
+
+
+def build_all(force=False):
+    return build_host(force), build_hip(force), build_oracle(force)

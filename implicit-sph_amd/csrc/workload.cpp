@@ -1,0 +1,220 @@
+// workload.cpp -- synthetic Taylor-Green-vortex particle bricks (host C++).
+//
+// Stands in for the LAMMPS side of the boundary: per-rank atoms + ghost atoms
+// (periodic images / off-rank neighbours) and the full neighbour list that
+// PairISPH::compute receives (ref: pair_isph.cpp:1241-1260, functor.h:86-104),
+// for the lattices of sph-script/taylor-green-vortex-{2d,3d}.lmp.
+#include "isph_workload.h"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace {
+
+struct Layout {
+  int dim;
+  int N[3], P[3], rc[3], lo[3], hi[3], n[3], g[3], ext[3], bs[3];
+  double dx[3], h, cut, cutn;
+  int nlocal, nghost;
+};
+
+inline int wrap(int c, int n) { int r = c % n; return r < 0 ? r + n : r; }
+
+inline void split(int N, int P, int r, int &lo, int &hi) {
+  lo = (int)((long long)r * N / P);
+  hi = (int)((long long)(r + 1) * N / P);
+}
+
+// local index of owned cell c (coordinates relative to the rank's lo) in a
+// rank whose owned extent is n, ordered in bricks of bs (x fastest everywhere)
+inline int brick_index(const int n[3], const int bs[3], const int c[3]) {
+  int b[3], i[3], bd[3];
+  for (int a = 0; a < 3; ++a) {
+    const int s = bs[a] > 0 ? bs[a] : n[a];
+    b[a] = c[a] / s;
+    i[a] = c[a] % s;
+    const int rem = n[a] - b[a] * s;
+    bd[a] = rem < s ? rem : s;
+  }
+  const int s0 = bs[0] > 0 ? bs[0] : n[0], s1 = bs[1] > 0 ? bs[1] : n[1], s2 = bs[2] > 0 ? bs[2] : n[2];
+  long long off = (long long)b[2] * s2 * n[0] * n[1];
+  off += (long long)b[1] * s1 * n[0] * bd[2];
+  off += (long long)b[0] * s0 * bd[1] * bd[2];
+  off += ((long long)i[2] * bd[1] + i[1]) * bd[0] + i[0];
+  return (int)off;
+}
+
+inline uint64_t splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ULL;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+inline double u01(uint64_t seed, uint64_t gid, int axis) {
+  const uint64_t r = splitmix64(splitmix64(seed) ^ (gid * 3u + (uint64_t)axis));
+  return (double)(r >> 11) * (1.0 / 9007199254740992.0);
+}
+
+bool make_layout(const isph_tgv_spec *s, Layout &L) {
+  L.dim = s->dim;
+  if (s->dim != 2 && s->dim != 3) return false;
+  double maxdisp = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    L.N[a] = (a < s->dim) ? s->ncell[a] : 1;
+    L.P[a] = (a < s->dim) ? (s->pgrid[a] > 0 ? s->pgrid[a] : 1) : 1;
+    L.bs[a] = (a < s->dim) ? s->brick[a] : 0;
+    if (L.N[a] < 1 || L.P[a] > L.N[a]) return false;
+    L.dx[a] = 2.0 * M_PI / L.N[a];
+  }
+  int r = s->rank;
+  if (r < 0 || r >= L.P[0] * L.P[1] * L.P[2]) return false;
+  L.rc[0] = r % L.P[0]; r /= L.P[0];
+  L.rc[1] = r % L.P[1]; r /= L.P[1];
+  L.rc[2] = r;
+  L.h = s->h_over_dx * L.dx[0];
+  L.cut = s->cut_over_h * L.h;
+  L.cutn = L.cut + s->skin;
+  if (s->mode == ISPH_TGV_JITTER) maxdisp = s->jitter_amp * L.h;
+  if (s->mode == ISPH_TGV_ADVECT) maxdisp = std::fabs(s->advect_dt) * s->umax;
+  L.nlocal = 1;
+  long long nall = 1;
+  for (int a = 0; a < 3; ++a) {
+    split(L.N[a], L.P[a], L.rc[a], L.lo[a], L.hi[a]);
+    L.n[a] = L.hi[a] - L.lo[a];
+    L.g[a] = (a < s->dim) ? (int)std::floor((L.cutn + 2.0 * maxdisp) / L.dx[a] + 1e-6) : 0;
+    L.ext[a] = L.n[a] + 2 * L.g[a];
+    L.nlocal *= L.n[a];
+    nall *= L.ext[a];
+  }
+  if (nall > 2000000000LL) return false;
+  L.nghost = (int)nall - L.nlocal;
+  return true;
+}
+
+inline void tgv_velocity(double umax, const double p[3], double v[3]) {
+  v[0] = umax * std::sin(p[0]) * std::cos(p[1]);
+  v[1] = -umax * std::cos(p[0]) * std::sin(p[1]);
+  v[2] = 0.0;
+}
+
+// position / velocity of the particle born in wrapped global cell gw, placed
+// at unwrapped cell gc (gc == gw for owned cells)
+void particle_state(const isph_tgv_spec *s, const Layout &L, const int gc[3], const int gw[3],
+                    double x[3], double v[3]) {
+  double base[3], disp[3] = {0, 0, 0};
+  const uint64_t gid = ((uint64_t)gw[2] * L.N[1] + gw[1]) * L.N[0] + gw[0];
+  for (int a = 0; a < 3; ++a)
+    base[a] = (a < L.dim) ? (gw[a] + s->origin[a]) * L.dx[a] : 0.0;
+  if (s->mode == ISPH_TGV_JITTER) {
+    for (int a = 0; a < L.dim; ++a) disp[a] = s->jitter_amp * L.h * (2.0 * u01(s->seed, gid, a) - 1.0);
+    double p[3] = {base[0] + disp[0], base[1] + disp[1], base[2] + disp[2]};
+    tgv_velocity(s->umax, p, v);
+  } else {
+    tgv_velocity(s->umax, base, v);
+    if (s->mode == ISPH_TGV_ADVECT)
+      for (int a = 0; a < L.dim; ++a) disp[a] = s->advect_dt * v[a];
+  }
+  for (int a = 0; a < 3; ++a)
+    x[a] = (a < L.dim) ? (gc[a] + s->origin[a]) * L.dx[a] + disp[a] : 0.0;
+}
+
+}  // namespace
+
+extern "C" int isph_tgv_count(const isph_tgv_spec *s, int *nlocal, int *nghost, long long *neigh_cap) {
+  Layout L;
+  if (!make_layout(s, L)) return -1;
+  *nlocal = L.nlocal;
+  *nghost = L.nghost;
+  long long stencil = 1;
+  for (int a = 0; a < 3; ++a) stencil *= (2 * L.g[a] + 1);
+  *neigh_cap = (long long)L.nlocal * (stencil - 1);
+  return 0;
+}
+
+extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v, int *tag,
+                                   int *owner_rank, int *owner_index,
+                                   int *neigh_ptr, int *neigh_idx) {
+  Layout L;
+  if (!make_layout(s, L)) return -1;
+  const long long next = (long long)L.ext[0] * L.ext[1] * L.ext[2];
+  std::vector<int> pidx((size_t)next);  // extended cell -> particle index
+  // owned cells -> brick order, ghosts -> nlocal + running counter
+  int ghost = L.nlocal;
+  for (int ez = 0; ez < L.ext[2]; ++ez)
+    for (int ey = 0; ey < L.ext[1]; ++ey)
+      for (int ex = 0; ex < L.ext[0]; ++ex) {
+        const int e[3] = {ex, ey, ez};
+        int c[3], gc[3], gw[3];
+        bool own = true;
+        for (int a = 0; a < 3; ++a) {
+          c[a] = e[a] - L.g[a];
+          gc[a] = L.lo[a] + c[a];
+          gw[a] = wrap(gc[a], L.N[a]);
+          if (c[a] < 0 || c[a] >= L.n[a]) own = false;
+        }
+        const long long ec = ((long long)ez * L.ext[1] + ey) * L.ext[0] + ex;
+        int p;
+        if (own) {
+          p = brick_index(L.n, L.bs, c);
+          owner_rank[p] = s->rank;
+          owner_index[p] = p;
+        } else {
+          p = ghost++;
+          int orc[3], olo[3], ohi[3], on[3], oc[3];
+          for (int a = 0; a < 3; ++a) {
+            // owner rank coordinate along a: invert split()
+            int r = (int)(((long long)(gw[a] + 1) * L.P[a] - 1) / L.N[a]);
+            split(L.N[a], L.P[a], r, olo[a], ohi[a]);
+            while (gw[a] < olo[a]) { --r; split(L.N[a], L.P[a], r, olo[a], ohi[a]); }
+            while (gw[a] >= ohi[a]) { ++r; split(L.N[a], L.P[a], r, olo[a], ohi[a]); }
+            orc[a] = r;
+            on[a] = ohi[a] - olo[a];
+            oc[a] = gw[a] - olo[a];
+          }
+          owner_rank[p] = (orc[2] * L.P[1] + orc[1]) * L.P[0] + orc[0];
+          owner_index[p] = brick_index(on, L.bs, oc);
+        }
+        pidx[(size_t)ec] = p;
+        tag[p] = 1 + (int)(((long long)gw[2] * L.N[1] + gw[1]) * L.N[0] + gw[0]);
+        particle_state(s, L, gc, gw, &x[3 * (size_t)p], &v[3 * (size_t)p]);
+      }
+  // full neighbour list, candidates in ascending extended-cell order
+  const double cutnsq = L.cutn * L.cutn;
+  std::vector<int> rowcnt((size_t)L.nlocal, 0);
+  // pass 1 counts, pass 2 fills (rows are in brick order, cells are visited
+  // lexicographically, so we need the counts first)
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      neigh_ptr[0] = 0;
+      for (int i = 0; i < L.nlocal; ++i) neigh_ptr[i + 1] = neigh_ptr[i] + rowcnt[(size_t)i];
+    }
+    for (int cz = 0; cz < L.n[2]; ++cz)
+      for (int cy = 0; cy < L.n[1]; ++cy)
+        for (int cx = 0; cx < L.n[0]; ++cx) {
+          const int ex = cx + L.g[0], ey = cy + L.g[1], ez = cz + L.g[2];
+          const int i = pidx[(size_t)(((long long)ez * L.ext[1] + ey) * L.ext[0] + ex)];
+          const double *xi = &x[3 * (size_t)i];
+          int cnt = 0;
+          int *out = pass == 1 ? &neigh_idx[neigh_ptr[i]] : nullptr;
+          for (int oz = -L.g[2]; oz <= L.g[2]; ++oz)
+            for (int oy = -L.g[1]; oy <= L.g[1]; ++oy)
+              for (int ox = -L.g[0]; ox <= L.g[0]; ++ox) {
+                if (!ox && !oy && !oz) continue;
+                const int j = pidx[(size_t)(((long long)(ez + oz) * L.ext[1] + (ey + oy)) * L.ext[0] + (ex + ox))];
+                const double *xj = &x[3 * (size_t)j];
+                double rsq = 0.0;
+                for (int a = 0; a < L.dim; ++a) {
+                  const double d = xi[a] - xj[a];
+                  rsq += d * d;
+                }
+                if (rsq < cutnsq) {
+                  if (out) out[cnt] = j;
+                  ++cnt;
+                }
+              }
+          if (pass == 0) rowcnt[(size_t)i] = cnt;
+        }
+  }
+  return neigh_ptr[L.nlocal];
+}

@@ -1,0 +1,127 @@
+"""ctypes front end of the host-side TGV particle generator (csrc/workload.cpp,
+include/isph_workload.h).  Produces what the LAMMPS adapter would hand over:
+atom arrays + ghosts + full neighbour list for one rank's brick."""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import build as _build
+
+LATTICE, JITTER, ADVECT = 0, 1, 2
+
+
+class _Spec(C.Structure):
+    _fields_ = [("dim", C.c_int), ("ncell", C.c_int * 3), ("pgrid", C.c_int * 3), ("rank", C.c_int),
+                ("brick", C.c_int * 3), ("origin", C.c_double * 3), ("h_over_dx", C.c_double),
+                ("cut_over_h", C.c_double), ("skin", C.c_double), ("mode", C.c_int),
+                ("jitter_amp", C.c_double), ("seed", C.c_ulonglong), ("umax", C.c_double),
+                ("advect_dt", C.c_double)]
+
+
+_lib = None
+
+
+def _host():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_build.build_host())
+        _lib.isph_tgv_count.restype = C.c_int
+        _lib.isph_tgv_fill.restype = C.c_longlong
+    return _lib
+
+
+@dataclass
+class TGVSpec:
+    dim: int = 3
+    ncell: tuple = (16, 16, 16)
+    pgrid: tuple = (1, 1, 1)
+    rank: int = 0
+    brick: tuple = (8, 8, 8)
+    origin: tuple = (0.0, 0.0, 0.0)
+    h_over_dx: float = 1.5
+    cut_over_h: float = 2.0
+    skin: float = 0.0
+    mode: int = ADVECT
+    jitter_amp: float = 0.05
+    seed: int = 42
+    umax: float = 0.1
+    advect_dt: float = -1.0  # <0 => 0.1*h/umax (3-D script) / 0.05*dx/umax (2-D)
+    kernel: str = "wendland"
+    rho: float = 1.0
+    nu: float = 0.1
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def dx(self):
+        return 2.0 * math.pi / self.ncell[0]
+
+    @property
+    def h(self):
+        return self.h_over_dx * self.dx
+
+    @property
+    def cut(self):
+        return self.cut_over_h * self.h
+
+    @property
+    def dt(self):
+        """time step of the reference scripts: taylor-green-vortex-3d.lmp:27,
+        taylor-green-vortex-2d.lmp:29"""
+        if self.dim == 3:
+            return 0.1 * self.h / self.umax
+        return 0.05 * self.dx / self.umax
+
+    def c_spec(self):
+        s = _Spec()
+        s.dim = self.dim
+        nc = list(self.ncell) + [1] * (3 - len(self.ncell))
+        pg = list(self.pgrid) + [1] * (3 - len(self.pgrid))
+        br = list(self.brick) + [0] * (3 - len(self.brick))
+        og = list(self.origin) + [0.0] * (3 - len(self.origin))
+        if self.dim == 2:
+            nc[2], pg[2], br[2], og[2] = 1, 1, 0, 0.0
+        for a in range(3):
+            s.ncell[a], s.pgrid[a], s.brick[a], s.origin[a] = nc[a], pg[a], br[a], og[a]
+        s.rank = self.rank
+        s.h_over_dx, s.cut_over_h, s.skin = self.h_over_dx, self.cut_over_h, self.skin
+        s.mode, s.jitter_amp, s.seed, s.umax = self.mode, self.jitter_amp, self.seed, self.umax
+        s.advect_dt = self.advect_dt if self.advect_dt >= 0 else self.dt
+        return s
+
+
+def make_tgv(spec: TGVSpec):
+    """Returns a dict of numpy arrays for one rank: x,v [nall,3]; tag, type,
+    owner_rank, owner_index [nall]; neigh_ptr [nlocal+1]; neigh_idx; plus
+    scalars nlocal, nall and per-particle rho, nu."""
+    lib = _host()
+    cs = spec.c_spec()
+    nlocal, nghost, cap = C.c_int(), C.c_int(), C.c_longlong()
+    if lib.isph_tgv_count(C.byref(cs), C.byref(nlocal), C.byref(nghost), C.byref(cap)) != 0:
+        raise ValueError("invalid TGV spec")
+    nlocal, nall = nlocal.value, nlocal.value + nghost.value
+    x = np.zeros((nall, 3))
+    v = np.zeros((nall, 3))
+    tag = np.zeros(nall, dtype=np.int32)
+    orank = np.zeros(nall, dtype=np.int32)
+    oidx = np.zeros(nall, dtype=np.int32)
+    nptr = np.zeros(nlocal + 1, dtype=np.int32)
+    nidx = np.zeros(cap.value, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    nn = lib.isph_tgv_fill(C.byref(cs), p(x), p(v), p(tag), p(orank), p(oidx), p(nptr), p(nidx))
+    if nn < 0:
+        raise RuntimeError("isph_tgv_fill failed")
+    nidx = nidx[:nn].copy()
+    return dict(spec=spec, dim=spec.dim, nlocal=nlocal, nall=nall, x=x, v=v, tag=tag,
+                type=np.ones(nall, dtype=np.int32), owner_rank=orank, owner_index=oidx,
+                neigh_ptr=nptr, neigh_idx=nidx,
+                rho=np.full(nall, spec.rho), nu=np.full(nall, spec.nu),
+                h=spec.h, cut=spec.cut, dt=spec.dt)
+
+
+def single_rank_colmap(parts):
+    """Matrix column of every particle on one rank: ghosts are periodic images,
+    their column is the owner's local id (Epetra LID of the shared tag)."""
+    assert np.all(parts["owner_rank"] == parts["spec"].rank)
+    return parts["owner_index"].astype(np.int32).copy()

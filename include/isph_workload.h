@@ -1,0 +1,55 @@
+/*
+ * isph_workload.h -- synthetic Taylor-Green-vortex particle sets (host only).
+ *
+ * Replaces, for benchmarking and tests, what LAMMPS hands PairISPH::compute
+ * in the reference: atom->x / v / tag / type, the full neighbour list
+ * (list->numneigh / firstneigh) and the ghost atoms of the rank's brick.
+ * Geometry follows sph-script/taylor-green-vortex-{2d,3d}.lmp: box [0,2pi)^d
+ * periodic, simple-cubic lattice dx = 2pi/N, h = 1.5 dx, cut = "cut over h"*h.
+ *
+ * No GPU code and no oracle code in here: this is the input side of the
+ * drop-in boundary (what the LAMMPS adapter would pass in).
+ */
+#ifndef ISPH_WORKLOAD_H
+#define ISPH_WORKLOAD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ISPH_TGV_LATTICE = 0, ISPH_TGV_JITTER = 1, ISPH_TGV_ADVECT = 2 };
+
+typedef struct {
+  int dim;               /* 2 or 3                                            */
+  int ncell[3];          /* global lattice cells per axis (ncell[2]=1 in 2-D) */
+  int pgrid[3];          /* rank grid (domain decomposition bricks)           */
+  int rank;              /* this rank, x fastest                              */
+  int brick[3];          /* in-rank particle ordering: bricks of this many cells
+                            (0 => plain lexicographic order)                  */
+  double origin[3];      /* lattice origin as a fraction of dx (0.5 in the 2-D
+                            script, 0 in the 3-D script)                      */
+  double h_over_dx;      /* 1.5                                               */
+  double cut_over_h;     /* 2.0 Wendland, 3.0 Quintic                         */
+  double skin;           /* neighbour-list skin (absolute length)             */
+  int mode;              /* ISPH_TGV_*                                        */
+  double jitter_amp;     /* JITTER: positions += U(-a,a)*h per axis           */
+  unsigned long long seed;
+  double umax;           /* 0.1                                               */
+  double advect_dt;      /* ADVECT: positions += advect_dt * v_tgv(lattice)   */
+} isph_tgv_spec;
+
+/* Sizes needed to allocate the arrays of isph_tgv_fill. */
+int isph_tgv_count(const isph_tgv_spec *s, int *nlocal, int *nghost, long long *neigh_cap);
+
+/* x,v: [nall][3]; tag: [nall] global 1-based id (ghost images share the
+ * owner's tag); owner_rank/owner_index: [nall] owning rank and its local index
+ * there; neigh_ptr: [nlocal+1]; neigh_idx: [<=neigh_cap] indices into
+ * [0,nall).  Returns the number of neighbour entries, <0 on error. */
+long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v, int *tag,
+                        int *owner_rank, int *owner_index,
+                        int *neigh_ptr, int *neigh_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,131 @@
+/*
+ * isph_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the implicit-sph pressure-Poisson hot path
+ * (assembly functors + SolverLin_Belos/Ifpack semantics).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product path (implicit-sph_amd/) never links or calls it.
+ *
+ * Every function cites the reference file:line (relative to
+ * /root/reference/IMPLICIT-SPH/) whose algorithm it restates.
+ *
+ * PARITY PINNING STATUS
+ *   - assembly half: restated from the reference functors; pinned by the
+ *     reference's own end-to-end known answers (2-D TGV convergence table,
+ *     sph-script/conv-taylor-green-vortex-2d-rev390.txt) through
+ *     oracle/tgv_driver.py, plus analytic invariants (tests/test_oracle_*).
+ *   - solve half: the arithmetic lives in Trilinos (Belos/Ifpack/Epetra,
+ *     un-vendored, no pinned version: README:9-11).  The reference holds no
+ *     numeric vectors at that boundary, so the Krylov/ILU restatement follows
+ *     the published Belos/Ifpack algorithm definitions and is cross-checked
+ *     against SciPy only: solver parity is otherwise UNPINNED.
+ */
+#ifndef ISPH_ORACLE_H
+#define ISPH_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* particle kinds, pair_isph.h:113-123 */
+enum { ORC_KIND_FLUID = 99, ORC_KIND_SOLID = 12, ORC_KIND_ALL = 127,
+       ORC_KIND_BUFFER_DIRICHLET = 32, ORC_KIND_BUFFER_NEUMANN = 64 };
+/* SingularPoisson, pair_isph.h:134-138 */
+enum { ORC_NOT_SINGULAR = 0, ORC_NULLSPACE = 1, ORC_PINZERO = 2, ORC_DOUBLEDIAG = 3 };
+/* kernels */
+enum { ORC_WENDLAND = 0, ORC_QUINTIC = 1, ORC_CUBIC = 2 };
+
+typedef struct {
+  int dim, nlocal, nall, ntypes, kernel;
+  const double *x;       /* [nall][3]   atom->x                              */
+  const int *type;       /* [nall]      atom->type, 1..ntypes                */
+  const int *kind;       /* [ntypes+1]  PairISPH::getParticleKind(type)      */
+  const double *h;       /* [(ntypes+1)^2] pair->h[itype][jtype]             */
+  const double *cutsq;   /* [(ntypes+1)^2] pair->cutsq                       */
+  const int *neigh_ptr;  /* [nlocal+1]  flattened list->firstneigh           */
+  const int *neigh_idx;  /* neighbour indices into [0,nall)                  */
+  const int *colmap;     /* [nall] matrix column of particle j (LID of tag)  */
+  const int *owner;      /* [nall] local index owning ghost j (forward comm) */
+  double *vfrac;         /* [nall]      atom->vfrac                          */
+  double *Gc;            /* [nall][dim*dim] column-major (VIEW2)             */
+  double *Lc;            /* [nall][dimL] packed upper                         */
+  const double *pnd;     /* [nall] particle number density (MorrisHolmes) or NULL */
+  double morris_safe_coeff;
+} orc_particles;
+
+typedef struct {
+  int solver_type;       /* 0 = "Block GMRES", 1 = "Block CG"                */
+  int flexible;          /* "Flexible Gmres"                                 */
+  int num_blocks;        /* "Num Blocks"                                     */
+  int max_iters;         /* "Maximum Iterations"                             */
+  int max_restarts;      /* "Maximum Restarts"                               */
+  double tol;            /* "Convergence Tolerance"                          */
+  int ortho;             /* 0 DGKS, 1 ICGS, 2 IMGS                           */
+  int verbose;
+} orc_solver_params;
+
+typedef struct {
+  int converged, iters, restarts;
+  double rel_res_implicit;   /* recurrence residual / ||r0||                 */
+  double rel_res_explicit;   /* ||b - A x|| / ||b||  (solver_lin_belos.h:201-212) */
+  double setup_seconds, solve_seconds;
+} orc_solve_info;
+
+/* ---- kernels (kernel_wendland.h, kernel_quintic.h, kernel_cubic.h) ---- */
+double orc_kernel_val(int kernel, int dim, double r, double h);
+double orc_kernel_dval(int kernel, int dim, double r, double h);
+
+/* ---- pre-computation (functor_volume.h, functor_gradient_correction.h,
+ *      functor_laplacian_correction.h) ---- */
+void orc_forward_comm(const orc_particles *P, double *arr, int ncomp);
+void orc_compute_volumes(const orc_particles *P);
+void orc_compute_gradient_correction(const orc_particles *P);
+int  orc_compute_laplacian_correction(const orc_particles *P);
+
+/* ---- graph + operators ---- */
+int  orc_graph(const orc_particles *P, int *rowptr, int *colidx, int cap);
+int  orc_laplacian_matrix(const orc_particles *P, int antisym, double alpha,
+                          const double *material, int filt_i, int filt_j,
+                          int morris_holmes,
+                          const int *rowptr, const int *colidx, double *val);
+void orc_divergence(const orc_particles *P, int antisym, const double *f,
+                    double alpha, int use_filter, int filt_i, int filt_j,
+                    int morris_holmes, double *div);
+void orc_gradient(const orc_particles *P, int antisym, const double *f,
+                  double alpha, int use_filter, int filt_i, int filt_j,
+                  double *grad /* [nlocal][3] */);
+void orc_laplacian_apply(const orc_particles *P, int antisym, const double *f,
+                         int ncomp, double alpha, const double *material,
+                         int filt_i, int filt_j, double *lap);
+int  orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
+                 double dt, const double *rho, const double *vstar,
+                 const double *normal, int singular_mode, int is_rank0,
+                 const int *rowptr, const int *colidx, double *val,
+                 double *b, double *work);
+
+/* ---- linear algebra restatement (Epetra/Belos/Ifpack semantics) ---- */
+void orc_spmv(int n, const int *rowptr, const int *colidx, const double *val,
+              const double *x, double *y);
+void orc_null_vector(int n, const int *mask, double *nvec);
+
+typedef struct orc_ilu orc_ilu;
+orc_ilu *orc_ilu_create(int n, const int *rowptr, const int *colidx,
+                        const double *val, int level_of_fill,
+                        int nblocks, const int *block_ptr);
+void orc_ilu_apply(const orc_ilu *F, const double *r, double *z);
+int  orc_ilu_nnz(const orc_ilu *F);
+void orc_ilu_export(const orc_ilu *F, int *rowptr, int *colidx, double *val);
+void orc_ilu_destroy(orc_ilu *F);
+
+/* prec_type: 0 none, 1 jacobi, 2 (block-)ILU(k) given by F */
+int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
+              double *b, double *x, int is_singular, const int *null_mask,
+              int prec_type, const orc_ilu *F,
+              const orc_solver_params *prm, orc_solve_info *info);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
