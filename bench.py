@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- pressure-Poisson solves/sec + SpMV roofline on the 3-D Taylor-Green
+vortex, one process per GPU.
+
+A "step" = one pass of the reference's `ISPH: solvePoisson` scope
+(pair_isph.cpp:1008-1012 -> solver_lin_belos.h:130-222) over the resident
+system: preconditioner build (rebuilt every solve like prec->create()/free())
++ right-preconditioned FGMRES(50)/DGKS + null-space projections.  The matrix
+and right-hand side are assembled on the GPU before the timed region
+(`ISPH: computePoisson`, reported separately as assemble_ms).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def spmv_algorithmic_bytes(nrow, nnz):
+    """12 B per stored entry (fp64 value + int32 column),
+    x read once, y written once, row pointers."""
+    return 12 * nnz + 16 * nrow + 4 * (nrow + 1)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ncell", type=int, default=100, help="lattice cells per axis PER GPU brick edge")
+    ap.add_argument("--mode", default="advect", choices=["advect", "jitter", "lattice"])
+    ap.add_argument("--prec", default="bjacobi-ilu0", choices=["none", "jacobi", "bjacobi-ilu0"])
+    ap.add_argument("--block", type=int, default=512)
+    ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--spmv-reps", type=int, default=50)
+    return ap.parse_args()
+
+
+def pgrid_for(n):
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
+
+
+def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters):
+    """Oracle (CPU restatement of Belos FGMRES + Ifpack block-ILU(0)) timed on the
+    host cores on a bounded sample: preconditioner setup + `cpu_iters` of the
+    iterations the full solve needs, extrapolated linearly."""
+    import oracle as orc
+    n = len(rp) - 1
+    t0 = time.perf_counter()
+    ilu = None
+    if prec == "bjacobi-ilu0":
+        bp = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
+        ilu = orc.ILU(rp, ci, val, 0, bp)
+    t_setup = time.perf_counter() - t0
+    pk = {"none": "none", "jacobi": "jacobi", "bjacobi-ilu0": "ilu"}[prec]
+    ts = []
+    for it in (max(cpu_iters // 2, 1), cpu_iters):
+        t0 = time.perf_counter()
+        orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, params=orc.SolverParams(max_iters=it))
+        ts.append((it, time.perf_counter() - t0))
+    per_iter = (ts[1][1] - ts[0][1]) / max(ts[1][0] - ts[0][0], 1)
+    total = t_setup + ts[1][1] + per_iter * max(iters_gpu - ts[1][0], 0)
+    return dict(value=1.0 / total, unit="solves/s", cores=orc.num_threads(), kind="port",
+                sample="same %d-row system: block-ILU(0) setup (%.2fs) + %d of %d FGMRES iterations (%.2fs), "
+                       "extrapolated at %.3fs/iteration" % (n, t_setup, ts[1][0], iters_gpu, ts[1][1], per_iter),
+                seconds_per_solve=total)
+
+
+def main():
+    args = parse()
+    import torch
+    import isph_amd  # noqa: F401
+    from isph_amd import hip, workload, dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ngpu = args.gpus
+    assert world == ngpu, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (ngpu, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=dev)
+        uid = [hip.Context.unique_id() if rank == 0 else None]
+        td.broadcast_object_list(uid, src=0)
+        ctx = hip.Context(local_rank, stream=stream, rank=rank, nranks=world, uid=uid[0])
+    else:
+        td = None
+        ctx = hip.Context(local_rank, stream=stream)
+
+    # ---- synthetic input: one brick of ncell^3 particles per GPU (weak scaling)
+    pg = pgrid_for(world)
+    n = args.ncell
+    mode = {"advect": workload.ADVECT, "jitter": workload.JITTER, "lattice": workload.LATTICE}[args.mode]
+    spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=(8, 8, 8),
+                            mode=mode, kernel=args.kernel, cut_over_h=2.0 if args.kernel == "wendland" else 3.0)
+    parts = workload.make_tgv(spec)
+    plan = dist.make_plan(parts, td)                      # column map + halo lists (trivial on 1 rank)
+    nlocal = parts["nlocal"]
+
+    # device-resident particle arrays
+    dparts = dict(parts)
+    for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+        dparts[k] = torch.from_numpy(np.ascontiguousarray(parts[k])).to(dev)
+    colmap = torch.from_numpy(plan.colmap).to(dev)
+    rho = torch.from_numpy(parts["rho"]).to(dev)
+    vstar = torch.from_numpy(np.ascontiguousarray(parts["v"])).to(dev)
+
+    # computePre: volumes on the GPU + forward comm of ghost volumes
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    vf = hip.compute_volumes(ctx, dparts, colmap, kernel=args.kernel)
+    vfrac = dist.forward_scalar(plan, vf, td, dev)
+    A, b = hip.assemble_poisson(ctx, dparts, colmap, spec.dt, rho, vstar, vfrac=vfrac, ncol=plan.ncol,
+                                kernel=args.kernel, rank0=(rank == 0))
+    if plan.npeers:
+        A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+    torch.cuda.synchronize()
+    assemble_ms = (time.perf_counter() - t0) * 1e3
+    info_m = A.info()
+
+    x = torch.zeros(nlocal, dtype=torch.float64, device=dev)
+    bwork = torch.empty_like(b)
+    prm = hip.SolverParams()
+    ctx.set_profile(True)
+
+    def step():
+        bwork.copy_(b)
+        x.zero_()
+        M = hip.Precond(ctx, A, args.prec, args.block)
+        inf = hip.solve(ctx, A, bwork, x, prec=M, singular=True, params=prm)
+        M.close()
+        return inf
+
+    def barrier():
+        if td is not None:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        inf = step()
+    barrier()
+    t0 = time.perf_counter()
+    spmv_ms, spmv_calls = 0.0, 0
+    for _ in range(args.steps):
+        inf = step()
+        spmv_ms += inf.spmv_ms
+        spmv_calls += inf.spmv_calls
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if td is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # isolated SpMV (no halo, back-to-back launches) for reference
+    ctx.set_profile(False)
+    xin = torch.randn(plan.ncol, dtype=torch.float64, device=dev)
+    yout = torch.empty(nlocal, dtype=torch.float64, device=dev)
+    iso_ms = A.spmv_time(xin, yout, reps=args.spmv_reps) if world == 1 else None
+
+    alg_bytes = spmv_algorithmic_bytes(info_m["nrow"], info_m["nnz"])
+    avg_ms = spmv_ms / max(spmv_calls, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+block-Jacobi ILU(0), tol 1e-8)",
+            "value": args.steps * world / elapsed,
+            "unit": "solves/s (1M-particle bricks; x n_gpus under weak scaling)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3D Taylor-Green vortex, %d^3 particles per GPU, Wendland cut=2h (BASELINE configs[1]%s), "
+                                   "state after one Lagrangian step (mode=%s)" % (n, "" if world == 1 else "/[2] brick", args.mode),
+                       "rows_per_gpu": nlocal, "global_rows": nlocal * world, "nnz_per_gpu": info_m["nnz"],
+                       "nnz_per_row": info_m["nnz"] / max(nlocal, 1), "sell_padding": info_m["stored"] / max(info_m["nnz"], 1),
+                       "solver": "FGMRES(50) DGKS tol 1e-8, right prec", "precond": args.prec, "block_rows": args.block,
+                       "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
+                       "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
+                       "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms,
+                       "spmv_isolated_ms": iso_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_sell_spmv", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": spmv_calls},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rp, ci, val = A.export_csr()
+            out["cpu_baseline"] = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, inf.iters, args.prec,
+                                               args.cpu_iters)
+            out["config"]["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if td is not None:
+        td.barrier()
+        td.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

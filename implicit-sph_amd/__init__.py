@@ -6,3 +6,5 @@ The directory name carries a hyphen (it mirrors the reference repo name), so it
 is imported through ``isph_amd`` (repo root) or ``importlib.import_module``."""
 from . import build  # noqa: F401
 from . import workload  # noqa: F401
+from . import dist  # noqa: F401
+from . import hip  # noqa: F401

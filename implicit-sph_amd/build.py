@@ -1,6 +1,6 @@
-"""In-tree builds: host library (g++), HIP library (hipcc, gfx950) and -- for the
-test/bench checker only -- the CPU oracle (gcc).  No JIT cache: the .so files
-land next to the sources so they travel to the GPU box with the snapshot."""
+"""In-tree builds: host library (g++) and HIP library (hipcc, gfx950).  No JIT
+cache: the .so files land next to the sources so they travel to the GPU box
+with the snapshot."""
 import os
 import shutil
 import subprocess
@@ -9,11 +9,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(ROOT, "include")
-ORACLE = os.path.join(ROOT, "oracle")
 
 HOST_LIB = os.path.join(PKG, "libisph_host.so")
 HIP_LIB = os.path.join(PKG, "libisph_hip.so")
-ORACLE_LIB = os.path.join(ORACLE, "libisph_oracle.so")
 
 HOST_SRCS = ["workload.cpp"]
 HIP_SRCS = ["isph_capi.hip"]
@@ -62,16 +60,5 @@ def build_hip(force=False):
     return HIP_LIB
 
 
-def build_oracle(force=False):
-    """Compiles the CPU restatement used as the parity checker (tests, smoke,
-    bench cpu_baseline).  Building the checker is not using it."""
-    srcs = [os.path.join(ORACLE, "isph_oracle.c")]
-    deps = srcs + [os.path.join(ORACLE, "isph_oracle.h")]
-    if force or _stale(ORACLE_LIB, deps):
-        _run(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
-              "-o", ORACLE_LIB] + srcs + ["-lm"])
-    return ORACLE_LIB
-
-
 def build_all(force=False):
-    return build_host(force), build_hip(force), build_oracle(force)
+    return build_host(force), build_hip(force)

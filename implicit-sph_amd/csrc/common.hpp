@@ -1,0 +1,121 @@
+// common.hpp -- shared host/device helpers of libisph_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "isph_hip.h"
+
+namespace isph {
+
+extern thread_local std::string g_last_error;
+
+inline int fail(const char *what, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s (%s:%d)", what, file, line);
+  g_last_error = buf;
+  return ISPH_FAILURE;
+}
+
+#define ISPH_CHECK_HIP(expr)                                                        \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) return ::isph::fail(hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define ISPH_CHECK_NCCL(expr)                                                        \
+  do {                                                                               \
+    ncclResult_t e_ = (expr);                                                        \
+    if (e_ != ncclSuccess) return ::isph::fail(ncclGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define ISPH_CHECK(expr)                                  \
+  do {                                                    \
+    int rc_ = (expr);                                     \
+    if (rc_ != ISPH_SUCCESS) return rc_;                  \
+  } while (0)
+#define ISPH_REQUIRE(cond, msg)                                        \
+  do {                                                                 \
+    if (!(cond)) return ::isph::fail(msg, __FILE__, __LINE__);        \
+  } while (0)
+
+// grow-only device buffer (hipMalloc is synchronous and slow: never inside the
+// Krylov loop; workspaces are sized once per solve)
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t n) {
+    if (n <= cap) return ISPH_SUCCESS;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    ISPH_CHECK_HIP(hipMalloc((void **)&p, n * sizeof(T)));
+    cap = n;
+    return ISPH_SUCCESS;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kSlice = 64;         // SELL slice height = one wavefront
+constexpr int kBlock = 256;        // 4 waves
+constexpr int kXcd = 8;            // XCDs (per-XCD L2)
+constexpr int kMaxRedBlocks = 2048;
+
+// ---- wave-level reductions with DPP (no LDS traffic) --------------------
+// row_shr / row_bcast patterns of the gfx9 DPP encoding; a double moves as two
+// 32-bit halves.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes; result valid in lane 63, broadcast by readlane
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_move<0x111>(v);        // row_shr:1
+  v += dpp_move<0x112>(v);        // row_shr:2
+  v += dpp_move<0x114>(v);        // row_shr:4
+  v += dpp_move<0x118>(v);        // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_move<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    int t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// sum within aligned groups of 8 lanes (result in every lane of the group)
+__device__ __forceinline__ double group8_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// XCD-aware block remap: the dispatcher deals blocks round-robin over the 8
+// XCDs, so blockIdx b lands on XCD b%8.  Give each XCD one contiguous range of
+// work items so its private L2 only sees that range's slice of x.
+__device__ __forceinline__ int xcd_remap(int b, int nblocks_padded) {
+  const int per = nblocks_padded / kXcd;
+  return (b % kXcd) * per + (b / kXcd);
+}
+
+}  // namespace isph

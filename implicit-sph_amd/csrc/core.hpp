@@ -1,0 +1,46 @@
+// core.hpp -- context / matrix / preconditioner objects behind the C ABI.
+#pragma once
+#include "common.hpp"
+#include "sell.hpp"
+
+struct isph_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int rank = 0, nranks = 1;
+  ncclComm_t comm = nullptr;
+  bool profile = false;
+  // reduction scratch + small scalar mailboxes
+  isph::DevBuf<double> partial;   // per-block partials
+  isph::DevBuf<double> dscal;     // device scalars (dot results, Hessenberg column, ...)
+  double *hscal = nullptr;        // pinned host mirror
+  size_t hscal_cap = 0;
+  // Krylov workspaces (grow-only, reused across solves)
+  isph::DevBuf<double> V, Z, wv, tv, rv, pv, nvec, xext, sendbuf, bdev, xdev;
+  isph::DevBuf<int> imask;
+  // profiling events
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct isph_halo {
+  int npeers = 0;
+  std::vector<int> peer, send_ptr, recv_ptr;
+  isph::DevBuf<int> send_idx;
+  int nsend = 0, nrecv = 0;
+};
+
+struct isph_mat {
+  isph::Sell S;
+  isph_halo halo;
+};
+
+struct isph_ilu;  // ilu.hpp
+
+struct isph_prec {
+  int type = 0;  // 0 none, 1 jacobi, 2 bjacobi-ilu0
+  int n = 0;
+  isph::DevBuf<double> invdiag;
+  isph_ilu *ilu = nullptr;
+};

@@ -1,0 +1,482 @@
+// isph_capi.hip -- the extern "C" surface of libisph_hip.so (include/isph_hip.h).
+// gfx950 only; no CPU fallback anywhere in this library.
+#include <algorithm>
+#include <numeric>
+
+#include "assemble.hpp"
+#include "core.hpp"
+#include "ilu.hpp"
+#include "krylov.hpp"
+#include "sell.hpp"
+#include "solver.hpp"
+
+namespace isph {
+thread_local std::string g_last_error;
+
+int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z) {
+  const int n = M ? M->n : 0;
+  if (!M || M->type == 0) {
+    // identity: callers pass distinct buffers
+    if (r != z && M) ISPH_CHECK_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    return ISPH_SUCCESS;
+  }
+  if (M->type == 1) {
+    hipLaunchKernelGGL(k_mul_elem, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, r, M->invdiag.p, z);
+    return ISPH_SUCCESS;
+  }
+  return ilu_apply(ctx, M->ilu, r, z);
+}
+
+// upload helper: returns device pointer (either the caller's or a staged copy)
+template <class T>
+int stage_in(isph_ctx *ctx, const T *src, size_t n, int on_device, DevBuf<T> &tmp, const T **out) {
+  if (on_device) { *out = src; return ISPH_SUCCESS; }
+  ISPH_CHECK(tmp.reserve(n > 0 ? n : 1));
+  ISPH_CHECK_HIP(hipMemcpyAsync(tmp.p, src, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+  *out = tmp.p;
+  return ISPH_SUCCESS;
+}
+
+int sell_finalize_offsets(isph_ctx *ctx, Sell &S) {
+  // slice_off currently holds per-slice entry counts in [0,nslices)
+  hipLaunchKernelGGL(k_exclusive_scan_ll, dim3(1), dim3(1024), 0, ctx->stream, S.nslices, S.slice_off.p, S.slice_off.p);
+  long long total = 0;
+  ISPH_CHECK_HIP(hipMemcpyAsync(&total, S.slice_off.p + S.nslices, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  S.stored = total;
+  ISPH_CHECK(S.col.reserve((size_t)(total > 0 ? total : 1)));
+  ISPH_CHECK(S.val.reserve((size_t)(total > 0 ? total : 1)));
+  return ISPH_SUCCESS;
+}
+
+}  // namespace isph
+
+using namespace isph;
+
+extern "C" {
+
+const char *isph_last_error(void) { return g_last_error.c_str(); }
+
+int isph_comm_unique_id(char *uid) {
+  static_assert(sizeof(ncclUniqueId) <= ISPH_UID_BYTES, "uid size");
+  ncclUniqueId id;
+  ISPH_CHECK_NCCL(ncclGetUniqueId(&id));
+  memset(uid, 0, ISPH_UID_BYTES);
+  memcpy(uid, &id, sizeof(id));
+  return ISPH_SUCCESS;
+}
+
+static int ctx_create_common(int device, void *stream, isph_ctx **out) {
+  ISPH_REQUIRE(out != nullptr, "ctx out pointer is NULL");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail("no HIP device: libisph_hip has no CPU fallback", __FILE__, __LINE__);
+  ISPH_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+  ISPH_CHECK_HIP(hipSetDevice(device));
+  isph_ctx *c = new isph_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    ISPH_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  ISPH_CHECK_HIP(hipEventCreate(&c->ev0));
+  ISPH_CHECK_HIP(hipEventCreate(&c->ev1));
+  ISPH_CHECK(ensure_scalars(c));
+  *out = c;
+  return ISPH_SUCCESS;
+}
+
+int isph_ctx_create(int device, void *stream, isph_ctx **ctx) { return ctx_create_common(device, stream, ctx); }
+
+int isph_ctx_create_dist(int device, void *stream, int rank, int nranks, const char *uid, isph_ctx **ctx) {
+  ISPH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && uid, "bad rank/nranks/uid");
+  ISPH_CHECK(ctx_create_common(device, stream, ctx));
+  isph_ctx *c = *ctx;
+  c->rank = rank;
+  c->nranks = nranks;
+  ncclUniqueId id;
+  memcpy(&id, uid, sizeof(id));
+  ISPH_CHECK_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
+  return ISPH_SUCCESS;
+}
+
+int isph_ctx_sync(isph_ctx *ctx) {
+  ISPH_REQUIRE(ctx, "ctx is NULL");
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+int isph_ctx_set_profile(isph_ctx *ctx, int on) {
+  ISPH_REQUIRE(ctx, "ctx is NULL");
+  ctx->profile = on != 0;
+  return ISPH_SUCCESS;
+}
+
+void isph_ctx_destroy(isph_ctx *c) {
+  if (!c) return;
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  for (auto e : c->ev) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  c->partial.release(); c->dscal.release(); c->V.release(); c->Z.release(); c->wv.release(); c->tv.release();
+  c->rv.release(); c->pv.release(); c->nvec.release(); c->xext.release(); c->sendbuf.release();
+  c->bdev.release(); c->xdev.release(); c->imask.release();
+  if (c->hscal) (void)hipHostFree(c->hscal);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+/* ---- matrix ----------------------------------------------------------- */
+
+int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx,
+                        const double *val, int on_device, isph_mat **Aout) {
+  ISPH_REQUIRE(ctx && Aout && rowptr && colidx && val, "NULL argument");
+  ISPH_REQUIRE(nrow >= 0 && ncol >= nrow, "need 0 <= nrow <= ncol");
+  DevBuf<int> trp, tci;
+  DevBuf<double> tv;
+  const int *drp, *dci;
+  const double *dv;
+  long long nnz = 0;
+  ISPH_CHECK(stage_in(ctx, rowptr, (size_t)nrow + 1, on_device, trp, &drp));
+  if (on_device) {
+    int last = 0;
+    ISPH_CHECK_HIP(hipMemcpyAsync(&last, rowptr + nrow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    nnz = last;
+  } else {
+    nnz = rowptr[nrow];
+    // host-side validation of the operand shapes the kernels assume
+    for (int i = 0; i < nrow; ++i) ISPH_REQUIRE(rowptr[i + 1] >= rowptr[i], "rowptr not monotone");
+    for (long long p = 0; p < nnz; ++p) ISPH_REQUIRE(colidx[p] >= 0 && colidx[p] < ncol, "column index out of range");
+  }
+  ISPH_CHECK(stage_in(ctx, colidx, (size_t)nnz, on_device, tci, &dci));
+  ISPH_CHECK(stage_in(ctx, val, (size_t)nnz, on_device, tv, &dv));
+  isph_mat *A = new isph_mat();
+  Sell &S = A->S;
+  S.nrow = nrow; S.ncol = ncol; S.nnz = nnz;
+  S.nslices = (nrow + kSlice - 1) / kSlice;
+  int rc = S.slice_off.reserve((size_t)S.nslices + 1);
+  if (rc == ISPH_SUCCESS) rc = S.rowlen.reserve((size_t)(nrow > 0 ? nrow : 1));
+  if (rc == ISPH_SUCCESS && nrow > 0) {
+    hipLaunchKernelGGL(k_csr_rowlen_slicew, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, drp,
+                       S.rowlen.p, S.slice_off.p);
+    rc = sell_finalize_offsets(ctx, S);
+    if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL(k_csr_to_sell, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
+                         S.slice_off.p, S.col.p, S.val.p);
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+        rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);
+    }
+  }
+  trp.release(); tci.release(); tv.release();
+  if (rc != ISPH_SUCCESS) { isph_mat_destroy(A); return rc; }
+  *Aout = A;
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_rank, const int *send_ptr,
+                      const int *send_idx, const int *recv_ptr) {
+  ISPH_REQUIRE(ctx && A, "NULL argument");
+  isph_halo &H = A->halo;
+  H.npeers = npeers;
+  H.peer.assign(peer_rank, peer_rank + npeers);
+  H.send_ptr.assign(send_ptr, send_ptr + npeers + 1);
+  H.recv_ptr.assign(recv_ptr, recv_ptr + npeers + 1);
+  H.nsend = H.send_ptr[npeers];
+  H.nrecv = H.recv_ptr[npeers];
+  ISPH_REQUIRE(H.nrecv == A->S.ncol - A->S.nrow, "halo receive count != number of ghost columns");
+  for (int p = 0; p < npeers; ++p) ISPH_REQUIRE(peer_rank[p] >= 0 && peer_rank[p] < ctx->nranks, "peer rank out of range");
+  for (int k = 0; k < H.nsend; ++k) ISPH_REQUIRE(send_idx[k] >= 0 && send_idx[k] < A->S.nrow, "send index out of range");
+  ISPH_CHECK(H.send_idx.reserve((size_t)(H.nsend > 0 ? H.nsend : 1)));
+  if (H.nsend > 0) {
+    ISPH_CHECK_HIP(hipMemcpyAsync(H.send_idx.p, send_idx, sizeof(int) * (size_t)H.nsend, hipMemcpyHostToDevice, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_info(const isph_mat *A, long long info[6]) {
+  ISPH_REQUIRE(A && info, "NULL argument");
+  info[0] = A->S.nrow; info[1] = A->S.ncol; info[2] = A->S.nnz; info[3] = A->S.nslices;
+  info[4] = A->S.stored; info[5] = A->S.stored * 12 + ((long long)A->S.nslices + 1) * 8;
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_export_csr(isph_ctx *ctx, const isph_mat *A, int *rowptr, int *colidx, double *val) {
+  ISPH_REQUIRE(ctx && A && rowptr && colidx && val, "NULL argument");
+  const Sell &S = A->S;
+  std::vector<int> len((size_t)S.nrow);
+  ISPH_CHECK_HIP(hipMemcpyAsync(len.data(), S.rowlen.p, sizeof(int) * (size_t)S.nrow, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<long long> rp((size_t)S.nrow + 1, 0);
+  for (int i = 0; i < S.nrow; ++i) rp[(size_t)i + 1] = rp[(size_t)i] + len[(size_t)i];
+  const long long nnz = rp[(size_t)S.nrow];
+  ISPH_REQUIRE(nnz < 2147483647LL, "nnz exceeds 32-bit CSR export");
+  DevBuf<long long> drp;
+  DevBuf<int> dci;
+  DevBuf<double> dv;
+  ISPH_CHECK(drp.reserve((size_t)S.nrow + 1));
+  ISPH_CHECK(dci.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  ISPH_CHECK(dv.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  ISPH_CHECK_HIP(hipMemcpyAsync(drp.p, rp.data(), sizeof(long long) * ((size_t)S.nrow + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (S.nrow > 0)
+    hipLaunchKernelGGL(k_sell_to_csr, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow,
+                       S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, drp.p, dci.p, dv.p);
+  std::vector<int> ci((size_t)nnz);
+  std::vector<double> v((size_t)nnz);
+  ISPH_CHECK_HIP(hipMemcpyAsync(ci.data(), dci.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(v.data(), dv.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  drp.release(); dci.release(); dv.release();
+  // sort columns inside each row (Epetra OptimizeStorage order)
+  std::vector<int> perm;
+  for (int i = 0; i < S.nrow; ++i) {
+    const long long b = rp[(size_t)i], e = rp[(size_t)i + 1];
+    perm.resize((size_t)(e - b));
+    std::iota(perm.begin(), perm.end(), 0);
+    std::sort(perm.begin(), perm.end(), [&](int a, int c) { return ci[(size_t)(b + a)] < ci[(size_t)(b + c)]; });
+    for (long long k = b; k < e; ++k) {
+      colidx[k] = ci[(size_t)(b + perm[(size_t)(k - b)])];
+      val[k] = v[(size_t)(b + perm[(size_t)(k - b)])];
+    }
+    rowptr[i] = (int)b;
+  }
+  rowptr[S.nrow] = (int)nnz;
+  return ISPH_SUCCESS;
+}
+
+void isph_mat_destroy(isph_mat *A) {
+  if (!A) return;
+  A->S.release();
+  A->halo.send_idx.release();
+  delete A;
+}
+
+int isph_spmv(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, int on_device) {
+  ISPH_REQUIRE(ctx && A && x && y, "NULL argument");
+  const Sell &S = A->S;
+  if (on_device) {
+    ISPH_CHECK(spmv_dev(ctx, A, x, y, nullptr));
+    return ISPH_SUCCESS;
+  }
+  const size_t nx = (S.ncol > S.nrow && A->halo.npeers == 0) ? (size_t)S.ncol : (size_t)S.nrow;
+  ISPH_CHECK(ctx->xdev.reserve((size_t)S.ncol));
+  ISPH_CHECK(ctx->bdev.reserve((size_t)(S.nrow > 0 ? S.nrow : 1)));
+  ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
+  if (S.ncol > S.nrow && A->halo.npeers == 0) {
+    // caller supplied all ncol entries (ghost values included): plain kernel
+    int nbp = 0;
+    const int grid = spmv_grid(S.nslices, &nbp);
+    hipLaunchKernelGGL((k_sell_spmv<4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                       S.slice_off.p, S.col.p, S.val.p, (const double *)ctx->xdev.p, ctx->bdev.p, (const double *)nullptr,
+                       (double *)nullptr);
+  } else {
+    ISPH_CHECK(spmv_dev(ctx, A, ctx->xdev.p, ctx->bdev.p, nullptr));
+  }
+  ISPH_CHECK_HIP(hipMemcpyAsync(y, ctx->bdev.p, sizeof(double) * (size_t)S.nrow, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double *y_dev, int reps, double *avg_ms) {
+  ISPH_REQUIRE(ctx && A && x_dev && y_dev && avg_ms && reps > 0, "bad argument");
+  const Sell &S = A->S;
+  ISPH_REQUIRE(S.ncol == S.nrow || A->halo.npeers > 0, "ghost columns without halo plan");
+  const double *xuse = x_dev;
+  ISPH_CHECK(halo_exchange(ctx, A, x_dev, &xuse));
+  int nbp = 0;
+  const int grid = spmv_grid(S.nslices, &nbp);
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL((k_sell_spmv<4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                       S.slice_off.p, S.col.p, S.val.p, xuse, y_dev, (const double *)nullptr, (double *)nullptr);
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+  ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  ISPH_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *avg_ms = (double)ms / reps;
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+/* ---- preconditioner --------------------------------------------------- */
+
+int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int block_size, isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && A && type && Mout, "NULL argument");
+  isph_prec *M = new isph_prec();
+  M->n = A->S.nrow;
+  int rc = ISPH_SUCCESS;
+  if (!strcmp(type, "none")) {
+    M->type = 0;
+  } else if (!strcmp(type, "jacobi")) {
+    M->type = 1;
+    rc = M->invdiag.reserve((size_t)(M->n > 0 ? M->n : 1));
+    if (rc == ISPH_SUCCESS && M->n > 0) {
+      hipLaunchKernelGGL(k_sell_inv_diag, dim3((M->n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, M->n,
+                         A->S.rowlen.p, A->S.slice_off.p, A->S.col.p, A->S.val.p, M->invdiag.p);
+      if (hipGetLastError() != hipSuccess) rc = fail("jacobi setup failed", __FILE__, __LINE__);
+    }
+  } else if (!strcmp(type, "bjacobi-ilu0")) {
+    M->type = 2;
+    rc = ilu_create(ctx, A, block_size, &M->ilu);
+  } else {
+    rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu0)", __FILE__, __LINE__);
+  }
+  if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
+  *Mout = M;
+  return ISPH_SUCCESS;
+}
+
+int isph_prec_apply(isph_ctx *ctx, const isph_prec *M, const double *r, double *z, int on_device) {
+  ISPH_REQUIRE(ctx && M && r && z, "NULL argument");
+  if (on_device) return prec_apply_dev(ctx, M, r, z);
+  const size_t n = (size_t)M->n;
+  ISPH_CHECK(ctx->xdev.reserve(n > 0 ? n : 1));
+  ISPH_CHECK(ctx->bdev.reserve(n > 0 ? n : 1));
+  ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p, r, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK(prec_apply_dev(ctx, M, ctx->xdev.p, ctx->bdev.p));
+  ISPH_CHECK_HIP(hipMemcpyAsync(z, ctx->bdev.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+int isph_prec_export_ilu(isph_ctx *ctx, const isph_prec *M, int *rowptr, int *colidx, double *val) {
+  ISPH_REQUIRE(ctx && M && M->type == 2 && M->ilu, "not an ILU preconditioner");
+  return ilu_export(ctx, M->ilu, rowptr, colidx, val);
+}
+
+long long isph_prec_nnz(const isph_prec *M) { return (M && M->type == 2 && M->ilu) ? ilu_nnz(M->ilu) : 0; }
+
+void isph_prec_destroy(isph_prec *M) {
+  if (!M) return;
+  M->invdiag.release();
+  if (M->ilu) ilu_destroy(M->ilu);
+  delete M;
+}
+
+/* ---- solve ------------------------------------------------------------ */
+
+void isph_solver_params_default(isph_solver_params *p) {
+  // SolverLin_Belos::setParameters(NULL), ref: solver_lin_belos.h:226-240
+  p->solver_type = 0; p->flexible = 1; p->num_blocks = 50; p->max_iters = 500; p->max_restarts = 15;
+  p->tol = 1.0e-8; p->ortho = 0; p->verbose = 0;
+}
+
+int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, double *x, int nvec, int lda,
+               int is_singular, const int *null_mask, const isph_solver_params *prm_in, isph_solve_info *info,
+               int on_device) {
+  ISPH_REQUIRE(ctx && A && b && x && info, "NULL argument");
+  const int n = A->S.nrow;
+  ISPH_REQUIRE(nvec >= 1 && lda >= n, "need nvec >= 1 and lda >= nlocal");
+  ISPH_REQUIRE(!M || M->n == n, "preconditioner / matrix size mismatch");
+  isph_solver_params prm;
+  if (prm_in) prm = *prm_in; else isph_solver_params_default(&prm);
+  memset(info, 0, sizeof(*info));
+  ISPH_CHECK(ensure_scalars(ctx));
+  hipStream_t st = ctx->stream;
+  ctx->ev_used = 0;
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, st));
+
+  double *db = b, *dx = x;
+  const size_t tot = (size_t)lda * (size_t)nvec;
+  if (!on_device) {
+    ISPH_CHECK(ctx->bdev.reserve(tot));
+    ISPH_CHECK(ctx->xdev.reserve(tot));
+    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->bdev.p, b, sizeof(double) * tot, hipMemcpyHostToDevice, st));
+    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p, x, sizeof(double) * tot, hipMemcpyHostToDevice, st));
+    db = ctx->bdev.p;
+    dx = ctx->xdev.p;
+  }
+  const int sg = stream_grid(n);
+  const double *nv = nullptr;
+  if (is_singular) {
+    // SolverLin::createNullVector, ref: solver_lin.cpp:59-77
+    ISPH_CHECK(ctx->nvec.reserve((size_t)(n > 0 ? n : 1)));
+    if (null_mask) {
+      ISPH_CHECK(ctx->imask.reserve((size_t)(n > 0 ? n : 1)));
+      ISPH_CHECK_HIP(hipMemcpyAsync(ctx->imask.p, null_mask, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_mask_to_double, dim3(sg), dim3(kBlock), 0, st, n, ctx->imask.p, ctx->nvec.p);
+    } else {
+      hipLaunchKernelGGL(k_fill, dim3(sg), dim3(kBlock), 0, st, n, ctx->nvec.p, 1.0);
+    }
+    ISPH_CHECK(dot_dev(ctx, n, ctx->nvec.p, ctx->nvec.p, nullptr, nullptr, SC_MISC + 6));
+    hipLaunchKernelGGL(k_scale_copy, dim3(sg), dim3(kBlock), 0, st, n, ctx->nvec.p, ctx->nvec.p, 1.0,
+                       ctx->dscal.p + SC_MISC + 6, 1);
+    nv = ctx->nvec.p;
+  }
+  LinOp op{ctx, A, M, nv, n};
+  int iters = 0, restarts = 0, conv = 1;
+  double worst_imp = 0.0, worst_exp = 0.0;
+  for (int c = 0; c < nvec; ++c) {
+    double *bc = db + (size_t)c * lda, *xc = dx + (size_t)c * lda;
+    if (nv) ISPH_CHECK(project_dev(ctx, n, nv, bc));  // b -= (b.n) n   (:141-143)
+    isph_solve_info ci;
+    memset(&ci, 0, sizeof(ci));
+    if (prm.solver_type == 1) ISPH_CHECK(pcg(op, bc, xc, &prm, &ci));
+    else ISPH_CHECK(gmres(op, bc, xc, &prm, &ci));
+    {  // ||b - A x|| / ||b|| with the unprojected A (:201-212)
+      ISPH_CHECK(ctx->wv.reserve((size_t)n + 64));
+      ISPH_CHECK(spmv_dev(ctx, A, xc, ctx->wv.p, nullptr));
+      hipLaunchKernelGGL(k_residual, dim3(sg), dim3(kBlock), 0, st, n, bc, ctx->wv.p);
+      ISPH_CHECK(dot_dev(ctx, n, ctx->wv.p, ctx->wv.p, bc, bc, SC_MISC + 16));
+    }
+    if (nv) ISPH_CHECK(project_dev(ctx, n, nv, xc));  // x -= (x.n) n   (:215-219)
+    ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 16, 2));
+    const double bn = std::sqrt(ctx->hscal[SC_MISC + 17]);
+    ci.rel_res_explicit = std::sqrt(ctx->hscal[SC_MISC + 16]) / (bn == 0.0 ? 1.0 : bn);
+    iters += ci.iters;
+    restarts += ci.restarts;
+    conv = conv && ci.converged;
+    worst_imp = std::max(worst_imp, ci.rel_res_implicit);
+    worst_exp = std::max(worst_exp, ci.rel_res_explicit);
+    if (ctx->rank == 0 && prm.verbose) {
+      // non-convergence is reported, never raised (:192-213)
+      if (ci.converged) printf(">> isph::Status - Passed! (%d iterations)\n", ci.iters);
+      else printf(">> isph::Status - Failed to converge! ||r|| / ||b|| = %6.4e\n", ci.rel_res_explicit);
+    }
+  }
+  if (!on_device) {
+    ISPH_CHECK_HIP(hipMemcpyAsync(b, db, sizeof(double) * tot, hipMemcpyDeviceToHost, st));
+    ISPH_CHECK_HIP(hipMemcpyAsync(x, dx, sizeof(double) * tot, hipMemcpyDeviceToHost, st));
+  }
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev1, st));
+  ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  ISPH_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  info->converged = conv; info->iters = iters; info->restarts = restarts;
+  info->rel_res_implicit = worst_imp; info->rel_res_explicit = worst_exp;
+  info->solve_ms = ms;
+  if (ctx->profile) {
+    double tot_ms = 0.0;
+    for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+      float t = 0.f;
+      ISPH_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev[k], ctx->ev[k + 1]));
+      tot_ms += t;
+    }
+    info->spmv_ms = tot_ms;
+    info->spmv_calls = (int)(ctx->ev_used / 2);
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+/* ---- assembly --------------------------------------------------------- */
+
+int isph_assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, const double *rho,
+                          const double *vstar, int singular_mode, int is_rank0, int ncol, isph_mat **A_out,
+                          double *b_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && rho && vstar && A_out && b_out, "NULL argument");
+  return assemble_poisson(ctx, P, antisym, dt, rho, vstar, singular_mode, is_rank0, ncol, A_out, b_out, on_device);
+}
+
+int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && vfrac_out, "NULL argument");
+  return compute_volumes(ctx, P, vfrac_out, on_device);
+}
+
+}  // extern "C"

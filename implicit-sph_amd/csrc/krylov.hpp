@@ -1,0 +1,186 @@
+// krylov.hpp -- fused Krylov primitives (what Epetra_MultiVector Dot/Norm2/
+// Update/Scale and Belos' orthogonalisation supply in the reference:
+// solver_lin.h:136-137, solver_lin_belos.h:142-143,217-218).
+//
+// All reductions are two-stage and deterministic: per-block partials via DPP
+// wave sums (+ LDS across the 4 waves), then one small kernel that adds the
+// partials in a fixed order.  Scalars stay on the device between kernels; the
+// host reads one small batch per Gram-Schmidt pass.
+#pragma once
+#include "common.hpp"
+
+namespace isph {
+
+constexpr int kDotRows = 4;  // rows per thread per chunk in the multi-dot
+
+// partial[(k)*nblk + blockIdx] = sum over this block's rows of V_k[i]*w[i],
+// k in [0,nk); slot nk holds w.w.  V_k = V + k*ld.  w is read once per
+// chunk and kept in registers while the nk basis vectors stream by.
+__global__ __launch_bounds__(kBlock) void k_multi_dot(int n, int nk, const double *__restrict__ V, long long ld,
+                                                      const double *__restrict__ w,
+                                                      double *__restrict__ partial) {
+  extern __shared__ double sacc[];  // [(nk+1)][4 waves]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = threadIdx.x; k < (nk + 1) * 4; k += blockDim.x) sacc[k] = 0.0;
+  __syncthreads();
+  const long long chunk = (long long)kBlock * kDotRows;
+  for (long long base = (long long)blockIdx.x * chunk; base < n; base += (long long)gridDim.x * chunk) {
+    double wr[kDotRows];
+    long long idx[kDotRows];
+    double ww = 0.0;
+#pragma unroll
+    for (int r = 0; r < kDotRows; ++r) {
+      idx[r] = base + (long long)r * kBlock + threadIdx.x;
+      wr[r] = idx[r] < n ? w[idx[r]] : 0.0;
+      ww = fma(wr[r], wr[r], ww);
+    }
+    for (int k = 0; k < nk; ++k) {
+      const double *__restrict__ vk = V + (long long)k * ld;
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < kDotRows; ++r)
+        if (idx[r] < n) s = fma(vk[idx[r]], wr[r], s);
+      s = wave_sum(s);
+      if (lane == 0) sacc[k * 4 + wave] += s;
+    }
+    ww = wave_sum(ww);
+    if (lane == 0) sacc[nk * 4 + wave] += ww;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= nk; k += blockDim.x)
+    partial[(long long)k * gridDim.x + blockIdx.x] = (sacc[k * 4] + sacc[k * 4 + 1]) + (sacc[k * 4 + 2] + sacc[k * 4 + 3]);
+}
+
+// out[k] = sum_b partial[k*nblk + b], one wave per k, fixed order
+__global__ void k_reduce_partials(int nk, int nblk, const double *__restrict__ partial, double *__restrict__ out) {
+  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (k >= nk) return;
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int b = lane; b < nblk; b += 64) s += partial[(long long)k * nblk + b];
+  s = wave_sum(s);
+  if (lane == 0) out[k] = s;
+}
+
+// w -= sum_k c[k] V_k ; partial[blockIdx] = sum of the new w.w  (c on device)
+__global__ __launch_bounds__(kBlock) void k_multi_axpy_norm(int n, int nk, const double *__restrict__ V, long long ld,
+                                                            const double *__restrict__ c, double *__restrict__ w,
+                                                            double *__restrict__ partial) {
+  __shared__ double sw[4];
+  double ww = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double s = w[i];
+    for (int k = 0; k < nk; ++k) s = fma(-c[k], V[(long long)k * ld + i], s);
+    w[i] = s;
+    ww = fma(s, s, ww);
+  }
+  ww = wave_sum(ww);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = ww;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+// x += sum_k c[k] Z_k   (solution update, c on device)
+__global__ void k_multi_axpy(int n, int nk, const double *__restrict__ Z, long long ld, const double *__restrict__ c,
+                             double *__restrict__ x) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double s = x[i];
+    for (int k = 0; k < nk; ++k) s = fma(c[k], Z[(long long)k * ld + i], s);
+    x[i] = s;
+  }
+}
+
+// dot partials of two vectors (plus optional second pair): partial[0*nblk+b]=a.b
+__global__ __launch_bounds__(kBlock) void k_dot2(int n, const double *__restrict__ a, const double *__restrict__ b,
+                                                 const double *__restrict__ c, const double *__restrict__ d,
+                                                 double *__restrict__ partial) {
+  __shared__ double s0[4], s1[4];
+  double p = 0.0, q = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    p = fma(a[i], b[i], p);
+    if (c) q = fma(c[i], d[i], q);
+  }
+  p = wave_sum(p);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = p; s1[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+    partial[gridDim.x + blockIdx.x] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+  }
+}
+
+// y = a*x  with a = alpha_host * (inv_sqrt ? 1/sqrt(*s) : (s ? *s : 1))
+__global__ void k_scale_copy(int n, const double *__restrict__ x, double *__restrict__ y, double alpha,
+                             const double *__restrict__ s, int inv_sqrt) {
+  double a = alpha;
+  if (s) a *= inv_sqrt ? 1.0 / sqrt(*s) : *s;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = a * x[i];
+}
+
+// y += (alpha * (*s)) * x       (s on device, may be NULL)
+__global__ void k_axpy_dev(int n, double alpha, const double *__restrict__ s, const double *__restrict__ x,
+                           double *__restrict__ y) {
+  const double a = s ? alpha * (*s) : alpha;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = fma(a, x[i], y[i]);
+}
+
+// r = b - r
+__global__ void k_residual(int n, const double *__restrict__ b, double *__restrict__ r) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    r[i] = b[i] - r[i];
+}
+
+// p = z + beta p   with beta = num/den on device
+__global__ void k_cg_update_p(int n, const double *__restrict__ z, double *__restrict__ p,
+                              const double *__restrict__ num, const double *__restrict__ den) {
+  const double beta = *num / *den;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    p[i] = fma(beta, p[i], z[i]);
+}
+
+// x += a p ; r -= a ap ; a = num/den on device; partial = new r.r
+__global__ __launch_bounds__(kBlock) void k_cg_update_xr(int n, const double *__restrict__ p,
+                                                         const double *__restrict__ ap, double *__restrict__ x,
+                                                         double *__restrict__ r, const double *__restrict__ num,
+                                                         const double *__restrict__ den, double *__restrict__ partial) {
+  __shared__ double sw[4];
+  const double a = *num / *den;
+  double rr = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    x[i] = fma(a, p[i], x[i]);
+    const double t = fma(-a, ap[i], r[i]);
+    r[i] = t;
+    rr = fma(t, t, rr);
+  }
+  rr = wave_sum(rr);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = rr;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+__global__ void k_mul_elem(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = a[i] * b[i];
+}
+
+__global__ void k_fill(int n, double *__restrict__ y, double v) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = v;
+}
+
+__global__ void k_mask_to_double(int n, const int *__restrict__ m, double *__restrict__ y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = (double)m[i];
+}
+
+inline int stream_grid(long long n) {
+  long long g = (n + kBlock - 1) / kBlock;
+  if (g > kMaxRedBlocks) g = kMaxRedBlocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace isph

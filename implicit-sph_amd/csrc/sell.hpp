@@ -1,0 +1,207 @@
+// sell.hpp -- sliced-ELL (SELL-64, pair-interleaved) matrix + SpMV for gfx950.
+//
+// Layout (DESIGN.md "data layout"): rows are cut into slices of 64 (= one
+// wavefront, lane == row).  A slice of width w (max row length, rounded up to
+// even) stores its entries pair-interleaved:
+//     entry (row lane, k)  ->  off + (k>>1)*128 + lane*2 + (k&1)
+// so one wave-instruction loads 64 x double2 = 1 KiB contiguous values
+// (global_load_dwordx4) and 64 x int2 = 512 B contiguous column ids.
+// Padding entries carry value 0 and the row's own column.
+// Replaces Epetra_CrsMatrix's CSR + Apply (ref: solver_lin.h:133).
+#pragma once
+#include "common.hpp"
+
+namespace isph {
+
+struct Sell {
+  int nrow = 0, ncol = 0, nslices = 0;
+  long long nnz = 0, stored = 0;
+  DevBuf<long long> slice_off;  // [nslices+1] entry offsets (multiples of 128)
+  DevBuf<int> rowlen;           // [nrow]
+  DevBuf<int> col;              // [stored]
+  DevBuf<double> val;           // [stored]
+  void release() { slice_off.release(); rowlen.release(); col.release(); val.release(); }
+};
+
+__device__ __forceinline__ long long sell_pos(long long off, int lane, int k) {
+  return off + (long long)(k >> 1) * 128 + lane * 2 + (k & 1);
+}
+
+// ---- CSR -> SELL ---------------------------------------------------------
+__global__ void k_csr_rowlen_slicew(int nrow, const int *__restrict__ rowptr, int *__restrict__ rowlen,
+                                    long long *__restrict__ slice_cnt) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  int len = 0;
+  if (row < nrow) {
+    len = rowptr[row + 1] - rowptr[row];
+    rowlen[row] = len;
+  }
+  const int w = wave_max_i32(len);
+  if ((threadIdx.x & 63) == 0 && row < nrow) slice_cnt[row >> 6] = (long long)((w + 1) & ~1) * kSlice;
+}
+
+// generic: slice entry counts from a row-length array
+__global__ void k_slicew_from_rowlen(int nrow, const int *__restrict__ rowlen, long long *__restrict__ slice_cnt) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  const int len = row < nrow ? rowlen[row] : 0;
+  const int w = wave_max_i32(len);
+  if ((threadIdx.x & 63) == 0 && row < nrow) slice_cnt[row >> 6] = (long long)((w + 1) & ~1) * kSlice;
+}
+
+// single-block exclusive scan of n long longs (n ~ 1e4..1e5): in[i] counts ->
+// out[i] offsets, out[n] total.  In-place allowed.
+__global__ void k_exclusive_scan_ll(int n, const long long *in, long long *out) {
+  __shared__ long long wsum[16];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    const long long v = i < n ? in[i] : 0;
+    long long s = v;  // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long t = __shfl_up(s, o, 64);
+      if ((threadIdx.x & 63) >= o) s += t;
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[wv] = s;
+    __syncthreads();
+    long long woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    const long long c = carry;
+    if (i < n) out[i] = c + woff + s - v;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry = c + woff + s;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
+__global__ void k_csr_to_sell(int nrow, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                              const double *__restrict__ cval, const long long *__restrict__ slice_off,
+                              int *__restrict__ scol, double *__restrict__ sval) {
+  const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int row = slice * kSlice + lane;
+  const int nslices = (nrow + kSlice - 1) / kSlice;
+  if (slice >= nslices) return;
+  const long long off = slice_off[slice];
+  const int w = (int)((slice_off[slice + 1] - off) >> 6);
+  int beg = 0, len = 0;
+  if (row < nrow) {
+    beg = rowptr[row];
+    len = rowptr[row + 1] - beg;
+  }
+  const int padcol = row < nrow ? row : 0;
+  for (int k = 0; k < w; ++k) {
+    const long long p = sell_pos(off, lane, k);
+    if (k < len) {
+      scol[p] = colidx[beg + k];
+      sval[p] = cval[beg + k];
+    } else {
+      scol[p] = padcol;
+      sval[p] = 0.0;
+    }
+  }
+}
+
+// ---- SELL -> CSR (export for tests; unsorted within the row) -------------
+__global__ void k_sell_to_csr(int nrow, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
+                              const int *__restrict__ scol, const double *__restrict__ sval,
+                              const long long *__restrict__ rowptr, int *__restrict__ colidx,
+                              double *__restrict__ cval) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrow) return;
+  const long long off = slice_off[row >> 6];
+  const int lane = row & 63;
+  const long long beg = rowptr[row];
+  for (int k = 0; k < rowlen[row]; ++k) {
+    const long long p = sell_pos(off, lane, k);
+    colidx[beg + k] = scol[p];
+    cval[beg + k] = sval[p];
+  }
+}
+
+// ---- SpMV ----------------------------------------------------------------
+// One wavefront per slice, lane == row.  UNROLL pair-columns are issued
+// back-to-back so each lane keeps UNROLL 16-B value loads, UNROLL 8-B index
+// loads and 2*UNROLL x-gathers in flight.  HBM-bound: 12 B/entry streamed,
+// x gathered through the XCD-local L2 (xcd_remap keeps an XCD on one
+// contiguous row range).  Optionally accumulates per-slice partials of y.n
+// for the PoissonProjection (ref: solver_lin.h:131-140).
+template <int UNROLL, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int nblocks_padded,
+                                                      const long long *__restrict__ slice_off,
+                                                      const int *__restrict__ scol,
+                                                      const double *__restrict__ sval,
+                                                      const double *__restrict__ x, double *__restrict__ y,
+                                                      const double *__restrict__ nvec,
+                                                      double *__restrict__ dot_partial) {
+  const int b = xcd_remap(blockIdx.x, nblocks_padded);
+  const int slice = b * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (slice >= nslices) return;
+  const int lane = threadIdx.x & 63;
+  const long long off = slice_off[slice];
+  const int npair = (int)((slice_off[slice + 1] - off) >> 7);
+  const double2 *__restrict__ v = reinterpret_cast<const double2 *>(sval + off) + lane;
+  const int2 *__restrict__ c = reinterpret_cast<const int2 *>(scol + off) + lane;
+  double acc0 = 0.0, acc1 = 0.0;
+  int q = 0;
+  for (; q + UNROLL <= npair; q += UNROLL) {
+    double2 vv[UNROLL];
+    int2 cc[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      vv[u] = v[(q + u) * 64];
+      cc[u] = c[(q + u) * 64];
+    }
+    double xa[UNROLL], xb[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      xa[u] = x[cc[u].x];
+      xb[u] = x[cc[u].y];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      acc0 = fma(vv[u].x, xa[u], acc0);
+      acc1 = fma(vv[u].y, xb[u], acc1);
+    }
+  }
+  for (; q < npair; ++q) {
+    const double2 vv = v[q * 64];
+    const int2 cc = c[q * 64];
+    acc0 = fma(vv.x, x[cc.x], acc0);
+    acc1 = fma(vv.y, x[cc.y], acc1);
+  }
+  const int row = slice * kSlice + lane;
+  const double r = acc0 + acc1;
+  if (row < nrow) y[row] = r;
+  if (DOT) {
+    const double d = wave_sum(row < nrow ? r * nvec[row] : 0.0);
+    if (lane == 0) dot_partial[slice] = d;
+  }
+}
+
+// invdiag[row] = 1 / A(row,row)  (point-Jacobi debug preconditioner)
+__global__ void k_sell_inv_diag(int nrow, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
+                                const int *__restrict__ scol, const double *__restrict__ sval,
+                                double *__restrict__ invdiag) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrow) return;
+  const long long off = slice_off[row >> 6];
+  double d = 0.0;
+  for (int k = 0; k < rowlen[row]; ++k) {
+    const long long p = sell_pos(off, row & 63, k);
+    if (scol[p] == row) d += sval[p];
+  }
+  invdiag[row] = d != 0.0 ? 1.0 / d : 1.0;
+}
+
+inline int spmv_grid(int nslices, int *nblocks_padded) {
+  const int nb = (nslices + 3) / 4;
+  const int per = (nb + kXcd - 1) / kXcd;
+  *nblocks_padded = per * kXcd;
+  return per * kXcd;
+}
+
+}  // namespace isph

@@ -1,0 +1,359 @@
+// solver.hpp -- host-side Krylov drivers issuing HIP kernels on one stream.
+//
+// Restates SolverLin_Belos::solveProblem (ref: solver_lin_belos.h:130-222):
+// Belos BlockGmresSolMgr (flexible, block size 1, DGKS) and BlockCGSolMgr,
+// right preconditioning, PoissonProjection for the singular pressure system
+// (ref: solver_lin.h:131-140).  Hessenberg / Givens live on the host (m<=50);
+// every vector operation is a kernel from krylov.hpp / sell.hpp.
+#pragma once
+#include <cmath>
+
+#include "core.hpp"
+#include "krylov.hpp"
+
+namespace isph {
+
+int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z);  // isph_capi.hip
+
+inline int allreduce_inplace(isph_ctx *ctx, double *d, int count) {
+  if (ctx->nranks > 1) ISPH_CHECK_NCCL(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+// device scalar mailbox layout
+enum { SC_DOT = 0 /* SC_DOT..SC_DOT+63: multi-dot results */, SC_Y = 64 /* 64 ys */, SC_MISC = 128, SC_COUNT = 160 };
+
+inline int ensure_scalars(isph_ctx *ctx) {
+  ISPH_CHECK(ctx->dscal.reserve(SC_COUNT));
+  ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
+  if (ctx->hscal_cap < SC_COUNT) {
+    if (ctx->hscal) (void)hipHostFree(ctx->hscal);
+    ISPH_CHECK_HIP(hipHostMalloc((void **)&ctx->hscal, SC_COUNT * sizeof(double)));
+    ctx->hscal_cap = SC_COUNT;
+  }
+  return ISPH_SUCCESS;
+}
+
+// read `count` device scalars starting at slot `first` into hscal[first..]
+inline int fetch_scalars(isph_ctx *ctx, int first, int count) {
+  ISPH_CHECK_HIP(hipMemcpyAsync(ctx->hscal + first, ctx->dscal.p + first, sizeof(double) * (size_t)count,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+// ---- halo exchange + SpMV -------------------------------------------------
+__global__ void k_gather(int n, const int *__restrict__ idx, const double *__restrict__ x, double *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = x[idx[i]];
+}
+
+// returns the pointer the SpMV kernel should gather from
+inline int halo_exchange(isph_ctx *ctx, const isph_mat *A, const double *x, const double **xuse) {
+  const Sell &S = A->S;
+  if (S.ncol == S.nrow) { *xuse = x; return ISPH_SUCCESS; }
+  const isph_halo &H = A->halo;
+  ISPH_REQUIRE(H.nrecv == S.ncol - S.nrow, "matrix has ghost columns but no matching halo plan");
+  ISPH_CHECK(ctx->xext.reserve((size_t)S.ncol));
+  ISPH_CHECK(ctx->sendbuf.reserve((size_t)(H.nsend > 0 ? H.nsend : 1)));
+  ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xext.p, x, sizeof(double) * (size_t)S.nrow, hipMemcpyDeviceToDevice, ctx->stream));
+  if (H.nsend > 0)
+    hipLaunchKernelGGL(k_gather, dim3(stream_grid(H.nsend)), dim3(kBlock), 0, ctx->stream, H.nsend, H.send_idx.p, x,
+                       ctx->sendbuf.p);
+  ISPH_CHECK_NCCL(ncclGroupStart());
+  for (int p = 0; p < H.npeers; ++p) {
+    const int ns = H.send_ptr[p + 1] - H.send_ptr[p], nr = H.recv_ptr[p + 1] - H.recv_ptr[p];
+    if (ns > 0) ISPH_CHECK_NCCL(ncclSend(ctx->sendbuf.p + H.send_ptr[p], (size_t)ns, ncclDouble, H.peer[p], ctx->comm, ctx->stream));
+    if (nr > 0) ISPH_CHECK_NCCL(ncclRecv(ctx->xext.p + S.nrow + H.recv_ptr[p], (size_t)nr, ncclDouble, H.peer[p], ctx->comm, ctx->stream));
+  }
+  ISPH_CHECK_NCCL(ncclGroupEnd());
+  *xuse = ctx->xext.p;
+  return ISPH_SUCCESS;
+}
+
+inline int profile_begin(isph_ctx *ctx, size_t *slot) {
+  *slot = (size_t)-1;
+  if (!ctx->profile) return ISPH_SUCCESS;
+  if (ctx->ev_used + 2 > ctx->ev.size()) {
+    for (int k = 0; k < 2; ++k) {
+      hipEvent_t e;
+      ISPH_CHECK_HIP(hipEventCreate(&e));
+      ctx->ev.push_back(e);
+    }
+  }
+  *slot = ctx->ev_used;
+  ctx->ev_used += 2;
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev[*slot], ctx->stream));
+  return ISPH_SUCCESS;
+}
+inline int profile_end(isph_ctx *ctx, size_t slot) {
+  if (slot != (size_t)-1) ISPH_CHECK_HIP(hipEventRecord(ctx->ev[slot + 1], ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+// y = A x ; if nvec: also SC_MISC+0 = y.nvec (all-reduced)
+inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, const double *nvec) {
+  const Sell &S = A->S;
+  const double *xuse = x;
+  ISPH_CHECK(halo_exchange(ctx, A, x, &xuse));
+  int nbp = 0;
+  const int grid = spmv_grid(S.nslices, &nbp);
+  size_t slot;
+  ISPH_CHECK(profile_begin(ctx, &slot));
+  if (nvec) {
+    ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
+    hipLaunchKernelGGL((k_sell_spmv<4, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                       S.slice_off.p, S.col.p, S.val.p, xuse, y, nvec, ctx->partial.p);
+  } else {
+    hipLaunchKernelGGL((k_sell_spmv<4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                       S.slice_off.p, S.col.p, S.val.p, xuse, y, (const double *)nullptr, (double *)nullptr);
+  }
+  ISPH_CHECK(profile_end(ctx, slot));
+  if (nvec) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, ctx->stream, 1, S.nslices, ctx->partial.p,
+                       ctx->dscal.p + SC_MISC);
+    ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_MISC, 1));
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+struct LinOp {
+  isph_ctx *ctx;
+  const isph_mat *A;
+  const isph_prec *M;
+  const double *nvec;  // device, NULL unless singular
+  int n;
+  // PoissonProjection::Apply: y = A x; y -= (y.n) n
+  int apply(const double *x, double *y) const {
+    ISPH_CHECK(spmv_dev(ctx, A, x, y, nvec));
+    if (nvec)
+      hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, -1.0,
+                         ctx->dscal.p + SC_MISC, nvec, y);
+    return ISPH_SUCCESS;
+  }
+  int prec(const double *r, double *z) const { return prec_apply_dev(ctx, M, r, z); }
+};
+
+// dot(a,b) -> dscal[slot] (all-reduced); optionally dot(c,d) -> dscal[slot+1]
+inline int dot_dev(isph_ctx *ctx, int n, const double *a, const double *b, const double *c, const double *d, int slot) {
+  const int g = stream_grid(n);
+  hipLaunchKernelGGL(k_dot2, dim3(g), dim3(kBlock), 0, ctx->stream, n, a, b, c, d, ctx->partial.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(128), 0, ctx->stream, 2, g, ctx->partial.p, ctx->dscal.p + slot);
+  return allreduce_inplace(ctx, ctx->dscal.p + slot, 2);
+}
+
+// project v -= (v.n) n
+inline int project_dev(isph_ctx *ctx, int n, const double *nvec, double *v) {
+  ISPH_CHECK(dot_dev(ctx, n, v, nvec, nullptr, nullptr, SC_MISC + 2));
+  hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, -1.0, ctx->dscal.p + SC_MISC + 2,
+                     nvec, v);
+  return ISPH_SUCCESS;
+}
+
+// one classical Gram-Schmidt pass of w against V[0..nk): c = V^T w (one fused
+// multi-dot + one all-reduce), w -= V c, and the norms before/after.
+// Host gets c[0..nk), ww_old, ww_new in hscal[SC_DOT ..].
+inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld, double *w) {
+  int g = (int)((n + (long long)kBlock * kDotRows - 1) / ((long long)kBlock * kDotRows));
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  ISPH_CHECK(ctx->partial.reserve((size_t)(nk + 2) * 1024 > (size_t)kMaxRedBlocks * 66 ? (size_t)(nk + 2) * 1024 : (size_t)kMaxRedBlocks * 66));
+  hipLaunchKernelGGL(k_multi_dot, dim3(g), dim3(kBlock), sizeof(double) * 4 * (size_t)(nk + 1), ctx->stream, n, nk, V, ld,
+                     w, ctx->partial.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((nk + 1 + 3) / 4), dim3(256), 0, ctx->stream, nk + 1, g, ctx->partial.p,
+                     ctx->dscal.p + SC_DOT);
+  ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_DOT, nk + 1));
+  const int g2 = stream_grid(n);
+  hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, ctx->dscal.p + SC_DOT, w,
+                     ctx->partial.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, ctx->stream, 1, g2, ctx->partial.p,
+                     ctx->dscal.p + SC_DOT + nk + 1);
+  ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_DOT + nk + 1, 1));
+  ISPH_CHECK_HIP(hipGetLastError());
+  return fetch_scalars(ctx, SC_DOT, nk + 2);
+}
+
+// Belos DGKS / ICGS / IMGS for block size 1. h[0..j] coefficients, returns ||w||.
+inline int orthogonalize(isph_ctx *ctx, int n, int j, const double *V, long long ld, double *w, double *h, int ortho,
+                         double *wnorm) {
+  const int nk = j + 1;
+  for (int k = 0; k < nk; ++k) h[k] = 0.0;
+  if (ortho == 2) {  // IMGS: two modified Gram-Schmidt sweeps
+    double nn = 0.0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int k = 0; k < nk; ++k) {
+        ISPH_CHECK(cgs_pass(ctx, n, 1, V + (long long)k * ld, ld, w));
+        h[k] += ctx->hscal[SC_DOT];
+        nn = ctx->hscal[SC_DOT + 2];
+      }
+    *wnorm = std::sqrt(nn);
+    return ISPH_SUCCESS;
+  }
+  ISPH_CHECK(cgs_pass(ctx, n, nk, V, ld, w));
+  for (int k = 0; k < nk; ++k) h[k] += ctx->hscal[SC_DOT + k];
+  const double old = std::sqrt(ctx->hscal[SC_DOT + nk]);
+  double nw = std::sqrt(ctx->hscal[SC_DOT + nk + 1]);
+  if (ortho == 1 || nw < M_SQRT1_2 * old) {  // DGKS: dep_tol = 1/sqrt(2)
+    ISPH_CHECK(cgs_pass(ctx, n, nk, V, ld, w));
+    for (int k = 0; k < nk; ++k) h[k] += ctx->hscal[SC_DOT + k];
+    nw = std::sqrt(ctx->hscal[SC_DOT + nk + 1]);
+  }
+  *wnorm = nw;
+  return ISPH_SUCCESS;
+}
+
+inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_params *prm, isph_solve_info *info) {
+  isph_ctx *ctx = op.ctx;
+  const int n = op.n, m = prm->num_blocks;
+  ISPH_REQUIRE(m >= 1 && m <= 62, "Num Blocks must be in [1,62]");
+  const long long ld = ((long long)n + 63) / 64 * 64;
+  ISPH_CHECK(ctx->V.reserve((size_t)ld * (size_t)(m + 1)));
+  if (prm->flexible) ISPH_CHECK(ctx->Z.reserve((size_t)ld * (size_t)m));
+  ISPH_CHECK(ctx->wv.reserve((size_t)ld));
+  ISPH_CHECK(ctx->tv.reserve((size_t)ld));
+  double *V = ctx->V.p, *Z = ctx->Z.p, *w = ctx->wv.p, *t = ctx->tv.p;
+  std::vector<double> H((size_t)(m + 1) * (size_t)m, 0.0), cs((size_t)m), sn((size_t)m), g((size_t)m + 1), y((size_t)m);
+  const int sg = stream_grid(n);
+  hipStream_t st = ctx->stream;
+
+  // r0 = b - Op(x)
+  ISPH_CHECK(op.apply(x, w));
+  hipLaunchKernelGGL(k_residual, dim3(sg), dim3(kBlock), 0, st, n, b, w);
+  ISPH_CHECK(dot_dev(ctx, n, w, w, nullptr, nullptr, SC_MISC + 4));
+  ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 4, 1));
+  double beta = std::sqrt(ctx->hscal[SC_MISC + 4]);
+  const double scale = beta == 0.0 ? 1.0 : beta;  // Belos: zero scale -> 1
+  info->iters = 0;
+  info->restarts = 0;
+  info->converged = 0;
+  info->rel_res_implicit = beta / scale;
+  if (beta / scale <= prm->tol) info->converged = 1;
+
+  while (!info->converged && info->iters < prm->max_iters) {
+    hipLaunchKernelGGL(k_scale_copy, dim3(sg), dim3(kBlock), 0, st, n, w, V, 1.0 / beta, (const double *)nullptr, 0);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = beta;
+    int j = 0;
+    while (j < m) {
+      const double *zj;
+      double *vj = V + (long long)j * ld;
+      if (prm->flexible) {
+        ISPH_CHECK(op.prec(vj, Z + (long long)j * ld));
+        zj = Z + (long long)j * ld;
+      } else {
+        ISPH_CHECK(op.prec(vj, t));
+        zj = t;
+      }
+      ISPH_CHECK(op.apply(zj, w));
+      double *h = &H[(size_t)j * (size_t)(m + 1)];
+      double wn = 0.0;
+      ISPH_CHECK(orthogonalize(ctx, n, j, V, ld, w, h, prm->ortho, &wn));
+      h[j + 1] = wn;
+      if (wn != 0.0)
+        hipLaunchKernelGGL(k_scale_copy, dim3(sg), dim3(kBlock), 0, st, n, w, V + (long long)(j + 1) * ld, 1.0 / wn,
+                           (const double *)nullptr, 0);
+      for (int k = 0; k < j; ++k) {
+        const double a = cs[k] * h[k] + sn[k] * h[k + 1];
+        h[k + 1] = -sn[k] * h[k] + cs[k] * h[k + 1];
+        h[k] = a;
+      }
+      {
+        const double a = h[j], bb = h[j + 1], rr = std::hypot(a, bb);
+        cs[j] = rr == 0.0 ? 1.0 : a / rr;
+        sn[j] = rr == 0.0 ? 0.0 : bb / rr;
+        h[j] = rr;
+        h[j + 1] = 0.0;
+        g[j + 1] = -sn[j] * g[j];
+        g[j] = cs[j] * g[j];
+      }
+      ++j;
+      ++info->iters;
+      info->rel_res_implicit = std::fabs(g[j]) / scale;
+      if (prm->verbose && ctx->rank == 0 && info->iters % 10 == 0)
+        printf(">> isph::gmres iter %d  rel res %.3e\n", info->iters, info->rel_res_implicit);
+      if (info->rel_res_implicit <= prm->tol) { info->converged = 1; break; }
+      if (info->iters >= prm->max_iters) break;
+    }
+    for (int k = j - 1; k >= 0; --k) {
+      double s = g[k];
+      for (int l = k + 1; l < j; ++l) s -= H[(size_t)l * (size_t)(m + 1) + k] * y[l];
+      y[k] = s / H[(size_t)k * (size_t)(m + 1) + k];
+    }
+    // x += Z y  (flexible)  or  x += M^-1 (V y)
+    for (int k = 0; k < j; ++k) ctx->hscal[SC_Y + k] = y[k];
+    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->dscal.p + SC_Y, ctx->hscal + SC_Y, sizeof(double) * (size_t)j, hipMemcpyHostToDevice, st));
+    if (prm->flexible) {
+      hipLaunchKernelGGL(k_multi_axpy, dim3(sg), dim3(kBlock), 0, st, n, j, Z, ld, ctx->dscal.p + SC_Y, x);
+    } else {
+      hipLaunchKernelGGL(k_fill, dim3(sg), dim3(kBlock), 0, st, n, w, 0.0);
+      hipLaunchKernelGGL(k_multi_axpy, dim3(sg), dim3(kBlock), 0, st, n, j, V, ld, ctx->dscal.p + SC_Y, w);
+      ISPH_CHECK(op.prec(w, t));
+      hipLaunchKernelGGL(k_axpy_dev, dim3(sg), dim3(kBlock), 0, st, n, 1.0, (const double *)nullptr, t, x);
+    }
+    // the H2D source (hscal) must not be rewritten before the copy has run
+    ISPH_CHECK_HIP(hipStreamSynchronize(st));
+    if (info->converged || info->iters >= prm->max_iters) break;
+    if (info->restarts >= prm->max_restarts) break;
+    ++info->restarts;
+    ISPH_CHECK(op.apply(x, w));
+    hipLaunchKernelGGL(k_residual, dim3(sg), dim3(kBlock), 0, st, n, b, w);
+    ISPH_CHECK(dot_dev(ctx, n, w, w, nullptr, nullptr, SC_MISC + 4));
+    ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 4, 1));
+    beta = std::sqrt(ctx->hscal[SC_MISC + 4]);
+    if (beta == 0.0) { info->converged = 1; break; }
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+// Belos BlockCGSolMgr, block size 1: the right-preconditioner slot is the
+// preconditioner (ref: USER-REAXC-T/solver_lin_belos.h:236-245).
+inline int pcg(const LinOp &op, const double *b, double *x, const isph_solver_params *prm, isph_solve_info *info) {
+  isph_ctx *ctx = op.ctx;
+  const int n = op.n;
+  const long long ld = ((long long)n + 63) / 64 * 64;
+  ISPH_CHECK(ctx->wv.reserve((size_t)ld));
+  ISPH_CHECK(ctx->tv.reserve((size_t)ld));
+  ISPH_CHECK(ctx->rv.reserve((size_t)ld));
+  ISPH_CHECK(ctx->pv.reserve((size_t)ld));
+  double *r = ctx->rv.p, *z = ctx->tv.p, *p = ctx->pv.p, *ap = ctx->wv.p;
+  const int sg = stream_grid(n);
+  hipStream_t st = ctx->stream;
+  double *ds = ctx->dscal.p;
+  enum { RZ = SC_MISC + 8, PAP = SC_MISC + 10, RR = SC_MISC + 12, RZN = SC_MISC + 14 };
+  ISPH_CHECK(op.apply(x, r));
+  hipLaunchKernelGGL(k_residual, dim3(sg), dim3(kBlock), 0, st, n, b, r);
+  ISPH_CHECK(op.prec(r, z));
+  ISPH_CHECK_HIP(hipMemcpyAsync(p, z, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+  ISPH_CHECK(dot_dev(ctx, n, r, z, r, r, RZ));  // RZ = r.z, RZ+1 = r.r
+  ISPH_CHECK(fetch_scalars(ctx, RZ, 2));
+  const double r0 = std::sqrt(ctx->hscal[RZ + 1]);
+  const double scale = r0 == 0.0 ? 1.0 : r0;
+  info->iters = 0;
+  info->restarts = 0;
+  info->rel_res_implicit = r0 / scale;
+  info->converged = (r0 / scale <= prm->tol);
+  int rz = RZ, rzn = RZN;
+  while (!info->converged && info->iters < prm->max_iters) {
+    ISPH_CHECK(op.apply(p, ap));
+    ISPH_CHECK(dot_dev(ctx, n, p, ap, nullptr, nullptr, PAP));
+    const int g = stream_grid(n);
+    hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(kBlock), 0, st, n, p, ap, x, r, ds + rz, ds + PAP, ctx->partial.p);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, st, 1, g, ctx->partial.p, ds + RR);
+    ISPH_CHECK(allreduce_inplace(ctx, ds + RR, 1));
+    ISPH_CHECK(fetch_scalars(ctx, RR, 1));
+    ++info->iters;
+    info->rel_res_implicit = std::sqrt(ctx->hscal[RR]) / scale;
+    if (prm->verbose && ctx->rank == 0 && info->iters % 10 == 0)
+      printf(">> isph::cg iter %d  rel res %.3e\n", info->iters, info->rel_res_implicit);
+    if (info->rel_res_implicit <= prm->tol) { info->converged = 1; break; }
+    ISPH_CHECK(op.prec(r, z));
+    ISPH_CHECK(dot_dev(ctx, n, r, z, nullptr, nullptr, rzn));
+    hipLaunchKernelGGL(k_cg_update_p, dim3(sg), dim3(kBlock), 0, st, n, z, p, ds + rzn, ds + rz);
+    const int tsw = rz; rz = rzn; rzn = tsw;
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+}  // namespace isph

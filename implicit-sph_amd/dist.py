@@ -1,0 +1,119 @@
+"""Domain-decomposition plumbing for the multi-GPU path (one process per GPU).
+
+What Epetra builds inside FillComplete for the reference (column map +
+Epetra_Import, ref: functor_graph.h:97, pair_isph.cpp:1258-1270) and what
+LAMMPS' forward_comm_pair does for per-atom scalars: from each rank's ghost
+atoms (owner rank, owner local index) derive
+  * colmap   matrix column of every local+ghost particle (owned columns first,
+             ghost columns grouped by owning rank),
+  * the send/recv lists of the per-SpMV halo exchange.
+Index lists are exchanged once at plan time with torch.distributed object
+collectives (works on gloo and nccl); the per-SpMV exchange itself runs inside
+libisph_hip on RCCL (csrc/solver.hpp halo_exchange).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class HaloPlan:
+    rank: int
+    nranks: int
+    nlocal: int
+    ncol: int
+    colmap: np.ndarray
+    peers: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    send_ptr: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
+    send_idx: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    recv_ptr: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
+    ghost_col_of: np.ndarray = None   # [nall-nlocal] column of each ghost particle
+
+    @property
+    def npeers(self):
+        return len(self.peers)
+
+
+def make_plan(parts, td=None):
+    """parts: output of workload.make_tgv for this rank.  td: torch.distributed
+    (initialised) or None for a single rank."""
+    me = int(parts["spec"].rank)
+    nlocal, nall = int(parts["nlocal"]), int(parts["nall"])
+    orank = parts["owner_rank"].astype(np.int64)
+    oidx = parts["owner_index"].astype(np.int64)
+    colmap = np.empty(nall, dtype=np.int32)
+    colmap[:nlocal] = np.arange(nlocal, dtype=np.int32)
+    g = np.arange(nlocal, nall)
+    local_img = orank[g] == me
+    colmap[g[local_img]] = oidx[g[local_img]]            # periodic image of an owned particle
+    remote = g[~local_img]
+    nranks = 1 if td is None else td.get_world_size()
+    if len(remote) == 0 or td is None:
+        assert len(remote) == 0, "remote ghosts need torch.distributed"
+        plan = HaloPlan(me, nranks, nlocal, nlocal, colmap)
+        plan.ghost_col_of = colmap[nlocal:].copy()
+        if td is not None:                                # still take part in the collective
+            out = [None] * nranks
+            td.all_gather_object(out, {})
+        return plan
+    key = orank[remote] * (1 << 32) + oidx[remote]
+    ukey, inv = np.unique(key, return_inverse=True)       # sorted by (rank, index): ghost column order
+    colmap[remote] = (nlocal + inv).astype(np.int32)
+    urank = (ukey >> 32).astype(np.int32)
+    uidx = (ukey & 0xFFFFFFFF).astype(np.int32)
+    want = {int(r): uidx[urank == r] for r in np.unique(urank)}
+    allwant = [None] * nranks
+    td.all_gather_object(allwant, want)
+    sends = {p: np.asarray(allwant[p][me], dtype=np.int32) for p in range(nranks) if p != me and me in allwant[p]}
+    peers = sorted(set(want) | set(sends))
+    send_ptr, recv_ptr, send_idx = [0], [0], []
+    for p in peers:
+        s = sends.get(p, np.zeros(0, np.int32))
+        send_idx.append(s)
+        send_ptr.append(send_ptr[-1] + len(s))
+        recv_ptr.append(recv_ptr[-1] + len(want.get(p, ())))
+    plan = HaloPlan(me, nranks, nlocal, nlocal + len(ukey), colmap,
+                    np.asarray(peers, np.int32), np.asarray(send_ptr, np.int32),
+                    np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32),
+                    np.asarray(recv_ptr, np.int32))
+    plan.ghost_col_of = colmap[nlocal:].copy()
+    return plan
+
+
+def exchange(plan, owned, td, device=None):
+    """Halo exchange of one owned vector with torch.distributed p2p (plan-time
+    utility and CPU/gloo test path).  Returns the ncol-long extended vector."""
+    import torch
+    owned_t = owned if isinstance(owned, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(owned))
+    if device is not None:
+        owned_t = owned_t.to(device)
+    ext = torch.empty(plan.ncol, dtype=owned_t.dtype, device=owned_t.device)
+    ext[:plan.nlocal] = owned_t[:plan.nlocal]
+    if plan.npeers == 0:
+        return ext
+    sidx = torch.from_numpy(plan.send_idx.astype(np.int64)).to(owned_t.device)
+    sbuf = owned_t[sidx].contiguous()
+    ops, keep = [], []
+    for k, p in enumerate(plan.peers):
+        s0, s1 = int(plan.send_ptr[k]), int(plan.send_ptr[k + 1])
+        r0, r1 = int(plan.recv_ptr[k]), int(plan.recv_ptr[k + 1])
+        if s1 > s0:
+            ops.append(td.P2POp(td.isend, sbuf[s0:s1], int(p)))
+        if r1 > r0:
+            rb = torch.empty(r1 - r0, dtype=owned_t.dtype, device=owned_t.device)
+            keep.append((r0, r1, rb))
+            ops.append(td.P2POp(td.irecv, rb, int(p)))
+    for w in td.batch_isend_irecv(ops):
+        w.wait()
+    for r0, r1, rb in keep:
+        ext[plan.nlocal + r0:plan.nlocal + r1] = rb
+    return ext
+
+
+def forward_scalar(plan, owned, td, device=None):
+    """forward_comm_pair of a per-atom scalar (e.g. Vfrac, functor_volume.h:76-80):
+    returns the [nall] array with every ghost holding its owner's value."""
+    import torch
+    ext = exchange(plan, owned, td, device)
+    cm = torch.from_numpy(plan.colmap.astype(np.int64)).to(ext.device)
+    return ext[cm].contiguous()

@@ -1,0 +1,335 @@
+"""ctypes binding of libisph_hip.so (include/isph_hip.h) -- the product path.
+
+Nothing in here touches the oracle or any CPU fallback: if the HIP library is
+missing or no GPU is usable, calls raise.  Arrays may be numpy (host) or torch
+CUDA tensors (device pointers are passed straight through).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+UID_BYTES = 128
+NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
+KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
+
+EXPORTS = [
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy",
+    "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
+    "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
+    "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
+    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_compute_volumes",
+]
+
+
+class SolverParams(C.Structure):
+    """Mirror of isph_solver_params == SolverLin_Belos::setParameters keys
+    (ref: solver_lin_belos.h:224-264)."""
+    _fields_ = [("solver_type", C.c_int), ("flexible", C.c_int), ("num_blocks", C.c_int),
+                ("max_iters", C.c_int), ("max_restarts", C.c_int), ("tol", C.c_double),
+                ("ortho", C.c_int), ("verbose", C.c_int)]
+
+    def __init__(self, solver_type=0, flexible=1, num_blocks=50, max_iters=500, max_restarts=15, tol=1e-8,
+                 ortho=0, verbose=0):
+        super().__init__(solver_type, flexible, num_blocks, max_iters, max_restarts, tol, ortho, verbose)
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iters", C.c_int), ("restarts", C.c_int),
+                ("rel_res_implicit", C.c_double), ("rel_res_explicit", C.c_double),
+                ("prec_setup_ms", C.c_double), ("solve_ms", C.c_double), ("spmv_ms", C.c_double),
+                ("spmv_calls", C.c_int)]
+
+
+class _Particles(C.Structure):
+    _fields_ = [("dim", C.c_int), ("nlocal", C.c_int), ("nall", C.c_int), ("ntypes", C.c_int),
+                ("kernel", C.c_int), ("x", C.c_void_p), ("type", C.c_void_p), ("kind", C.c_void_p),
+                ("h", C.c_void_p), ("cutsq", C.c_void_p), ("neigh_ptr", C.c_void_p), ("neigh_idx", C.c_void_p),
+                ("colmap", C.c_void_p), ("vfrac", C.c_void_p), ("Gc", C.c_void_p), ("Lc", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.HIP_LIB
+
+
+def lib():
+    """Loads libisph_hip.so; raises (never falls back) if it is not there."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError("libisph_hip.so is missing (%s): run __graft_entry__.build(); "
+                               "there is no CPU fallback" % path)
+        L = C.CDLL(path)
+        L.isph_last_error.restype = C.c_char_p
+        L.isph_prec_nnz.restype = C.c_longlong
+        L.isph_prec_nnz.argtypes = [C.c_void_p]
+        L.isph_ctx_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.isph_ctx_create_dist.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+        L.isph_ctx_sync.argtypes = [C.c_void_p]
+        L.isph_ctx_destroy.argtypes = [C.c_void_p]
+        L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.isph_mat_create_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p]
+        L.isph_mat_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+        L.isph_mat_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.isph_mat_export_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_mat_destroy.argtypes = [C.c_void_p]
+        L.isph_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_spmv_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.isph_prec_create.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+        L.isph_prec_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_prec_export_ilu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_prec_destroy.argtypes = [C.c_void_p]
+        L.isph_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_assemble_poisson.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_compute_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+class IsphError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise IsphError(lib().isph_last_error().decode() or "isph call failed")
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _on_device(*arrs):
+    flags = {bool(_is_torch(a) and a.is_cuda) for a in arrs if a is not None}
+    if len(flags) != 1:
+        raise ValueError("mix of host and device arrays")
+    return int(flags.pop())
+
+
+def _i32(a):
+    return a if _is_torch(a) else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a):
+    return a if _is_torch(a) else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """isph_ctx: device + stream (+ RCCL communicator when nranks > 1)."""
+
+    def __init__(self, device=0, stream=None, rank=0, nranks=1, uid=None):
+        self.h = C.c_void_p()
+        self.rank, self.nranks = rank, nranks
+        sp = C.c_void_p(stream) if stream else None
+        if nranks > 1 or uid is not None:
+            _check(lib().isph_ctx_create_dist(device, sp, rank, nranks, uid, C.byref(self.h)))
+        else:
+            _check(lib().isph_ctx_create(device, sp, C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(UID_BYTES)
+        _check(lib().isph_comm_unique_id(buf))
+        return buf.raw
+
+    def sync(self):
+        _check(lib().isph_ctx_sync(self.h))
+
+    def set_profile(self, on):
+        _check(lib().isph_ctx_set_profile(self.h, int(on)))
+
+    def close(self):
+        if self.h:
+            lib().isph_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Matrix:
+    """isph_mat: sliced-ELL device matrix (SolverLin::setMatrix ingress)."""
+
+    def __init__(self, ctx, handle=None):
+        self.ctx = ctx
+        self.h = handle if handle is not None else C.c_void_p()
+
+    @classmethod
+    def from_csr(cls, ctx, rowptr, colidx, val, ncol=None):
+        rowptr, colidx, val = _i32(rowptr), _i32(colidx), _f64(val)
+        nrow = int(rowptr.shape[0]) - 1
+        m = cls(ctx)
+        _check(lib().isph_mat_create_csr(ctx.h, nrow, nrow if ncol is None else ncol, _ptr(rowptr), _ptr(colidx),
+                                         _ptr(val), _on_device(rowptr, colidx, val), C.byref(m.h)))
+        return m
+
+    def set_halo(self, peers, send_ptr, send_idx, recv_ptr):
+        peers, send_ptr, send_idx, recv_ptr = map(lambda a: np.ascontiguousarray(a, dtype=np.int32),
+                                                  (peers, send_ptr, send_idx, recv_ptr))
+        _check(lib().isph_mat_set_halo(self.ctx.h, self.h, len(peers), _ptr(peers), _ptr(send_ptr), _ptr(send_idx),
+                                       _ptr(recv_ptr)))
+
+    def info(self):
+        a = (C.c_longlong * 6)()
+        _check(lib().isph_mat_info(self.h, a))
+        return dict(nrow=a[0], ncol=a[1], nnz=a[2], nslices=a[3], stored=a[4], sell_bytes=a[5])
+
+    def export_csr(self):
+        i = self.info()
+        rp = np.zeros(i["nrow"] + 1, dtype=np.int32)
+        ci = np.zeros(i["nnz"], dtype=np.int32)
+        v = np.zeros(i["nnz"])
+        _check(lib().isph_mat_export_csr(self.ctx.h, self.h, _ptr(rp), _ptr(ci), _ptr(v)))
+        return rp, ci, v
+
+    def spmv(self, x, y=None):
+        x = _f64(x)
+        if y is None:
+            n = self.info()["nrow"]
+            if _is_torch(x):
+                import torch
+                y = torch.empty(n, dtype=torch.float64, device=x.device)
+            else:
+                y = np.zeros(n)
+        _check(lib().isph_spmv(self.ctx.h, self.h, _ptr(x), _ptr(y), _on_device(x, y)))
+        return y
+
+    def spmv_time(self, x, y, reps=20):
+        ms = C.c_double()
+        _check(lib().isph_spmv_time(self.ctx.h, self.h, _ptr(x), _ptr(y), reps, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            lib().isph_mat_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Precond:
+    """isph_prec == PrecondWrapper_Ifpack::create() result."""
+
+    def __init__(self, ctx, A, kind="bjacobi-ilu0", block_size=512):
+        self.ctx, self.n = ctx, A.info()["nrow"]
+        self.h = C.c_void_p()
+        _check(lib().isph_prec_create(ctx.h, A.h, kind.encode(), block_size, C.byref(self.h)))
+
+    def apply(self, r, z=None):
+        r = _f64(r)
+        if z is None:
+            if _is_torch(r):
+                import torch
+                z = torch.empty_like(r)
+            else:
+                z = np.zeros(self.n)
+        _check(lib().isph_prec_apply(self.ctx.h, self.h, _ptr(r), _ptr(z), _on_device(r, z)))
+        return z
+
+    def export_ilu(self):
+        nnz = lib().isph_prec_nnz(self.h)
+        rp = np.zeros(self.n + 1, dtype=np.int32)
+        ci = np.zeros(nnz, dtype=np.int32)
+        v = np.zeros(nnz)
+        _check(lib().isph_prec_export_ilu(self.ctx.h, self.h, _ptr(rp), _ptr(ci), _ptr(v)))
+        return rp, ci, v
+
+    def close(self):
+        if self.h:
+            lib().isph_prec_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve(ctx, A, b, x, prec=None, singular=False, null_mask=None, params=None, nvec=1, lda=None):
+    """isph_solve == SolverLin_Belos::solveProblem.  b and x are updated in
+    place (b by its projection when singular); returns SolveInfo."""
+    prm = params or SolverParams()
+    info = SolveInfo()
+    n = A.info()["nrow"]
+    mask = None if null_mask is None else np.ascontiguousarray(null_mask, dtype=np.int32)
+    _check(lib().isph_solve(ctx.h, A.h, prec.h if prec is not None else None, _ptr(b), _ptr(x), nvec,
+                            n if lda is None else lda, int(singular), _ptr(mask), C.byref(prm), C.byref(info),
+                            _on_device(b, x)))
+    return info
+
+
+def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=None, Lc=None, keep=None):
+    """Builds the isph_particles struct over host (numpy) or device (torch)
+    arrays.  `keep` collects references so the buffers outlive the call."""
+    keep = keep if keep is not None else []
+    ntypes = int(np.max(parts["type"])) if not _is_torch(parts["type"]) else int(parts["type"].max().item())
+    kind = np.ascontiguousarray([0] + list(kinds if kinds is not None else [99] * ntypes), dtype=np.int32)
+    h = np.full((ntypes + 1, ntypes + 1), float(parts["h"]))
+    cutsq = np.full((ntypes + 1, ntypes + 1), float(parts["cut"]) ** 2)
+    x, typ = _f64(parts["x"]), _i32(parts["type"])
+    nptr, nidx, cm = _i32(parts["neigh_ptr"]), _i32(parts["neigh_idx"]), _i32(colmap)
+    keep += [kind, h, cutsq, x, typ, nptr, nidx, cm, vfrac, Gc, Lc]
+    pv = _Particles(int(parts["dim"]), int(parts["nlocal"]), int(parts["nall"]), ntypes, KERNELS[kernel],
+                    _ptr(x), _ptr(typ), _ptr(kind), _ptr(h), _ptr(cutsq), _ptr(nptr), _ptr(nidx), _ptr(cm),
+                    _ptr(vfrac), _ptr(Gc), _ptr(Lc))
+    return pv, _on_device(x, typ, nptr, nidx, cm), keep
+
+
+def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=NULLSPACE, rank0=True,
+                     ncol=None, vfrac=None, kernel="wendland", b_out=None):
+    """isph_assemble_poisson == PairISPH_Corrected::computePoisson."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, keep=keep)
+    rho, vstar = _f64(rho), _f64(vstar)
+    nlocal = int(parts["nlocal"])
+    if b_out is None:
+        if dev:
+            import torch
+            b_out = torch.zeros(nlocal, dtype=torch.float64, device=rho.device)
+        else:
+            b_out = np.zeros(nlocal)
+    A = Matrix(ctx)
+    _check(lib().isph_assemble_poisson(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(rho), _ptr(vstar),
+                                       singular, int(rank0), nlocal if ncol is None else ncol, C.byref(A.h),
+                                       _ptr(b_out), dev))
+    return A, b_out
+
+
+def compute_volumes(ctx, parts, colmap, kernel="wendland"):
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, keep=keep)
+    nlocal = int(parts["nlocal"])
+    if dev:
+        import torch
+        out = torch.zeros(nlocal, dtype=torch.float64, device=parts["x"].device)
+    else:
+        out = np.zeros(nlocal)
+    _check(lib().isph_compute_volumes(ctx.h, C.byref(pv), _ptr(out), dev))
+    return out

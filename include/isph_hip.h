@@ -1,0 +1,185 @@
+/*
+ * isph_hip.h -- C ABI of libisph_hip.so: the MI355X (gfx950) implementation of
+ * implicit-sph's pressure-Poisson / Helmholtz inner loop.
+ *
+ * This is the drop-in boundary.  Everything above it (the SolverLin /
+ * PrecondWrapper C++ classes in implicit-sph_amd/host/, a LAMMPS adapter, the
+ * Python ctypes binding) talks to the GPU only through these entry points:
+ * plain pointers and sizes, opaque handles, int return codes
+ * (0 = LAMMPS_SUCCESS, -1 = LAMMPS_FAILURE, ref: macrodef.h:20-24), no
+ * exceptions, no torch types.  The caller keeps ownership of every pointer it
+ * passes; the library owns the device mirrors it creates.
+ *
+ * "ref:" citations are relative to /root/reference/IMPLICIT-SPH/ and name the
+ * reference interface each entry point replaces.
+ *
+ * Pointer arguments marked [h|d] may be host or device pointers; the `on_device`
+ * flag of the call says which (0 = host, the library stages the copy).
+ * There is NO CPU fallback: every compute entry point fails with -1 if no
+ * HIP device is usable.
+ */
+#ifndef ISPH_HIP_H
+#define ISPH_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct isph_ctx isph_ctx;   /* device, stream, workspaces, RCCL communicator */
+typedef struct isph_mat isph_mat;   /* device matrix: sliced-ELL (+ CSR view) + halo plan */
+typedef struct isph_prec isph_prec; /* device preconditioner */
+
+#define ISPH_SUCCESS 0
+#define ISPH_FAILURE (-1)
+#define ISPH_UID_BYTES 128
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Replaces the Epetra_MpiComm every reference object is built on
+ * (ref: solver_lin.cpp:30-31, precond.h:26).  `stream` = an existing
+ * hipStream_t to launch on (NULL: the library creates its own). */
+int isph_ctx_create(int device, void *stream, isph_ctx **ctx);
+/* Multi-GPU: one process per GPU; the communicator is RCCL.  `uid` is the
+ * ncclUniqueId (ISPH_UID_BYTES) produced on rank 0 by isph_comm_unique_id
+ * and broadcast by the launcher (torch.distributed / MPI). */
+int isph_comm_unique_id(char *uid);
+int isph_ctx_create_dist(int device, void *stream, int rank, int nranks,
+                         const char *uid, isph_ctx **ctx);
+int isph_ctx_sync(isph_ctx *ctx);
+void isph_ctx_destroy(isph_ctx *ctx);
+const char *isph_last_error(void);
+
+/* ---- matrix ----------------------------------------------------------- */
+
+/* Ingress of an assembled local matrix: the three arrays
+ * Epetra_CrsMatrix::ExtractCrsDataPointers returns after
+ * FillComplete+OptimizeStorage (ref: pair_isph.cpp:1266-1270,
+ * solver_lin.h:52 setMatrix).  Rows = locally owned particles; columns
+ * [0,nrow) = owned, [nrow,ncol) = ghost columns filled by the halo exchange.
+ * Replaces SolverLin::setMatrix / PrecondWrapper::setMatrix. */
+int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h|d]*/,
+                        const int *colidx /*[h|d]*/, const double *val /*[h|d]*/,
+                        int on_device, isph_mat **A);
+/* Halo plan = what Epetra builds inside FillComplete (column map + Import,
+ * ref: functor_graph.h:97).  For peer p: send x[send_idx[send_ptr[p]..send_ptr[p+1])]
+ * and receive the ghost columns nrow+recv_ptr[p] .. nrow+recv_ptr[p+1]. */
+int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_rank,
+                      const int *send_ptr, const int *send_idx, const int *recv_ptr);
+/* sizes: [0]=nrow [1]=ncol [2]=nnz [3]=number of 64-row slices
+ *        [4]=stored (padded) entries [5]=bytes of the sliced-ELL arrays */
+int isph_mat_info(const isph_mat *A, long long info[6]);
+/* Export as CSR with sorted columns (device->host); caller sizes from info. */
+int isph_mat_export_csr(isph_ctx *ctx, const isph_mat *A, int *rowptr, int *colidx, double *val);
+void isph_mat_destroy(isph_mat *A);
+
+/* y = A x  (Epetra_CrsMatrix::Apply incl. the ghost Import; ref: solver_lin.h:133).
+ * x: ncol entries if on one rank all ghosts are local images (ncol == nrow),
+ * otherwise nrow owned entries (ghosts are fetched).  y: nrow entries. */
+int isph_spmv(isph_ctx *ctx, const isph_mat *A, const double *x /*[h|d]*/,
+              double *y /*[h|d]*/, int on_device);
+/* Time `reps` back-to-back SpMV launches with HIP events on the library
+ * stream; returns the average kernel time in milliseconds. */
+int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double *y_dev,
+                   int reps, double *avg_ms);
+
+/* ---- preconditioner --------------------------------------------------- */
+
+/* Replaces PrecondWrapper_Ifpack::create() = Ifpack factory + Initialize +
+ * Compute (ref: precond_ifpack.h:52-75).  type:
+ *   "none"          identity
+ *   "jacobi"        point Jacobi (debug)
+ *   "bjacobi-ilu0"  block-Jacobi, ILU(0) per block == Ifpack
+ *                   AdditiveSchwarz<ILU>, "Overlap Level"=0,
+ *                   "fact: level-of-fill"=0, one block per `block_size` rows
+ * Rebuilt every solve in the reference (solver_lin_belos.h:153,190). */
+int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int block_size,
+                     isph_prec **M);
+/* z = M^-1 r (Belos::EpetraPrecOp::Apply -> Ifpack ApplyInverse). */
+int isph_prec_apply(isph_ctx *ctx, const isph_prec *M, const double *r /*[h|d]*/,
+                    double *z /*[h|d]*/, int on_device);
+/* Export the factor as CSR (strict L, D, strict U in one pattern == A's
+ * in-block pattern, columns sorted) for parity tests. */
+int isph_prec_export_ilu(isph_ctx *ctx, const isph_prec *M, int *rowptr, int *colidx, double *val);
+long long isph_prec_nnz(const isph_prec *M);
+void isph_prec_destroy(isph_prec *M);
+
+/* ---- solve ------------------------------------------------------------ */
+
+/* Same keys and defaults as SolverLin_Belos::setParameters
+ * (ref: solver_lin_belos.h:224-264). */
+typedef struct {
+  int solver_type;   /* 0 "Block GMRES" (default), 1 "Block CG"            */
+  int flexible;      /* "Flexible Gmres" (default 1)                        */
+  int num_blocks;    /* "Num Blocks" (50)                                   */
+  int max_iters;     /* "Maximum Iterations" (500)                          */
+  int max_restarts;  /* "Maximum Restarts" (15)                             */
+  double tol;        /* "Convergence Tolerance" (1e-8)                      */
+  int ortho;         /* "Orthogonalization": 0 DGKS (default), 1 ICGS, 2 IMGS */
+  int verbose;       /* rank-0 status lines like Belos "Verbosity"          */
+} isph_solver_params;
+void isph_solver_params_default(isph_solver_params *p);
+
+typedef struct {
+  int converged, iters, restarts;
+  double rel_res_implicit;  /* recurrence residual / ||r0||                 */
+  double rel_res_explicit;  /* ||b - A x|| / ||b|| (solver_lin_belos.h:201-212) */
+  double prec_setup_ms;     /* filled by callers that build M around the solve */
+  double solve_ms;          /* HIP-event time of the whole call on the stream */
+  double spmv_ms;           /* sum of SpMV kernel times (profile mode only) */
+  int spmv_calls;
+} isph_solve_info;
+
+/* Replaces SolverLin_Belos::solveProblem (ref: solver_lin_belos.h:130-222):
+ * singular => n = mask/||mask||, b -= (b.n)n, operator y = Ax - (Ax.n)n,
+ * x -= (x.n)n; right preconditioning; non-convergence is reported in `info`,
+ * never an error.  b and x are column-major [lda x nvec] exactly as
+ * createLoadMultiVector / createSolutionMultiVector receive them
+ * (ref: solver_lin.cpp:45-58); columns are solved one after another
+ * (Belos block size 1).  x holds the initial guess on entry.
+ * b is overwritten by its projection when singular, as in the reference. */
+int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M,
+               double *b /*[h|d]*/, double *x /*[h|d]*/, int nvec, int lda,
+               int is_singular, const int *null_mask /*[h] or NULL*/,
+               const isph_solver_params *prm, isph_solve_info *info, int on_device);
+/* profile mode: record HIP events around every SpMV launch inside isph_solve */
+int isph_ctx_set_profile(isph_ctx *ctx, int on);
+
+/* ---- assembly --------------------------------------------------------- */
+
+/* Particle view = the LAMMPS arrays the reference functors capture
+ * (ref: functor.h:86-104) flattened; all pointers [h|d] per `on_device`. */
+typedef struct {
+  int dim, nlocal, nall, ntypes;
+  int kernel;              /* 0 Wendland, 1 Quintic, 2 Cubic (kernel_*.h)     */
+  const double *x;         /* [nall][3]  atom->x                              */
+  const int *type;         /* [nall]     atom->type (1-based)                 */
+  const int *kind;         /* [ntypes+1] getParticleKind(type)  (host always) */
+  const double *h;         /* [(ntypes+1)^2] pair->h            (host always) */
+  const double *cutsq;     /* [(ntypes+1)^2] pair->cutsq        (host always) */
+  const int *neigh_ptr;    /* [nlocal+1] flattened list->firstneigh           */
+  const int *neigh_idx;    /* neighbour indices into [0,nall)                 */
+  const int *colmap;       /* [nall] matrix column of particle j              */
+  const double *vfrac;     /* [nall] atom->vfrac (NULL: computed on device)   */
+  const double *Gc;        /* [nall][dim*dim] or NULL (AntiSymmetric family)  */
+  const double *Lc;        /* [nall][dimL]    or NULL                         */
+} isph_particles;
+
+/* Replaces PairISPH_Corrected::computePoisson -> FunctorOuterIncompNavierStokesPoisson
+ * (ref: pair_isph_corrected.cpp:969-1015, functor_incomp_navier_stokes_poisson.h:52-181)
+ * including FunctorOuterGraph (functor_graph.h:38-99), the Laplacian rows
+ * (functor_laplacian_matrix.h:73-316) and the divergence RHS
+ * (functor_divergence.h:54-124).  antisym=1 is the momentum-preserving family
+ * (default, pair_isph.cpp:1779).  singular_mode: 0 NotSingular, 1 NullSpace,
+ * 2 PinZero, 3 DoubleDiag (pair_isph.h:134-138).  ncol = number of matrix
+ * columns (owned + ghost).  b_out: nlocal entries. */
+int isph_assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym, double dt,
+                          const double *rho /*[nall]*/, const double *vstar /*[nall][3]*/,
+                          int singular_mode, int is_rank0, int ncol,
+                          isph_mat **A_out, double *b_out /*[h|d]*/, int on_device);
+/* FunctorOuterVolume (ref: functor_volume.h:40-80); vfrac_out [nlocal]. */
+int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -47,9 +47,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libisph_oracle.so")
-        if not os.path.exists(path):
-            raise RuntimeError("oracle library missing: run __graft_entry__.build() (or `make -C oracle`)")
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_oracle_build", os.path.join(_HERE, "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        path = mod.build_oracle()
         L = C.CDLL(path)
         L.orc_kernel_val.restype = C.c_double
         L.orc_kernel_dval.restype = C.c_double

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Host + oracle libraries are built on demand (seconds); the HIP library is
+    built by __graft_entry__.build() and must already exist for -m gpu."""
+    import isph_amd
+    isph_amd.build.build_host()
+    import oracle
+    oracle.lib()
+    yield
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from isph_amd import hip
+    ctx = hip.Context(0)
+    yield ctx
+    ctx.close()

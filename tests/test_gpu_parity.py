@@ -1,0 +1,201 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on
+seeded TGV problems.  Tolerances are stated per test; integer/index work
+(sparsity pattern) must match exactly."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from isph_amd import hip, workload
+import oracle as orc
+from problems import Problem, tgv_spec
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(dim=2, n=16, mode=workload.JITTER),
+    dict(dim=2, n=33, mode=workload.ADVECT),            # ragged: 1089 rows, not a multiple of 64
+    dict(dim=3, n=12, mode=workload.JITTER),
+    dict(dim=3, n=16, mode=workload.ADVECT),
+    dict(dim=3, n=10, mode=workload.JITTER, kernel="quintic", cut_over_h=3.0),
+    dict(dim=2, n=12, mode=workload.LATTICE, kernel="cubic", cut_over_h=2.0),
+]
+
+
+def _csr(rp, ci, v, n):
+    return sps.csr_matrix((v, ci, rp), shape=(n, n))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_csr_ingress_roundtrip_and_spmv(gpu_ctx, case):
+    pr = Problem(tgv_spec(**case))
+    rp, ci, val, b = pr.poisson()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    info = A.info()
+    assert info["nrow"] == pr.n and info["nnz"] == len(val)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2, val)   # bit-exact layout round trip
+    x = np.random.default_rng(1).standard_normal(pr.n)
+    y = A.spmv(x)
+    yo = orc.spmv(rp, ci, val, x)
+    scale = np.abs(_csr(rp, ci, np.abs(val), pr.n) @ np.abs(x))
+    assert np.max(np.abs(y - yo) / scale) < 1e-14          # fp64, different summation order only
+    # linearity (size-independent property)
+    x2 = np.random.default_rng(2).standard_normal(pr.n)
+    assert np.allclose(A.spmv(2.0 * x + x2), 2.0 * y + A.spmv(x2), rtol=1e-12, atol=1e-12 * scale.max())
+
+
+def test_empty_and_tiny_matrices(gpu_ctx):
+    A = hip.Matrix.from_csr(gpu_ctx, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    assert A.info()["nrow"] == 0
+    rp = np.array([0, 1, 1, 3], np.int32)            # row 1 is empty
+    ci = np.array([0, 0, 2], np.int32)
+    v = np.array([2.0, -1.0, 4.0])
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, v)
+    assert np.array_equal(A.spmv(np.array([1.0, 5.0, 0.5])), np.array([2.0, 0.0, 1.0]))
+    with pytest.raises(hip.IsphError):
+        hip.Matrix.from_csr(gpu_ctx, rp, np.array([0, 0, 7], np.int32), v)     # column out of range
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("antisym", [True, False])
+def test_gpu_assembly_matches_oracle(gpu_ctx, case, antisym):
+    pr = Problem(tgv_spec(**case), antisym=antisym)
+    rp, ci, val, b = pr.poisson()
+    p = pr.parts
+    vfrac = pr.P.vfrac.copy()
+    # volumes first (FunctorOuterVolume): parity 1e-14 relative
+    vg = hip.compute_volumes(gpu_ctx, p, pr.colmap, kernel=pr.spec.kernel)
+    assert np.max(np.abs(vg - vfrac[:pr.n]) / vfrac[:pr.n]) < 1e-13
+    keep = []
+    pv, dev, keep = hip.particles_view(p, pr.colmap, kernel=pr.spec.kernel, vfrac=vfrac,
+                                       Gc=None if antisym else pr.P.Gc, Lc=None if antisym else pr.P.Lc, keep=keep)
+    import ctypes as C
+    A = hip.Matrix(gpu_ctx)
+    bg = np.zeros(pr.n)
+    hip._check(hip.lib().isph_assemble_poisson(gpu_ctx.h, C.byref(pv), int(antisym), float(pr.spec.dt),
+                                               hip._ptr(p["rho"]), hip._ptr(np.ascontiguousarray(p["v"])),
+                                               hip.NULLSPACE, 1, pr.n, C.byref(A.h), hip._ptr(bg), 0))
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci)          # sparsity pattern: exact
+    scale = np.abs(val).max()
+    assert np.max(np.abs(v2 - val)) < 1e-12 * scale                     # values: fp64 round-off only
+    assert np.max(np.abs(bg - b)) < 1e-12 * max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("mode", [hip.PINZERO, hip.DOUBLEDIAG, hip.NOT_SINGULAR])
+def test_gpu_assembly_singular_modes(gpu_ctx, mode):
+    pr = Problem(tgv_spec(dim=2, n=12, mode=workload.JITTER), singular=mode)
+    rp, ci, val, b = pr.poisson()
+    A, bg = hip.assemble_poisson(gpu_ctx, pr.parts, pr.colmap, pr.spec.dt, pr.parts["rho"],
+                                 np.ascontiguousarray(pr.parts["v"]), singular=mode, vfrac=pr.P.vfrac)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(ci2, ci)
+    assert np.max(np.abs(v2 - val)) < 1e-12 * np.abs(val).max()
+    assert np.max(np.abs(bg - b)) < 1e-12 * np.abs(b).max()
+
+
+def test_gpu_assembly_merges_duplicate_images(gpu_ctx):
+    pr = Problem(tgv_spec(dim=2, n=4, mode=workload.JITTER, brick=0))
+    rp, ci, val, b = pr.poisson()
+    A, bg = hip.assemble_poisson(gpu_ctx, pr.parts, pr.colmap, pr.spec.dt, pr.parts["rho"],
+                                 np.ascontiguousarray(pr.parts["v"]), vfrac=pr.P.vfrac)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci)
+    assert np.max(np.abs(v2 - val)) < 1e-12 * np.abs(val).max()
+
+
+SOLVES = [("none", 0), ("jacobi", 0)]
+
+
+@pytest.mark.parametrize("case", CASES[:4])
+@pytest.mark.parametrize("prec,bs", SOLVES)
+def test_gmres_solve_matches_oracle(gpu_ctx, case, prec, bs):
+    """Pressure vector parity: ||x_gpu - x_cpu|| / ||x_cpu|| <= 1e-6 with both at
+    relative residual <= 1e-8; iteration counts within +-1;
+    x.n = 0 to 1e-12."""
+    pr = Problem(tgv_spec(**case))
+    rp, ci, val, b = pr.poisson()
+    xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec=prec)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, prec, 0)
+    bg, xg = b.copy(), np.zeros(pr.n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=True)
+    assert info.converged == 1 and info.rel_res_implicit <= 1e-8
+    assert abs(info.iters - io.iters) <= 1
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+    assert abs(xg.sum()) / np.sqrt(pr.n) <= 1e-12 * np.linalg.norm(xg)
+    assert np.allclose(bg, bo, rtol=0, atol=1e-14 * np.abs(bo).max())   # b projected in place like the reference
+    assert abs(info.rel_res_explicit - io.rel_res_explicit) <= 1e-6 * max(io.rel_res_explicit, 1e-12) + 1e-12
+
+
+def test_cg_solve_matches_oracle(gpu_ctx):
+    pr = Problem(tgv_spec(dim=2, n=32, mode=workload.LATTICE))
+    rp, ci, val, _ = pr.poisson()
+    x = pr.parts["x"][:pr.n]
+    b = np.cos(2 * x[:, 0]) + np.cos(2 * x[:, 1])
+    prm_o = orc.SolverParams(solver_type=1, tol=1e-8)
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=True, prec="jacobi", params=prm_o)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "jacobi", 0)
+    bg, xg = b.copy(), np.zeros(pr.n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=True, params=hip.SolverParams(solver_type=1, tol=1e-8))
+    assert info.converged == 1 and abs(info.iters - io.iters) <= 1
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+def test_nonconvergence_is_reported_not_raised(gpu_ctx):
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    xg = np.zeros(pr.n)
+    info = hip.solve(gpu_ctx, A, b.copy(), xg, singular=True, params=hip.SolverParams(max_iters=3))
+    assert info.converged == 0 and info.iters == 3            # LAMMPS_SUCCESS, solver_lin_belos.h:194-221
+
+
+def test_multi_rhs_and_restart(gpu_ctx):
+    """nvec=3 column-major [lda x nvec] like the Helmholtz call (pair_isph.cpp:936-942),
+    with a short restart length to exercise restarts."""
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER), singular=orc.NOT_SINGULAR)
+    rp, ci, val, b = pr.poisson()
+    val = val.copy()
+    for i in range(pr.n):                      # make it Helmholtz-like: I + A
+        val[rp[i]:rp[i + 1]][ci[rp[i]:rp[i + 1]] == i] += 1.0
+    rng = np.random.default_rng(3)
+    B = np.asfortranarray(rng.standard_normal((pr.n, 3)))
+    X = np.zeros_like(B, order="F")
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    prm = hip.SolverParams(num_blocks=5, max_iters=500, max_restarts=100)
+    bflat, xflat = B.ravel(order="F").copy(), X.ravel(order="F").copy()
+    info = hip.solve(gpu_ctx, A, bflat, xflat, params=prm, nvec=3, lda=pr.n)
+    assert info.converged == 1 and info.restarts > 0
+    for c in range(3):
+        xo, io, _ = orc.solve(rp, ci, val, B[:, c], params=orc.SolverParams(num_blocks=5, max_iters=500, max_restarts=100))
+        xc = xflat[c * pr.n:(c + 1) * pr.n]
+        assert np.linalg.norm(xc - xo) / np.linalg.norm(xo) < 1e-6
+
+
+def test_full_size_properties(gpu_ctx):
+    """Size-independent properties at a size the oracle would not finish quickly:
+    48^3 assembled and solved entirely on the GPU: row sums vanish, the solve
+    reaches the tolerance, the solution is mean-free, residual re-checked on host."""
+    import torch
+    sp = tgv_spec(dim=3, n=48, mode=workload.ADVECT)
+    p = workload.make_tgv(sp)
+    colmap = workload.single_rank_colmap(p)
+    vf = hip.compute_volumes(gpu_ctx, p, colmap)
+    vfrac = np.zeros(p["nall"])
+    vfrac[:p["nlocal"]] = vf
+    vfrac[p["nlocal"]:] = vf[p["owner_index"][p["nlocal"]:]]
+    A, b = hip.assemble_poisson(gpu_ctx, p, colmap, sp.dt, p["rho"], np.ascontiguousarray(p["v"]), vfrac=vfrac)
+    n = p["nlocal"]
+    ones = A.spmv(np.ones(n))
+    rp, ci, v = A.export_csr()
+    assert np.max(np.abs(ones)) < 1e-11 * np.abs(v).max()
+    x = np.zeros(n)
+    bb = b.copy()
+    info = hip.solve(gpu_ctx, A, bb, x, singular=True)
+    assert info.converged == 1
+    r = bb - _csr(rp, ci, v, n) @ x
+    r -= r.mean()
+    assert np.linalg.norm(r) / np.linalg.norm(bb) < 2e-8
+    assert abs(x.mean()) < 1e-12 * np.abs(x).max()
