@@ -14,10 +14,11 @@ namespace isph {
 thread_local std::string g_last_error;
 
 int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z) {
-  const int n = M ? M->n : 0;
-  if (!M || M->type == 0) {
+  ISPH_REQUIRE(M != nullptr, "preconditioner is NULL");
+  const int n = M->n;
+  if (M->type == 0) {
     // identity: callers pass distinct buffers
-    if (r != z && M) ISPH_CHECK_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (r != z) ISPH_CHECK_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     return ISPH_SUCCESS;
   }
   if (M->type == 1) {

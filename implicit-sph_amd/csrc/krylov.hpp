@@ -51,15 +51,27 @@ __global__ __launch_bounds__(kBlock) void k_multi_dot(int n, int nk, const doubl
     partial[(long long)k * gridDim.x + blockIdx.x] = (sacc[k * 4] + sacc[k * 4 + 1]) + (sacc[k * 4 + 2] + sacc[k * 4 + 3]);
 }
 
-// out[k] = sum_b partial[k*nblk + b], one wave per k, fixed order
-__global__ void k_reduce_partials(int nk, int nblk, const double *__restrict__ partial, double *__restrict__ out) {
-  const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+// out[k] = sum_b partial[k*nblk + b]: one 256-thread block per k, fixed
+// (launch-independent) summation order -> bitwise reproducible
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(int nk, int nblk, const double *__restrict__ partial,
+                                                            double *__restrict__ out) {
+  __shared__ double sw[4];
+  const int k = blockIdx.x;
   if (k >= nk) return;
-  const int lane = threadIdx.x & 63;
-  double s = 0.0;
-  for (int b = lane; b < nblk; b += 64) s += partial[(long long)k * nblk + b];
-  s = wave_sum(s);
-  if (lane == 0) out[k] = s;
+  const double *__restrict__ p = partial + (long long)k * nblk;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 3 * kBlock < nblk; b += 4 * kBlock) {
+    s0 += p[b];
+    s1 += p[b + kBlock];
+    s2 += p[b + 2 * kBlock];
+    s3 += p[b + 3 * kBlock];
+  }
+  for (; b < nblk; b += kBlock) s0 += p[b];
+  double s = wave_sum((s0 + s1) + (s2 + s3));
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[k] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
 // w -= sum_k c[k] V_k ; partial[blockIdx] = sum of the new w.w  (c on device)

@@ -109,7 +109,7 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
   }
   ISPH_CHECK(profile_end(ctx, slot));
   if (nvec) {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, ctx->stream, 1, S.nslices, ctx->partial.p,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, 1, S.nslices, ctx->partial.p,
                        ctx->dscal.p + SC_MISC);
     ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_MISC, 1));
   }
@@ -131,14 +131,20 @@ struct LinOp {
                          ctx->dscal.p + SC_MISC, nvec, y);
     return ISPH_SUCCESS;
   }
-  int prec(const double *r, double *z) const { return prec_apply_dev(ctx, M, r, z); }
+  int prec(const double *r, double *z) const {
+    if (!M) {  // no preconditioner object: identity
+      ISPH_CHECK_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+      return ISPH_SUCCESS;
+    }
+    return prec_apply_dev(ctx, M, r, z);
+  }
 };
 
 // dot(a,b) -> dscal[slot] (all-reduced); optionally dot(c,d) -> dscal[slot+1]
 inline int dot_dev(isph_ctx *ctx, int n, const double *a, const double *b, const double *c, const double *d, int slot) {
   const int g = stream_grid(n);
   hipLaunchKernelGGL(k_dot2, dim3(g), dim3(kBlock), 0, ctx->stream, n, a, b, c, d, ctx->partial.p);
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(128), 0, ctx->stream, 2, g, ctx->partial.p, ctx->dscal.p + slot);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(kBlock), 0, ctx->stream, 2, g, ctx->partial.p, ctx->dscal.p + slot);
   return allreduce_inplace(ctx, ctx->dscal.p + slot, 2);
 }
 
@@ -160,13 +166,13 @@ inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld,
   ISPH_CHECK(ctx->partial.reserve((size_t)(nk + 2) * 1024 > (size_t)kMaxRedBlocks * 66 ? (size_t)(nk + 2) * 1024 : (size_t)kMaxRedBlocks * 66));
   hipLaunchKernelGGL(k_multi_dot, dim3(g), dim3(kBlock), sizeof(double) * 4 * (size_t)(nk + 1), ctx->stream, n, nk, V, ld,
                      w, ctx->partial.p);
-  hipLaunchKernelGGL(k_reduce_partials, dim3((nk + 1 + 3) / 4), dim3(256), 0, ctx->stream, nk + 1, g, ctx->partial.p,
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, ctx->stream, nk + 1, g, ctx->partial.p,
                      ctx->dscal.p + SC_DOT);
   ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_DOT, nk + 1));
   const int g2 = stream_grid(n);
   hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, ctx->dscal.p + SC_DOT, w,
                      ctx->partial.p);
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, ctx->stream, 1, g2, ctx->partial.p,
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, 1, g2, ctx->partial.p,
                      ctx->dscal.p + SC_DOT + nk + 1);
   ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_DOT + nk + 1, 1));
   ISPH_CHECK_HIP(hipGetLastError());
@@ -339,7 +345,7 @@ inline int pcg(const LinOp &op, const double *b, double *x, const isph_solver_pa
     ISPH_CHECK(dot_dev(ctx, n, p, ap, nullptr, nullptr, PAP));
     const int g = stream_grid(n);
     hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(kBlock), 0, st, n, p, ap, x, r, ds + rz, ds + PAP, ctx->partial.p);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, st, 1, g, ctx->partial.p, ds + RR);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, 1, g, ctx->partial.p, ds + RR);
     ISPH_CHECK(allreduce_inplace(ctx, ds + RR, 1));
     ISPH_CHECK(fetch_scalars(ctx, RR, 1));
     ++info->iters;

@@ -37,6 +37,13 @@ int orc_num_threads(void) {
   return 1;
 #endif
 }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 /* ===================================================================== *
  *  SPH kernels
@@ -700,7 +707,7 @@ int orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
 
 void orc_spmv(int n, const int *rowptr, const int *colidx, const double *val,
               const double *x, double *y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
   for (int i = 0; i < n; ++i) {
     double s = 0.0;
     for (int p = rowptr[i]; p < rowptr[i + 1]; ++p) s += val[p] * x[colidx[p]];
@@ -710,16 +717,16 @@ void orc_spmv(int n, const int *rowptr, const int *colidx, const double *val,
 
 static double vdot(int n, const double *a, const double *b) {
   double s = 0.0;
-#pragma omp parallel for reduction(+ : s) schedule(static)
+#pragma omp parallel for reduction(+ : s) schedule(static) if (n > 16384)
   for (int i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
 static void vaxpy(int n, double a, const double *x, double *y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
   for (int i = 0; i < n; ++i) y[i] += a * x[i];
 }
 static void vscale_copy(int n, double a, const double *x, double *y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
   for (int i = 0; i < n; ++i) y[i] = a * x[i];
 }
 
@@ -863,7 +870,7 @@ orc_ilu *orc_ilu_create(int n, const int *rowptr, const int *colidx,
 
 /* z = U^-1 D^-1 L^-1 r, block by block */
 void orc_ilu_apply(const orc_ilu *F, const double *r, double *z) {
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (F->n > 16384)
   for (int b = 0; b < F->nblocks; ++b) {
     const int lo = F->block_ptr[b], hi = F->block_ptr[b + 1];
     for (int i = lo; i < hi; ++i) {
@@ -913,7 +920,7 @@ static void op_apply(const lin_ctx *c, const double *x, double *y) {
 static void prec_apply(const lin_ctx *c, const double *r, double *z) {
   if (c->prec_type == 2 && c->F) orc_ilu_apply(c->F, r, z);
   else if (c->prec_type == 1) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (c->n > 16384)
     for (int i = 0; i < c->n; ++i) z[i] = r[i] * c->invdiag[i];
   } else memcpy(z, r, sizeof(double) * (size_t)c->n);
 }
@@ -964,7 +971,7 @@ static void gmres(const lin_ctx *c, const double *b, double *x,
   double *w = (double *)malloc(sizeof(double) * (size_t)n), *t = (double *)malloc(sizeof(double) * (size_t)n);
 
   op_apply(c, x, w);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
   for (int i = 0; i < n; ++i) w[i] = b[i] - w[i];
   double beta = sqrt(vdot(n, w, w));
   const double scale = beta == 0.0 ? 1.0 : beta; /* Belos: zero scale -> 1 */
@@ -1042,7 +1049,7 @@ static void pcg(const lin_ctx *c, const double *b, double *x,
   double *r = (double *)malloc(sizeof(double) * (size_t)n), *z = (double *)malloc(sizeof(double) * (size_t)n);
   double *p = (double *)malloc(sizeof(double) * (size_t)n), *ap = (double *)malloc(sizeof(double) * (size_t)n);
   op_apply(c, x, ap);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
   for (int i = 0; i < n; ++i) r[i] = b[i] - ap[i];
   const double r0 = sqrt(vdot(n, r, r));
   const double scale = r0 == 0.0 ? 1.0 : r0;
@@ -1065,7 +1072,7 @@ static void pcg(const lin_ctx *c, const double *b, double *x,
     const double rz_new = vdot(n, r, z);
     const double betak = rz_new / rz;
     rz = rz_new;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
     for (int i = 0; i < n; ++i) p[i] = z[i] + betak * p[i];
   }
   free(r); free(z); free(p); free(ap);
@@ -1108,7 +1115,7 @@ int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
   { /* ||b - A x|| / ||b|| with the unprojected A (:201-212) */
     double *r = (double *)malloc(sizeof(double) * (size_t)n);
     orc_spmv(n, rowptr, colidx, val, x, r);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n > 16384)
     for (int i = 0; i < n; ++i) r[i] = b[i] - r[i];
     const double bn = sqrt(vdot(n, b, b));
     info->rel_res_explicit = sqrt(vdot(n, r, r)) / (bn == 0.0 ? 1.0 : bn);

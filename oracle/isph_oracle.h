@@ -124,6 +124,7 @@ int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
               const orc_solver_params *prm, orc_solve_info *info);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,9 @@ def lib():
         L.orc_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_forward_comm.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        # GPU boxes expose 256 hardware threads but give a job a 16-CPU share: cap the team size
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        L.orc_set_num_threads(int(os.environ.get("ISPH_ORACLE_THREADS", min(16, ncpu))))
         _lib = L
     return _lib
 
