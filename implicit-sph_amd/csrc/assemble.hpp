@@ -22,6 +22,7 @@
 namespace isph {
 
 int sell_finalize_offsets(isph_ctx *ctx, Sell &S);  // isph_capi.hip
+int sell_sort_rows(isph_ctx *ctx, Sell &S);         // isph_capi.hip
 
 constexpr double kEps = 1.0e-24;  // ISPH_EPSILON, ref: macrodef.h:6
 enum { KIND_FLUID = 99, KIND_SOLID = 12, KIND_ALL = 127 };
@@ -489,6 +490,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
             rc = fail("copy failed", __FILE__, __LINE__);
         }
       }
+      if (rc == ISPH_SUCCESS) rc = sell_sort_rows(ctx, M);  // columns ascending, like Epetra after FillComplete
       if (rc == ISPH_SUCCESS && !on_device &&
           hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         rc = fail("copy failed", __FILE__, __LINE__);

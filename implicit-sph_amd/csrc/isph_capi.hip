@@ -50,6 +50,29 @@ int sell_finalize_offsets(isph_ctx *ctx, Sell &S) {
   return ISPH_SUCCESS;
 }
 
+// sort every row's entries by column (invariant of isph_mat, needs max width from host)
+int sell_sort_rows(isph_ctx *ctx, Sell &S) {
+  if (S.nslices == 0) return ISPH_SUCCESS;
+  std::vector<long long> so((size_t)S.nslices + 1);
+  ISPH_CHECK_HIP(hipMemcpyAsync(so.data(), S.slice_off.p, sizeof(long long) * so.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  int wmax = 0;
+  for (int s = 0; s < S.nslices; ++s) wmax = std::max(wmax, (int)((so[(size_t)s + 1] - so[(size_t)s]) >> 6));
+  S.wmax = wmax;
+  if (wmax == 0) return ISPH_SUCCESS;
+  const int Ws = wmax | 1;
+  int R = 64;
+  while (R > 1 && (size_t)R * Ws * 24 > 144 * 1024) R >>= 1;
+  ISPH_REQUIRE((size_t)R * Ws * 24 <= 160 * 1024, "row too long for the LDS row sort");
+  const size_t lds = (size_t)R * Ws * 24;
+  ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sell_sort_rows),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sell_sort_rows, dim3(S.nslices), dim3(kBlock), lds, ctx->stream, S.nrow, S.nslices, R, Ws,
+                     S.rowlen.p, S.slice_off.p, S.col.p, S.val.p);
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
 }  // namespace isph
 
 using namespace isph;
@@ -168,6 +191,7 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, co
     if (rc == ISPH_SUCCESS) {
       hipLaunchKernelGGL(k_csr_to_sell, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
                          S.slice_off.p, S.col.p, S.val.p);
+      rc = sell_sort_rows(ctx, S);
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);
     }

@@ -14,7 +14,7 @@
 namespace isph {
 
 struct Sell {
-  int nrow = 0, ncol = 0, nslices = 0;
+  int nrow = 0, ncol = 0, nslices = 0, wmax = 0;
   long long nnz = 0, stored = 0;
   DevBuf<long long> slice_off;  // [nslices+1] entry offsets (multiples of 128)
   DevBuf<int> rowlen;           // [nrow]
@@ -102,6 +102,63 @@ __global__ void k_csr_to_sell(int nrow, const int *__restrict__ rowptr, const in
       scol[p] = padcol;
       sval[p] = 0.0;
     }
+  }
+}
+
+// ---- row sort: columns ascending inside every row (Epetra OptimizeStorage order)
+// One workgroup per slice.  R rows at a time are staged through LDS (coalesced
+// k-pair segments), ranked by counting (all lanes read the same LDS word ->
+// broadcast), written to a second LDS image in sorted order and streamed back.
+// LDS: 24 bytes * R * Ws.
+__global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int nrow, int nslices, int R, int Ws,
+                                                           const int *__restrict__ rowlen,
+                                                           const long long *__restrict__ slice_off,
+                                                           int *__restrict__ scol, double *__restrict__ sval) {
+  extern __shared__ double lds_raw[];
+  const int slice = blockIdx.x;
+  if (slice >= nslices) return;
+  double *valA = lds_raw;                 // [R][Ws]
+  double *valB = valA + (size_t)R * Ws;   // [R][Ws]
+  int *colA = reinterpret_cast<int *>(valB + (size_t)R * Ws);
+  int *colB = colA + (size_t)R * Ws;
+  const long long off = slice_off[slice];
+  const int w = (int)((slice_off[slice + 1] - off) >> 6);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r0 = 0; r0 < kSlice; r0 += R) {
+    const int total = R * w;  // w is even
+    for (int e = threadIdx.x; e < total; e += kBlock) {
+      const int kk = e & 1, r = (e >> 1) % R, kp = (e >> 1) / R;
+      const long long g = off + (long long)kp * 128 + (r0 + r) * 2 + kk;
+      colA[r * Ws + 2 * kp + kk] = scol[g];
+      valA[r * Ws + 2 * kp + kk] = sval[g];
+    }
+    __syncthreads();
+    for (int r = wave; r < R; r += kBlock / kWave) {
+      const int row = slice * kSlice + r0 + r;
+      const int len = row < nrow ? rowlen[row] : 0;
+      for (int k = lane; k < w; k += kWave) {
+        int dst = k;  // padding keeps its slot
+        if (k < len) {
+          const int c = colA[r * Ws + k];
+          int rank = 0;
+          for (int q = 0; q < len; ++q) {
+            const int cq = colA[r * Ws + q];
+            rank += (cq < c) || (cq == c && q < k);
+          }
+          dst = rank;
+        }
+        colB[r * Ws + dst] = colA[r * Ws + k];
+        valB[r * Ws + dst] = valA[r * Ws + k];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += kBlock) {
+      const int kk = e & 1, r = (e >> 1) % R, kp = (e >> 1) / R;
+      const long long g = off + (long long)kp * 128 + (r0 + r) * 2 + kk;
+      scol[g] = colB[r * Ws + 2 * kp + kk];
+      sval[g] = valB[r * Ws + 2 * kp + kk];
+    }
+    __syncthreads();
   }
 }
 

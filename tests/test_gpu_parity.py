@@ -200,3 +200,55 @@ def test_full_size_properties(gpu_ctx):
     r -= r.mean()
     assert np.linalg.norm(r) / np.linalg.norm(bb) < 2e-8
     assert abs(x.mean()) < 1e-12 * np.abs(x).max()
+
+
+# ---------------------------------------------------------------- block-Jacobi ILU(0)
+ILU_CASES = [
+    (dict(dim=2, n=16, mode=workload.JITTER, brick=8), 64),
+    (dict(dim=2, n=33, mode=workload.ADVECT, brick=8), 256),      # ragged last block
+    (dict(dim=3, n=12, mode=workload.JITTER, brick=4), 64),
+    (dict(dim=3, n=16, mode=workload.ADVECT, brick=8), 512),
+    (dict(dim=3, n=10, mode=workload.JITTER, kernel="quintic", cut_over_h=3.0, brick=5), 1024),  # one block, wide rows
+]
+
+
+@pytest.mark.parametrize("case,bs", ILU_CASES)
+def test_ilu0_factor_and_apply_match_oracle(gpu_ctx, case, bs):
+    pr = Problem(tgv_spec(**case))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    bp = np.arange(0, n + bs, bs).clip(0, n).astype(np.int32)
+    ref = orc.ILU(rp, ci, val, 0, bp)
+    frp, fci, fv = ref.export()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", bs)
+    grp, gci, gv = M.export_ilu()
+    assert np.array_equal(grp, frp) and np.array_equal(gci, fci)            # factor pattern: exact
+    assert np.max(np.abs(gv - fv) / np.maximum(np.abs(fv), 1e-300 + 1e-10 * np.abs(fv).max())) < 1e-10
+    r = np.random.default_rng(5).standard_normal(n)
+    z = M.apply(r)
+    zo = ref.apply(r)
+    assert np.linalg.norm(z - zo) / np.linalg.norm(zo) < 1e-11
+
+
+@pytest.mark.parametrize("case,bs", ILU_CASES[:4])
+def test_gmres_bjacobi_ilu0_matches_oracle(gpu_ctx, case, bs):
+    pr = Problem(tgv_spec(**case))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    bp = np.arange(0, n + bs, bs).clip(0, n).astype(np.int32)
+    xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", bs)
+    bg, xg = b.copy(), np.zeros(n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=True)
+    assert info.converged == 1 and abs(info.iters - io.iters) <= 1
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+def test_ilu_rejects_bad_block_size(gpu_ctx):
+    pr = Problem(tgv_spec(dim=2, n=16, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    with pytest.raises(hip.IsphError):
+        hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 100)
