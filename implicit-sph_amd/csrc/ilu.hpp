@@ -27,6 +27,13 @@ struct isph_ilu {
   const isph::Sell *S = nullptr;  // geometry shared with A (A must outlive the factor)
   isph::DevBuf<int> fcol, flen, fdiag, err;
   isph::DevBuf<double> fval;
+  // statically scheduled triangular solves (see k_ilu_schedule / k_ilu_solve_stream)
+  isph::DevBuf<double> sv;        // chunk stream values   [nchunks*64]
+  isph::DevBuf<unsigned> sc;      // chunk stream words    col | row<<16 | END<<31
+  isph::DevBuf<int> fdst;         // factor slot -> stream index (-1: diagonal)
+  isph::DevBuf<int> blkinfo;      // [nblocks][2] chunks in the L / U stream
+  isph::DevBuf<double> dinv;      // [n] 1/d_i
+  long long stream_chunks = 0;
   long long nnz = 0;
 };
 
@@ -82,7 +89,9 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, const long long *__restrict__ slice_off,
                                                            const int *__restrict__ fcol, double *__restrict__ fval,
                                                            const int *__restrict__ flen,
-                                                           const int *__restrict__ fdiag, int *__restrict__ err) {
+                                                           const int *__restrict__ fdiag, const int *__restrict__ fdst,
+                                                           double *__restrict__ sv, double *__restrict__ dinv,
+                                                           int *__restrict__ err) {
   extern __shared__ double lds_f[];
   double *diag = lds_f;                                   // [B]
   double *wval = diag + B;                                // [WAVES][W]
@@ -127,10 +136,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
       __builtin_amdgcn_wave_barrier();
     }
     for (int s = lane; s < len; s += 64) {
-      fval[sell_pos(off, li, s)] = mv[s];
+      const long long p = sell_pos(off, li, s);
+      fval[p] = mv[s];
+      const int d = fdst[p];
+      if (d >= 0) sv[d] = mv[s];  // triangular-solve stream
       mp[mc[s] - blo] = 0;
     }
-    if (lane == 0) diag[r] = mv[dg];
+    if (lane == 0) { diag[r] = mv[dg]; dinv[i] = 1.0 / mv[dg]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // row i (global) + diag (LDS) before the flag
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) done[r] = 1;
@@ -241,9 +253,229 @@ __global__ __launch_bounds__(1024) void k_ilu_solve(int n, int B, const long lon
   }
 }
 
+// ---------------------------------------------------------------------------
+// Static schedule of the triangular solves (built per factorisation, on the GPU)
+//
+// For each block and each direction (L: dependencies = strictly-lower entries,
+// U: strictly-upper) rows are levelled (lev = 1 + max lev of dependencies; level
+// 0 rows need no work), sorted by level, and packed 8 rows per "step" with 8
+// lanes per row.  A step is a run of chunks; chunk = 64 x (value, word) with
+//   word = local column (11 bits) | local row << 11 (11 bits) | log2(G/8) << 22 | END << 31
+// (END: last chunk of step; G = lanes per row in this step: 8 for a full step of
+// 8 rows, 16/32/64 when a level leaves only <=4/2/1 rows for its last step)
+// so the solve kernel is a pure coalesced stream: per chunk one fma against x in
+// LDS, per step one 8-lane reduction and one LDS update.  No flags, no waiting.
+// Stream capacity per block = kCapFactor x the block's sliced-ELL region + slack
+// (+ prefetch pad); running out of it fails the build loudly.
+constexpr unsigned kRowInvalid = 0x7FFu;
+constexpr int kRowShift = 11, kGShift = 22;
+constexpr unsigned kEndBit = 0x80000000u;
+constexpr int kPrefetch = 8;    // chunks kept in flight per wave
+constexpr int kPadChunks = 16;    // per-block tail pad so the prefetch never leaves the buffer
+constexpr int kSlackChunks = 64;  // per-block slack on top of kCapFactor x the block's ELL region
+constexpr int kCapFactor = 3;
+
+__device__ __forceinline__ long long ilu_base_chunk(const long long *slice_off, int b, int B) {
+  return kCapFactor * (slice_off[(long long)b * (B / 64)] >> 6) + (long long)(kPadChunks + kSlackChunks) * b;
+}
+
+__global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long long *__restrict__ slice_off,
+                                                       const int *__restrict__ fcol, const int *__restrict__ flen,
+                                                       const int *__restrict__ fdiag, double *__restrict__ sv,
+                                                       unsigned *__restrict__ sc, int *__restrict__ fdst,
+                                                       int *__restrict__ blkinfo, int *__restrict__ err) {
+  extern __shared__ int lds_i[];
+  int *lev = lds_i;              // [B]
+  int *cnt = lev + B;            // [B+1]
+  int *stepstart = cnt + B + 1;  // [B+1]
+  int *tmaxs = stepstart + B + 1;  // [B+1]
+  int *choff = tmaxs + B + 1;    // [B+2]
+  __shared__ int s_nlev, s_nsteps, s_nch;
+  const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
+  const int t = threadIdx.x;
+  const bool active = t < m;
+  const int i = blo + t;
+  const int nslices_blk = (m + 63) / 64;
+  const long long region = slice_off[(long long)b * (B / 64) + nslices_blk] - slice_off[(long long)b * (B / 64)];
+  const long long cap = kCapFactor * (region >> 6) + kSlackChunks;
+  const long long base = ilu_base_chunk(slice_off, b, B);
+  long long off = 0;
+  int li = 0, len = 0, dg = 0;
+  if (active) {
+    off = slice_off[i >> 6];
+    li = i & 63;
+    len = flen[i];
+    dg = fdiag[i];
+    fdst[sell_pos(off, li, dg)] = -1;
+  }
+  int used = 0;  // chunks used so far in this block (L then U)
+  for (int dir = 0; dir < 2; ++dir) {
+    const int d0 = dir == 0 ? 0 : dg + 1, d1 = dir == 0 ? dg : len;  // dependency slots
+    const int ndep = active ? d1 - d0 : 0;
+    // ---- levels by relaxation (monotone, converges in #levels sweeps)
+    if (t < B) lev[t] = 0;
+    __syncthreads();
+    for (int sweep = 0; sweep <= B; ++sweep) {
+      int nl = 0;
+      for (int e = 0; e < ndep; ++e) nl = max(nl, lev[fcol[sell_pos(off, li, d0 + e)] - blo] + 1);
+      const int changed = active && nl != lev[t];
+      if (!__syncthreads_or(changed)) break;
+      if (active) lev[t] = nl;
+      __syncthreads();
+    }
+    // ---- histogram of levels
+    if (t == 0) s_nlev = 0;
+    for (int k = t; k <= B; k += blockDim.x) { cnt[k] = 0; tmaxs[k] = 0; }
+    __syncthreads();
+    const int mylev = active ? lev[t] : 0;
+    if (active) { atomicAdd(&cnt[mylev], 1); atomicMax(&s_nlev, mylev + 1); }
+    __syncthreads();
+    // deterministic rank inside the level (row order)
+    int rk = 0;
+    if (active && mylev > 0)
+      for (int q = 0; q < t; ++q) rk += (lev[q] == mylev);
+    if (t == 0) {
+      int run = 0;
+      stepstart[0] = 0;
+      for (int l = 1; l < s_nlev; ++l) { stepstart[l] = run; run += (cnt[l] + 7) >> 3; }
+      s_nsteps = run;
+    }
+    __syncthreads();
+    const int step = (active && mylev > 0) ? stepstart[mylev] + (rk >> 3) : -1;
+    const int g = rk & 7;
+    const int rows_in_step = (active && mylev > 0) ? min(8, cnt[mylev] - ((rk >> 3) << 3)) : 8;
+    const int gcode = rows_in_step > 4 ? 0 : rows_in_step > 2 ? 1 : rows_in_step > 1 ? 2 : 3;
+    const int G = 8 << gcode;           // lanes per row in this step
+    const int tneed = (ndep + G - 1) / G;  // >= 1 for scheduled rows
+    if (step >= 0) atomicMax(&tmaxs[step], tneed);
+    __syncthreads();
+    if (t == 0) {
+      int run = 0;
+      for (int q = 0; q < s_nsteps; ++q) { choff[q] = run; run += tmaxs[q]; }
+      choff[s_nsteps] = run;
+      s_nch = run;
+      blkinfo[2 * b + dir] = run;
+      if ((long long)used + run > cap) atomicOr(err, 16);  // stream capacity exceeded
+    }
+    __syncthreads();
+    if ((long long)used + s_nch > cap) return;  // uniform exit; host reports the error
+    if (step >= 0) {
+      const int tm = tmaxs[step];
+      const unsigned gbits = (unsigned)gcode << kGShift;
+      for (int c = 0; c < tm; ++c) {
+        const long long chunk = base + used + choff[step] + c;
+        const unsigned endbit = ((c == tm - 1) ? kEndBit : 0u) | gbits;
+        for (int j = 0; j < G; ++j) {
+          const int e = c * G + j;
+          const long long idx = chunk * 64 + g * G + j;
+          if (e < ndep) {
+            const long long slot = sell_pos(off, li, d0 + e);
+            sc[idx] = (unsigned)(fcol[slot] - blo) | ((unsigned)t << kRowShift) | endbit;
+            fdst[slot] = (int)idx;
+          } else {
+            sc[idx] = ((unsigned)t << kRowShift) | endbit;
+            sv[idx] = 0.0;
+          }
+        }
+        if (g == 0)  // lanes of the groups this step does not use
+          for (int gg = rows_in_step; gg < 64 / G; ++gg)
+            for (int j = 0; j < G; ++j) {
+              const long long idx = chunk * 64 + gg * G + j;
+              sc[idx] = (kRowInvalid << kRowShift) | endbit;
+              sv[idx] = 0.0;
+            }
+      }
+    }
+    used += s_nch;
+    __syncthreads();
+  }
+}
+
+// z = U^-1 D^-1 L^-1 r : one wave per block streams the block's chunk list.
+// LDS per wave: y[B].  kPrefetch chunks (values + words) are kept in flight.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, int nblocks,
+                                                                 const long long *__restrict__ slice_off,
+                                                                 const double *__restrict__ sv,
+                                                                 const unsigned *__restrict__ sc,
+                                                                 const int *__restrict__ blkinfo,
+                                                                 const int *__restrict__ flen,
+                                                                 const int *__restrict__ fdiag,
+                                                                 const double *__restrict__ dinv,
+                                                                 const double *__restrict__ r, double *__restrict__ z) {
+  extern __shared__ double lds_y[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * WAVES + wave;
+  if (b >= nblocks) return;
+  double *y = lds_y + (size_t)wave * B;
+  const int blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
+  for (int t = lane; t < m; t += 64) y[t] = r[blo + t];
+  const long long base = ilu_base_chunk(slice_off, b, B);
+  const int nL = blkinfo[2 * b], nU = blkinfo[2 * b + 1];
+  const double *__restrict__ pv = sv + base * 64 + lane;
+  const unsigned *__restrict__ pc = sc + base * 64 + lane;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double vq[kPrefetch];
+  unsigned cq[kPrefetch];
+  const int ntot = nL + nU;
+#pragma unroll
+  for (int u = 0; u < kPrefetch; ++u) {
+    vq[u] = pv[(long long)u * 64];
+    cq[u] = pc[(long long)u * 64];
+  }
+  double acc = 0.0;
+  bool upper = false;
+  for (int c0 = 0; c0 < ntot; c0 += kPrefetch) {
+#pragma unroll
+    for (int u = 0; u < kPrefetch; ++u) {
+      const int c = c0 + u;
+      const double v = vq[u];
+      const unsigned cw = cq[u];
+      vq[u] = pv[(long long)(c + kPrefetch) * 64];  // stays inside the padded buffer
+      cq[u] = pc[(long long)(c + kPrefetch) * 64];
+      if (c < ntot) {
+        if (c == nL && !upper) {
+          // switch to the U phase: rows without upper dependencies finish here
+          upper = true;
+          for (int t = lane; t < m; t += 64)
+            if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dinv[blo + t];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+        acc = fma(v, y[cw & 0x7FFu], acc);
+        const unsigned cw0 = __builtin_amdgcn_readfirstlane(cw);
+        if (cw0 & kEndBit) {
+          const int gcode = (cw0 >> kGShift) & 3;  // wave-uniform
+          double s = group8_sum(acc);
+          if (gcode > 0) s += __shfl_xor(s, 8, 64);
+          if (gcode > 1) s += __shfl_xor(s, 16, 64);
+          if (gcode > 2) s += __shfl_xor(s, 32, 64);
+          const unsigned row = (cw >> kRowShift) & 0x7FFu;
+          if ((lane & ((8 << gcode) - 1)) == 0 && row != kRowInvalid) {
+            const double yr = y[row] - s;
+            y[row] = upper ? yr * dinv[blo + row] : yr;
+          }
+          acc = 0.0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+  if (!upper) {  // no U chunks at all (or empty stream): still scale the rows without upper deps
+    for (int t = lane; t < m; t += 64)
+      if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dinv[blo + t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int t = lane; t < m; t += 64) z[blo + t] = y[t];
+}
+
 inline void ilu_destroy(isph_ilu *F) {
   if (!F) return;
   F->fcol.release(); F->flen.release(); F->fdiag.release(); F->err.release(); F->fval.release();
+  F->sv.release(); F->sc.release(); F->fdst.release(); F->blkinfo.release(); F->dinv.release();
   delete F;
 }
 
@@ -262,6 +494,14 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   if (rc == ISPH_SUCCESS) rc = F->flen.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->fdiag.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->err.reserve(1);
+  F->stream_chunks = kCapFactor * (S.stored >> 6) + (long long)(kPadChunks + kSlackChunks) * (F->nblocks + 1) + kPrefetch;
+  if (rc == ISPH_SUCCESS) rc = F->sv.reserve((size_t)F->stream_chunks * 64);
+  if (rc == ISPH_SUCCESS) rc = F->sc.reserve((size_t)F->stream_chunks * 64);
+  if (rc == ISPH_SUCCESS) rc = F->fdst.reserve(stored);
+  if (rc == ISPH_SUCCESS) rc = F->blkinfo.reserve((size_t)2 * (F->nblocks > 0 ? F->nblocks : 1));
+  if (rc == ISPH_SUCCESS) rc = F->dinv.reserve(n1);
+  if (rc == ISPH_SUCCESS && (long long)F->stream_chunks * 64 >= 2147483647LL)
+    rc = fail("ILU stream exceeds 32-bit indexing", __FILE__, __LINE__);
   if (rc == ISPH_SUCCESS && S.nrow > 0) {
     const int W = ((S.wmax + 63) / 64) * 64;
     const size_t lds = sizeof(double) * (size_t)block_size + (size_t)kIluWaves * W * 12 + 4 * (size_t)block_size +
@@ -281,18 +521,34 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
         rc = fail("matrix row without a diagonal entry: ILU(0) undefined", __FILE__, __LINE__);
     }
     if (rc == ISPH_SUCCESS) {
+      const size_t lds_s = sizeof(int) * (5 * (size_t)block_size + 8);
+      hipLaunchKernelGGL(k_ilu_schedule, dim3(F->nblocks), dim3(block_size), lds_s, ctx->stream, S.nrow, block_size,
+                         S.slice_off.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->fdst.p, F->blkinfo.p,
+                         F->err.p);
+      int herr = 0;
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpyAsync(&herr, F->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = fail("ILU schedule kernel failed", __FILE__, __LINE__);
+      else if (herr)  // the factor kernel must not run on a partial schedule
+        rc = fail("ILU triangular-solve stream capacity exceeded", __FILE__, __LINE__);
+    }
+    if (rc == ISPH_SUCCESS) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_factor<kIluWaves>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         rc = fail("LDS attribute failed", __FILE__, __LINE__);
       else
         hipLaunchKernelGGL((k_ilu_factor<kIluWaves>), dim3(F->nblocks), dim3(kIluWaves * 64), lds, ctx->stream, S.nrow,
-                           block_size, W, S.slice_off.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->err.p);
+                           block_size, W, S.slice_off.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->sv.p,
+                           F->dinv.p, F->err.p);
       if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("ILU factor launch failed", __FILE__, __LINE__);
       if (rc == ISPH_SUCCESS) {
         int herr = 0;
         if (hipMemcpyAsync(&herr, F->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)
           rc = fail("ILU factor kernel failed", __FILE__, __LINE__);
+        else if (herr & 16)
+          rc = fail("ILU triangular-solve stream capacity exceeded", __FILE__, __LINE__);
         else if (herr)
           rc = fail("ILU factor: dependency wait timed out", __FILE__, __LINE__);
       }
@@ -306,9 +562,11 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
 inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z) {
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
   if (F->n == 0) return ISPH_SUCCESS;
-  const size_t lds = (size_t)F->B * 24;
-  hipLaunchKernelGGL(k_ilu_solve, dim3(F->nblocks), dim3(F->B), lds, ctx->stream, F->n, F->B, F->S->slice_off.p,
-                     F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, r, z, F->err.p);
+  constexpr int WV = 4;
+  const size_t lds = sizeof(double) * (size_t)F->B * WV;
+  hipLaunchKernelGGL((k_ilu_solve_stream<WV>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, F->n,
+                     F->B, F->nblocks, F->S->slice_off.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p,
+                     F->dinv.p, r, z);
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
