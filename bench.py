@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--force-rccl", action="store_true",
+                    help="1 GPU only: route the periodic images through the RCCL halo path (send/recv to self)")
     return ap.parse_args()
 
 
@@ -102,6 +104,9 @@ def main():
         uid = [hip.Context.unique_id() if rank == 0 else None]
         td.broadcast_object_list(uid, src=0)
         ctx = hip.Context(local_rank, stream=stream, rank=rank, nranks=world, uid=uid[0])
+    elif args.force_rccl:
+        td = None
+        ctx = hip.Context(local_rank, stream=stream, rank=0, nranks=1, uid=hip.Context.unique_id())
     else:
         td = None
         ctx = hip.Context(local_rank, stream=stream)
@@ -113,7 +118,10 @@ def main():
     spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=(8, 8, 8),
                             mode=mode, kernel=args.kernel, cut_over_h=2.0 if args.kernel == "wendland" else 3.0)
     parts = workload.make_tgv(spec)
-    plan = dist.make_plan(parts, td)                      # column map + halo lists (trivial on 1 rank)
+    if args.force_rccl and world == 1:
+        plan = dist.make_self_halo_plan(parts)
+    else:
+        plan = dist.make_plan(parts, td)                  # column map + halo lists (trivial on 1 rank)
     nlocal = parts["nlocal"]
 
     # device-resident particle arrays
@@ -128,7 +136,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     vf = hip.compute_volumes(ctx, dparts, colmap, kernel=args.kernel)
-    vfrac = dist.forward_scalar(plan, vf, td, dev)
+    if world == 1:
+        vfrac = vf[torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)].contiguous()
+    else:
+        vfrac = dist.forward_scalar(plan, vf, td, dev)
     A, b = hip.assemble_poisson(ctx, dparts, colmap, spec.dt, rho, vstar, vfrac=vfrac, ncol=plan.ncol,
                                 kernel=args.kernel, rank0=(rank == 0))
     if plan.npeers:
@@ -175,7 +186,7 @@ def main():
     ctx.set_profile(False)
     xin = torch.randn(plan.ncol, dtype=torch.float64, device=dev)
     yout = torch.empty(nlocal, dtype=torch.float64, device=dev)
-    iso_ms = A.spmv_time(xin, yout, reps=args.spmv_reps) if world == 1 else None
+    iso_ms = A.spmv_time(xin, yout, reps=args.spmv_reps) if (world == 1 and not args.force_rccl) else None
 
     alg_bytes = spmv_algorithmic_bytes(info_m["nrow"], info_m["nnz"])
     avg_ms = spmv_ms / max(spmv_calls, 1)

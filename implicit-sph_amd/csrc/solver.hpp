@@ -16,7 +16,7 @@ namespace isph {
 int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z);  // isph_capi.hip
 
 inline int allreduce_inplace(isph_ctx *ctx, double *d, int count) {
-  if (ctx->nranks > 1) ISPH_CHECK_NCCL(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+  if (ctx->comm) ISPH_CHECK_NCCL(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
   return ISPH_SUCCESS;
 }
 

@@ -34,6 +34,24 @@ class HaloPlan:
         return len(self.peers)
 
 
+def make_self_halo_plan(parts):
+    """Single-rank plan that routes the periodic images through the halo machinery
+    (ghost columns + send/recv to self) instead of folding them onto the owner's
+    column.  Used to exercise the RCCL halo path on one GPU."""
+    me = int(parts["spec"].rank)
+    nlocal, nall = int(parts["nlocal"]), int(parts["nall"])
+    assert np.all(parts["owner_rank"] == me)
+    oidx = parts["owner_index"].astype(np.int64)
+    colmap = np.empty(nall, dtype=np.int32)
+    colmap[:nlocal] = np.arange(nlocal, dtype=np.int32)
+    uidx, inv = np.unique(oidx[nlocal:], return_inverse=True)
+    colmap[nlocal:] = (nlocal + inv).astype(np.int32)
+    plan = HaloPlan(me, 1, nlocal, nlocal + len(uidx), colmap, np.asarray([me], np.int32),
+                    np.asarray([0, len(uidx)], np.int32), uidx.astype(np.int32), np.asarray([0, len(uidx)], np.int32))
+    plan.ghost_col_of = colmap[nlocal:].copy()
+    return plan
+
+
 def make_plan(parts, td=None):
     """parts: output of workload.make_tgv for this rank.  td: torch.distributed
     (initialised) or None for a single rank."""
