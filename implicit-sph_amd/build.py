@@ -60,5 +60,21 @@ def build_hip(force=False):
     return HIP_LIB
 
 
+CPP_TEST = os.path.join(ROOT, "tests", "cpp", "test_solver_lin")
+
+
+def build_cpp_test(force=False):
+    """C++ driver of the SolverLin / PrecondWrapper mirror classes (host/*.h),
+    linked against libisph_hip.so; used by the -m gpu tests."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_solver_lin.cpp")
+    host = os.path.join(PKG, "host")
+    deps = [src] + [os.path.join(host, f) for f in os.listdir(host)] + [os.path.join(INC, "isph_hip.h")]
+    if force or _stale(CPP_TEST, deps):
+        build_hip()
+        _run(["g++", "-O2", "-std=c++17", "-I", INC, "-I", host, "-o", CPP_TEST, src,
+              "-L", PKG, "-lisph_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    return CPP_TEST
+
+
 def build_all(force=False):
-    return build_host(force), build_hip(force)
+    return build_host(force), build_hip(force), build_cpp_test(force)

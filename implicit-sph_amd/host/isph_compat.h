@@ -1,0 +1,161 @@
+// isph_compat.h -- the small slice of the Epetra / Teuchos vocabulary that the
+// SolverLin / PrecondWrapper signatures use (ref: solver_lin.h:23-98,
+// precond.h:17-46), for builds WITHOUT Trilinos.  With -DHAVE_EPETRA the real
+// Trilinos headers are used instead and these types are not defined.
+//
+// These are the product's own host-side value types (non-owning views over the
+// caller's arrays); they carry exactly the members PairISPH and fix_qeq_reax
+// touch on the objects they pass to / get back from the solver.
+#pragma once
+#ifdef HAVE_EPETRA
+#include "Epetra_CrsMatrix.h"
+#include "Epetra_IntSerialDenseVector.h"
+#include "Epetra_Map.h"
+#include "Epetra_MpiComm.h"
+#include "Epetra_MultiVector.h"
+#include "Epetra_Vector.h"
+#include "Teuchos_ParameterList.hpp"
+#include "Teuchos_RCP.hpp"
+#else
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#ifndef ISPH_HAVE_MPI
+typedef int MPI_Comm;  // single-process builds: the communicator is a placeholder
+#endif
+
+namespace Teuchos {
+template <class T>
+using RCP = std::shared_ptr<T>;
+// rcp(p,false): non-owning, like the reference's borrowed pointers (solver_lin.cpp:109-126)
+template <class T>
+RCP<T> rcp(T *p, bool owns = true) {
+  return owns ? RCP<T>(p) : RCP<T>(p, [](T *) {});
+}
+const std::nullptr_t null = nullptr;
+
+// typed key/value list with the get(name, default) idiom of Teuchos::ParameterList
+class ParameterList {
+ public:
+  void set(const std::string &k, int v) { i_[k] = v; }
+  void set(const std::string &k, bool v) { i_[k] = v ? 1 : 0; }
+  void set(const std::string &k, double v) { d_[k] = v; }
+  void set(const std::string &k, const char *v) { s_[k] = v; }
+  void set(const std::string &k, const std::string &v) { s_[k] = v; }
+  int get(const std::string &k, int def) const { auto it = i_.find(k); return it == i_.end() ? def : it->second; }
+  bool get(const std::string &k, bool def) const { auto it = i_.find(k); return it == i_.end() ? def : it->second != 0; }
+  double get(const std::string &k, double def) const {
+    auto it = d_.find(k);
+    if (it != d_.end()) return it->second;
+    auto jt = i_.find(k);
+    return jt == i_.end() ? def : (double)jt->second;
+  }
+  std::string get(const std::string &k, const char *def) const { auto it = s_.find(k); return it == s_.end() ? std::string(def) : it->second; }
+  bool isParameter(const std::string &k) const { return i_.count(k) || d_.count(k) || s_.count(k); }
+ private:
+  std::map<std::string, int> i_;
+  std::map<std::string, double> d_;
+  std::map<std::string, std::string> s_;
+};
+}  // namespace Teuchos
+
+enum Epetra_DataAccess { Copy, View };
+
+class Epetra_MpiComm {
+ public:
+  explicit Epetra_MpiComm(MPI_Comm c = 0) : comm_(c) {}
+  int MyPID() const { return 0; }
+  int NumProc() const { return 1; }
+  MPI_Comm Comm() const { return comm_; }
+ private:
+  MPI_Comm comm_;
+};
+
+class Epetra_IntSerialDenseVector {
+ public:
+  Epetra_IntSerialDenseVector() {}
+  explicit Epetra_IntSerialDenseVector(int n) : own_((size_t)n, 0), p_(own_.data()), n_(n) {}
+  Epetra_IntSerialDenseVector(Epetra_DataAccess a, int *v, int n) : n_(n) {
+    if (a == Copy) { own_.assign(v, v + n); p_ = own_.data(); } else p_ = v;
+  }
+  int Length() const { return n_; }
+  int *Values() { return p_; }
+  const int *Values() const { return p_; }
+  int &operator[](int i) { return p_[i]; }
+ private:
+  std::vector<int> own_;
+  int *p_ = nullptr;
+  int n_ = 0;
+};
+
+// row map: locally owned global ids (atom tags), ref: pair_isph.cpp:1258-1259
+class Epetra_Map {
+ public:
+  Epetra_Map(int nglobal, int nlocal, const int *gids, int index_base, const Epetra_MpiComm &)
+      : nglobal_(nglobal < 0 ? nlocal : nglobal), base_(index_base), gid_(gids, gids + nlocal) {}
+  Epetra_Map(int nglobal, int index_base, const Epetra_MpiComm &) : nglobal_(nglobal), base_(index_base), gid_((size_t)nglobal) {
+    for (int i = 0; i < nglobal; ++i) gid_[(size_t)i] = i + index_base;
+  }
+  int NumMyElements() const { return (int)gid_.size(); }
+  int NumGlobalElements() const { return nglobal_; }
+  int GID(int lid) const { return gid_[(size_t)lid]; }
+ private:
+  int nglobal_, base_;
+  std::vector<int> gid_;
+};
+
+// the filled matrix as Epetra hands it over after FillComplete+OptimizeStorage:
+// contiguous CSR with local column ids (ExtractCrsDataPointers)
+class Epetra_CrsMatrix {
+ public:
+  Epetra_CrsMatrix(int nrow, int ncol, int *rowptr, int *colidx, double *val)
+      : nrow_(nrow), ncol_(ncol), rp_(rowptr), ci_(colidx), v_(val) {}
+  int NumMyRows() const { return nrow_; }
+  int NumMyCols() const { return ncol_; }
+  int NumMyNonzeros() const { return rp_[nrow_]; }
+  bool Filled() const { return true; }
+  int ExtractCrsDataPointers(int *&rowptr, int *&colidx, double *&val) const {
+    rowptr = rp_; colidx = ci_; val = v_;
+    return 0;
+  }
+ private:
+  int nrow_, ncol_;
+  int *rp_, *ci_;
+  double *v_;
+};
+
+// column-major [lda x nvec] view or owned storage (solver_lin.cpp:45-58)
+class Epetra_MultiVector {
+ public:
+  Epetra_MultiVector(const Epetra_Map &map, int nvec) : n_(map.NumMyElements()), lda_(map.NumMyElements()), nvec_(nvec),
+                                                        own_((size_t)n_ * (size_t)nvec, 0.0), p_(own_.data()) {}
+  Epetra_MultiVector(Epetra_DataAccess, const Epetra_Map &map, double *v, int lda, int nvec)
+      : n_(map.NumMyElements()), lda_(lda), nvec_(nvec), p_(v) {}
+  double *Values() { return p_; }
+  const double *Values() const { return p_; }
+  int NumVectors() const { return nvec_; }
+  int MyLength() const { return n_; }
+  int Stride() const { return lda_; }
+  void PutScalar(double a) { for (int c = 0; c < nvec_; ++c) for (int i = 0; i < n_; ++i) p_[(size_t)c * lda_ + i] = a; }
+  // *b = *x  (pair_isph.cpp:940-946)
+  Epetra_MultiVector &operator=(const Epetra_MultiVector &o) {
+    for (int c = 0; c < nvec_ && c < o.nvec_; ++c)
+      std::memcpy(p_ + (size_t)c * lda_, o.p_ + (size_t)c * o.lda_, sizeof(double) * (size_t)(n_ < o.n_ ? n_ : o.n_));
+    return *this;
+  }
+ protected:
+  int n_, lda_, nvec_;
+  std::vector<double> own_;
+  double *p_;
+};
+
+class Epetra_Vector : public Epetra_MultiVector {
+ public:
+  explicit Epetra_Vector(const Epetra_Map &map, bool = true) : Epetra_MultiVector(map, 1) {}
+};
+
+class Epetra_Operator;  // only ever passed around as an opaque pointer here
+#endif  // HAVE_EPETRA

@@ -1,0 +1,46 @@
+// precond.h -- PrecondWrapper: header-compatible with the reference
+// (ref: precond.h:17-46) so PairISPH::initializeSolvers compiles unchanged,
+// forwarding to libisph_hip through the C ABI (include/isph_hip.h).
+#pragma once
+#include <stdexcept>
+
+#include "isph_compat.h"
+#include "isph_hip.h"
+
+namespace LAMMPS_NS {
+
+class SolverLin_HIP;
+
+class PrecondWrapper {
+ protected:
+  Epetra_MpiComm _comm;
+  Teuchos::RCP<Teuchos::ParameterList> _param;
+  Teuchos::RCP<Epetra_CrsMatrix> _A;
+  // device side (owned): created by create(), released by free()
+  isph_prec *_M = nullptr;
+  friend class SolverLin_HIP;
+  // hook used by SolverLin_HIP: build the device preconditioner for matrix A
+  virtual int createOnDevice(isph_ctx *, const isph_mat *) { return ISPH_SUCCESS; }
+
+ public:
+  PrecondWrapper(MPI_Comm comm) : _comm(comm) {}
+  virtual ~PrecondWrapper() { free(); }
+
+  virtual void setMatrix(Epetra_CrsMatrix *A) {
+    if (A != NULL) _A = Teuchos::rcp(A, false);
+  }
+  virtual Teuchos::ParameterList *setParameters(Teuchos::ParameterList *param = NULL) { return _param.get(); }
+  virtual void setNullVector(double *) { return; }  // base no-op, ref: precond.h:40
+  // The reference builds the Ifpack/ML object here; the device object needs the
+  // device matrix, which SolverLin_HIP owns, so create() only records the request
+  // and the build happens inside solveProblem (same place in the timeline:
+  // solver_lin_belos.h:147-156), via createOnDevice().
+  virtual void create() { return; }
+  virtual void create(const int) { return; }
+  virtual void free() {
+    if (_M) { isph_prec_destroy(_M); _M = nullptr; }
+  }
+  virtual Epetra_Operator *getPrecondOperator() { return NULL; }
+};
+
+}  // namespace LAMMPS_NS

@@ -1,0 +1,68 @@
+// Drives the C++ mirror exactly like the reference's second consumer does
+// (ref: USER-REAXC-T/fix_qeq_reax.cpp:671-693): SolverLin_Belos li_solver(world);
+// setParameters(); setNodalMap; setMatrix; prec.setMatrix; create*MultiVector;
+// solveProblem(&prec, "...").  Reads a CSR system from a binary file, writes x.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "precond_ifpack.h"
+#include "solver_lin_hip.h"
+
+using namespace LAMMPS_NS;
+
+int main(int argc, char **argv) {
+  if (argc < 4) { std::fprintf(stderr, "usage: %s in.bin out.bin singular(0/1) [cg]\n", argv[0]); return 2; }
+  FILE *f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  int n = 0, nnz = 0;
+  if (std::fread(&n, 4, 1, f) != 1 || std::fread(&nnz, 4, 1, f) != 1) return 2;
+  std::vector<int> rp((size_t)n + 1), ci((size_t)nnz), gid((size_t)n);
+  std::vector<double> val((size_t)nnz), b((size_t)n), x((size_t)n, 0.0);
+  if (std::fread(rp.data(), 4, rp.size(), f) != rp.size() || std::fread(ci.data(), 4, ci.size(), f) != ci.size() ||
+      std::fread(val.data(), 8, val.size(), f) != val.size() || std::fread(b.data(), 8, b.size(), f) != b.size()) return 2;
+  std::fclose(f);
+  for (int i = 0; i < n; ++i) gid[(size_t)i] = i + 1;
+  const bool singular = std::atoi(argv[3]) != 0;
+
+  MPI_Comm world = 0;
+  Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
+  Epetra_CrsMatrix AA(n, n, rp.data(), ci.data(), val.data());
+
+  PrecondWrapper_Ifpack prec(world);
+  Teuchos::ParameterList *pp = prec.setParameters();
+  pp->set("fact: level-of-fill", 0);
+  pp->set("Overlap Level", 0);
+  pp->set("isph: block rows", 256);
+
+  SolverLin_Belos li_solver(world);
+  li_solver.setParameters();
+  Teuchos::ParameterList cgp;
+  if (argc > 4) {  // USER-REAXC-T defaults: Block CG (USER-REAXC-T/solver_lin_belos.h:236-245)
+    cgp.set("Solver Type", "Block CG");
+    cgp.set("Convergence Tolerance", 1.0e-8);
+    cgp.set("Maximum Iterations", 500);
+    li_solver.setParameters(&cgp);
+  }
+  li_solver.setNodalMap(&nodalmap);
+  li_solver.setMatrix(&AA);
+  prec.setMatrix(&AA);
+  li_solver.createSolutionMultiVector(x.data(), n, 1);
+  li_solver.createLoadMultiVector(b.data(), n, 1);
+  Epetra_IntSerialDenseVector null_mask(n);
+  if (singular) {
+    for (int i = 0; i < n; ++i) null_mask[i] = 1;
+    li_solver.setNullVectorMask(&null_mask);
+    li_solver.setMatrixIsSingular(true);
+  }
+  li_solver.setInitialSolution(SolverLin::Zero);
+  const int rc = li_solver.solveProblem(&prec, "test_solver_lin");
+  if (rc != LAMMPS_SUCCESS) return 1;
+  const isph_solve_info &info = li_solver.lastSolveInfo();
+  std::printf("converged=%d iters=%d rel=%.3e\n", info.converged, info.iters, info.rel_res_implicit);
+  f = std::fopen(argv[2], "wb");
+  std::fwrite(x.data(), 8, x.size(), f);
+  std::fwrite(b.data(), 8, b.size(), f);
+  std::fclose(f);
+  return info.converged ? 0 : 3;
+}

@@ -284,3 +284,38 @@ def test_rccl_self_halo_spmv_and_solve(gpu_ctx):
         assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------- C++ mirror of the reference interface
+@pytest.mark.parametrize("singular,cg", [(1, False), (0, True)])
+def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
+    """SolverLin_Belos / PrecondWrapper_Ifpack (implicit-sph_amd/host/*.h) driven
+    exactly like USER-REAXC-T/fix_qeq_reax.cpp:671-693 drives the reference."""
+    import subprocess
+    from isph_amd import build
+    exe = build.build_cpp_test()
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER if singular else workload.LATTICE),
+                 singular=orc.NULLSPACE if singular else orc.NOT_SINGULAR)
+    rp, ci, val, b = pr.poisson()
+    if not singular:                       # SPD system for the CG path: lattice matrix + I
+        val = val.copy()
+        for i in range(pr.n):
+            val[rp[i]:rp[i + 1]][ci[rp[i]:rp[i + 1]] == i] += 1.0
+        b = np.cos(pr.parts["x"][:pr.n, 0]) + 0.3
+    fin, fout = tmp_path / "sys.bin", tmp_path / "x.bin"
+    with open(fin, "wb") as f:
+        np.array([pr.n, len(val)], np.int32).tofile(f)
+        rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
+        val.tofile(f); b.tofile(f)
+    r = subprocess.run([exe, str(fin), str(fout), str(singular)] + (["cg"] if cg else []),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ">> Belos::Status - Passed!" in r.stdout
+    out = np.fromfile(fout)
+    x, bproj = out[:pr.n], out[pr.n:]
+    bp = np.arange(0, pr.n + 256, 256).clip(0, pr.n).astype(np.int32)
+    prm = orc.SolverParams(solver_type=1, tol=1e-8) if cg else orc.SolverParams()
+    xo, io, bo = orc.solve(rp, ci, val, b, singular=bool(singular), prec="ilu",
+                           ilu=orc.ILU(rp, ci, val, 0, bp), params=prm)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    assert np.allclose(bproj, bo, rtol=0, atol=1e-13 * np.abs(bo).max())   # b view updated in place
