@@ -153,10 +153,14 @@ def main():
     prm = hip.SolverParams()
     ctx.set_profile(True)
 
+    pinfo = {}
+
     def step():
         bwork.copy_(b)
         x.zero_()
         M = hip.Precond(ctx, A, args.prec, args.block)
+        if not pinfo and args.prec == "bjacobi-ilu0":
+            pinfo.update(M.info())
         inf = hip.solve(ctx, A, bwork, x, prec=M, singular=True, params=prm)
         M.close()
         return inf
@@ -189,6 +193,14 @@ def main():
     iso_ms = A.spmv_time(xin, yout, reps=args.spmv_reps) if (world == 1 and not args.force_rccl) else None
 
     alg_bytes = spmv_algorithmic_bytes(info_m["nrow"], info_m["nnz"])
+    # HBM traffic of the SpMV kernel from the PMC passes committed under profiles/ (rocprofv3
+    # cannot run inside this process); only quoted when it was taken on this very matrix.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_spmv_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("nrow") == info_m["nrow"] and tj.get("nnz") == info_m["nnz"]:
+            traffic = tj["traffic_bytes_per_launch"]
     avg_ms = spmv_ms / max(spmv_calls, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
 
@@ -209,9 +221,10 @@ def main():
                        "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms,
-                       "spmv_isolated_ms": iso_ms},
+                       "spmv_isolated_ms": iso_ms, "ilu": pinfo},
             "roofline": {"bound": "hbm", "kernel": "k_sell_spmv", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_spmv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": spmv_calls},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -375,6 +375,20 @@ int isph_prec_export_ilu(isph_ctx *ctx, const isph_prec *M, int *rowptr, int *co
   return ilu_export(ctx, M->ilu, rowptr, colidx, val);
 }
 
+int isph_prec_info(isph_ctx *ctx, const isph_prec *M, long long info[4]) {
+  ISPH_REQUIRE(ctx && M && info, "NULL argument");
+  info[0] = info[1] = info[2] = info[3] = 0;
+  if (M->type != 2 || !M->ilu) return ISPH_SUCCESS;
+  const isph_ilu *F = M->ilu;
+  std::vector<int> bi((size_t)2 * F->nblocks);
+  ISPH_CHECK_HIP(hipMemcpyAsync(bi.data(), F->blkinfo.p, sizeof(int) * bi.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  long long used = 0;
+  for (int v : bi) used += v;
+  info[0] = ilu_nnz(F); info[1] = used; info[2] = F->stream_chunks; info[3] = F->nblocks;
+  return ISPH_SUCCESS;
+}
+
 long long isph_prec_nnz(const isph_prec *M) { return (M && M->type == 2 && M->ilu) ? ilu_nnz(M->ilu) : 0; }
 
 void isph_prec_destroy(isph_prec *M) {

@@ -19,7 +19,7 @@ EXPORTS = [
     "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
-    "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
+    "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_assemble_poisson", "isph_compute_volumes",
 ]
 
@@ -87,6 +87,7 @@ def lib():
         L.isph_prec_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_prec_export_ilu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_prec_destroy.argtypes = [C.c_void_p]
+        L.isph_prec_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_assemble_poisson.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
@@ -251,6 +252,11 @@ class Precond:
                 z = np.zeros(self.n)
         _check(lib().isph_prec_apply(self.ctx.h, self.h, _ptr(r), _ptr(z), _on_device(r, z)))
         return z
+
+    def info(self):
+        a = (C.c_longlong * 4)()
+        _check(lib().isph_prec_info(self.ctx.h, self.h, a))
+        return dict(factor_nnz=a[0], stream_chunks=a[1], stream_capacity=a[2], nblocks=a[3])
 
     def export_ilu(self):
         nnz = lib().isph_prec_nnz(self.h)

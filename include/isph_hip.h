@@ -101,6 +101,9 @@ int isph_prec_apply(isph_ctx *ctx, const isph_prec *M, const double *r /*[h|d]*/
  * in-block pattern, columns sorted) for parity tests. */
 int isph_prec_export_ilu(isph_ctx *ctx, const isph_prec *M, int *rowptr, int *colidx, double *val);
 long long isph_prec_nnz(const isph_prec *M);
+/* sizes: [0]=factor entries [1]=triangular-solve stream chunks in use (64 entries each)
+ *        [2]=stream capacity in chunks [3]=number of blocks */
+int isph_prec_info(isph_ctx *ctx, const isph_prec *M, long long info[4]);
 void isph_prec_destroy(isph_prec *M);
 
 /* ---- solve ------------------------------------------------------------ */
