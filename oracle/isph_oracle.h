@@ -10,15 +10,22 @@
  * /root/reference/IMPLICIT-SPH/) whose algorithm it restates.
  *
  * PARITY PINNING STATUS
- *   - assembly half: restated from the reference functors; pinned by the
- *     reference's own end-to-end known answers (2-D TGV convergence table,
- *     sph-script/conv-taylor-green-vortex-2d-rev390.txt) through
- *     oracle/tgv_driver.py, plus analytic invariants (tests/test_oracle_*).
+ *   - assembly half: restated from the reference functors.  Pinned by (1) the
+ *     one output of the reference's own functor recorded in SURVEY.md
+ *     Appendix A (8x8 lattice row: diag 3.6692e-02, 25 nnz, row sum ~1e-18;
+ *     reproduced to all printed digits) and (2) analytic invariants
+ *     (tests/test_oracle.py).  The reference's end-to-end 2-D TGV table
+ *     (sph-script/conv-taylor-green-vortex-2d-rev390.txt) is reproduced through
+ *     oracle/tgv_driver.py only loosely (norms to 4e-4, pressure error within
+ *     20 %): that table comes from an older revision whose scheme details are
+ *     not recorded.
  *   - solve half: the arithmetic lives in Trilinos (Belos/Ifpack/Epetra,
  *     un-vendored, no pinned version: README:9-11).  The reference holds no
  *     numeric vectors at that boundary, so the Krylov/ILU restatement follows
  *     the published Belos/Ifpack algorithm definitions and is cross-checked
- *     against SciPy only: solver parity is otherwise UNPINNED.
+ *     against SciPy only: solver parity is UNPINNED.
+ *   - the reference itself cannot be built here (needs Trilinos + LAMMPS
+ *     headers): there is no oracle/_ref.
  */
 #ifndef ISPH_ORACLE_H
 #define ISPH_ORACLE_H

@@ -187,3 +187,20 @@ def test_cg_on_symmetric_lattice_system():
     A = sps.csr_matrix((val, ci, rp))
     r = bp - A @ xs
     assert np.linalg.norm(r - r.mean()) / np.linalg.norm(bp) < 1e-5
+
+
+def test_tgv2d_known_answer_table_loose():
+    """End-to-end known answer of the reference itself
+    (sph-script/conv-taylor-green-vortex-2d-rev390.txt, Wendland, NullSpace, no shift,
+    N=16, step 3, t=1.767146): the oracle's assembly+solve chained through the
+    pressure-correction scheme (oracle/tgv_driver.py) lands on the table's norms to
+    4e-4 and on its pressure error to within 20 %.  The revision that produced the
+    table (rev390) is not the one in /root/reference (>= rev423) and its theta /
+    fix order are not recorded, so this is a smoke-level pin, not a digit-for-digit one."""
+    import tgv_driver as T
+    ref = T.TABLE_REV390_WENDLAND[16]
+    h = T.run_tgv2d(16, ref["step"], antisym=True)[-1]
+    assert abs(h["time"] - ref["time"]) < 1e-6
+    assert abs(h["p_norm"] / ref["p_norm"] - 1) < 1e-3 and abs(h["u_norm"] / ref["u_norm"] - 1) < 1e-3
+    assert 0.8 < h["p_err"] / ref["p_err"] < 1.25
+    assert 0.1 < h["u_err"] / ref["u_err"] < 3.0
