@@ -304,6 +304,171 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   b[i] = bi;
 }
 
+
+// ---------------------------------------------------------------------------
+// Helmholtz rows (ref: functor_incomp_navier_stokes_helmholtz.h:52-159):
+//   A = diag(1/rho) Laplacian(dt, mu = nu rho), filter (Fluid, All)
+//   w = (1-theta) A v ;  A <- -theta A ;  diag = 1 + A_ii (fluid) | 1 (solid)
+//   b_ik = v_ik + w_ik + dt (f_ik/rho_i + g_k) - dt/rho_i (grad p)_k
+// One lane per row like k_asm_poisson; w is accumulated while the row is built
+// (the reference forms it with Epetra's Multiply on the assembled matrix).
+struct HelmholtzArgs {
+  int nlocal, antisym, incremental, lda;
+  double dt, theta, g[3];
+  const double *x, *vfrac, *Gc, *Lc, *rho, *nu, *p, *f, *v;
+  const int *type, *nptr, *nidx, *colmap;
+};
+
+__global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, HelmholtzArgs a,
+                                                          const long long *__restrict__ slice_off,
+                                                          int *__restrict__ scol, double *__restrict__ sval,
+                                                          double *__restrict__ b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  if (i >= a.nlocal) {
+    const int nslices = (a.nlocal + kSlice - 1) / kSlice;
+    const int slice = i >> 6;
+    if (slice < nslices) {
+      const long long off = slice_off[slice];
+      const int w = (int)((slice_off[slice + 1] - off) >> 6);
+      for (int k = 0; k < w; ++k) { const long long p = sell_pos(off, lane, k); scol[p] = 0; sval[p] = 0.0; }
+    }
+    return;
+  }
+  const int dim = T.dim, nt1 = T.ntypes + 1, dL = dim * (dim + 1) / 2;
+  const int it = a.type[i], ikind = T.kind[it];
+  const long long off = slice_off[i >> 6];
+  const int w = (int)((slice_off[(i >> 6) + 1] - off) >> 6);
+  const int filt_i = KIND_FLUID, filt_j = KIND_ALL;
+  const double alpha = a.dt;
+  const double invrho = 1.0 / a.rho[i];
+  const double mi = a.nu[i] * a.rho[i];
+  const int jb = a.nptr[i], je = a.nptr[i + 1];
+  int cnt = 0;
+  double diag_final;
+  double wv[3] = {0, 0, 0}, gp[3] = {0, 0, 0};
+
+  if (!(ikind & filt_i)) {
+    for (int jj = jb; jj < je; ++jj) {
+      const int j = a.nidx[jj];
+      double rij[3];
+      if (pair_rsq(dim, a.x, i, j, rij) < T.cutsq[it * nt1 + a.type[j]]) {
+        const long long p = sell_pos(off, lane, cnt++);
+        scol[p] = a.colmap[j];
+        sval[p] = 0.0;
+      }
+    }
+    diag_final = 1.0;  // solid rows: unit diagonal, b unchanged (:114-117)
+  } else {
+    double G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, L[6] = {1, 0, 1, 0, 0, 1};
+    if (dim == 2) { G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 1; L[0] = 1; L[1] = 0; L[2] = 1; }
+    if (!a.antisym) {
+      for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
+      for (int k = 0; k < dL; ++k) L[k] = a.Lc[(size_t)i * dL + k];
+    }
+    const double vi = a.vfrac[i];
+    double grad_m[3] = {0, 0, 0}, ci[3] = {0, 0, 0};
+    double diag1 = 0.0;
+    for (int jj = jb; jj < je; ++jj) {  // sweep 1
+      const int j = a.nidx[jj];
+      const int jt = a.type[j], jkind = T.kind[jt];
+      double rij[3];
+      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
+      const double mj = a.nu[j] * a.rho[j];
+      double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
+      if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
+      const double r = sqrt(rsq) + kEps;
+      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      double e[3] = {0, 0, 0};
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
+      const double vjtmp = dwdr * vfrac;
+      for (int k2 = 0; k2 < dim; ++k2) {
+        double gitmp = 0.0;
+        for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * e[k1];
+        if (ikind & jkind) grad_m[k2] += gitmp * vjtmp * (a.antisym ? (mi + mj) : (mj - mi));
+      }
+      double aij = 0.0;
+      for (int k2 = 0, op = 0; k2 < dim; ++k2)
+        for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      aij *= 2.0 * dwdr * vfrac;
+      if (!a.antisym)
+        for (int k = 0; k < dim; ++k) ci[k] += aij * e[k];
+      aij *= mi * coeff / r;
+      diag1 += aij;
+      // gradient of p, filter (Fluid, Fluid) (functor_gradient.h:120-150)
+      if (a.incremental && (ikind & KIND_FLUID) && (jkind & KIND_FLUID)) {
+        const double vd = dwdr / r * vfrac;
+        for (int k2 = 0; k2 < dim; ++k2) {
+          double gitmp = 0.0;
+          for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
+          gp[k2] += gitmp * vd * (a.antisym ? (a.p[i] + a.p[j]) : (a.p[j] - a.p[i]));
+        }
+      }
+    }
+    double diag2 = 0.0;
+    for (int jj = jb; jj < je; ++jj) {  // sweep 2
+      const int j = a.nidx[jj];
+      const int jt = a.type[j], jkind = T.kind[jt];
+      double rij[3];
+      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
+      double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
+      if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
+      const double r = sqrt(rsq) + kEps;
+      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      double e[3] = {0, 0, 0};
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
+      const double vjtmp = dwdr * vfrac;
+      double aij = 0.0;
+      for (int k2 = 0, op = 0; k2 < dim; ++k2)
+        for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      aij *= 2.0 * dwdr * vfrac;
+      aij *= mi * coeff / r;
+      double bc = 0.0, bg = 0.0;
+      for (int k2 = 0; k2 < dim; ++k2) {
+        double bij = 0.0;
+        for (int k1 = 0; k1 < dim; ++k1) bij += G[k2 * dim + k1] * e[k1];
+        bc += bij * ci[k2];
+        bg += bij * grad_m[k2];
+      }
+      const double tmp = coeff * (mi * bc * vjtmp - bg * vjtmp);
+      double v = -aij;
+      v -= tmp;
+      diag2 += tmp;
+      const double aval = (v * alpha) * invrho;  // SumInto(alpha) then LeftScale(1/rho)
+      for (int k = 0; k < dim; ++k) wv[k] += aval * a.v[3 * (size_t)j + k];
+      const long long p = sell_pos(off, lane, cnt++);
+      scol[p] = a.colmap[j];
+      sval[p] = aval * (-a.theta);
+    }
+    const double dval = ((diag1 + diag2) * alpha) * invrho;
+    for (int k = 0; k < dim; ++k) wv[k] += dval * a.v[3 * (size_t)i + k];
+    diag_final = 1.0 + dval * (-a.theta);
+  }
+  {
+    const long long p = sell_pos(off, lane, cnt++);
+    scol[p] = a.colmap[i];
+    sval[p] = diag_final;
+  }
+  for (int k = cnt; k < w; ++k) {
+    const long long p = sell_pos(off, lane, k);
+    scol[p] = a.colmap[i];
+    sval[p] = 0.0;
+  }
+  for (int k = 0; k < dim; ++k) {
+    double bk = a.v[3 * (size_t)i + k];
+    if (ikind & filt_i) {
+      bk += wv[k] * (1.0 - a.theta);
+      bk += a.dt * (a.f[3 * (size_t)i + k] / a.rho[i] + a.g[k]);
+      if (a.incremental) bk += a.dt * (-1.0 / a.rho[i] * gp[k]);
+    }
+    b[(size_t)k * a.lda + i] = bk;
+  }
+}
+
 // merge duplicate columns inside a row (periodic images sharing a tag in a
 // box narrower than 2*cut; what FillComplete + SumIntoGlobalValues do):
 // later duplicates are added into the first occurrence and turned into
@@ -508,6 +673,105 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     }
   }
   S.release();
+  bdev.release();
+  newlen.release();
+  if (rc != ISPH_SUCCESS) { A->S.release(); delete A; return rc; }
+  *A_out = A;
+  return ISPH_SUCCESS;
+}
+
+inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                              const double *nu, const double *rho, const double *pres, const double *force,
+                              const double *gvec, int incremental, const double *vel, int ncol, isph_mat **A_out,
+                              double *b_out, int lda, int on_device) {
+  ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
+  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx && P->colmap, "particle arrays missing");
+  ISPH_REQUIRE(antisym || (P->Gc && P->Lc), "Symmetric family needs Gc and Lc");
+  ISPH_REQUIRE(P->vfrac, "vfrac is required (isph_compute_volumes + forward comm first)");
+  ISPH_REQUIRE(ncol >= P->nlocal && lda >= P->nlocal, "need ncol >= nlocal and lda >= nlocal");
+  const int n = P->nlocal, dim = P->dim, dL = dim * (dim + 1) / 2;
+  StagedParticles S;
+  DevBuf<double> snu, sp, sf, sv;
+  AsmTables T;
+  HelmholtzArgs a;
+  memset(&a, 0, sizeof(a));
+  isph_mat *A = new isph_mat();
+  DevBuf<double> bdev;
+  DevBuf<int> newlen;
+  int rc = stage_tables(ctx, P, S, T);
+  long long nnb = 0;
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->x, (size_t)P->nall * 3, on_device, S.x, &a.x);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->type, (size_t)P->nall, on_device, S.type, &a.type);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->colmap, (size_t)P->nall, on_device, S.colmap, &a.colmap);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->vfrac, (size_t)P->nall, on_device, S.vfrac, &a.vfrac);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, S.Gc, &a.Gc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nall * dL, on_device, S.Lc, &a.Lc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, rho, (size_t)P->nall, on_device, S.rho, &a.rho);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, nu, (size_t)P->nall, on_device, snu, &a.nu);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, pres, (size_t)P->nall, on_device, sp, &a.p);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, force, (size_t)P->nall * 3, on_device, sf, &a.f);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, vel, (size_t)P->nall * 3, on_device, sv, &a.v);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &a.nptr);
+  if (rc == ISPH_SUCCESS) {
+    if (on_device) {
+      int last = 0;
+      if (hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("neigh_ptr read failed", __FILE__, __LINE__);
+      nnb = last;
+    } else {
+      nnb = P->neigh_ptr[n];
+      for (long long k = 0; k < nnb && rc == ISPH_SUCCESS; ++k)
+        if (P->neigh_idx[k] < 0 || P->neigh_idx[k] >= P->nall) rc = fail("neighbour index out of range", __FILE__, __LINE__);
+      for (int j = 0; j < P->nall && rc == ISPH_SUCCESS; ++j)
+        if (P->colmap[j] < 0 || P->colmap[j] >= ncol) rc = fail("colmap entry out of range", __FILE__, __LINE__);
+    }
+  }
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
+  if (rc == ISPH_SUCCESS)
+    for (int t = 1; t <= P->ntypes; ++t)
+      if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);
+  Sell &M = A->S;
+  M.nrow = n; M.ncol = ncol; M.nslices = (n + kSlice - 1) / kSlice;
+  if (rc == ISPH_SUCCESS) rc = M.rowlen.reserve((size_t)(n > 0 ? n : 1));
+  if (rc == ISPH_SUCCESS) rc = M.slice_off.reserve((size_t)M.nslices + 1);
+  double *db = b_out;
+  if (rc == ISPH_SUCCESS && !on_device) { rc = bdev.reserve((size_t)lda * dim); db = bdev.p; }
+  if (rc == ISPH_SUCCESS && n > 0) {
+    const int grid = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_asm_count, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
+    hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
+    rc = sell_finalize_offsets(ctx, M);
+    if (rc == ISPH_SUCCESS) {
+      a.nlocal = n; a.antisym = antisym; a.incremental = incremental; a.lda = lda; a.dt = dt; a.theta = theta;
+      for (int k = 0; k < 3; ++k) a.g[k] = gvec ? gvec[k] : 0.0;
+      const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
+      hipLaunchKernelGGL(k_asm_helmholtz, dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+      if (n <= 32768) {
+        rc = newlen.reserve((size_t)n);
+        if (rc == ISPH_SUCCESS) {
+          hipLaunchKernelGGL(k_sell_merge_duplicates, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p,
+                             M.col.p, M.val.p, newlen.p);
+          if (hipMemcpyAsync(M.rowlen.p, newlen.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            rc = fail("copy failed", __FILE__, __LINE__);
+        }
+      }
+      if (rc == ISPH_SUCCESS) rc = sell_sort_rows(ctx, M);
+      if (rc == ISPH_SUCCESS && !on_device &&
+          hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)lda * dim, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = fail("copy failed", __FILE__, __LINE__);
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+        rc = fail("assembly kernel failed", __FILE__, __LINE__);
+    }
+    if (rc == ISPH_SUCCESS) {
+      std::vector<int> len((size_t)n);
+      if (hipMemcpy(len.data(), M.rowlen.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail("copy failed", __FILE__, __LINE__);
+      long long tot = 0;
+      for (int v : len) tot += v;
+      M.nnz = tot;
+    }
+  }
+  S.release(); snu.release(); sp.release(); sf.release(); sv.release();
   bdev.release();
   newlen.release();
   if (rc != ISPH_SUCCESS) { A->S.release(); delete A; return rc; }

@@ -513,6 +513,15 @@ int isph_assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym, d
   return assemble_poisson(ctx, P, antisym, dt, rho, vstar, singular_mode, is_rank0, ncol, A_out, b_out, on_device);
 }
 
+int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                            const double *nu, const double *rho, const double *pres, const double *force,
+                            const double *g, int incremental_pressure, const double *v, int ncol, isph_mat **A_out,
+                            double *b_out, int lda, int on_device) {
+  ISPH_REQUIRE(ctx && P && nu && rho && pres && force && v && A_out && b_out, "NULL argument");
+  return assemble_helmholtz(ctx, P, antisym, dt, theta, nu, rho, pres, force, g, incremental_pressure, v, ncol, A_out,
+                            b_out, lda, on_device);
+}
+
 int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device) {
   ISPH_REQUIRE(ctx && P && vfrac_out, "NULL argument");
   return compute_volumes(ctx, P, vfrac_out, on_device);

@@ -20,7 +20,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_compute_volumes",
+    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes",
 ]
 
 
@@ -93,6 +93,9 @@ def lib():
         L.isph_assemble_poisson.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_compute_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_assemble_helmholtz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -325,6 +328,27 @@ def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=
     _check(lib().isph_assemble_poisson(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(rho), _ptr(vstar),
                                        singular, int(rank0), nlocal if ncol is None else ncol, C.byref(A.h),
                                        _ptr(b_out), dev))
+    return A, b_out
+
+
+def assemble_helmholtz(ctx, parts, colmap, dt, theta, nu, rho, pres, force, g, vel, antisym=True, incremental=True,
+                       ncol=None, vfrac=None, Gc=None, Lc=None, kernel="wendland"):
+    """isph_assemble_helmholtz == PairISPH_Corrected::computeHelmholtz.  Returns (Matrix, b) with b
+    column-major [nlocal x dim] flattened (component k at b[k*nlocal:(k+1)*nlocal])."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, Lc=Lc, keep=keep)
+    nu, rho, pres, force, vel = map(_f64, (nu, rho, pres, force, vel))
+    gv = np.ascontiguousarray(g, dtype=np.float64)
+    nlocal, dim = int(parts["nlocal"]), int(parts["dim"])
+    if dev:
+        import torch
+        b_out = torch.zeros(nlocal * dim, dtype=torch.float64, device=rho.device)
+    else:
+        b_out = np.zeros(nlocal * dim)
+    A = Matrix(ctx)
+    _check(lib().isph_assemble_helmholtz(ctx.h, C.byref(pv), int(antisym), float(dt), float(theta), _ptr(nu), _ptr(rho),
+                                         _ptr(pres), _ptr(force), _ptr(gv), int(incremental), _ptr(vel),
+                                         nlocal if ncol is None else ncol, C.byref(A.h), _ptr(b_out), nlocal, dev))
     return A, b_out
 
 

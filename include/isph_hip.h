@@ -179,6 +179,17 @@ int isph_assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym, d
                           const double *rho /*[nall]*/, const double *vstar /*[nall][3]*/,
                           int singular_mode, int is_rank0, int ncol,
                           isph_mat **A_out, double *b_out /*[h|d]*/, int on_device);
+/* Replaces PairISPH_Corrected::computeHelmholtz -> FunctorOuterIncompNavierStokesHelmholtz
+ * (ref: pair_isph_corrected.cpp:868-925, functor_incomp_navier_stokes_helmholtz.h:52-159) for the
+ * NoBoundaryCond/HomogeneousNeumann family: A = I - theta dt (1/rho) div(nu rho grad .),
+ * b = v + (1-theta) dt (1/rho) div(nu rho grad v) + dt (f/rho + g) - dt/rho grad p.
+ * v, force: [nall][3] (atom->v, atom->f, ghosts included); nu, rho, pres: [nall];
+ * g: 3 doubles (host).  b_out: column-major [lda x dim] like the reference's
+ * b multivector (pair_isph.cpp:936-946); the result feeds isph_solve(nvec=dim). */
+int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                            const double *nu, const double *rho, const double *pres, const double *force,
+                            const double *g, int incremental_pressure, const double *v, int ncol,
+                            isph_mat **A_out, double *b_out /*[h|d]*/, int lda, int on_device);
 /* FunctorOuterVolume (ref: functor_volume.h:40-80); vfrac_out [nlocal]. */
 int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device);
 

@@ -702,6 +702,63 @@ int orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
 }
 
 /* ===================================================================== *
+ *  Helmholtz system builder
+ * ===================================================================== */
+
+/* ref: functor_incomp_navier_stokes_helmholtz.h:52-159.
+ *   A = Laplacian(dt, mu = nu rho), filter (Fluid, All)      (:64-79)
+ *   A <- diag(1/rho) A                                       (:81-85)
+ *   w = (1-theta) A v                                        (:87-94)
+ *   A <- -theta A ; diag_i = 1 + A_ii (fluid) | 1 (solid)    (:96-98,:114-121)
+ *   b_i = v_i + w_i + dt (f_i/rho_i + g) - dt/rho_i grad p_i (:124-135)
+ * vall [nall][3] are the velocities (ghosts included; the reference reads the
+ * ghost values through Epetra's import of b).  b is column-major [lda x dim]
+ * and holds v^n of the owned particles on entry. */
+int orc_helmholtz(const orc_particles *P, int antisym, double dt, double theta,
+                  const double *nu, const double *rho, const double *p,
+                  const double *f, const double *g, int incremental_pressure,
+                  const double *vall, const int *rowptr, const int *colidx,
+                  double *val, double *b, int lda, double *work) {
+  const int n = P->nlocal, dim = P->dim;
+  memset(val, 0, sizeof(double) * (size_t)rowptr[n]);
+  for (int i = 0; i < P->nall; ++i) work[i] = nu[i] * rho[i];
+  if (orc_laplacian_matrix(P, antisym, dt, work, ORC_KIND_FLUID, ORC_KIND_ALL, 0, rowptr, colidx, val)) return -1;
+  int ncol = 0;
+  for (int j = 0; j < P->nall; ++j) if (P->colmap[j] + 1 > ncol) ncol = P->colmap[j] + 1;
+  double *vext = (double *)calloc((size_t)ncol * 3, sizeof(double));
+  for (int j = 0; j < P->nall; ++j)
+    for (int k = 0; k < 3; ++k) vext[(size_t)P->colmap[j] * 3 + k] = vall[(size_t)j * 3 + k];
+  double *grad = (double *)calloc((size_t)n * 3, sizeof(double));
+  if (incremental_pressure) orc_gradient(P, antisym, p, 1.0, 1, ORC_KIND_FLUID, ORC_KIND_FLUID, grad);
+  for (int i = 0; i < n; ++i) {
+    const int ikind = kind_of(P, i);
+    const double invrho = 1.0 / rho[i];
+    double w[3] = {0, 0, 0};
+    int pd = -1;
+    for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+      val[q] *= invrho;                                   /* LeftScale */
+      for (int k = 0; k < dim; ++k) w[k] += val[q] * vext[(size_t)colidx[q] * 3 + k];
+      val[q] *= -theta;                                   /* Scale(-theta) */
+      if (colidx[q] == P->colmap[i]) pd = q;
+    }
+    if (pd < 0) { free(vext); free(grad); return -1; }
+    if (ikind == ORC_KIND_SOLID) {
+      val[pd] = 1.0;
+    } else {
+      val[pd] = 1.0 + val[pd];
+      for (int k = 0; k < dim; ++k) {
+        double *bk = &b[(size_t)k * lda + i];
+        *bk += w[k] * (1.0 - theta);
+        *bk += dt * (f[(size_t)i * 3 + k] / rho[i] + g[k]);
+        if (incremental_pressure) *bk += dt * (-1.0 / rho[i] * grad[(size_t)i * 3 + k]);
+      }
+    }
+  }
+  free(vext); free(grad);
+  return 0;
+}
+
+/* ===================================================================== *
  *  linear algebra: Epetra / Belos / Ifpack semantics
  * ===================================================================== */
 

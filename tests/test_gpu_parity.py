@@ -319,3 +319,50 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
                            ilu=orc.ILU(rp, ci, val, 0, bp), params=prm)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
     assert np.allclose(bproj, bo, rtol=0, atol=1e-13 * np.abs(bo).max())   # b view updated in place
+
+
+# ---------------------------------------------------------------- Helmholtz builder
+@pytest.mark.parametrize("case", [dict(dim=2, n=20, mode=workload.JITTER), dict(dim=3, n=12, mode=workload.ADVECT),
+                                  dict(dim=2, n=4, mode=workload.JITTER, brick=0)])
+@pytest.mark.parametrize("antisym", [True, False])
+@pytest.mark.parametrize("theta", [0.0, 0.5, 1.0])
+def test_gpu_helmholtz_matches_oracle(gpu_ctx, case, antisym, theta):
+    pr = Problem(tgv_spec(**case), antisym=antisym)
+    p = pr.parts
+    x, nall = p["x"], p["nall"]
+    rng = np.random.default_rng(11)
+    pres = np.cos(x[:, 0]) * np.sin(x[:, 1])
+    force = np.ascontiguousarray(0.01 * np.stack([np.sin(x[:, 1]), np.cos(x[:, 0]), np.zeros(nall)], axis=1))
+    nu = p["nu"] * (1.0 + 0.1 * np.sin(x[:, 0]))            # variable viscosity exercises grad(m)
+    g = np.array([0.05, -0.02, 0.01 if pr.spec.dim == 3 else 0.0])
+    vel = np.ascontiguousarray(p["v"])
+    rp, ci, val, b = pr.P.helmholtz(pr.spec.dt, theta, nu, p["rho"], pres, force, g, vel, antisym=antisym)
+    A, bg = hip.assemble_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, theta, nu, p["rho"], pres, force, g, vel,
+                                   antisym=antisym, vfrac=pr.P.vfrac, Gc=None if antisym else pr.P.Gc,
+                                   Lc=None if antisym else pr.P.Lc, kernel=pr.spec.kernel)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci)
+    assert np.max(np.abs(v2 - val)) < 1e-12 * max(np.abs(val).max(), 1.0)
+    bo = b.ravel()                                            # oracle b is [dim][nlocal] == column-major flattened
+    assert np.max(np.abs(bg - bo)) < 1e-12 * np.abs(bo).max()
+
+
+def test_helmholtz_solve_three_rhs(gpu_ctx):
+    """computeHelmholtz + solveProblem("Helmholtz") with x0 = v^n (pair_isph.cpp:932-971), theta = 0.5."""
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER))
+    p = pr.parts
+    nall, n = p["nall"], pr.n
+    zeros = np.zeros(nall)
+    vel = np.ascontiguousarray(p["v"])
+    A, bg = hip.assemble_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, 0.5, p["nu"], p["rho"], zeros,
+                                   np.zeros((nall, 3)), np.zeros(3), vel, vfrac=pr.P.vfrac)
+    rp, ci, val, b = pr.P.helmholtz(pr.spec.dt, 0.5, p["nu"], p["rho"], zeros, np.zeros((nall, 3)), np.zeros(3), vel)
+    xg = np.ascontiguousarray(vel[:n].T).ravel().copy()       # initial guess = v^n, column-major
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 256)
+    info = hip.solve(gpu_ctx, A, bg.copy(), xg, prec=M, nvec=3, lda=n)
+    assert info.converged == 1
+    bp = np.arange(0, n + 256, 256).clip(0, n).astype(np.int32)
+    for k in range(3):
+        xo, io, _ = orc.solve(rp, ci, val, b[k], x0=vel[:n, k], prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
+        nrm = max(np.linalg.norm(xo), 1e-30)
+        assert np.linalg.norm(xg[k * n:(k + 1) * n] - xo) / nrm <= 1e-6 or np.linalg.norm(xo) < 1e-12
