@@ -13,8 +13,9 @@
 // per-entry column search (Epetra SumIntoGlobalValues) is needed.  The two
 // neighbour sweeps of the reference stay (the second needs grad m_i and c_i
 // complete), but the second one recomputes a_ij instead of re-reading the row.
-// Not covered yet (fails loudly): MorrisHolmes mirroring and wall Neumann rows
-// (functor_gradient_dot_operator_matrix.h) -- TGV configs have fluid only.
+// MorrisHolmes mirroring (mirror_morris_holmes.h) is applied where the reference's
+// *_MorrisHolmes functor combinations apply it.  Not covered yet (fails loudly):
+// wall Neumann rows (functor_gradient_dot_operator_matrix.h), i.e. solids with normals.
 #pragma once
 #include "core.hpp"
 #include "sell.hpp"
@@ -99,6 +100,16 @@ __device__ __forceinline__ double pair_rsq(int dim, const double *__restrict__ x
   return rsq;
 }
 
+// MirrorMorrisHolmes::computeMirrorCoefficient (ref: mirror_morris_holmes.h:39-52)
+__device__ __forceinline__ double mirror_coeff(const double *__restrict__ pnd, const double *__restrict__ vfrac,
+                                               double safe, double hij, int i, int j, double cut) {
+  double di = 2.0 * cut * (pnd[i] * vfrac[i] - 0.5) + kEps;
+  const double dj = 2.0 * cut * (pnd[j] * vfrac[j] - 0.5) + kEps;
+  const double dmin = safe * hij;
+  if (di < dmin) di = dmin;
+  return 1.0 + dj / di;
+}
+
 // FunctorOuterVolume: V_i = 1/(W(0) + sum_j W(r_ij))
 __global__ void k_volumes(AsmTables T, int nlocal, const double *__restrict__ x, const int *__restrict__ type,
                           const int *__restrict__ nptr, const int *__restrict__ nidx, double *__restrict__ vfrac) {
@@ -138,9 +149,9 @@ __global__ void k_first_fluid(int nlocal, const int *__restrict__ type, const in
 }
 
 struct PoissonArgs {
-  int nlocal, antisym, singular_mode, pin_enabled;
-  double dt;
-  const double *x, *vfrac, *Gc, *Lc, *rho, *vstar;
+  int nlocal, antisym, singular_mode, pin_enabled, morris;
+  double dt, safe;
+  const double *x, *vfrac, *Gc, *Lc, *rho, *vstar, *pnd;
   const int *type, *nptr, *nidx, *colmap;
   const int *first_fluid;
 };
@@ -228,9 +239,12 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
         for (int k = 0; k < dim; ++k) ci[k] += aij * e[k];
       aij *= mi * coeff / r;
       diag1 += aij;
-      // divergence of vstar, filter (Fluid, All), coeff 1 (MirrorNothing)
+      // divergence of vstar, filter (Fluid, All); coeff = mirror for fluid-solid pairs
       {
-        const double vd = dwdr / r * vfrac;
+        double dcoeff = 1.0;
+        if (a.morris && !(ikind & KIND_SOLID) && (jkind & KIND_SOLID))
+          dcoeff = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
+        const double vd = dwdr / r * vfrac * dcoeff;
         for (int k2 = 0; k2 < dim; ++k2) {
           double gitmp = 0.0;
           for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
@@ -313,9 +327,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
 // One lane per row like k_asm_poisson; w is accumulated while the row is built
 // (the reference forms it with Epetra's Multiply on the assembled matrix).
 struct HelmholtzArgs {
-  int nlocal, antisym, incremental, lda;
-  double dt, theta, g[3];
-  const double *x, *vfrac, *Gc, *Lc, *rho, *nu, *p, *f, *v;
+  int nlocal, antisym, incremental, lda, morris;
+  double dt, theta, g[3], safe;
+  const double *x, *vfrac, *Gc, *Lc, *rho, *nu, *p, *f, *v, *pnd;
   const int *type, *nptr, *nidx, *colmap;
 };
 
@@ -377,7 +391,11 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       const double mj = a.nu[j] * a.rho[j];
       double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
-      if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
+      if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) {
+        coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
+        if (a.morris && coeff != 0.0)  // FunctorOuterLaplacianMatrix_MorrisHolmes (functor_boundary_morris_holmes.h:49-64)
+          coeff = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
+      }
       const double r = sqrt(rsq) + kEps;
       const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
@@ -414,8 +432,13 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       double rij[3];
       const double rsq = pair_rsq(dim, a.x, i, j, rij);
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
+      // the correction term uses the plain filter coefficient (:225-227); a_ij keeps the
+      // mirror-weighted coefficient of the first sweep (:144-146)
       double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
       if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
+      double coeff_a = coeff;
+      if (a.morris && coeff != 0.0 && !(ikind & KIND_SOLID) && (jkind & KIND_SOLID))
+        coeff_a = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
       const double r = sqrt(rsq) + kEps;
       const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
@@ -426,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       for (int k2 = 0, op = 0; k2 < dim; ++k2)
         for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
       aij *= 2.0 * dwdr * vfrac;
-      aij *= mi * coeff / r;
+      aij *= mi * coeff_a / r;
       double bc = 0.0, bg = 0.0;
       for (int k2 = 0; k2 < dim; ++k2) {
         double bij = 0.0;
@@ -504,11 +527,11 @@ __global__ void k_sell_merge_duplicates(int nrow, const int *__restrict__ rowlen
 }
 
 struct StagedParticles {
-  DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar;
+  DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar, pnd;
   DevBuf<int> type, kind, nptr, nidx, colmap, first;
   void release() {
     x.release(); vfrac.release(); Gc.release(); Lc.release(); h.release(); cutsq.release(); rho.release();
-    vstar.release(); type.release(); kind.release(); nptr.release(); nidx.release(); colmap.release(); first.release();
+    vstar.release(); pnd.release(); type.release(); kind.release(); nptr.release(); nidx.release(); colmap.release(); first.release();
   }
 };
 
@@ -597,6 +620,10 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nall * dL, on_device, S.Lc, &a.Lc);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, rho, (size_t)P->nall, on_device, S.rho, &a.rho);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, vstar, (size_t)P->nall * 3, on_device, S.vstar, &a.vstar);
+  if (rc == ISPH_SUCCESS && P->morris_holmes) {
+    if (!P->pnd) rc = fail("MorrisHolmes needs pnd", __FILE__, __LINE__);
+    else rc = stage(ctx, P->pnd, (size_t)P->nall, on_device, S.pnd, &a.pnd);
+  }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &a.nptr);
   if (rc == ISPH_SUCCESS) {
     if (on_device) {
@@ -632,6 +659,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     rc = sell_finalize_offsets(ctx, M);
     if (rc == ISPH_SUCCESS) {
       a.nlocal = n; a.antisym = antisym; a.singular_mode = singular_mode; a.dt = dt;
+      a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
       a.pin_enabled = (is_rank0 && singular_mode >= 2) ? 1 : 0;
       rc = S.first.reserve(1);
       if (rc == ISPH_SUCCESS) {
@@ -711,6 +739,10 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   if (rc == ISPH_SUCCESS) rc = stage(ctx, pres, (size_t)P->nall, on_device, sp, &a.p);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, force, (size_t)P->nall * 3, on_device, sf, &a.f);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, vel, (size_t)P->nall * 3, on_device, sv, &a.v);
+  if (rc == ISPH_SUCCESS && P->morris_holmes) {
+    if (!P->pnd) rc = fail("MorrisHolmes needs pnd", __FILE__, __LINE__);
+    else rc = stage(ctx, P->pnd, (size_t)P->nall, on_device, S.pnd, &a.pnd);
+  }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &a.nptr);
   if (rc == ISPH_SUCCESS) {
     if (on_device) {
@@ -743,6 +775,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
     rc = sell_finalize_offsets(ctx, M);
     if (rc == ISPH_SUCCESS) {
       a.nlocal = n; a.antisym = antisym; a.incremental = incremental; a.lda = lda; a.dt = dt; a.theta = theta;
+      a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
       for (int k = 0; k < 3; ++k) a.g[k] = gvec ? gvec[k] : 0.0;
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
       hipLaunchKernelGGL(k_asm_helmholtz, dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);

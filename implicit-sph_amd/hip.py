@@ -47,7 +47,8 @@ class _Particles(C.Structure):
     _fields_ = [("dim", C.c_int), ("nlocal", C.c_int), ("nall", C.c_int), ("ntypes", C.c_int),
                 ("kernel", C.c_int), ("x", C.c_void_p), ("type", C.c_void_p), ("kind", C.c_void_p),
                 ("h", C.c_void_p), ("cutsq", C.c_void_p), ("neigh_ptr", C.c_void_p), ("neigh_idx", C.c_void_p),
-                ("colmap", C.c_void_p), ("vfrac", C.c_void_p), ("Gc", C.c_void_p), ("Lc", C.c_void_p)]
+                ("colmap", C.c_void_p), ("vfrac", C.c_void_p), ("Gc", C.c_void_p), ("Lc", C.c_void_p),
+                ("morris_holmes", C.c_int), ("pnd", C.c_void_p), ("morris_safe_coeff", C.c_double)]
 
 
 _lib = None
@@ -294,7 +295,8 @@ def solve(ctx, A, b, x, prec=None, singular=False, null_mask=None, params=None, 
     return info
 
 
-def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=None, Lc=None, keep=None):
+def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=None, Lc=None, keep=None,
+                   pnd=None, morris_safe_coeff=0.43301):
     """Builds the isph_particles struct over host (numpy) or device (torch)
     arrays.  `keep` collects references so the buffers outlive the call."""
     keep = keep if keep is not None else []
@@ -304,18 +306,21 @@ def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=
     cutsq = np.full((ntypes + 1, ntypes + 1), float(parts["cut"]) ** 2)
     x, typ = _f64(parts["x"]), _i32(parts["type"])
     nptr, nidx, cm = _i32(parts["neigh_ptr"]), _i32(parts["neigh_idx"]), _i32(colmap)
-    keep += [kind, h, cutsq, x, typ, nptr, nidx, cm, vfrac, Gc, Lc]
+    pnd = None if pnd is None else _f64(pnd)
+    keep += [kind, h, cutsq, x, typ, nptr, nidx, cm, vfrac, Gc, Lc, pnd]
     pv = _Particles(int(parts["dim"]), int(parts["nlocal"]), int(parts["nall"]), ntypes, KERNELS[kernel],
                     _ptr(x), _ptr(typ), _ptr(kind), _ptr(h), _ptr(cutsq), _ptr(nptr), _ptr(nidx), _ptr(cm),
-                    _ptr(vfrac), _ptr(Gc), _ptr(Lc))
+                    _ptr(vfrac), _ptr(Gc), _ptr(Lc), int(pnd is not None), _ptr(pnd), float(morris_safe_coeff))
     return pv, _on_device(x, typ, nptr, nidx, cm), keep
 
 
 def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=NULLSPACE, rank0=True,
-                     ncol=None, vfrac=None, kernel="wendland", b_out=None):
+                     ncol=None, vfrac=None, kernel="wendland", b_out=None, kinds=None, pnd=None, Gc=None, Lc=None,
+                     morris_safe_coeff=0.43301):
     """isph_assemble_poisson == PairISPH_Corrected::computePoisson."""
     keep = []
-    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, keep=keep)
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, keep=keep, kinds=kinds, pnd=pnd, Gc=Gc,
+                                   Lc=Lc, morris_safe_coeff=morris_safe_coeff)
     rho, vstar = _f64(rho), _f64(vstar)
     nlocal = int(parts["nlocal"])
     if b_out is None:
@@ -332,11 +337,13 @@ def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=
 
 
 def assemble_helmholtz(ctx, parts, colmap, dt, theta, nu, rho, pres, force, g, vel, antisym=True, incremental=True,
-                       ncol=None, vfrac=None, Gc=None, Lc=None, kernel="wendland"):
+                       ncol=None, vfrac=None, Gc=None, Lc=None, kernel="wendland", kinds=None, pnd=None,
+                       morris_safe_coeff=0.43301):
     """isph_assemble_helmholtz == PairISPH_Corrected::computeHelmholtz.  Returns (Matrix, b) with b
     column-major [nlocal x dim] flattened (component k at b[k*nlocal:(k+1)*nlocal])."""
     keep = []
-    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, Lc=Lc, keep=keep)
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, Lc=Lc, keep=keep, kinds=kinds,
+                                   pnd=pnd, morris_safe_coeff=morris_safe_coeff)
     nu, rho, pres, force, vel = map(_f64, (nu, rho, pres, force, vel))
     gv = np.ascontiguousarray(g, dtype=np.float64)
     nlocal, dim = int(parts["nlocal"]), int(parts["dim"])

@@ -165,6 +165,12 @@ typedef struct {
   const double *vfrac;     /* [nall] atom->vfrac (NULL: computed on device)   */
   const double *Gc;        /* [nall][dim*dim] or NULL (AntiSymmetric family)  */
   const double *Lc;        /* [nall][dimL]    or NULL                         */
+  /* ns.boundary == MorrisHolmes (pair_isph.h:125-132): fluid-solid pairs are weighted by
+   * MirrorMorrisHolmes::computeMirrorCoefficient (mirror_morris_holmes.h:39-52) -- in the
+   * divergence of the Poisson RHS and in the Laplacian of the Helmholtz matrix */
+  int morris_holmes;       /* 0 = MirrorNothing                               */
+  const double *pnd;       /* [nall] particle number density (pair->pnd) or NULL */
+  double morris_safe_coeff;/* pair->morris_safe_coeff (default 0.43301)       */
 } isph_particles;
 
 /* Replaces PairISPH_Corrected::computePoisson -> FunctorOuterIncompNavierStokesPoisson

@@ -660,8 +660,10 @@ int orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
   if (singular_mode == ORC_NOT_SINGULAR) { filt_j = ORC_KIND_ALL; neumann = 0; }   /* :73-78 */
   else                                   { filt_j = ORC_KIND_FLUID; neumann = 1; } /* :79-85 */
   for (int i = 0; i < P->nall; ++i) work[i] = 1.0 / rho[i];                          /* :88-91 */
+  /* the MorrisHolmes Poisson variant keeps the plain Laplacian and only swaps the
+   * divergence's mirror (pair_isph_corrected.cpp:174-178) */
   int bad = orc_laplacian_matrix(P, antisym, -dt, work, ORC_KIND_FLUID, filt_j,
-                                 morris_holmes, rowptr, colidx, val);               /* :93-96 */
+                                 0, rowptr, colidx, val);                           /* :93-96 */
   if (bad) return -1;
   if (neumann && normal != NULL) {
     for (int i = 0; i < n; ++i)
@@ -714,7 +716,7 @@ int orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
  * vall [nall][3] are the velocities (ghosts included; the reference reads the
  * ghost values through Epetra's import of b).  b is column-major [lda x dim]
  * and holds v^n of the owned particles on entry. */
-int orc_helmholtz(const orc_particles *P, int antisym, double dt, double theta,
+int orc_helmholtz(const orc_particles *P, int antisym, int morris_holmes, double dt, double theta,
                   const double *nu, const double *rho, const double *p,
                   const double *f, const double *g, int incremental_pressure,
                   const double *vall, const int *rowptr, const int *colidx,
@@ -722,7 +724,9 @@ int orc_helmholtz(const orc_particles *P, int antisym, double dt, double theta,
   const int n = P->nlocal, dim = P->dim;
   memset(val, 0, sizeof(double) * (size_t)rowptr[n]);
   for (int i = 0; i < P->nall; ++i) work[i] = nu[i] * rho[i];
-  if (orc_laplacian_matrix(P, antisym, dt, work, ORC_KIND_FLUID, ORC_KIND_ALL, 0, rowptr, colidx, val)) return -1;
+  /* MorrisHolmes variant: the Laplacian carries the mirror, the pressure gradient does not
+   * (pair_isph_corrected.cpp:157-161) */
+  if (orc_laplacian_matrix(P, antisym, dt, work, ORC_KIND_FLUID, ORC_KIND_ALL, morris_holmes, rowptr, colidx, val)) return -1;
   int ncol = 0;
   for (int j = 0; j < P->nall; ++j) if (P->colmap[j] + 1 > ncol) ncol = P->colmap[j] + 1;
   double *vext = (double *)calloc((size_t)ncol * 3, sizeof(double));

@@ -110,7 +110,7 @@ int  orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
                  const int *rowptr, const int *colidx, double *val,
                  double *b, double *work);
 
-int  orc_helmholtz(const orc_particles *P, int antisym, double dt, double theta,
+int  orc_helmholtz(const orc_particles *P, int antisym, int morris_holmes, double dt, double theta,
                    const double *nu, const double *rho, const double *p,
                    const double *f, const double *g, int incremental_pressure,
                    const double *vall, const int *rowptr, const int *colidx,

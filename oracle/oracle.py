@@ -75,7 +75,7 @@ def lib():
                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
         L.orc_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.orc_helmholtz.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+        L.orc_helmholtz.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
         L.orc_spmv.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -205,7 +205,7 @@ class Particles:
         return rowptr, colidx, val, b
 
 
-def _helmholtz(self, dt, theta, nu, rho, p, f, g, vall, antisym=True, incremental=True, graph=None):
+def _helmholtz(self, dt, theta, nu, rho, p, f, g, vall, antisym=True, incremental=True, graph=None, morris=0):
     """computeHelmholtz: returns (rowptr, colidx, val, b[nlocal, dim] column-major as [dim][nlocal])."""
     rowptr, colidx = graph if graph is not None else self.graph()
     val = np.zeros(len(colidx))
@@ -214,7 +214,7 @@ def _helmholtz(self, dt, theta, nu, rho, p, f, g, vall, antisym=True, incrementa
     b = np.ascontiguousarray(vall[:n, :self.dim].T.copy())      # column-major [lda x dim], holds v^n
     work = np.zeros(self.nall)
     nu, rho, p, f, g = _f64(nu), _f64(rho), _f64(p), _f64(f), _f64(g)
-    rc = lib().orc_helmholtz(self.ref(), int(antisym), float(dt), float(theta), _p(nu), _p(rho), _p(p), _p(f), _p(g),
+    rc = lib().orc_helmholtz(self.ref(), int(antisym), int(morris), float(dt), float(theta), _p(nu), _p(rho), _p(p), _p(f), _p(g),
                              int(incremental), _p(vall), _p(rowptr), _p(colidx), _p(val), _p(b), n, _p(work))
     assert rc == 0, "orc_helmholtz rc=%d" % rc
     return rowptr, colidx, val, b

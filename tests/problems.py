@@ -18,14 +18,19 @@ def tgv_spec(dim=3, n=12, mode=workload.ADVECT, brick=8, kernel="wendland", cut_
 class Problem:
     """particles + oracle precompute + oracle Poisson system for one rank."""
 
-    def __init__(self, spec, antisym=True, singular=orc.NULLSPACE, kinds=None, types=None):
+    def __init__(self, spec, antisym=True, singular=orc.NULLSPACE, kinds=None, types=None, pnd=None,
+                 morris_safe_coeff=0.43301):
         self.spec = spec
         self.parts = workload.make_tgv(spec)
         if types is not None:
             self.parts["type"] = np.ascontiguousarray(types(self.parts), dtype=np.int32)
         self.colmap = workload.single_rank_colmap(self.parts)
         self.antisym, self.singular, self.kinds = antisym, singular, kinds
-        self.P = orc.Particles(self.parts, self.colmap, kernel=spec.kernel, kinds=kinds)
+        self.pnd = None if pnd is None else np.ascontiguousarray(pnd(self.parts))
+        self.morris = int(pnd is not None)
+        self.safe = morris_safe_coeff
+        self.P = orc.Particles(self.parts, self.colmap, kernel=spec.kernel, kinds=kinds, pnd=self.pnd,
+                               morris_safe_coeff=morris_safe_coeff)
         self.P.precompute(corrections=not antisym)
         if not antisym:  # ghosts need the owner's G_i / L_i only through row i: no comm needed
             pass
@@ -33,4 +38,22 @@ class Problem:
 
     def poisson(self):
         p = self.parts
-        return self.P.poisson(self.spec.dt, p["rho"], p["v"], antisym=self.antisym, singular=self.singular)
+        return self.P.poisson(self.spec.dt, p["rho"], p["v"], antisym=self.antisym, singular=self.singular,
+                              morris=self.morris)
+
+
+def wall_types(parts):
+    """type 2 (solid) for the particles of a slab y < 0.9, type 1 (fluid) elsewhere; images follow owners"""
+    own = parts["owner_index"]
+    x = parts["x"]
+    t = np.where((x[:parts["nlocal"], 1] % (2 * np.pi)) < 0.9, 2, 1).astype(np.int32)
+    return t[own]
+
+
+def fake_pnd(parts):
+    """any positive per-particle number density exercises the mirror formula; owners and images agree"""
+    own = parts["owner_index"]
+    x = parts["x"][:parts["nlocal"]]
+    dx = parts["spec"].dx
+    d = (1.0 / dx ** parts["dim"]) * (0.9 + 0.2 * np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]))
+    return d[own]

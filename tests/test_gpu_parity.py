@@ -366,3 +366,62 @@ def test_helmholtz_solve_three_rhs(gpu_ctx):
         xo, io, _ = orc.solve(rp, ci, val, b[k], x0=vel[:n, k], prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
         nrm = max(np.linalg.norm(xo), 1e-30)
         assert np.linalg.norm(xg[k * n:(k + 1) * n] - xo) / nrm <= 1e-6 or np.linalg.norm(xo) < 1e-12
+
+
+# ---------------------------------------------------------------- solid particles + MorrisHolmes mirror
+from problems import wall_types, fake_pnd  # noqa: E402
+
+
+@pytest.mark.parametrize("dim,n", [(2, 20), (3, 12)])
+@pytest.mark.parametrize("antisym", [True, False])
+@pytest.mark.parametrize("singular", [orc.NOT_SINGULAR, orc.NULLSPACE])
+@pytest.mark.parametrize("morris", [False, True])
+def test_gpu_poisson_with_solid_wall(gpu_ctx, dim, n, antisym, singular, morris):
+    pr = Problem(tgv_spec(dim=dim, n=n, mode=workload.JITTER), antisym=antisym, singular=singular,
+                 kinds=[orc.FLUID, orc.SOLID], types=wall_types, pnd=fake_pnd if morris else None)
+    assert (pr.parts["type"][:pr.n] == 2).sum() > 0
+    rp, ci, val, b = pr.poisson()
+    A, bg = hip.assemble_poisson(gpu_ctx, pr.parts, pr.colmap, pr.spec.dt, pr.parts["rho"],
+                                 np.ascontiguousarray(pr.parts["v"]), antisym=antisym, singular=singular,
+                                 vfrac=pr.P.vfrac, kinds=[orc.FLUID, orc.SOLID], pnd=pr.pnd,
+                                 Gc=None if antisym else pr.P.Gc, Lc=None if antisym else pr.P.Lc)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci)
+    assert np.max(np.abs(v2 - val)) < 1e-12 * np.abs(val).max()
+    assert np.max(np.abs(bg - b)) < 1e-12 * np.abs(b).max()
+    solid = pr.parts["type"][:pr.n] == 2
+    d = sps.csr_matrix((v2, ci2, rp2)).diagonal()
+    assert np.all(d[solid] == 1.0) and np.all(bg[solid] == 0.0)          # functor_incomp_navier_stokes_poisson.h:137-147
+    if singular == orc.NULLSPACE:
+        # null-space mask = non-solid particles (pair_isph.cpp:996-1005); GMRES + block-ILU(0) vs oracle
+        mask = (~solid).astype(np.int32)
+        bs = 256
+        bp = np.arange(0, pr.n + bs, bs).clip(0, pr.n).astype(np.int32)
+        xo, io, _ = orc.solve(rp, ci, val, b, singular=True, null_mask=mask, prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
+        M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", bs)
+        xg = np.zeros(pr.n)
+        info = hip.solve(gpu_ctx, A, bg.copy(), xg, prec=M, singular=True, null_mask=mask)
+        assert info.converged == 1 and abs(info.iters - io.iters) <= 1
+        assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+@pytest.mark.parametrize("morris", [False, True])
+@pytest.mark.parametrize("antisym", [True, False])
+def test_gpu_helmholtz_with_solid_wall(gpu_ctx, morris, antisym):
+    pr = Problem(tgv_spec(dim=2, n=20, mode=workload.JITTER), antisym=antisym, kinds=[orc.FLUID, orc.SOLID],
+                 types=wall_types, pnd=fake_pnd if morris else None)
+    p = pr.parts
+    nall = p["nall"]
+    pres = np.cos(p["x"][:, 0])
+    force = np.zeros((nall, 3))
+    g = np.array([0.0, -0.1, 0.0])
+    vel = np.ascontiguousarray(p["v"])
+    rp, ci, val, b = pr.P.helmholtz(pr.spec.dt, 0.5, p["nu"], p["rho"], pres, force, g, vel, antisym=antisym,
+                                    morris=int(morris))
+    A, bg = hip.assemble_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, 0.5, p["nu"], p["rho"], pres, force, g, vel,
+                                   antisym=antisym, vfrac=pr.P.vfrac, kinds=[orc.FLUID, orc.SOLID], pnd=pr.pnd,
+                                   Gc=None if antisym else pr.P.Gc, Lc=None if antisym else pr.P.Lc)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(ci2, ci)
+    assert np.max(np.abs(v2 - val)) < 1e-12 * np.abs(val).max()
+    assert np.max(np.abs(bg - b.ravel())) < 1e-12 * np.abs(b).max()
