@@ -127,6 +127,154 @@ __global__ void k_volumes(AsmTables T, int nlocal, const double *__restrict__ x,
   vfrac[i] = 1.0 / w;
 }
 
+
+// ---------------------------------------------------------------------------
+// computePre tensors of the Symmetric (consistent) family, one lane per particle.
+// G_i = ( - sum_j r_ij (x) r_ij  W'/r  V_j )^-1          (ref: functor_gradient_correction.h:23-71)
+// closed-form adjugate inverse like UtilsReference::invertDenseMatrix (utils_reference.cpp:251-326)
+__global__ void k_gradient_correction(AsmTables T, int nlocal, const double *__restrict__ x,
+                                      const int *__restrict__ type, const int *__restrict__ nptr,
+                                      const int *__restrict__ nidx, const double *__restrict__ vfrac,
+                                      double *__restrict__ Gc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const int dim = T.dim, nt1 = T.ntypes + 1, it = type[i];
+  double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {
+    const int j = nidx[jj];
+    const int jt = type[j];
+    double rij[3];
+    const double rsq = pair_rsq(dim, x, i, j, rij);
+    if (rsq < T.cutsq[it * nt1 + jt]) {
+      const double r = sqrt(rsq) + kEps;
+      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      for (int k2 = 0; k2 < dim; ++k2)
+        for (int k1 = 0; k1 < dim; ++k1) G[k2 * dim + k1] -= rij[k1] * rij[k2] * dwdr / r * vfrac[j];
+    }
+  }
+  double *B = &Gc[(size_t)i * dim * dim];
+#define A_(r, c) G[(c) * dim + (r)]
+#define B_(r, c) B[(c) * dim + (r)]
+  if (dim == 2) {
+    const double det = A_(0, 0) * A_(1, 1) - A_(0, 1) * A_(1, 0);
+    B_(0, 0) = A_(1, 1) / det;
+    B_(1, 1) = A_(0, 0) / det;
+    B_(1, 0) = -A_(1, 0) / det;
+    B_(0, 1) = -A_(0, 1) / det;
+  } else {
+    const double c00 = A_(1, 1) * A_(2, 2) - A_(2, 1) * A_(1, 2);
+    const double c01 = -A_(1, 0) * A_(2, 2) + A_(2, 0) * A_(1, 2);
+    const double c02 = A_(1, 0) * A_(2, 1) - A_(2, 0) * A_(1, 1);
+    const double det = A_(0, 0) * c00 + A_(0, 1) * c01 + A_(0, 2) * c02;
+    B_(0, 0) = c00 / det;
+    B_(1, 0) = c01 / det;
+    B_(2, 0) = c02 / det;
+    B_(0, 1) = (-A_(0, 1) * A_(2, 2) + A_(2, 1) * A_(0, 2)) / det;
+    B_(1, 1) = (A_(0, 0) * A_(2, 2) - A_(2, 0) * A_(0, 2)) / det;
+    B_(2, 1) = (-A_(0, 0) * A_(2, 1) + A_(2, 0) * A_(0, 1)) / det;
+    B_(0, 2) = (A_(0, 1) * A_(1, 2) - A_(1, 1) * A_(0, 2)) / det;
+    B_(1, 2) = (-A_(0, 0) * A_(1, 2) + A_(1, 0) * A_(0, 2)) / det;
+    B_(2, 2) = (A_(0, 0) * A_(1, 1) - A_(1, 0) * A_(0, 1)) / det;
+  }
+#undef A_
+#undef B_
+}
+
+// L_i from the dimL x dimL system of functor_laplacian_correction.h:24-153, solved by
+// LU with partial pivoting (what LAPACK dgesv does for the reference, utils_reference.cpp:398-407).
+__global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__restrict__ x,
+                                       const int *__restrict__ type, const int *__restrict__ nptr,
+                                       const int *__restrict__ nidx, const double *__restrict__ vfrac,
+                                       const double *__restrict__ Gc, double *__restrict__ Lc, int *__restrict__ nfail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const int dim = T.dim, d2 = dim * dim, dL = dim * (dim + 1) / 2, nt1 = T.ntypes + 1, it = type[i];
+  double A[27], L[36], G[9];
+  for (int k = 0; k < 27; ++k) A[k] = 0.0;
+  for (int k = 0; k < 36; ++k) L[k] = 0.0;
+  for (int k = 0; k < d2; ++k) G[k] = Gc[(size_t)i * d2 + k];
+  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {  // third-order tensor A^{kmn}
+    const int j = nidx[jj];
+    const int jt = type[j];
+    double rij[3];
+    const double rsq = pair_rsq(dim, x, i, j, rij);
+    if (rsq < T.cutsq[it * nt1 + jt]) {
+      const double r = sqrt(rsq) + kEps;
+      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      double aij[3] = {0, 0, 0};
+      for (int k2 = 0; k2 < dim; ++k2) {
+        for (int k1 = 0; k1 < dim; ++k1) aij[k2] += G[k2 * dim + k1] * rij[k1];
+        aij[k2] *= dwdr / r * vfrac[j];
+      }
+      for (int k3 = 0; k3 < dim; ++k3)
+        for (int k2 = 0; k2 < dim; ++k2)
+          for (int k1 = 0; k1 < k2 + 1; ++k1) A[k3 * d2 + k2 * dim + k1] += aij[k3] * rij[k1] * rij[k2];
+    }
+  }
+  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {  // linear system
+    const int j = nidx[jj];
+    const int jt = type[j];
+    double rij[3];
+    const double rsq = pair_rsq(dim, x, i, j, rij);
+    if (rsq < T.cutsq[it * nt1 + jt]) {
+      const double r = sqrt(rsq) + kEps;
+      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      double e[3] = {0, 0, 0};
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k3 = 0; k3 < dim; ++k3)
+        for (int k2 = 0; k2 < dim; ++k2)
+          for (int k1 = 0; k1 < k2 + 1; ++k1) C[k2 * dim + k1] += A[k3 * d2 + k2 * dim + k1] * e[k3];
+      for (int k2 = 0; k2 < dim; ++k2)
+        for (int k1 = 0; k1 < k2 + 1; ++k1) {
+          C[k2 * dim + k1] += rij[k1] * e[k2];
+          C[k2 * dim + k1] *= dwdr * vfrac[j];
+        }
+      for (int k4 = 0, op = 0; k4 < dim; ++k4)
+        for (int k3 = 0; k3 < k4 + 1; ++k3, ++op)
+          for (int k2 = 0, mn = 0; k2 < dim; ++k2)
+            for (int k1 = 0; k1 < k2 + 1; ++k1, ++mn)
+              L[op * dL + mn] += C[k2 * dim + k1] * e[k3] * e[k4] * (k3 == k4 ? 1.0 : 2.0);
+    }
+  }
+  double rhs[6];
+  for (int k2 = 0, op = 0; k2 < dim; ++k2)
+    for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) rhs[op] = -(double)(k1 == k2);
+  // LU with partial pivoting, column-major L[col*dL + row]
+  bool singular = false;
+  for (int k = 0; k < dL; ++k) {
+    int pv = k;
+    double amax = fabs(L[k * dL + k]);
+    for (int r2 = k + 1; r2 < dL; ++r2)
+      if (fabs(L[k * dL + r2]) > amax) { amax = fabs(L[k * dL + r2]); pv = r2; }
+    if (amax == 0.0) { singular = true; break; }
+    if (pv != k) {
+      for (int c = 0; c < dL; ++c) { const double t = L[c * dL + k]; L[c * dL + k] = L[c * dL + pv]; L[c * dL + pv] = t; }
+      const double t = rhs[k]; rhs[k] = rhs[pv]; rhs[pv] = t;
+    }
+    const double piv = 1.0 / L[k * dL + k];
+    for (int r2 = k + 1; r2 < dL; ++r2) {
+      const double l = L[k * dL + r2] * piv;
+      L[k * dL + r2] = l;
+      if (l != 0.0) {
+        for (int c = k + 1; c < dL; ++c) L[c * dL + r2] -= l * L[c * dL + k];
+        rhs[r2] -= l * rhs[k];
+      }
+    }
+  }
+  if (singular) {
+    atomicAdd(nfail, 1);
+    for (int k = 0; k < dL; ++k) Lc[(size_t)i * dL + k] = 0.0;
+    return;
+  }
+  for (int r2 = dL - 1; r2 >= 0; --r2) {
+    double sacc = rhs[r2];
+    for (int c = r2 + 1; c < dL; ++c) sacc -= L[c * dL + r2] * rhs[c];
+    rhs[r2] = sacc / L[r2 * dL + r2];
+  }
+  for (int k = 0; k < dL; ++k) Lc[(size_t)i * dL + k] = rhs[k];
+}
+
 // FunctorOuterGraph row lengths: in-cut neighbours + self
 __global__ void k_asm_count(AsmTables T, int nlocal, const double *__restrict__ x, const int *__restrict__ type,
                             const int *__restrict__ nptr, const int *__restrict__ nidx, int *__restrict__ rowlen) {
@@ -810,6 +958,60 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   if (rc != ISPH_SUCCESS) { A->S.release(); delete A; return rc; }
   *A_out = A;
   return ISPH_SUCCESS;
+}
+
+// FunctorOuterGradientCorrection + FunctorOuterLaplacianCorrection for the owned particles
+inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *Gc_out, double *Lc_out, int on_device) {
+  ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
+  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx && P->vfrac, "particle arrays missing (vfrac incl. ghosts)");
+  const int n = P->nlocal, dim = P->dim, d2 = dim * dim, dL = dim * (dim + 1) / 2;
+  StagedParticles S;
+  AsmTables T;
+  int rc = stage_tables(ctx, P, S, T);
+  const double *dx = nullptr, *dvf = nullptr;
+  const int *dt = nullptr, *dp = nullptr, *di = nullptr;
+  long long nnb = 0;
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->x, (size_t)P->nall * 3, on_device, S.x, &dx);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->type, (size_t)P->nall, on_device, S.type, &dt);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->vfrac, (size_t)P->nall, on_device, S.vfrac, &dvf);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &dp);
+  if (rc == ISPH_SUCCESS) {
+    if (on_device) {
+      int last = 0;
+      if (hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("neigh_ptr read failed", __FILE__, __LINE__);
+      nnb = last;
+    } else nnb = P->neigh_ptr[n];
+  }
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &di);
+  DevBuf<double> g, l;
+  DevBuf<int> nf;
+  double *dG = Gc_out, *dLc = Lc_out;
+  if (rc == ISPH_SUCCESS && !on_device) {
+    rc = g.reserve((size_t)(n > 0 ? n : 1) * d2);
+    if (rc == ISPH_SUCCESS) rc = l.reserve((size_t)(n > 0 ? n : 1) * dL);
+    dG = g.p; dLc = l.p;
+  }
+  if (rc == ISPH_SUCCESS) rc = nf.reserve(1);
+  int nfail = 0;
+  if (rc == ISPH_SUCCESS && n > 0) {
+    const int grid = (n + kBlock - 1) / kBlock;
+    if (hipMemsetAsync(nf.p, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+    hipLaunchKernelGGL(k_gradient_correction, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf, dG);
+    hipLaunchKernelGGL(k_laplacian_correction, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf,
+                       (const double *)dG, dLc, nf.p);
+    if (!on_device) {
+      if (hipMemcpyAsync(Gc_out, dG, sizeof(double) * (size_t)n * d2, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(Lc_out, dLc, sizeof(double) * (size_t)n * dL, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = fail("copy failed", __FILE__, __LINE__);
+    }
+    if (hipMemcpyAsync(&nfail, nf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+      rc = fail("correction kernels failed", __FILE__, __LINE__);
+  }
+  S.release(); g.release(); l.release(); nf.release();
+  if (rc == ISPH_SUCCESS && nfail > 0) return fail("singular Laplacian-correction system (DGESV failed in the reference)", __FILE__, __LINE__);
+  return rc;
 }
 
 }  // namespace isph

@@ -20,7 +20,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes",
+    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.isph_assemble_poisson.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_compute_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_compute_corrections.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_assemble_helmholtz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -370,3 +371,20 @@ def compute_volumes(ctx, parts, colmap, kernel="wendland"):
         out = np.zeros(nlocal)
     _check(lib().isph_compute_volumes(ctx.h, C.byref(pv), _ptr(out), dev))
     return out
+
+
+def compute_corrections(ctx, parts, colmap, vfrac, kernel="wendland"):
+    """isph_compute_corrections == computeGradientCorrection + computeLaplacianCorrection.
+    Returns (Gc [nlocal, dim*dim], Lc [nlocal, dimL])."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, keep=keep)
+    nlocal, dim = int(parts["nlocal"]), int(parts["dim"])
+    dL = dim * (dim + 1) // 2
+    if dev:
+        import torch
+        G = torch.zeros((nlocal, dim * dim), dtype=torch.float64, device=parts["x"].device)
+        Lc = torch.zeros((nlocal, dL), dtype=torch.float64, device=parts["x"].device)
+    else:
+        G, Lc = np.zeros((nlocal, dim * dim)), np.zeros((nlocal, dL))
+    _check(lib().isph_compute_corrections(ctx.h, C.byref(pv), _ptr(G), _ptr(Lc), dev))
+    return G, Lc

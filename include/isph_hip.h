@@ -199,6 +199,13 @@ int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym,
 /* FunctorOuterVolume (ref: functor_volume.h:40-80); vfrac_out [nlocal]. */
 int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device);
 
+/* FunctorOuterGradientCorrection + FunctorOuterLaplacianCorrection
+ * (ref: functor_gradient_correction.h:23-71, functor_laplacian_correction.h:24-153,
+ * pair_isph_corrected.cpp:333-369): G_i [nlocal][dim*dim] column-major and L_i
+ * [nlocal][dimL] packed upper for the owned particles; P->vfrac must hold the
+ * ghosts' volumes already (forward comm). */
+int isph_compute_corrections(isph_ctx *ctx, const isph_particles *P, double *Gc_out, double *Lc_out, int on_device);
+
 #ifdef __cplusplus
 }
 #endif
