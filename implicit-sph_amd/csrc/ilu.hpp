@@ -173,7 +173,17 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
     for (int sweep = 0; sweep <= B; ++sweep) {
       int nl = 0;
       if (ccap > 0) {
-        for (int e = 0; e < ndep; ++e) nl = max(nl, lev[ccol[(d0 + e) * B + t]] + 1);
+        // 8 independent column/level look-ups in flight (a plain loop serialises two LDS latencies per dependency)
+        for (int e0 = 0; e0 < ndep; e0 += 8) {
+          int lv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + u, ndep - 1);
+            lv[u] = lev[ccol[(d0 + e) * B + t]];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) nl = max(nl, lv[u] + 1);
+        }
       } else {
         for (int e = 0; e < ndep; ++e) nl = max(nl, lev[fcol[rp + d0 + e] - blo] + 1);
       }
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
                                                            const int *__restrict__ llev, double *__restrict__ sv,
                                                            double *__restrict__ dinv) {
   extern __shared__ double lds_f[];
-  double *diag = lds_f;                                   // [B]
+  double *diag = lds_f;                                   // [B] 1/d_k of the finished rows
   double *wval = diag + B;                                // [WAVES][W]
   long long *rpL = reinterpret_cast<long long *>(wval + WAVES * W);  // [B] frp
   int *wcol = reinterpret_cast<int *>(rpL + B);           // [WAVES][W]
@@ -331,47 +341,46 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
       __builtin_amdgcn_wave_barrier();
       // software-pipelined elimination: the U-row of step s+kFacPrefetch is
       // requested while step s is applied (one entry per lane per 64 columns)
-      int pcq[kFacPrefetch];
-      double pvq[kFacPrefetch];
-      auto request = [&](int s, int &pc, double &pvv) {
-        pc = -1;
+      int psq[kFacPrefetch];      // slot+1 in row i of the prefetched U-row entry (0: not in the pattern)
+      double pvq[kFacPrefetch];   // its value
+      double pdq[kFacPrefetch];   // 1/d_k of that step
+      auto request = [&](int s, int &ps, double &pvv, double &pdv) {
+        ps = 0;
         pvv = 0.0;
+        pdv = 0.0;
         if (s < dg) {
           const int k = mc[s];
+          pdv = diag[k];
           const int t = dgL[k] + 1 + lane;
           if (t < lenL[k]) {
             const long long p = rpL[k] + t;
-            pc = fcol[p] - blo;
+            ps = mp[fcol[p] - blo];
             pvv = fval[p];
           }
         }
       };
 #pragma unroll
-      for (int u = 0; u < kFacPrefetch; ++u) request(u, pcq[u], pvq[u]);
+      for (int u = 0; u < kFacPrefetch; ++u) request(u, psq[u], pvq[u], pdq[u]);
       for (int s0 = 0; s0 < dg; s0 += kFacPrefetch) {
 #pragma unroll
         for (int u = 0; u < kFacPrefetch; ++u) {
           const int s = s0 + u;
           if (s < dg) {
-            const int pc = pcq[u];
-            const double pvv = pvq[u];
-            const int k = mc[s];
-            const double lik = mv[s] / diag[k];
+            const int ps = psq[u];
+            const double lik = mv[s] * pdq[u];   // l_ik = a_ik / d_k (reciprocal stored once per pivot)
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) mv[s] = lik;
-            if (pc >= 0) {
-              const int ps = mp[pc];
-              if (ps) mv[ps - 1] -= lik * pvv;
-            }
+            if (ps) mv[ps - 1] -= lik * pvq[u];
+            const int k = mc[s];
             // U-rows wider than one wave (rare: > 64 in-block upper entries)
             for (int t = dgL[k] + 1 + 64 + lane; t < lenL[k]; t += 64) {
               const long long p = rpL[k] + t;
-              const int ps = mp[fcol[p] - blo];
-              if (ps) mv[ps - 1] -= lik * fval[p];
+              const int ps2 = mp[fcol[p] - blo];
+              if (ps2) mv[ps2 - 1] -= lik * fval[p];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            request(s + kFacPrefetch, pcq[u], pvq[u]);
+            request(s + kFacPrefetch, psq[u], pvq[u], pdq[u]);
           }
         }
       }
@@ -382,9 +391,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
         mp[mc[s]] = 0;
       }
       if (lane == 0) {
-        const double d = mv[dg];
-        diag[r] = d;
-        dinv[i] = 1.0 / d;
+        const double rd = 1.0 / mv[dg];
+        diag[r] = rd;
+        dinv[i] = rd;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();

@@ -62,7 +62,9 @@ int sell_sort_rows(isph_ctx *ctx, Sell &S) {
   if (wmax == 0) return ISPH_SUCCESS;
   const int Ws = wmax | 1;
   int R = 64;
-  while (R > 1 && (size_t)R * Ws * 24 > 144 * 1024) R >>= 1;
+  // <= 48 KiB per workgroup keeps >= 3 workgroups (12 waves) per CU in flight: the kernel is a
+  // global-load/store stream, the LDS rank sort in between is cheap
+  while (R > 1 && (size_t)R * Ws * 24 > 48 * 1024) R >>= 1;
   ISPH_REQUIRE((size_t)R * Ws * 24 <= 160 * 1024, "row too long for the LDS row sort");
   const size_t lds = (size_t)R * Ws * 24;
   ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sell_sort_rows),
