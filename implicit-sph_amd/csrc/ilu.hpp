@@ -432,9 +432,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
   unsigned cq[kPrefetch];
   const int ntot = nL + nU;
 #pragma unroll
-  for (int u = 0; u < kPrefetch; ++u) {
-    vq[u] = pv[(long long)u * 64];
-    cq[u] = pc[(long long)u * 64];
+  for (int u = 0; u < kPrefetch; ++u) {  // non-temporal: the stream is read once per apply
+    vq[u] = __builtin_nontemporal_load(&pv[(long long)u * 64]);
+    cq[u] = __builtin_nontemporal_load(&pc[(long long)u * 64]);
   }
   double acc = 0.0;
   bool upper = false;
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
       const int c = c0 + u;
       const double v = vq[u];
       const unsigned cw = cq[u];
-      vq[u] = pv[(long long)(c + kPrefetch) * 64];  // stays inside the padded buffer
-      cq[u] = pc[(long long)(c + kPrefetch) * 64];
+      vq[u] = __builtin_nontemporal_load(&pv[(long long)(c + kPrefetch) * 64]);  // stays inside the padded buffer
+      cq[u] = __builtin_nontemporal_load(&pc[(long long)(c + kPrefetch) * 64]);
       if (c < ntot) {
         if (c == nL && !upper) {
           // switch to the U phase: rows without upper dependencies finish here

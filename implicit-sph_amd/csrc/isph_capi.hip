@@ -297,7 +297,7 @@ int isph_spmv(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, int 
     // caller supplied all ncol entries (ghost values included): plain kernel
     int nbp = 0;
     const int grid = spmv_grid(S.nslices, &nbp);
-    hipLaunchKernelGGL((k_sell_spmv<4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+    hipLaunchKernelGGL((k_sell_spmv<8, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
                        S.slice_off.p, S.col.p, S.val.p, (const double *)ctx->xdev.p, ctx->bdev.p, (const double *)nullptr,
                        (double *)nullptr);
   } else {
@@ -317,10 +317,25 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
   ISPH_CHECK(halo_exchange(ctx, A, x_dev, &xuse));
   int nbp = 0;
   const int grid = spmv_grid(S.nslices, &nbp);
+  // kernel-tuning aid: ISPH_SPMV_VARIANT selects an experimental instantiation for this timing call only
+  const char *vs = getenv("ISPH_SPMV_VARIANT");
+  const int variant = vs ? atoi(vs) : 0;
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-  for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL((k_sell_spmv<4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
-                       S.slice_off.p, S.col.p, S.val.p, xuse, y_dev, (const double *)nullptr, (double *)nullptr);
+#define ISPH_SPMV_LAUNCH(U, NTF)                                                                                      \
+  hipLaunchKernelGGL((k_sell_spmv<U, false, NTF>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp, \
+                     S.slice_off.p, S.col.p, S.val.p, xuse, y_dev, (const double *)nullptr, (double *)nullptr)
+  for (int r = 0; r < reps; ++r) {
+    switch (variant) {
+      case 1: ISPH_SPMV_LAUNCH(8, false); break;
+      case 2: ISPH_SPMV_LAUNCH(4, true); break;
+      case 3: ISPH_SPMV_LAUNCH(12, true); break;
+      case 4: ISPH_SPMV_LAUNCH(2, false); break;
+      case 5: ISPH_SPMV_LAUNCH(6, false); break;
+      case 6: ISPH_SPMV_LAUNCH(4, false); break;
+      default: ISPH_SPMV_LAUNCH(8, true); break;  // production instantiation
+    }
+  }
+#undef ISPH_SPMV_LAUNCH
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
   ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev1));
   float ms = 0.f;

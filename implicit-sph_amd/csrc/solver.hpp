@@ -101,10 +101,10 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
   ISPH_CHECK(profile_begin(ctx, &slot));
   if (nvec) {
     ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
-    hipLaunchKernelGGL((k_sell_spmv<4, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+    hipLaunchKernelGGL((k_sell_spmv<8, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
                        S.slice_off.p, S.col.p, S.val.p, xuse, y, nvec, ctx->partial.p);
   } else {
-    hipLaunchKernelGGL((k_sell_spmv<4, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+    hipLaunchKernelGGL((k_sell_spmv<8, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
                        S.slice_off.p, S.col.p, S.val.p, xuse, y, (const double *)nullptr, (double *)nullptr);
   }
   ISPH_CHECK(profile_end(ctx, slot));
