@@ -66,6 +66,12 @@ def lib():
         if not os.path.exists(path):
             raise RuntimeError("libisph_hip.so is missing (%s): run __graft_entry__.build(); "
                                "there is no CPU fallback" % path)
+        # When torch is in the process, load it first so both bind to ONE HIP/RCCL runtime
+        # (torch ships its own libamdhip64/librccl; two runtimes in one process do not share the device).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(path)
         L.isph_last_error.restype = C.c_char_p
         L.isph_prec_nnz.restype = C.c_longlong
