@@ -33,7 +33,56 @@ struct AsmTables {  // small per-type tables, device resident
   const double *h;      // [(ntypes+1)^2]
   const double *cutsq;  // [(ntypes+1)^2]
   int ntypes, kernel, dim;
+  // per type pair, precomputed on the host: 1/h, C(h) and C(h)/h (the reference recomputes the
+  // normalisation with pow() on every call, kernel_wendland.h:34-46; the value is the same)
+  const double *hinv, *knorm, *kdnorm;
+  // neighbour list re-laid out per 64-row slice, lane == row (see k_neigh_transpose):
+  // neighbour k of row i sits at nt[noff[i>>6] + k*64 + (i&63)], so the one-lane-per-row
+  // kernels read it with coalesced 256-B wave loads instead of 64 scattered lines
+  const long long *noff;
+  const int *nt;
 };
+
+__device__ __forceinline__ int neigh_at(const AsmTables &T, int i, int k) {
+  return T.nt[T.noff[i >> 6] + (long long)k * 64 + (i & 63)];
+}
+
+// numneigh per row (for the slice widths of the transposed list)
+__global__ void k_numneigh(int n, const int *__restrict__ nptr, int *__restrict__ len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) len[i] = nptr[i + 1] - nptr[i];
+}
+
+// CSR neighbour list -> lane-interleaved slices.  One wave per slice; 64 rows x 16 ids are staged
+// through LDS: the CSR side is read in 64-B row segments, the ELL side written as 256-B wave stores.
+__global__ __launch_bounds__(kBlock) void k_neigh_transpose(int n, const int *__restrict__ nptr,
+                                                            const int *__restrict__ nidx,
+                                                            const long long *__restrict__ noff, int *__restrict__ nt) {
+  __shared__ int lds[kBlock / 64][64 * 17];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * (kBlock / 64) + wave;
+  const int nslices = (n + 63) / 64;
+  if (slice >= nslices) return;
+  int *wl = lds[wave];
+  const int row = slice * 64 + lane;
+  const int jb = row < n ? nptr[row] : 0, je = row < n ? nptr[row + 1] : 0;
+  const long long off = noff[slice];
+  const int w = (int)((noff[slice + 1] - off) >> 6);
+  for (int c0 = 0; c0 < w; c0 += 16) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int r = s * 4 + (lane >> 4), t = lane & 15;
+      const int rb = __shfl(jb, r, 64), re = __shfl(je, r, 64);
+      const int p = rb + c0 + t;
+      wl[r * 17 + t] = p < re ? nidx[p] : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < 16 && c0 + t < w; ++t) nt[off + (long long)(c0 + t) * 64 + lane] = wl[lane * 17 + t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
 
 // kernel normalisation C(h) (ref: kernel_wendland.h:34-46, kernel_quintic.h:34-46, kernel_cubic.h:33-44)
 __host__ __device__ inline double kernel_norm(int kernel, int dim, double h) {
@@ -50,8 +99,9 @@ __device__ __forceinline__ double pow4(double a) { const double b = a * a; retur
 __device__ __forceinline__ double pow5(double a) { const double b = a * a; return b * b * a; }
 
 // W(r,h)  (ref: kernel_wendland.h:50-58, kernel_quintic.h:48-66, kernel_cubic.h:45-56)
-__device__ inline double kernel_val(int kernel, int dim, double r, double h) {
-  const double s = fabs(r / h);
+// hinv = 1/h and C = normalisation come from the per-type-pair tables.
+__device__ inline double kernel_val(int kernel, double r, double hinv, double C) {
+  const double s = fabs(r * hinv);
   double v = 0.0;
   if (kernel == 0) {
     v = s < 2.0 ? pow4(1.0 - 0.5 * s) * (2.0 * s + 1.0) : 0.0;
@@ -65,12 +115,12 @@ __device__ inline double kernel_val(int kernel, int dim, double r, double h) {
     if (fs == 0) v = 1.0 - 0.75 * (2.0 - s) * s * s;
     else if (fs == 1) v = 0.25 * pow3(2.0 - s);
   }
-  return v * kernel_norm(kernel, dim, h);
+  return v * C;
 }
 
-// dW/dr(r,h)  (ref: kernel_wendland.h:60-68, kernel_quintic.h:68-82, kernel_cubic.h:58-70)
-__device__ inline double kernel_dval(int kernel, int dim, double r, double h) {
-  const double s = fabs(r / h);
+// dW/dr(r,h)  (ref: kernel_wendland.h:60-68, kernel_quintic.h:68-82, kernel_cubic.h:58-70); Ch = C/h
+__device__ inline double kernel_dval(int kernel, double r, double hinv, double Ch) {
+  const double s = fabs(r * hinv);
   double v = 0.0;
   if (kernel == 0) {
     v = s < 2.0 ? -5.0 * s * pow3(1.0 - 0.5 * s) : 0.0;
@@ -84,7 +134,7 @@ __device__ inline double kernel_dval(int kernel, int dim, double r, double h) {
     if (fs == 0) v = (2.25 * s - 3.0) * s;
     else if (fs == 1) { const double a = 2.0 - s; v = -0.75 * a * a; }
   }
-  return v * kernel_norm(kernel, dim, h) / h;
+  return v * Ch;
 }
 
 // r_ij and |r_ij|^2 with the reference's operation order and NO fma
@@ -116,13 +166,13 @@ __global__ void k_volumes(AsmTables T, int nlocal, const double *__restrict__ x,
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
   const int it = type[i], nt1 = T.ntypes + 1;
-  double w = kernel_val(T.kernel, T.dim, 0.0, T.h[it * nt1 + it]);
+  double w = kernel_val(T.kernel, 0.0, T.hinv[it * nt1 + it], T.knorm[it * nt1 + it]);
   for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {
-    const int j = nidx[jj];
+    const int j = neigh_at(T, i, jj - nptr[i]);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(T.dim, x, i, j, rij);
-    if (rsq < T.cutsq[it * nt1 + jt]) w += kernel_val(T.kernel, T.dim, sqrt(rsq), T.h[it * nt1 + jt]);
+    if (rsq < T.cutsq[it * nt1 + jt]) w += kernel_val(T.kernel, sqrt(rsq), T.hinv[it * nt1 + jt], T.knorm[it * nt1 + jt]);
   }
   vfrac[i] = 1.0 / w;
 }
@@ -141,15 +191,16 @@ __global__ void k_gradient_correction(AsmTables T, int nlocal, const double *__r
   const int dim = T.dim, nt1 = T.ntypes + 1, it = type[i];
   double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {
-    const int j = nidx[jj];
+    const int j = neigh_at(T, i, jj - nptr[i]);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(dim, x, i, j, rij);
     if (rsq < T.cutsq[it * nt1 + jt]) {
       const double r = sqrt(rsq) + kEps;
-      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      const double rinv = 1.0 / r;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       for (int k2 = 0; k2 < dim; ++k2)
-        for (int k1 = 0; k1 < dim; ++k1) G[k2 * dim + k1] -= rij[k1] * rij[k2] * dwdr / r * vfrac[j];
+        for (int k1 = 0; k1 < dim; ++k1) G[k2 * dim + k1] -= rij[k1] * rij[k2] * dwdr * rinv * vfrac[j];
     }
   }
   double *B = &Gc[(size_t)i * dim * dim];
@@ -194,17 +245,18 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
   for (int k = 0; k < 36; ++k) L[k] = 0.0;
   for (int k = 0; k < d2; ++k) G[k] = Gc[(size_t)i * d2 + k];
   for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {  // third-order tensor A^{kmn}
-    const int j = nidx[jj];
+    const int j = neigh_at(T, i, jj - nptr[i]);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(dim, x, i, j, rij);
     if (rsq < T.cutsq[it * nt1 + jt]) {
       const double r = sqrt(rsq) + kEps;
-      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      const double rinv = 1.0 / r;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double aij[3] = {0, 0, 0};
       for (int k2 = 0; k2 < dim; ++k2) {
         for (int k1 = 0; k1 < dim; ++k1) aij[k2] += G[k2 * dim + k1] * rij[k1];
-        aij[k2] *= dwdr / r * vfrac[j];
+        aij[k2] *= dwdr * rinv * vfrac[j];
       }
       for (int k3 = 0; k3 < dim; ++k3)
         for (int k2 = 0; k2 < dim; ++k2)
@@ -212,15 +264,16 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
     }
   }
   for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {  // linear system
-    const int j = nidx[jj];
+    const int j = neigh_at(T, i, jj - nptr[i]);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(dim, x, i, j, rij);
     if (rsq < T.cutsq[it * nt1 + jt]) {
       const double r = sqrt(rsq) + kEps;
-      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      const double rinv = 1.0 / r;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
-      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
       double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       for (int k3 = 0; k3 < dim; ++k3)
         for (int k2 = 0; k2 < dim; ++k2)
@@ -275,6 +328,12 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
   for (int k = 0; k < dL; ++k) Lc[(size_t)i * dL + k] = rhs[k];
 }
 
+// material = 1/rho over nlocal+nghost (functor_incomp_navier_stokes_poisson.h:88-91)
+__global__ void k_reciprocal(int n, const double *__restrict__ a, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.0 / a[i];
+}
+
 // FunctorOuterGraph row lengths: in-cut neighbours + self
 __global__ void k_asm_count(AsmTables T, int nlocal, const double *__restrict__ x, const int *__restrict__ type,
                             const int *__restrict__ nptr, const int *__restrict__ nidx, int *__restrict__ rowlen) {
@@ -283,7 +342,7 @@ __global__ void k_asm_count(AsmTables T, int nlocal, const double *__restrict__ 
   const int it = type[i], nt1 = T.ntypes + 1;
   int cnt = 1;
   for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {
-    const int j = nidx[jj];
+    const int j = neigh_at(T, i, jj - nptr[i]);
     double rij[3];
     const double rsq = pair_rsq(T.dim, x, i, j, rij);
     if (rsq < T.cutsq[it * nt1 + type[j]]) ++cnt;
@@ -299,7 +358,7 @@ __global__ void k_first_fluid(int nlocal, const int *__restrict__ type, const in
 struct PoissonArgs {
   int nlocal, antisym, singular_mode, pin_enabled, morris;
   double dt, safe;
-  const double *x, *vfrac, *Gc, *Lc, *rho, *vstar, *pnd;
+  const double *x, *vfrac, *Gc, *Lc, *rho, *invrho, *vstar, *pnd;
   const int *type, *nptr, *nidx, *colmap;
   const int *first_fluid;
 };
@@ -330,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   const int filt_i = KIND_FLUID;
   const int filt_j = a.singular_mode == 0 ? KIND_ALL : KIND_FLUID;
   const double alpha = -a.dt;
-  const double mi = 1.0 / a.rho[i];
+  const double mi = a.invrho[i];
   const int jb = a.nptr[i], je = a.nptr[i + 1];
   int cnt = 0;
   double diag_final;
@@ -339,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   if (!(ikind & filt_i)) {
     // row not computed: in-cut pattern with zeros (functor_laplacian_matrix.h:88-96)
     for (int jj = jb; jj < je; ++jj) {
-      const int j = a.nidx[jj];
+      const int j = neigh_at(T, i, jj - jb);
       double rij[3];
       if (pair_rsq(dim, a.x, i, j, rij) < T.cutsq[it * nt1 + a.type[j]]) {
         const long long p = sell_pos(off, lane, cnt++);
@@ -360,18 +419,19 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
     double diag1 = 0.0, div = 0.0;
     // ---- sweep 1: grad m_i, c_i, diag, divergence (:127-201, functor_divergence.h:79-117)
     for (int jj = jb; jj < je; ++jj) {
-      const int j = a.nidx[jj];
+      const int j = neigh_at(T, i, jj - jb);
       const int jt = a.type[j], jkind = T.kind[jt];
       double rij[3];
       const double rsq = pair_rsq(dim, a.x, i, j, rij);
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
-      const double mj = 1.0 / a.rho[j];
+      const double mj = a.invrho[j];
       double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
       if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
       const double r = sqrt(rsq) + kEps;
-      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      const double rinv = 1.0 / r;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
-      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
       const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
       const double vjtmp = dwdr * vfrac;
       for (int k2 = 0; k2 < dim; ++k2) {
@@ -385,14 +445,14 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       aij *= 2.0 * dwdr * vfrac;
       if (!a.antisym)
         for (int k = 0; k < dim; ++k) ci[k] += aij * e[k];
-      aij *= mi * coeff / r;
+      aij *= mi * coeff * rinv;
       diag1 += aij;
       // divergence of vstar, filter (Fluid, All); coeff = mirror for fluid-solid pairs
       {
         double dcoeff = 1.0;
         if (a.morris && !(ikind & KIND_SOLID) && (jkind & KIND_SOLID))
           dcoeff = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
-        const double vd = dwdr / r * vfrac * dcoeff;
+        const double vd = dwdr * rinv * vfrac * dcoeff;
         for (int k2 = 0; k2 < dim; ++k2) {
           double gitmp = 0.0;
           for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
@@ -404,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
     // ---- sweep 2: final off-diagonal values (:204-264), written once
     double diag2 = 0.0;
     for (int jj = jb; jj < je; ++jj) {
-      const int j = a.nidx[jj];
+      const int j = neigh_at(T, i, jj - jb);
       const int jt = a.type[j], jkind = T.kind[jt];
       double rij[3];
       const double rsq = pair_rsq(dim, a.x, i, j, rij);
@@ -412,16 +472,17 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
       if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
       const double r = sqrt(rsq) + kEps;
-      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      const double rinv = 1.0 / r;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
-      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
       const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
       const double vjtmp = dwdr * vfrac;
       double aij = 0.0;
       for (int k2 = 0, op = 0; k2 < dim; ++k2)
         for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
       aij *= 2.0 * dwdr * vfrac;
-      aij *= mi * coeff / r;
+      aij *= mi * coeff * rinv;
       double bc = 0.0, bg = 0.0;
       for (int k2 = 0; k2 < dim; ++k2) {
         double bij = 0.0;
@@ -512,7 +573,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
 
   if (!(ikind & filt_i)) {
     for (int jj = jb; jj < je; ++jj) {
-      const int j = a.nidx[jj];
+      const int j = neigh_at(T, i, jj - jb);
       double rij[3];
       if (pair_rsq(dim, a.x, i, j, rij) < T.cutsq[it * nt1 + a.type[j]]) {
         const long long p = sell_pos(off, lane, cnt++);
@@ -532,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
     double grad_m[3] = {0, 0, 0}, ci[3] = {0, 0, 0};
     double diag1 = 0.0;
     for (int jj = jb; jj < je; ++jj) {  // sweep 1
-      const int j = a.nidx[jj];
+      const int j = neigh_at(T, i, jj - jb);
       const int jt = a.type[j], jkind = T.kind[jt];
       double rij[3];
       const double rsq = pair_rsq(dim, a.x, i, j, rij);
@@ -545,9 +606,10 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
           coeff = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
       }
       const double r = sqrt(rsq) + kEps;
-      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      const double rinv = 1.0 / r;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
-      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
       const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
       const double vjtmp = dwdr * vfrac;
       for (int k2 = 0; k2 < dim; ++k2) {
@@ -561,11 +623,11 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       aij *= 2.0 * dwdr * vfrac;
       if (!a.antisym)
         for (int k = 0; k < dim; ++k) ci[k] += aij * e[k];
-      aij *= mi * coeff / r;
+      aij *= mi * coeff * rinv;
       diag1 += aij;
       // gradient of p, filter (Fluid, Fluid) (functor_gradient.h:120-150)
       if (a.incremental && (ikind & KIND_FLUID) && (jkind & KIND_FLUID)) {
-        const double vd = dwdr / r * vfrac;
+        const double vd = dwdr * rinv * vfrac;
         for (int k2 = 0; k2 < dim; ++k2) {
           double gitmp = 0.0;
           for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
@@ -575,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
     }
     double diag2 = 0.0;
     for (int jj = jb; jj < je; ++jj) {  // sweep 2
-      const int j = a.nidx[jj];
+      const int j = neigh_at(T, i, jj - jb);
       const int jt = a.type[j], jkind = T.kind[jt];
       double rij[3];
       const double rsq = pair_rsq(dim, a.x, i, j, rij);
@@ -588,16 +650,17 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       if (a.morris && coeff != 0.0 && !(ikind & KIND_SOLID) && (jkind & KIND_SOLID))
         coeff_a = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
       const double r = sqrt(rsq) + kEps;
-      const double dwdr = kernel_dval(T.kernel, dim, r, T.h[it * nt1 + jt]);
+      const double rinv = 1.0 / r;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
-      for (int k = 0; k < dim; ++k) e[k] = rij[k] / r;
+      for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
       const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
       const double vjtmp = dwdr * vfrac;
       double aij = 0.0;
       for (int k2 = 0, op = 0; k2 < dim; ++k2)
         for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
       aij *= 2.0 * dwdr * vfrac;
-      aij *= mi * coeff_a / r;
+      aij *= mi * coeff_a * rinv;
       double bc = 0.0, bg = 0.0;
       for (int k2 = 0; k2 < dim; ++k2) {
         double bij = 0.0;
@@ -675,13 +738,42 @@ __global__ void k_sell_merge_duplicates(int nrow, const int *__restrict__ rowlen
 }
 
 struct StagedParticles {
-  DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar, pnd;
+  DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar, pnd, hinv, knorm, kdnorm, invrho;
   DevBuf<int> type, kind, nptr, nidx, colmap, first;
   void release() {
     x.release(); vfrac.release(); Gc.release(); Lc.release(); h.release(); cutsq.release(); rho.release();
-    vstar.release(); pnd.release(); type.release(); kind.release(); nptr.release(); nidx.release(); colmap.release(); first.release();
+    vstar.release(); pnd.release(); hinv.release(); knorm.release(); kdnorm.release(); invrho.release(); type.release(); kind.release(); nptr.release(); nidx.release(); colmap.release(); first.release();
   }
 };
+
+
+struct NeighEll {
+  DevBuf<long long> off;
+  DevBuf<int> idx, len;
+  void release() { off.release(); idx.release(); len.release(); }
+};
+
+// builds the lane-interleaved neighbour list and hooks it into T
+inline int build_neigh_ell(isph_ctx *ctx, int n, const int *dnptr, const int *dnidx, NeighEll &E, AsmTables &T) {
+  const int nslices = (n + kSlice - 1) / kSlice;
+  ISPH_CHECK(E.len.reserve((size_t)(n > 0 ? n : 1)));
+  ISPH_CHECK(E.off.reserve((size_t)nslices + 1));
+  if (n == 0) { T.noff = E.off.p; T.nt = nullptr; return ISPH_SUCCESS; }
+  const int grid = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_numneigh, dim3(grid), dim3(kBlock), 0, ctx->stream, n, dnptr, E.len.p);
+  hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, E.len.p, E.off.p);
+  hipLaunchKernelGGL(k_exclusive_scan_ll, dim3(1), dim3(1024), 0, ctx->stream, nslices, E.off.p, E.off.p);
+  long long total = 0;
+  ISPH_CHECK_HIP(hipMemcpyAsync(&total, E.off.p + nslices, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  ISPH_CHECK(E.idx.reserve((size_t)(total > 0 ? total : 1)));
+  hipLaunchKernelGGL(k_neigh_transpose, dim3((nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, E.off.p,
+                     E.idx.p);
+  ISPH_CHECK_HIP(hipGetLastError());
+  T.noff = E.off.p;
+  T.nt = E.idx.p;
+  return ISPH_SUCCESS;
+}
 
 template <class T>
 inline int stage(isph_ctx *ctx, const T *src, size_t n, int on_device, DevBuf<T> &tmp, const T **out) {
@@ -701,6 +793,18 @@ inline int stage_tables(isph_ctx *ctx, const isph_particles *P, StagedParticles 
   ISPH_CHECK(stage(ctx, P->h, nt1 * nt1, 0, S.h, &dh));
   ISPH_CHECK(stage(ctx, P->cutsq, nt1 * nt1, 0, S.cutsq, &dc));
   T.kind = dk; T.h = dh; T.cutsq = dc; T.ntypes = P->ntypes; T.kernel = P->kernel; T.dim = P->dim;
+  T.noff = nullptr; T.nt = nullptr;
+  std::vector<double> hi(nt1 * nt1), kn(nt1 * nt1), kd(nt1 * nt1);
+  for (size_t k = 0; k < nt1 * nt1; ++k) {
+    const double hh = P->h[k];
+    hi[k] = hh != 0.0 ? 1.0 / hh : 0.0;
+    kn[k] = hh != 0.0 ? kernel_norm(P->kernel, P->dim, hh) : 0.0;
+    kd[k] = hh != 0.0 ? kn[k] / hh : 0.0;
+  }
+  ISPH_CHECK(stage(ctx, hi.data(), nt1 * nt1, 0, S.hinv, &T.hinv));
+  ISPH_CHECK(stage(ctx, kn.data(), nt1 * nt1, 0, S.knorm, &T.knorm));
+  ISPH_CHECK(stage(ctx, kd.data(), nt1 * nt1, 0, S.kdnorm, &T.kdnorm));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // hi/kn/kd are stack-lived
   return ISPH_SUCCESS;
 }
 
@@ -724,6 +828,8 @@ inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac
     } else nnb = P->neigh_ptr[P->nlocal];
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &di);
+  NeighEll E;
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, P->nlocal, dp, di, E, T);
   DevBuf<double> out;
   double *dout = vfrac_out;
   if (rc == ISPH_SUCCESS && !on_device) { rc = out.reserve((size_t)(P->nlocal > 0 ? P->nlocal : 1)); dout = out.p; }
@@ -737,6 +843,7 @@ inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac
       rc = fail("volume kernel failed", __FILE__, __LINE__);
   }
   S.release();
+  E.release();
   out.release();
   return rc;
 }
@@ -789,6 +896,8 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     }
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
+  NeighEll E;
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T);
   // kinds present: refuse what this build does not restate
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
@@ -808,6 +917,14 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     if (rc == ISPH_SUCCESS) {
       a.nlocal = n; a.antisym = antisym; a.singular_mode = singular_mode; a.dt = dt;
       a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
+      rc = S.invrho.reserve((size_t)P->nall);
+      if (rc == ISPH_SUCCESS) {
+        hipLaunchKernelGGL(k_reciprocal, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall, a.rho,
+                           S.invrho.p);
+        a.invrho = S.invrho.p;
+      }
+    }
+    if (rc == ISPH_SUCCESS) {
       a.pin_enabled = (is_rank0 && singular_mode >= 2) ? 1 : 0;
       rc = S.first.reserve(1);
       if (rc == ISPH_SUCCESS) {
@@ -849,6 +966,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     }
   }
   S.release();
+  E.release();
   bdev.release();
   newlen.release();
   if (rc != ISPH_SUCCESS) { A->S.release(); delete A; return rc; }
@@ -907,6 +1025,8 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
     }
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
+  NeighEll E;
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T);
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
       if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);
@@ -952,7 +1072,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
       M.nnz = tot;
     }
   }
-  S.release(); snu.release(); sp.release(); sf.release(); sv.release();
+  S.release(); E.release(); snu.release(); sp.release(); sf.release(); sv.release();
   bdev.release();
   newlen.release();
   if (rc != ISPH_SUCCESS) { A->S.release(); delete A; return rc; }
@@ -984,6 +1104,8 @@ inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *G
     } else nnb = P->neigh_ptr[n];
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &di);
+  NeighEll E;
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, dp, di, E, T);
   DevBuf<double> g, l;
   DevBuf<int> nf;
   double *dG = Gc_out, *dLc = Lc_out;
@@ -1009,7 +1131,7 @@ inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *G
         hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
       rc = fail("correction kernels failed", __FILE__, __LINE__);
   }
-  S.release(); g.release(); l.release(); nf.release();
+  S.release(); E.release(); g.release(); l.release(); nf.release();
   if (rc == ISPH_SUCCESS && nfail > 0) return fail("singular Laplacian-correction system (DGESV failed in the reference)", __FILE__, __LINE__);
   return rc;
 }

@@ -446,3 +446,35 @@ def test_gpu_corrections_match_oracle_and_feed_assembly(gpu_ctx, case):
                                  kernel=pr.spec.kernel)
     rp2, ci2, v2 = A.export_csr()
     assert np.array_equal(ci2, ci) and np.max(np.abs(v2 - val)) < 1e-9 * np.abs(val).max()
+
+
+# ---------------------------------------------------------------- device-pointer ingress (on_device = 1)
+def test_device_pointer_paths(gpu_ctx):
+    """The same calls with HBM-resident operands (torch CUDA tensors passed as raw pointers):
+    CSR ingress, SpMV, preconditioner apply, solve -- identical results to the host-pointer path."""
+    import torch
+    dev = torch.device("cuda", 0)
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Ah = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    Ad = hip.Matrix.from_csr(gpu_ctx, t(rp), t(ci), t(val))
+    gpu_ctx.sync()
+    for x, y in zip(Ah.export_csr(), Ad.export_csr()):
+        assert np.array_equal(x, y)
+    xr = np.random.default_rng(3).standard_normal(pr.n)
+    yd = Ad.spmv(t(xr))
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), Ah.spmv(xr))              # same kernel, same order: bitwise
+    M = hip.Precond(gpu_ctx, Ad, "bjacobi-ilu0", 128)
+    zd = M.apply(t(xr))
+    torch.cuda.synchronize()
+    assert np.array_equal(zd.cpu().numpy(), M.apply(xr))
+    bd, xd = t(b), torch.zeros(pr.n, dtype=torch.float64, device=dev)
+    info_d = hip.solve(gpu_ctx, Ad, bd, xd, prec=M, singular=True)
+    bh, xh = b.copy(), np.zeros(pr.n)
+    info_h = hip.solve(gpu_ctx, Ah, bh, xh, prec=M, singular=True)
+    assert info_d.iters == info_h.iters and info_d.converged == 1
+    assert np.array_equal(xd.cpu().numpy(), xh) and np.array_equal(bd.cpu().numpy(), bh)   # deterministic reductions
+    with pytest.raises(ValueError):
+        hip.solve(gpu_ctx, Ad, bd, xh, prec=M, singular=True)          # mixing host and device operands is refused
