@@ -11,44 +11,56 @@
 
 namespace isph {
 
-constexpr int kDotRows = 4;  // rows per thread per chunk in the multi-dot
+constexpr int kDotBatch = 16;  // basis vectors whose partial sums a thread keeps in registers
 
 // partial[(k)*nblk + blockIdx] = sum over this block's rows of V_k[i]*w[i],
-// k in [0,nk); slot nk holds w.w.  V_k = V + k*ld.  w is read once per
-// chunk and kept in registers while the nk basis vectors stream by.
+// k in [0,nk); slot nk holds w.w.  V_k = V + k*ld.
+// Basis vectors are processed in batches of kDotBatch: every thread keeps one running sum per vector of the
+// batch in registers while it grid-strides over its rows, so the wave/block reduction (DPP + LDS) happens once
+// per batch instead of once per row chunk; w is re-read once per batch (+8N bytes per 16 vectors).
 __global__ __launch_bounds__(kBlock) void k_multi_dot(int n, int nk, const double *__restrict__ V, long long ld,
                                                       const double *__restrict__ w,
                                                       double *__restrict__ partial) {
-  extern __shared__ double sacc[];  // [(nk+1)][4 waves]
+  __shared__ double sred[kDotBatch + 1][4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int k = threadIdx.x; k < (nk + 1) * 4; k += blockDim.x) sacc[k] = 0.0;
-  __syncthreads();
-  const long long chunk = (long long)kBlock * kDotRows;
-  for (long long base = (long long)blockIdx.x * chunk; base < n; base += (long long)gridDim.x * chunk) {
-    double wr[kDotRows];
-    long long idx[kDotRows];
+  const long long stride = (long long)gridDim.x * kBlock;
+  const long long i0 = (long long)blockIdx.x * kBlock + threadIdx.x;
+  for (int k0 = 0; k0 < nk || k0 == 0; k0 += kDotBatch) {
+    const int nb = min(kDotBatch, nk - k0);
+    const bool last = k0 + kDotBatch >= nk;  // the last batch also accumulates w.w
+    double acc[kDotBatch];
+#pragma unroll
+    for (int u = 0; u < kDotBatch; ++u) acc[u] = 0.0;
     double ww = 0.0;
+    const double *__restrict__ vb = V + (long long)k0 * ld;
+    for (long long i = i0; i < n; i += stride) {
+      const double wi = w[i];
+      if (last) ww = fma(wi, wi, ww);
 #pragma unroll
-    for (int r = 0; r < kDotRows; ++r) {
-      idx[r] = base + (long long)r * kBlock + threadIdx.x;
-      wr[r] = idx[r] < n ? w[idx[r]] : 0.0;
-      ww = fma(wr[r], wr[r], ww);
+      for (int u = 0; u < kDotBatch; ++u)
+        if (u < nb) acc[u] = fma(vb[(long long)u * ld + i], wi, acc[u]);
     }
-    for (int k = 0; k < nk; ++k) {
-      const double *__restrict__ vk = V + (long long)k * ld;
-      double s = 0.0;
 #pragma unroll
-      for (int r = 0; r < kDotRows; ++r)
-        if (idx[r] < n) s = fma(vk[idx[r]], wr[r], s);
-      s = wave_sum(s);
-      if (lane == 0) sacc[k * 4 + wave] += s;
+    for (int u = 0; u < kDotBatch; ++u) {
+      if (u < nb) {  // wave-uniform
+        const double s = wave_sum(acc[u]);
+        if (lane == 0) sred[u][wave] = s;
+      }
     }
-    ww = wave_sum(ww);
-    if (lane == 0) sacc[nk * 4 + wave] += ww;
+    if (last) {
+      ww = wave_sum(ww);
+      if (lane == 0) sred[kDotBatch][wave] = ww;
+    }
+    __syncthreads();
+    if (threadIdx.x < nb)
+      partial[(long long)(k0 + threadIdx.x) * gridDim.x + blockIdx.x] =
+          (sred[threadIdx.x][0] + sred[threadIdx.x][1]) + (sred[threadIdx.x][2] + sred[threadIdx.x][3]);
+    if (last && threadIdx.x == 0)
+      partial[(long long)nk * gridDim.x + blockIdx.x] =
+          (sred[kDotBatch][0] + sred[kDotBatch][1]) + (sred[kDotBatch][2] + sred[kDotBatch][3]);
+    __syncthreads();
+    if (last) break;
   }
-  __syncthreads();
-  for (int k = threadIdx.x; k <= nk; k += blockDim.x)
-    partial[(long long)k * gridDim.x + blockIdx.x] = (sacc[k * 4] + sacc[k * 4 + 1]) + (sacc[k * 4 + 2] + sacc[k * 4 + 3]);
 }
 
 // out[k] = sum_b partial[k*nblk + b]: one 256-thread block per k, fixed
