@@ -14,8 +14,8 @@
 // neighbour sweeps of the reference stay (the second needs grad m_i and c_i
 // complete), but the second one recomputes a_ij instead of re-reading the row.
 // MorrisHolmes mirroring (mirror_morris_holmes.h) is applied where the reference's
-// *_MorrisHolmes functor combinations apply it.  Not covered yet (fails loudly):
-// wall Neumann rows (functor_gradient_dot_operator_matrix.h), i.e. solids with normals.
+// *_MorrisHolmes functor combinations apply it; Solid rows with wall normals get the
+// homogeneous-Neumann operator rows of functor_gradient_dot_operator_matrix.h.
 #pragma once
 #include "core.hpp"
 #include "sell.hpp"
@@ -357,8 +357,8 @@ __global__ void k_first_fluid(int nlocal, const int *__restrict__ type, const in
 
 struct PoissonArgs {
   int nlocal, antisym, singular_mode, pin_enabled, morris;
-  double dt, safe;
-  const double *x, *vfrac, *Gc, *Lc, *rho, *invrho, *vstar, *pnd;
+  double dt, safe, solid_normal_diag;
+  const double *x, *vfrac, *Gc, *Lc, *rho, *invrho, *vstar, *pnd, *normal;
   const int *type, *nptr, *nidx, *colmap;
   const int *first_fluid;
 };
@@ -395,15 +395,41 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   double diag_final;
   double bi = 0.0;
 
+  bool wall_normal = false;
   if (!(ikind & filt_i)) {
-    // row not computed: in-cut pattern with zeros (functor_laplacian_matrix.h:88-96)
+    // Laplacian not computed for this row (functor_laplacian_matrix.h:88-96).  Solid rows get the
+    // homogeneous-Neumann operator -dt n.grad when a wall normal is present and the Poisson problem is
+    // treated as singular (functor_incomp_navier_stokes_poisson.h:98-107,
+    // functor_gradient_dot_operator_matrix.h:39-79, functor_gradient_operator.h:74-169: G_i, V_j, coeff 1).
+    double nrm[3] = {0, 0, 0}, G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool neumann = a.singular_mode != 0 && a.normal != nullptr && (ikind & KIND_SOLID);
+    if (neumann) {
+      for (int k = 0; k < dim; ++k) nrm[k] = a.normal[3 * (size_t)i + k];
+      for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
+      double nn = 0.0;
+      for (int k = 0; k < dim; ++k) nn += nrm[k] * nrm[k];
+      wall_normal = !(nn < 0.5);
+    }
     for (int jj = jb; jj < je; ++jj) {
       const int j = neigh_at(T, i, jj - jb);
       double rij[3];
-      if (pair_rsq(dim, a.x, i, j, rij) < T.cutsq[it * nt1 + a.type[j]]) {
+      const int jt = a.type[j];
+      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      if (rsq < T.cutsq[it * nt1 + jt]) {
+        double v = 0.0;
+        if (neumann) {
+          const double r = sqrt(rsq) + kEps;
+          const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
+          const double vjtmp = dwdr / r * a.vfrac[j];
+          for (int k2 = 0; k2 < dim; ++k2) {
+            double gitmp = 0.0;
+            for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
+            v += (gitmp * vjtmp) * alpha * nrm[k2];
+          }
+        }
         const long long p = sell_pos(off, lane, cnt++);
         scol[p] = a.colmap[j];
-        sval[p] = 0.0;
+        sval[p] = v;
       }
     }
     diag_final = 0.0;
@@ -503,7 +529,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   }
   // ---- diagonal / RHS fix-ups (functor_incomp_navier_stokes_poisson.h:126-173)
   if (ikind == KIND_SOLID) {
-    diag_final = 1.0;  // no wall normals in this build: norm < 0.5 branch
+    // the functor assigns the diagonal only when there is no wall normal (:137-147)
+    diag_final = (a.singular_mode != 0 && wall_normal) ? a.solid_normal_diag : 1.0;
     bi = 0.0;
   } else if (a.pin_enabled && *a.first_fluid == i) {  // modifySingularMatrix, once, rank 0
     if (a.singular_mode == 2) {
@@ -738,11 +765,11 @@ __global__ void k_sell_merge_duplicates(int nrow, const int *__restrict__ rowlen
 }
 
 struct StagedParticles {
-  DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar, pnd, hinv, knorm, kdnorm, invrho;
+  DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar, pnd, hinv, knorm, kdnorm, invrho, normal;
   DevBuf<int> type, kind, nptr, nidx, colmap, first;
   void release() {
     x.release(); vfrac.release(); Gc.release(); Lc.release(); h.release(); cutsq.release(); rho.release();
-    vstar.release(); pnd.release(); hinv.release(); knorm.release(); kdnorm.release(); invrho.release(); type.release(); kind.release(); nptr.release(); nidx.release(); colmap.release(); first.release();
+    vstar.release(); pnd.release(); hinv.release(); knorm.release(); kdnorm.release(); invrho.release(); normal.release(); type.release(); kind.release(); nptr.release(); nidx.release(); colmap.release(); first.release();
   }
 };
 
@@ -879,6 +906,11 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     if (!P->pnd) rc = fail("MorrisHolmes needs pnd", __FILE__, __LINE__);
     else rc = stage(ctx, P->pnd, (size_t)P->nall, on_device, S.pnd, &a.pnd);
   }
+  if (rc == ISPH_SUCCESS && P->normal && singular_mode != 0) {
+    if (!P->Gc) rc = fail("wall normals need Gc (gradient-operator rows use G_i)", __FILE__, __LINE__);
+    else rc = stage(ctx, P->normal, (size_t)P->nall * 3, on_device, S.normal, &a.normal);
+    if (rc == ISPH_SUCCESS && !a.Gc) rc = stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, S.Gc, &a.Gc);
+  }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &a.nptr);
   if (rc == ISPH_SUCCESS) {
     if (on_device) {
@@ -917,6 +949,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     if (rc == ISPH_SUCCESS) {
       a.nlocal = n; a.antisym = antisym; a.singular_mode = singular_mode; a.dt = dt;
       a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
+      a.solid_normal_diag = P->solid_normal_diag;
       rc = S.invrho.reserve((size_t)P->nall);
       if (rc == ISPH_SUCCESS) {
         hipLaunchKernelGGL(k_reciprocal, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall, a.rho,

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,25 +44,82 @@ inline int fail(const char *what, const char *file, int line) {
     if (!(cond)) return ::isph::fail(msg, __FILE__, __LINE__);        \
   } while (0)
 
-// grow-only device buffer (hipMalloc is synchronous and slow: never inside the
-// Krylov loop; workspaces are sized once per solve)
+// Process-wide cache of freed device blocks.  The matrix, the ILU factor and its stream are rebuilt every
+// time step (the reference deletes A / graph / map after every compute(), pair_isph.cpp:1351-1372); going
+// back to hipMalloc/hipFree for multi-GB buffers each step costs milliseconds and an implicit device sync
+// per call.  Blocks are reused when the request fits within 25 % slack; at most kPoolCapBytes stay cached.
+// release() synchronises the device first (as hipFree would), so a recycled block is never still in use
+// by a kernel of another stream.
+struct DevPool {
+  static constexpr size_t kPoolCapBytes = (size_t)48 << 30;
+  std::multimap<size_t, void *> free_blocks;
+  size_t cached = 0;
+  std::mutex mu;
+  static DevPool &get() {
+    static DevPool p;
+    return p;
+  }
+  void *alloc(size_t bytes, size_t *got) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = free_blocks.lower_bound(bytes);
+      if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+        void *p = it->second;
+        *got = it->first;
+        cached -= it->first;
+        free_blocks.erase(it);
+        return p;
+      }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      trim();  // give cached blocks back and retry once
+      if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    }
+    *got = bytes;
+    return p;
+  }
+  void release(void *p, size_t bytes) {
+    if (!p) return;
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes >= 4096 && cached + bytes <= kPoolCapBytes) {
+      free_blocks.emplace(bytes, p);
+      cached += bytes;
+    } else {
+      (void)hipFree(p);
+    }
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
+    cached = 0;
+  }
+};
+
+// grow-only device buffer backed by the pool (never allocates inside the Krylov loop:
+// workspaces are sized once per solve)
 template <class T>
 struct DevBuf {
   T *p = nullptr;
-  size_t cap = 0;
+  size_t cap = 0;       // elements usable
+  size_t bytes = 0;     // size of the underlying block
   int reserve(size_t n) {
     if (n <= cap) return ISPH_SUCCESS;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    ISPH_CHECK_HIP(hipMalloc((void **)&p, n * sizeof(T)));
-    cap = n;
+    release();
+    size_t got = 0;
+    p = static_cast<T *>(DevPool::get().alloc(n * sizeof(T), &got));
+    if (!p) return ::isph::fail("device allocation failed", __FILE__, __LINE__);
+    bytes = got;
+    cap = got / sizeof(T);
     return ISPH_SUCCESS;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) DevPool::get().release(p, bytes);
     p = nullptr;
     cap = 0;
+    bytes = 0;
   }
 };
 

@@ -153,6 +153,7 @@ void isph_ctx_destroy(isph_ctx *c) {
   if (c->hscal) (void)hipHostFree(c->hscal);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  DevPool::get().trim();  // cached device blocks go back to the driver with the context
 }
 
 /* ---- matrix ----------------------------------------------------------- */

@@ -48,7 +48,8 @@ class _Particles(C.Structure):
                 ("kernel", C.c_int), ("x", C.c_void_p), ("type", C.c_void_p), ("kind", C.c_void_p),
                 ("h", C.c_void_p), ("cutsq", C.c_void_p), ("neigh_ptr", C.c_void_p), ("neigh_idx", C.c_void_p),
                 ("colmap", C.c_void_p), ("vfrac", C.c_void_p), ("Gc", C.c_void_p), ("Lc", C.c_void_p),
-                ("morris_holmes", C.c_int), ("pnd", C.c_void_p), ("morris_safe_coeff", C.c_double)]
+                ("morris_holmes", C.c_int), ("pnd", C.c_void_p), ("morris_safe_coeff", C.c_double),
+                ("normal", C.c_void_p), ("solid_normal_diag", C.c_double)]
 
 
 _lib = None
@@ -303,7 +304,7 @@ def solve(ctx, A, b, x, prec=None, singular=False, null_mask=None, params=None, 
 
 
 def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=None, Lc=None, keep=None,
-                   pnd=None, morris_safe_coeff=0.43301):
+                   pnd=None, morris_safe_coeff=0.43301, normal=None, solid_normal_diag=1.0):
     """Builds the isph_particles struct over host (numpy) or device (torch)
     arrays.  `keep` collects references so the buffers outlive the call."""
     keep = keep if keep is not None else []
@@ -314,20 +315,23 @@ def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=
     x, typ = _f64(parts["x"]), _i32(parts["type"])
     nptr, nidx, cm = _i32(parts["neigh_ptr"]), _i32(parts["neigh_idx"]), _i32(colmap)
     pnd = None if pnd is None else _f64(pnd)
-    keep += [kind, h, cutsq, x, typ, nptr, nidx, cm, vfrac, Gc, Lc, pnd]
+    normal = None if normal is None else _f64(normal)
+    keep += [kind, h, cutsq, x, typ, nptr, nidx, cm, vfrac, Gc, Lc, pnd, normal]
     pv = _Particles(int(parts["dim"]), int(parts["nlocal"]), int(parts["nall"]), ntypes, KERNELS[kernel],
                     _ptr(x), _ptr(typ), _ptr(kind), _ptr(h), _ptr(cutsq), _ptr(nptr), _ptr(nidx), _ptr(cm),
-                    _ptr(vfrac), _ptr(Gc), _ptr(Lc), int(pnd is not None), _ptr(pnd), float(morris_safe_coeff))
+                    _ptr(vfrac), _ptr(Gc), _ptr(Lc), int(pnd is not None), _ptr(pnd), float(morris_safe_coeff),
+                    _ptr(normal), float(solid_normal_diag))
     return pv, _on_device(x, typ, nptr, nidx, cm), keep
 
 
 def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=NULLSPACE, rank0=True,
                      ncol=None, vfrac=None, kernel="wendland", b_out=None, kinds=None, pnd=None, Gc=None, Lc=None,
-                     morris_safe_coeff=0.43301):
+                     morris_safe_coeff=0.43301, normal=None, solid_normal_diag=1.0):
     """isph_assemble_poisson == PairISPH_Corrected::computePoisson."""
     keep = []
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, keep=keep, kinds=kinds, pnd=pnd, Gc=Gc,
-                                   Lc=Lc, morris_safe_coeff=morris_safe_coeff)
+                                   Lc=Lc, morris_safe_coeff=morris_safe_coeff, normal=normal,
+                                   solid_normal_diag=solid_normal_diag)
     rho, vstar = _f64(rho), _f64(vstar)
     nlocal = int(parts["nlocal"])
     if b_out is None:

@@ -171,6 +171,14 @@ typedef struct {
   int morris_holmes;       /* 0 = MirrorNothing                               */
   const double *pnd;       /* [nall] particle number density (pair->pnd) or NULL */
   double morris_safe_coeff;/* pair->morris_safe_coeff (default 0.43301)       */
+  /* wall normals (pair->normal, [nall][3]) or NULL.  With a singular-Poisson mode other than
+   * NotSingular the Solid rows receive the homogeneous-Neumann operator -dt n.grad
+   * (ref: functor_incomp_navier_stokes_poisson.h:98-107, functor_gradient_dot_operator_matrix.h:39-79);
+   * needs Gc.  solid_normal_diag = what A.diagonal[i] holds for such a row when the Poisson functor
+   * runs: the functor does not assign it (:137-147); it is 1 after the scalar Helmholtz pass of the
+   * same step, 0 if only block matrices were built. */
+  const double *normal;
+  double solid_normal_diag;
 } isph_particles;
 
 /* Replaces PairISPH_Corrected::computePoisson -> FunctorOuterIncompNavierStokesPoisson

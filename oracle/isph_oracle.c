@@ -646,12 +646,11 @@ void orc_laplacian_apply(const orc_particles *P, int antisym, const double *f,
 /* ref: functor_incomp_navier_stokes_poisson.h:52-181 and
  * PairISPH::modifySingularMatrix, pair_isph.cpp:493-520.
  * val must be zero-initialised by the caller or is zeroed here (PutScalar(0)).
- * normal may be NULL (no wall particles); Neumann wall rows
- * (functor_gradient_dot_operator_matrix.h) are only needed when Solid
- * particles carry normals and are not restated yet -> returns -2 then. */
+ * normal may be NULL (no wall normals).  With normals the Solid rows receive the
+ * homogeneous-Neumann operator -dt n.grad (functor_gradient_dot_operator_matrix.h). */
 int orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
                 double dt, const double *rho, const double *vstar,
-                const double *normal, int singular_mode, int is_rank0,
+                const double *normal, double solid_normal_diag, int singular_mode, int is_rank0,
                 const int *rowptr, const int *colidx, double *val,
                 double *b, double *work) {
   const int n = P->nlocal, dim = P->dim;
@@ -666,12 +665,53 @@ int orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
                                  0, rowptr, colidx, val);                           /* :93-96 */
   if (bad) return -1;
   if (neumann && normal != NULL) {
-    for (int i = 0; i < n; ++i)
-      if (kind_of(P, i) & ORC_KIND_SOLID) {
-        double nn = 0.0;
-        for (int k = 0; k < dim; ++k) nn += normal[3 * i + k] * normal[3 * i + k];
-        if (nn > 0.5) return -2; /* wall Neumann rows: not restated yet */
+    /* homogeneous Neumann rows on the wall particles (:98-107):
+     * FunctorOuterGradientDotOperatorMatrix(normal, alpha=-dt), filter (Solid, All)
+     * (ref: functor_gradient_dot_operator_matrix.h:39-79) on top of
+     * FunctorOuterGradientOperator (ref: functor_gradient_operator.h:74-169): always G_i and V_j,
+     * self entry first. */
+    const int d2 = dim * dim;
+    int maxn = 0;
+    for (int i = 0; i < n; ++i) {
+      const int m = P->neigh_ptr[i + 1] - P->neigh_ptr[i] + 1;
+      if (m > maxn) maxn = m;
+    }
+    double *gv = (double *)malloc(sizeof(double) * (size_t)maxn);
+    int *gi = (int *)malloc(sizeof(int) * (size_t)maxn);
+    for (int i = 0; i < n; ++i) {
+      const int it = P->type[i], ikind = kind_of(P, i);
+      if (!fyes1(ORC_KIND_SOLID, ikind)) continue;
+      const double *G = &P->Gc[(size_t)i * d2];
+      int cnt = 0;
+      gi[cnt] = P->colmap[i];
+      gv[cnt++] = 0.0;
+      for (int jj = P->neigh_ptr[i]; jj < P->neigh_ptr[i + 1]; ++jj) {
+        const int j = P->neigh_idx[jj];
+        const int jt = P->type[j];
+        double rsq = 0.0, rij[3] = {0, 0, 0};
+        for (int k = 0; k < dim; ++k) {
+          rij[k] = P->x[3 * i + k] - P->x[3 * j + k];
+          rsq += rij[k] * rij[k];
+        }
+        if (rsq < tab(P, P->cutsq, it, jt)) {
+          const double r = sqrt(rsq) + ORC_EPS;
+          const double dwdr = orc_kernel_dval(P->kernel, dim, r, tab(P, P->h, it, jt));
+          const double vjtmp = dwdr / r * P->vfrac[j];   /* coeff = 1: particle i is solid */
+          double v = 0.0;
+          for (int k2 = 0; k2 < dim; ++k2) {
+            double gitmp = 0.0;
+            for (int k1 = 0; k1 < dim; ++k1) gitmp += G2(G, dim, k1, k2) * rij[k1];
+            v += (gitmp * vjtmp) * (-dt) * normal[3 * i + k2];
+          }
+          gi[cnt] = P->colmap[j];
+          gv[cnt++] = v;
+          gv[0] -= v;
+        }
       }
+      if (sum_into(rowptr, colidx, val, i, cnt, gv, gi)) { free(gv); free(gi); return -1; }
+    }
+    free(gv);
+    free(gi);
   }
   /* diag bookkeeping: ExtractDiagonalCopy ... ReplaceDiagonalValues (:109,:179-181) */
   orc_divergence(P, antisym, vstar, 1.0, 1, ORC_KIND_FLUID, ORC_KIND_ALL, morris_holmes, b); /* :113-116 */
@@ -684,7 +724,10 @@ int orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
       if (neumann) {
         double nn = 0.0;
         if (normal) for (int k = 0; k < dim; ++k) nn += normal[3 * i + k] * normal[3 * i + k];
-        if (nn < 0.5) diag = 1.0;
+        /* with a wall normal the functor leaves A.diagonal[i] untouched: the row keeps whatever
+         * the vector held before (1 after the scalar Helmholtz pass of the same step, 0 when only
+         * block matrices were built; pair_isph.cpp:1269, functor_incomp_navier_stokes_helmholtz.h:114-117) */
+        diag = nn < 0.5 ? 1.0 : solid_normal_diag;
       } else diag = 1.0;
       b[i] = 0.0;
     } else { /* Fluid / buffers, :150-164 */

@@ -106,7 +106,7 @@ void orc_laplacian_apply(const orc_particles *P, int antisym, const double *f,
                          int filt_i, int filt_j, double *lap);
 int  orc_poisson(const orc_particles *P, int antisym, int morris_holmes,
                  double dt, const double *rho, const double *vstar,
-                 const double *normal, int singular_mode, int is_rank0,
+                 const double *normal, double solid_normal_diag, int singular_mode, int is_rank0,
                  const int *rowptr, const int *colidx, double *val,
                  double *b, double *work);
 

@@ -72,7 +72,7 @@ def lib():
         L.orc_laplacian_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                           C.c_int, C.c_int, C.c_void_p]
         L.orc_poisson.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
         L.orc_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_helmholtz.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -192,7 +192,7 @@ class Particles:
         return arr
 
     def poisson(self, dt, rho, vstar, antisym=True, singular=NULLSPACE, normal=None, morris=0, rank0=True,
-                graph=None):
+                graph=None, solid_normal_diag=1.0):
         rowptr, colidx = graph if graph is not None else self.graph()
         val = np.zeros(len(colidx))
         b = np.zeros(self.nlocal)
@@ -200,7 +200,7 @@ class Particles:
         rho, vstar = _f64(rho), _f64(vstar)
         nrm = None if normal is None else _f64(normal)
         rc = lib().orc_poisson(self.ref(), int(antisym), morris, float(dt), _p(rho), _p(vstar), _p(nrm),
-                               singular, int(rank0), _p(rowptr), _p(colidx), _p(val), _p(b), _p(work))
+                               float(solid_normal_diag), singular, int(rank0), _p(rowptr), _p(colidx), _p(val), _p(b), _p(work))
         assert rc == 0, "orc_poisson rc=%d" % rc
         return rowptr, colidx, val, b
 

@@ -19,7 +19,7 @@ class Problem:
     """particles + oracle precompute + oracle Poisson system for one rank."""
 
     def __init__(self, spec, antisym=True, singular=orc.NULLSPACE, kinds=None, types=None, pnd=None,
-                 morris_safe_coeff=0.43301):
+                 morris_safe_coeff=0.43301, normal=None, solid_normal_diag=1.0):
         self.spec = spec
         self.parts = workload.make_tgv(spec)
         if types is not None:
@@ -31,7 +31,11 @@ class Problem:
         self.safe = morris_safe_coeff
         self.P = orc.Particles(self.parts, self.colmap, kernel=spec.kernel, kinds=kinds, pnd=self.pnd,
                                morris_safe_coeff=morris_safe_coeff)
-        self.P.precompute(corrections=not antisym)
+        self.normal = None if normal is None else np.ascontiguousarray(normal(self.parts))
+        self.solid_normal_diag = solid_normal_diag
+        # computePre always forms G_i/L_i (pair_isph_corrected.cpp:302-313); only the wall rows and the
+        # Symmetric family read them
+        self.P.precompute(corrections=(not antisym) or normal is not None)
         if not antisym:  # ghosts need the owner's G_i / L_i only through row i: no comm needed
             pass
         self.n = self.parts["nlocal"]
@@ -39,7 +43,7 @@ class Problem:
     def poisson(self):
         p = self.parts
         return self.P.poisson(self.spec.dt, p["rho"], p["v"], antisym=self.antisym, singular=self.singular,
-                              morris=self.morris)
+                              morris=self.morris, normal=self.normal, solid_normal_diag=self.solid_normal_diag)
 
 
 def wall_types(parts):
@@ -57,3 +61,13 @@ def fake_pnd(parts):
     dx = parts["spec"].dx
     d = (1.0 / dx ** parts["dim"]) * (0.9 + 0.2 * np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]))
     return d[own]
+
+
+def wall_normals(parts):
+    """unit normal +y on the solid particles next to the fluid (upper part of the slab), zero elsewhere"""
+    own = parts["owner_index"]
+    x = parts["x"][:parts["nlocal"]]
+    y = x[:, 1] % (2 * np.pi)
+    nrm = np.zeros((parts["nlocal"], 3))
+    nrm[(y < 0.9) & (y > 0.35), 1] = 1.0
+    return nrm[own]

@@ -478,3 +478,34 @@ def test_device_pointer_paths(gpu_ctx):
     assert np.array_equal(xd.cpu().numpy(), xh) and np.array_equal(bd.cpu().numpy(), bh)   # deterministic reductions
     with pytest.raises(ValueError):
         hip.solve(gpu_ctx, Ad, bd, xh, prec=M, singular=True)          # mixing host and device operands is refused
+
+
+# ---------------------------------------------------------------- wall Neumann rows
+from problems import wall_normals  # noqa: E402
+
+
+@pytest.mark.parametrize("dim,n", [(2, 20), (3, 12)])
+@pytest.mark.parametrize("antisym", [True, False])
+@pytest.mark.parametrize("snd", [1.0, 0.0])
+def test_gpu_poisson_wall_neumann_rows(gpu_ctx, dim, n, antisym, snd):
+    """Solid rows with a wall normal carry -dt n.grad (functor_gradient_dot_operator_matrix.h); their diagonal is
+    the state A.diagonal was left in (solid_normal_diag), solids without a normal get a unit row."""
+    pr = Problem(tgv_spec(dim=dim, n=n, mode=workload.JITTER), antisym=antisym, singular=orc.NULLSPACE,
+                 kinds=[orc.FLUID, orc.SOLID], types=wall_types, normal=wall_normals, solid_normal_diag=snd)
+    solid = pr.parts["type"][:pr.n] == 2
+    withn = np.abs(pr.normal[:pr.n]).sum(axis=1) > 0.5
+    assert (solid & withn).sum() > 0 and (solid & ~withn).sum() > 0
+    rp, ci, val, b = pr.poisson()
+    A, bg = hip.assemble_poisson(gpu_ctx, pr.parts, pr.colmap, pr.spec.dt, pr.parts["rho"],
+                                 np.ascontiguousarray(pr.parts["v"]), antisym=antisym, singular=orc.NULLSPACE,
+                                 vfrac=pr.P.vfrac, kinds=[orc.FLUID, orc.SOLID], Gc=pr.P.Gc,
+                                 Lc=None if antisym else pr.P.Lc, normal=pr.normal, solid_normal_diag=snd)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci)
+    assert np.max(np.abs(v2 - val)) < 1e-12 * np.abs(val).max()
+    assert np.max(np.abs(bg - b)) < 1e-12 * np.abs(b).max()
+    M = sps.csr_matrix((v2, ci2, rp2))
+    d = M.diagonal()
+    assert np.all(d[solid & withn] == snd) and np.all(d[solid & ~withn] == 1.0)
+    offdiag = np.abs(M - sps.diags(d)).sum(axis=1).A1
+    assert np.all(offdiag[solid & withn] > 0) and np.all(offdiag[solid & ~withn] == 0)
