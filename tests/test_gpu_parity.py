@@ -509,3 +509,33 @@ def test_gpu_poisson_wall_neumann_rows(gpu_ctx, dim, n, antisym, snd):
     assert np.all(d[solid & withn] == snd) and np.all(d[solid & ~withn] == 1.0)
     offdiag = np.abs(M - sps.diags(d)).sum(axis=1).A1
     assert np.all(offdiag[solid & withn] > 0) and np.all(offdiag[solid & ~withn] == 0)
+
+
+# ---------------------------------------------------------------- BASELINE configs[0]: 2-D TGV 128^2, CG + ILU(0)
+def test_baseline_config0_2d_tgv_cg_ilu0(gpu_ctx):
+    """BASELINE.json configs[0]: 2-D Taylor-Green vortex (fix_isph_tgv lattice, origin 0.5), ~16k particles,
+    Wendland, CG + ILU(0) (the USER-REAXC-T defaults: Block CG, tol 1e-6,
+    USER-REAXC-T/solver_lin_belos.h:236-245, precond_ifpack.h:35).  Exact lattice => the
+    momentum-preserving operator is symmetric, so CG applies; one ILU(0) subdomain of 1024 rows per block."""
+    pr = Problem(tgv_spec(dim=2, n=128, mode=workload.LATTICE, brick=8))
+    assert pr.n == 16384
+    rp, ci, val, _ = pr.poisson()
+    A0 = _csr(rp, ci, val, pr.n)
+    assert abs(A0 - A0.T).max() < 1e-12 * abs(A0).max()
+    x = pr.parts["x"][:pr.n]
+    b = -0.5 * (np.cos(2 * x[:, 0]) + np.cos(2 * x[:, 1]))          # TGV pressure source shape (the lattice RHS itself is ~1e-16)
+    bs = 1024
+    bp = np.arange(0, pr.n + bs, bs).clip(0, pr.n).astype(np.int32)
+    prm_o = orc.SolverParams(solver_type=1, tol=1e-6)
+    xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp), params=prm_o)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", bs)
+    bg, xg = b.copy(), np.zeros(pr.n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=True, params=hip.SolverParams(solver_type=1, tol=1e-6))
+    assert io.converged and info.converged == 1 and abs(info.iters - io.iters) <= 1
+    # both stop at 1e-6 relative residual: the solutions agree to that level times the conditioning of the
+    # restricted operator; in practice far better because the iterations track each other
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+    r = bg - A0 @ xg
+    r -= r.mean()
+    assert np.linalg.norm(r) / np.linalg.norm(bg) <= 2e-6
