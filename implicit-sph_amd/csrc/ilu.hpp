@@ -39,6 +39,7 @@ struct isph_ilu {
   isph::DevBuf<int> llev;         // [n] L-level of every row (level-synchronous factorisation)
   isph::DevBuf<double> dinv;      // [n] 1/d_i
   long long stream_chunks = 0;
+  int capf = 0, slack = 0;  // stream capacity rule in force (see kCapFactorSafe)
 };
 
 namespace isph {
@@ -121,11 +122,16 @@ constexpr int kRowShift = 11, kGShift = 22;
 constexpr unsigned kEndBit = 0x80000000u;
 constexpr int kPrefetch = 8;      // chunks kept in flight per wave
 constexpr int kPadChunks = 16;    // per-block tail pad so the prefetch never leaves the buffer
-constexpr int kSlackChunks = 64;  // per-block slack on top of kCapFactor x the block's ELL region
+// Capacity is (capf x the block's ELL region + slack) chunks per block.  First attempt: capf 3, slack 64
+// (the 3-D production matrices use ~1.75 x).  A step of r rows uses max_r ceil(ndep/G) <= sum(ndep)/8 + 1
+// chunks and there are at most 2 m steps, so capf 8 with slack 2 B can never overflow: the build falls back
+// to that bound when the first attempt reports an overflow (small 2-D blocks with one row per level).
+constexpr int kSlackChunks = 64;
 constexpr int kCapFactor = 3;
+constexpr int kCapFactorSafe = 8;
 
-__device__ __forceinline__ long long ilu_base_chunk(const long long *slice_off, int b, int B) {
-  return kCapFactor * (slice_off[(long long)b * (B / 64)] >> 6) + (long long)(kPadChunks + kSlackChunks) * b;
+__device__ __forceinline__ long long ilu_base_chunk(const long long *slice_off, int b, int B, int capf, int slack) {
+  return capf * (slice_off[(long long)b * (B / 64)] >> 6) + (long long)(kPadChunks + slack) * b;
 }
 
 __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long long *__restrict__ slice_off,
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        const int *__restrict__ fdiag, double *__restrict__ sv,
                                                        unsigned *__restrict__ sc, int *__restrict__ fdst,
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
-                                                       int ccap, int *__restrict__ err) {
+                                                       int ccap, int capf, int slack, int *__restrict__ err) {
   extern __shared__ int lds_i[];
   int *lev = lds_i;              // [B]
   int *cnt = lev + B;            // [B+1]
@@ -150,8 +156,8 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   const int i = blo + t;
   const int nslices_blk = (m + 63) / 64;
   const long long region = slice_off[(long long)b * (B / 64) + nslices_blk] - slice_off[(long long)b * (B / 64)];
-  const long long cap = kCapFactor * (region >> 6) + kSlackChunks;
-  const long long base = ilu_base_chunk(slice_off, b, B);
+  const long long cap = capf * (region >> 6) + slack;
+  const long long base = ilu_base_chunk(slice_off, b, B, capf, slack);
   long long rp = 0;
   int len = 0, dg = 0;
   if (active) {
@@ -414,7 +420,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
                                                                  const int *__restrict__ flen,
                                                                  const int *__restrict__ fdiag,
                                                                  const double *__restrict__ dinv,
-                                                                 const double *__restrict__ r, double *__restrict__ z) {
+                                                                 const double *__restrict__ r, double *__restrict__ z,
+                                                                 int capf, int slack) {
   extern __shared__ double lds_y[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * WAVES + wave;
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
   double *y = lds_y + (size_t)wave * B;
   const int blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   for (int t = lane; t < m; t += 64) y[t] = r[blo + t];
-  const long long base = ilu_base_chunk(slice_off, b, B);
+  const long long base = ilu_base_chunk(slice_off, b, B, capf, slack);
   const int nL = blkinfo[2 * b], nU = blkinfo[2 * b + 1];
   const double *__restrict__ pv = sv + base * 64 + lane;
   const unsigned *__restrict__ pc = sc + base * 64 + lane;
@@ -492,13 +499,14 @@ inline void ilu_destroy(isph_ilu *F) {
   delete F;
 }
 
-inline int ilu_check_err(isph_ctx *ctx, isph_ilu *F, const char *what) {
+inline int ilu_check_err(isph_ctx *ctx, isph_ilu *F, const char *what, bool *overflow = nullptr) {
   int herr = 0;
   if (hipGetLastError() != hipSuccess ||
       hipMemcpyAsync(&herr, F->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     return fail(what, __FILE__, __LINE__);
   if (herr & 1) return fail("matrix row without a diagonal entry: ILU(0) undefined", __FILE__, __LINE__);
+  if ((herr & 16) && overflow) { *overflow = true; return ISPH_SUCCESS; }
   if (herr & 16) return fail("ILU triangular-solve stream capacity exceeded", __FILE__, __LINE__);
   if (herr) return fail(what, __FILE__, __LINE__);
   return ISPH_SUCCESS;
@@ -512,7 +520,15 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   F->n = S.nrow; F->B = block_size; F->S = &S; F->wmax = S.wmax;
   F->nblocks = (S.nrow + block_size - 1) / block_size;
   const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
-  F->stream_chunks = kCapFactor * (S.stored >> 6) + (long long)(kPadChunks + kSlackChunks) * (F->nblocks + 1) + kPrefetch;
+  F->capf = kCapFactor; F->slack = kSlackChunks;
+  auto size_stream = [&]() {
+    F->stream_chunks = F->capf * (S.stored >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPrefetch;
+    int r = F->sv.reserve((size_t)F->stream_chunks * 64);
+    if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
+    if (r == ISPH_SUCCESS && (long long)F->stream_chunks * 64 >= 2147483647LL)
+      r = fail("ILU stream exceeds 32-bit indexing", __FILE__, __LINE__);
+    return r;
+  };
   int rc = F->fcol.reserve(stored);
   if (rc == ISPH_SUCCESS) rc = F->fval.reserve(stored);
   if (rc == ISPH_SUCCESS) rc = F->fdst.reserve(stored);
@@ -522,11 +538,8 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   if (rc == ISPH_SUCCESS) rc = F->dinv.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->llev.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->err.reserve(1);
-  if (rc == ISPH_SUCCESS) rc = F->sv.reserve((size_t)F->stream_chunks * 64);
-  if (rc == ISPH_SUCCESS) rc = F->sc.reserve((size_t)F->stream_chunks * 64);
+  if (rc == ISPH_SUCCESS) rc = size_stream();
   if (rc == ISPH_SUCCESS) rc = F->blkinfo.reserve((size_t)2 * (F->nblocks > 0 ? F->nblocks : 1));
-  if (rc == ISPH_SUCCESS && (long long)F->stream_chunks * 64 >= 2147483647LL)
-    rc = fail("ILU stream exceeds 32-bit indexing", __FILE__, __LINE__);
   if (rc == ISPH_SUCCESS && S.nrow > 0) {
     const int W = ((S.wmax + 63) / 64) * 64;
     const size_t Bz = (size_t)block_size;
@@ -545,12 +558,18 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_s) != hipSuccess)
         rc = fail("LDS attribute failed", __FILE__, __LINE__);
-      if (rc == ISPH_SUCCESS) {
+      for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
         hipLaunchKernelGGL(k_ilu_schedule, dim3(F->nblocks), dim3(block_size), lds_s, ctx->stream, S.nrow, block_size,
                            S.slice_off.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->fdst.p,
-                           F->blkinfo.p, F->llev.p, ccap, F->err.p);
+                           F->blkinfo.p, F->llev.p, ccap, F->capf, F->slack, F->err.p);
         // the factor kernel must not run on a partial schedule: check now (one sync per build)
-        rc = ilu_check_err(ctx, F, "ILU extract/schedule kernel failed");
+        bool overflow = false;
+        rc = ilu_check_err(ctx, F, "ILU extract/schedule kernel failed", attempt == 0 ? &overflow : nullptr);
+        if (!overflow) break;
+        F->capf = kCapFactorSafe; F->slack = 2 * block_size;  // proven bound, see kCapFactorSafe
+        rc = size_stream();
+        if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
+          rc = fail("memset failed", __FILE__, __LINE__);
       }
     }
     if (rc == ISPH_SUCCESS) {
@@ -576,7 +595,7 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
   const size_t lds = sizeof(double) * (size_t)F->B * WV;
   hipLaunchKernelGGL((k_ilu_solve_stream<WV>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, F->n,
                      F->B, F->nblocks, F->S->slice_off.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p,
-                     F->dinv.p, r, z);
+                     F->dinv.p, r, z, F->capf, F->slack);
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }

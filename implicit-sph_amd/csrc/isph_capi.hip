@@ -4,6 +4,7 @@
 #include <numeric>
 
 #include "assemble.hpp"
+#include "operators.hpp"
 #include "core.hpp"
 #include "ilu.hpp"
 #include "krylov.hpp"
@@ -548,6 +549,36 @@ int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_o
 int isph_compute_corrections(isph_ctx *ctx, const isph_particles *P, double *Gc_out, double *Lc_out, int on_device) {
   ISPH_REQUIRE(ctx && P && Gc_out && Lc_out, "NULL argument");
   return compute_corrections(ctx, P, Gc_out, Lc_out, on_device);
+}
+
+int isph_gradient(isph_ctx *ctx, const isph_particles *P, int antisym, const double *f, double alpha, int use_filter,
+                  int filt_i, int filt_j, double *grad_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && f && grad_out, "NULL argument");
+  return op_apply(ctx, P, 0, antisym, f, alpha, use_filter, filt_i, filt_j, grad_out, on_device);
+}
+
+int isph_divergence(isph_ctx *ctx, const isph_particles *P, int antisym, const double *f, double alpha, int use_filter,
+                    int filt_i, int filt_j, double *div_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && f && div_out, "NULL argument");
+  return op_apply(ctx, P, 1, antisym, f, alpha, use_filter, filt_i, filt_j, div_out, on_device);
+}
+
+int isph_correct_velocity_pressure(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, const double *rho,
+                                   const double *dp, double *vstar, double *p, int incremental_pressure, int on_device) {
+  ISPH_REQUIRE(ctx && P && rho && dp && vstar && p, "NULL argument");
+  return correct_velocity_pressure(ctx, P, antisym, dt, rho, dp, vstar, p, incremental_pressure, on_device);
+}
+
+int isph_advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, const double *p, const double *v,
+                       const double *vnp1, double *dp_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && p && v && vnp1 && dp_out, "NULL argument");
+  return advance_begin(ctx, P, antisym, dt, p, v, vnp1, dp_out, on_device);
+}
+
+int isph_advance_end(isph_ctx *ctx, int count, int dim, double dt, const double *dp, const double *vnp1, double *p,
+                     double *x, double *v, int on_device) {
+  ISPH_REQUIRE(ctx && dp && vnp1 && p && x && v && count >= 0, "bad argument");
+  return advance_end(ctx, count, dim, dt, dp, vnp1, p, x, v, on_device);
 }
 
 }  // extern "C"

@@ -20,7 +20,8 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections",
+    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_advance_begin", "isph_advance_end",
 ]
 
 
@@ -102,6 +103,15 @@ def lib():
                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_compute_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_compute_corrections.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        for fn in (L.isph_gradient, L.isph_divergence):
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int,
+                           C.c_void_p, C.c_int]
+        L.isph_correct_velocity_pressure.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.isph_advance_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_advance_end.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int]
         L.isph_assemble_helmholtz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -398,3 +408,51 @@ def compute_corrections(ctx, parts, colmap, vfrac, kernel="wendland"):
         G, Lc = np.zeros((nlocal, dim * dim)), np.zeros((nlocal, dL))
     _check(lib().isph_compute_corrections(ctx.h, C.byref(pv), _ptr(G), _ptr(Lc), dev))
     return G, Lc
+
+
+def gradient(ctx, parts, colmap, f, vfrac, antisym=True, alpha=1.0, filt=None, Gc=None, kernel="wendland", kinds=None):
+    """isph_gradient: scalar field f [nall] -> [nlocal, 3]."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
+    f = _f64(f)
+    out = np.zeros((int(parts["nlocal"]), 3))
+    fi, fj = filt if filt is not None else (127, 127)
+    _check(lib().isph_gradient(ctx.h, C.byref(pv), int(antisym), _ptr(f), float(alpha), int(filt is not None), fi, fj,
+                               _ptr(out), 0))
+    return out
+
+
+def divergence(ctx, parts, colmap, f, vfrac, antisym=True, alpha=1.0, filt=None, Gc=None, kernel="wendland", kinds=None):
+    """isph_divergence: vector field f [nall, 3] -> [nlocal]."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
+    f = _f64(f)
+    out = np.zeros(int(parts["nlocal"]))
+    fi, fj = filt if filt is not None else (127, 127)
+    _check(lib().isph_divergence(ctx.h, C.byref(pv), int(antisym), _ptr(f), float(alpha), int(filt is not None), fi, fj,
+                                 _ptr(out), 0))
+    return out
+
+
+def correct_velocity_pressure(ctx, parts, colmap, dt, rho, dp, vstar, p, vfrac, antisym=True, incremental=True, Gc=None,
+                              kernel="wendland"):
+    """in-place on vstar [nall,3] and p [nall] (numpy)."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep)
+    _check(lib().isph_correct_velocity_pressure(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(_f64(rho)),
+                                                _ptr(_f64(dp)), _ptr(vstar), _ptr(p), int(incremental), 0))
+
+
+def advance_begin(ctx, parts, colmap, dt, p, v, vnp1, vfrac, antisym=True, Gc=None, kernel="wendland"):
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep)
+    out = np.zeros(int(parts["nlocal"]))
+    _check(lib().isph_advance_begin(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(_f64(p)), _ptr(_f64(v)),
+                                    _ptr(_f64(vnp1)), _ptr(out), 0))
+    return out
+
+
+def advance_end(ctx, count, dim, dt, dp, vnp1, p, x, v):
+    """in-place on p [count], x [count,3], v [count,3] (numpy)."""
+    _check(lib().isph_advance_end(ctx.h, int(count), int(dim), float(dt), _ptr(_f64(dp)), _ptr(_f64(vnp1)), _ptr(p),
+                                  _ptr(x), _ptr(v), 0))

@@ -214,6 +214,29 @@ int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_o
  * ghosts' volumes already (forward comm). */
 int isph_compute_corrections(isph_ctx *ctx, const isph_particles *P, double *Gc_out, double *Lc_out, int on_device);
 
+/* ---- streaming operators either side of the solve -------- */
+
+/* Corrected::FunctorOuterGradient<.,AntiSymmetric?> (ref: functor_gradient.h:78-170): f [nall] ->
+ * grad_out [nlocal][3].  use_filter/filt_i/filt_j = FilterBinary particle-kind masks (filter.h:37-54). */
+int isph_gradient(isph_ctx *ctx, const isph_particles *P, int antisym, const double *f, double alpha,
+                  int use_filter, int filt_i, int filt_j, double *grad_out, int on_device);
+/* Corrected::FunctorOuterDivergence (ref: functor_divergence.h:54-124): f [nall][3] -> div_out [nlocal]. */
+int isph_divergence(isph_ctx *ctx, const isph_particles *P, int antisym, const double *f, double alpha,
+                    int use_filter, int filt_i, int filt_j, double *div_out, int on_device);
+/* PairISPH_Corrected::correctVelocity + correctPressure (ref: pair_isph_corrected.cpp:1020-1050,
+ * functor_correct_velocity.h, functor_correct_pressure.h): vstar [nall][3] (owned rows updated),
+ * p [nall] (all updated), dp [nall] with ghost values. */
+int isph_correct_velocity_pressure(isph_ctx *ctx, const isph_particles *P, int antisym, double dt,
+                                   const double *rho, const double *dp, double *vstar, double *p,
+                                   int incremental_pressure, int on_device);
+/* PairISPH_Corrected::advanceTime (ref: pair_isph_corrected.cpp:1172-1199): begin computes
+ * dp_out[nlocal] = grad p . dt/2 (vnp1+v); the caller forward-communicates it; end applies
+ * p += dp, x += dt/2 (vnp1+v), v = vnp1 to the first `count` atoms. */
+int isph_advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, const double *p,
+                       const double *v, const double *vnp1, double *dp_out, int on_device);
+int isph_advance_end(isph_ctx *ctx, int count, int dim, double dt, const double *dp, const double *vnp1,
+                     double *p, double *x, double *v, int on_device);
+
 #ifdef __cplusplus
 }
 #endif

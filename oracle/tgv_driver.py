@@ -82,7 +82,7 @@ def tgv_exact(x, t, umax, nu, rho):
 
 
 def run_tgv2d(N, nsteps, antisym=True, umax=0.1, nu=0.1, rho0=1.0, kernel="wendland", cut_over_h=2.0,
-              dt=None, prec="ilu", verbose=False):
+              dt=None, prec="ilu", verbose=False, return_state=False):
     L = 2 * np.pi
     dx = L / N
     h = 1.5 * dx
@@ -139,6 +139,8 @@ def run_tgv2d(N, nsteps, antisym=True, umax=0.1, nu=0.1, rho0=1.0, kernel="wendl
         x = x + dxp
         x[:, :2] %= L
         v = vstar
+    if return_state:
+        return hist, dict(x=x, v=v, p=p)
     return hist
 
 

@@ -209,6 +209,7 @@ ILU_CASES = [
     (dict(dim=3, n=12, mode=workload.JITTER, brick=4), 64),
     (dict(dim=3, n=16, mode=workload.ADVECT, brick=8), 512),
     (dict(dim=3, n=10, mode=workload.JITTER, kernel="quintic", cut_over_h=3.0, brick=5), 1024),  # one block, wide rows
+    (dict(dim=2, n=16, mode=workload.LATTICE, brick=16), 256),    # row-major block: few rows per level (stream fallback)
 ]
 
 
@@ -244,6 +245,32 @@ def test_gmres_bjacobi_ilu0_matches_oracle(gpu_ctx, case, bs):
     info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=True)
     assert info.converged == 1 and abs(info.iters - io.iters) <= 1
     assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+def test_ilu0_one_row_per_level_uses_the_safe_stream_capacity(gpu_ctx):
+    """Tridiagonal chain: every level holds one row, so the triangular-solve stream needs one chunk per row and
+    direction -- far above the first-attempt capacity; the build must fall back to its proven bound, not fail."""
+    n, bs = 1200, 512
+    rp = np.zeros(n + 1, np.int32)
+    ci, val = [], []
+    rng = np.random.default_rng(11)
+    for i in range(n):
+        for j in (i - 1, i, i + 1):
+            if 0 <= j < n:
+                ci.append(j)
+                val.append(4.0 + rng.random() if j == i else -1.0 - rng.random())
+        rp[i + 1] = len(ci)
+    ci, val = np.asarray(ci, np.int32), np.asarray(val)
+    bp = np.arange(0, n + bs, bs).clip(0, n).astype(np.int32)
+    ref = orc.ILU(rp, ci, val, 0, bp)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", bs)
+    frp, fci, fv = ref.export()
+    grp, gci, gv = M.export_ilu()
+    assert np.array_equal(grp, frp) and np.array_equal(gci, fci)
+    assert np.max(np.abs(gv - fv)) < 1e-12
+    r = rng.standard_normal(n)
+    assert np.linalg.norm(M.apply(r) - ref.apply(r)) / np.linalg.norm(r) < 1e-12
 
 
 def test_ilu_rejects_bad_block_size(gpu_ctx):
@@ -539,3 +566,68 @@ def test_baseline_config0_2d_tgv_cg_ilu0(gpu_ctx):
     r = bg - A0 @ xg
     r -= r.mean()
     assert np.linalg.norm(r) / np.linalg.norm(bg) <= 2e-6
+
+
+# ---------------------------------------------------------------- streaming operators
+@pytest.mark.parametrize("dim,kernel", [(2, "wendland"), (3, "wendland"), (3, "quintic")])
+@pytest.mark.parametrize("antisym", [True, False])
+@pytest.mark.parametrize("filt", [None, (orc.FLUID, orc.FLUID), (orc.FLUID, orc.ALL)])
+def test_gradient_and_divergence_match_oracle(gpu_ctx, dim, kernel, antisym, filt):
+    """functor_gradient.h / functor_divergence.h incl. the type filters, on a domain with a solid slab."""
+    n = 20 if dim == 2 else 10
+    pr = Problem(tgv_spec(dim=dim, n=n, mode=workload.JITTER, kernel=kernel), antisym=antisym,
+                 kinds=[orc.FLUID, orc.SOLID], types=wall_types)
+    parts, P = pr.parts, pr.P
+    nall = parts["nall"]
+    rng = np.random.default_rng(3)
+    own = parts["owner_index"]
+    f = rng.standard_normal(parts["nlocal"])[own]
+    u = rng.standard_normal((parts["nlocal"], 3))[own]
+    if dim == 2:
+        u[:, 2] = 0.0
+    Gc = None if antisym else P.Gc
+    kw = dict(antisym=antisym, alpha=0.7, filt=filt, Gc=Gc, kernel=kernel, kinds=[orc.FLUID, orc.SOLID])
+    g = hip.gradient(gpu_ctx, parts, pr.colmap, f, P.vfrac, **kw)
+    go = P.gradient(f, antisym, alpha=0.7, filt=filt)
+    assert np.max(np.abs(g - go)) <= 1e-12 * np.abs(go).max()
+    d = hip.divergence(gpu_ctx, parts, pr.colmap, u, P.vfrac, **kw)
+    do = P.divergence(u, antisym, alpha=0.7, filt=filt)
+    assert np.max(np.abs(d - do)) <= 1e-12 * np.abs(do).max()
+    assert nall == len(f)
+
+
+@pytest.mark.parametrize("antisym", [True, False])
+@pytest.mark.parametrize("incremental", [True, False])
+def test_correct_velocity_pressure_and_advance_match_oracle_formulas(gpu_ctx, antisym, incremental):
+    """functor_correct_velocity.h, functor_correct_pressure.h, functor_advance_time_{begin,end}.h."""
+    pr = Problem(tgv_spec(dim=3, n=10, mode=workload.JITTER), antisym=antisym)
+    parts, P = pr.parts, pr.P
+    n, own = parts["nlocal"], parts["owner_index"]
+    rng = np.random.default_rng(9)
+    dt = 0.013
+    rho = (1.0 + 0.2 * rng.random(n))[own]
+    dp = rng.standard_normal(n)[own]
+    vstar = rng.standard_normal((n, 3))[own]
+    p = rng.standard_normal(n)[own]
+    v = rng.standard_normal((n, 3))[own]
+    Gc = None if antisym else P.Gc
+    filt = (orc.FLUID, orc.FLUID)
+    gdp = P.gradient(dp, antisym, filt=filt)
+    vs_ref = vstar[:n] - dt / rho[:n, None] * gdp
+    p_ref = p + dp if incremental else dp.copy()       # over nlocal + nghost (pair_isph_corrected.cpp:1046)
+    vs_g, p_g = np.ascontiguousarray(vstar.copy()), p.copy()
+    hip.correct_velocity_pressure(gpu_ctx, parts, pr.colmap, dt, rho, dp, vs_g, p_g, P.vfrac, antisym=antisym,
+                                  incremental=incremental, Gc=Gc)
+    assert np.max(np.abs(vs_g[:n] - vs_ref)) <= 1e-12 * np.abs(vs_ref).max()
+    assert np.array_equal(p_g, p_ref)
+    assert np.array_equal(vs_g[n:], vstar[n:])          # ghost velocities wait for the next forward comm
+    # advance
+    dxp = 0.5 * dt * (vstar[:n] + v[:n])
+    dpa_ref = np.sum(P.gradient(p, antisym, filt=filt) * dxp, axis=1)
+    dpa = hip.advance_begin(gpu_ctx, parts, pr.colmap, dt, p, v, vstar, P.vfrac, antisym=antisym, Gc=Gc)
+    assert np.max(np.abs(dpa - dpa_ref)) <= 1e-12 * np.abs(dpa_ref).max()
+    x_g = np.ascontiguousarray(parts["x"][:n].copy())
+    v_g, pp = np.ascontiguousarray(v[:n].copy()), p[:n].copy()
+    hip.advance_end(gpu_ctx, n, 3, dt, dpa, np.ascontiguousarray(vstar[:n]), pp, x_g, v_g)
+    assert np.max(np.abs(x_g - (parts["x"][:n] + dxp))) < 1e-14
+    assert np.array_equal(v_g, vstar[:n]) and np.max(np.abs(pp - (p[:n] + dpa))) < 1e-14
