@@ -581,4 +581,23 @@ int isph_advance_end(isph_ctx *ctx, int count, int dim, double dt, const double 
   return advance_end(ctx, count, dim, dt, dp, vnp1, p, x, v, on_device);
 }
 
+int isph_compute_shift(isph_ctx *ctx, const isph_particles *P, double alpha, double shiftcut, double nonfluidweight,
+                       double *dr, int on_device) {
+  ISPH_REQUIRE(ctx && P && dr && shiftcut > 0.0, "bad argument");
+  return compute_shift(ctx, P, alpha, shiftcut, nonfluidweight, dr, on_device);
+}
+
+int isph_apply_shift(isph_ctx *ctx, const isph_particles *P, int antisym, const int *fixed, const double *dr, double *x,
+                     double *v, double *p, int on_device) {
+  ISPH_REQUIRE(ctx && P && dr && x && v && p, "bad argument");
+  return shift_apply(ctx, P, antisym, fixed, dr, 0.0, 1.0, 0.0, 0.0, x, v, p, nullptr, on_device);
+}
+
+int isph_shift_particles(isph_ctx *ctx, const isph_particles *P, int antisym, const int *fixed, double shift,
+                         double shiftcut, double nonfluidweight, double dt, double *x, double *v, double *p,
+                         double *vmax_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && x && v && p && shiftcut > 0.0, "bad argument");
+  return shift_apply(ctx, P, antisym, fixed, nullptr, shift, shiftcut, nonfluidweight, dt, x, v, p, vmax_out, on_device);
+}
+
 }  // extern "C"

@@ -9,6 +9,8 @@
 //   FunctorOuterCorrectVelocity                (ref: functor_correct_velocity.h:42-78)
 //   FunctorOuterCorrectPressure                (ref: functor_correct_pressure.h:30-45)
 //   FunctorOuterAdvanceTimeBegin / End         (ref: functor_advance_time_begin.h:40-75, functor_advance_time_end.h:45-72)
+//   FunctorOuterComputeShift / ApplyShift      (ref: functor_compute_shift.h:48-113, functor_apply_shift.h:76-108)
+//   PairISPH_Corrected::shiftParticles         (ref: pair_isph_corrected.cpp:1203-1262)
 // One lane per particle, neighbour list read through the lane-interleaved copy
 // (assemble.hpp), MirrorNothing coefficients.
 #pragma once
@@ -135,6 +137,134 @@ __global__ void k_advance_end(int n, int dim, double dt, const double *__restric
     x[3 * (size_t)i + k] += delta;
     v[3 * (size_t)i + k] = vnp1[3 * (size_t)i + k];
   }
+}
+
+// max over fluid particles of |v| (pair_isph_corrected.cpp:1216-1236); non-negative doubles order like their bit patterns
+__global__ void k_max_fluid_speed(int nlocal, int dim, const int *__restrict__ type, const int *__restrict__ kind,
+                                  const double *__restrict__ v, unsigned long long *__restrict__ vmax_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double mag = 0.0;
+  if (i < nlocal && (kind[type[i]] & KIND_FLUID)) {
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) { const double a = fabs(v[3 * (size_t)i + k]); s += a * a; }
+    mag = sqrt(s);
+  }
+  for (int o = 32; o > 0; o >>= 1) mag = fmax(mag, __shfl_xor(mag, o, 64));
+  if ((threadIdx.x & 63) == 0 && mag > 0.0) atomicMax(vmax_bits, (unsigned long long)__double_as_longlong(mag));
+}
+
+// dr_i = sum_j beta_ij r_ij, beta = alpha/r (ri/r)^2 (1 + [j not fluid] w (ri/r)^2), ri = mean neighbour distance;
+// fluid rows, filter (Fluid, All), pairs inside min(cutsq, shiftcut^2); alpha = alpha0 * (*scale) when scale != NULL
+__global__ __launch_bounds__(kBlock) void k_compute_shift(AsmTables T, OpArgs a, double alpha0,
+                                                          const double *__restrict__ scale, double shiftcutsq,
+                                                          double nonfluidweight, double *__restrict__ dr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nlocal) return;
+  const int dim = T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
+  double d[3] = {0, 0, 0};
+  if (ikind & KIND_FLUID) {
+    const double alpha = scale ? alpha0 * scale[0] : alpha0;
+    const int jb = a.nptr[i], je = a.nptr[i + 1];
+    int cnt = 0;
+    double ri = 0.0;
+    for (int jj = jb; jj < je; ++jj) {
+      const int j = neigh_at(T, i, jj - jb);
+      const int jt = a.type[j];
+      if (!(T.kind[jt] & KIND_ALL)) continue;
+      double rij[3];
+      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      if (rsq < fmin(T.cutsq[it * nt1 + jt], shiftcutsq)) { ++cnt; ri += sqrt(rsq); }
+    }
+    if (cnt) ri /= (double)cnt;
+    for (int jj = jb; jj < je; ++jj) {
+      const int j = neigh_at(T, i, jj - jb);
+      const int jt = a.type[j], jkind = T.kind[jt];
+      if (!(jkind & KIND_ALL)) continue;
+      double rij[3];
+      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      if (rsq < fmin(T.cutsq[it * nt1 + jt], shiftcutsq)) {
+        const double r = sqrt(rsq) + kEps, q = ri / r, rir2 = q * q;
+        const double beta = alpha / r * rir2 * (1.0 + ((jkind & KIND_FLUID) ? 0.0 : nonfluidweight) * rir2);
+        for (int k = 0; k < dim; ++k) d[k] += beta * rij[k];
+      }
+    }
+  }
+  for (int k = 0; k < 3; ++k) dr[3 * (size_t)i + k] = d[k];
+}
+
+// ApplyShift: p_i += grad p . dr_i, v_i^k += grad v^k . dr_i, x_i += dr_i (gradients with filter (Fluid, All)).
+// Every row reads the PRE-shift x / p / v and writes to xn / vn / pn: the reference's serial loop updates
+// them in place, so its row i sees rows < i already shifted -- an ordering artefact of O(|dr|^2) that no
+// parallel execution can (or should) reproduce; the oracle restates both and the tests bound the gap.
+__global__ __launch_bounds__(kBlock) void k_apply_shift(AsmTables T, OpArgs a, const int *__restrict__ fixed,
+                                                        const double *__restrict__ dr, const double *__restrict__ xin,
+                                                        const double *__restrict__ v, const double *__restrict__ p,
+                                                        double *__restrict__ xn, double *__restrict__ vn,
+                                                        double *__restrict__ pn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nlocal) return;
+  const int dim = T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
+  double gp[3] = {0, 0, 0}, gv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  const double pi = p[i];
+  double vi3[3], xi3[3], di[3];
+  for (int k = 0; k < 3; ++k) { vi3[k] = v[3 * (size_t)i + k]; xi3[k] = xin[3 * (size_t)i + k]; di[k] = dr[3 * (size_t)i + k]; }
+  const bool moves = !(fixed && fixed[it]);
+  if (moves && (ikind & KIND_FLUID)) {
+    double G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (dim == 2) { G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 1; }
+    if (!a.antisym)
+      for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
+    const double vfi = a.vfrac[i];
+    const int jb = a.nptr[i], je = a.nptr[i + 1];
+    for (int jj = jb; jj < je; ++jj) {
+      const int j = neigh_at(T, i, jj - jb);
+      const int jt = a.type[j];
+      if (!(T.kind[jt] & KIND_ALL)) continue;
+      double rij[3];
+      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
+      const double r = sqrt(rsq) + kEps;
+      const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
+      const double vfrac = a.antisym ? sqrt(vfi * a.vfrac[j]) : a.vfrac[j];
+      const double vjtmp = dwdr / r * vfrac;
+      const double dfp = a.antisym ? (pi + p[j]) : (p[j] - pi);
+      double dfv[3];
+      for (int k = 0; k < dim; ++k) {
+        const double vj = v[3 * (size_t)j + k];
+        dfv[k] = a.antisym ? (vi3[k] + vj) : (vj - vi3[k]);
+      }
+      for (int k2 = 0; k2 < dim; ++k2) {
+        double gitmp = 0.0;
+        for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
+        const double ijtmp = gitmp * vjtmp;
+        gp[k2] += ijtmp * dfp;
+        for (int k1 = 0; k1 < dim; ++k1) gv[k1][k2] += ijtmp * dfv[k1];
+      }
+    }
+  }
+  double pnew = pi;
+  if (moves) {
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) s += gp[k] * di[k];
+    pnew += s;
+    for (int k = 0; k < dim; ++k) {
+      double t = 0.0;
+      for (int q = 0; q < dim; ++q) t += gv[k][q] * di[q];
+      vi3[k] += t;
+      xi3[k] += di[k];
+    }
+  }
+  pn[i] = pnew;
+  for (int k = 0; k < 3; ++k) { vn[3 * (size_t)i + k] = vi3[k]; xn[3 * (size_t)i + k] = xi3[k]; }
+}
+
+__global__ void k_shift_commit(int nlocal, const double *__restrict__ xn, const double *__restrict__ vn,
+                               const double *__restrict__ pn, double *__restrict__ x, double *__restrict__ v,
+                               double *__restrict__ p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  p[i] = pn[i];
+  for (int k = 0; k < 3; ++k) { x[3 * (size_t)i + k] = xn[3 * (size_t)i + k]; v[3 * (size_t)i + k] = vn[3 * (size_t)i + k]; }
 }
 
 // common staging for the neighbour-sweep operators
@@ -306,6 +436,86 @@ inline int advance_end(isph_ctx *ctx, int count, int dim, double dt, const doubl
       rc = fail("advance kernel failed", __FILE__, __LINE__);
   }
   sdp.release(); svn.release(); ip.buf.release(); ix.buf.release(); iv.buf.release();
+  return rc;
+}
+
+// FunctorOuterComputeShift (ref: functor_compute_shift.h:48-113): dr[nlocal][3]
+inline int compute_shift(isph_ctx *ctx, const isph_particles *P, double alpha, double shiftcut, double nonfluidweight,
+                         double *dr, int on_device) {
+  OpStage st;
+  int rc = op_stage(ctx, P, 1, on_device, st);
+  const int n = P->nlocal;
+  double *dout = dr;
+  if (rc == ISPH_SUCCESS && !on_device) { rc = st.out.reserve((size_t)(n > 0 ? n : 1) * 3); dout = st.out.p; }
+  if (rc == ISPH_SUCCESS && n > 0) {
+    hipLaunchKernelGGL(k_compute_shift, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, st.T, st.a, alpha,
+                       (const double *)nullptr, shiftcut * shiftcut, nonfluidweight, dout);
+    if (!on_device && hipMemcpyAsync(dr, dout, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      rc = fail("copy failed", __FILE__, __LINE__);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+      rc = fail("shift kernel failed", __FILE__, __LINE__);
+  }
+  st.release();
+  return rc;
+}
+
+// shift step on a staged particle set: optional compute (dr == NULL: shift distance from shift*dt*vmax, the
+// whole PairISPH_Corrected::shiftParticles, pair_isph_corrected.cpp:1203-1262) then ApplyShift.
+// x, v [nall][3], p [nall] are updated on their nlocal rows.
+inline int shift_apply(isph_ctx *ctx, const isph_particles *P, int antisym, const int *fixed, const double *dr_in,
+                       double shift, double shiftcut, double nonfluidweight, double dt, double *x, double *v, double *p,
+                       double *vmax_out, int on_device) {
+  OpStage st;
+  int rc = op_stage(ctx, P, antisym, on_device, st);
+  const int n = P->nlocal, n1 = n > 0 ? n : 1;
+  DevBuf<double> sdr, xn, vn, pn, scal;
+  DevBuf<int> sfix;
+  InOut ix, iv, ip;
+  const double *ddr = nullptr;
+  const int *dfix = nullptr;
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, fixed, (size_t)P->ntypes + 1, 0, sfix, &dfix);
+  if (rc == ISPH_SUCCESS) rc = xn.reserve((size_t)n1 * 3);
+  if (rc == ISPH_SUCCESS) rc = vn.reserve((size_t)n1 * 3);
+  if (rc == ISPH_SUCCESS) rc = pn.reserve((size_t)n1);
+  if (rc == ISPH_SUCCESS) rc = scal.reserve(2);
+  if (rc == ISPH_SUCCESS) rc = ix.open(ctx, x, (size_t)P->nall * 3, on_device);
+  if (rc == ISPH_SUCCESS) rc = iv.open(ctx, v, (size_t)P->nall * 3, on_device);
+  if (rc == ISPH_SUCCESS) rc = ip.open(ctx, p, (size_t)P->nall, on_device);
+  double vmax = 0.0;
+  if (rc == ISPH_SUCCESS && dr_in) rc = stage(ctx, dr_in, (size_t)n * 3, on_device, sdr, &ddr);
+  const int grid = (n1 + kBlock - 1) / kBlock;
+  if (rc == ISPH_SUCCESS && !dr_in) {
+    // vshift = max fluid speed over all ranks (MPI_Allreduce MAX in the reference)
+    rc = sdr.reserve((size_t)n1 * 3);
+    if (rc == ISPH_SUCCESS && hipMemsetAsync(scal.p, 0, 2 * sizeof(double), ctx->stream) != hipSuccess)
+      rc = fail("memset failed", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) {
+      if (n > 0)
+        hipLaunchKernelGGL(k_max_fluid_speed, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, st.a.type, st.T.kind,
+                           (const double *)iv.dev, reinterpret_cast<unsigned long long *>(scal.p));
+      if (ctx->comm && ncclAllReduce(scal.p, scal.p, 1, ncclDouble, ncclMax, ctx->comm, ctx->stream) != ncclSuccess)
+        rc = fail("ncclAllReduce(max) failed", __FILE__, __LINE__);
+      if (n > 0)
+        hipLaunchKernelGGL(k_compute_shift, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, shift * dt,
+                           (const double *)scal.p, shiftcut * shiftcut, nonfluidweight, sdr.p);
+      ddr = sdr.p;
+      if (vmax_out && hipMemcpyAsync(&vmax, scal.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = fail("copy failed", __FILE__, __LINE__);
+    }
+  }
+  if (rc == ISPH_SUCCESS && n > 0) {
+    hipLaunchKernelGGL(k_apply_shift, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, dfix, ddr,
+                       (const double *)ix.dev, (const double *)iv.dev, (const double *)ip.dev, xn.p, vn.p, pn.p);
+    hipLaunchKernelGGL(k_shift_commit, dim3(grid), dim3(kBlock), 0, ctx->stream, n, (const double *)xn.p,
+                       (const double *)vn.p, (const double *)pn.p, ix.dev, iv.dev, ip.dev);
+    if (ix.close(ctx) != ISPH_SUCCESS || iv.close(ctx) != ISPH_SUCCESS || ip.close(ctx) != ISPH_SUCCESS) rc = ISPH_FAILURE;
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+    rc = rc == ISPH_SUCCESS ? fail("shift kernels failed", __FILE__, __LINE__) : rc;
+  if (vmax_out) *vmax_out = vmax;
+  sdr.release(); xn.release(); vn.release(); pn.release(); scal.release(); sfix.release();
+  ix.buf.release(); iv.buf.release(); ip.buf.release();
+  st.release();
   return rc;
 }
 

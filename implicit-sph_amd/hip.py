@@ -21,7 +21,7 @@ EXPORTS = [
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
-    "isph_advance_begin", "isph_advance_end",
+    "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
 ]
 
 
@@ -112,6 +112,12 @@ def lib():
                                          C.c_void_p, C.c_void_p, C.c_int]
         L.isph_advance_end.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_compute_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int]
+        L.isph_apply_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int]
+        L.isph_shift_particles.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int]
         L.isph_assemble_helmholtz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -456,3 +462,32 @@ def advance_end(ctx, count, dim, dt, dp, vnp1, p, x, v):
     """in-place on p [count], x [count,3], v [count,3] (numpy)."""
     _check(lib().isph_advance_end(ctx.h, int(count), int(dim), float(dt), _ptr(_f64(dp)), _ptr(_f64(vnp1)), _ptr(p),
                                   _ptr(x), _ptr(v), 0))
+
+
+def compute_shift(ctx, parts, colmap, alpha, shiftcut, nonfluidweight, kernel="wendland", kinds=None):
+    """isph_compute_shift -> dr [nlocal, 3]."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=np.ones(int(parts["nall"])), keep=keep, kinds=kinds)
+    dr = np.zeros((int(parts["nlocal"]), 3))
+    _check(lib().isph_compute_shift(ctx.h, C.byref(pv), float(alpha), float(shiftcut), float(nonfluidweight), _ptr(dr), 0))
+    return dr
+
+
+def apply_shift(ctx, parts, colmap, dr, x, v, p, vfrac, antisym=True, fixed=None, Gc=None, kernel="wendland", kinds=None):
+    """isph_apply_shift: in place on x, v [nall,3] and p [nall] (numpy)."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
+    fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.int32)
+    _check(lib().isph_apply_shift(ctx.h, C.byref(pv), int(antisym), _ptr(fx), _ptr(_f64(dr)), _ptr(x), _ptr(v), _ptr(p), 0))
+
+
+def shift_particles(ctx, parts, colmap, shift, shiftcut, nonfluidweight, dt, x, v, p, vfrac, antisym=True, fixed=None,
+                    Gc=None, kernel="wendland", kinds=None):
+    """isph_shift_particles: in place on x, v, p; returns the max fluid speed used."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
+    fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.int32)
+    vmax = C.c_double(0.0)
+    _check(lib().isph_shift_particles(ctx.h, C.byref(pv), int(antisym), _ptr(fx), float(shift), float(shiftcut),
+                                      float(nonfluidweight), float(dt), _ptr(x), _ptr(v), _ptr(p), C.byref(vmax), 0))
+    return vmax.value

@@ -237,6 +237,23 @@ int isph_advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, doub
 int isph_advance_end(isph_ctx *ctx, int count, int dim, double dt, const double *dp, const double *vnp1,
                      double *p, double *x, double *v, int on_device);
 
+/* Particle shifting (fix isph/shift -> PairISPH_Corrected::shiftParticles, pair_isph_corrected.cpp:1203-1262).
+ * isph_compute_shift replaces FunctorOuterComputeShift (functor_compute_shift.h:48-113): dr[nlocal][3] for the fluid
+ * particles, pairs inside min(cutsq, shiftcut^2), alpha = shift*dt*vmax.
+ * isph_apply_shift replaces FunctorOuterApplyShift (functor_apply_shift.h:76-108): p += grad p . dr,
+ * v_k += grad v_k . dr, x += dr on the nlocal rows of x, v [nall][3], p [nall]; types with fixed[type] != 0
+ * (PairISPH::isParticleFixed; fixed may be NULL) do not move.  All rows read the pre-shift state (the reference's
+ * serial loop lets row i see rows < i already shifted).
+ * isph_shift_particles is the whole shiftParticles(): vmax = max fluid |v| over all ranks (returned in *vmax_out
+ * when not NULL), dr from shift*dt*vmax, then the apply. */
+int isph_compute_shift(isph_ctx *ctx, const isph_particles *P, double alpha, double shiftcut, double nonfluidweight,
+                       double *dr, int on_device);
+int isph_apply_shift(isph_ctx *ctx, const isph_particles *P, int antisym, const int *fixed, const double *dr,
+                     double *x, double *v, double *p, int on_device);
+int isph_shift_particles(isph_ctx *ctx, const isph_particles *P, int antisym, const int *fixed, double shift,
+                         double shiftcut, double nonfluidweight, double dt, double *x, double *v, double *p,
+                         double *vmax_out, int on_device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -609,6 +609,104 @@ void orc_gradient(const orc_particles *P, int antisym, const double *f,
   }
 }
 
+/* FunctorOuterComputeShift (ref: functor_compute_shift.h:48-113): dr_i for
+ * fluid particles, filter (Fluid, All); alpha = shift*dt*vmax. */
+void orc_compute_shift(const orc_particles *P, double alpha, double shiftcut, double nonfluidweight, double *dr) {
+  const int dim = P->dim;
+  const double shiftcutsq = shiftcut * shiftcut;
+  for (int i = 0; i < P->nlocal; ++i) {
+    const int it = P->type[i], ikind = kind_of(P, i);
+    dr[3 * i] = dr[3 * i + 1] = dr[3 * i + 2] = 0.0;
+    if (!fyes1(ORC_KIND_FLUID, ikind)) continue;
+    int cnt = 0;
+    double ri = 0.0;
+    for (int jj = P->neigh_ptr[i]; jj < P->neigh_ptr[i + 1]; ++jj) {
+      const int j = P->neigh_idx[jj], jt = P->type[j], jkind = kind_of(P, j);
+      if (!fyes2(ORC_KIND_FLUID, ORC_KIND_ALL, ikind, jkind)) continue;
+      double rsq = 0.0;
+      for (int k = 0; k < dim; ++k) rsq += pow(P->x[3 * i + k] - P->x[3 * j + k], 2);
+      const double c = tab(P, P->cutsq, it, jt), rth = c < shiftcutsq ? c : shiftcutsq;
+      if (rsq < rth) { ++cnt; ri += sqrt(rsq); }
+    }
+    if (cnt) ri /= (double)cnt;
+    for (int jj = P->neigh_ptr[i]; jj < P->neigh_ptr[i + 1]; ++jj) {
+      const int j = P->neigh_idx[jj], jt = P->type[j], jkind = kind_of(P, j);
+      if (!fyes2(ORC_KIND_FLUID, ORC_KIND_ALL, ikind, jkind)) continue;
+      double rsq = 0.0, rij[3] = {0, 0, 0};
+      for (int k = 0; k < dim; ++k) { rij[k] = P->x[3 * i + k] - P->x[3 * j + k]; rsq += rij[k] * rij[k]; }
+      const double c = tab(P, P->cutsq, it, jt), rth = c < shiftcutsq ? c : shiftcutsq;
+      if (rsq < rth) {
+        const double r = sqrt(rsq) + ORC_EPS, rir2 = pow(ri / r, 2);
+        const double beta = alpha / r * rir2 * (1.0 + (!(jkind & ORC_KIND_FLUID)) * nonfluidweight * rir2);
+        for (int k = 0; k < dim; ++k) dr[3 * i + k] += beta * rij[k];
+      }
+    }
+  }
+}
+
+/* corrected gradients of p and of the dim components of v at row i with the
+ * (Fluid, All) filter, geometry from x (functor_gradient.h:78-170 as used by
+ * functor_apply_shift.h:60-66) */
+static void shift_gradients(const orc_particles *P, int antisym, const double *x, const double *v, const double *p,
+                            int i, double gp[3], double gv[3][3]) {
+  const int dim = P->dim, d2 = dim * dim;
+  double Gi[9] = {0};
+  for (int k = 0; k < dim; ++k) G2(Gi, dim, k, k) = 1.0;
+  const int it = P->type[i], ikind = kind_of(P, i);
+  for (int k = 0; k < 3; ++k) { gp[k] = 0.0; gv[0][k] = gv[1][k] = gv[2][k] = 0.0; }
+  if (!fyes1(ORC_KIND_FLUID, ikind)) return;
+  const double *G = antisym ? Gi : &P->Gc[(size_t)i * d2];
+  for (int jj = P->neigh_ptr[i]; jj < P->neigh_ptr[i + 1]; ++jj) {
+    const int j = P->neigh_idx[jj], jt = P->type[j], jkind = kind_of(P, j);
+    if (!fyes2(ORC_KIND_FLUID, ORC_KIND_ALL, ikind, jkind)) continue;
+    double rsq = 0.0, rij[3] = {0, 0, 0};
+    for (int k = 0; k < dim; ++k) { rij[k] = x[3 * i + k] - x[3 * j + k]; rsq += rij[k] * rij[k]; }
+    if (rsq < tab(P, P->cutsq, it, jt)) {
+      const double r = sqrt(rsq) + ORC_EPS;
+      const double dwdr = orc_kernel_dval(P->kernel, dim, r, tab(P, P->h, it, jt));
+      const double vfrac = antisym ? sqrt(P->vfrac[i] * P->vfrac[j]) : P->vfrac[j];
+      const double vjtmp = dwdr / r * vfrac;
+      for (int k2 = 0; k2 < dim; ++k2) {
+        double gitmp = 0.0;
+        for (int k1 = 0; k1 < dim; ++k1) gitmp += G2(G, dim, k1, k2) * rij[k1];
+        const double ijtmp = gitmp * vjtmp;
+        gp[k2] += ijtmp * sph_op(antisym, p[i], p[j]);
+        for (int k1 = 0; k1 < dim; ++k1) gv[k1][k2] += ijtmp * sph_op(antisym, v[3 * i + k1], v[3 * j + k1]);
+      }
+    }
+  }
+}
+
+/* FunctorOuterApplyShift (ref: functor_apply_shift.h:76-108) */
+void orc_apply_shift(const orc_particles *P, int antisym, const int *fixed, const double *dr, double *x, double *v,
+                     double *p, int sequential) {
+  const int dim = P->dim, n = P->nlocal;
+  double *x0 = x, *v0 = v, *p0 = p;
+  if (!sequential) {  /* every row reads the pre-shift state */
+    x0 = (double *)malloc(sizeof(double) * 3 * (size_t)P->nall);
+    v0 = (double *)malloc(sizeof(double) * 3 * (size_t)P->nall);
+    p0 = (double *)malloc(sizeof(double) * (size_t)P->nall);
+    memcpy(x0, x, sizeof(double) * 3 * (size_t)P->nall);
+    memcpy(v0, v, sizeof(double) * 3 * (size_t)P->nall);
+    memcpy(p0, p, sizeof(double) * (size_t)P->nall);
+  }
+  for (int i = 0; i < n; ++i) {
+    if (fixed && fixed[P->type[i]]) continue;
+    double gp[3], gv[3][3];
+    shift_gradients(P, antisym, x0, v0, p0, i, gp, gv);
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) s += gp[k] * dr[3 * i + k];
+    p[i] += s;
+    for (int k = 0; k < dim; ++k) {
+      double t = 0.0;
+      for (int q = 0; q < dim; ++q) t += gv[k][q] * dr[3 * i + q];
+      v[3 * i + k] += t;
+    }
+    for (int k = 0; k < dim; ++k) x[3 * i + k] += dr[3 * i + k];
+  }
+  if (!sequential) { free(x0); free(v0); free(p0); }
+}
+
 /* Matrix-free application of the Laplacian rows to a field with ncomp
  * components: lap_i = sum_j A_ij f_j using exactly the row values of
  * orc_laplacian_matrix (the Helmholtz functor forms w = A v through the

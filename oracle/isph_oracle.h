@@ -101,6 +101,16 @@ void orc_divergence(const orc_particles *P, int antisym, const double *f,
 void orc_gradient(const orc_particles *P, int antisym, const double *f,
                   double alpha, int use_filter, int filt_i, int filt_j,
                   double *grad /* [nlocal][3] */);
+/* particle shifting (functor_compute_shift.h:48-113, functor_apply_shift.h:76-108).
+ * orc_apply_shift: sequential != 0 restates the reference's serial in-place loop
+ * (pair_for.h:9-14: row i sees the already shifted x/p/v of rows < i);
+ * sequential == 0 reads the pre-shift state for every row, which is what any
+ * parallel execution (the device) computes; the two differ by O(|dr|^2).
+ * x, v [nall][3] and p [nall] are updated for the nlocal rows only. */
+void orc_compute_shift(const orc_particles *P, double alpha, double shiftcut, double nonfluidweight,
+                       double *dr /* [nlocal][3] */);
+void orc_apply_shift(const orc_particles *P, int antisym, const int *fixed /* [ntypes+1] or NULL */,
+                     const double *dr, double *x, double *v, double *p, int sequential);
 void orc_laplacian_apply(const orc_particles *P, int antisym, const double *f,
                          int ncomp, double alpha, const double *material,
                          int filt_i, int filt_j, double *lap);

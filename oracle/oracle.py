@@ -69,6 +69,9 @@ def lib():
                                      C.c_int, C.c_void_p]
         L.orc_gradient.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]
+        L.orc_compute_shift.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.orc_apply_shift.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int]
         L.orc_laplacian_apply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                           C.c_int, C.c_int, C.c_void_p]
         L.orc_poisson.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
@@ -175,6 +178,18 @@ class Particles:
         fi, fj = filt if use else (ALL, ALL)
         lib().orc_gradient(self.ref(), int(antisym), _p(f), float(alpha), int(use), fi, fj, _p(g))
         return g
+
+    def compute_shift(self, alpha, shiftcut, nonfluidweight):
+        dr = np.zeros((self.nlocal, 3))
+        lib().orc_compute_shift(self.ref(), float(alpha), float(shiftcut), float(nonfluidweight), _p(dr))
+        return dr
+
+    def apply_shift(self, antisym, dr, v, p, fixed=None, sequential=False):
+        """returns shifted copies (x, v, p); `fixed` is per type (index 0 unused)."""
+        x, v, p = self.x.copy(), _f64(v).copy(), _f64(p).copy()
+        fx = None if fixed is None else _i32(fixed)
+        lib().orc_apply_shift(self.ref(), int(antisym), _p(fx), _p(_f64(dr)), _p(x), _p(v), _p(p), int(sequential))
+        return x, v, p
 
     def laplacian_apply(self, f, antisym, alpha, material=None, filt=(FLUID, ALL)):
         f = _f64(f)

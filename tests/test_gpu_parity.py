@@ -631,3 +631,43 @@ def test_correct_velocity_pressure_and_advance_match_oracle_formulas(gpu_ctx, an
     hip.advance_end(gpu_ctx, n, 3, dt, dpa, np.ascontiguousarray(vstar[:n]), pp, x_g, v_g)
     assert np.max(np.abs(x_g - (parts["x"][:n] + dxp))) < 1e-14
     assert np.array_equal(v_g, vstar[:n]) and np.max(np.abs(pp - (p[:n] + dpa))) < 1e-14
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("antisym", [True, False])
+def test_particle_shifting_matches_oracle(gpu_ctx, dim, antisym):
+    """functor_compute_shift.h / functor_apply_shift.h / PairISPH_Corrected::shiftParticles with a solid slab
+    (non-fluid weight) and a shift cut-off shorter than the kernel support."""
+    n = 20 if dim == 2 else 10
+    kinds = [orc.FLUID, orc.SOLID]
+    pr = Problem(tgv_spec(dim=dim, n=n, mode=workload.JITTER), antisym=antisym, kinds=kinds, types=wall_types)
+    parts, P = pr.parts, pr.P
+    nl, own = parts["nlocal"], parts["owner_index"]
+    rng = np.random.default_rng(21)
+    v = np.ascontiguousarray(parts["v"][:nl][own])
+    p = rng.standard_normal(nl)[own]
+    shift, weight, dt = 0.05, 0.7, pr.spec.dt
+    shiftcut = 0.8 * parts["cut"]
+    fluid = parts["type"][:nl] == 1
+    vmax_ref = np.sqrt((v[:nl][fluid] ** 2).sum(axis=1)).max()
+    alpha = shift * dt * vmax_ref
+    dr_o = P.compute_shift(alpha, shiftcut, weight)
+    dr_g = hip.compute_shift(gpu_ctx, parts, pr.colmap, alpha, shiftcut, weight, kinds=kinds)
+    assert np.abs(dr_o).max() > 0 and not dr_o[~fluid].any()
+    assert np.max(np.abs(dr_g - dr_o)) <= 1e-12 * np.abs(dr_o).max()
+    Gc = None if antisym else P.Gc
+    fixed = np.array([0, 0, 1], np.int32)
+    xo, vo, po = P.apply_shift(antisym, dr_o, v, p, fixed=fixed, sequential=False)
+    xg, vg, pg = np.ascontiguousarray(parts["x"].copy()), v.copy(), p.copy()
+    hip.apply_shift(gpu_ctx, parts, pr.colmap, dr_o, xg, vg, pg, P.vfrac, antisym=antisym, fixed=fixed, Gc=Gc, kinds=kinds)
+    assert np.max(np.abs(xg - xo)) < 1e-14
+    assert np.max(np.abs(vg - vo)) <= 1e-12 * np.abs(vo).max()
+    assert np.max(np.abs(pg - po)) <= 1e-12 * np.abs(po).max()
+    assert np.array_equal(xg[nl:], parts["x"][nl:]) and np.array_equal(pg[nl:], p[nl:])   # ghosts wait for the comm
+    # whole shiftParticles(): vmax on the device, then compute + apply
+    x2, v2, p2 = np.ascontiguousarray(parts["x"].copy()), v.copy(), p.copy()
+    vmax = hip.shift_particles(gpu_ctx, parts, pr.colmap, shift, shiftcut, weight, dt, x2, v2, p2, P.vfrac, antisym=antisym,
+                               fixed=fixed, Gc=Gc, kinds=kinds)
+    assert vmax == vmax_ref
+    assert np.max(np.abs(x2 - xo)) < 1e-13 and np.max(np.abs(p2 - po)) <= 1e-11 * np.abs(po).max()
+    assert np.max(np.abs(v2 - vo)) <= 1e-11 * np.abs(vo).max()

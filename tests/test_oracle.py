@@ -204,3 +204,23 @@ def test_tgv2d_known_answer_table_loose():
     assert abs(h["p_norm"] / ref["p_norm"] - 1) < 1e-3 and abs(h["u_norm"] / ref["u_norm"] - 1) < 1e-3
     assert 0.8 < h["p_err"] / ref["p_err"] < 1.25
     assert 0.1 < h["u_err"] / ref["u_err"] < 3.0
+
+
+def test_shift_serial_in_place_and_pre_shift_state_differ_at_second_order():
+    """The reference applies the shift in a serial in-place loop (pair_for.h:9-14, functor_apply_shift.h:76-108);
+    a parallel device reads the pre-shift state.  The oracle restates both: the gap must scale like |dr|^2."""
+    pr = Problem(tgv_spec(dim=2, n=16, mode=workload.JITTER))
+    parts, P = pr.parts, pr.P
+    nl, own = parts["nlocal"], parts["owner_index"]
+    v = np.ascontiguousarray(parts["v"][:nl][own])
+    p = np.cos(parts["x"][:, 0]) * np.sin(parts["x"][:, 1])
+    gaps = []
+    for alpha in (1e-3, 1e-4):
+        dr = P.compute_shift(alpha, parts["cut"], 0.0)
+        xs, vs, ps = P.apply_shift(True, dr, v, p, sequential=True)
+        xj, vj, pj = P.apply_shift(True, dr, v, p, sequential=False)
+        assert np.array_equal(xs, xj)                       # positions do not depend on the order
+        first = np.abs(pj - p).max()
+        gaps.append(np.abs(ps - pj).max() / first)
+        assert first > 0 and gaps[-1] < 0.2
+    assert gaps[1] < 0.2 * gaps[0]                          # relative gap ~ |dr|
