@@ -108,26 +108,33 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
 //
 // For each block and each direction (L: dependencies = strictly-lower entries,
 // U: strictly-upper) rows are levelled (lev = 1 + max lev of dependencies; level
-// 0 rows need no work), sorted by level, and packed up to 8 rows per "step" with
-// G lanes per row.  A step is a run of chunks; chunk = 64 x (value, word) with
-//   word = local column (11 bits) | local row << 11 (11 bits) | log2(G/8) << 22 | END << 31
-// (END: last chunk of step; G = lanes per row in this step: 8 for a full step of
-// 8 rows, 16/32/64 when a level leaves only <=4/2/1 rows for its last step)
-// so the solve kernel is a pure coalesced stream: per chunk one fma against x in
-// LDS, per step one G-lane reduction and one LDS update.  No flags, no waiting.
-// Stream capacity per block = kCapFactor x the block's sliced-ELL region + slack
-// (+ prefetch pad); running out of it fails the build loudly.
+// 0 rows need no work) and the rows of a level are packed into "steps".  A step
+// is a run of T chunks of 64 x (value, word); row i of the step owns g_i =
+// ceil(d_i / T) CONTIGUOUS lanes (d_i = its dependency count) and streams its
+// entries through them, so a step of rows with 5..50 dependencies fills the 64
+// lanes instead of padding every row to the longest one.  Rows of a level are
+// taken longest first; a step grows while its chunk count T stays, or -- when the
+// next row would raise T -- while it is less than 90 % full and stays at least
+// half full afterwards (on the production 3-D matrices this greedy rule reaches
+// the optimal consecutive partition: 1.18 x the entry count instead of 1.73 x for
+// fixed 8-lane groups; scripts/ilu_pack_model.py).
+//   word = local column (11 bits) | local row << 11 | TAIL << 22 | CONT << 23 | p << 24 | need << 28 | END << 31
+// END: last chunk of the step (wave-uniform).  The step ends with a segmented
+// scan in registers: p = distance of the lane from the start of its row's lanes
+// inside its 16-lane DPP row (row_shr:1,2,4,8 add when p >= shift), CONT = the
+// row's lanes began in the previous DPP row (row_bcast:15 carries the partial sum
+// over, DPP row by DPP row; `need` says which of the three carries the step
+// uses), TAIL = last lane of the row: it holds the row's sum and updates y.
+// Per chunk one fma against y in LDS; no flags, no waiting.
+// Every step is at least half full or one chunk long, so a block never needs more
+// than (entries/32 + rows per direction) chunks: capacity = 2 x its sliced-ELL
+// region + 2 B, checked by the kernel all the same.
 constexpr unsigned kRowInvalid = 0x7FFu;
-constexpr int kRowShift = 11, kGShift = 22;
+constexpr int kRowShift = 11, kTailShift = 22, kContShift = 23, kPosShift = 24, kNeedShift = 28;
 constexpr unsigned kEndBit = 0x80000000u;
-constexpr int kPrefetch = 8;      // chunks kept in flight per wave
-constexpr int kPadChunks = 16;    // per-block tail pad so the prefetch never leaves the buffer
-// Capacity is (capf x the block's ELL region + slack) chunks per block.  First attempt: capf 3, slack 64
-// (the 3-D production matrices use ~1.75 x).  A step of r rows uses max_r ceil(ndep/G) <= sum(ndep)/8 + 1
-// chunks and there are at most 2 m steps, so capf 8 with slack 2 B can never overflow: the build falls back
-// to that bound when the first attempt reports an overflow (small 2-D blocks with one row per level).
-constexpr int kSlackChunks = 64;
-constexpr int kCapFactor = 3;
+constexpr int kPrefetch = 16;     // chunks kept in flight per wave (default; ISPH_ILU_PREFETCH picks 8/12/16/24)
+constexpr int kPadChunks = 32;    // per-block tail pad so the prefetch never leaves the buffer (>= deepest prefetch)
+constexpr int kCapFactor = 2;
 constexpr int kCapFactorSafe = 8;
 
 __device__ __forceinline__ long long ilu_base_chunk(const long long *slice_off, int b, int B, int capf, int slack) {
@@ -143,13 +150,18 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        int ccap, int capf, int slack, int *__restrict__ err) {
   extern __shared__ int lds_i[];
   int *lev = lds_i;              // [B]
-  int *cnt = lev + B;            // [B+1]
-  int *stepstart = cnt + B + 1;  // [B+1]
-  int *tmaxs = stepstart + B + 1;  // [B+1]
-  int *choff = tmaxs + B + 1;    // [B+2]
+  int *cnt = lev + B;            // [B+1] rows per level
+  int *lvoff = cnt + B + 1;      // [B+1] sorted position of the first row of a level
+  int *choff = lvoff + B + 1;    // [B+2] first chunk of every step
+  int *skey = choff + B + 2;     // [B] sort key (level, -ndep) of the rank computation
+  int *sd = skey + B;            // [B] dependency count, by sorted position
+  int *slane = sd + B;           // [B] first lane of the row inside its step
+  int *sT = slane + B;           // [B] chunk count of the row's step
+  int *sinfo = sT + B;           // [B] bit 0: first row of its step, bits 1-3: carries needed, bits 8-14: lanes used
+  int *sstep = sinfo + B;        // [B] step index
   // optional cache of every row's in-block local columns, [slot][row] (conflict-free across rows)
-  unsigned short *ccol = reinterpret_cast<unsigned short *>(choff + B + 2);  // [ccap][B], ccap == 0: read global
-  __shared__ int s_nlev, s_nsteps, s_nch;
+  unsigned short *ccol = reinterpret_cast<unsigned short *>(sstep + B);  // [ccap][B], ccap == 0: read global
+  __shared__ int s_nlev, s_nsched, s_nch;
   const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   const int t = threadIdx.x;
   const bool active = t < m;
@@ -201,65 +213,110 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
     if (dir == 0 && active) llev[i] = lev[t];  // the numeric factorisation walks the same levels
     // ---- histogram of levels
     if (t == 0) s_nlev = 0;
-    for (int k = t; k <= B; k += blockDim.x) { cnt[k] = 0; tmaxs[k] = 0; }
+    for (int k = t; k <= B; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
     const int mylev = active ? lev[t] : 0;
     if (active) { atomicAdd(&cnt[mylev], 1); atomicMax(&s_nlev, mylev + 1); }
+    // deterministic rank inside the level: longest rows first (ties in row order)
+    if (t < B) skey[t] = active ? ((mylev << 12) | (4095 - min(ndep, 4095))) : -1;
     __syncthreads();
-    // deterministic rank inside the level (row order)
+    const bool sched = active && mylev > 0;
     int rk = 0;
-    if (active && mylev > 0)
-      for (int q = 0; q < t; ++q) rk += (lev[q] == mylev);
+    if (sched) {
+      const int mykey = skey[t];
+      for (int q = 0; q < m; ++q) {
+        const int kq = skey[q];
+        rk += (kq < mykey && (kq >> 12) == mylev) || (kq == mykey && q < t);
+      }
+    }
     if (t == 0) {
       int run = 0;
-      stepstart[0] = 0;
-      for (int l = 1; l < s_nlev; ++l) { stepstart[l] = run; run += (cnt[l] + 7) >> 3; }
-      s_nsteps = run;
+      for (int l = 1; l < s_nlev; ++l) { lvoff[l] = run; run += cnt[l]; }
+      s_nsched = run;
     }
     __syncthreads();
-    const int step = (active && mylev > 0) ? stepstart[mylev] + (rk >> 3) : -1;
-    const int g = rk & 7;
-    const int rows_in_step = (active && mylev > 0) ? min(8, cnt[mylev] - ((rk >> 3) << 3)) : 8;
-    const int gcode = rows_in_step > 4 ? 0 : rows_in_step > 2 ? 1 : rows_in_step > 1 ? 2 : 3;
-    const int G = 8 << gcode;           // lanes per row in this step
-    const int tneed = (ndep + G - 1) / G;  // >= 1 for scheduled rows
-    if (step >= 0) atomicMax(&tmaxs[step], tneed);
+    const int sp = sched ? lvoff[mylev] + rk : 0;
+    if (sched) sd[sp] = ndep;
+    __syncthreads();
+    // ---- steps: the first row of every run of 64 ranks packs its run greedily
+    if (sched && (rk & 63) == 0) {
+      const int k = min(64, cnt[mylev] - rk);
+      int a = 0;
+      while (a < k) {
+        int e = a + 1;
+        int S = sd[sp + a];
+        int T = (S + 63) >> 6;
+        int lanes = (S + T - 1) / T;
+        while (e < k) {
+          const int de = sd[sp + e];
+          int T2 = T, lanes2 = lanes + (de + T - 1) / T;
+          if (lanes2 > 64) {
+            do {
+              ++T2;
+              lanes2 = 0;
+              for (int q = a; q <= e; ++q) lanes2 += (sd[sp + q] + T2 - 1) / T2;
+            } while (lanes2 > 64);
+            // a higher chunk count is accepted only while the step is < 90 % full and stays >= 50 % full
+            if (!(10 * S < 9 * 64 * T && 2 * (S + de) >= 64 * T2)) break;
+          }
+          T = T2; lanes = lanes2; S += de; ++e;
+        }
+        int run = 0, need = 0;
+        for (int q = a; q < e; ++q) {
+          const int g = (sd[sp + q] + T - 1) / T;
+          slane[sp + q] = run;
+          for (int r = (run >> 4) + 1; r <= ((run + g - 1) >> 4); ++r) need |= 1 << (r - 1);
+          run += g;
+        }
+        for (int q = a; q < e; ++q) {
+          sT[sp + q] = T;
+          sinfo[sp + q] = (q == a ? 1 : 0) | (need << 1) | (run << 8);
+        }
+        a = e;
+      }
+    }
     __syncthreads();
     if (t == 0) {
-      int run = 0;
-      for (int q = 0; q < s_nsteps; ++q) { choff[q] = run; run += tmaxs[q]; }
-      choff[s_nsteps] = run;
+      int step = -1, run = 0;
+      for (int q = 0; q < s_nsched; ++q) {
+        if (sinfo[q] & 1) { ++step; choff[step] = run; run += sT[q]; }
+        sstep[q] = step;
+      }
       s_nch = run;
       blkinfo[2 * b + dir] = run;
       if ((long long)used + run > cap) atomicOr(err, 16);  // stream capacity exceeded
     }
     __syncthreads();
     if ((long long)used + s_nch > cap) return;  // uniform exit; host reports the error
-    if (step >= 0) {
-      const int tm = tmaxs[step];
-      const unsigned gbits = (unsigned)gcode << kGShift;
-      for (int c = 0; c < tm; ++c) {
-        const long long chunk = base + used + choff[step] + c;
-        const unsigned endbit = ((c == tm - 1) ? kEndBit : 0u) | gbits;
-        for (int j = 0; j < G; ++j) {
-          const int e = c * G + j;
-          const long long idx = chunk * 64 + g * G + j;
+    if (sched) {
+      const int T = sT[sp], ls = slane[sp], info = sinfo[sp];
+      const int g = (ndep + T - 1) / T;
+      const unsigned needbits = (unsigned)((info >> 1) & 7) << kNeedShift;
+      const long long chunk0 = base + used + choff[sstep[sp]];
+      for (int c = 0; c < T; ++c) {
+        const unsigned endbits = ((c == T - 1) ? kEndBit : 0u) | needbits;
+        for (int q = 0; q < g; ++q) {
+          const int e = c * g + q, lane = ls + q;
+          const long long idx = (chunk0 + c) * 64 + lane;
+          const int segstart = max(ls, lane & ~15);
+          const unsigned flags = endbits | ((unsigned)(lane - segstart) << kPosShift) |
+                                 ((lane >> 4) > (ls >> 4) ? (1u << kContShift) : 0u) |
+                                 (q == g - 1 ? (1u << kTailShift) : 0u) | ((unsigned)t << kRowShift);
           if (e < ndep) {
             const long long slot = rp + d0 + e;
-            sc[idx] = (unsigned)(fcol[slot] - blo) | ((unsigned)t << kRowShift) | endbit;
+            sc[idx] = (unsigned)(fcol[slot] - blo) | flags;
             fdst[slot] = (int)idx;
           } else {
-            sc[idx] = ((unsigned)t << kRowShift) | endbit;
+            sc[idx] = flags;
             sv[idx] = 0.0;
           }
         }
-        if (g == 0)  // lanes of the groups this step does not use
-          for (int gg = rows_in_step; gg < 64 / G; ++gg)
-            for (int j = 0; j < G; ++j) {
-              const long long idx = chunk * 64 + gg * G + j;
-              sc[idx] = (kRowInvalid << kRowShift) | endbit;
-              sv[idx] = 0.0;
-            }
+        if (info & 1)  // lanes the step does not use
+          for (int lane = (info >> 8) & 127; lane < 64; ++lane) {
+            const long long idx = (chunk0 + c) * 64 + lane;
+            sc[idx] = (kRowInvalid << kRowShift) | endbits;
+            sv[idx] = 0.0;
+          }
       }
     }
     used += s_nch;
@@ -410,8 +467,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
 
 // ---------------------------------------------------------------------------
 // z = U^-1 D^-1 L^-1 r : one wave per block streams the block's chunk list.
-// LDS per wave: y[B].  kPrefetch chunks (values + words) are kept in flight.
-template <int WAVES>
+// LDS per wave: y[B] and the block's reciprocal pivots.  kPrefetch chunks (values + words) are kept in flight.
+template <int WAVES, int PF>
 __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, int nblocks,
                                                                  const long long *__restrict__ slice_off,
                                                                  const double *__restrict__ sv,
@@ -426,54 +483,64 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * WAVES + wave;
   if (b >= nblocks) return;
-  double *y = lds_y + (size_t)wave * B;
+  double *y = lds_y + (size_t)wave * 2 * B;
+  double *dv = y + B;  // reciprocal pivots of the block: the U steps must not wait on a global load each
   const int blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
-  for (int t = lane; t < m; t += 64) y[t] = r[blo + t];
+  for (int t = lane; t < m; t += 64) { y[t] = r[blo + t]; dv[t] = dinv[blo + t]; }
   const long long base = ilu_base_chunk(slice_off, b, B, capf, slack);
   const int nL = blkinfo[2 * b], nU = blkinfo[2 * b + 1];
   const double *__restrict__ pv = sv + base * 64 + lane;
   const unsigned *__restrict__ pc = sc + base * 64 + lane;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  double vq[kPrefetch];
-  unsigned cq[kPrefetch];
+  double vq[PF];
+  unsigned cq[PF];
   const int ntot = nL + nU;
 #pragma unroll
-  for (int u = 0; u < kPrefetch; ++u) {  // non-temporal: the stream is read once per apply
+  for (int u = 0; u < PF; ++u) {  // non-temporal: the stream is read once per apply
     vq[u] = __builtin_nontemporal_load(&pv[(long long)u * 64]);
     cq[u] = __builtin_nontemporal_load(&pc[(long long)u * 64]);
   }
   double acc = 0.0;
   bool upper = false;
-  for (int c0 = 0; c0 < ntot; c0 += kPrefetch) {
+  for (int c0 = 0; c0 < ntot; c0 += PF) {
 #pragma unroll
-    for (int u = 0; u < kPrefetch; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int c = c0 + u;
       const double v = vq[u];
       const unsigned cw = cq[u];
-      vq[u] = __builtin_nontemporal_load(&pv[(long long)(c + kPrefetch) * 64]);  // stays inside the padded buffer
-      cq[u] = __builtin_nontemporal_load(&pc[(long long)(c + kPrefetch) * 64]);
+      vq[u] = __builtin_nontemporal_load(&pv[(long long)(c + PF) * 64]);  // stays inside the padded buffer
+      cq[u] = __builtin_nontemporal_load(&pc[(long long)(c + PF) * 64]);
       if (c < ntot) {
         if (c == nL && !upper) {
           // switch to the U phase: rows without upper dependencies finish here
           upper = true;
           for (int t = lane; t < m; t += 64)
-            if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dinv[blo + t];
+            if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dv[t];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
         acc = fma(v, y[cw & 0x7FFu], acc);
         const unsigned cw0 = __builtin_amdgcn_readfirstlane(cw);
         if (cw0 & kEndBit) {
-          const int gcode = (cw0 >> kGShift) & 3;  // wave-uniform
-          double s = group8_sum(acc);
-          if (gcode > 0) s += __shfl_xor(s, 8, 64);
-          if (gcode > 1) s += __shfl_xor(s, 16, 64);
-          if (gcode > 2) s += __shfl_xor(s, 32, 64);
-          const unsigned row = (cw >> kRowShift) & 0x7FFu;
-          if ((lane & ((8 << gcode) - 1)) == 0 && row != kRowInvalid) {
+          // segmented inclusive scan towards the last lane of every row (see k_ilu_schedule)
+          const int p = (cw >> kPosShift) & 15;
+          double s = acc, q;
+          q = dpp_move<0x111>(s); s += p >= 1 ? q : 0.0;  // row_shr:1
+          q = dpp_move<0x112>(s); s += p >= 2 ? q : 0.0;  // row_shr:2
+          q = dpp_move<0x114>(s); s += p >= 4 ? q : 0.0;  // row_shr:4
+          q = dpp_move<0x118>(s); s += p >= 8 ? q : 0.0;  // row_shr:8
+          const unsigned need = (cw0 >> kNeedShift) & 7u;  // wave-uniform
+          if (need) {
+            const bool cont = (cw >> kContShift) & 1u;
+            if (need & 1u) { q = dpp_move<0x142, 0x2>(s); s += cont ? q : 0.0; }  // lane 15 -> DPP row 1
+            if (need & 2u) { q = dpp_move<0x142, 0x4>(s); s += cont ? q : 0.0; }  // lane 31 -> DPP row 2
+            if (need & 4u) { q = dpp_move<0x142, 0x8>(s); s += cont ? q : 0.0; }  // lane 47 -> DPP row 3
+          }
+          if ((cw >> kTailShift) & 1u) {
+            const unsigned row = (cw >> kRowShift) & 0x7FFu;
             const double yr = y[row] - s;
-            y[row] = upper ? yr * dinv[blo + row] : yr;
+            y[row] = upper ? yr * dv[row] : yr;
           }
           acc = 0.0;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -484,7 +551,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
   }
   if (!upper) {  // no U chunks at all (or empty stream): still scale the rows without upper deps
     for (int t = lane; t < m; t += 64)
-      if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dinv[blo + t];
+      if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dv[t];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -520,9 +587,9 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   F->n = S.nrow; F->B = block_size; F->S = &S; F->wmax = S.wmax;
   F->nblocks = (S.nrow + block_size - 1) / block_size;
   const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
-  F->capf = kCapFactor; F->slack = kSlackChunks;
+  F->capf = kCapFactor; F->slack = 2 * block_size;
   auto size_stream = [&]() {
-    F->stream_chunks = F->capf * (S.stored >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPrefetch;
+    F->stream_chunks = F->capf * (S.stored >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
     int r = F->sv.reserve((size_t)F->stream_chunks * 64);
     if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
     if (r == ISPH_SUCCESS && (long long)F->stream_chunks * 64 >= 2147483647LL)
@@ -551,7 +618,7 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       hipLaunchKernelGGL(k_ilu_extract, dim3(F->nblocks), dim3(block_size), 0, ctx->stream, S.nrow, block_size,
                          S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, F->frp.p, F->fcol.p, F->fval.p, F->flen.p,
                          F->fdiag.p, F->err.p);
-      size_t lds_s = sizeof(int) * (5 * Bz + 8);
+      size_t lds_s = sizeof(int) * (10 * Bz + 8);
       int ccap = S.wmax;  // cache every row's local columns in LDS when it fits
       if (lds_s + 2 * (size_t)ccap * Bz > 150 * 1024) ccap = 0;
       lds_s += 2 * (size_t)ccap * Bz;
@@ -592,10 +659,17 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
   if (F->n == 0) return ISPH_SUCCESS;
   constexpr int WV = 4;
-  const size_t lds = sizeof(double) * (size_t)F->B * WV;
-  hipLaunchKernelGGL((k_ilu_solve_stream<WV>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, F->n,
-                     F->B, F->nblocks, F->S->slice_off.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p,
-                     F->dinv.p, r, z, F->capf, F->slack);
+  const size_t lds = sizeof(double) * 2 * (size_t)F->B * WV;
+  static const int pf = []() { const char *e = getenv("ISPH_ILU_PREFETCH"); return e ? atoi(e) : kPrefetch; }();
+#define ISPH_ILU_LAUNCH(PF)                                                                                             \
+  hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream,   \
+                     F->n, F->B, F->nblocks, F->S->slice_off.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p, \
+                     F->dinv.p, r, z, F->capf, F->slack)
+  if (pf == 12) ISPH_ILU_LAUNCH(12);
+  else if (pf == 16) ISPH_ILU_LAUNCH(16);
+  else if (pf == 24) ISPH_ILU_LAUNCH(24);
+  else ISPH_ILU_LAUNCH(8);
+#undef ISPH_ILU_LAUNCH
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
