@@ -104,6 +104,53 @@ __global__ __launch_bounds__(kBlock) void k_multi_axpy_norm(int n, int nk, const
   if (threadIdx.x == 0) partial[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
 
+// Fused first-pass update + second-pass projection of a DGKS / ICGS step:
+//   w -= sum_k c[k] V_k ;  partial[k*nblk+b] = sum_rows V_k[i] * w_new[i] ;  slot nk = w_new . w_new
+// The second Gram-Schmidt pass needs V^T w_new; w_new[i] only depends on row i, so the projection is
+// accumulated while the row of V is still in registers: V is read once instead of twice per pass pair.
+template <int NK>
+__global__ __launch_bounds__(kBlock) void k_multi_axpy_dot(int n, int nk, const double *__restrict__ V, long long ld,
+                                                           const double *__restrict__ c, double *__restrict__ w,
+                                                           double *__restrict__ partial) {
+  __shared__ double sred[NK + 1][4];
+  __shared__ double sc[NK];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < NK) sc[threadIdx.x] = threadIdx.x < nk ? c[threadIdx.x] : 0.0;
+  __syncthreads();
+  double acc[NK];
+#pragma unroll
+  for (int u = 0; u < NK; ++u) acc[u] = 0.0;
+  double ww = 0.0;
+  const long long stride = (long long)gridDim.x * kBlock;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    double v[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) v[u] = u < nk ? V[(long long)u * ld + i] : 0.0;
+    double s = w[i];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) s = fma(-sc[u], v[u], s);
+    w[i] = s;
+    ww = fma(s, s, ww);
+#pragma unroll
+    for (int u = 0; u < NK; ++u) acc[u] = fma(v[u], s, acc[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < NK; ++u) {
+    if (u < nk) {  // wave-uniform
+      const double r = wave_sum(acc[u]);
+      if (lane == 0) sred[u][wave] = r;
+    }
+  }
+  ww = wave_sum(ww);
+  if (lane == 0) sred[NK][wave] = ww;
+  __syncthreads();
+  if (threadIdx.x < nk)
+    partial[(long long)threadIdx.x * gridDim.x + blockIdx.x] =
+        (sred[threadIdx.x][0] + sred[threadIdx.x][1]) + (sred[threadIdx.x][2] + sred[threadIdx.x][3]);
+  if (threadIdx.x == 0)
+    partial[(long long)nk * gridDim.x + blockIdx.x] = (sred[NK][0] + sred[NK][1]) + (sred[NK][2] + sred[NK][3]);
+}
+
 // x += sum_k c[k] Z_k   (solution update, c on device)
 __global__ void k_multi_axpy(int n, int nk, const double *__restrict__ Z, long long ld, const double *__restrict__ c,
                              double *__restrict__ x) {

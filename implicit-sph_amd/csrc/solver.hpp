@@ -193,14 +193,41 @@ inline int orthogonalize(isph_ctx *ctx, int n, int j, const double *V, long long
     *wnorm = std::sqrt(nn);
     return ISPH_SUCCESS;
   }
-  ISPH_CHECK(cgs_pass(ctx, n, nk, V, ld, w));
+  // DGKS / ICGS.  Pass 1: c = V^T w, then ONE kernel applies w -= V c and already accumulates the second
+  // pass's projection c2 = V^T w_new (and |w_new|^2) while the rows of V are in registers.  The host reads
+  // c, |w|^2, c2, |w_new|^2 in one fetch; the second update w -= V c2 runs only when DGKS asks for it
+  // (dep_tol = 1/sqrt(2)) or always for ICGS -- the same arithmetic as two separate passes with one read of
+  // V and one host round trip less.
+  int g = stream_grid(n);
+  if (g > 1024) g = 1024;  // 4 workgroups per CU: more did not raise the achieved bandwidth (measured)
+  ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
+  double *dh1 = ctx->dscal.p + SC_DOT, *dh2 = ctx->dscal.p + SC_Y;
+  hipLaunchKernelGGL(k_multi_dot, dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, w, ctx->partial.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, ctx->stream, nk + 1, g, ctx->partial.p, dh1);
+  ISPH_CHECK(allreduce_inplace(ctx, dh1, nk + 1));
+  if (nk <= 16)
+    hipLaunchKernelGGL((k_multi_axpy_dot<16>), dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh1, w, ctx->partial.p);
+  else if (nk <= 32)
+    hipLaunchKernelGGL((k_multi_axpy_dot<32>), dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh1, w, ctx->partial.p);
+  else
+    hipLaunchKernelGGL((k_multi_axpy_dot<64>), dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh1, w, ctx->partial.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, ctx->stream, nk + 1, g, ctx->partial.p, dh2);
+  ISPH_CHECK(allreduce_inplace(ctx, dh2, nk + 1));
+  ISPH_CHECK_HIP(hipGetLastError());
+  ISPH_CHECK(fetch_scalars(ctx, SC_DOT, SC_Y + nk + 1 - SC_DOT));
   for (int k = 0; k < nk; ++k) h[k] += ctx->hscal[SC_DOT + k];
   const double old = std::sqrt(ctx->hscal[SC_DOT + nk]);
-  double nw = std::sqrt(ctx->hscal[SC_DOT + nk + 1]);
+  double nw = std::sqrt(ctx->hscal[SC_Y + nk]);
   if (ortho == 1 || nw < M_SQRT1_2 * old) {  // DGKS: dep_tol = 1/sqrt(2)
-    ISPH_CHECK(cgs_pass(ctx, n, nk, V, ld, w));
-    for (int k = 0; k < nk; ++k) h[k] += ctx->hscal[SC_DOT + k];
-    nw = std::sqrt(ctx->hscal[SC_DOT + nk + 1]);
+    for (int k = 0; k < nk; ++k) h[k] += ctx->hscal[SC_Y + k];
+    const int g2 = stream_grid(n);
+    hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh2, w, ctx->partial.p);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, 1, g2, ctx->partial.p,
+                       ctx->dscal.p + SC_MISC + 20);
+    ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_MISC + 20, 1));
+    ISPH_CHECK_HIP(hipGetLastError());
+    ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 20, 1));
+    nw = std::sqrt(ctx->hscal[SC_MISC + 20]);
   }
   *wnorm = nw;
   return ISPH_SUCCESS;
