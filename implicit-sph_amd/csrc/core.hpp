@@ -22,6 +22,7 @@ struct isph_ctx {
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_fetch = nullptr;  // marks the scalar mailbox copy of a Krylov iteration (host waits on it only)
 };
 
 struct isph_halo {

@@ -110,6 +110,7 @@ static int ctx_create_common(int device, void *stream, isph_ctx **out) {
   }
   ISPH_CHECK_HIP(hipEventCreate(&c->ev0));
   ISPH_CHECK_HIP(hipEventCreate(&c->ev1));
+  ISPH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
   ISPH_CHECK(ensure_scalars(c));
   *out = c;
   return ISPH_SUCCESS;
@@ -148,6 +149,7 @@ void isph_ctx_destroy(isph_ctx *c) {
   for (auto e : c->ev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  if (c->ev_fetch) (void)hipEventDestroy(c->ev_fetch);
   c->partial.release(); c->dscal.release(); c->V.release(); c->Z.release(); c->wv.release(); c->tv.release();
   c->rv.release(); c->pv.release(); c->nvec.release(); c->xext.release(); c->sendbuf.release();
   c->bdev.release(); c->xdev.release(); c->imask.release();

@@ -66,10 +66,15 @@ __global__ __launch_bounds__(kBlock) void k_multi_dot(int n, int nk, const doubl
 // out[k] = sum_b partial[k*nblk + b]: one 256-thread block per k, fixed
 // (launch-independent) summation order -> bitwise reproducible
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(int nk, int nblk, const double *__restrict__ partial,
-                                                            double *__restrict__ out) {
+                                                            double *__restrict__ out,
+                                                            const double *__restrict__ flag = nullptr) {
   __shared__ double sw[4];
   const int k = blockIdx.x;
   if (k >= nk) return;
+  if (flag && *flag == 0.0) {  // the producing kernel was skipped: nothing to sum
+    if (threadIdx.x == 0) out[k] = 0.0;
+    return;
+  }
   const double *__restrict__ p = partial + (long long)k * nblk;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int b = threadIdx.x;
@@ -89,8 +94,10 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(int nk, int nblk, co
 // w -= sum_k c[k] V_k ; partial[blockIdx] = sum of the new w.w  (c on device)
 __global__ __launch_bounds__(kBlock) void k_multi_axpy_norm(int n, int nk, const double *__restrict__ V, long long ld,
                                                             const double *__restrict__ c, double *__restrict__ w,
-                                                            double *__restrict__ partial) {
+                                                            double *__restrict__ partial,
+                                                            const double *__restrict__ flag = nullptr) {
   __shared__ double sw[4];
+  if (flag && *flag == 0.0) return;  // DGKS decided on the device that no second pass is needed
   double ww = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     double s = w[i];
@@ -179,6 +186,23 @@ __global__ __launch_bounds__(kBlock) void k_dot2(int n, const double *__restrict
     partial[blockIdx.x] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
     partial[gridDim.x + blockIdx.x] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
   }
+}
+
+// DGKS decision on the device: d[0] = 1 when a second Gram-Schmidt pass is due (|w_new| < dep_tol |w|,
+// dep_tol = 1/sqrt(2), or always when force != 0), else 0
+__global__ void k_dgks_decide(const double *__restrict__ ww_old, const double *__restrict__ ww_new, int force,
+                              double *__restrict__ d) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    d[0] = (force || sqrt(*ww_new) < M_SQRT1_2 * sqrt(*ww_old)) ? 1.0 : 0.0;
+}
+
+// y = x / sqrt(*flag != 0 ? *s1 : *s0)   (next Krylov vector from the norm the DGKS branch produced)
+__global__ void k_scale_copy_sel(int n, const double *__restrict__ x, double *__restrict__ y,
+                                 const double *__restrict__ flag, const double *__restrict__ s1,
+                                 const double *__restrict__ s0) {
+  const double a = 1.0 / sqrt(*flag != 0.0 ? *s1 : *s0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = a * x[i];
 }
 
 // y = a*x  with a = alpha_host * (inv_sqrt ? 1/sqrt(*s) : (s ? *s : 1))

@@ -177,6 +177,55 @@ inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld,
   return fetch_scalars(ctx, SC_DOT, nk + 2);
 }
 
+// DGKS / ICGS step without any host round trip.  Pass 1: c = V^T w; then ONE kernel applies w -= V c and
+// already accumulates the second pass's projection c2 = V^T w_new and |w_new|^2 while the rows of V are in
+// registers; the DGKS test (dep_tol = 1/sqrt(2); ICGS: always) is taken on the device and the second update
+// w -= V c2 (+ its norm) skips itself when it is not due.  Same arithmetic as two separate passes, one read of
+// V less.  When vnext != NULL the next basis vector w/|w| is formed on the device as well, so the caller can
+// queue the next preconditioner/operator application before it looks at the scalars.
+// Mailbox: c at SC_DOT.., |w|^2 at SC_DOT+nk; c2 at SC_Y.., |w_new|^2 at SC_Y+nk; flag, |w_final|^2 at SC_ORTHO..
+enum { SC_ORTHO = SC_MISC + 20 };
+inline int ortho_enqueue(isph_ctx *ctx, int n, int j, const double *V, long long ld, double *w, int ortho, double *vnext) {
+  const int nk = j + 1;
+  int g = stream_grid(n);
+  if (g > 1024) g = 1024;  // 4 workgroups per CU: more did not raise the achieved bandwidth (measured)
+  ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
+  hipStream_t st = ctx->stream;
+  double *dh1 = ctx->dscal.p + SC_DOT, *dh2 = ctx->dscal.p + SC_Y, *dor = ctx->dscal.p + SC_ORTHO;
+  hipLaunchKernelGGL(k_multi_dot, dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh1,
+                     (const double *)nullptr);
+  ISPH_CHECK(allreduce_inplace(ctx, dh1, nk + 1));
+  if (nk <= 16)
+    hipLaunchKernelGGL((k_multi_axpy_dot<16>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+  else if (nk <= 32)
+    hipLaunchKernelGGL((k_multi_axpy_dot<32>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+  else
+    hipLaunchKernelGGL((k_multi_axpy_dot<64>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh2,
+                     (const double *)nullptr);
+  ISPH_CHECK(allreduce_inplace(ctx, dh2, nk + 1));
+  hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(64), 0, st, (const double *)(dh1 + nk), (const double *)(dh2 + nk),
+                     ortho == 1 ? 1 : 0, dor);
+  const int g2 = stream_grid(n);
+  hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, dh2, w, ctx->partial.p,
+                     (const double *)dor);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, 1, g2, ctx->partial.p, dor + 1, (const double *)dor);
+  ISPH_CHECK(allreduce_inplace(ctx, dor + 1, 1));
+  if (vnext)
+    hipLaunchKernelGGL(k_scale_copy_sel, dim3(stream_grid(n)), dim3(kBlock), 0, st, n, w, vnext, (const double *)dor,
+                       (const double *)(dor + 1), (const double *)(dh2 + nk));
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+// host side of ortho_enqueue, once the mailbox is in hscal
+inline void ortho_collect(const isph_ctx *ctx, int nk, double *h, double *wnorm) {
+  const bool second = ctx->hscal[SC_ORTHO] != 0.0;
+  for (int k = 0; k < nk; ++k) h[k] = ctx->hscal[SC_DOT + k] + (second ? ctx->hscal[SC_Y + k] : 0.0);
+  *wnorm = std::sqrt(second ? ctx->hscal[SC_ORTHO + 1] : ctx->hscal[SC_Y + nk]);
+}
+
 // Belos DGKS / ICGS / IMGS for block size 1. h[0..j] coefficients, returns ||w||.
 inline int orthogonalize(isph_ctx *ctx, int n, int j, const double *V, long long ld, double *w, double *h, int ortho,
                          double *wnorm) {
@@ -193,43 +242,10 @@ inline int orthogonalize(isph_ctx *ctx, int n, int j, const double *V, long long
     *wnorm = std::sqrt(nn);
     return ISPH_SUCCESS;
   }
-  // DGKS / ICGS.  Pass 1: c = V^T w, then ONE kernel applies w -= V c and already accumulates the second
-  // pass's projection c2 = V^T w_new (and |w_new|^2) while the rows of V are in registers.  The host reads
-  // c, |w|^2, c2, |w_new|^2 in one fetch; the second update w -= V c2 runs only when DGKS asks for it
-  // (dep_tol = 1/sqrt(2)) or always for ICGS -- the same arithmetic as two separate passes with one read of
-  // V and one host round trip less.
-  int g = stream_grid(n);
-  if (g > 1024) g = 1024;  // 4 workgroups per CU: more did not raise the achieved bandwidth (measured)
-  ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
-  double *dh1 = ctx->dscal.p + SC_DOT, *dh2 = ctx->dscal.p + SC_Y;
-  hipLaunchKernelGGL(k_multi_dot, dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, w, ctx->partial.p);
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, ctx->stream, nk + 1, g, ctx->partial.p, dh1);
-  ISPH_CHECK(allreduce_inplace(ctx, dh1, nk + 1));
-  if (nk <= 16)
-    hipLaunchKernelGGL((k_multi_axpy_dot<16>), dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh1, w, ctx->partial.p);
-  else if (nk <= 32)
-    hipLaunchKernelGGL((k_multi_axpy_dot<32>), dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh1, w, ctx->partial.p);
-  else
-    hipLaunchKernelGGL((k_multi_axpy_dot<64>), dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh1, w, ctx->partial.p);
-  hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, ctx->stream, nk + 1, g, ctx->partial.p, dh2);
-  ISPH_CHECK(allreduce_inplace(ctx, dh2, nk + 1));
-  ISPH_CHECK_HIP(hipGetLastError());
-  ISPH_CHECK(fetch_scalars(ctx, SC_DOT, SC_Y + nk + 1 - SC_DOT));
-  for (int k = 0; k < nk; ++k) h[k] += ctx->hscal[SC_DOT + k];
-  const double old = std::sqrt(ctx->hscal[SC_DOT + nk]);
-  double nw = std::sqrt(ctx->hscal[SC_Y + nk]);
-  if (ortho == 1 || nw < M_SQRT1_2 * old) {  // DGKS: dep_tol = 1/sqrt(2)
-    for (int k = 0; k < nk; ++k) h[k] += ctx->hscal[SC_Y + k];
-    const int g2 = stream_grid(n);
-    hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, dh2, w, ctx->partial.p);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, 1, g2, ctx->partial.p,
-                       ctx->dscal.p + SC_MISC + 20);
-    ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_MISC + 20, 1));
-    ISPH_CHECK_HIP(hipGetLastError());
-    ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 20, 1));
-    nw = std::sqrt(ctx->hscal[SC_MISC + 20]);
-  }
-  *wnorm = nw;
+  // DGKS / ICGS: device-only part, then wait for the scalars
+  ISPH_CHECK(ortho_enqueue(ctx, n, j, V, ld, w, ortho, nullptr));
+  ISPH_CHECK(fetch_scalars(ctx, 0, SC_COUNT));
+  ortho_collect(ctx, nk, h, wnorm);
   return ISPH_SUCCESS;
 }
 
@@ -265,24 +281,44 @@ inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_
     std::fill(g.begin(), g.end(), 0.0);
     g[0] = beta;
     int j = 0;
-    while (j < m) {
+    // queue z_j = M^-1 v_j, w = Op z_j
+    auto enqueue_op = [&](int col) -> int {
       const double *zj;
-      double *vj = V + (long long)j * ld;
+      double *vj = V + (long long)col * ld;
       if (prm->flexible) {
-        ISPH_CHECK(op.prec(vj, Z + (long long)j * ld));
-        zj = Z + (long long)j * ld;
+        ISPH_CHECK(op.prec(vj, Z + (long long)col * ld));
+        zj = Z + (long long)col * ld;
       } else {
         ISPH_CHECK(op.prec(vj, t));
         zj = t;
       }
-      ISPH_CHECK(op.apply(zj, w));
+      return op.apply(zj, w);
+    };
+    bool op_queued = false;  // column j's operator application is already in the stream
+    while (j < m) {
+      if (!op_queued) ISPH_CHECK(enqueue_op(j));
+      op_queued = false;
       double *h = &H[(size_t)j * (size_t)(m + 1)];
       double wn = 0.0;
-      ISPH_CHECK(orthogonalize(ctx, n, j, V, ld, w, h, prm->ortho, &wn));
+      if (prm->ortho == 2) {
+        ISPH_CHECK(orthogonalize(ctx, n, j, V, ld, w, h, prm->ortho, &wn));
+        if (wn != 0.0)
+          hipLaunchKernelGGL(k_scale_copy, dim3(sg), dim3(kBlock), 0, st, n, w, V + (long long)(j + 1) * ld, 1.0 / wn,
+                             (const double *)nullptr, 0);
+      } else {
+        // the whole Gram-Schmidt step and v_{j+1} = w/|w| stay on the device; the host only waits for the copy of
+        // the scalar mailbox, and while it does the Givens update the GPU already works on the next column
+        ISPH_CHECK(ortho_enqueue(ctx, n, j, V, ld, w, prm->ortho, V + (long long)(j + 1) * ld));
+        ISPH_CHECK_HIP(hipMemcpyAsync(ctx->hscal, ctx->dscal.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
+        ISPH_CHECK_HIP(hipEventRecord(ctx->ev_fetch, st));
+        if (j + 1 < m && info->iters + 1 < prm->max_iters) {  // speculative: discarded if this column converges
+          ISPH_CHECK(enqueue_op(j + 1));
+          op_queued = true;
+        }
+        ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev_fetch));
+        ortho_collect(ctx, j + 1, h, &wn);
+      }
       h[j + 1] = wn;
-      if (wn != 0.0)
-        hipLaunchKernelGGL(k_scale_copy, dim3(sg), dim3(kBlock), 0, st, n, w, V + (long long)(j + 1) * ld, 1.0 / wn,
-                           (const double *)nullptr, 0);
       for (int k = 0; k < j; ++k) {
         const double a = cs[k] * h[k] + sn[k] * h[k + 1];
         h[k + 1] = -sn[k] * h[k] + cs[k] * h[k + 1];
