@@ -1,0 +1,840 @@
+// amg.hpp -- smoothed-aggregation AMG on the GPU, standing in for PrecondWrapper_ML
+// (ref: IMPLICIT-SPH/precond_ml.h:40-171).
+//
+// Configuration restated from the wrapper: "max levels" 5, "aggregation: type" Uncoupled (aggregates never
+// leave the rank), threshold 0, prolongator damping 4/3, symmetric Gauss-Seidel, 1 sweep pre and post, V cycle,
+// direct coarse solve -- or, when a null vector is injected (setNullVector, :97-127), a one-dimensional
+// pre-computed null space and the smoother as the coarse solver.  ML itself is an un-vendored Trilinos package:
+// the method is the published smoothed aggregation (Vanek/Mandel/Brezina) with two GPU-minded choices that the
+// oracle (oracle/isph_amg_oracle.c) shares entry by entry:
+//   * aggregate roots = distance-2 maximal independent set, synchronous rounds with hashed priorities
+//     (Bell/Dalton/Olson 2012) instead of ML's sequential greedy sweep: same "root + all neighbours" aggregates;
+//   * Gauss-Seidel local to blocks of `block` rows (ML: local to the processor), one residual per sweep:
+//     x += M_B^-1 (b - A x), M_B = blockdiag[(D+L_B) D^-1 (D+U_B)], run through the ILU chunk stream (k_sgs_fill);
+//   * damping from rho = ||D^-1 A||_inf ("eigen-analysis: type" Anorm).
+// Set-up kernels work on device CSR copies, one wave per row (rows hold ~100 entries on the fine level); the
+// cycle itself uses the SELL SpMV and the chunk-stream triangular solves of the rest of the library.
+#pragma once
+#include <rocprim/rocprim.hpp>
+
+#include "ilu.hpp"
+#include "solver.hpp"
+
+int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const int *dci, const double *dv, long long nnz,
+                        isph_mat **Aout);  // isph_capi.hip
+void isph_mat_destroy(isph_mat *A);
+
+namespace isph {
+
+struct DCsr {
+  int n = 0, m = 0;
+  long long nnz = 0;
+  DevBuf<int> rp, ci;
+  DevBuf<double> v;
+  void release() { rp.release(); ci.release(); v.release(); n = m = 0; nnz = 0; }
+};
+
+struct AmgLevel {
+  DCsr A;                    // device CSR of the level operator (fine level: a copy of the SELL matrix)
+  const isph_mat *Am = nullptr;
+  isph_mat *Aown = nullptr;  // coarse levels own their SELL matrix
+  DCsr P;                    // prolongator (kept in CSR for export)
+  isph_mat *Pm = nullptr, *Rm = nullptr;
+  isph_ilu *sgs = nullptr;   // block-local symmetric Gauss-Seidel in stream form
+  DevBuf<int> agg;
+  DevBuf<double> nv, x, b, r, z;
+};
+
+}  // namespace isph
+
+struct isph_amg {
+  int nlev = 0, block = 512, sweeps = 1, singular = 0;
+  std::vector<isph::AmgLevel *> L;
+  isph::DevBuf<double> cinv;  // dense inverse of the coarsest operator (non-singular case)
+  int nc = 0;
+};
+
+namespace isph {
+
+constexpr int kAmgWaves = 4;  // rows per 256-thread workgroup in the wave-per-row kernels
+enum { AMG_COVERED = 0, AMG_UNDECIDED = 1, AMG_ROOT = 3 };
+
+__device__ __forceinline__ unsigned amg_hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned long long amg_key(int state, int i) {
+  return ((unsigned long long)state << 62) | ((unsigned long long)amg_hash32((unsigned)i) << 30) | (unsigned long long)i;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// ML's strength test: a_ij strong iff a_ij^2 > theta^2 |a_ii a_jj| ("aggregation: threshold", default 0)
+#define AMG_STRONG(val, i, j) ((j) < n && (j) != (i) && (val) * (val) > th2 * fabs(dg[i] * dg[j]))
+
+__global__ void k_sell_to_csr_i32(int nrow, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
+                                  const int *__restrict__ scol, const double *__restrict__ sval,
+                                  const int *__restrict__ rowptr, int *__restrict__ colidx, double *__restrict__ cval) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrow) return;
+  const long long off = slice_off[row >> 6];
+  const int lane = row & 63, beg = rowptr[row];
+  for (int k = 0; k < rowlen[row]; ++k) {
+    const long long p = sell_pos(off, lane, k);
+    colidx[beg + k] = scol[p];
+    cval[beg + k] = sval[p];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_amg_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                  const double *__restrict__ v, double *__restrict__ dg) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double d = 0.0;
+  bool found = false;
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64)
+    if (ci[p] == i && !found) { d = v[p]; found = true; }
+  const unsigned long long any = __ballot(found);
+  if (any) d = __shfl(d, __ffsll((long long)any) - 1, 64);
+  if (lane == 0) dg[i] = any ? d : 1.0;
+}
+
+__global__ __launch_bounds__(256) void k_mis_init(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                  const double *__restrict__ v, const double *__restrict__ dg, double th2,
+                                                  unsigned long long *__restrict__ key) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  bool strong = false;
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+    const int j = ci[p];
+    strong |= AMG_STRONG(v[p], i, j);
+  }
+  const bool any_strong = __ballot(strong) != 0;  // every lane takes part in the vote
+  if (lane == 0) key[i] = amg_key(any_strong ? AMG_UNDECIDED : AMG_COVERED, i);
+}
+
+// out[i] = max(in[i], max over strong neighbours in[j])
+__global__ __launch_bounds__(256) void k_mis_max(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                 const double *__restrict__ v, const double *__restrict__ dg, double th2,
+                                                 const unsigned long long *__restrict__ in,
+                                                 unsigned long long *__restrict__ out) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  unsigned long long m = in[i];
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+    const int j = ci[p];
+    if (AMG_STRONG(v[p], i, j)) { const unsigned long long kj = in[j]; m = kj > m ? kj : m; }
+  }
+  m = wave_max_u64(m);
+  if (lane == 0) out[i] = m;
+}
+
+__global__ void k_mis_decide(int n, unsigned long long *__restrict__ key, const unsigned long long *__restrict__ t2,
+                             int *__restrict__ undecided) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool und = false;
+  if (i < n && (key[i] >> 62) == AMG_UNDECIDED) {
+    if (t2[i] == key[i]) key[i] = amg_key(AMG_ROOT, i);
+    else if ((t2[i] >> 62) == AMG_ROOT) key[i] = amg_key(AMG_COVERED, i);
+    else und = true;
+  }
+  const unsigned long long votes = __ballot(und);  // every lane takes part in the vote
+  if (votes && (threadIdx.x & 63) == 0) atomicAdd(undecided, __popcll(votes));
+}
+
+__global__ void k_flag_roots(int n, const unsigned long long *__restrict__ key, int *__restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (key[i] >> 62) == AMG_ROOT;
+}
+
+// pass 1: roots take their scan id, a non-root takes the id of the first strong neighbour that is a root
+__global__ __launch_bounds__(256) void k_agg_pass1(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                   const double *__restrict__ v, const double *__restrict__ dg, double th2,
+                                                   const unsigned long long *__restrict__ key,
+                                                   const int *__restrict__ rootid, int *__restrict__ a1) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  if ((key[i] >> 62) == AMG_ROOT) { if (lane == 0) a1[i] = rootid[i]; return; }
+  int best = 0x7fffffff;
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+    const int j = ci[p];
+    if (AMG_STRONG(v[p], i, j) && (key[j] >> 62) == AMG_ROOT && p < best) best = p;
+  }
+  best = wave_min_i32(best);
+  if (lane == 0) a1[i] = best == 0x7fffffff ? -1 : rootid[ci[best]];
+}
+
+// pass 2: the rest joins the pass-1 neighbour it is most strongly coupled to (ties: first in the row)
+__global__ __launch_bounds__(256) void k_agg_pass2(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                   const double *__restrict__ v, const double *__restrict__ dg, double th2,
+                                                   const int *__restrict__ a1, int *__restrict__ agg,
+                                                   int *__restrict__ leftover) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  if (a1[i] >= 0) { if (lane == 0) { agg[i] = a1[i]; leftover[i] = 0; } return; }
+  double bw = -1.0;
+  int bp = 0x7fffffff;
+  bool strong = false;
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+    const int j = ci[p];
+    if (!AMG_STRONG(v[p], i, j)) continue;
+    strong = true;
+    if (a1[j] < 0) continue;
+    const double w = fabs(v[p]);
+    if (w > bw) { bw = w; bp = p; }
+  }
+  const double wmax = wave_max_f64(bw);
+  const int pbest = wave_min_i32((bw == wmax && wmax >= 0.0) ? bp : 0x7fffffff);
+  const bool any_strong = __ballot(strong) != 0;
+  if (lane == 0) {
+    const int a = pbest == 0x7fffffff ? -1 : a1[ci[pbest]];
+    agg[i] = a;
+    leftover[i] = (a < 0 && any_strong) ? 1 : 0;  // unsymmetric patterns only: becomes a singleton (pass 3)
+  }
+}
+
+__global__ void k_agg_pass3(int n, const int *__restrict__ leftover, const int *__restrict__ leftid, int base,
+                            int *__restrict__ agg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && leftover[i]) agg[i] = base + leftid[i];
+}
+
+__global__ void k_member_keys(int n, const int *__restrict__ agg, unsigned long long *__restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = agg[i] >= 0 ? (((unsigned long long)agg[i] << 32) | (unsigned)i) : ~0ull;
+}
+
+// start[a] = first sorted position of aggregate a, start[nagg] = number of aggregated nodes
+__global__ void k_segment_starts(int n, int nagg, const unsigned long long *__restrict__ keys, int *__restrict__ start) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const unsigned long long k = keys[p];
+  if (k == ~0ull) {
+    if (p == 0 || keys[p - 1] != ~0ull) start[nagg] = p;
+    return;
+  }
+  const int a = (int)(k >> 32);
+  if (p == 0 || (int)(keys[p - 1] >> 32) != a) start[a] = p;
+  if (p == n - 1) start[nagg] = n;
+}
+
+// nvc[a] = |nv restricted to aggregate a|, members summed in index order (reproducible, equals the CPU order)
+__global__ void k_agg_norm(int nagg, const int *__restrict__ start, const unsigned long long *__restrict__ keys,
+                           const double *__restrict__ nv, double *__restrict__ nvc) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nagg) return;
+  double s = 0.0;
+  for (int p = start[a]; p < start[a + 1]; ++p) {
+    const double x = nv[(unsigned)(keys[p] & 0xffffffffu)];
+    s += x * x;
+  }
+  nvc[a] = sqrt(s);
+}
+
+__global__ void k_ptent(int n, const int *__restrict__ agg, const double *__restrict__ nv, const double *__restrict__ nvc,
+                        double *__restrict__ pt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pt[i] = (agg[i] >= 0 && nvc[agg[i]] > 0.0) ? nv[i] / nvc[agg[i]] : 0.0;
+}
+
+// rho = max_i sum_j |a_ij| / |a_ii|  (bit pattern of a non-negative double orders like the number)
+__global__ __launch_bounds__(256) void k_amg_rho(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                 const double *__restrict__ v, const double *__restrict__ dg,
+                                                 unsigned long long *__restrict__ rho_bits) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64)
+    if (ci[p] < n) s += fabs(v[p]);
+  s = wave_sum(s) / fabs(dg[i]);
+  if (lane == 0) atomicMax(rho_bits, (unsigned long long)__double_as_longlong(s));
+}
+
+// Row i of P = (I - damp D^-1 A) P_tent.  The row's distinct aggregates (<= 64) live one per lane in registers:
+// entries are taken 64 at a time, every distinct aggregate of the chunk is summed with a fixed-order wave sum and
+// merged into the table, so the result does not depend on scheduling.  FILL = false only counts.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_prolong(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                 const double *__restrict__ v, const double *__restrict__ dg,
+                                                 const int *__restrict__ agg, const double *__restrict__ pt, double damp,
+                                                 int *__restrict__ prp, int *__restrict__ pci, double *__restrict__ pv,
+                                                 int *__restrict__ err) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  int tkey = 0x7fffffff, cnt = 0;
+  double tval = 0.0;
+  const int ai = agg[i];
+  if (ai >= 0) { if (lane == 0) { tkey = ai; tval = pt[i]; } cnt = 1; }
+  const double f = damp / dg[i];
+  for (int p0 = rp[i]; p0 < rp[i + 1]; p0 += 64) {
+    const int p = p0 + lane;
+    int a = -1;
+    double term = 0.0;
+    if (p < rp[i + 1]) {
+      const int j = ci[p];
+      if (j < n && agg[j] >= 0) { a = agg[j]; term = f * v[p] * pt[j]; }
+    }
+    unsigned long long live = __ballot(a >= 0);
+    while (live) {
+      const int src = __ffsll((long long)live) - 1;
+      const int acur = __shfl(a, src, 64);
+      const bool mine = a == acur;
+      const double s = wave_sum(mine ? term : 0.0);
+      const unsigned long long hit = __ballot(lane < cnt && tkey == acur);
+      if (hit) {
+        if (lane == __ffsll((long long)hit) - 1) tval -= s;
+      } else {
+        if (cnt < 64) { if (lane == cnt) { tkey = acur; tval = -s; } ++cnt; }
+        else if (lane == 0) atomicOr(err, 1);  // a row touching more than 64 aggregates
+      }
+      live &= ~__ballot(mine);
+    }
+  }
+  if (!FILL) { if (lane == 0) prp[i] = cnt; return; }
+  // rank sort by aggregate id (ascending columns)
+  int rank = 0;
+  for (int t = 0; t < cnt; ++t) rank += __shfl(tkey, t, 64) < tkey;
+  if (lane < cnt) { pci[prp[i] + rank] = tkey; pv[prp[i] + rank] = tval; }
+}
+
+__global__ void k_count_cols(long long nnz, const int *__restrict__ ci, int *__restrict__ cnt) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < nnz) atomicAdd(&cnt[ci[p]], 1);
+}
+__global__ void k_transpose_keys(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                 unsigned long long *__restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int p = rp[i]; p < rp[i + 1]; ++p) keys[p] = ((unsigned long long)ci[p] << 32) | (unsigned)i;
+}
+__global__ void k_low32(long long nnz, const unsigned long long *__restrict__ keys, int *__restrict__ out) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < nnz) out[p] = (int)(keys[p] & 0xffffffffu);
+}
+
+// C = X * Y, one workgroup per row of C, LDS accumulator: direct-addressed when Y has <= TABLE columns, open
+// addressing otherwise.  Thread t walks entries t, t+BS, .. of X's row and the whole Y row behind each.
+// FILL = false counts the row's entries.  Output columns are in table order (the SELL conversion sorts rows).
+template <int TABLE, int BS, bool FILL>
+__global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, const int *__restrict__ xrp,
+                                               const int *__restrict__ xci, const double *__restrict__ xv,
+                                               const int *__restrict__ yrp, const int *__restrict__ yci,
+                                               const double *__restrict__ yv, int *__restrict__ crp,
+                                               int *__restrict__ cci, double *__restrict__ cv, int *__restrict__ err) {
+  __shared__ int tk[TABLE];
+  __shared__ double tv[TABLE];
+  __shared__ int s_cnt;
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const bool dense = ycols <= TABLE;
+  for (int s = threadIdx.x; s < TABLE; s += BS) { tk[s] = -1; if (FILL) tv[s] = 0.0; }
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  for (int p = xrp[i] + threadIdx.x; p < xrp[i + 1]; p += BS) {
+    const int k = xci[p];
+    if (k >= yrows) continue;
+    const double xa = xv[p];
+    for (int q = yrp[k]; q < yrp[k + 1]; ++q) {
+      const int c = yci[q];
+      int slot = dense ? c : (int)((amg_hash32((unsigned)c)) & (TABLE - 1));
+      if (dense) {
+        tk[slot] = c;  // benign race: every writer stores the same value
+      } else {
+        int tries = 0;
+        while (true) {
+          const int old = atomicCAS(&tk[slot], -1, c);
+          if (old == -1 || old == c) break;
+          slot = (slot + 1) & (TABLE - 1);
+          if (++tries >= TABLE) { atomicOr(err, 2); slot = -1; break; }  // table full
+        }
+        if (slot < 0) continue;
+      }
+      if (FILL) atomicAdd(&tv[slot], xa * yv[q]);
+    }
+  }
+  __syncthreads();
+  if (!FILL) {
+    int c = 0;
+    for (int s = threadIdx.x; s < TABLE; s += BS) c += tk[s] >= 0;
+    if (c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) crp[i] = s_cnt;
+    return;
+  }
+  const int beg = crp[i];
+  for (int s = threadIdx.x; s < TABLE; s += BS)
+    if (tk[s] >= 0) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      cci[beg + pos] = tk[s];
+      cv[beg + pos] = tv[s];
+    }
+}
+
+// ---- dense direct solve of the coarsest level (non-singular case) ---------------------------------------
+__global__ void k_dense_from_csr(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                 const double *__restrict__ v, double *__restrict__ aug) {
+  // aug = [A | I], row-major n x 2n
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < 2 * n; c += blockDim.x) aug[(size_t)i * 2 * n + c] = c == n + i ? 1.0 : 0.0;
+  __syncthreads();
+  for (int p = rp[i] + threadIdx.x; p < rp[i + 1]; p += blockDim.x)
+    if (ci[p] < n) aug[(size_t)i * 2 * n + ci[p]] = v[p];
+}
+// Gauss-Jordan with partial pivoting (first maximal row), one elimination step per launch pair; the right half of
+// aug ends as A^-1.  k_gj_pivot: pivot search, row swap, scaling of the pivot row, copy of column k.
+__global__ __launch_bounds__(1024) void k_gj_pivot(int n, int k, double *__restrict__ aug, double *__restrict__ colk,
+                                                   int *__restrict__ err) {
+  __shared__ double sval[1024];
+  __shared__ int sidx[1024];
+  const int t = threadIdx.x, w = 2 * n;
+  double best = -1.0;
+  int bi = 0x7fffffff;
+  for (int r = k + t; r < n; r += blockDim.x) {
+    const double a = fabs(aug[(size_t)r * w + k]);
+    if (a > best) { best = a; bi = r; }
+  }
+  sval[t] = best; sidx[t] = bi;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if (t < o) {
+      const double a = sval[t + o];
+      const int ai = sidx[t + o];
+      if (a > sval[t] || (a == sval[t] && ai < sidx[t])) { sval[t] = a; sidx[t] = ai; }
+    }
+    __syncthreads();
+  }
+  const int piv = sidx[0];
+  if (!(sval[0] > 0.0)) { if (t == 0) atomicOr(err, 4); return; }  // singular coarse operator
+  const double d = 1.0 / aug[(size_t)piv * w + k];
+  __syncthreads();
+  for (int c = t; c < w; c += blockDim.x) {
+    const double a = aug[(size_t)piv * w + c];
+    if (piv != k) aug[(size_t)piv * w + c] = aug[(size_t)k * w + c];
+    aug[(size_t)k * w + c] = a * d;
+  }
+  __syncthreads();
+  for (int r = t; r < n; r += blockDim.x) colk[r] = aug[(size_t)r * w + k];
+}
+__global__ __launch_bounds__(256) void k_gj_elim(int n, int k, double *__restrict__ aug, const double *__restrict__ colk,
+                                                 const int *__restrict__ err) {
+  const int r = blockIdx.x, w = 2 * n;
+  if (r == k || (*err & 4)) return;
+  const double f = colk[r];
+  if (f == 0.0) return;
+  for (int c = threadIdx.x; c < w; c += blockDim.x) aug[(size_t)r * w + c] -= f * aug[(size_t)k * w + c];
+}
+__global__ __launch_bounds__(256) void k_dense_apply(int n, const double *__restrict__ aug, const double *__restrict__ b,
+                                                     double *__restrict__ x) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int c = lane; c < n; c += 64) s += aug[(size_t)i * 2 * n + n + c] * b[c];
+  s = wave_sum(s);
+  if (lane == 0) x[i] = s;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+inline int amg_scan(isph_ctx *ctx, const int *in, int *out, int n, DevBuf<char> &tmp) {
+  size_t bytes = 0;
+  ISPH_CHECK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), ctx->stream));
+  ISPH_CHECK(tmp.reserve(bytes > 0 ? bytes : 1));
+  ISPH_CHECK_HIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+inline int amg_read_int(isph_ctx *ctx, const int *dev, int *host) {
+  ISPH_CHECK_HIP(hipMemcpyAsync(host, dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+inline int amg_wave_grid(int n) { return (n + kAmgWaves - 1) / kAmgWaves; }
+
+// device CSR copy of a SELL matrix (rows stay column-sorted)
+inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char> &tmp) {
+  A.n = S.nrow; A.m = S.ncol; A.nnz = S.nnz;
+  ISPH_REQUIRE(S.nnz < 2147483647LL, "matrix too large for 32-bit CSR offsets");
+  ISPH_CHECK(A.rp.reserve((size_t)S.nrow + 1));
+  ISPH_CHECK(A.ci.reserve((size_t)(S.nnz > 0 ? S.nnz : 1)));
+  ISPH_CHECK(A.v.reserve((size_t)(S.nnz > 0 ? S.nnz : 1)));
+  // exclusive scan over n+1 entries: the last input is ignored by giving the scan n+1 items of a padded copy
+  DevBuf<int> len1;
+  ISPH_CHECK(len1.reserve((size_t)S.nrow + 1));
+  ISPH_CHECK_HIP(hipMemcpyAsync(len1.p, S.rowlen.p, sizeof(int) * (size_t)S.nrow, hipMemcpyDeviceToDevice, ctx->stream));
+  ISPH_CHECK_HIP(hipMemsetAsync(len1.p + S.nrow, 0, sizeof(int), ctx->stream));
+  int rc = amg_scan(ctx, len1.p, A.rp.p, S.nrow + 1, tmp);
+  if (rc == ISPH_SUCCESS && S.nrow > 0)
+    hipLaunchKernelGGL(k_sell_to_csr_i32, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow,
+                       S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, (const int *)A.rp.p, A.ci.p, A.v.p);
+  if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("SELL->CSR failed", __FILE__, __LINE__);
+  len1.release();
+  return rc;
+}
+
+// R = P^T through a stable radix sort of (column, row) keys
+inline int amg_transpose(isph_ctx *ctx, const DCsr &P, DCsr &R, DevBuf<char> &tmp) {
+  R.n = P.m; R.m = P.n; R.nnz = P.nnz;
+  const size_t nnz1 = (size_t)(P.nnz > 0 ? P.nnz : 1);
+  ISPH_CHECK(R.rp.reserve((size_t)R.n + 1));
+  ISPH_CHECK(R.ci.reserve(nnz1));
+  ISPH_CHECK(R.v.reserve(nnz1));
+  DevBuf<unsigned long long> k0, k1;
+  DevBuf<int> cnt;
+  int rc = k0.reserve(nnz1);
+  if (rc == ISPH_SUCCESS) rc = k1.reserve(nnz1);
+  if (rc == ISPH_SUCCESS) rc = cnt.reserve((size_t)R.n + 1);
+  if (rc == ISPH_SUCCESS && hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)R.n + 1), ctx->stream) != hipSuccess)
+    rc = fail("memset failed", __FILE__, __LINE__);
+  if (rc == ISPH_SUCCESS && P.nnz > 0) {
+    const int gn = (int)((P.nnz + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_count_cols, dim3(gn), dim3(kBlock), 0, ctx->stream, P.nnz, (const int *)P.ci.p, cnt.p);
+    hipLaunchKernelGGL(k_transpose_keys, dim3((P.n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P.n,
+                       (const int *)P.rp.p, (const int *)P.ci.p, k0.p);
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, k0.p, k1.p, P.v.p, R.v.p, (size_t)P.nnz, 0, 64, ctx->stream) != hipSuccess)
+      rc = fail("radix sort sizing failed", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) rc = tmp.reserve(bytes > 0 ? bytes : 1);
+    if (rc == ISPH_SUCCESS &&
+        rocprim::radix_sort_pairs(tmp.p, bytes, k0.p, k1.p, P.v.p, R.v.p, (size_t)P.nnz, 0, 64, ctx->stream) != hipSuccess)
+      rc = fail("radix sort failed", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) hipLaunchKernelGGL(k_low32, dim3(gn), dim3(kBlock), 0, ctx->stream, P.nnz, (const unsigned long long *)k1.p, R.ci.p);
+  }
+  if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, R.rp.p, R.n + 1, tmp);
+  if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("transpose failed", __FILE__, __LINE__);
+  k0.release(); k1.release(); cnt.release();
+  return rc;
+}
+
+template <int TABLE, int BS>
+inline int amg_spgemm_t(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C, DevBuf<char> &tmp, int *derr) {
+  C.n = X.n; C.m = Y.m;
+  ISPH_CHECK(C.rp.reserve((size_t)C.n + 1));
+  DevBuf<int> cnt;
+  ISPH_CHECK(cnt.reserve((size_t)C.n + 1));
+  ISPH_CHECK_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)C.n + 1), ctx->stream));
+  if (C.n > 0)
+    hipLaunchKernelGGL((k_spgemm<TABLE, BS, false>), dim3(C.n), dim3(BS), 0, ctx->stream, X.n, Y.m, Y.n, (const int *)X.rp.p,
+                       (const int *)X.ci.p, (const double *)X.v.p, (const int *)Y.rp.p, (const int *)Y.ci.p,
+                       (const double *)Y.v.p, cnt.p, (int *)nullptr, (double *)nullptr, derr);
+  int rc = amg_scan(ctx, cnt.p, C.rp.p, C.n + 1, tmp);
+  int nnz = 0;
+  if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, C.rp.p + C.n, &nnz);
+  C.nnz = nnz;
+  if (rc == ISPH_SUCCESS) rc = C.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
+  if (rc == ISPH_SUCCESS) rc = C.v.reserve((size_t)(nnz > 0 ? nnz : 1));
+  if (rc == ISPH_SUCCESS && C.n > 0)
+    hipLaunchKernelGGL((k_spgemm<TABLE, BS, true>), dim3(C.n), dim3(BS), 0, ctx->stream, X.n, Y.m, Y.n, (const int *)X.rp.p,
+                       (const int *)X.ci.p, (const double *)X.v.p, (const int *)Y.rp.p, (const int *)Y.ci.p,
+                       (const double *)Y.v.p, C.rp.p, C.ci.p, C.v.p, derr);
+  if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("SpGEMM launch failed", __FILE__, __LINE__);
+  cnt.release();
+  return rc;
+}
+
+inline void amg_level_destroy(AmgLevel *L) {
+  if (!L) return;
+  L->A.release(); L->P.release();
+  if (L->Aown) isph_mat_destroy(L->Aown);
+  if (L->Pm) isph_mat_destroy(L->Pm);
+  if (L->Rm) isph_mat_destroy(L->Rm);
+  if (L->sgs) ilu_destroy(L->sgs);
+  L->agg.release(); L->nv.release(); L->x.release(); L->b.release(); L->r.release(); L->z.release();
+  delete L;
+}
+
+inline void amg_destroy(isph_amg *G) {
+  if (!G) return;
+  for (auto *L : G->L) amg_level_destroy(L);
+  G->cinv.release();
+  delete G;
+}
+
+// aggregates of level L (sets L->agg) ; returns the number of aggregates in *nagg_out
+inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double theta, DevBuf<char> &tmp, int *nagg_out) {
+  const DCsr &A = L->A;
+  const int n = A.n;
+  const double th2 = theta * theta;
+  DevBuf<unsigned long long> key, t1, t2;
+  DevBuf<int> flag, id, a1, cnt;
+  int rc = key.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = t1.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = t2.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = flag.reserve((size_t)n + 1);
+  if (rc == ISPH_SUCCESS) rc = id.reserve((size_t)n + 1);
+  if (rc == ISPH_SUCCESS) rc = a1.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = cnt.reserve(1);
+  if (rc == ISPH_SUCCESS) rc = L->agg.reserve((size_t)n);
+  const int gw = amg_wave_grid(n), gt = (n + kBlock - 1) / kBlock;
+  const int *rp = A.rp.p, *ci = A.ci.p;
+  const double *v = A.v.p;
+  if (rc == ISPH_SUCCESS) {
+    hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, key.p);
+    for (int round = 0; round < 1000 && rc == ISPH_SUCCESS; ++round) {
+      if (hipMemsetAsync(cnt.p, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
+      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
+                         (const unsigned long long *)key.p, t1.p);
+      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
+                         (const unsigned long long *)t1.p, t2.p);
+      hipLaunchKernelGGL(k_mis_decide, dim3(gt), dim3(kBlock), 0, ctx->stream, n, key.p, (const unsigned long long *)t2.p, cnt.p);
+      int und = 0;
+      rc = amg_read_int(ctx, cnt.p, &und);
+      if (und == 0) break;
+      if (round == 999) rc = fail("MIS did not terminate", __FILE__, __LINE__);
+    }
+  }
+  int nroot = 0, nleft = 0, last = 0;
+  if (rc == ISPH_SUCCESS) {
+    hipLaunchKernelGGL(k_flag_roots, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const unsigned long long *)key.p, flag.p);
+    if (hipMemsetAsync(flag.p + n, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+  }
+  if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, flag.p, id.p, n + 1, tmp);
+  if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, id.p + n, &nroot);
+  if (rc == ISPH_SUCCESS) {
+    hipLaunchKernelGGL(k_agg_pass1, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
+                       (const unsigned long long *)key.p, (const int *)id.p, a1.p);
+    hipLaunchKernelGGL(k_agg_pass2, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, (const int *)a1.p, L->agg.p,
+                       flag.p);
+    rc = amg_scan(ctx, flag.p, id.p, n + 1, tmp);
+  }
+  if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, id.p + n, &nleft);
+  (void)last;
+  if (rc == ISPH_SUCCESS && nleft > 0)
+    hipLaunchKernelGGL(k_agg_pass3, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const int *)flag.p, (const int *)id.p, nroot,
+                       L->agg.p);
+  if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("aggregation kernels failed", __FILE__, __LINE__);
+  *nagg_out = nroot + nleft;
+  key.release(); t1.release(); t2.release(); flag.release(); id.release(); a1.release(); cnt.release();
+  return rc;
+}
+
+// P = (I - omega/rho D^-1 A) P_tent and the coarse null vector
+inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, int nagg, double omega, DevBuf<double> &nvc,
+                           DevBuf<char> &tmp, int *derr) {
+  const DCsr &A = L->A;
+  const int n = A.n;
+  DevBuf<unsigned long long> k0, k1;
+  DevBuf<int> start, cnt;
+  DevBuf<double> pt;
+  DevBuf<unsigned long long> rho;
+  int rc = k0.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = k1.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = start.reserve((size_t)nagg + 1);
+  if (rc == ISPH_SUCCESS) rc = cnt.reserve((size_t)n + 1);
+  if (rc == ISPH_SUCCESS) rc = pt.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = rho.reserve(1);
+  if (rc == ISPH_SUCCESS) rc = nvc.reserve((size_t)nagg);
+  const int gw = amg_wave_grid(n), gt = (n + kBlock - 1) / kBlock;
+  if (rc == ISPH_SUCCESS) {
+    hipLaunchKernelGGL(k_member_keys, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const int *)L->agg.p, k0.p);
+    size_t bytes = 0;
+    if (rocprim::radix_sort_keys(nullptr, bytes, k0.p, k1.p, (size_t)n, 0, 64, ctx->stream) != hipSuccess)
+      rc = fail("radix sort sizing failed", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) rc = tmp.reserve(bytes > 0 ? bytes : 1);
+    if (rc == ISPH_SUCCESS && rocprim::radix_sort_keys(tmp.p, bytes, k0.p, k1.p, (size_t)n, 0, 64, ctx->stream) != hipSuccess)
+      rc = fail("radix sort failed", __FILE__, __LINE__);
+  }
+  double rho_h = 0.0;
+  if (rc == ISPH_SUCCESS) {
+    hipLaunchKernelGGL(k_segment_starts, dim3(gt), dim3(kBlock), 0, ctx->stream, n, nagg, (const unsigned long long *)k1.p, start.p);
+    hipLaunchKernelGGL(k_agg_norm, dim3((nagg + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nagg, (const int *)start.p,
+                       (const unsigned long long *)k1.p, (const double *)L->nv.p, nvc.p);
+    hipLaunchKernelGGL(k_ptent, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const int *)L->agg.p, (const double *)L->nv.p,
+                       (const double *)nvc.p, pt.p);
+    if (hipMemsetAsync(rho.p, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+    hipLaunchKernelGGL(k_amg_rho, dim3(gw), dim3(256), 0, ctx->stream, n, (const int *)A.rp.p, (const int *)A.ci.p,
+                       (const double *)A.v.p, dg, rho.p);
+    if (rc == ISPH_SUCCESS &&
+        (hipMemcpyAsync(&rho_h, rho.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+         hipStreamSynchronize(ctx->stream) != hipSuccess))
+      rc = fail("rho read-back failed", __FILE__, __LINE__);
+  }
+  const double damp = rho_h > 0.0 ? omega / rho_h : 0.0;
+  DCsr &P = L->P;
+  P.n = n; P.m = nagg;
+  if (rc == ISPH_SUCCESS) rc = P.rp.reserve((size_t)n + 1);
+  if (rc == ISPH_SUCCESS) {
+    if (hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)n + 1), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+    hipLaunchKernelGGL((k_prolong<false>), dim3(gw), dim3(256), 0, ctx->stream, n, (const int *)A.rp.p, (const int *)A.ci.p,
+                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, cnt.p, (int *)nullptr,
+                       (double *)nullptr, derr);
+  }
+  if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, P.rp.p, n + 1, tmp);
+  int nnz = 0;
+  if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, P.rp.p + n, &nnz);
+  P.nnz = nnz;
+  if (rc == ISPH_SUCCESS) rc = P.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
+  if (rc == ISPH_SUCCESS) rc = P.v.reserve((size_t)(nnz > 0 ? nnz : 1));
+  if (rc == ISPH_SUCCESS)
+    hipLaunchKernelGGL((k_prolong<true>), dim3(gw), dim3(256), 0, ctx->stream, n, (const int *)A.rp.p, (const int *)A.ci.p,
+                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, P.rp.p, P.ci.p, P.v.p, derr);
+  if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("prolongator kernels failed", __FILE__, __LINE__);
+  k0.release(); k1.release(); start.release(); cnt.release(); pt.release(); rho.release();
+  return rc;
+}
+
+inline int amg_level_buffers(AmgLevel *L) {
+  const size_t m = (size_t)(L->A.n > 0 ? L->A.n : 1) + 64;
+  ISPH_CHECK(L->x.reserve(m));
+  ISPH_CHECK(L->b.reserve(m));
+  ISPH_CHECK(L->r.reserve(m));
+  ISPH_CHECK(L->z.reserve(m));
+  return ISPH_SUCCESS;
+}
+
+inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *prm, const double *nullvec_dev,
+                      isph_amg **out) {
+  ISPH_REQUIRE(prm->max_levels >= 1 && prm->max_levels <= 8, "max_levels must be in [1,8]");
+  ISPH_REQUIRE(prm->block >= 64 && prm->block <= 1024 && prm->block % 64 == 0, "smoother block must be a multiple of 64 in [64,1024]");
+  ISPH_REQUIRE(prm->sweeps >= 1, "smoother sweeps must be >= 1");
+  isph_amg *G = new isph_amg();
+  G->block = prm->block; G->sweeps = prm->sweeps; G->singular = nullvec_dev != nullptr;
+  DevBuf<char> tmp;
+  DevBuf<int> derr;
+  DevBuf<double> dg;
+  int rc = derr.reserve(1);
+  if (rc == ISPH_SUCCESS && hipMemsetAsync(derr.p, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+  AmgLevel *L0 = new AmgLevel();
+  G->L.push_back(L0);
+  G->nlev = 1;
+  L0->Am = Am;
+  const int n0 = Am->S.nrow;
+  if (rc == ISPH_SUCCESS) rc = amg_csr_from_sell(ctx, Am->S, L0->A, tmp);
+  if (rc == ISPH_SUCCESS) rc = L0->nv.reserve((size_t)(n0 > 0 ? n0 : 1));
+  if (rc == ISPH_SUCCESS) {
+    if (nullvec_dev) {
+      if (hipMemcpyAsync(L0->nv.p, nullvec_dev, sizeof(double) * (size_t)n0, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+        rc = fail("copy failed", __FILE__, __LINE__);
+    } else if (n0 > 0) {
+      hipLaunchKernelGGL(k_fill, dim3(stream_grid(n0)), dim3(kBlock), 0, ctx->stream, n0, L0->nv.p, 1.0);
+    }
+  }
+  while (rc == ISPH_SUCCESS && G->nlev < prm->max_levels) {
+    AmgLevel *L = G->L.back();
+    const int n = L->A.n;
+    if (n <= prm->coarse_max) break;
+    rc = dg.reserve((size_t)n);
+    if (rc != ISPH_SUCCESS) break;
+    hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const int *)L->A.rp.p,
+                       (const int *)L->A.ci.p, (const double *)L->A.v.p, dg.p);
+    int nagg = 0;
+    rc = amg_aggregate(ctx, L, dg.p, prm->theta, tmp, &nagg);
+    if (rc != ISPH_SUCCESS) break;
+    // no coarsening, or a coarse space too small to carry anything but the null vector: stop here
+    if (nagg < 8 || nagg >= n) { L->agg.release(); break; }
+    AmgLevel *Lc = new AmgLevel();
+    rc = amg_prolongator(ctx, L, dg.p, nagg, prm->omega, Lc->nv, tmp, derr.p);
+    DCsr R, AP;
+    if (rc == ISPH_SUCCESS) rc = amg_transpose(ctx, L->P, R, tmp);
+    if (rc == ISPH_SUCCESS) rc = amg_spgemm_t<4096, 64>(ctx, L->A, L->P, AP, tmp, derr.p);
+    if (rc == ISPH_SUCCESS) rc = amg_spgemm_t<4096, 256>(ctx, R, AP, Lc->A, tmp, derr.p);
+    int herr = 0;
+    if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, derr.p, &herr);
+    if (rc == ISPH_SUCCESS && (herr & 1)) rc = fail("AMG: a row touches more than 64 aggregates (raise the threshold)", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS && (herr & 2)) rc = fail("AMG: coarse operator row too dense for the SpGEMM table", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, L->P.n, L->P.m, L->P.rp.p, L->P.ci.p, L->P.v.p, L->P.nnz, &L->Pm);
+    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, R.n, R.m, R.rp.p, R.ci.p, R.v.p, R.nnz, &L->Rm);
+    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, Lc->A.n, Lc->A.m, Lc->A.rp.p, Lc->A.ci.p, Lc->A.v.p, Lc->A.nnz, &Lc->Aown);
+    R.release(); AP.release();
+    if (rc != ISPH_SUCCESS) { amg_level_destroy(Lc); break; }
+    L->Pm->local = L->Rm->local = Lc->Aown->local = true;
+    Lc->Am = Lc->Aown;
+    G->L.push_back(Lc);
+    ++G->nlev;
+  }
+  // smoothers, work vectors, coarse solve
+  for (int l = 0; l < G->nlev && rc == ISPH_SUCCESS; ++l) {
+    AmgLevel *L = G->L[(size_t)l];
+    rc = amg_level_buffers(L);
+    const bool last = l == G->nlev - 1;
+    if (rc == ISPH_SUCCESS && (!last || G->singular)) rc = ilu_create(ctx, L->Am, G->block, &L->sgs, /*sgs=*/true);
+  }
+  if (rc == ISPH_SUCCESS && !G->singular) {
+    AmgLevel *L = G->L.back();
+    const int nc = L->A.n;
+    G->nc = nc;
+    if (nc > 2048) rc = fail("AMG: coarsest level too large for the dense direct solve", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) rc = G->cinv.reserve((size_t)2 * nc * nc + (size_t)nc + 1);
+    if (rc == ISPH_SUCCESS && nc > 0) {
+      hipLaunchKernelGGL(k_dense_from_csr, dim3(nc), dim3(kBlock), 0, ctx->stream, nc, (const int *)L->A.rp.p,
+                         (const int *)L->A.ci.p, (const double *)L->A.v.p, G->cinv.p);
+      double *colk = G->cinv.p + (size_t)2 * nc * nc;
+      for (int k = 0; k < nc; ++k) {
+        hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, ctx->stream, nc, k, G->cinv.p, colk, derr.p);
+        hipLaunchKernelGGL(k_gj_elim, dim3(nc), dim3(256), 0, ctx->stream, nc, k, G->cinv.p, (const double *)colk,
+                           (const int *)derr.p);
+      }
+      int herr = 0;
+      rc = amg_read_int(ctx, derr.p, &herr);
+      if (rc == ISPH_SUCCESS && (herr & 4)) rc = fail("AMG: coarsest operator is singular (pass the null vector)", __FILE__, __LINE__);
+    }
+  }
+  if (rc == ISPH_SUCCESS && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess))
+    rc = fail("AMG setup failed", __FILE__, __LINE__);
+  tmp.release(); derr.release(); dg.release();
+  if (rc != ISPH_SUCCESS) { amg_destroy(G); return rc; }
+  *out = G;
+  return ISPH_SUCCESS;
+}
+
+// x += M_B^-1 (b - A x); zero_guess: x = M_B^-1 b
+inline int amg_smooth(isph_ctx *ctx, const isph_amg *G, int l, const double *b, double *x, bool zero_guess) {
+  AmgLevel *L = G->L[(size_t)l];
+  const int n = L->A.n;
+  if (zero_guess) return ilu_apply(ctx, L->sgs, b, x);
+  ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
+  hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
+  ISPH_CHECK(ilu_apply(ctx, L->sgs, L->r.p, L->z.p));
+  hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
+                     (const double *)L->z.p, x);
+  return ISPH_SUCCESS;
+}
+
+inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, double *x) {
+  AmgLevel *L = G->L[(size_t)l];
+  const int n = L->A.n;
+  if (l == G->nlev - 1) {
+    if (G->singular) {
+      ISPH_CHECK(amg_smooth(ctx, G, l, b, x, true));
+      for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
+    } else if (n > 0) {
+      hipLaunchKernelGGL(k_dense_apply, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const double *)G->cinv.p, b, x);
+    }
+    return ISPH_SUCCESS;
+  }
+  AmgLevel *Lc = G->L[(size_t)l + 1];
+  ISPH_CHECK(amg_smooth(ctx, G, l, b, x, true));
+  for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
+  ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
+  hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
+  ISPH_CHECK(spmv_dev(ctx, L->Rm, L->r.p, Lc->b.p, nullptr));
+  ISPH_CHECK(amg_vcycle(ctx, G, l + 1, Lc->b.p, Lc->x.p));
+  ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, L->r.p, nullptr));
+  hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
+                     (const double *)L->r.p, x);
+  for (int s = 0; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
+  return ISPH_SUCCESS;
+}
+
+inline int amg_apply(isph_ctx *ctx, const isph_amg *G, const double *r, double *z) {
+  ISPH_REQUIRE(G != nullptr, "AMG hierarchy is NULL");
+  ISPH_CHECK(amg_vcycle(ctx, G, 0, r, z));
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+}  // namespace isph

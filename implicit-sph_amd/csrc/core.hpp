@@ -35,13 +35,16 @@ struct isph_halo {
 struct isph_mat {
   isph::Sell S;
   isph_halo halo;
+  bool local = false;  // rectangular operator on rank-local vectors (AMG transfer operators): no ghost columns
 };
 
 struct isph_ilu;  // ilu.hpp
+struct isph_amg;  // amg.hpp
 
 struct isph_prec {
-  int type = 0;  // 0 none, 1 jacobi, 2 bjacobi-ilu0
+  int type = 0;  // 0 none, 1 jacobi, 2 bjacobi-ilu0, 3 sa-amg
   int n = 0;
   isph::DevBuf<double> invdiag;
   isph_ilu *ilu = nullptr;
+  isph_amg *amg = nullptr;
 };

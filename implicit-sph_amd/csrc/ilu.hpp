@@ -466,6 +466,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
 }
 
 // ---------------------------------------------------------------------------
+// Block-local symmetric Gauss-Seidel in the same stream form (no factorisation): with
+// M_B = (D+L_B) D^-1 (D+U_B),  M_B^-1 r = (D+U_B)^-1 [ D (D+L_B)^-1 r ]  and  y = D (D+L_B)^-1 r  solves the
+// unit-lower system  y_i = r_i - sum_j (a_ij / a_jj) y_j,  so the "L factor" is a_ij / a_jj, the "U factor" a_ij
+// and the pivots a_ii.  Used as the AMG smoother (amg.hpp).
+__global__ void k_sgs_fill(int n, const long long *__restrict__ frp, const int *__restrict__ fcol,
+                           const double *__restrict__ fval, const int *__restrict__ flen,
+                           const int *__restrict__ fdiag, const int *__restrict__ fdst, double *__restrict__ sv,
+                           double *__restrict__ dinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long rp = frp[i];
+  const int len = flen[i], dg = fdiag[i];
+  dinv[i] = 1.0 / fval[rp + dg];
+  for (int s = 0; s < len; ++s) {
+    const int d = fdst[rp + s];
+    if (d < 0) continue;
+    double a = fval[rp + s];
+    if (s < dg) {
+      const int j = fcol[rp + s];
+      a *= 1.0 / fval[frp[j] + fdiag[j]];
+    }
+    sv[d] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // z = U^-1 D^-1 L^-1 r : one wave per block streams the block's chunk list.
 // LDS per wave: y[B] and the block's reciprocal pivots.  kPrefetch chunks (values + words) are kept in flight.
 template <int WAVES, int PF>
@@ -579,7 +605,7 @@ inline int ilu_check_err(isph_ctx *ctx, isph_ilu *F, const char *what, bool *ove
   return ISPH_SUCCESS;
 }
 
-inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out) {
+inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false) {
   const Sell &S = A->S;
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
                "bjacobi-ilu0 block size must be a multiple of 64 in [64,1024]");
@@ -611,7 +637,7 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
     const int W = ((S.wmax + 63) / 64) * 64;
     const size_t Bz = (size_t)block_size;
     const size_t lds_f = 8 * Bz + (size_t)kIluWaves * W * 12 + 8 * Bz + 4 * (5 * Bz + 4) + 2 * Bz + 2 * (size_t)kIluWaves * Bz + 16;
-    if (lds_f > 160 * 1024) rc = fail("ILU factor kernel needs too much LDS for this row width", __FILE__, __LINE__);
+    if (!sgs && lds_f > 160 * 1024) rc = fail("ILU factor kernel needs too much LDS for this row width", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
       rc = fail("memset failed", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) {
@@ -639,7 +665,11 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
           rc = fail("memset failed", __FILE__, __LINE__);
       }
     }
-    if (rc == ISPH_SUCCESS) {
+    if (rc == ISPH_SUCCESS && sgs) {
+      hipLaunchKernelGGL(k_sgs_fill, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
+                         F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->sv.p, F->dinv.p);
+      if (hipGetLastError() != hipSuccess) rc = fail("SGS fill launch failed", __FILE__, __LINE__);
+    } else if (rc == ISPH_SUCCESS) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_factor<kIluWaves>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess)
         rc = fail("LDS attribute failed", __FILE__, __LINE__);

@@ -10,6 +10,7 @@
 #include "krylov.hpp"
 #include "sell.hpp"
 #include "solver.hpp"
+#include "amg.hpp"
 
 namespace isph {
 thread_local std::string g_last_error;
@@ -26,6 +27,7 @@ int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z
     hipLaunchKernelGGL(k_mul_elem, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, r, M->invdiag.p, z);
     return ISPH_SUCCESS;
   }
+  if (M->type == 3) return amg_apply(ctx, M->amg, r, z);
   return ilu_apply(ctx, M->ilu, r, z);
 }
 
@@ -161,6 +163,36 @@ void isph_ctx_destroy(isph_ctx *c) {
 
 /* ---- matrix ----------------------------------------------------------- */
 
+}  // extern "C"
+
+// CSR (device pointers, any shape) -> sliced-ELL matrix; rows end up column-sorted
+int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const int *dci, const double *dv, long long nnz,
+                        isph_mat **Aout) {
+  isph_mat *A = new isph_mat();
+  Sell &S = A->S;
+  S.nrow = nrow; S.ncol = ncol; S.nnz = nnz;
+  S.nslices = (nrow + kSlice - 1) / kSlice;
+  int rc = S.slice_off.reserve((size_t)S.nslices + 1);
+  if (rc == ISPH_SUCCESS) rc = S.rowlen.reserve((size_t)(nrow > 0 ? nrow : 1));
+  if (rc == ISPH_SUCCESS && nrow > 0) {
+    hipLaunchKernelGGL(k_csr_rowlen_slicew, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, drp,
+                       S.rowlen.p, S.slice_off.p);
+    rc = sell_finalize_offsets(ctx, S);
+    if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL(k_csr_to_sell, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
+                         S.slice_off.p, S.col.p, S.val.p);
+      rc = sell_sort_rows(ctx, S);
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+        rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);
+    }
+  }
+  if (rc != ISPH_SUCCESS) { isph_mat_destroy(A); return rc; }
+  *Aout = A;
+  return ISPH_SUCCESS;
+}
+
+extern "C" {
+
 int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx,
                         const double *val, int on_device, isph_mat **Aout) {
   ISPH_REQUIRE(ctx && Aout && rowptr && colidx && val, "NULL argument");
@@ -184,26 +216,10 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, co
   }
   ISPH_CHECK(stage_in(ctx, colidx, (size_t)nnz, on_device, tci, &dci));
   ISPH_CHECK(stage_in(ctx, val, (size_t)nnz, on_device, tv, &dv));
-  isph_mat *A = new isph_mat();
-  Sell &S = A->S;
-  S.nrow = nrow; S.ncol = ncol; S.nnz = nnz;
-  S.nslices = (nrow + kSlice - 1) / kSlice;
-  int rc = S.slice_off.reserve((size_t)S.nslices + 1);
-  if (rc == ISPH_SUCCESS) rc = S.rowlen.reserve((size_t)(nrow > 0 ? nrow : 1));
-  if (rc == ISPH_SUCCESS && nrow > 0) {
-    hipLaunchKernelGGL(k_csr_rowlen_slicew, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, drp,
-                       S.rowlen.p, S.slice_off.p);
-    rc = sell_finalize_offsets(ctx, S);
-    if (rc == ISPH_SUCCESS) {
-      hipLaunchKernelGGL(k_csr_to_sell, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
-                         S.slice_off.p, S.col.p, S.val.p);
-      rc = sell_sort_rows(ctx, S);
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
-        rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);
-    }
-  }
+  isph_mat *A = nullptr;
+  const int rc = mat_from_device_csr(ctx, nrow, ncol, drp, dci, dv, nnz, &A);
   trp.release(); tci.release(); tv.release();
-  if (rc != ISPH_SUCCESS) { isph_mat_destroy(A); return rc; }
+  if (rc != ISPH_SUCCESS) return rc;
   *Aout = A;
   return ISPH_SUCCESS;
 }
@@ -416,7 +432,77 @@ void isph_prec_destroy(isph_prec *M) {
   if (!M) return;
   M->invdiag.release();
   if (M->ilu) ilu_destroy(M->ilu);
+  if (M->amg) amg_destroy(M->amg);
   delete M;
+}
+
+/* ---- SA-AMG ----------------------------------------------------------- */
+
+void isph_amg_params_default(isph_amg_params *p) {
+  // PrecondWrapper_ML::setParameters(NULL), ref: precond_ml.h:44-55, plus ML's own defaults
+  p->max_levels = 5; p->coarse_max = 128; p->omega = 4.0 / 3.0; p->block = 512; p->sweeps = 1; p->theta = 0.0;
+}
+
+int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params *prm, const double *nullvec,
+                         int on_device, isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && A && Mout, "NULL argument");
+  isph_amg_params def;
+  isph_amg_params_default(&def);
+  if (!prm) prm = &def;
+  isph_prec *M = new isph_prec();
+  M->n = A->S.nrow;
+  M->type = 3;
+  DevBuf<double> tn;
+  const double *dn = nullptr;
+  int rc = nullvec ? stage_in(ctx, nullvec, (size_t)M->n, on_device, tn, &dn) : ISPH_SUCCESS;
+  if (rc == ISPH_SUCCESS) rc = amg_create(ctx, A, prm, dn, &M->amg);
+  tn.release();
+  if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
+  *Mout = M;
+  return ISPH_SUCCESS;
+}
+
+int isph_prec_amg_levels(const isph_prec *M) { return (M && M->type == 3 && M->amg) ? M->amg->nlev : 0; }
+
+int isph_prec_amg_info(isph_ctx *ctx, const isph_prec *M, int level, long long info[3]) {
+  ISPH_REQUIRE(ctx && M && M->type == 3 && M->amg && info, "not an AMG preconditioner");
+  ISPH_REQUIRE(level >= 0 && level < M->amg->nlev, "level out of range");
+  const AmgLevel *L = M->amg->L[(size_t)level];
+  info[0] = L->A.n; info[1] = L->A.nnz; info[2] = level < M->amg->nlev - 1 ? L->P.nnz : 0;
+  return ISPH_SUCCESS;
+}
+
+int isph_prec_amg_export(isph_ctx *ctx, const isph_prec *M, int level, int what, int *rowptr, int *colidx, double *val) {
+  ISPH_REQUIRE(ctx && M && M->type == 3 && M->amg && rowptr && colidx && val, "not an AMG preconditioner");
+  ISPH_REQUIRE(level >= 0 && level < M->amg->nlev && (what == 0 || (what == 1 && level < M->amg->nlev - 1)), "level out of range");
+  const DCsr &C = what == 0 ? M->amg->L[(size_t)level]->A : M->amg->L[(size_t)level]->P;
+  std::vector<int> ci((size_t)C.nnz);
+  std::vector<double> v((size_t)C.nnz);
+  ISPH_CHECK_HIP(hipMemcpyAsync(rowptr, C.rp.p, sizeof(int) * ((size_t)C.n + 1), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(ci.data(), C.ci.p, sizeof(int) * (size_t)C.nnz, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(v.data(), C.v.p, sizeof(double) * (size_t)C.nnz, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int> perm;
+  for (int i = 0; i < C.n; ++i) {  // coarse rows come out of the SpGEMM in table order: sort for the caller
+    const int b = rowptr[i], e = rowptr[i + 1];
+    perm.resize((size_t)(e - b));
+    std::iota(perm.begin(), perm.end(), 0);
+    std::sort(perm.begin(), perm.end(), [&](int a, int c) { return ci[(size_t)(b + a)] < ci[(size_t)(b + c)]; });
+    for (int k = b; k < e; ++k) {
+      colidx[k] = ci[(size_t)(b + perm[(size_t)(k - b)])];
+      val[k] = v[(size_t)(b + perm[(size_t)(k - b)])];
+    }
+  }
+  return ISPH_SUCCESS;
+}
+
+int isph_prec_amg_aggregates(isph_ctx *ctx, const isph_prec *M, int level, int *agg) {
+  ISPH_REQUIRE(ctx && M && M->type == 3 && M->amg && agg, "not an AMG preconditioner");
+  ISPH_REQUIRE(level >= 0 && level < M->amg->nlev - 1, "level out of range");
+  const AmgLevel *L = M->amg->L[(size_t)level];
+  ISPH_CHECK_HIP(hipMemcpyAsync(agg, L->agg.p, sizeof(int) * (size_t)L->A.n, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return ISPH_SUCCESS;
 }
 
 /* ---- solve ------------------------------------------------------------ */

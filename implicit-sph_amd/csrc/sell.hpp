@@ -92,7 +92,8 @@ __global__ void k_csr_to_sell(int nrow, const int *__restrict__ rowptr, const in
     beg = rowptr[row];
     len = rowptr[row + 1] - beg;
   }
-  const int padcol = row < nrow ? row : 0;
+  // padding repeats a column the row already reads (always in range, also for rectangular operators)
+  const int padcol = len > 0 ? colidx[beg] : 0;
   for (int k = 0; k < w; ++k) {
     const long long p = sell_pos(off, lane, k);
     if (k < len) {

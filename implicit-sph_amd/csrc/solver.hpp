@@ -50,7 +50,7 @@ __global__ void k_gather(int n, const int *__restrict__ idx, const double *__res
 // returns the pointer the SpMV kernel should gather from
 inline int halo_exchange(isph_ctx *ctx, const isph_mat *A, const double *x, const double **xuse) {
   const Sell &S = A->S;
-  if (S.ncol == S.nrow) { *xuse = x; return ISPH_SUCCESS; }
+  if (S.ncol == S.nrow || A->local) { *xuse = x; return ISPH_SUCCESS; }
   const isph_halo &H = A->halo;
   ISPH_REQUIRE(H.nrecv == S.ncol - S.nrow, "matrix has ghost columns but no matching halo plan");
   ISPH_CHECK(ctx->xext.reserve((size_t)S.ncol));

@@ -22,7 +22,21 @@ EXPORTS = [
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
+    "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
+    "isph_prec_amg_export", "isph_prec_amg_aggregates",
 ]
+
+
+class AmgParams(C.Structure):
+    """Mirror of isph_amg_params == the keys PrecondWrapper_ML::setParameters sets (precond_ml.h:44-55)."""
+    _fields_ = [("max_levels", C.c_int), ("coarse_max", C.c_int), ("omega", C.c_double), ("block", C.c_int),
+                ("sweeps", C.c_int), ("theta", C.c_double)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib().isph_amg_params_default(C.byref(self))
+        for k, v in kw.items():
+            setattr(self, k, v)
 
 
 class SolverParams(C.Structure):
@@ -112,6 +126,12 @@ def lib():
                                          C.c_void_p, C.c_void_p, C.c_int]
         L.isph_advance_end.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_amg_params_default.argtypes = [C.c_void_p]
+        L.isph_prec_create_amg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.isph_prec_amg_levels.argtypes = [C.c_void_p]
+        L.isph_prec_amg_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.isph_prec_amg_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_prec_amg_aggregates.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.isph_compute_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.isph_apply_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int]
@@ -304,6 +324,41 @@ class Precond:
             self.close()
         except Exception:
             pass
+
+
+class PrecondAMG(Precond):
+    """isph_prec_create_amg == PrecondWrapper_ML::create() (with setNullVector when nullvec is given)."""
+
+    def __init__(self, ctx, A, nullvec=None, params=None):
+        self.ctx, self.n = ctx, A.info()["nrow"]
+        self.h = C.c_void_p()
+        prm = params or AmgParams()
+        nv = None if nullvec is None else _f64(nullvec)
+        _check(lib().isph_prec_create_amg(ctx.h, A.h, C.byref(prm), _ptr(nv), int(nv is not None and _is_torch(nv)),
+                                          C.byref(self.h)))
+
+    @property
+    def levels(self):
+        return lib().isph_prec_amg_levels(self.h)
+
+    def level_info(self, l):
+        a = (C.c_longlong * 3)()
+        _check(lib().isph_prec_amg_info(self.ctx.h, self.h, l, a))
+        return dict(rows=int(a[0]), nnz=int(a[1]), nnz_p=int(a[2]))
+
+    def export(self, l, what="A"):
+        i = self.level_info(l)
+        nnz = i["nnz"] if what == "A" else i["nnz_p"]
+        rp = np.zeros(i["rows"] + 1, dtype=np.int32)
+        ci = np.zeros(nnz, dtype=np.int32)
+        v = np.zeros(nnz)
+        _check(lib().isph_prec_amg_export(self.ctx.h, self.h, l, 0 if what == "A" else 1, _ptr(rp), _ptr(ci), _ptr(v)))
+        return rp, ci, v
+
+    def aggregates(self, l):
+        a = np.zeros(self.level_info(l)["rows"], dtype=np.int32)
+        _check(lib().isph_prec_amg_aggregates(self.ctx.h, self.h, l, _ptr(a)))
+        return a
 
 
 def solve(ctx, A, b, x, prec=None, singular=False, null_mask=None, params=None, nvec=1, lda=None):

@@ -237,6 +237,28 @@ int isph_advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, doub
 int isph_advance_end(isph_ctx *ctx, int count, int dim, double dt, const double *dp, const double *vnp1,
                      double *p, double *x, double *v, int on_device);
 
+/* ---- smoothed-aggregation AMG in place of PrecondWrapper_ML (precond_ml.h:40-171) ----
+ * Parameters mirror the keys the wrapper sets (precond_ml.h:44-55): "max levels" 5, "aggregation: type" Uncoupled,
+ * "smoother: type" symmetric Gauss-Seidel with "smoother: sweeps" 1 pre and post, direct coarse solve; plus ML's
+ * defaults "coarse: max size" 128, "aggregation: damping factor" 4/3, "aggregation: threshold" 0.  `block` is the
+ * row-block the Gauss-Seidel sweeps are local to (ML: the processor).  nullvec != NULL restates
+ * PrecondWrapper_ML::setNullVector (precond_ml.h:97-127): one pre-computed null-space vector, smoother as the
+ * coarse solver.  The hierarchy is rebuilt on every create, like the reference does on every solve. */
+typedef struct {
+  int max_levels, coarse_max;
+  double omega;
+  int block, sweeps;
+  double theta;
+} isph_amg_params;
+void isph_amg_params_default(isph_amg_params *p);
+int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params *prm, const double *nullvec,
+                         int on_device, isph_prec **M);
+/* test/diagnostic access: info = {rows, nnz(A_l), nnz(P_l)}; what: 0 = A_l, 1 = P_l (CSR, columns ascending) */
+int isph_prec_amg_levels(const isph_prec *M);
+int isph_prec_amg_info(isph_ctx *ctx, const isph_prec *M, int level, long long info[3]);
+int isph_prec_amg_export(isph_ctx *ctx, const isph_prec *M, int level, int what, int *rowptr, int *colidx, double *val);
+int isph_prec_amg_aggregates(isph_ctx *ctx, const isph_prec *M, int level, int *agg);
+
 /* Particle shifting (fix isph/shift -> PairISPH_Corrected::shiftParticles, pair_isph_corrected.cpp:1203-1262).
  * isph_compute_shift replaces FunctorOuterComputeShift (functor_compute_shift.h:48-113): dr[nlocal][3] for the fluid
  * particles, pairs inside min(cutsq, shiftcut^2), alpha = shift*dt*vmax.

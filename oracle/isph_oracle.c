@@ -1108,6 +1108,7 @@ typedef struct {
   const double *nvec; /* NULL unless singular */
   int prec_type;
   const orc_ilu *F;
+  const orc_amg *G;
   double *invdiag;
 } lin_ctx;
 
@@ -1121,6 +1122,7 @@ static void op_apply(const lin_ctx *c, const double *x, double *y) {
 }
 static void prec_apply(const lin_ctx *c, const double *r, double *z) {
   if (c->prec_type == 2 && c->F) orc_ilu_apply(c->F, r, z);
+  else if (c->prec_type == 3 && c->G) orc_amg_apply(c->G, r, z);
   else if (c->prec_type == 1) {
 #pragma omp parallel for schedule(static) if (c->n > 16384)
     for (int i = 0; i < c->n; ++i) z[i] = r[i] * c->invdiag[i];
@@ -1289,13 +1291,15 @@ static void pcg(const lin_ctx *c, const double *b, double *x,
  * b is modified in place exactly as the reference modifies *_b. */
 int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
               double *b, double *x, int is_singular, const int *null_mask,
-              int prec_type, const orc_ilu *F,
+              int prec_type, const void *prec_obj,
               const orc_solver_params *prm, orc_solve_info *info) {
   const double t0 = now_sec();
   lin_ctx c;
   memset(&c, 0, sizeof(c));
   c.n = n; c.rowptr = rowptr; c.colidx = colidx; c.val = val;
-  c.prec_type = prec_type; c.F = F;
+  c.prec_type = prec_type;
+  c.F = prec_type == 2 ? (const orc_ilu *)prec_obj : NULL;
+  c.G = prec_type == 3 ? (const orc_amg *)prec_obj : NULL;
   double *nvec = NULL;
   if (is_singular) {
     nvec = (double *)malloc(sizeof(double) * (size_t)n);

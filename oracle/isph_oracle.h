@@ -140,10 +140,24 @@ int  orc_ilu_nnz(const orc_ilu *F);
 void orc_ilu_export(const orc_ilu *F, int *rowptr, int *colidx, double *val);
 void orc_ilu_destroy(orc_ilu *F);
 
-/* prec_type: 0 none, 1 jacobi, 2 (block-)ILU(k) given by F */
+/* ---- smoothed-aggregation AMG standing in for PrecondWrapper_ML
+ *      (precond_ml.h:40-171; isph_amg_oracle.c states what is restated and what departs) ---- */
+typedef struct orc_amg orc_amg;
+orc_amg *orc_amg_create(int n, const int *rowptr, const int *colidx, const double *val,
+                        const double *nullvec /* NULL: non-singular, constant near-null space */,
+                        int max_levels, int coarse_max, double omega, int block, int sweeps,
+                        double theta /* "aggregation: threshold", ML default 0 */);
+void orc_amg_apply(const orc_amg *G, const double *r, double *z);
+int  orc_amg_levels(const orc_amg *G);
+void orc_amg_level_info(const orc_amg *G, int l, int *info /* rows, nnz A_l, nnz P_l */);
+void orc_amg_export(const orc_amg *G, int l, int what /* 0 A_l, 1 P_l */, int *rowptr, int *colidx, double *val);
+void orc_amg_export_aggregates(const orc_amg *G, int l, int *agg);
+void orc_amg_destroy(orc_amg *G);
+
+/* prec_type: 0 none, 1 jacobi, 2 (block-)ILU(k) (prec_obj = orc_ilu*), 3 SA-AMG (prec_obj = orc_amg*) */
 int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
               double *b, double *x, int is_singular, const int *null_mask,
-              int prec_type, const orc_ilu *F,
+              int prec_type, const void *prec_obj,
               const orc_solver_params *prm, orc_solve_info *info);
 
 int orc_num_threads(void);

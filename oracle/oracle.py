@@ -63,6 +63,15 @@ def lib():
         L.orc_ilu_nnz.argtypes = [C.c_void_p]
         L.orc_ilu_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ilu_destroy.argtypes = [C.c_void_p]
+        L.orc_amg_create.restype = C.c_void_p
+        L.orc_amg_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_double, C.c_int, C.c_int, C.c_double]
+        L.orc_amg_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_amg_levels.argtypes = [C.c_void_p]
+        L.orc_amg_level_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_amg_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_amg_export_aggregates.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_amg_destroy.argtypes = [C.c_void_p]
         L.orc_laplacian_matrix.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_divergence.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int,
@@ -284,8 +293,53 @@ class ILU:
             self.h = None
 
 
+class AMG:
+    """Smoothed-aggregation AMG standing in for PrecondWrapper_ML (isph_amg_oracle.c)."""
+
+    def __init__(self, rowptr, colidx, val, nullvec=None, max_levels=5, coarse_max=128, omega=4.0 / 3.0, block=512,
+                 sweeps=1, theta=0.0):
+        self.n = len(rowptr) - 1
+        self._keep = (_i32(rowptr), _i32(colidx), _f64(val), None if nullvec is None else _f64(nullvec))
+        self.h = lib().orc_amg_create(self.n, _p(self._keep[0]), _p(self._keep[1]), _p(self._keep[2]), _p(self._keep[3]),
+                                      max_levels, coarse_max, omega, block, sweeps, theta)
+
+    @property
+    def levels(self):
+        return lib().orc_amg_levels(self.h)
+
+    def level_info(self, l):
+        a = np.zeros(3, dtype=np.int32)
+        lib().orc_amg_level_info(self.h, l, _p(a))
+        return dict(rows=int(a[0]), nnz=int(a[1]), nnz_p=int(a[2]))
+
+    def export(self, l, what="A"):
+        i = self.level_info(l)
+        nnz = i["nnz"] if what == "A" else i["nnz_p"]
+        rp = np.zeros(i["rows"] + 1, dtype=np.int32)
+        ci = np.zeros(nnz, dtype=np.int32)
+        v = np.zeros(nnz)
+        lib().orc_amg_export(self.h, l, 0 if what == "A" else 1, _p(rp), _p(ci), _p(v))
+        return rp, ci, v
+
+    def aggregates(self, l):
+        a = np.zeros(self.level_info(l)["rows"], dtype=np.int32)
+        lib().orc_amg_export_aggregates(self.h, l, _p(a))
+        return a
+
+    def apply(self, r):
+        r = _f64(r)
+        z = np.zeros(self.n)
+        lib().orc_amg_apply(self.h, _p(r), _p(z))
+        return z
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_amg_destroy(self.h)
+            self.h = None
+
+
 def solve(rowptr, colidx, val, b, x0=None, singular=False, null_mask=None, prec="none", ilu=None,
-          params=None):
+          params=None, amg=None):
     """SolverLin_Belos::solveProblem restatement.  Returns (x, info, b_projected)."""
     n = len(rowptr) - 1
     rowptr, colidx, val = _i32(rowptr), _i32(colidx), _f64(val)
@@ -294,9 +348,10 @@ def solve(rowptr, colidx, val, b, x0=None, singular=False, null_mask=None, prec=
     prm = params or SolverParams()
     info = SolveInfo()
     mask = None if null_mask is None else _i32(null_mask)
-    ptype = {"none": 0, "jacobi": 1, "ilu": 2}[prec]
+    ptype = {"none": 0, "jacobi": 1, "ilu": 2, "amg": 3}[prec]
+    obj = amg.h if prec == "amg" else (ilu.h if ilu is not None else None)
     lib().orc_solve(n, _p(rowptr), _p(colidx), _p(val), _p(b), _p(x), int(singular), _p(mask), ptype,
-                    ilu.h if ilu is not None else None, C.byref(prm), C.byref(info))
+                    obj, C.byref(prm), C.byref(info))
     return x, info, b
 
 

@@ -1,0 +1,69 @@
+"""-m gpu: smoothed-aggregation AMG (PrecondWrapper_ML) against the oracle's restatement
+(oracle/isph_amg_oracle.c): hierarchy entry by entry, one V cycle, and the preconditioned solve."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from isph_amd import hip, workload
+import oracle as orc
+from problems import Problem, tgv_spec, wall_types
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(rp, ci, v, n, m):
+    return sps.csr_matrix((v, ci, rp), shape=(n, m))
+
+
+CASES = [
+    (dict(dim=3, n=16, mode=workload.ADVECT, brick=8), 0.0, True),
+    (dict(dim=3, n=20, mode=workload.JITTER, brick=4), 0.02, True),
+    (dict(dim=2, n=48, mode=workload.JITTER, brick=8), 0.0, True),
+    (dict(dim=2, n=40, mode=workload.JITTER, brick=8), 0.05, False),
+]
+
+
+@pytest.mark.parametrize("case,theta,singular", CASES)
+def test_amg_hierarchy_cycle_and_solve_match_oracle(gpu_ctx, case, theta, singular):
+    if singular:
+        pr = Problem(tgv_spec(**case))
+    else:  # solid slab + NotSingular Poisson: a non-singular operator, direct coarse solve
+        pr = Problem(tgv_spec(**case), singular=orc.NOT_SINGULAR, kinds=[orc.FLUID, orc.SOLID], types=wall_types)
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    nv = np.ones(n) / np.sqrt(n) if singular else None
+    kw = dict(theta=theta, block=256, coarse_max=64)
+    G = orc.AMG(rp, ci, val, nullvec=nv, **kw)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(**kw))
+    assert M.levels == G.levels and M.levels >= 2
+    for l in range(G.levels):
+        io, ig = G.level_info(l), M.level_info(l)
+        assert io == ig
+        ro, co, vo = G.export(l, "A")
+        rg, cg, vg = M.export(l, "A")
+        assert np.array_equal(ro, rg) and np.array_equal(co, cg)
+        assert np.max(np.abs(vo - vg)) <= 1e-11 * np.abs(vo).max()
+        if l < G.levels - 1:
+            assert np.array_equal(G.aggregates(l), M.aggregates(l))
+            ro, co, vo = G.export(l, "P")
+            rg, cg, vg = M.export(l, "P")
+            assert np.array_equal(ro, rg) and np.array_equal(co, cg)
+            assert np.max(np.abs(vo - vg)) <= 1e-12 * np.abs(vo).max()
+    r = np.random.default_rng(4).standard_normal(n)
+    zo, zg = G.apply(r), M.apply(r)
+    assert np.linalg.norm(zg - zo) <= 1e-9 * np.linalg.norm(zo)
+    xo, io_, _ = orc.solve(rp, ci, val, b, singular=singular, prec="amg", amg=G)
+    bg, xg = b.copy(), np.zeros(n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=singular)
+    assert info.converged == 1 and io_.converged == 1 and abs(info.iters - io_.iters) <= 1
+    assert np.linalg.norm(xg - xo) <= 1e-6 * np.linalg.norm(xo)
+    # the coarse operator keeps the null space: A_c n_c = P^T A P n_c = P^T A n ~ 0
+    if singular:
+        r1, c1, v1 = M.export(1, "A")
+        n1 = M.level_info(1)["rows"]
+        rP, cP, vP = M.export(0, "P")
+        P = _csr(rP, cP, vP, n, n1)
+        nc = np.linalg.lstsq(P.toarray(), nv, rcond=None)[0] if n <= 4096 else None
+        if nc is not None:
+            assert np.linalg.norm(_csr(r1, c1, v1, n1, n1) @ nc) <= 1e-10 * np.abs(v1).max() * np.linalg.norm(nc)

@@ -8,7 +8,7 @@ import scipy.sparse.linalg as spla
 
 from isph_amd import workload
 import oracle as orc
-from problems import Problem, tgv_spec
+from problems import Problem, tgv_spec, wall_types
 
 
 def test_reference_probe_row_from_survey():
@@ -224,3 +224,42 @@ def test_shift_serial_in_place_and_pre_shift_state_differ_at_second_order():
         gaps.append(np.abs(ps - pj).max() / first)
         assert first > 0 and gaps[-1] < 0.2
     assert gaps[1] < 0.2 * gaps[0]                          # relative gap ~ |dr|
+
+
+# ---------------------------------------------------------------- smoothed-aggregation AMG restatement
+def test_amg_oracle_hierarchy_invariants_and_convergence():
+    """oracle/isph_amg_oracle.c: aggregates partition the nodes, P reproduces the null vector, the Galerkin
+    operator keeps it in its kernel, and the cycle beats point Jacobi as a GMRES preconditioner."""
+    pr = Problem(tgv_spec(dim=3, n=20, mode=workload.JITTER, brick=4))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    nv = np.ones(n) / np.sqrt(n)
+    G = orc.AMG(rp, ci, val, nullvec=nv, theta=0.02, block=256, coarse_max=64)
+    assert G.levels >= 2
+    agg = G.aggregates(0)
+    n1 = G.level_info(1)["rows"]
+    assert agg.min() == 0 and agg.max() == n1 - 1 and len(np.unique(agg)) == n1
+    rP, cP, vP = G.export(0, "P")
+    P = sps.csr_matrix((vP, cP, rP), shape=(n, n1))
+    A = sps.csr_matrix((val, ci, rp), shape=(n, n))
+    nc = np.sqrt(np.bincount(agg, weights=nv * nv))          # coarse null vector = aggregate norms
+    assert np.linalg.norm(P @ nc - nv) <= 1e-12              # (I - w D^-1 A) P_t n_c = n - w D^-1 A n = n
+    r1, c1, v1 = G.export(1, "A")
+    A1 = sps.csr_matrix((v1, c1, r1), shape=(n1, n1))
+    assert abs(A1 - P.T @ A @ P).max() <= 1e-12 * abs(A1).max()
+    assert np.linalg.norm(A1 @ nc) <= 1e-10 * abs(A1).max()
+    x, info, _ = orc.solve(rp, ci, val, b, singular=True, prec="amg", amg=G)
+    xj, infoj, _ = orc.solve(rp, ci, val, b, singular=True, prec="jacobi")
+    assert info.converged == 1 and info.iters < infoj.iters
+    assert np.linalg.norm(x - xj) <= 1e-6 * np.linalg.norm(xj)
+
+
+def test_amg_oracle_nonsingular_direct_coarse_solve():
+    pr = Problem(tgv_spec(dim=2, n=40, mode=workload.JITTER, brick=8), singular=orc.NOT_SINGULAR,
+                 kinds=[orc.FLUID, orc.SOLID], types=wall_types)
+    rp, ci, val, b = pr.poisson()
+    G = orc.AMG(rp, ci, val, theta=0.05, block=256, coarse_max=64)
+    x, info, _ = orc.solve(rp, ci, val, b, singular=False, prec="amg", amg=G)
+    A = sps.csr_matrix((val, ci, rp), shape=(pr.n, pr.n))
+    assert info.converged == 1
+    assert np.linalg.norm(b - A @ x) <= 2e-8 * np.linalg.norm(b)
