@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncell", type=int, default=100, help="lattice cells per axis PER GPU brick edge")
     ap.add_argument("--mode", default="advect", choices=["advect", "jitter", "lattice"])
-    ap.add_argument("--prec", default="bjacobi-ilu0", choices=["none", "jacobi", "bjacobi-ilu0"])
+    ap.add_argument("--prec", default="bjacobi-ilu0", choices=["none", "jacobi", "bjacobi-ilu0", "sa-amg"])
+    ap.add_argument("--amg-theta", type=float, default=0.0, help='"aggregation: threshold" of the sa-amg variant (ML default 0)')
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,11 +53,17 @@ def parse():
     return ap.parse_args()
 
 
+METRIC_NAME = {
+    "bjacobi-ilu0": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+block-Jacobi ILU(0), tol 1e-8)",
+    "sa-amg": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+SA-AMG V cycle, tol 1e-8)",
+}
+
+
 def pgrid_for(n):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
 
 
-def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters):
+def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters, amg_theta=0.0):
     """Oracle (CPU restatement of Belos FGMRES + Ifpack block-ILU(0)) timed on the
     host cores on a bounded sample: preconditioner setup + `cpu_iters` of the
     iterations the full solve needs, extrapolated linearly."""
@@ -67,18 +74,21 @@ def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters):
     if prec == "bjacobi-ilu0":
         bp = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
         ilu = orc.ILU(rp, ci, val, 0, bp)
+    amg = None
+    if prec == "sa-amg":
+        amg = orc.AMG(rp, ci, val, nullvec=np.full(n, 1.0 / np.sqrt(n)), block=block, theta=amg_theta)
     t_setup = time.perf_counter() - t0
-    pk = {"none": "none", "jacobi": "jacobi", "bjacobi-ilu0": "ilu"}[prec]
+    pk = {"none": "none", "jacobi": "jacobi", "bjacobi-ilu0": "ilu", "sa-amg": "amg"}[prec]
     ts = []
     for it in (max(cpu_iters // 2, 1), cpu_iters):
         t0 = time.perf_counter()
-        orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, params=orc.SolverParams(max_iters=it))
+        orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, amg=amg, params=orc.SolverParams(max_iters=it))
         ts.append((it, time.perf_counter() - t0))
     per_iter = (ts[1][1] - ts[0][1]) / max(ts[1][0] - ts[0][0], 1)
     total = t_setup + ts[1][1] + per_iter * max(iters_gpu - ts[1][0], 0)
     return dict(value=1.0 / total, unit="solves/s", cores=orc.num_threads(), kind="port",
-                sample="same %d-row system: block-ILU(0) setup (%.2fs) + %d of %d FGMRES iterations (%.2fs), "
-                       "extrapolated at %.3fs/iteration" % (n, t_setup, ts[1][0], iters_gpu, ts[1][1], per_iter),
+                sample="same %d-row system: %s setup (%.2fs) + %d of %d FGMRES iterations (%.2fs), "
+                       "extrapolated at %.3fs/iteration" % (n, prec, t_setup, ts[1][0], iters_gpu, ts[1][1], per_iter),
                 seconds_per_solve=total)
 
 
@@ -156,11 +166,17 @@ def main():
     ctx.set_profile(True)
 
     pinfo = {}
+    nullvec = torch.full((nlocal,), 1.0 / np.sqrt(float(nlocal * world)), dtype=torch.float64, device=dev)
 
     def step():
         bwork.copy_(b)
         x.zero_()
-        M = hip.Precond(ctx, A, args.prec, args.block)
+        if args.prec == "sa-amg":
+            M = hip.PrecondAMG(ctx, A, nullvec=nullvec, params=hip.AmgParams(block=args.block, theta=args.amg_theta))
+            if not pinfo:
+                pinfo.update(levels=[M.level_info(l) for l in range(M.levels)])
+        else:
+            M = hip.Precond(ctx, A, args.prec, args.block)
         if not pinfo and args.prec == "bjacobi-ilu0":
             pinfo.update(M.info())
         inf = hip.solve(ctx, A, bwork, x, prec=M, singular=True, params=prm)
@@ -208,7 +224,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+block-Jacobi ILU(0), tol 1e-8)",
+            "metric": METRIC_NAME.get(args.prec, METRIC_NAME["bjacobi-ilu0"]),
             "value": args.steps * world / elapsed,
             "unit": "solves/s (1M-particle bricks; x n_gpus under weak scaling)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,7 +239,7 @@ def main():
                        "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms,
-                       "spmv_isolated_ms": iso_ms, "ilu": pinfo},
+                       "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo},
             "roofline": {"bound": "hbm", "kernel": "k_sell_spmv", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_spmv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
@@ -232,7 +248,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rp, ci, val = A.export_csr()
             out["cpu_baseline"] = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, inf.iters, args.prec,
-                                               args.cpu_iters)
+                                               args.cpu_iters, args.amg_theta)
             out["config"]["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if td is not None:

@@ -21,7 +21,7 @@
 #include "solver.hpp"
 
 int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const int *dci, const double *dv, long long nnz,
-                        isph_mat **Aout);  // isph_capi.hip
+                        isph_mat **Aout, bool rows_sorted = false);  // isph_capi.hip
 void isph_mat_destroy(isph_mat *A);
 
 namespace isph {
@@ -132,9 +132,12 @@ __global__ __launch_bounds__(256) void k_mis_init(int n, const int *__restrict__
 __global__ __launch_bounds__(256) void k_mis_max(int n, const int *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ v, const double *__restrict__ dg, double th2,
                                                  const unsigned long long *__restrict__ in,
-                                                 unsigned long long *__restrict__ out) {
+                                                 unsigned long long *__restrict__ out,
+                                                 const unsigned long long *__restrict__ only_undecided) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
+  // second sweep: only undecided rows read their result
+  if (only_undecided && (only_undecided[i] >> 62) != AMG_UNDECIDED) return;
   unsigned long long m = in[i];
   for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
     const int j = ci[p];
@@ -255,14 +258,16 @@ __global__ void k_ptent(int n, const int *__restrict__ agg, const double *__rest
 // rho = max_i sum_j |a_ij| / |a_ii|  (bit pattern of a non-negative double orders like the number)
 __global__ __launch_bounds__(256) void k_amg_rho(int n, const int *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ v, const double *__restrict__ dg,
-                                                 unsigned long long *__restrict__ rho_bits) {
+                                                 volatile unsigned long long *rho_bits) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   double s = 0.0;
   for (int p = rp[i] + lane; p < rp[i + 1]; p += 64)
     if (ci[p] < n) s += fabs(v[p]);
   s = wave_sum(s) / fabs(dg[i]);
-  if (lane == 0) atomicMax(rho_bits, (unsigned long long)__double_as_longlong(s));
+  // one atomic per row would serialise a million updates of one word: only candidates above the running maximum try
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+  if (lane == 0 && bits > *rho_bits) atomicMax(const_cast<unsigned long long *>(rho_bits), bits);
 }
 
 // Row i of P = (I - damp D^-1 A) P_tent.  The row's distinct aggregates (<= 64) live one per lane in registers:
@@ -546,6 +551,20 @@ inline int amg_spgemm_t(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C, De
   return rc;
 }
 
+// A*P: rows see few distinct aggregates, so a small table is tried first (clearing the table is most of the cost)
+inline int amg_spgemm_ap(isph_ctx *ctx, const DCsr &A, const DCsr &P, DCsr &AP, DevBuf<char> &tmp, int *derr) {
+  int before = 0, after = 0;
+  ISPH_CHECK(amg_read_int(ctx, derr, &before));
+  ISPH_CHECK((amg_spgemm_t<1024, 64>(ctx, A, P, AP, tmp, derr)));
+  ISPH_CHECK(amg_read_int(ctx, derr, &after));
+  if (!(after & 2) || (before & 2)) return ISPH_SUCCESS;
+  after &= ~2;  // the small table overflowed: clear that flag and redo with the large one
+  ISPH_CHECK_HIP(hipMemcpyAsync(derr, &after, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  AP.release();
+  return amg_spgemm_t<4096, 64>(ctx, A, P, AP, tmp, derr);
+}
+
 inline void amg_level_destroy(AmgLevel *L) {
   if (!L) return;
   L->A.release(); L->P.release();
@@ -587,9 +606,9 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
     for (int round = 0; round < 1000 && rc == ISPH_SUCCESS; ++round) {
       if (hipMemsetAsync(cnt.p, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
       hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
-                         (const unsigned long long *)key.p, t1.p);
+                         (const unsigned long long *)key.p, t1.p, (const unsigned long long *)nullptr);
       hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
-                         (const unsigned long long *)t1.p, t2.p);
+                         (const unsigned long long *)t1.p, t2.p, (const unsigned long long *)key.p);
       hipLaunchKernelGGL(k_mis_decide, dim3(gt), dim3(kBlock), 0, ctx->stream, n, key.p, (const unsigned long long *)t2.p, cnt.p);
       int und = 0;
       rc = amg_read_int(ctx, cnt.p, &und);
@@ -740,14 +759,14 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     rc = amg_prolongator(ctx, L, dg.p, nagg, prm->omega, Lc->nv, tmp, derr.p);
     DCsr R, AP;
     if (rc == ISPH_SUCCESS) rc = amg_transpose(ctx, L->P, R, tmp);
-    if (rc == ISPH_SUCCESS) rc = amg_spgemm_t<4096, 64>(ctx, L->A, L->P, AP, tmp, derr.p);
+    if (rc == ISPH_SUCCESS) rc = amg_spgemm_ap(ctx, L->A, L->P, AP, tmp, derr.p);
     if (rc == ISPH_SUCCESS) rc = amg_spgemm_t<4096, 256>(ctx, R, AP, Lc->A, tmp, derr.p);
     int herr = 0;
     if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, derr.p, &herr);
     if (rc == ISPH_SUCCESS && (herr & 1)) rc = fail("AMG: a row touches more than 64 aggregates (raise the threshold)", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS && (herr & 2)) rc = fail("AMG: coarse operator row too dense for the SpGEMM table", __FILE__, __LINE__);
-    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, L->P.n, L->P.m, L->P.rp.p, L->P.ci.p, L->P.v.p, L->P.nnz, &L->Pm);
-    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, R.n, R.m, R.rp.p, R.ci.p, R.v.p, R.nnz, &L->Rm);
+    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, L->P.n, L->P.m, L->P.rp.p, L->P.ci.p, L->P.v.p, L->P.nnz, &L->Pm, /*rows_sorted=*/true);
+    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, R.n, R.m, R.rp.p, R.ci.p, R.v.p, R.nnz, &L->Rm, /*rows_sorted=*/true);
     if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, Lc->A.n, Lc->A.m, Lc->A.rp.p, Lc->A.ci.p, Lc->A.v.p, Lc->A.nnz, &Lc->Aown);
     R.release(); AP.release();
     if (rc != ISPH_SUCCESS) { amg_level_destroy(Lc); break; }

@@ -53,6 +53,17 @@ int sell_finalize_offsets(isph_ctx *ctx, Sell &S) {
   return ISPH_SUCCESS;
 }
 
+// widest slice (the row sort computes it on the way; callers with already sorted rows only need this)
+int sell_set_wmax(isph_ctx *ctx, Sell &S) {
+  S.wmax = 0;
+  if (S.nslices == 0) return ISPH_SUCCESS;
+  std::vector<long long> so((size_t)S.nslices + 1);
+  ISPH_CHECK_HIP(hipMemcpyAsync(so.data(), S.slice_off.p, sizeof(long long) * so.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < S.nslices; ++s) S.wmax = std::max(S.wmax, (int)((so[(size_t)s + 1] - so[(size_t)s]) >> 6));
+  return ISPH_SUCCESS;
+}
+
 // sort every row's entries by column (invariant of isph_mat, needs max width from host)
 int sell_sort_rows(isph_ctx *ctx, Sell &S) {
   if (S.nslices == 0) return ISPH_SUCCESS;
@@ -167,7 +178,7 @@ void isph_ctx_destroy(isph_ctx *c) {
 
 // CSR (device pointers, any shape) -> sliced-ELL matrix; rows end up column-sorted
 int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const int *dci, const double *dv, long long nnz,
-                        isph_mat **Aout) {
+                        isph_mat **Aout, bool rows_sorted) {
   isph_mat *A = new isph_mat();
   Sell &S = A->S;
   S.nrow = nrow; S.ncol = ncol; S.nnz = nnz;
@@ -181,7 +192,7 @@ int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const
     if (rc == ISPH_SUCCESS) {
       hipLaunchKernelGGL(k_csr_to_sell, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
                          S.slice_off.p, S.col.p, S.val.p);
-      rc = sell_sort_rows(ctx, S);
+      rc = rows_sorted ? sell_set_wmax(ctx, S) : sell_sort_rows(ctx, S);
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);
     }
