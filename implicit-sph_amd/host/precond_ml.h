@@ -1,0 +1,68 @@
+// precond_ml.h -- PrecondWrapper_ML over the HIP smoothed-aggregation AMG
+// (ref: precond_ml.h:28-171: same parameter keys and defaults, same setNullVector behaviour).
+#pragma once
+#include <cstdio>
+#include <string>
+
+#include "precond.h"
+
+namespace LAMMPS_NS {
+
+class PrecondWrapper_ML : public PrecondWrapper {
+ public:
+  PrecondWrapper_ML(MPI_Comm comm) : PrecondWrapper(comm) {}
+  virtual ~PrecondWrapper_ML() {}
+
+  virtual Teuchos::ParameterList *setParameters(Teuchos::ParameterList *param = NULL) {
+    if (param == NULL) {
+      _param = Teuchos::rcp(new Teuchos::ParameterList);
+      _param->set("ML output", 10);                               // ref: precond_ml.h:46
+      _param->set("max levels", 5);                               // :47
+      _param->set("increasing or decreasing", "increasing");      // :48
+      _param->set("aggregation: type", "Uncoupled");              // :49
+      _param->set("smoother: type", "symmetric Gauss-Seidel");    // :50
+      _param->set("smoother: sweeps", 1);                         // :51
+      _param->set("smoother: pre or post", "both");               // :52
+      _param->set("coarse: type", "Amesos-KLU");                  // :53
+      // ML's own defaults, spelled out because the device side needs them
+      _param->set("coarse: max size", 128);
+      _param->set("aggregation: damping factor", 4.0 / 3.0);
+      _param->set("aggregation: threshold", 0.0);
+      // device-side extension: rows the Gauss-Seidel sweeps are local to (ML: the processor).  Not a reference key.
+      _param->set("isph: block rows", 512);
+    } else if (_param.get() != param) {
+      _param = Teuchos::rcp(param, false);
+    }
+    return _param.get();
+  }
+
+  // ref: precond_ml.h:62-94 -- coordinates only feed ML's Zoltan repartitioning, which has no device counterpart
+  virtual void setCoordinates(const int, double *, double *, double *) { return; }
+
+  // ref: precond_ml.h:97-127 -- one pre-computed null-space vector; the smoother becomes the coarse solver
+  virtual void setNullVector(double *n) { _null = n; }
+
+ protected:
+  virtual int createOnDevice(isph_ctx *ctx, const isph_mat *A) {
+    setParameters(_param.get());
+    const std::string agg = _param->get("aggregation: type", "Uncoupled");
+    const std::string smo = _param->get("smoother: type", "symmetric Gauss-Seidel");
+    if (agg != "Uncoupled" || smo != "symmetric Gauss-Seidel") {
+      std::fprintf(stderr, ">> PrecondWrapper_ML(HIP): only Uncoupled aggregation with symmetric Gauss-Seidel is available\n");
+      return ISPH_FAILURE;
+    }
+    isph_amg_params prm;
+    isph_amg_params_default(&prm);
+    prm.max_levels = _param->get("max levels", 5);
+    prm.coarse_max = _param->get("coarse: max size", 128);
+    prm.omega = _param->get("aggregation: damping factor", 4.0 / 3.0);
+    prm.theta = _param->get("aggregation: threshold", 0.0);
+    prm.sweeps = _param->get("smoother: sweeps", 1);
+    prm.block = _param->get("isph: block rows", 512);
+    free();
+    return isph_prec_create_amg(ctx, A, &prm, _null, /*on_device=*/0, &_M);
+  }
+  double *_null = nullptr;
+};
+
+}  // namespace LAMMPS_NS

@@ -4,15 +4,17 @@
 // solveProblem(&prec, "...").  Reads a CSR system from a binary file, writes x.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "precond_ifpack.h"
+#include "precond_ml.h"
 #include "solver_lin_hip.h"
 
 using namespace LAMMPS_NS;
 
 int main(int argc, char **argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: %s in.bin out.bin singular(0/1) [cg]\n", argv[0]); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: %s in.bin out.bin singular(0/1) [cg|ml]\n", argv[0]); return 2; }
   FILE *f = std::fopen(argv[1], "rb");
   if (!f) return 2;
   int n = 0, nnz = 0;
@@ -29,16 +31,25 @@ int main(int argc, char **argv) {
   Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
   Epetra_CrsMatrix AA(n, n, rp.data(), ci.data(), val.data());
 
-  PrecondWrapper_Ifpack prec(world);
+  const bool use_ml = argc > 4 && std::string(argv[4]) == "ml";
+  const bool use_cg = argc > 4 && std::string(argv[4]) == "cg";
+  PrecondWrapper_Ifpack prec_ifpack(world);
+  PrecondWrapper_ML prec_ml(world);
+  PrecondWrapper &prec = use_ml ? static_cast<PrecondWrapper &>(prec_ml) : static_cast<PrecondWrapper &>(prec_ifpack);
   Teuchos::ParameterList *pp = prec.setParameters();
-  pp->set("fact: level-of-fill", 0);
-  pp->set("Overlap Level", 0);
+  if (use_ml) {  // the keys of precond_ml.h:44-55 are already set; shrink the hierarchy to the test size
+    pp->set("coarse: max size", 64);
+    pp->set("aggregation: threshold", 0.02);
+  } else {
+    pp->set("fact: level-of-fill", 0);
+    pp->set("Overlap Level", 0);
+  }
   pp->set("isph: block rows", 256);
 
   SolverLin_Belos li_solver(world);
   li_solver.setParameters();
   Teuchos::ParameterList cgp;
-  if (argc > 4) {  // USER-REAXC-T defaults: Block CG (USER-REAXC-T/solver_lin_belos.h:236-245)
+  if (use_cg) {  // USER-REAXC-T defaults: Block CG (USER-REAXC-T/solver_lin_belos.h:236-245)
     cgp.set("Solver Type", "Block CG");
     cgp.set("Convergence Tolerance", 1.0e-8);
     cgp.set("Maximum Iterations", 500);

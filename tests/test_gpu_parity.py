@@ -314,7 +314,7 @@ def test_rccl_self_halo_spmv_and_solve(gpu_ctx):
 
 
 # ---------------------------------------------------------------- C++ mirror of the reference interface
-@pytest.mark.parametrize("singular,cg", [(1, False), (0, True)])
+@pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml")])
 def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     """SolverLin_Belos / PrecondWrapper_Ifpack (implicit-sph_amd/host/*.h) driven
     exactly like USER-REAXC-T/fix_qeq_reax.cpp:671-693 drives the reference."""
@@ -334,7 +334,9 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
         np.array([pr.n, len(val)], np.int32).tofile(f)
         rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
         val.tofile(f); b.tofile(f)
-    r = subprocess.run([exe, str(fin), str(fout), str(singular)] + (["cg"] if cg else []),
+    ml = cg == "ml"
+    cg = bool(cg) and not ml
+    r = subprocess.run([exe, str(fin), str(fout), str(singular)] + (["cg"] if cg else ["ml"] if ml else []),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert ">> Belos::Status - Passed!" in r.stdout
@@ -342,8 +344,12 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     x, bproj = out[:pr.n], out[pr.n:]
     bp = np.arange(0, pr.n + 256, 256).clip(0, pr.n).astype(np.int32)
     prm = orc.SolverParams(solver_type=1, tol=1e-8) if cg else orc.SolverParams()
-    xo, io, bo = orc.solve(rp, ci, val, b, singular=bool(singular), prec="ilu",
-                           ilu=orc.ILU(rp, ci, val, 0, bp), params=prm)
+    if ml:   # PrecondWrapper_ML mirror: setNullVector reaches the AMG through solveProblem (solver_lin_belos.h:149-151)
+        G = orc.AMG(rp, ci, val, nullvec=np.full(pr.n, 1.0 / np.sqrt(pr.n)), coarse_max=64, theta=0.02, block=256)
+        xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="amg", amg=G, params=prm)
+    else:
+        xo, io, bo = orc.solve(rp, ci, val, b, singular=bool(singular), prec="ilu",
+                               ilu=orc.ILU(rp, ci, val, 0, bp), params=prm)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
     assert np.allclose(bproj, bo, rtol=0, atol=1e-13 * np.abs(bo).max())   # b view updated in place
 
