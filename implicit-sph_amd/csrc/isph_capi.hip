@@ -622,6 +622,73 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
   return ISPH_SUCCESS;
 }
 
+// SolverLin_Belos::solveBlockProblem (ref: solver_lin_belos.h:53-128): GMRES / CG over the product vector
+// [x_0; ..; x_{dim-1}] with the dim x dim blocked operator and the block-diagonal right preconditioner.
+int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, const isph_prec *M, double *b, double *x,
+                     int lda, const isph_solver_params *prm_in, isph_solve_info *info, int on_device) {
+  ISPH_REQUIRE(ctx && blocks && b && x && info, "NULL argument");
+  ISPH_REQUIRE(dim >= 1 && dim <= 3, "block dimension must be 1, 2 or 3");
+  int n = -1;
+  for (int k = 0; k < dim * dim; ++k)
+    if (blocks[k]) {
+      if (n < 0) n = blocks[k]->S.nrow;
+      ISPH_REQUIRE(blocks[k]->S.nrow == n, "blocks must have the same number of rows");
+    }
+  ISPH_REQUIRE(n >= 0, "at least one block is needed");
+  for (int k = 0; k < dim; ++k) ISPH_REQUIRE(blocks[k * dim + k] != nullptr, "diagonal blocks must be set");
+  ISPH_REQUIRE(lda >= n, "need lda >= nlocal");
+  ISPH_REQUIRE(!M || M->n == n, "preconditioner / block size mismatch");
+  isph_solver_params prm;
+  if (prm_in) prm = *prm_in; else isph_solver_params_default(&prm);
+  memset(info, 0, sizeof(*info));
+  ISPH_CHECK(ensure_scalars(ctx));
+  hipStream_t st = ctx->stream;
+  ctx->ev_used = 0;
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, st));
+  // product vectors are contiguous [dim][n] on the device
+  const size_t nt = (size_t)dim * (size_t)n;
+  ISPH_CHECK(ctx->bdev.reserve(nt + 64));
+  ISPH_CHECK(ctx->xdev.reserve(nt + 64));
+  const hipMemcpyKind in = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind out = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  for (int k = 0; k < dim; ++k) {
+    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->bdev.p + (size_t)k * n, b + (size_t)k * lda, sizeof(double) * (size_t)n, in, st));
+    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p + (size_t)k * n, x + (size_t)k * lda, sizeof(double) * (size_t)n, in, st));
+  }
+  DevBuf<double> tmp, res;
+  ISPH_CHECK(tmp.reserve((size_t)n + 64));
+  LinOp op{ctx, nullptr, M, nullptr, (int)nt};
+  op.dim = dim; op.nloc = n; op.blk = blocks; op.tmp = tmp.p;
+  isph_solve_info ci;
+  memset(&ci, 0, sizeof(ci));
+  int rc = prm.solver_type == 1 ? pcg(op, ctx->bdev.p, ctx->xdev.p, &prm, &ci) : gmres(op, ctx->bdev.p, ctx->xdev.p, &prm, &ci);
+  if (rc == ISPH_SUCCESS) rc = res.reserve(nt + 64);
+  if (rc == ISPH_SUCCESS) rc = op.apply(ctx->xdev.p, res.p);
+  if (rc == ISPH_SUCCESS) {
+    hipLaunchKernelGGL(k_residual, dim3(stream_grid((long long)nt)), dim3(kBlock), 0, st, (int)nt, (const double *)ctx->bdev.p, res.p);
+    rc = dot_dev(ctx, (int)nt, res.p, res.p, ctx->bdev.p, ctx->bdev.p, SC_MISC + 16);
+  }
+  if (rc == ISPH_SUCCESS) rc = fetch_scalars(ctx, SC_MISC + 16, 2);
+  tmp.release(); res.release();
+  ISPH_CHECK(rc);
+  const double bn = std::sqrt(ctx->hscal[SC_MISC + 17]);
+  ci.rel_res_explicit = std::sqrt(ctx->hscal[SC_MISC + 16]) / (bn == 0.0 ? 1.0 : bn);
+  for (int k = 0; k < dim; ++k)
+    ISPH_CHECK_HIP(hipMemcpyAsync(x + (size_t)k * lda, ctx->xdev.p + (size_t)k * n, sizeof(double) * (size_t)n, out, st));
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev1, st));
+  ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  ISPH_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *info = ci;
+  info->solve_ms = ms;
+  if (ctx->rank == 0 && prm.verbose) {
+    if (ci.converged) printf(">> isph::Status - Passed! (%d iterations)\n", ci.iters);
+    else printf(">> isph::Status - Failed to converge! ||r|| / ||b|| = %6.4e\n", ci.rel_res_explicit);
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
 /* ---- assembly --------------------------------------------------------- */
 
 int isph_assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, const double *rho,

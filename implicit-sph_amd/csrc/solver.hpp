@@ -122,9 +122,32 @@ struct LinOp {
   const isph_mat *A;
   const isph_prec *M;
   const double *nvec;  // device, NULL unless singular
-  int n;
+  int n;               // length of the Krylov vectors (dim * nloc for a blocked operator)
+  // blocked operator (SolverLin::setBlock / Thyra::DefaultBlockedLinearOp, ref: solver_lin.cpp:127-138):
+  // dim x dim sparse blocks over product vectors [x_0; ..; x_{dim-1}], NULL blocks are zero; the
+  // preconditioner is block-diagonal with the same operator on every component (precond_ml.h:138-155)
+  int dim = 1, nloc = 0;
+  const isph_mat *const *blk = nullptr;
+  double *tmp = nullptr;  // [nloc] scratch of the blocked product
   // PoissonProjection::Apply: y = A x; y -= (y.n) n
   int apply(const double *x, double *y) const {
+    if (blk) {
+      for (int i = 0; i < dim; ++i) {
+        double *yi = y + (size_t)i * nloc;
+        bool first = true;
+        for (int j = 0; j < dim; ++j) {
+          const isph_mat *B = blk[i * dim + j];
+          if (!B) continue;
+          ISPH_CHECK(spmv_dev(ctx, B, x + (size_t)j * nloc, first ? yi : tmp, nullptr));
+          if (!first)
+            hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(nloc)), dim3(kBlock), 0, ctx->stream, nloc, 1.0,
+                               (const double *)nullptr, (const double *)tmp, yi);
+          first = false;
+        }
+        if (first) ISPH_CHECK_HIP(hipMemsetAsync(yi, 0, sizeof(double) * (size_t)nloc, ctx->stream));
+      }
+      return ISPH_SUCCESS;
+    }
     ISPH_CHECK(spmv_dev(ctx, A, x, y, nvec));
     if (nvec)
       hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, -1.0,
@@ -134,6 +157,10 @@ struct LinOp {
   int prec(const double *r, double *z) const {
     if (!M) {  // no preconditioner object: identity
       ISPH_CHECK_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+      return ISPH_SUCCESS;
+    }
+    if (blk) {
+      for (int i = 0; i < dim; ++i) ISPH_CHECK(prec_apply_dev(ctx, M, r + (size_t)i * nloc, z + (size_t)i * nloc));
       return ISPH_SUCCESS;
     }
     return prec_apply_dev(ctx, M, r, z);

@@ -22,7 +22,7 @@ EXPORTS = [
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
-    "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
+    "isph_solve_block", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
 ]
 
@@ -125,6 +125,8 @@ def lib():
         L.isph_advance_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int]
         L.isph_advance_end.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_solve_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_int]
         L.isph_amg_params_default.argtypes = [C.c_void_p]
         L.isph_prec_create_amg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -324,6 +326,25 @@ class Precond:
             self.close()
         except Exception:
             pass
+
+
+def solve_block(ctx, blocks, b, x, prec=None, params=None, lda=None):
+    """isph_solve_block == SolverLin_Belos::solveBlockProblem.  blocks: dim x dim nested list of Matrix / None;
+    b, x column-major [lda x dim] (numpy [dim, lda] arrays or flat); x is updated in place."""
+    dim = len(blocks)
+    arr = (C.c_void_p * (dim * dim))()
+    n = None
+    for i in range(dim):
+        for j in range(dim):
+            Bm = blocks[i][j]
+            arr[i * dim + j] = Bm.h if Bm is not None else None
+            if Bm is not None and n is None:
+                n = Bm.info()["nrow"]
+    prm = params or SolverParams()
+    info = SolveInfo()
+    _check(lib().isph_solve_block(ctx.h, dim, arr, prec.h if prec is not None else None, _ptr(b), _ptr(x),
+                                  n if lda is None else lda, C.byref(prm), C.byref(info), _on_device(b, x)))
+    return info
 
 
 class PrecondAMG(Precond):

@@ -73,8 +73,11 @@ class SolverLin {
   void setMatrix(Epetra_CrsMatrix *A) {
     if (A != NULL) _A = Teuchos::rcp(A, false);
   }
-  void setBlockBegin() {}
-  void setBlock(const int, const int, const Epetra_CrsMatrix *) {}
+  // ref: solver_lin.cpp:127-138 -- blocks are borrowed, NULL or out-of-range requests are ignored
+  void setBlockBegin() { for (int k = 0; k < 9; ++k) _blk[k] = NULL; }
+  void setBlock(const int i, const int j, const Epetra_CrsMatrix *A) {
+    if ((A != NULL) && (i < _dim && j < _dim)) _blk[i * 3 + j] = A;
+  }
   void setBlockEnd() {}
 
   void setInitialSolution(SolutionInitType init, double val = 0.0) {
@@ -109,6 +112,7 @@ class SolverLin {
   Teuchos::RCP<Teuchos::ParameterList> _param;
   Teuchos::RCP<Epetra_CrsMatrix> _A;
   int _dim;
+  const Epetra_CrsMatrix *_blk[9] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL};
   bool _is_blocked;
   Teuchos::RCP<Epetra_MultiVector> _x, _b;
   Teuchos::RCP<Epetra_Vector> _n;

@@ -41,6 +41,25 @@ class SolverLin_HIP : public SolverLin {
     }
   }
 
+  // Belos-style keys -> isph_solver_params
+  isph_solver_params solverParams() {
+    isph_solver_params p;
+    isph_solver_params_default(&p);
+    const std::string type = _param->get("Solver Type", "Block GMRES");
+    if (type == "Block CG") p.solver_type = 1;
+    else if (type != "Block GMRES" && _comm.MyPID() == 0)
+      std::printf(">> SolverLin_HIP: Solver Type '%s' not available, using Block GMRES\n", type.c_str());
+    p.flexible = _param->get("Flexible Gmres", true) ? 1 : 0;
+    p.num_blocks = _param->get("Num Blocks", 50);
+    p.max_iters = _param->get("Maximum Iterations", 500);
+    p.max_restarts = _param->get("Maximum Restarts", 15);
+    p.tol = _param->get("Convergence Tolerance", 1.0e-8);
+    const std::string ortho = _param->get("Orthogonalization", "DGKS");
+    p.ortho = ortho == "ICGS" ? 1 : ortho == "IMGS" ? 2 : 0;
+    p.verbose = 0;
+    return p;
+  }
+
   int solveProblem(PrecondWrapper *prec = NULL, const char *name = NULL) {
     if (_comm.MyPID() == 0 && name != NULL) std::cout << ">> Belos::Label - " << name << std::endl;
     setParameters(_param.get());
@@ -60,20 +79,7 @@ class SolverLin_HIP : public SolverLin {
       prec->create();
       rc = prec->createOnDevice(_ctx, A);  // Ifpack Initialize+Compute happen here (:153)
     }
-    isph_solver_params p;
-    isph_solver_params_default(&p);
-    const std::string type = _param->get("Solver Type", "Block GMRES");
-    if (type == "Block CG") p.solver_type = 1;
-    else if (type != "Block GMRES" && _comm.MyPID() == 0)
-      std::printf(">> SolverLin_HIP: Solver Type '%s' not available, using Block GMRES\n", type.c_str());
-    p.flexible = _param->get("Flexible Gmres", true) ? 1 : 0;
-    p.num_blocks = _param->get("Num Blocks", 50);
-    p.max_iters = _param->get("Maximum Iterations", 500);
-    p.max_restarts = _param->get("Maximum Restarts", 15);
-    p.tol = _param->get("Convergence Tolerance", 1.0e-8);
-    const std::string ortho = _param->get("Orthogonalization", "DGKS");
-    p.ortho = ortho == "ICGS" ? 1 : ortho == "IMGS" ? 2 : 0;
-    p.verbose = 0;
+    isph_solver_params p = solverParams();
 
     isph_solve_info info;
     if (rc == ISPH_SUCCESS)
@@ -96,9 +102,68 @@ class SolverLin_HIP : public SolverLin {
     return LAMMPS_SUCCESS;
   }
 
+  // ref: solver_lin_belos.h:53-128
   int solveBlockProblem(PrecondWrapper *prec = NULL, const char *name = NULL) {
-    // block (dim x dim) Helmholtz systems are not on the device yet (next)
-    throw std::runtime_error("SolverLin_HIP::solveBlockProblem is not available in this build");
+    if (_comm.MyPID() == 0 && name != NULL) std::cout << ">> Belos(Block)::Label - " << name << std::endl;
+    if (!_x || !_b || _b->NumVectors() != _dim) {
+      std::fprintf(stderr, ">> SolverLin_Belos::solveBlockProblem, dimension of rhs does not match to the block matrix\n");
+      return LAMMPS_FAILURE;
+    }
+    if (_is_singular) {
+      std::fprintf(stderr, ">> SolverLin_Belos::solveBlockProblem does not support singular problems\n");
+      return LAMMPS_FAILURE;
+    }
+    setParameters(_param.get());
+    if (ensureContext() != ISPH_SUCCESS) return LAMMPS_FAILURE;
+    isph_mat *blk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const isph_mat *cblk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = ISPH_SUCCESS;
+    for (int i = 0; i < _dim && rc == ISPH_SUCCESS; ++i)
+      for (int j = 0; j < _dim && rc == ISPH_SUCCESS; ++j) {
+        const Epetra_CrsMatrix *B = _blk[i * 3 + j];
+        if (!B) continue;
+        int *rp = nullptr, *ci = nullptr;
+        double *v = nullptr;
+        B->ExtractCrsDataPointers(rp, ci, v);
+        rc = isph_mat_create_csr(_ctx, B->NumMyRows(), B->NumMyCols(), rp, ci, v, 0, &blk[i * _dim + j]);
+        cblk[i * _dim + j] = blk[i * _dim + j];
+      }
+    // diagonal preconditioner: one operator, built from the matrix the wrapper was given (precond_ml.h:138-155:
+    // "assume that all diagonals are same now"), or from block (0,0) when none was set
+    isph_mat *Aprec = nullptr;
+    if (rc == ISPH_SUCCESS && prec != NULL) {
+      prec->create(_dim);
+      const Epetra_CrsMatrix *P = prec->_A.get() ? prec->_A.get() : _blk[0];
+      if (!P) throw std::runtime_error("SolverLin_Belos::solveProblem getBlockPrecondOperator failed");
+      int *rp = nullptr, *ci = nullptr;
+      double *v = nullptr;
+      P->ExtractCrsDataPointers(rp, ci, v);
+      rc = isph_mat_create_csr(_ctx, P->NumMyRows(), P->NumMyCols(), rp, ci, v, 0, &Aprec);
+      if (rc == ISPH_SUCCESS) rc = prec->createOnDevice(_ctx, Aprec);
+      if (rc == ISPH_SUCCESS && !prec->_M) {
+        isph_mat_destroy(Aprec);
+        for (int k = 0; k < 9; ++k) isph_mat_destroy(blk[k]);
+        throw std::runtime_error("SolverLin_Belos::solveProblem getBlockPrecondOperator failed");
+      }
+    }
+    isph_solver_params p = solverParams();
+    isph_solve_info info;
+    if (rc == ISPH_SUCCESS)
+      rc = isph_solve_block(_ctx, _dim, cblk, prec ? prec->_M : nullptr, _b->Values(), _x->Values(), _x->Stride(), &p,
+                            &info, 0);
+    if (prec != NULL) prec->free();
+    isph_mat_destroy(Aprec);
+    for (int k = 0; k < 9; ++k) isph_mat_destroy(blk[k]);
+    if (rc != ISPH_SUCCESS) return report_failure();
+    _last = info;
+    if (_comm.MyPID() == 0) {
+      if (info.converged) std::cout << ">> Belos::Status - Passed! " << (name == NULL ? " " : name) << std::endl;
+      else {
+        std::cout << ">> Belos::Status - Failed to converge! " << (name == NULL ? " " : name) << std::endl;
+        std::printf(">> Belos:: ||r|| / ||b|| = %6.4e\n", info.rel_res_explicit);
+      }
+    }
+    return LAMMPS_SUCCESS;
   }
 
   const isph_solve_info &lastSolveInfo() const { return _last; }

@@ -237,6 +237,14 @@ int isph_advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, doub
 int isph_advance_end(isph_ctx *ctx, int count, int dim, double dt, const double *dp, const double *vnp1,
                      double *p, double *x, double *v, int on_device);
 
+/* SolverLin_Belos::solveBlockProblem (solver_lin_belos.h:53-128) over the blocks SolverLin::setBlock collects
+ * (solver_lin.cpp:127-138): blocks[i*dim+j] is block (i,j) of the dim x dim operator (NULL = zero block, diagonal
+ * blocks required), b and x are column-major [lda x dim] like the reference's multivectors, M (may be NULL) is
+ * applied to every component -- the block-diagonal preconditioner PrecondWrapper_ML::create(dim) builds
+ * (precond_ml.h:138-155).  Singular systems are not supported, as in the reference (:60-61). */
+int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, const isph_prec *M, double *b, double *x,
+                     int lda, const isph_solver_params *prm, isph_solve_info *info, int on_device);
+
 /* ---- smoothed-aggregation AMG in place of PrecondWrapper_ML (precond_ml.h:40-171) ----
  * Parameters mirror the keys the wrapper sets (precond_ml.h:44-55): "max levels" 5, "aggregation: type" Uncoupled,
  * "smoother: type" symmetric Gauss-Seidel with "smoother: sweeps" 1 pre and post, direct coarse solve; plus ML's

@@ -1110,6 +1110,7 @@ typedef struct {
   const orc_ilu *F;
   const orc_amg *G;
   double *invdiag;
+  int ncomp; /* > 1: block-diagonal preconditioner, the same operator on every component (precond_ml.h:138-155) */
 } lin_ctx;
 
 /* PoissonProjection::Apply, ref: solver_lin.h:131-140: y = A x; y -= (y.n) n */
@@ -1121,6 +1122,14 @@ static void op_apply(const lin_ctx *c, const double *x, double *y) {
   }
 }
 static void prec_apply(const lin_ctx *c, const double *r, double *z) {
+  if (c->ncomp > 1 && (c->prec_type == 2 || c->prec_type == 3)) {
+    const int m = c->n / c->ncomp;
+    for (int k = 0; k < c->ncomp; ++k) {
+      if (c->prec_type == 2) orc_ilu_apply(c->F, r + (size_t)k * m, z + (size_t)k * m);
+      else orc_amg_apply(c->G, r + (size_t)k * m, z + (size_t)k * m);
+    }
+    return;
+  }
   if (c->prec_type == 2 && c->F) orc_ilu_apply(c->F, r, z);
   else if (c->prec_type == 3 && c->G) orc_amg_apply(c->G, r, z);
   else if (c->prec_type == 1) {
@@ -1289,13 +1298,36 @@ static void pcg(const lin_ctx *c, const double *b, double *x,
  *  4. right preconditioning, solver by "Solver Type"           (:168-184)
  *  5. x -= (x.n) n ; non-convergence is reported, not raised   (:192-219)
  * b is modified in place exactly as the reference modifies *_b. */
+static int solve_impl(int n, const int *rowptr, const int *colidx, const double *val,
+                      double *b, double *x, int is_singular, const int *null_mask,
+                      int prec_type, const void *prec_obj, int ncomp,
+                      const orc_solver_params *prm, orc_solve_info *info);
+
 int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
               double *b, double *x, int is_singular, const int *null_mask,
               int prec_type, const void *prec_obj,
               const orc_solver_params *prm, orc_solve_info *info) {
+  return solve_impl(n, rowptr, colidx, val, b, x, is_singular, null_mask, prec_type, prec_obj, 1, prm, info);
+}
+
+/* SolverLin_Belos::solveBlockProblem, ref: solver_lin_belos.h:53-128: the dim x dim blocked operator is given
+ * here as one CSR over the product vector [x_0; ..; x_{dim-1}] (n = dim * nlocal rows); the preconditioner
+ * object (built for one nlocal x nlocal block) is applied to every component; singular systems are refused
+ * like the reference does (:60-61). */
+int orc_solve_block(int n, int dim, const int *rowptr, const int *colidx, const double *val,
+                    double *b, double *x, int prec_type, const void *prec_obj,
+                    const orc_solver_params *prm, orc_solve_info *info) {
+  return solve_impl(n, rowptr, colidx, val, b, x, 0, NULL, prec_type, prec_obj, dim, prm, info);
+}
+
+static int solve_impl(int n, const int *rowptr, const int *colidx, const double *val,
+                      double *b, double *x, int is_singular, const int *null_mask,
+                      int prec_type, const void *prec_obj, int ncomp,
+                      const orc_solver_params *prm, orc_solve_info *info) {
   const double t0 = now_sec();
   lin_ctx c;
   memset(&c, 0, sizeof(c));
+  c.ncomp = ncomp;
   c.n = n; c.rowptr = rowptr; c.colidx = colidx; c.val = val;
   c.prec_type = prec_type;
   c.F = prec_type == 2 ? (const orc_ilu *)prec_obj : NULL;

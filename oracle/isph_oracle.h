@@ -160,6 +160,10 @@ int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
               int prec_type, const void *prec_obj,
               const orc_solver_params *prm, orc_solve_info *info);
 
+int orc_solve_block(int n, int dim, const int *rowptr, const int *colidx, const double *val,
+                    double *b, double *x, int prec_type, const void *prec_obj,
+                    const orc_solver_params *prm, orc_solve_info *info);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -93,6 +93,8 @@ def lib():
         L.orc_spmv.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_solve_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_forward_comm.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         # GPU boxes expose 256 hardware threads but give a job a 16-CPU share: cap the team size
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -353,6 +355,22 @@ def solve(rowptr, colidx, val, b, x0=None, singular=False, null_mask=None, prec=
     lib().orc_solve(n, _p(rowptr), _p(colidx), _p(val), _p(b), _p(x), int(singular), _p(mask), ptype,
                     obj, C.byref(prm), C.byref(info))
     return x, info, b
+
+
+def solve_block(rowptr, colidx, val, b, dim, x0=None, prec="none", ilu=None, amg=None, params=None):
+    """SolverLin_Belos::solveBlockProblem restatement: the blocked operator as one CSR over [x_0;..;x_{dim-1}],
+    the preconditioner object (one block's size) applied to every component."""
+    n = len(rowptr) - 1
+    rowptr, colidx, val = _i32(rowptr), _i32(colidx), _f64(val)
+    b = _f64(b).copy()
+    x = np.zeros(n) if x0 is None else _f64(x0).copy()
+    prm = params or SolverParams()
+    info = SolveInfo()
+    ptype = {"none": 0, "ilu": 2, "amg": 3}[prec]
+    obj = amg.h if prec == "amg" else (ilu.h if prec == "ilu" else None)
+    lib().orc_solve_block(n, dim, _p(rowptr), _p(colidx), _p(val), _p(b), _p(x), ptype, obj, C.byref(prm),
+                          C.byref(info))
+    return x, info
 
 
 def num_threads():

@@ -13,7 +13,71 @@
 
 using namespace LAMMPS_NS;
 
+// "block": in.bin = n, nnz, H (rp, ci, val) | dim | for each block (i,j) row-major: flag [, nnz, rp, ci, val] |
+// b [dim][n].  Drives createBlockMatrix / setBlock / solveBlockProblem exactly like pair_isph.cpp:944-972, with
+// PrecondWrapper_ML built from H (prec->setMatrix(A.crs), pair_isph.cpp:926).
+static int run_block(const char *fin, const char *fout) {
+  FILE *f = std::fopen(fin, "rb");
+  if (!f) return 2;
+  int n = 0, nnz = 0, dim = 0;
+  if (std::fread(&n, 4, 1, f) != 1 || std::fread(&nnz, 4, 1, f) != 1) return 2;
+  std::vector<int> rp((size_t)n + 1), ci((size_t)nnz), gid((size_t)n);
+  std::vector<double> val((size_t)nnz);
+  if (std::fread(rp.data(), 4, rp.size(), f) != rp.size() || std::fread(ci.data(), 4, ci.size(), f) != ci.size() ||
+      std::fread(val.data(), 8, val.size(), f) != val.size() || std::fread(&dim, 4, 1, f) != 1) return 2;
+  std::vector<std::vector<int> > brp(9), bci(9);
+  std::vector<std::vector<double> > bval(9);
+  std::vector<Epetra_CrsMatrix *> blk(9, (Epetra_CrsMatrix *)NULL);
+  for (int k = 0; k < dim * dim; ++k) {
+    int flag = 0, bn = 0;
+    if (std::fread(&flag, 4, 1, f) != 1) return 2;
+    if (!flag) continue;
+    if (std::fread(&bn, 4, 1, f) != 1) return 2;
+    brp[k].resize((size_t)n + 1); bci[k].resize((size_t)bn); bval[k].resize((size_t)bn);
+    if (std::fread(brp[k].data(), 4, brp[k].size(), f) != brp[k].size() ||
+        std::fread(bci[k].data(), 4, bci[k].size(), f) != bci[k].size() ||
+        std::fread(bval[k].data(), 8, bval[k].size(), f) != bval[k].size()) return 2;
+    blk[k] = new Epetra_CrsMatrix(n, n, brp[k].data(), bci[k].data(), bval[k].data());
+  }
+  std::vector<double> b((size_t)n * dim), x((size_t)n * dim, 0.0);
+  if (std::fread(b.data(), 8, b.size(), f) != b.size()) return 2;
+  std::fclose(f);
+  for (int i = 0; i < n; ++i) gid[(size_t)i] = i + 1;
+  MPI_Comm world = 0;
+  Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
+  Epetra_CrsMatrix H(n, n, rp.data(), ci.data(), val.data());
+  PrecondWrapper_ML prec(world);
+  Teuchos::ParameterList *pp = prec.setParameters();
+  pp->set("coarse: max size", 64);
+  pp->set("aggregation: threshold", 0.02);
+  pp->set("isph: block rows", 256);
+  SolverLin_Belos li_solver(world);
+  li_solver.setParameters();
+  li_solver.setNodalMap(&nodalmap);
+  li_solver.setMatrix(&H);
+  prec.setMatrix(&H);
+  li_solver.createBlockMatrix(dim, "Block Helmholtz");
+  li_solver.createSolutionMultiVector(x.data(), n, dim);
+  li_solver.createLoadMultiVector(b.data(), n, dim);
+  li_solver.setBlockBegin();
+  for (int k2 = 0; k2 < dim; ++k2)
+    for (int k1 = 0; k1 < dim; ++k1) li_solver.setBlock(k1, k2, blk[(size_t)(k1 * dim + k2)]);
+  li_solver.setBlockEnd();
+  li_solver.setMatrixIsBlocked(true);
+  const int rc = li_solver.solveBlockProblem(&prec, "Block 3x3 Helmholtz");
+  li_solver.freeBlockMatrix();
+  if (rc != LAMMPS_SUCCESS) return 1;
+  const isph_solve_info &info = li_solver.lastSolveInfo();
+  std::printf("converged=%d iters=%d rel=%.3e\n", info.converged, info.iters, info.rel_res_implicit);
+  f = std::fopen(fout, "wb");
+  std::fwrite(x.data(), 8, x.size(), f);
+  std::fclose(f);
+  for (size_t k = 0; k < blk.size(); ++k) delete blk[k];
+  return info.converged ? 0 : 3;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 4 && std::string(argv[4]) == "block") return run_block(argv[1], argv[2]);
   if (argc < 4) { std::fprintf(stderr, "usage: %s in.bin out.bin singular(0/1) [cg|ml]\n", argv[0]); return 2; }
   FILE *f = std::fopen(argv[1], "rb");
   if (!f) return 2;
