@@ -5,6 +5,7 @@
 
 #include "assemble.hpp"
 #include "operators.hpp"
+#include "block_helmholtz.hpp"
 #include "core.hpp"
 #include "ilu.hpp"
 #include "krylov.hpp"
@@ -705,6 +706,16 @@ int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym,
   ISPH_REQUIRE(ctx && P && nu && rho && pres && force && v && A_out && b_out, "NULL argument");
   return assemble_helmholtz(ctx, P, antisym, dt, theta, nu, rho, pres, force, g, incremental_pressure, v, ncol, A_out,
                             b_out, lda, on_device);
+}
+
+int isph_assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                                  double beta, const double *nu, const double *rho, const double *pres,
+                                  const double *force, const double *g, int incremental_pressure, const double *v,
+                                  const double *normal, int ncol, isph_mat **blocks_out, double *b_out, int lda,
+                                  int on_device) {
+  ISPH_REQUIRE(ctx && P && nu && rho && pres && force && v && blocks_out && b_out, "NULL argument");
+  return assemble_block_helmholtz(ctx, P, ncol, antisym, dt, theta, beta, nu, rho, pres, force, g, incremental_pressure, v,
+                                  normal, lda, blocks_out, b_out, on_device);
 }
 
 int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device) {

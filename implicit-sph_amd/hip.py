@@ -22,7 +22,7 @@ EXPORTS = [
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
-    "isph_solve_block", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
+    "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
 ]
 
@@ -126,6 +126,10 @@ def lib():
                                          C.c_void_p, C.c_void_p, C.c_int]
         L.isph_advance_end.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_assemble_block_helmholtz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_int]
         L.isph_solve_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_int]
         L.isph_amg_params_default.argtypes = [C.c_void_p]
@@ -460,6 +464,38 @@ def assemble_helmholtz(ctx, parts, colmap, dt, theta, nu, rho, pres, force, g, v
                                          _ptr(pres), _ptr(force), _ptr(gv), int(incremental), _ptr(vel),
                                          nlocal if ncol is None else ncol, C.byref(A.h), _ptr(b_out), nlocal, dev))
     return A, b_out
+
+
+def assemble_block_helmholtz(ctx, parts, colmap, dt, theta, beta, nu, rho, pres, force, g, vel, normal=None, antisym=True,
+                             incremental=True, ncol=None, vfrac=None, Gc=None, Lc=None, kernel="wendland", kinds=None,
+                             pnd=None, morris_safe_coeff=0.43301):
+    """isph_assemble_block_helmholtz == PairISPH_Corrected::computeBlockHelmholtz.  Returns (blocks, b): blocks is a
+    dim x dim nested list of Matrix / None, b column-major [nlocal x dim] flattened."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, Lc=Lc, keep=keep, kinds=kinds,
+                                   pnd=pnd, morris_safe_coeff=morris_safe_coeff)
+    nu, rho, pres, force, vel = map(_f64, (nu, rho, pres, force, vel))
+    nrm = None if normal is None else _f64(normal)
+    gv = np.ascontiguousarray(g, dtype=np.float64)
+    nlocal, dim = int(parts["nlocal"]), int(parts["dim"])
+    if dev:
+        import torch
+        b_out = torch.zeros(nlocal * dim, dtype=torch.float64, device=rho.device)
+    else:
+        b_out = np.zeros(nlocal * dim)
+    hs = (C.c_void_p * (dim * dim))()
+    _check(lib().isph_assemble_block_helmholtz(ctx.h, C.byref(pv), int(antisym), float(dt), float(theta), float(beta),
+                                               _ptr(nu), _ptr(rho), _ptr(pres), _ptr(force), _ptr(gv), int(incremental),
+                                               _ptr(vel), _ptr(nrm), nlocal if ncol is None else ncol, hs, _ptr(b_out),
+                                               nlocal, dev))
+    blocks = [[None] * dim for _ in range(dim)]
+    for i in range(dim):
+        for j in range(dim):
+            if hs[i * dim + j]:
+                Bm = Matrix(ctx)
+                Bm.h = C.c_void_p(hs[i * dim + j])
+                blocks[i][j] = Bm
+    return blocks, b_out
 
 
 def compute_volumes(ctx, parts, colmap, kernel="wendland"):

@@ -204,6 +204,19 @@ int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym,
                             const double *nu, const double *rho, const double *pres, const double *force,
                             const double *g, int incremental_pressure, const double *v, int ncol,
                             isph_mat **A_out, double *b_out /*[h|d]*/, int lda, int on_device);
+/* Replaces PairISPH_Corrected::computeBlockHelmholtz -> FunctorOuterIncompNavierStokesBlockHelmholtz
+ * (ref: pair_isph_corrected.cpp:941-964, functor_incomp_navier_stokes_block_helmholtz.h:57-187) with the block branch
+ * of the Laplacian functor (functor_laplacian_matrix.h:269-314) and FunctorOuterBoundaryNavierSlip
+ * (functor_boundary_navier_slip.h:53-184): the dim x dim blocks A_blk(ib,jb) of the velocity Helmholtz system with
+ * wall rows distributed by the wall normals, exactly as the reference writes them (csrc/block_helmholtz.hpp lists
+ * the steps).  normal: [nall][3] wall normals (pair->normal) or NULL; beta: ns.beta (slip length factor).
+ * blocks_out[ib*dim+jb] receives block (ib,jb) on the scalar pattern; without normals the off-diagonal blocks are
+ * zero and returned as NULL.  b_out: column-major [lda x dim].  The result feeds isph_solve_block. */
+int isph_assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                                  double beta, const double *nu, const double *rho, const double *pres,
+                                  const double *force, const double *g, int incremental_pressure, const double *v,
+                                  const double *normal, int ncol, isph_mat **blocks_out, double *b_out, int lda,
+                                  int on_device);
 /* FunctorOuterVolume (ref: functor_volume.h:40-80); vfrac_out [nlocal]. */
 int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device);
 

@@ -903,6 +903,125 @@ int orc_helmholtz(const orc_particles *P, int antisym, int morris_holmes, double
   return 0;
 }
 
+/* ref: functor_incomp_navier_stokes_block_helmholtz.h:57-187 with
+ * Corrected::FunctorOuterLaplacianMatrix's block branch (functor_laplacian_matrix.h:269-314) and
+ * FunctorOuterBoundaryNavierSlip (functor_boundary_navier_slip.h:53-184), restated AS WRITTEN:
+ *   for ib = 0: Laplacian(dt, nu), filter (Fluid, Solid), with the wall normals: a fluid row whose own normal
+ *     is set (|n_i|^2 > 0.5) is distributed into blocks (ib*, jb) with weights n^_jb n^_ib*, n^ = the normalised
+ *     sum of the normals of every row entry (neighbours in the cut + self), ib* = first component with
+ *     n^_ib^2 >= 1/dim (last one otherwise); other fluid rows go to block (0,0)                (:71-76, :269-292)
+ *   for ib = 1..dim-1: NavierSlip(-beta dt): robin_i = -sum_{j solid} (-beta dt) W'/r V_j / rho_i
+ *     (n_i + n_j).(G_i^T r_ij) is added to the DIAGONAL ENTRY of EVERY block (ib', jb') with weight
+ *     delta - n^_jb' n^_ib' (n^ = n_i/|n_i|), once per pass, i.e. dim-1 times                 (:77-79, :150-162)
+ *   for every ib: Laplacian(dt, nu), filter (Fluid, Fluid) into block (ib, ib)                  (:82-85)
+ *   w_ib = (1-theta) sum_jb A(ib,jb) b_ib   -- the SAME column ib of b for every jb, as written (:94-97)
+ *   A(ib,jb) *= -theta ; diag(ib,ib) = 1 + A(ib,ib)_ii (fluid) | 1 (solid)                      (:101-104,:143-151)
+ *   b_i,ib += w_i,ib + dt (f/rho + g) - dt/rho grad p (incremental pressure)                    (:153-162)
+ * Every block is stored on the scalar pattern (rowptr/colidx of orc_graph): vals[(ib*dim+jb)*nnz + q].
+ * G_i of the slip term is Gc[i] for BOTH operator families (functor_boundary_navier_slip.h:79).
+ * material is nu (not nu*rho) and there is no 1/rho row scaling, unlike the scalar builder. */
+int orc_block_helmholtz(const orc_particles *P, int antisym, int morris_holmes, double dt, double theta, double beta,
+                        const double *nu, const double *rho, const double *p, const double *f, const double *g,
+                        int incremental_pressure, const double *normal, const double *vall,
+                        const int *rowptr, const int *colidx, double *vals, double *b, int lda) {
+  const int n = P->nlocal, dim = P->dim, d2 = dim * dim;
+  const size_t nnz = (size_t)rowptr[n];
+  memset(vals, 0, sizeof(double) * nnz * (size_t)d2);
+  double *ff = (double *)calloc(nnz, sizeof(double)), *fs = (double *)calloc(nnz, sizeof(double));
+  if (orc_laplacian_matrix(P, antisym, dt, nu, ORC_KIND_FLUID, ORC_KIND_FLUID, morris_holmes, rowptr, colidx, ff)) { free(ff); free(fs); return -1; }
+  if (orc_laplacian_matrix(P, antisym, dt, nu, ORC_KIND_FLUID, ORC_KIND_SOLID, morris_holmes, rowptr, colidx, fs)) { free(ff); free(fs); return -1; }
+  int ncol = 0;
+  for (int j = 0; j < P->nall; ++j) if (P->colmap[j] + 1 > ncol) ncol = P->colmap[j] + 1;
+  double *vext = (double *)calloc((size_t)ncol * 3, sizeof(double));
+  for (int j = 0; j < P->nall; ++j)
+    for (int k = 0; k < 3; ++k) vext[(size_t)P->colmap[j] * 3 + k] = vall[(size_t)j * 3 + k];
+  double *grad = (double *)calloc((size_t)n * 3, sizeof(double));
+  if (incremental_pressure) orc_gradient(P, antisym, p, 1.0, 1, ORC_KIND_FLUID, ORC_KIND_FLUID, grad);
+#define BLK(ib, jb) (vals + ((size_t)(ib) * dim + (jb)) * nnz)
+  for (int i = 0; i < n; ++i) {
+    const int it = P->type[i], ikind = kind_of(P, i);
+    const int pd = row_find(colidx, rowptr[i], rowptr[i + 1], P->colmap[i]);
+    if (pd >= rowptr[i + 1] || colidx[pd] != P->colmap[i]) { free(ff); free(fs); free(vext); free(grad); return -1; }
+    if (!(ikind & ORC_KIND_FLUID)) {  /* solid row: unit diagonal in the diagonal blocks, b untouched */
+      for (int ib = 0; ib < dim; ++ib) BLK(ib, ib)[pd] = 1.0;
+      continue;
+    }
+    /* (Fluid,Fluid) rows into every diagonal block */
+    for (int ib = 0; ib < dim; ++ib)
+      for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) BLK(ib, ib)[q] += ff[q];
+    /* (Fluid,Solid) row: plain or distributed by the wall normal */
+    const double *ni = normal ? &normal[3 * (size_t)i] : NULL;
+    double nn = 0.0;
+    if (ni) for (int k = 0; k < dim; ++k) nn += ni[k] * ni[k];
+    if (!(ni && nn > 0.5)) {
+      for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) BLK(0, 0)[q] += fs[q];
+    } else {
+      double nh[3] = {0, 0, 0};
+      for (int jj = P->neigh_ptr[i]; jj < P->neigh_ptr[i + 1]; ++jj) {
+        const int j = P->neigh_idx[jj];
+        double rsq = 0.0;
+        for (int k = 0; k < dim; ++k) { const double d = P->x[3 * i + k] - P->x[3 * j + k]; rsq += d * d; }
+        if (rsq < tab(P, P->cutsq, it, P->type[j]))
+          for (int k = 0; k < dim; ++k) nh[k] += normal[3 * (size_t)j + k];
+      }
+      for (int k = 0; k < dim; ++k) nh[k] += ni[k];
+      double norm = 0.0;
+      for (int k = 0; k < dim; ++k) norm += nh[k] * nh[k];
+      norm = sqrt(norm);
+      for (int k = 0; k < dim; ++k) nh[k] /= norm;
+      int ibp = 0;
+      for (; ibp < dim - 1 && (nh[ibp] * nh[ibp] < 1.0 / dim); ++ibp);
+      for (int jb = 0; jb < dim; ++jb)
+        for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) BLK(ibp, jb)[q] += fs[q] * nh[jb] * nh[ibp];
+    }
+    /* Navier slip: dim-1 passes, each adds the robin term to the diagonal entry of every block */
+    if (dim > 1 && normal) {
+      const double *G = &P->Gc[(size_t)i * d2];
+      double robin = 0.0;
+      for (int jj = P->neigh_ptr[i]; jj < P->neigh_ptr[i + 1]; ++jj) {
+        const int j = P->neigh_idx[jj], jt = P->type[j];
+        if (kind_of(P, j) != ORC_KIND_SOLID) continue;
+        double rsq = 0.0, rij[3] = {0, 0, 0};
+        for (int k = 0; k < dim; ++k) { rij[k] = P->x[3 * i + k] - P->x[3 * j + k]; rsq += rij[k] * rij[k]; }
+        if (rsq < tab(P, P->cutsq, it, jt)) {
+          const double r = sqrt(rsq) + ORC_EPS;
+          const double dwdr = orc_kernel_dval(P->kernel, dim, r, tab(P, P->h, it, jt));
+          double aij[3] = {0, 0, 0};
+          for (int k2 = 0; k2 < dim; ++k2)
+            for (int k1 = 0; k1 < dim; ++k1) aij[k2] += G2(G, dim, k1, k2) * rij[k1];
+          double tmp = 0.0;
+          for (int k = 0; k < dim; ++k) tmp += (normal[3 * (size_t)i + k] + normal[3 * (size_t)j + k]) * aij[k];
+          robin -= (-beta * dt) * dwdr / r * P->vfrac[j] / rho[i] * tmp;
+        }
+      }
+      double nh[3] = {0, 0, 0}, norm = 0.0;
+      for (int k = 0; k < dim; ++k) { nh[k] = normal[3 * (size_t)i + k]; norm += nh[k] * nh[k]; }
+      norm = sqrt(norm);
+      if (norm != 0) for (int k = 0; k < dim; ++k) nh[k] /= norm;
+      for (int pass = 1; pass < dim; ++pass)
+        for (int ib = 0; ib < dim; ++ib)
+          for (int jb = 0; jb < dim; ++jb) BLK(ib, jb)[pd] += robin * ((double)(ib == jb) - nh[jb] * nh[ib]);
+    }
+    /* w, theta scaling, diagonal, right-hand side */
+    for (int ib = 0; ib < dim; ++ib) {
+      double w = 0.0;
+      for (int jb = 0; jb < dim; ++jb)
+        for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+          w += BLK(ib, jb)[q] * vext[(size_t)colidx[q] * 3 + ib];
+          BLK(ib, jb)[q] *= -theta;
+        }
+      BLK(ib, ib)[pd] = 1.0 + BLK(ib, ib)[pd];
+      double *bk = &b[(size_t)ib * lda + i];
+      *bk += w * (1.0 - theta);
+      *bk += dt * (f[(size_t)i * 3 + ib] / rho[i] + g[ib]);
+      if (incremental_pressure) *bk += dt * (-1.0 / rho[i] * grad[(size_t)i * 3 + ib]);
+    }
+  }
+#undef BLK
+  free(ff); free(fs); free(vext); free(grad);
+  return 0;
+}
+
 /* ===================================================================== *
  *  linear algebra: Epetra / Belos / Ifpack semantics
  * ===================================================================== */

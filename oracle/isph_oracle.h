@@ -126,6 +126,13 @@ int  orc_helmholtz(const orc_particles *P, int antisym, int morris_holmes, doubl
                    const double *vall, const int *rowptr, const int *colidx,
                    double *val, double *b, int lda, double *work);
 
+/* block Helmholtz (functor_incomp_navier_stokes_block_helmholtz.h:57-187): dim x dim blocks on the scalar pattern,
+ * vals[(ib*dim+jb)*nnz + q]; normal [nall][3] or NULL; b column-major [lda x dim] holding v^n on entry */
+int  orc_block_helmholtz(const orc_particles *P, int antisym, int morris_holmes, double dt, double theta, double beta,
+                         const double *nu, const double *rho, const double *p, const double *f, const double *g,
+                         int incremental_pressure, const double *normal, const double *vall,
+                         const int *rowptr, const int *colidx, double *vals, double *b, int lda);
+
 /* ---- linear algebra restatement (Epetra/Belos/Ifpack semantics) ---- */
 void orc_spmv(int n, const int *rowptr, const int *colidx, const double *val,
               const double *x, double *y);

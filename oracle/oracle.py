@@ -90,6 +90,9 @@ def lib():
         L.orc_helmholtz.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_block_helmholtz.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_spmv.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_solve.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -247,6 +250,27 @@ def _helmholtz(self, dt, theta, nu, rho, p, f, g, vall, antisym=True, incrementa
 
 
 Particles.helmholtz = _helmholtz
+
+
+def _block_helmholtz(self, dt, theta, beta, nu, rho, p, f, g, vall, normal=None, antisym=True, incremental=True,
+                     graph=None, morris=0):
+    """computeBlockHelmholtz: returns (rowptr, colidx, vals[dim*dim, nnz], b[dim][nlocal]); block (ib,jb) = vals[ib*dim+jb]."""
+    rowptr, colidx = graph if graph is not None else self.graph()
+    d2 = self.dim * self.dim
+    vals = np.zeros((d2, len(colidx)))
+    n = self.nlocal
+    vall = _f64(vall)
+    b = np.ascontiguousarray(vall[:n, :self.dim].T.copy())
+    nu, rho, p, f, g = _f64(nu), _f64(rho), _f64(p), _f64(f), _f64(g)
+    nrm = None if normal is None else _f64(normal)
+    rc = lib().orc_block_helmholtz(self.ref(), int(antisym), int(morris), float(dt), float(theta), float(beta), _p(nu),
+                                   _p(rho), _p(p), _p(f), _p(g), int(incremental), _p(nrm), _p(vall), _p(rowptr),
+                                   _p(colidx), _p(vals), _p(b), n)
+    assert rc == 0, "orc_block_helmholtz rc=%d" % rc
+    return rowptr, colidx, vals, b
+
+
+Particles.block_helmholtz = _block_helmholtz
 
 
 def kernel_val(kernel, dim, r, h):

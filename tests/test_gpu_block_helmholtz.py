@@ -1,0 +1,96 @@
+"""-m gpu: block Helmholtz assembly (FunctorOuterIncompNavierStokesBlockHelmholtz with the wall-normal
+distribution of the Laplacian rows and the Navier-slip terms) against the oracle's restatement, block by block,
+and the assembled system solved through isph_solve_block."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from isph_amd import hip, workload
+import oracle as orc
+from problems import Problem, tgv_spec, wall_types, fake_pnd
+
+pytestmark = pytest.mark.gpu
+
+
+def band_normals(parts, dim):
+    """wall normals on every particle (fluid or solid) in a band around the slab surface y = 0.9; the direction
+    varies along x so that the block the distributed rows land in (the first large component) changes"""
+    own = parts["owner_index"]
+    x = parts["x"][:parts["nlocal"]]
+    y = x[:, 1] % (2 * np.pi)
+    nrm = np.zeros((parts["nlocal"], 3))
+    band = (y > 0.3) & (y < 1.6)
+    ang = 0.9 * np.sin(x[:, 0])
+    nrm[band, 0] = np.sin(ang[band])
+    nrm[band, 1] = np.cos(ang[band])
+    if dim == 3:
+        nrm[band, 2] = 0.4 * np.cos(x[band, 2])
+        nrm[band] /= np.linalg.norm(nrm[band], axis=1)[:, None]
+    return nrm[own]
+
+
+def _inputs(pr):
+    p = pr.parts
+    x, nall = p["x"], p["nall"]
+    pres = np.cos(x[:, 0]) * np.sin(x[:, 1])
+    force = np.ascontiguousarray(0.01 * np.stack([np.sin(x[:, 1]), np.cos(x[:, 0]), np.zeros(nall)], axis=1))
+    nu = p["nu"] * (1.0 + 0.1 * np.sin(x[:, 0]))
+    g = np.array([0.05, -0.02, 0.01 if pr.spec.dim == 3 else 0.0])
+    return pres, force, nu, g, np.ascontiguousarray(p["v"])
+
+
+@pytest.mark.parametrize("dim,n", [(2, 24), (3, 12)])
+@pytest.mark.parametrize("antisym", [True, False])
+@pytest.mark.parametrize("morris", [False, True])
+def test_block_helmholtz_matches_oracle(gpu_ctx, dim, n, antisym, morris):
+    kinds = [orc.FLUID, orc.SOLID]
+    pr = Problem(tgv_spec(dim=dim, n=n, mode=workload.JITTER, brick=4), antisym=antisym, kinds=kinds, types=wall_types,
+                 pnd=fake_pnd if morris else None, normal=lambda parts: band_normals(parts, dim))
+    p = pr.parts
+    pres, force, nu, g, vel = _inputs(pr)
+    theta, beta = 0.5, 0.3
+    rp, ci, vals, b = pr.P.block_helmholtz(pr.spec.dt, theta, beta, nu, p["rho"], pres, force, g, vel, normal=pr.normal,
+                                           antisym=antisym, morris=int(morris))
+    blocks, bg = hip.assemble_block_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, theta, beta, nu, p["rho"], pres, force, g,
+                                              vel, normal=pr.normal, antisym=antisym, vfrac=pr.P.vfrac, Gc=pr.P.Gc,
+                                              Lc=None if antisym else pr.P.Lc, kinds=kinds, pnd=pr.pnd)
+    scale = np.abs(vals).max()
+    offdiag_mass = 0.0
+    for ib in range(dim):
+        for jb in range(dim):
+            rg, cg, vg = blocks[ib][jb].export_csr()
+            assert np.array_equal(rg, rp) and np.array_equal(cg, ci)
+            assert np.max(np.abs(vg - vals[ib * dim + jb])) <= 1e-12 * scale
+            if ib != jb:
+                offdiag_mass += np.abs(vals[ib * dim + jb]).sum()
+    assert offdiag_mass > 0                                   # the wall rows really couple the components
+    assert np.max(np.abs(bg - b.ravel())) <= 1e-12 * np.abs(b).max()
+    # solve the assembled block system on the device and compare with the oracle on one CSR
+    nl = pr.n
+    big = sps.bmat([[sps.csr_matrix((vals[ib * dim + jb], ci, rp), shape=(nl, nl)) for jb in range(dim)]
+                    for ib in range(dim)], format="csr")
+    big.sort_indices()
+    xo, io = orc.solve_block(big.indptr, big.indices, big.data, b.ravel(), dim, prec="none")
+    x = np.zeros(dim * nl)
+    info = hip.solve_block(gpu_ctx, blocks, bg.copy(), x)
+    assert info.converged == 1 and io.converged == 1 and abs(info.iters - io.iters) <= 1
+    assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+def test_block_helmholtz_without_normals_is_block_diagonal(gpu_ctx):
+    """no wall normals: off-diagonal blocks are not created and the (Fluid,Solid) rows go to block (0,0) only,
+    as the reference writes it (functor_laplacian_matrix.h:269-271)."""
+    kinds = [orc.FLUID, orc.SOLID]
+    pr = Problem(tgv_spec(dim=2, n=24, mode=workload.JITTER, brick=4), kinds=kinds, types=wall_types)
+    p = pr.parts
+    pres, force, nu, g, vel = _inputs(pr)
+    rp, ci, vals, b = pr.P.block_helmholtz(pr.spec.dt, 1.0, 0.0, nu, p["rho"], pres, force, g, vel)
+    blocks, bg = hip.assemble_block_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, 1.0, 0.0, nu, p["rho"], pres, force, g,
+                                              vel, vfrac=pr.P.vfrac, kinds=kinds)
+    assert blocks[0][1] is None and blocks[1][0] is None
+    assert not vals[1].any() and not vals[2].any()
+    for k in (0, 1):
+        rg, cg, vg = blocks[k][k].export_csr()
+        assert np.array_equal(cg, ci) and np.max(np.abs(vg - vals[k * 2 + k])) <= 1e-12 * np.abs(vals).max()
+    assert np.abs(vals[0] - vals[3]).max() > 0               # block (0,0) carries the wall coupling, (1,1) does not
+    assert np.max(np.abs(bg - b.ravel())) <= 1e-12 * np.abs(b).max()
