@@ -677,3 +677,57 @@ def test_particle_shifting_matches_oracle(gpu_ctx, dim, antisym):
     assert vmax == vmax_ref
     assert np.max(np.abs(x2 - xo)) < 1e-13 and np.max(np.abs(p2 - po)) <= 1e-11 * np.abs(po).max()
     assert np.max(np.abs(v2 - vo)) <= 1e-11 * np.abs(vo).max()
+
+
+# ---------------------------------------------------------------- small / degenerate inputs
+@pytest.mark.parametrize("prec", ["none", "jacobi", "bjacobi-ilu0", "sa-amg"])
+def test_tiny_systems_with_every_preconditioner(gpu_ctx, prec):
+    """3x3 and 1x1 SPD systems: single block, single level, rows shorter than a wave."""
+    for dense in (np.array([[4.0, -1.0, 0.0], [-1.0, 4.0, -1.0], [0.0, -1.0, 3.0]]), np.array([[2.5]])):
+        S = sps.csr_matrix(dense)
+        S.sort_indices()
+        n = S.shape[0]
+        A = hip.Matrix.from_csr(gpu_ctx, S.indptr, S.indices, S.data)
+        M = hip.PrecondAMG(gpu_ctx, A) if prec == "sa-amg" else hip.Precond(gpu_ctx, A, prec, 64)
+        b = np.arange(1.0, n + 1.0)
+        x = np.zeros(n)
+        info = hip.solve(gpu_ctx, A, b.copy(), x, prec=M)
+        assert info.converged == 1
+        assert np.allclose(x, np.linalg.solve(dense, b), rtol=1e-8, atol=1e-12)
+
+
+def test_solve_with_zero_right_hand_side(gpu_ctx):
+    """Belos scales by |r0|; a zero residual means scale 1 and immediate convergence (x stays at the guess)."""
+    pr = Problem(tgv_spec(dim=2, n=16, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    x = np.zeros(pr.n)
+    info = hip.solve(gpu_ctx, A, np.zeros(pr.n), x, prec=hip.Precond(gpu_ctx, A, "jacobi"), singular=True)
+    assert info.converged == 1 and info.iters == 0 and not x.any()
+
+
+def test_assembly_with_an_isolated_particle(gpu_ctx):
+    """a particle without neighbours: its row is the diagonal alone (and zero for the Laplacian), on both sides"""
+    pr = Problem(tgv_spec(dim=2, n=12, mode=workload.JITTER))
+    p = dict(pr.parts)
+    nl = p["nlocal"]
+    # cut every link of particle 5: drop its list and remove it from the others' lists
+    ptr, idx = p["neigh_ptr"], p["neigh_idx"]
+    own = p["owner_index"]
+    new_ptr, new_idx = [0], []
+    for i in range(nl):
+        nb = idx[ptr[i]:ptr[i + 1]]
+        nb = nb[own[nb] != 5] if i != 5 else nb[:0]
+        new_idx.append(nb)
+        new_ptr.append(new_ptr[-1] + len(nb))
+    p["neigh_ptr"] = np.asarray(new_ptr, np.int32)
+    p["neigh_idx"] = np.concatenate(new_idx).astype(np.int32)
+    P = orc.Particles(p, pr.colmap, kernel=pr.spec.kernel)
+    P.precompute(corrections=False)
+    rp, ci, val, b = P.poisson(pr.spec.dt, p["rho"], p["v"], antisym=True, singular=orc.NOT_SINGULAR)
+    A, bg = hip.assemble_poisson(gpu_ctx, p, pr.colmap, pr.spec.dt, p["rho"], p["v"], antisym=True, vfrac=P.vfrac,
+                                 singular=hip.NOT_SINGULAR)
+    rg, cg, vg = A.export_csr()
+    assert rp[6] - rp[5] == 1 and np.array_equal(rg, rp) and np.array_equal(cg, ci)
+    assert np.max(np.abs(vg - val)) <= 1e-12 * np.abs(val).max()
+    assert np.max(np.abs(bg - b)) <= 1e-12 * max(np.abs(b).max(), 1e-300)
