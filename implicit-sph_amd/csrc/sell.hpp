@@ -20,8 +20,20 @@ struct Sell {
   DevBuf<int> rowlen;           // [nrow]
   DevBuf<int> col;              // [stored]
   DevBuf<double> val;           // [stored]
-  void release() { slice_off.release(); rowlen.release(); col.release(); val.release(); }
+  // windowed 16-bit copy of col for the SpMV (built on first use, see k_sell_compress_cols):
+  // col = wtab[slice*64 + (c16 >> 10)] << 10 | (c16 & 1023).  c16_state: 0 not tried, 1 usable, -1 some slice
+  // touches more than 64 windows of 1024 columns (then the 32-bit kernel stays in use)
+  mutable DevBuf<unsigned short> col16;
+  mutable DevBuf<int> wtab;
+  mutable int c16_state = 0;
+  void release() { slice_off.release(); rowlen.release(); col.release(); val.release(); col16.release(); wtab.release(); c16_state = 0; }
 };
+
+__device__ __forceinline__ unsigned amg_like_hash(int x) {
+  unsigned h = (unsigned)x;
+  h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+  return h;
+}
 
 __device__ __forceinline__ long long sell_pos(long long off, int lane, int k) {
   return off + (long long)(k >> 1) * 128 + lane * 2 + (k & 1);
@@ -240,6 +252,112 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int
     const int2 cc = c[q * 64];
     acc0 = fma(vv.x, x[cc.x], acc0);
     acc1 = fma(vv.y, x[cc.y], acc1);
+  }
+  const int row = slice * kSlice + lane;
+  const double r = acc0 + acc1;
+  if (row < nrow) y[row] = r;
+  if (DOT) {
+    const double d = wave_sum(row < nrow ? r * nvec[row] : 0.0);
+    if (lane == 0) dot_partial[slice] = d;
+  }
+}
+
+// ---- 16-bit windowed column indices ------------------------------------------------------------------
+// The SpMV streams 8 B of value and 4 B of column per entry; a slice's rows are 64 neighbouring particles whose
+// columns fall into a few dozen aligned windows of 1024 indices (the bricks around them), so a per-slice table of
+// <= 64 window numbers plus 6+10 bits per entry carries the same information in 2 B: 10 B instead of 12 B per
+// entry for the HBM-bound kernel.  One wave per slice builds the table (LDS set with atomicCAS) and re-encodes.
+__global__ __launch_bounds__(kBlock) void k_sell_compress_cols(int nslices, const long long *__restrict__ slice_off,
+                                                               const int *__restrict__ scol,
+                                                               unsigned short *__restrict__ c16, int *__restrict__ wtab,
+                                                               int *__restrict__ fail) {
+  __shared__ int tab[kBlock / kWave][64];
+  __shared__ int cnt[kBlock / kWave];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * (kBlock / kWave) + wave;
+  if (slice >= nslices) return;
+  tab[wave][lane] = -1;
+  if (lane == 0) cnt[wave] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const long long off = slice_off[slice];
+  const long long nent = slice_off[slice + 1] - off;
+  bool bad = false;
+  for (long long e = lane; e < nent; e += 64) {
+    const int win = scol[off + e] >> 10;
+    int slot = (int)(amg_like_hash(win) & 63u);
+    for (int tries = 0; tries < 64; ++tries) {
+      const int old = atomicCAS(&tab[wave][slot], -1, win);
+      if (old == -1 || old == win) break;
+      slot = (slot + 1) & 63;
+      if (tries == 63) bad = true;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (__ballot(bad)) { if (lane == 0) atomicOr(fail, 1); return; }
+  wtab[(long long)slice * 64 + lane] = tab[wave][lane];
+  for (long long e = lane; e < nent; e += 64) {
+    const int c = scol[off + e], win = c >> 10;
+    int slot = (int)(amg_like_hash(win) & 63u);
+    while (tab[wave][slot] != win) slot = (slot + 1) & 63;
+    c16[off + e] = (unsigned short)((slot << 10) | (c & 1023));
+  }
+}
+
+template <int UNROLL, bool DOT>
+__global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, int nblocks_padded,
+                                                        const long long *__restrict__ slice_off,
+                                                        const unsigned short *__restrict__ c16,
+                                                        const int *__restrict__ wtab,
+                                                        const double *__restrict__ sval,
+                                                        const double *__restrict__ x, double *__restrict__ y,
+                                                        const double *__restrict__ nvec,
+                                                        double *__restrict__ dot_partial) {
+  __shared__ int tab[kBlock / kWave][64];
+  const int b = xcd_remap(blockIdx.x, nblocks_padded);
+  const int wave = threadIdx.x >> 6;
+  const int slice = b * (kBlock / kWave) + wave;
+  if (slice >= nslices) return;
+  const int lane = threadIdx.x & 63;
+  tab[wave][lane] = wtab[(long long)slice * 64 + lane] << 10;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int *__restrict__ tw = tab[wave];
+  const long long off = slice_off[slice];
+  const int npair = (int)((slice_off[slice + 1] - off) >> 7);
+  const double2 *__restrict__ v = reinterpret_cast<const double2 *>(sval + off) + lane;
+  const unsigned *__restrict__ c = reinterpret_cast<const unsigned *>(c16 + off) + lane;  // two 16-bit columns
+  double acc0 = 0.0, acc1 = 0.0;
+  int q = 0;
+  for (; q + UNROLL <= npair; q += UNROLL) {
+    double2 vv[UNROLL];
+    unsigned cc[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      vv[u].x = __builtin_nontemporal_load(&v[(q + u) * 64].x);
+      vv[u].y = __builtin_nontemporal_load(&v[(q + u) * 64].y);
+      cc[u] = __builtin_nontemporal_load(&c[(q + u) * 64]);
+    }
+    double xa[UNROLL], xb[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const unsigned lo = cc[u] & 0xffffu, hi = cc[u] >> 16;
+      xa[u] = x[tw[lo >> 10] | (int)(lo & 1023u)];
+      xb[u] = x[tw[hi >> 10] | (int)(hi & 1023u)];
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      acc0 = fma(vv[u].x, xa[u], acc0);
+      acc1 = fma(vv[u].y, xb[u], acc1);
+    }
+  }
+  for (; q < npair; ++q) {
+    const double2 vv = v[q * 64];
+    const unsigned cc = c[q * 64];
+    const unsigned lo = cc & 0xffffu, hi = cc >> 16;
+    acc0 = fma(vv.x, x[tw[lo >> 10] | (int)(lo & 1023u)], acc0);
+    acc1 = fma(vv.y, x[tw[hi >> 10] | (int)(hi & 1023u)], acc1);
   }
   const int row = slice * kSlice + lane;
   const double r = acc0 + acc1;

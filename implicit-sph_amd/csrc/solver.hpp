@@ -90,6 +90,28 @@ inline int profile_end(isph_ctx *ctx, size_t slot) {
   return ISPH_SUCCESS;
 }
 
+// builds the 16-bit column copy of a matrix on first use (see k_sell_compress_cols); returns whether it is usable
+inline bool sell_cols16(isph_ctx *ctx, const Sell &S) {
+  if (S.c16_state != 0) return S.c16_state > 0;
+  static const bool off = getenv("ISPH_SPMV_COL32") != nullptr;  // tuning aid: keep the 32-bit kernel
+  S.c16_state = -1;
+  if (off || S.nslices == 0 || S.stored == 0) return false;
+  DevBuf<int> flag;
+  if (flag.reserve(1) != ISPH_SUCCESS || S.col16.reserve((size_t)S.stored) != ISPH_SUCCESS ||
+      S.wtab.reserve((size_t)S.nslices * 64) != ISPH_SUCCESS) { flag.release(); return false; }
+  int h = 0;
+  if (hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream) == hipSuccess) {
+    hipLaunchKernelGGL(k_sell_compress_cols, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, S.nslices,
+                       (const long long *)S.slice_off.p, (const int *)S.col.p, S.col16.p, S.wtab.p, flag.p);
+    if (hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess && h == 0)
+      S.c16_state = 1;
+  }
+  flag.release();
+  if (S.c16_state < 0) { S.col16.release(); S.wtab.release(); }
+  return S.c16_state > 0;
+}
+
 // y = A x ; if nvec: also SC_MISC+0 = y.nvec (all-reduced)
 inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, const double *nvec) {
   const Sell &S = A->S;
@@ -97,15 +119,24 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
   ISPH_CHECK(halo_exchange(ctx, A, x, &xuse));
   int nbp = 0;
   const int grid = spmv_grid(S.nslices, &nbp);
+  const bool c16 = sell_cols16(ctx, S);
   size_t slot;
   ISPH_CHECK(profile_begin(ctx, &slot));
   if (nvec) {
     ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
-    hipLaunchKernelGGL((k_sell_spmv<8, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
-                       S.slice_off.p, S.col.p, S.val.p, xuse, y, nvec, ctx->partial.p);
+    if (c16)
+      hipLaunchKernelGGL((k_sell_spmv16<8, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                         S.slice_off.p, S.col16.p, S.wtab.p, S.val.p, xuse, y, nvec, ctx->partial.p);
+    else
+      hipLaunchKernelGGL((k_sell_spmv<8, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                         S.slice_off.p, S.col.p, S.val.p, xuse, y, nvec, ctx->partial.p);
   } else {
-    hipLaunchKernelGGL((k_sell_spmv<8, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
-                       S.slice_off.p, S.col.p, S.val.p, xuse, y, (const double *)nullptr, (double *)nullptr);
+    if (c16)
+      hipLaunchKernelGGL((k_sell_spmv16<8, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                         S.slice_off.p, S.col16.p, S.wtab.p, S.val.p, xuse, y, (const double *)nullptr, (double *)nullptr);
+    else
+      hipLaunchKernelGGL((k_sell_spmv<8, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                         S.slice_off.p, S.col.p, S.val.p, xuse, y, (const double *)nullptr, (double *)nullptr);
   }
   ISPH_CHECK(profile_end(ctx, slot));
   if (nvec) {

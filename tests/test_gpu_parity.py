@@ -731,3 +731,33 @@ def test_assembly_with_an_isolated_particle(gpu_ctx):
     assert rp[6] - rp[5] == 1 and np.array_equal(rg, rp) and np.array_equal(cg, ci)
     assert np.max(np.abs(vg - val)) <= 1e-12 * np.abs(val).max()
     assert np.max(np.abs(bg - b)) <= 1e-12 * max(np.abs(b).max(), 1e-300)
+
+
+def test_spmv_window_compressed_columns_and_fallback(gpu_ctx, monkeypatch):
+    """The SpMV re-encodes columns as (window, offset) in 16 bits per slice when a slice touches <= 64 windows of
+    1024 columns; a matrix that scatters its columns keeps the 32-bit kernel.  Both must agree with SciPy, through
+    the host-pointer and the device-pointer entry."""
+    rng = np.random.default_rng(8)
+    n = 150_000
+    # (a) banded: columns within +-20000 of the row in 40 clusters -> compressible
+    rows = np.repeat(np.arange(n), 40)
+    cols_a = (rows + rng.integers(-20000, 20000, size=rows.size)) % n
+    # (b) scattered over the whole range -> more than 64 windows per slice
+    cols_b = rng.integers(0, n, size=rows.size)
+    x = rng.standard_normal(n)
+    for cols in (cols_a, cols_b):
+        S = sps.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, n))
+        S.sum_duplicates(); S.sort_indices()
+        ys = S @ x
+        A = hip.Matrix.from_csr(gpu_ctx, S.indptr, S.indices, S.data)
+        y = A.spmv(x)
+        assert np.max(np.abs(y - ys)) <= 1e-12 * np.abs(ys).max()
+    import torch
+    S = sps.csr_matrix((rng.standard_normal(rows.size), (rows, cols_a)), shape=(n, n))
+    S.sum_duplicates(); S.sort_indices()
+    A = hip.Matrix.from_csr(gpu_ctx, S.indptr, S.indices, S.data)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros_like(xd)
+    hip._check(hip.lib().isph_spmv(gpu_ctx.h, A.h, hip._ptr(xd), hip._ptr(yd), 1))
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), A.spmv(x))
