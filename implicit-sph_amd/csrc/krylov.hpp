@@ -190,10 +190,15 @@ __global__ __launch_bounds__(kBlock) void k_dot2(int n, const double *__restrict
 
 // DGKS decision on the device: d[0] = 1 when a second Gram-Schmidt pass is due (|w_new| < dep_tol |w|,
 // dep_tol = 1/sqrt(2), or always when force != 0), else 0
+// dn != NULL: the first projected vector is the unit null vector n; the reference measures |w| after its
+// operator removed that component, so the "old" norm is sqrt(|w|^2 - (w.n)^2)
 __global__ void k_dgks_decide(const double *__restrict__ ww_old, const double *__restrict__ ww_new, int force,
-                              double *__restrict__ d) {
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-    d[0] = (force || sqrt(*ww_new) < M_SQRT1_2 * sqrt(*ww_old)) ? 1.0 : 0.0;
+                              double *__restrict__ d, const double *__restrict__ dn) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double old2 = *ww_old;
+    if (dn) old2 = fmax(old2 - dn[0] * dn[0], 0.0);
+    d[0] = (force || sqrt(*ww_new) < M_SQRT1_2 * sqrt(old2)) ? 1.0 : 0.0;
+  }
 }
 
 // y = x / sqrt(*flag != 0 ? *s1 : *s0)   (next Krylov vector from the norm the DGKS branch produced)

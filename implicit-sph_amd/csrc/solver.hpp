@@ -243,8 +243,8 @@ inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld,
 // queue the next preconditioner/operator application before it looks at the scalars.
 // Mailbox: c at SC_DOT.., |w|^2 at SC_DOT+nk; c2 at SC_Y.., |w_new|^2 at SC_Y+nk; flag, |w_final|^2 at SC_ORTHO..
 enum { SC_ORTHO = SC_MISC + 20 };
-inline int ortho_enqueue(isph_ctx *ctx, int n, int j, const double *V, long long ld, double *w, int ortho, double *vnext) {
-  const int nk = j + 1;
+inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long long ld, double *w, int ortho, double *vnext,
+                         bool deflate = false) {
   int g = stream_grid(n);
   if (g > 1024) g = 1024;  // 4 workgroups per CU: more did not raise the achieved bandwidth (measured)
   ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
@@ -264,7 +264,7 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int j, const double *V, long long
                      (const double *)nullptr);
   ISPH_CHECK(allreduce_inplace(ctx, dh2, nk + 1));
   hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(64), 0, st, (const double *)(dh1 + nk), (const double *)(dh2 + nk),
-                     ortho == 1 ? 1 : 0, dor);
+                     ortho == 1 ? 1 : 0, dor, deflate ? (const double *)dh1 : (const double *)nullptr);
   const int g2 = stream_grid(n);
   hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, dh2, w, ctx->partial.p,
                      (const double *)dor);
@@ -301,7 +301,7 @@ inline int orthogonalize(isph_ctx *ctx, int n, int j, const double *V, long long
     return ISPH_SUCCESS;
   }
   // DGKS / ICGS: device-only part, then wait for the scalars
-  ISPH_CHECK(ortho_enqueue(ctx, n, j, V, ld, w, ortho, nullptr));
+  ISPH_CHECK(ortho_enqueue(ctx, n, nk, V, ld, w, ortho, nullptr));
   ISPH_CHECK(fetch_scalars(ctx, 0, SC_COUNT));
   ortho_collect(ctx, nk, h, wnorm);
   return ISPH_SUCCESS;
@@ -312,11 +312,19 @@ inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_
   const int n = op.n, m = prm->num_blocks;
   ISPH_REQUIRE(m >= 1 && m <= 62, "Num Blocks must be in [1,62]");
   const long long ld = ((long long)n + 63) / 64 * 64;
-  ISPH_CHECK(ctx->V.reserve((size_t)ld * (size_t)(m + 1)));
+  // Singular systems (null vector n): n is kept as column 0 of the basis array.  Every Krylov vector is orthogonal
+  // to n, so V^T (w - (w.n) n) = V^T w: the projection of PoissonProjection::Apply is folded into the Gram-Schmidt
+  // step (n rides along as one more vector of the multi-dot / update), which saves one reduction, one all-reduce
+  // and one vector pass per iteration.  IMGS keeps the explicit projection.
+  static const bool no_deflate = getenv("ISPH_NO_DEFLATE") != nullptr;  // tuning aid: explicit projection as in the operator
+  const bool deflate = op.nvec != nullptr && !op.blk && prm->ortho != 2 && !no_deflate;
+  ISPH_CHECK(ctx->V.reserve((size_t)ld * (size_t)(m + 2)));
   if (prm->flexible) ISPH_CHECK(ctx->Z.reserve((size_t)ld * (size_t)m));
   ISPH_CHECK(ctx->wv.reserve((size_t)ld));
   ISPH_CHECK(ctx->tv.reserve((size_t)ld));
-  double *V = ctx->V.p, *Z = ctx->Z.p, *w = ctx->wv.p, *t = ctx->tv.p;
+  double *Vall = ctx->V.p, *V = ctx->V.p + (deflate ? ld : 0), *Z = ctx->Z.p, *w = ctx->wv.p, *t = ctx->tv.p;
+  if (deflate)
+    ISPH_CHECK_HIP(hipMemcpyAsync(Vall, op.nvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
   std::vector<double> H((size_t)(m + 1) * (size_t)m, 0.0), cs((size_t)m), sn((size_t)m), g((size_t)m + 1), y((size_t)m);
   const int sg = stream_grid(n);
   hipStream_t st = ctx->stream;
@@ -350,7 +358,8 @@ inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_
         ISPH_CHECK(op.prec(vj, t));
         zj = t;
       }
-      return op.apply(zj, w);
+      // with deflation the raw product goes to the Gram-Schmidt step, which removes the n component itself
+      return deflate ? spmv_dev(ctx, op.A, zj, w, nullptr) : op.apply(zj, w);
     };
     bool op_queued = false;  // column j's operator application is already in the stream
     while (j < m) {
@@ -366,7 +375,8 @@ inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_
       } else {
         // the whole Gram-Schmidt step and v_{j+1} = w/|w| stay on the device; the host only waits for the copy of
         // the scalar mailbox, and while it does the Givens update the GPU already works on the next column
-        ISPH_CHECK(ortho_enqueue(ctx, n, j, V, ld, w, prm->ortho, V + (long long)(j + 1) * ld));
+        const int nkt = j + 1 + (deflate ? 1 : 0);  // basis vectors (+ n) the step projects against
+        ISPH_CHECK(ortho_enqueue(ctx, n, nkt, Vall, ld, w, prm->ortho, V + (long long)(j + 1) * ld, deflate));
         ISPH_CHECK_HIP(hipMemcpyAsync(ctx->hscal, ctx->dscal.p, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
         ISPH_CHECK_HIP(hipEventRecord(ctx->ev_fetch, st));
         if (j + 1 < m && info->iters + 1 < prm->max_iters) {  // speculative: discarded if this column converges
@@ -374,7 +384,13 @@ inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_
           op_queued = true;
         }
         ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev_fetch));
-        ortho_collect(ctx, j + 1, h, &wn);
+        if (deflate) {
+          double hh[66];
+          ortho_collect(ctx, nkt, hh, &wn);
+          for (int k = 0; k <= j; ++k) h[k] = hh[k + 1];
+        } else {
+          ortho_collect(ctx, nkt, h, &wn);
+        }
       }
       h[j + 1] = wn;
       for (int k = 0; k < j; ++k) {
