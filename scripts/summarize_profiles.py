@@ -44,11 +44,12 @@ def traffic(prefix):
     return f, w, sum(n for n, a in nf)
 
 
-sf, sw, sn = traffic("void isph::k_sell_spmv")
+spmv_prefix = "void isph::k_sell_spmv16" if any(k.startswith("void isph::k_sell_spmv16") for k in fetch) else "void isph::k_sell_spmv"
+sf, sw, sn = traffic(spmv_prefix)
 jf, jw, jn = traffic("void isph::k_ilu_solve_stream")
 old = json.load(open(os.path.join(PROF, "%s_spmv_traffic.json" % tag))) if os.path.exists(os.path.join(PROF, "%s_spmv_traffic.json" % tag)) else {}
 doc = {
-    "kernel": "k_sell_spmv<8,*,true>",
+    "kernel": spmv_prefix.replace("void isph::", "") + "<8,*>",
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (scripts/collect_profiles.sh)",
     "workload": old.get("workload", "3D TGV 100^3 advect"),
     "fetch_size_kb_raw": sf, "write_size_kb": sw,
