@@ -18,6 +18,7 @@ constexpr int kDotBatch = 16;  // basis vectors whose partial sums a thread keep
 // Basis vectors are processed in batches of kDotBatch: every thread keeps one running sum per vector of the
 // batch in registers while it grid-strides over its rows, so the wave/block reduction (DPP + LDS) happens once
 // per batch instead of once per row chunk; w is re-read once per batch (+8N bytes per 16 vectors).
+template <int ROWS>
 __global__ __launch_bounds__(kBlock) void k_multi_dot(int n, int nk, const double *__restrict__ V, long long ld,
                                                       const double *__restrict__ w,
                                                       double *__restrict__ partial) {
@@ -33,7 +34,21 @@ __global__ __launch_bounds__(kBlock) void k_multi_dot(int n, int nk, const doubl
     for (int u = 0; u < kDotBatch; ++u) acc[u] = 0.0;
     double ww = 0.0;
     const double *__restrict__ vb = V + (long long)k0 * ld;
-    for (long long i = i0; i < n; i += stride) {
+    long long i = i0;
+    if (ROWS == 2) {  // two rows per trip: twice the loads in flight per thread
+      for (; i + stride < n; i += 2 * stride) {
+        const double wa = w[i], wb = w[i + stride];
+        if (last) ww = fma(wb, wb, fma(wa, wa, ww));
+        double va[kDotBatch], vc[kDotBatch];
+#pragma unroll
+        for (int u = 0; u < kDotBatch; ++u)
+          if (u < nb) { va[u] = vb[(long long)u * ld + i]; vc[u] = vb[(long long)u * ld + i + stride]; }
+#pragma unroll
+        for (int u = 0; u < kDotBatch; ++u)
+          if (u < nb) acc[u] = fma(vc[u], wb, fma(va[u], wa, acc[u]));
+      }
+    }
+    for (; i < n; i += stride) {
       const double wi = w[i];
       if (last) ww = fma(wi, wi, ww);
 #pragma unroll

@@ -221,7 +221,7 @@ inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld,
   int g = stream_grid(n);
   if (g > 1024) g = 1024;  // 4 workgroups per CU: more did not raise the achieved bandwidth (measured)
   ISPH_CHECK(ctx->partial.reserve((size_t)(nk + 2) * kMaxRedBlocks > (size_t)kMaxRedBlocks * 66 ? (size_t)(nk + 2) * kMaxRedBlocks : (size_t)kMaxRedBlocks * 66));
-  hipLaunchKernelGGL(k_multi_dot, dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, w, ctx->partial.p);
+  hipLaunchKernelGGL((k_multi_dot<1>), dim3(g), dim3(kBlock), 0, ctx->stream, n, nk, V, ld, w, ctx->partial.p);
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, ctx->stream, nk + 1, g, ctx->partial.p,
                      ctx->dscal.p + SC_DOT);
   ISPH_CHECK(allreduce_inplace(ctx, ctx->dscal.p + SC_DOT, nk + 1));
@@ -246,11 +246,18 @@ enum { SC_ORTHO = SC_MISC + 20 };
 inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long long ld, double *w, int ortho, double *vnext,
                          bool deflate = false) {
   int g = stream_grid(n);
-  if (g > 1024) g = 1024;  // 4 workgroups per CU: more did not raise the achieved bandwidth (measured)
+  // 2 workgroups per CU with two rows per thread in flight: multi-dot 53.6 -> 44.4 us, the 64-wide fused update
+  // 92.8 -> 79.5 us against 4 workgroups per CU, one row (rocprofv3, bench matrix); ISPH_DOT_ROWS / ISPH_DOT_GRID
+  // are tuning switches
+  if (g > 1024) g = 1024;
   ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
   hipStream_t st = ctx->stream;
   double *dh1 = ctx->dscal.p + SC_DOT, *dh2 = ctx->dscal.p + SC_Y, *dor = ctx->dscal.p + SC_ORTHO;
-  hipLaunchKernelGGL(k_multi_dot, dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+  static const int dot_rows = []() { const char *e = getenv("ISPH_DOT_ROWS"); return e ? atoi(e) : 2; }();
+  static const int dot_grid = []() { const char *e = getenv("ISPH_DOT_GRID"); return e ? atoi(e) : 512; }();
+  if (g > dot_grid) g = dot_grid;
+  if (dot_rows == 2) hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+  else hipLaunchKernelGGL((k_multi_dot<1>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh1,
                      (const double *)nullptr);
   ISPH_CHECK(allreduce_inplace(ctx, dh1, nk + 1));
