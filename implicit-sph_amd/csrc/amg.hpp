@@ -39,7 +39,8 @@ struct AmgLevel {
   const isph_mat *Am = nullptr;
   isph_mat *Aown = nullptr;  // coarse levels own their SELL matrix
   DCsr P;                    // prolongator (kept in CSR for export)
-  isph_mat *Pm = nullptr, *Rm = nullptr;
+  isph_mat *Pm = nullptr;
+  DCsr R;                    // restriction P^T in CSR: its rows are hundreds of entries long, one wave per row
   isph_ilu *sgs = nullptr;   // block-local symmetric Gauss-Seidel in stream form
   DevBuf<int> agg;
   DevBuf<double> nv, x, b, r, z;
@@ -56,6 +57,7 @@ struct isph_amg {
 
 namespace isph {
 
+constexpr int kAmgCoarseBlock = 64;  // rows the Gauss-Seidel sweeps are local to on levels >= 1
 constexpr int kAmgWaves = 4;  // rows per 256-thread workgroup in the wave-per-row kernels
 enum { AMG_COVERED = 0, AMG_UNDECIDED = 1, AMG_ROOT = 3 };
 
@@ -390,6 +392,18 @@ __global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, cons
     }
 }
 
+// y = R x for a CSR matrix with long rows: one wave per row, coalesced reads of the row, fixed-order wave sum
+__global__ __launch_bounds__(256) void k_csr_spmv_wave(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                       const double *__restrict__ v, const double *__restrict__ x,
+                                                       double *__restrict__ y) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) s = fma(v[p], x[ci[p]], s);
+  s = wave_sum(s);
+  if (lane == 0) y[i] = s;
+}
+
 // ---- dense direct solve of the coarsest level (non-singular case) ---------------------------------------
 __global__ void k_dense_from_csr(int n, const int *__restrict__ rp, const int *__restrict__ ci,
                                  const double *__restrict__ v, double *__restrict__ aug) {
@@ -567,10 +581,9 @@ inline int amg_spgemm_ap(isph_ctx *ctx, const DCsr &A, const DCsr &P, DCsr &AP, 
 
 inline void amg_level_destroy(AmgLevel *L) {
   if (!L) return;
-  L->A.release(); L->P.release();
+  L->A.release(); L->P.release(); L->R.release();
   if (L->Aown) isph_mat_destroy(L->Aown);
   if (L->Pm) isph_mat_destroy(L->Pm);
-  if (L->Rm) isph_mat_destroy(L->Rm);
   if (L->sgs) ilu_destroy(L->sgs);
   L->agg.release(); L->nv.release(); L->x.release(); L->b.release(); L->r.release(); L->z.release();
   delete L;
@@ -757,7 +770,8 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (nagg < 8 || nagg >= n) { L->agg.release(); break; }
     AmgLevel *Lc = new AmgLevel();
     rc = amg_prolongator(ctx, L, dg.p, nagg, prm->omega, Lc->nv, tmp, derr.p);
-    DCsr R, AP;
+    DCsr AP;
+    DCsr &R = L->R;
     if (rc == ISPH_SUCCESS) rc = amg_transpose(ctx, L->P, R, tmp);
     if (rc == ISPH_SUCCESS) rc = amg_spgemm_ap(ctx, L->A, L->P, AP, tmp, derr.p);
     if (rc == ISPH_SUCCESS) rc = amg_spgemm_t<4096, 256>(ctx, R, AP, Lc->A, tmp, derr.p);
@@ -766,11 +780,10 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc == ISPH_SUCCESS && (herr & 1)) rc = fail("AMG: a row touches more than 64 aggregates (raise the threshold)", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS && (herr & 2)) rc = fail("AMG: coarse operator row too dense for the SpGEMM table", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, L->P.n, L->P.m, L->P.rp.p, L->P.ci.p, L->P.v.p, L->P.nnz, &L->Pm, /*rows_sorted=*/true);
-    if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, R.n, R.m, R.rp.p, R.ci.p, R.v.p, R.nnz, &L->Rm, /*rows_sorted=*/true);
     if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, Lc->A.n, Lc->A.m, Lc->A.rp.p, Lc->A.ci.p, Lc->A.v.p, Lc->A.nnz, &Lc->Aown);
-    R.release(); AP.release();
+    AP.release();
     if (rc != ISPH_SUCCESS) { amg_level_destroy(Lc); break; }
-    L->Pm->local = L->Rm->local = Lc->Aown->local = true;
+    L->Pm->local = Lc->Aown->local = true;
     Lc->Am = Lc->Aown;
     G->L.push_back(Lc);
     ++G->nlev;
@@ -780,7 +793,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     AmgLevel *L = G->L[(size_t)l];
     rc = amg_level_buffers(L);
     const bool last = l == G->nlev - 1;
-    if (rc == ISPH_SUCCESS && (!last || G->singular)) rc = ilu_create(ctx, L->Am, G->block, &L->sgs, /*sgs=*/true);
+    // coarse levels are small: 64-row blocks keep enough waves busy (an 8-block level ran its sweeps on 8 waves)
+    if (rc == ISPH_SUCCESS && (!last || G->singular))
+      rc = ilu_create(ctx, L->Am, l == 0 ? G->block : kAmgCoarseBlock, &L->sgs, /*sgs=*/true);
   }
   if (rc == ISPH_SUCCESS && !G->singular) {
     AmgLevel *L = G->L.back();
@@ -840,7 +855,8 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
   ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
   hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
-  ISPH_CHECK(spmv_dev(ctx, L->Rm, L->r.p, Lc->b.p, nullptr));
+  hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const int *)L->R.rp.p,
+                     (const int *)L->R.ci.p, (const double *)L->R.v.p, (const double *)L->r.p, Lc->b.p);
   ISPH_CHECK(amg_vcycle(ctx, G, l + 1, Lc->b.p, Lc->x.p));
   ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, L->r.p, nullptr));
   hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,

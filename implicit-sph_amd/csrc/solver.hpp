@@ -119,7 +119,8 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
   ISPH_CHECK(halo_exchange(ctx, A, x, &xuse));
   int nbp = 0;
   const int grid = spmv_grid(S.nslices, &nbp);
-  const bool c16 = sell_cols16(ctx, S);
+  // AMG transfer / coarse operators are small or have very long rows: the window tables do not pay there
+  const bool c16 = !A->local && sell_cols16(ctx, S);
   size_t slot;
   ISPH_CHECK(profile_begin(ctx, &slot));
   if (nvec) {

@@ -20,7 +20,7 @@
  *       rounds and hashed priorities (Bell, Dalton, Olson 2012) -- the same
  *       "root + all its neighbours" aggregates, order-independent.
  *   (2) ML's Gauss-Seidel is processor-local; here it is local to blocks of
- *       `block` consecutive rows: x += M_B^-1 (b - A x),
+ *       `block` consecutive rows on the fine level and to 64 rows on the coarse ones: x += M_B^-1 (b - A x),
  *       M_B = blockdiag[(D+L_B) D^-1 (D+U_B)], one residual per sweep.
  *   The damping uses rho = ||D^-1 A||_inf ("eigen-analysis: type" Anorm)
  *   instead of ML's default 10 CG-Lanczos steps.
@@ -34,6 +34,7 @@
 #include "isph_oracle.h"
 
 #define AMG_MAXLEV 8
+#define AMG_COARSE_BLOCK 64 /* rows the Gauss-Seidel sweeps are local to on levels >= 1 (shared with the GPU) */
 
 typedef struct { int n, m; int *rp, *ci; double *v; } csr_t; /* n rows, m columns */
 
@@ -283,11 +284,12 @@ static void sgs_solve(const csr_t *A, const double *dinv, int block, const doubl
 static void smooth(const orc_amg *G, int l, const double *b, double *x, int zero_guess) {
   const csr_t *A = &G->A[l];
   double *r = G->r[l];
-  if (zero_guess) { sgs_solve(A, G->dinv[l], G->block, b, x); return; }
+  const int blk = l == 0 ? G->block : AMG_COARSE_BLOCK;
+  if (zero_guess) { sgs_solve(A, G->dinv[l], blk, b, x); return; }
   spmv(A, x, r);
   for (int i = 0; i < A->n; ++i) r[i] = b[i] - r[i];
   double *z = (double *)malloc(sizeof(double) * (size_t)A->n);
-  sgs_solve(A, G->dinv[l], G->block, r, z);
+  sgs_solve(A, G->dinv[l], blk, r, z);
   for (int i = 0; i < A->n; ++i) x[i] += z[i];
   free(z);
 }
