@@ -87,7 +87,8 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   return v;
 }
 // ML's strength test: a_ij strong iff a_ij^2 > theta^2 |a_ii a_jj| ("aggregation: threshold", default 0)
-#define AMG_STRONG(val, i, j) ((j) < n && (j) != (i) && (val) * (val) > th2 * fabs(dg[i] * dg[j]))
+// (threshold 0: every non-zero off-diagonal entry is strong -- the diagonal gathers are skipped)
+#define AMG_STRONG(val, i, j) ((j) < n && (j) != (i) && (th2 == 0.0 ? (val) != 0.0 : (val) * (val) > th2 * fabs(dg[i] * dg[j])))
 
 __global__ void k_sell_to_csr_i32(int nrow, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
                                   const int *__restrict__ scol, const double *__restrict__ sval,

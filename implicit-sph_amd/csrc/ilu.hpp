@@ -470,23 +470,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
 // M_B = (D+L_B) D^-1 (D+U_B),  M_B^-1 r = (D+U_B)^-1 [ D (D+L_B)^-1 r ]  and  y = D (D+L_B)^-1 r  solves the
 // unit-lower system  y_i = r_i - sum_j (a_ij / a_jj) y_j,  so the "L factor" is a_ij / a_jj, the "U factor" a_ij
 // and the pivots a_ii.  Used as the AMG smoother (amg.hpp).
+__global__ void k_sgs_pivots(int n, const long long *__restrict__ frp, const double *__restrict__ fval,
+                             const int *__restrict__ fdiag, double *__restrict__ dinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dinv[i] = 1.0 / fval[frp[i] + fdiag[i]];
+}
 __global__ void k_sgs_fill(int n, const long long *__restrict__ frp, const int *__restrict__ fcol,
                            const double *__restrict__ fval, const int *__restrict__ flen,
                            const int *__restrict__ fdiag, const int *__restrict__ fdst, double *__restrict__ sv,
-                           double *__restrict__ dinv) {
+                           const double *__restrict__ dinv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long long rp = frp[i];
   const int len = flen[i], dg = fdiag[i];
-  dinv[i] = 1.0 / fval[rp + dg];
   for (int s = 0; s < len; ++s) {
     const int d = fdst[rp + s];
     if (d < 0) continue;
     double a = fval[rp + s];
-    if (s < dg) {
-      const int j = fcol[rp + s];
-      a *= 1.0 / fval[frp[j] + fdiag[j]];
-    }
+    if (s < dg) a *= dinv[fcol[rp + s]];
     sv[d] = a;
   }
 }
@@ -666,8 +667,10 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       }
     }
     if (rc == ISPH_SUCCESS && sgs) {
+      hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
+                         F->fval.p, F->fdiag.p, F->dinv.p);
       hipLaunchKernelGGL(k_sgs_fill, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
-                         F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->sv.p, F->dinv.p);
+                         F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->sv.p, (const double *)F->dinv.p);
       if (hipGetLastError() != hipSuccess) rc = fail("SGS fill launch failed", __FILE__, __LINE__);
     } else if (rc == ISPH_SUCCESS) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_factor<kIluWaves>),
