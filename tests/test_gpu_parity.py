@@ -761,3 +761,43 @@ def test_spmv_window_compressed_columns_and_fallback(gpu_ctx, monkeypatch):
     hip._check(hip.lib().isph_spmv(gpu_ctx.h, A.h, hip._ptr(xd), hip._ptr(yd), 1))
     torch.cuda.synchronize()
     assert np.array_equal(yd.cpu().numpy(), A.spmv(x))
+
+
+def test_gpu_matches_committed_golden_fixture(gpu_ctx):
+    """tests/golden/tgv2d_walls_12.npz: assembly (both families), Helmholtz, ILU(0) factor, solve and AMG aggregates on
+    the device against the committed expected outputs -- no live oracle in the comparison."""
+    import importlib.util
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    G = np.load(os.path.join(gdir, "tgv2d_walls_12.npz"))
+    kinds = [orc.FLUID, orc.SOLID]
+    for fam, pr in mg.golden_problem().items():
+        p = pr.parts
+        antisym = fam == "antisym"
+        kw = dict(antisym=antisym, vfrac=pr.P.vfrac, kinds=kinds, Gc=None if antisym else pr.P.Gc,
+                  Lc=None if antisym else pr.P.Lc)
+        A, bg = hip.assemble_poisson(gpu_ctx, p, pr.colmap, pr.spec.dt, p["rho"], p["v"], singular=hip.NOT_SINGULAR, **kw)
+        rg, cg, vg = A.export_csr()
+        assert np.array_equal(rg, G[fam + "_rowptr"]) and np.array_equal(cg, G[fam + "_colidx"])
+        assert np.max(np.abs(vg - G[fam + "_val"])) <= 1e-12 * np.abs(G[fam + "_val"]).max()
+        assert np.max(np.abs(bg - G[fam + "_b"])) <= 1e-12 * np.abs(G[fam + "_b"]).max()
+        x = p["x"]
+        nall = p["nall"]
+        pres = np.cos(x[:, 0]) * np.sin(x[:, 1])
+        force = np.ascontiguousarray(0.01 * np.stack([np.sin(x[:, 1]), np.cos(x[:, 0]), np.zeros(nall)], axis=1))
+        H, bh = hip.assemble_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, 0.5, p["nu"], p["rho"], pres, force,
+                                       np.array([0.05, -0.02, 0.0]), np.ascontiguousarray(p["v"]), **kw)
+        assert np.max(np.abs(H.export_csr()[2] - G[fam + "_helm_val"])) <= 1e-12 * np.abs(G[fam + "_helm_val"]).max()
+        assert np.max(np.abs(bh - G[fam + "_helm_b"].ravel())) <= 1e-12 * np.abs(G[fam + "_helm_b"]).max()
+        if antisym:
+            M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 64)
+            assert np.max(np.abs(M.export_ilu()[2] - G["ilu_val"])) <= 1e-10 * np.abs(G["ilu_val"]).max()
+            xs = np.zeros(pr.n)
+            info = hip.solve(gpu_ctx, A, bg.copy(), xs, prec=M)
+            assert info.converged == 1 and abs(info.iters - int(G["iters"][0])) <= 1
+            assert np.linalg.norm(xs - G["x"]) <= 1e-6 * np.linalg.norm(G["x"])
+            Mg = hip.PrecondAMG(gpu_ctx, A, params=hip.AmgParams(theta=0.05, block=64, coarse_max=16))
+            assert np.array_equal(Mg.aggregates(0), G["amg_aggregates"])
