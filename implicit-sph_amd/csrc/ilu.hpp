@@ -404,11 +404,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
       __builtin_amdgcn_wave_barrier();
       // software-pipelined elimination: the U-row of step s+kFacPrefetch is
       // requested while step s is applied (one entry per lane per 64 columns)
-      int psq[kFacPrefetch];      // slot+1 in row i of the prefetched U-row entry (0: not in the pattern)
+      // The prefetch only ISSUES the global loads (column and value of the U-row entry this lane will apply);
+      // the column -> slot look-up in LDS happens when the step is applied.  (Looking the slot up inside the
+      // request made every request wait for its own global load: no overlap at all.)
+      int pcq[kFacPrefetch];      // column of the prefetched U-row entry (-1: none for this lane)
       double pvq[kFacPrefetch];   // its value
       double pdq[kFacPrefetch];   // 1/d_k of that step
-      auto request = [&](int s, int &ps, double &pvv, double &pdv) {
-        ps = 0;
+      auto request = [&](int s, int &pc, double &pvv, double &pdv) {
+        pc = -1;
         pvv = 0.0;
         pdv = 0.0;
         if (s < dg) {
@@ -417,19 +420,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
           const int t = dgL[k] + 1 + lane;
           if (t < lenL[k]) {
             const long long p = rpL[k] + t;
-            ps = mp[fcol[p] - blo];
+            pc = fcol[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
             pvv = fval[p];
           }
         }
       };
 #pragma unroll
-      for (int u = 0; u < kFacPrefetch; ++u) request(u, psq[u], pvq[u], pdq[u]);
+      for (int u = 0; u < kFacPrefetch; ++u) request(u, pcq[u], pvq[u], pdq[u]);
       for (int s0 = 0; s0 < dg; s0 += kFacPrefetch) {
 #pragma unroll
         for (int u = 0; u < kFacPrefetch; ++u) {
           const int s = s0 + u;
           if (s < dg) {
-            const int ps = psq[u];
+            const int ps = pcq[u] >= 0 ? mp[pcq[u] - blo] : 0;  // slot+1 in row i (0: not in the pattern)
             const double lik = mv[s] * pdq[u];   // l_ik = a_ik / d_k (reciprocal stored once per pivot)
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) mv[s] = lik;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            request(s + kFacPrefetch, psq[u], pvq[u], pdq[u]);
+            request(s + kFacPrefetch, pcq[u], pvq[u], pdq[u]);
           }
         }
       }
