@@ -149,8 +149,9 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
                                                        int ccap, int capf, int slack, int *__restrict__ err) {
   extern __shared__ int lds_i[];
-  int *lev = lds_i;              // [B]
-  int *cnt = lev + B;            // [B+1] rows per level
+  int *levL = lds_i;             // [B] level of every row in the L solve
+  int *levU = levL + B;          // [B] ... in the U solve
+  int *cnt = levU + B;           // [B+1] rows per level
   int *lvoff = cnt + B + 1;      // [B+1] sorted position of the first row of a level
   int *choff = lvoff + B + 1;    // [B+2] first chunk of every step
   int *skey = choff + B + 2;     // [B] sort key (level, -ndep) of the rank computation
@@ -159,8 +160,9 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   int *sT = slane + B;           // [B] chunk count of the row's step
   int *sinfo = sT + B;           // [B] bit 0: first row of its step, bits 1-3: carries needed, bits 8-14: lanes used
   int *sstep = sinfo + B;        // [B] step index
-  // optional cache of every row's in-block local columns, [slot][row] (conflict-free across rows)
-  unsigned short *ccol = reinterpret_cast<unsigned short *>(sstep + B);  // [ccap][B], ccap == 0: read global
+  int *slen = sstep + B;         // [B] row length / diagonal slot / first entry, for the level walk
+  int *sdg = slen + B;           // [B]
+  long long *srp = reinterpret_cast<long long *>(sdg + B + (B & 1));  // [B]
   __shared__ int s_nlev, s_nsched, s_nch;
   const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   const int t = threadIdx.x;
@@ -177,39 +179,57 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
     len = flen[i];
     dg = fdiag[i];
     fdst[rp + dg] = -1;
-    if (ccap > 0)
-      for (int s = 0; s < len; ++s) ccol[s * B + t] = (unsigned short)(fcol[rp + s] - blo);
+    srp[t] = rp; slen[t] = len; sdg[t] = dg;
+  }
+  __syncthreads();
+  // ---- levels: lev = 1 + max lev of the dependencies (0: no dependencies).  Dependencies of the L solve have
+  // smaller, those of the U solve larger indices, so ONE walk over the rows in index order settles a direction:
+  // wave 0 walks upwards for L, wave 1 downwards for U, lanes over the row's dependencies, the columns of the
+  // next kLevAhead rows already requested.  (A relaxation over all rows needed one sweep per level, ~175 of them:
+  // half of this kernel's time, and its LDS column cache kept the kernel at one workgroup per CU.)
+  {
+    constexpr int kLevAhead = 4;
+    const int wave = t >> 6, lane = t & 63;
+    const int nwalk = blockDim.x >= 128 ? 2 : 1;  // 64-row blocks have a single wave: it walks both directions
+    for (int wdir = wave; wdir < 2; wdir += nwalk) {
+      if (wave >= nwalk) break;
+      int *lv = wdir == 0 ? levL : levU;
+      const int step = wdir == 0 ? 1 : -1;
+      const int r = wdir == 0 ? 0 : m - 1;
+      int cq[kLevAhead];
+      auto request = [&](int row, int &c) {
+        c = -1;
+        if (row >= 0 && row < m) {
+          const int d0r = wdir == 0 ? 0 : sdg[row] + 1, d1r = wdir == 0 ? sdg[row] : slen[row];
+          if (lane < d1r - d0r) c = fcol[srp[row] + d0r + lane];
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < kLevAhead; ++u) request(r + u * step, cq[u]);
+      for (int k0 = 0; k0 < m; k0 += kLevAhead) {
+#pragma unroll
+        for (int u = 0; u < kLevAhead; ++u) {
+          const int row = r + (k0 + u) * step;
+          if (k0 + u < m) {
+            int nl = cq[u] >= 0 ? lv[cq[u] - blo] + 1 : 0;
+            const int d0r = wdir == 0 ? 0 : sdg[row] + 1, d1r = wdir == 0 ? sdg[row] : slen[row];
+            for (int e = lane + 64; e < d1r - d0r; e += 64) nl = max(nl, lv[fcol[srp[row] + d0r + e] - blo] + 1);
+            nl = wave_max_i32(nl);
+            if (lane == 0) lv[row] = nl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            request(row + kLevAhead * step, cq[u]);
+          }
+        }
+      }
+    }
   }
   __syncthreads();
   int used = 0;  // chunks used so far in this block (L then U)
   for (int dir = 0; dir < 2; ++dir) {
     const int d0 = dir == 0 ? 0 : dg + 1, d1 = dir == 0 ? dg : len;  // dependency slots
     const int ndep = active ? d1 - d0 : 0;
-    // ---- levels by relaxation (monotone, converges in #levels sweeps)
-    if (t < B) lev[t] = 0;
-    __syncthreads();
-    for (int sweep = 0; sweep <= B; ++sweep) {
-      int nl = 0;
-      if (ccap > 0) {
-        // 8 independent column/level look-ups in flight (a plain loop serialises two LDS latencies per dependency)
-        for (int e0 = 0; e0 < ndep; e0 += 8) {
-          int lv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int e = min(e0 + u, ndep - 1);
-            lv[u] = lev[ccol[(d0 + e) * B + t]];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) nl = max(nl, lv[u] + 1);
-        }
-      } else {
-        for (int e = 0; e < ndep; ++e) nl = max(nl, lev[fcol[rp + d0 + e] - blo] + 1);
-      }
-      const int changed = active && nl != lev[t];
-      if (!__syncthreads_or(changed)) break;
-      if (active) lev[t] = nl;
-      __syncthreads();
-    }
+    const int *lev = dir == 0 ? levL : levU;
     if (dir == 0 && active) llev[i] = lev[t];  // the numeric factorisation walks the same levels
     // ---- histogram of levels
     if (t == 0) s_nlev = 0;
@@ -648,10 +668,8 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       hipLaunchKernelGGL(k_ilu_extract, dim3(F->nblocks), dim3(block_size), 0, ctx->stream, S.nrow, block_size,
                          S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, F->frp.p, F->fcol.p, F->fval.p, F->flen.p,
                          F->fdiag.p, F->err.p);
-      size_t lds_s = sizeof(int) * (10 * Bz + 8);
-      int ccap = S.wmax;  // cache every row's local columns in LDS when it fits
-      if (lds_s + 2 * (size_t)ccap * Bz > 150 * 1024) ccap = 0;
-      lds_s += 2 * (size_t)ccap * Bz;
+      const size_t lds_s = sizeof(int) * (13 * Bz + 10) + sizeof(long long) * Bz;
+      const int ccap = 0;  // (kept in the signature: the level walk no longer caches columns in LDS)
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_s) != hipSuccess)
         rc = fail("LDS attribute failed", __FILE__, __LINE__);
