@@ -573,6 +573,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
         acc = fma(v, y[cw & 0x7FFu], acc);
         const unsigned cw0 = __builtin_amdgcn_readfirstlane(cw);
         if (cw0 & kEndBit) {
+          // the row's current value and pivot are fetched before the scan, not after it: they do not depend on it,
+          // and this kernel is bound by the length of the per-step dependency chain (a quarter of the blocks take
+          // as long as all of them), not by bandwidth
+          const unsigned row = (cw >> kRowShift) & 0x7FFu;
+          const bool tail = (cw >> kTailShift) & 1u;
+          const unsigned rsafe = tail ? row : 0u;
+          const double yold = y[rsafe];
+          const double dvr = upper ? dv[rsafe] : 1.0;
           // segmented inclusive scan towards the last lane of every row (see k_ilu_schedule)
           const int p = (cw >> kPosShift) & 15;
           double s = acc, q;
@@ -587,11 +595,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
             if (need & 2u) { q = dpp_move<0x142, 0x4>(s); s += cont ? q : 0.0; }  // lane 31 -> DPP row 2
             if (need & 4u) { q = dpp_move<0x142, 0x8>(s); s += cont ? q : 0.0; }  // lane 47 -> DPP row 3
           }
-          if ((cw >> kTailShift) & 1u) {
-            const unsigned row = (cw >> kRowShift) & 0x7FFu;
-            const double yr = y[row] - s;
-            y[row] = upper ? yr * dv[row] : yr;
-          }
+          if (tail) y[row] = (yold - s) * dvr;
           acc = 0.0;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -715,8 +719,9 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
   constexpr int WV = 4;
   const size_t lds = sizeof(double) * 2 * (size_t)F->B * WV;
   static const int pf = []() { const char *e = getenv("ISPH_ILU_PREFETCH"); return e ? atoi(e) : kPrefetch; }();
+  static const int dbg_div = []() { const char *e = getenv("ISPH_ILU_DBG_DIV"); return e ? atoi(e) : 1; }();
 #define ISPH_ILU_LAUNCH(PF)                                                                                             \
-  hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream,   \
+  hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks / dbg_div + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream,   \
                      F->n, F->B, F->nblocks, F->S->slice_off.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p, \
                      F->dinv.p, r, z, F->capf, F->slack)
   if (pf == 12) ISPH_ILU_LAUNCH(12);
