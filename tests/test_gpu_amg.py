@@ -67,3 +67,45 @@ def test_amg_hierarchy_cycle_and_solve_match_oracle(gpu_ctx, case, theta, singul
         nc = np.linalg.lstsq(P.toarray(), nv, rcond=None)[0] if n <= 4096 else None
         if nc is not None:
             assert np.linalg.norm(_csr(r1, c1, v1, n1, n1) @ nc) <= 1e-10 * np.abs(v1).max() * np.linalg.norm(nc)
+
+
+@pytest.mark.parametrize("kw", [dict(sweeps=2), dict(max_levels=2), dict(max_levels=1), dict(omega=1.0, theta=0.03)])
+def test_amg_parameter_variants_match_oracle(gpu_ctx, kw):
+    """"smoother: sweeps", "max levels", damping and threshold follow the oracle through the same code paths."""
+    pr = Problem(tgv_spec(dim=3, n=14, mode=workload.JITTER, brick=7))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    nv = np.ones(n) / np.sqrt(n)
+    base = dict(theta=0.02, block=128, coarse_max=32)
+    base.update(kw)
+    G = orc.AMG(rp, ci, val, nullvec=nv, **base)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(**base))
+    assert M.levels == G.levels
+    r = np.random.default_rng(12).standard_normal(n)
+    zo, zg = G.apply(r), M.apply(r)
+    assert np.linalg.norm(zg - zo) <= 1e-9 * np.linalg.norm(zo)
+    xo, io_, _ = orc.solve(rp, ci, val, b, singular=True, prec="amg", amg=G)
+    xg = np.zeros(n)
+    info = hip.solve(gpu_ctx, A, b.copy(), xg, prec=M, singular=True)
+    assert info.converged == 1 and abs(info.iters - io_.iters) <= 1
+    assert np.linalg.norm(xg - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+def test_cg_with_amg_on_an_spd_system(gpu_ctx):
+    """Block CG (USER-REAXC-T defaults) with the AMG cycle as preconditioner: lattice Laplacian + I is SPD and the
+    block Gauss-Seidel cycle is symmetric (same pre and post smoother)."""
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.LATTICE), singular=orc.NOT_SINGULAR)
+    rp, ci, val, b = pr.poisson()
+    val = val.copy()
+    for i in range(pr.n):
+        val[rp[i]:rp[i + 1]][ci[rp[i]:rp[i + 1]] == i] += 1.0
+    b = np.cos(pr.parts["x"][:pr.n, 0]) + 0.3
+    kw = dict(theta=0.02, block=128, coarse_max=32)
+    prm_o, prm_g = orc.SolverParams(solver_type=1, tol=1e-8), hip.SolverParams(solver_type=1, tol=1e-8)
+    xo, io_, _ = orc.solve(rp, ci, val, b, prec="amg", amg=orc.AMG(rp, ci, val, **kw), params=prm_o)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    xg = np.zeros(pr.n)
+    info = hip.solve(gpu_ctx, A, b.copy(), xg, prec=hip.PrecondAMG(gpu_ctx, A, params=hip.AmgParams(**kw)), params=prm_g)
+    assert info.converged == 1 and io_.converged == 1 and abs(info.iters - io_.iters) <= 1
+    assert np.linalg.norm(xg - xo) <= 1e-6 * np.linalg.norm(xo)
