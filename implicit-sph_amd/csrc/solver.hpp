@@ -121,8 +121,8 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
   const int grid = spmv_grid(S.nslices, &nbp);
   // AMG transfer / coarse operators are small or have very long rows: the window tables do not pay there
   const bool c16 = !A->local && sell_cols16(ctx, S);
-  size_t slot;
-  ISPH_CHECK(profile_begin(ctx, &slot));
+  size_t slot = (size_t)-1;
+  if (!A->local) ISPH_CHECK(profile_begin(ctx, &slot));  // the SpMV statistics are those of the caller's operator only
   if (nvec) {
     ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
     if (c16)
