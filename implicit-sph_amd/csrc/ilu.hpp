@@ -49,6 +49,8 @@ namespace isph {
 // entries of row blo+t (A rows are column-sorted, lane==row reads are
 // coalesced), a block scan places the rows back to back inside the block's
 // region, then every thread copies its entries.
+constexpr int kExtChunk = 4;  // entries of a row staged per round (LDS: 16 waves x 64 rows x 4 x 12 B = 48 KB)
+
 __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *__restrict__ rowlen,
                                                       const long long *__restrict__ slice_off,
                                                       const int *__restrict__ scol, const double *__restrict__ sval,
@@ -56,6 +58,10 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
                                                       double *__restrict__ fval, int *__restrict__ flen,
                                                       int *__restrict__ fdiag, int *__restrict__ err) {
   __shared__ int wsum[16];
+  __shared__ int stage_col[16][64][kExtChunk];
+  __shared__ double stage_val[16][64][kExtChunk];
+  __shared__ int stage_cnt[16][64];
+  __shared__ long long stage_start[16][64];
   const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n);
   const int t = threadIdx.x, i = blo + t;
   const bool active = i < bhi;
@@ -90,17 +96,45 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
     flen[i] = cnt;
     fdiag[i] = dg;
     if (dg < 0) atomicOr(err, 1);  // structurally missing diagonal
-    long long q = start;
-    for (int k = 0; k < len; ++k) {
-      const long long p = sell_pos(off, lane, k);
+  }
+  // copy: a lane walks its own row in A (coalesced across the wave), but the row-major destination is written by
+  // the wave together -- kExtChunk entries of every row are staged in LDS, then kExtChunk consecutive lanes write
+  // one row's piece (64-B / 32-B segments instead of 64 scattered 8-B stores per instruction)
+  const int wv = t >> 6, ln = t & 63;
+  int *scnt = &stage_cnt[wv][0];
+  long long *sstart = &stage_start[wv][0];
+  sstart[ln] = start;
+  int kpos = 0, done = 0;
+  const int rounds = (wave_max_i32(cnt) + kExtChunk - 1) / kExtChunk;
+  for (int r = 0; r < rounds; ++r) {
+    int got = 0;
+    while (got < kExtChunk && kpos < len) {
+      const long long p = sell_pos(off, lane, kpos);
       const int c = scol[p];
       if (c >= blo && c < bhi) {
-        fcol[q] = c;
-        fval[q] = sval[p];
-        ++q;
+        stage_col[wv][ln][got] = c;
+        stage_val[wv][ln][got] = sval[p];
+        ++got;
+      }
+      ++kpos;
+    }
+    scnt[ln] = got;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < kExtChunk; ++it) {
+      const int e = ln + 64 * it, row = e / kExtChunk, slot = e % kExtChunk;
+      if (slot < scnt[row]) {
+        const long long q = sstart[row] + (long long)r * kExtChunk + slot;
+        fcol[q] = stage_col[wv][row][slot];
+        fval[q] = stage_val[wv][row][slot];
       }
     }
+    done += got;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
+  (void)done;
 }
 
 // ---------------------------------------------------------------------------
