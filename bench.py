@@ -108,7 +108,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one non-default stream for torch's own kernels AND the library: every producer/consumer pair is stream-ordered
+    # (handing the library the legacy default stream would make it create a private non-blocking one)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
 
     if world > 1:
         import torch.distributed as td
