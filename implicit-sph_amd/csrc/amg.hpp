@@ -117,23 +117,30 @@ __global__ __launch_bounds__(256) void k_amg_diag(int n, const int *__restrict__
   if (lane == 0) dg[i] = any ? d : 1.0;
 }
 
-__global__ __launch_bounds__(256) void k_mis_init(int n, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                  const double *__restrict__ v, const double *__restrict__ dg, double th2,
+// sc[p] = column of entry p when it is a strong off-diagonal coupling, -1 otherwise: the ~30 graph sweeps of the
+// aggregation then read 4 B per entry instead of column + value + two diagonal gathers
+__global__ void k_strong_cols(int n, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ v,
+                              const double *__restrict__ dg, double th2, int *__restrict__ sc) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+    const int j = ci[p];
+    sc[p] = AMG_STRONG(v[p], i, j) ? j : -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mis_init(int n, const int *__restrict__ rp, const int *__restrict__ sc,
                                                   unsigned long long *__restrict__ key) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   bool strong = false;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
-    const int j = ci[p];
-    strong |= AMG_STRONG(v[p], i, j);
-  }
+  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) strong |= sc[p] >= 0;
   const bool any_strong = __ballot(strong) != 0;  // every lane takes part in the vote
   if (lane == 0) key[i] = amg_key(any_strong ? AMG_UNDECIDED : AMG_COVERED, i);
 }
 
 // out[i] = max(in[i], max over strong neighbours in[j])
-__global__ __launch_bounds__(256) void k_mis_max(int n, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                 const double *__restrict__ v, const double *__restrict__ dg, double th2,
+__global__ __launch_bounds__(256) void k_mis_max(int n, const int *__restrict__ rp, const int *__restrict__ sc,
                                                  const unsigned long long *__restrict__ in,
                                                  unsigned long long *__restrict__ out,
                                                  const unsigned long long *__restrict__ only_undecided) {
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256) void k_mis_max(int n, const int *__restrict__ 
   if (only_undecided && (only_undecided[i] >> 62) != AMG_UNDECIDED) return;
   unsigned long long m = in[i];
   for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
-    const int j = ci[p];
-    if (AMG_STRONG(v[p], i, j)) { const unsigned long long kj = in[j]; m = kj > m ? kj : m; }
+    const int j = sc[p];
+    if (j >= 0) { const unsigned long long kj = in[j]; m = kj > m ? kj : m; }
   }
   m = wave_max_u64(m);
   if (lane == 0) out[i] = m;
@@ -169,8 +176,7 @@ __global__ void k_flag_roots(int n, const unsigned long long *__restrict__ key, 
 }
 
 // pass 1: roots take their scan id, a non-root takes the id of the first strong neighbour that is a root
-__global__ __launch_bounds__(256) void k_agg_pass1(int n, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                   const double *__restrict__ v, const double *__restrict__ dg, double th2,
+__global__ __launch_bounds__(256) void k_agg_pass1(int n, const int *__restrict__ rp, const int *__restrict__ sc,
                                                    const unsigned long long *__restrict__ key,
                                                    const int *__restrict__ rootid, int *__restrict__ a1) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -178,17 +184,16 @@ __global__ __launch_bounds__(256) void k_agg_pass1(int n, const int *__restrict_
   if ((key[i] >> 62) == AMG_ROOT) { if (lane == 0) a1[i] = rootid[i]; return; }
   int best = 0x7fffffff;
   for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
-    const int j = ci[p];
-    if (AMG_STRONG(v[p], i, j) && (key[j] >> 62) == AMG_ROOT && p < best) best = p;
+    const int j = sc[p];
+    if (j >= 0 && (key[j] >> 62) == AMG_ROOT && p < best) best = p;
   }
   best = wave_min_i32(best);
-  if (lane == 0) a1[i] = best == 0x7fffffff ? -1 : rootid[ci[best]];
+  if (lane == 0) a1[i] = best == 0x7fffffff ? -1 : rootid[sc[best]];
 }
 
 // pass 2: the rest joins the pass-1 neighbour it is most strongly coupled to (ties: first in the row)
-__global__ __launch_bounds__(256) void k_agg_pass2(int n, const int *__restrict__ rp, const int *__restrict__ ci,
-                                                   const double *__restrict__ v, const double *__restrict__ dg, double th2,
-                                                   const int *__restrict__ a1, int *__restrict__ agg,
+__global__ __launch_bounds__(256) void k_agg_pass2(int n, const int *__restrict__ rp, const int *__restrict__ sc,
+                                                   const double *__restrict__ v, const int *__restrict__ a1, int *__restrict__ agg,
                                                    int *__restrict__ leftover) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(256) void k_agg_pass2(int n, const int *__restrict_
   int bp = 0x7fffffff;
   bool strong = false;
   for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
-    const int j = ci[p];
-    if (!AMG_STRONG(v[p], i, j)) continue;
+    const int j = sc[p];
+    if (j < 0) continue;
     strong = true;
     if (a1[j] < 0) continue;
     const double w = fabs(v[p]);
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void k_agg_pass2(int n, const int *__restrict_
   const int pbest = wave_min_i32((bw == wmax && wmax >= 0.0) ? bp : 0x7fffffff);
   const bool any_strong = __ballot(strong) != 0;
   if (lane == 0) {
-    const int a = pbest == 0x7fffffff ? -1 : a1[ci[pbest]];
+    const int a = pbest == 0x7fffffff ? -1 : a1[sc[pbest]];
     agg[i] = a;
     leftover[i] = (a < 0 && any_strong) ? 1 : 0;  // unsymmetric patterns only: becomes a singleton (pass 3)
   }
@@ -603,8 +608,9 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   const int n = A.n;
   const double th2 = theta * theta;
   DevBuf<unsigned long long> key, t1, t2;
-  DevBuf<int> flag, id, a1, cnt;
+  DevBuf<int> flag, id, a1, cnt, scb;
   int rc = key.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = scb.reserve((size_t)(A.nnz > 0 ? A.nnz : 1));
   if (rc == ISPH_SUCCESS) rc = t1.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = t2.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = flag.reserve((size_t)n + 1);
@@ -616,12 +622,13 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   const int *rp = A.rp.p, *ci = A.ci.p;
   const double *v = A.v.p;
   if (rc == ISPH_SUCCESS) {
-    hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, key.p);
+    hipLaunchKernelGGL(k_strong_cols, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, scb.p);
+    hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p, key.p);
     for (int round = 0; round < 1000 && rc == ISPH_SUCCESS; ++round) {
       if (hipMemsetAsync(cnt.p, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
-      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
+      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
                          (const unsigned long long *)key.p, t1.p, (const unsigned long long *)nullptr);
-      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
+      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
                          (const unsigned long long *)t1.p, t2.p, (const unsigned long long *)key.p);
       hipLaunchKernelGGL(k_mis_decide, dim3(gt), dim3(kBlock), 0, ctx->stream, n, key.p, (const unsigned long long *)t2.p, cnt.p);
       int und = 0;
@@ -638,10 +645,10 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, flag.p, id.p, n + 1, tmp);
   if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, id.p + n, &nroot);
   if (rc == ISPH_SUCCESS) {
-    hipLaunchKernelGGL(k_agg_pass1, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2,
+    hipLaunchKernelGGL(k_agg_pass1, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
                        (const unsigned long long *)key.p, (const int *)id.p, a1.p);
-    hipLaunchKernelGGL(k_agg_pass2, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, (const int *)a1.p, L->agg.p,
-                       flag.p);
+    hipLaunchKernelGGL(k_agg_pass2, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p, v, (const int *)a1.p,
+                       L->agg.p, flag.p);
     rc = amg_scan(ctx, flag.p, id.p, n + 1, tmp);
   }
   if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, id.p + n, &nleft);
@@ -651,7 +658,7 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
                        L->agg.p);
   if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("aggregation kernels failed", __FILE__, __LINE__);
   *nagg_out = nroot + nleft;
-  key.release(); t1.release(); t2.release(); flag.release(); id.release(); a1.release(); cnt.release();
+  key.release(); t1.release(); t2.release(); flag.release(); id.release(); a1.release(); cnt.release(); scb.release();
   return rc;
 }
 
