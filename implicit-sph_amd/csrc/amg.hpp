@@ -10,7 +10,7 @@
 //   * aggregate roots = distance-2 maximal independent set, synchronous rounds with hashed priorities
 //     (Bell/Dalton/Olson 2012) instead of ML's sequential greedy sweep: same "root + all neighbours" aggregates;
 //   * Gauss-Seidel local to blocks of `block` rows (ML: local to the processor), one residual per sweep:
-//     x += M_B^-1 (b - A x), M_B = blockdiag[(D+L_B) D^-1 (D+U_B)], run through the ILU chunk stream (k_sgs_fill);
+//     x += M_B^-1 (b - A x), M_B = blockdiag[(D+L_B) D^-1 (D+U_B)], run through the ILU chunk stream (k_ilu_schedule in Gauss-Seidel mode);
 //   * damping from rho = ||D^-1 A||_inf ("eigen-analysis: type" Anorm).
 // Set-up kernels work on device CSR copies, one wave per row (rows hold ~100 entries on the fine level); the
 // cycle itself uses the SELL SpMV and the chunk-stream triangular solves of the rest of the library.

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        const int *__restrict__ fdiag, double *__restrict__ sv,
                                                        unsigned *__restrict__ sc, int *__restrict__ fdst,
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
-                                                       int ccap, int capf, int slack, int *__restrict__ err) {
+                                                       int ccap, int capf, int slack, int *__restrict__ err,
+                                                       const double *__restrict__ sgs_fval,
+                                                       const double *__restrict__ sgs_dinv) {
   extern __shared__ int lds_i[];
   int *levL = lds_i;             // [B] level of every row in the L solve
   int *levU = levL + B;          // [B] ... in the U solve
@@ -358,8 +360,11 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                  (q == g - 1 ? (1u << kTailShift) : 0u) | ((unsigned)t << kRowShift);
           if (e < ndep) {
             const long long slot = rp + d0 + e;
-            sc[idx] = (unsigned)(fcol[slot] - blo) | flags;
+            const int cj = fcol[slot];
+            sc[idx] = (unsigned)(cj - blo) | flags;
             fdst[slot] = (int)idx;
+            // Gauss-Seidel mode: the stream values are A's own entries (L part scaled by the column's pivot)
+            if (sgs_dinv) sv[idx] = dir == 0 ? sgs_fval[slot] * sgs_dinv[cj] : sgs_fval[slot];
           } else {
             sc[idx] = flags;
             sv[idx] = 0.0;
@@ -526,29 +531,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
 // Block-local symmetric Gauss-Seidel in the same stream form (no factorisation): with
 // M_B = (D+L_B) D^-1 (D+U_B),  M_B^-1 r = (D+U_B)^-1 [ D (D+L_B)^-1 r ]  and  y = D (D+L_B)^-1 r  solves the
 // unit-lower system  y_i = r_i - sum_j (a_ij / a_jj) y_j,  so the "L factor" is a_ij / a_jj, the "U factor" a_ij
-// and the pivots a_ii.  Used as the AMG smoother (amg.hpp).
+// and the pivots a_ii: k_sgs_pivots + the sgs_* arguments of k_ilu_schedule.  Used as the AMG smoother (amg.hpp).
 __global__ void k_sgs_pivots(int n, const long long *__restrict__ frp, const double *__restrict__ fval,
                              const int *__restrict__ fdiag, double *__restrict__ dinv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dinv[i] = 1.0 / fval[frp[i] + fdiag[i]];
 }
-__global__ void k_sgs_fill(int n, const long long *__restrict__ frp, const int *__restrict__ fcol,
-                           const double *__restrict__ fval, const int *__restrict__ flen,
-                           const int *__restrict__ fdiag, const int *__restrict__ fdst, double *__restrict__ sv,
-                           const double *__restrict__ dinv) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const long long rp = frp[i];
-  const int len = flen[i], dg = fdiag[i];
-  for (int s = 0; s < len; ++s) {
-    const int d = fdst[rp + s];
-    if (d < 0) continue;
-    double a = fval[rp + s];
-    if (s < dg) a *= dinv[fcol[rp + s]];
-    sv[d] = a;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // z = U^-1 D^-1 L^-1 r : one wave per block streams the block's chunk list.
 // LDS per wave: y[B] and the block's reciprocal pivots.  kPrefetch chunks (values + words) are kept in flight.
@@ -706,6 +694,9 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       hipLaunchKernelGGL(k_ilu_extract, dim3(F->nblocks), dim3(block_size), 0, ctx->stream, S.nrow, block_size,
                          S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, F->frp.p, F->fcol.p, F->fval.p, F->flen.p,
                          F->fdiag.p, F->err.p);
+      if (sgs)  // pivots first: the schedule writes the Gauss-Seidel stream values itself
+        hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
+                           F->fval.p, F->fdiag.p, F->dinv.p);
       const size_t lds_s = sizeof(int) * (13 * Bz + 10) + sizeof(long long) * Bz;
       const int ccap = 0;  // (kept in the signature: the level walk no longer caches columns in LDS)
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -714,7 +705,9 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
         hipLaunchKernelGGL(k_ilu_schedule, dim3(F->nblocks), dim3(block_size), lds_s, ctx->stream, S.nrow, block_size,
                            S.slice_off.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->fdst.p,
-                           F->blkinfo.p, F->llev.p, ccap, F->capf, F->slack, F->err.p);
+                           F->blkinfo.p, F->llev.p, ccap, F->capf, F->slack, F->err.p,
+                           sgs ? (const double *)F->fval.p : (const double *)nullptr,
+                           sgs ? (const double *)F->dinv.p : (const double *)nullptr);
         // the factor kernel must not run on a partial schedule: check now (one sync per build)
         bool overflow = false;
         rc = ilu_check_err(ctx, F, "ILU extract/schedule kernel failed", attempt == 0 ? &overflow : nullptr);
@@ -726,11 +719,7 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       }
     }
     if (rc == ISPH_SUCCESS && sgs) {
-      hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
-                         F->fval.p, F->fdiag.p, F->dinv.p);
-      hipLaunchKernelGGL(k_sgs_fill, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
-                         F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->sv.p, (const double *)F->dinv.p);
-      if (hipGetLastError() != hipSuccess) rc = fail("SGS fill launch failed", __FILE__, __LINE__);
+      // nothing left to do: k_ilu_schedule filled the stream
     } else if (rc == ISPH_SUCCESS) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_factor<kIluWaves>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess)
