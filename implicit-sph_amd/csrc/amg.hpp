@@ -90,17 +90,48 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 // (threshold 0: every non-zero off-diagonal entry is strong -- the diagonal gathers are skipped)
 #define AMG_STRONG(val, i, j) ((j) < n && (j) != (i) && (th2 == 0.0 ? (val) != 0.0 : (val) * (val) > th2 * fabs(dg[i] * dg[j])))
 
-__global__ void k_sell_to_csr_i32(int nrow, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
-                                  const int *__restrict__ scol, const double *__restrict__ sval,
-                                  const int *__restrict__ rowptr, int *__restrict__ colidx, double *__restrict__ cval) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= nrow) return;
-  const long long off = slice_off[row >> 6];
-  const int lane = row & 63, beg = rowptr[row];
-  for (int k = 0; k < rowlen[row]; ++k) {
-    const long long p = sell_pos(off, lane, k);
-    colidx[beg + k] = scol[p];
-    cval[beg + k] = sval[p];
+// SELL -> CSR, one wave per slice: a lane reads its own row (coalesced across the wave), kCsrChunk entries per
+// round are staged in LDS and kCsrChunk consecutive lanes write one row's piece of the row-major destination
+constexpr int kCsrChunk = 8;
+__global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__restrict__ rowlen,
+                                                         const long long *__restrict__ slice_off,
+                                                         const int *__restrict__ scol, const double *__restrict__ sval,
+                                                         const int *__restrict__ rowptr, int *__restrict__ colidx,
+                                                         double *__restrict__ cval) {
+  __shared__ int stc[4][64][kCsrChunk];
+  __shared__ double stv[4][64][kCsrChunk];
+  __shared__ int slen[4][64], sbeg[4][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * 4 + wv;
+  const int row = slice * 64 + lane;
+  if (slice * 64 >= nrow) return;
+  const long long off = slice_off[slice];
+  const int len = row < nrow ? rowlen[row] : 0;
+  slen[wv][lane] = len;
+  sbeg[wv][lane] = row < nrow ? rowptr[row] : 0;
+  const int rounds = (wave_max_i32(len) + kCsrChunk - 1) / kCsrChunk;
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int u = 0; u < kCsrChunk; ++u) {
+      const int k = r * kCsrChunk + u;
+      if (k < len) {
+        const long long p = sell_pos(off, lane, k);
+        stc[wv][lane][u] = scol[p];
+        stv[wv][lane][u] = sval[p];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < kCsrChunk; ++it) {
+      const int e = lane + 64 * it, rr = e / kCsrChunk, u = e % kCsrChunk, k = r * kCsrChunk + u;
+      if (k < slen[wv][rr]) {
+        colidx[sbeg[wv][rr] + k] = stc[wv][rr][u];
+        cval[sbeg[wv][rr] + k] = stv[wv][rr][u];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -504,7 +535,7 @@ inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char>
   ISPH_CHECK_HIP(hipMemsetAsync(len1.p + S.nrow, 0, sizeof(int), ctx->stream));
   int rc = amg_scan(ctx, len1.p, A.rp.p, S.nrow + 1, tmp);
   if (rc == ISPH_SUCCESS && S.nrow > 0)
-    hipLaunchKernelGGL(k_sell_to_csr_i32, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow,
+    hipLaunchKernelGGL(k_sell_to_csr_i32, dim3((S.nslices + 3) / 4), dim3(256), 0, ctx->stream, S.nrow,
                        S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, (const int *)A.rp.p, A.ci.p, A.v.p);
   if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("SELL->CSR failed", __FILE__, __LINE__);
   len1.release();
