@@ -49,7 +49,7 @@ namespace isph {
 // entries of row blo+t (A rows are column-sorted, lane==row reads are
 // coalesced), a block scan places the rows back to back inside the block's
 // region, then every thread copies its entries.
-constexpr int kExtChunk = 4;  // entries of a row staged per round (LDS: 16 waves x 64 rows x 4 x 12 B = 48 KB)
+constexpr int kExtChunk = 8;  // entries of a row staged per round (dynamic LDS: waves x 64 rows x 8 x 12 B)
 
 __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *__restrict__ rowlen,
                                                       const long long *__restrict__ slice_off,
@@ -58,10 +58,13 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
                                                       double *__restrict__ fval, int *__restrict__ flen,
                                                       int *__restrict__ fdiag, int *__restrict__ err) {
   __shared__ int wsum[16];
-  __shared__ int stage_col[16][64][kExtChunk];
-  __shared__ double stage_val[16][64][kExtChunk];
-  __shared__ int stage_cnt[16][64];
-  __shared__ long long stage_start[16][64];
+  extern __shared__ double ext_lds[];
+  const int nwv = blockDim.x >> 6;
+  double (*stage_val)[64][kExtChunk] = reinterpret_cast<double (*)[64][kExtChunk]>(ext_lds);
+  long long (*stage_start)[64] = reinterpret_cast<long long (*)[64]>(ext_lds + (size_t)nwv * 64 * kExtChunk);
+  int (*stage_col)[64][kExtChunk] = reinterpret_cast<int (*)[64][kExtChunk]>(ext_lds + (size_t)nwv * 64 * (kExtChunk + 1));
+  int (*stage_cnt)[64] = reinterpret_cast<int (*)[64]>(reinterpret_cast<int *>(ext_lds + (size_t)nwv * 64 * (kExtChunk + 1)) +
+                                                       (size_t)nwv * 64 * kExtChunk);
   const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n);
   const int t = threadIdx.x, i = blo + t;
   const bool active = i < bhi;
@@ -691,7 +694,11 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
     if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
       rc = fail("memset failed", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) {
-      hipLaunchKernelGGL(k_ilu_extract, dim3(F->nblocks), dim3(block_size), 0, ctx->stream, S.nrow, block_size,
+      const size_t lds_e = (size_t)(block_size / 64) * 64 * ((kExtChunk + 1) * 8 + (kExtChunk + 1) * 4);
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_e) != hipSuccess)
+        rc = fail("LDS attribute failed", __FILE__, __LINE__);
+      hipLaunchKernelGGL(k_ilu_extract, dim3(F->nblocks), dim3(block_size), lds_e, ctx->stream, S.nrow, block_size,
                          S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, F->frp.p, F->fcol.p, F->fval.p, F->flen.p,
                          F->fdiag.p, F->err.p);
       if (sgs)  // pivots first: the schedule writes the Gauss-Seidel stream values itself
