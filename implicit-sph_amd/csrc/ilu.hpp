@@ -749,9 +749,8 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
   constexpr int WV = 4;
   const size_t lds = sizeof(double) * 2 * (size_t)F->B * WV;
   static const int pf = []() { const char *e = getenv("ISPH_ILU_PREFETCH"); return e ? atoi(e) : kPrefetch; }();
-  static const int dbg_div = []() { const char *e = getenv("ISPH_ILU_DBG_DIV"); return e ? atoi(e) : 1; }();
 #define ISPH_ILU_LAUNCH(PF)                                                                                             \
-  hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks / dbg_div + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream,   \
+  hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream,   \
                      F->n, F->B, F->nblocks, F->S->slice_off.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p, \
                      F->dinv.p, r, z, F->capf, F->slack)
   if (pf == 12) ISPH_ILU_LAUNCH(12);
