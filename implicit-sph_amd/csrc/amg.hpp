@@ -602,17 +602,29 @@ inline int amg_spgemm_t(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C, De
   return rc;
 }
 
-// A*P: rows see few distinct aggregates, so a small table is tried first (clearing the table is most of the cost)
-inline int amg_spgemm_ap(isph_ctx *ctx, const DCsr &A, const DCsr &P, DCsr &AP, DevBuf<char> &tmp, int *derr) {
+// A*P: rows see few distinct aggregates, so small tables are tried first (clearing the table is most of the cost);
+// an overflow of the table is reported by the kernel and the next size is used
+template <int TABLE>
+inline int amg_spgemm_try(isph_ctx *ctx, const DCsr &A, const DCsr &P, DCsr &AP, DevBuf<char> &tmp, int *derr, bool *overflow) {
   int before = 0, after = 0;
   ISPH_CHECK(amg_read_int(ctx, derr, &before));
-  ISPH_CHECK((amg_spgemm_t<1024, 64>(ctx, A, P, AP, tmp, derr)));
+  ISPH_CHECK((amg_spgemm_t<TABLE, 64>(ctx, A, P, AP, tmp, derr)));
   ISPH_CHECK(amg_read_int(ctx, derr, &after));
-  if (!(after & 2) || (before & 2)) return ISPH_SUCCESS;
-  after &= ~2;  // the small table overflowed: clear that flag and redo with the large one
-  ISPH_CHECK_HIP(hipMemcpyAsync(derr, &after, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  AP.release();
+  *overflow = (after & 2) && !(before & 2);
+  if (*overflow) {
+    after &= ~2;
+    ISPH_CHECK_HIP(hipMemcpyAsync(derr, &after, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    AP.release();
+  }
+  return ISPH_SUCCESS;
+}
+inline int amg_spgemm_ap(isph_ctx *ctx, const DCsr &A, const DCsr &P, DCsr &AP, DevBuf<char> &tmp, int *derr) {
+  bool overflow = false;
+  ISPH_CHECK(amg_spgemm_try<256>(ctx, A, P, AP, tmp, derr, &overflow));
+  if (!overflow) return ISPH_SUCCESS;
+  ISPH_CHECK(amg_spgemm_try<1024>(ctx, A, P, AP, tmp, derr, &overflow));
+  if (!overflow) return ISPH_SUCCESS;
   return amg_spgemm_t<4096, 64>(ctx, A, P, AP, tmp, derr);
 }
 
