@@ -24,6 +24,7 @@ namespace isph {
 
 int sell_finalize_offsets(isph_ctx *ctx, Sell &S);  // isph_capi.hip
 int sell_sort_rows(isph_ctx *ctx, Sell &S);         // isph_capi.hip
+int sell_set_wmax(isph_ctx *ctx, Sell &S);          // isph_capi.hip
 
 constexpr double kEps = 1.0e-24;  // ISPH_EPSILON, ref: macrodef.h:6
 enum { KIND_FLUID = 99, KIND_SOLID = 12, KIND_ALL = 127 };
@@ -41,6 +42,9 @@ struct AsmTables {  // small per-type tables, device resident
   // kernels read it with coalesced 256-B wave loads instead of 64 scattered lines
   const long long *noff;
   const int *nt;
+  // 1: every row's neighbours are ordered by matrix column (k_neigh_sort), so the row kernels can emit column-sorted
+  // rows directly (the diagonal takes its slot on the way) and the SELL row sort is skipped
+  int sorted;
 };
 
 __device__ __forceinline__ int neigh_at(const AsmTables &T, int i, int k) {
@@ -51,6 +55,31 @@ __device__ __forceinline__ int neigh_at(const AsmTables &T, int i, int k) {
 __global__ void k_numneigh(int n, const int *__restrict__ nptr, int *__restrict__ len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) len[i] = nptr[i + 1] - nptr[i];
+}
+
+// Orders every row's neighbour ids by their matrix column (stable: equal columns -- periodic images -- keep their
+// list order).  One wave per row, keys in LDS, rank by counting.
+constexpr int kNeighSortCap = 1024;
+__global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const int *__restrict__ nptr, const int *__restrict__ nidx,
+                                                       const int *__restrict__ colmap, int *__restrict__ out) {
+  __shared__ int keys[kBlock / 64][kNeighSortCap];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (kBlock / 64) + wave;
+  if (row >= n) return;
+  const int jb = nptr[row], len = nptr[row + 1] - jb;
+  int *kw = keys[wave];
+  for (int k = lane; k < len; k += 64) kw[k] = colmap[nidx[jb + k]];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k < len; k += 64) {
+    const int c = kw[k];
+    int rank = 0;
+    for (int q = 0; q < len; ++q) {
+      const int cq = kw[q];
+      rank += (cq < c) || (cq == c && q < k);
+    }
+    out[jb + rank] = nidx[jb + k];
+  }
 }
 
 // CSR neighbour list -> lane-interleaved slices.  One wave per slice; 64 rows x 16 ids are staged
@@ -391,7 +420,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   const double alpha = -a.dt;
   const double mi = a.invrho[i];
   const int jb = a.nptr[i], je = a.nptr[i + 1];
-  int cnt = 0;
+  int cnt = 0, pdiag = -1;  // pdiag: slot of the diagonal (sorted lists: where the row's own column belongs)
+  const int ci_own = a.colmap[i];
   double diag_final;
   double bi = 0.0;
 
@@ -427,8 +457,10 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
             v += (gitmp * vjtmp) * alpha * nrm[k2];
           }
         }
+        const int cj = a.colmap[j];
+        if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
         const long long p = sell_pos(off, lane, cnt++);
-        scol[p] = a.colmap[j];
+        scol[p] = cj;
         sval[p] = v;
       }
     }
@@ -520,8 +552,10 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       double v = -aij;
       v -= tmp;
       diag2 += tmp;
+      const int cj = a.colmap[j];
+      if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
       const long long p = sell_pos(off, lane, cnt++);
-      scol[p] = a.colmap[j];
+      scol[p] = cj;
       sval[p] = v * alpha;
     }
     diag_final = (diag1 + diag2) * alpha;
@@ -534,7 +568,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
     bi = 0.0;
   } else if (a.pin_enabled && *a.first_fluid == i) {  // modifySingularMatrix, once, rank 0
     if (a.singular_mode == 2) {
-      for (int k = 0; k < cnt; ++k) sval[sell_pos(off, lane, k)] = 0.0;
+      for (int k = 0; k < cnt; ++k)
+        if (k != pdiag) sval[sell_pos(off, lane, k)] = 0.0;
       diag_final = -1.0;
       bi = 0.0;
     } else if (a.singular_mode == 3) {
@@ -542,8 +577,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
     }
   }
   {
-    const long long p = sell_pos(off, lane, cnt++);
-    scol[p] = a.colmap[i];
+    if (pdiag < 0) pdiag = cnt++;
+    const long long p = sell_pos(off, lane, pdiag);
+    scol[p] = ci_own;
     sval[p] = diag_final;
   }
   for (int k = cnt; k < w; ++k) {
@@ -594,7 +630,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
   const double invrho = 1.0 / a.rho[i];
   const double mi = a.nu[i] * a.rho[i];
   const int jb = a.nptr[i], je = a.nptr[i + 1];
-  int cnt = 0;
+  int cnt = 0, pdiag = -1;
+  const int ci_own = a.colmap[i];
   double diag_final;
   double wv[3] = {0, 0, 0}, gp[3] = {0, 0, 0};
 
@@ -603,8 +640,10 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       const int j = neigh_at(T, i, jj - jb);
       double rij[3];
       if (pair_rsq(dim, a.x, i, j, rij) < T.cutsq[it * nt1 + a.type[j]]) {
+        const int cj = a.colmap[j];
+        if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
         const long long p = sell_pos(off, lane, cnt++);
-        scol[p] = a.colmap[j];
+        scol[p] = cj;
         sval[p] = 0.0;
       }
     }
@@ -701,8 +740,10 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       diag2 += tmp;
       const double aval = (v * alpha) * invrho;  // SumInto(alpha) then LeftScale(1/rho)
       for (int k = 0; k < dim; ++k) wv[k] += aval * a.v[3 * (size_t)j + k];
+      const int cj = a.colmap[j];
+      if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
       const long long p = sell_pos(off, lane, cnt++);
-      scol[p] = a.colmap[j];
+      scol[p] = cj;
       sval[p] = aval * (-a.theta);
     }
     const double dval = ((diag1 + diag2) * alpha) * invrho;
@@ -710,8 +751,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
     diag_final = 1.0 + dval * (-a.theta);
   }
   {
-    const long long p = sell_pos(off, lane, cnt++);
-    scol[p] = a.colmap[i];
+    if (pdiag < 0) pdiag = cnt++;
+    const long long p = sell_pos(off, lane, pdiag);
+    scol[p] = ci_own;
     sval[p] = diag_final;
   }
   for (int k = cnt; k < w; ++k) {
@@ -776,12 +818,13 @@ struct StagedParticles {
 
 struct NeighEll {
   DevBuf<long long> off;
-  DevBuf<int> idx, len;
-  void release() { off.release(); idx.release(); len.release(); }
+  DevBuf<int> idx, len, sorted;
+  void release() { off.release(); idx.release(); len.release(); sorted.release(); }
 };
 
 // builds the lane-interleaved neighbour list and hooks it into T
-inline int build_neigh_ell(isph_ctx *ctx, int n, const int *dnptr, const int *dnidx, NeighEll &E, AsmTables &T) {
+inline int build_neigh_ell(isph_ctx *ctx, int n, const int *dnptr, const int *dnidx, NeighEll &E, AsmTables &T,
+                           const int *dcolmap = nullptr) {
   const int nslices = (n + kSlice - 1) / kSlice;
   ISPH_CHECK(E.len.reserve((size_t)(n > 0 ? n : 1)));
   ISPH_CHECK(E.off.reserve((size_t)nslices + 1));
@@ -794,6 +837,20 @@ inline int build_neigh_ell(isph_ctx *ctx, int n, const int *dnptr, const int *dn
   ISPH_CHECK_HIP(hipMemcpyAsync(&total, E.off.p + nslices, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   ISPH_CHECK(E.idx.reserve((size_t)(total > 0 ? total : 1)));
+  T.sorted = 0;
+  if (dcolmap) {  // order the lists by matrix column when every row fits the sort's LDS buffer
+    std::vector<long long> so((size_t)nslices + 1);
+    ISPH_CHECK_HIP(hipMemcpyAsync(so.data(), E.off.p, sizeof(long long) * so.size(), hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    long long wmax = 0;
+    for (int s = 0; s < nslices; ++s) wmax = std::max(wmax, (so[(size_t)s + 1] - so[(size_t)s]) >> 6);
+    if (wmax <= kNeighSortCap) {
+      ISPH_CHECK(E.sorted.reserve((size_t)(total > 0 ? total : 1)));
+      hipLaunchKernelGGL(k_neigh_sort, dim3((n + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, dcolmap, E.sorted.p);
+      dnidx = E.sorted.p;
+      T.sorted = 1;
+    }
+  }
   hipLaunchKernelGGL(k_neigh_transpose, dim3((nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, E.off.p,
                      E.idx.p);
   ISPH_CHECK_HIP(hipGetLastError());
@@ -820,7 +877,7 @@ inline int stage_tables(isph_ctx *ctx, const isph_particles *P, StagedParticles 
   ISPH_CHECK(stage(ctx, P->h, nt1 * nt1, 0, S.h, &dh));
   ISPH_CHECK(stage(ctx, P->cutsq, nt1 * nt1, 0, S.cutsq, &dc));
   T.kind = dk; T.h = dh; T.cutsq = dc; T.ntypes = P->ntypes; T.kernel = P->kernel; T.dim = P->dim;
-  T.noff = nullptr; T.nt = nullptr;
+  T.noff = nullptr; T.nt = nullptr; T.sorted = 0;
   std::vector<double> hi(nt1 * nt1), kn(nt1 * nt1), kd(nt1 * nt1);
   for (size_t k = 0; k < nt1 * nt1; ++k) {
     const double hh = P->h[k];
@@ -929,7 +986,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, a.colmap);
   // kinds present: refuse what this build does not restate
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
@@ -981,7 +1038,8 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
             rc = fail("copy failed", __FILE__, __LINE__);
         }
       }
-      if (rc == ISPH_SUCCESS) rc = sell_sort_rows(ctx, M);  // columns ascending, like Epetra after FillComplete
+      // rows come out column-sorted when the neighbour lists were ordered; merged duplicates break that order
+      if (rc == ISPH_SUCCESS) rc = (T.sorted && n > 32768) ? sell_set_wmax(ctx, M) : sell_sort_rows(ctx, M);  // columns ascending, like Epetra after FillComplete
       if (rc == ISPH_SUCCESS && !on_device &&
           hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         rc = fail("copy failed", __FILE__, __LINE__);
@@ -1059,7 +1117,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, a.colmap);
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
       if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);
@@ -1089,7 +1147,8 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
             rc = fail("copy failed", __FILE__, __LINE__);
         }
       }
-      if (rc == ISPH_SUCCESS) rc = sell_sort_rows(ctx, M);
+      // rows come out column-sorted when the neighbour lists were ordered; merged duplicates break that order
+      if (rc == ISPH_SUCCESS) rc = (T.sorted && n > 32768) ? sell_set_wmax(ctx, M) : sell_sort_rows(ctx, M);
       if (rc == ISPH_SUCCESS && !on_device &&
           hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)lda * dim, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         rc = fail("copy failed", __FILE__, __LINE__);

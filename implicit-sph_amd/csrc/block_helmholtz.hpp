@@ -56,19 +56,22 @@ __global__ __launch_bounds__(kBlock) void k_asm_block_helmholtz(AsmTables T, Blo
   const double mi = a.nu[i];
   const int jb0 = a.nptr[i], je = a.nptr[i + 1];
   const int ci_own = a.colmap[i];
-  int cnt = 0;
+  int cnt = 0, pdiag = -1;
 
   if (!(ikind & KIND_FLUID)) {  // solid row: zero row, unit diagonal in the diagonal blocks, b = v
     for (int jj = jb0; jj < je; ++jj) {
       const int j = neigh_at(T, i, jj - jb0);
       double rij[3];
       if (pair_rsq(dim, a.x, i, j, rij) < T.cutsq[it * nt1 + a.type[j]]) {
+        const int cj = a.colmap[j];
+        if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
         const long long p = sell_pos(off, lane, cnt++);
         for (int q = 0; q < d2; ++q)
-          if (A.bval[q]) { A.bcol[q][p] = a.colmap[j]; A.bval[q][p] = 0.0; }
+          if (A.bval[q]) { A.bcol[q][p] = cj; A.bval[q][p] = 0.0; }
       }
     }
-    const long long pd = sell_pos(off, lane, cnt++);
+    if (pdiag < 0) pdiag = cnt++;
+    const long long pd = sell_pos(off, lane, pdiag);
     for (int ib = 0; ib < dim; ++ib)
       for (int jb = 0; jb < dim; ++jb) {
         const int q = ib * dim + jb;
@@ -217,8 +220,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_block_helmholtz(AsmTables T, Blo
       diag2[s] += tmp;
       val[s] = v * alpha;
     }
-    const long long p = sell_pos(off, lane, cnt++);
     const int cj = a.colmap[j];
+    if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
+    const long long p = sell_pos(off, lane, cnt++);
     for (int ib = 0; ib < dim; ++ib)
       for (int jb = 0; jb < dim; ++jb) {
         const int q = ib * dim + jb;
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_block_helmholtz(AsmTables T, Blo
   }
   const double dff = (diag1[0] + diag2[0]) * alpha, dfs = (diag1[1] + diag2[1]) * alpha;
   {
-    const long long p = sell_pos(off, lane, cnt++);
+    if (pdiag < 0) pdiag = cnt++;
+    const long long p = sell_pos(off, lane, pdiag);
     for (int ib = 0; ib < dim; ++ib)
       for (int jb = 0; jb < dim; ++jb) {
         const int q = ib * dim + jb;
@@ -319,7 +324,7 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, a.colmap);
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
       if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);
@@ -378,7 +383,7 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
               rc = fail("copy failed", __FILE__, __LINE__);
           }
         }
-        if (rc == ISPH_SUCCESS) rc = sell_sort_rows(ctx, B);
+        if (rc == ISPH_SUCCESS) rc = (T.sorted && n > 32768) ? sell_set_wmax(ctx, B) : sell_sort_rows(ctx, B);
       }
       if (rc == ISPH_SUCCESS && !on_device &&
           hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)lda * dim, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
