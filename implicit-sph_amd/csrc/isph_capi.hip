@@ -397,8 +397,16 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
   } else if (!strcmp(type, "bjacobi-ilu0")) {
     M->type = 2;
     rc = ilu_create(ctx, A, block_size, &M->ilu);
+  } else if (!strcmp(type, "sa-amg")) {
+    // PrecondWrapper_ML defaults without a null vector; block_size is the Gauss-Seidel block of the fine level.
+    // isph_prec_create_amg takes the full parameter set and the null vector of a singular system.
+    isph_amg_params prm;
+    isph_amg_params_default(&prm);
+    prm.block = block_size;
+    M->type = 3;
+    rc = amg_create(ctx, A, &prm, nullptr, &M->amg);
   } else {
-    rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu0)", __FILE__, __LINE__);
+    rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu0|sa-amg)", __FILE__, __LINE__);
   }
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
   *Mout = M;

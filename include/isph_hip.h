@@ -91,6 +91,8 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
  *   "bjacobi-ilu0"  block-Jacobi, ILU(0) per block == Ifpack
  *                   AdditiveSchwarz<ILU>, "Overlap Level"=0,
  *                   "fact: level-of-fill"=0, one block per `block_size` rows
+ *   "sa-amg"        PrecondWrapper_ML::create() with its default parameters and no null vector
+ *                   (isph_prec_create_amg takes the parameters and the null vector of a singular system)
  * Rebuilt every solve in the reference (solver_lin_belos.h:153,190). */
 int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int block_size,
                      isph_prec **M);
