@@ -205,24 +205,26 @@ __global__ __launch_bounds__(kBlock) void k_dot2(int n, const double *__restrict
 
 // DGKS decision on the device: d[0] = 1 when a second Gram-Schmidt pass is due (|w_new| < dep_tol |w|,
 // dep_tol = 1/sqrt(2), or always when force != 0), else 0
-// dn != NULL: the first projected vector is the unit null vector n; the reference measures |w| after its
-// operator removed that component, so the "old" norm is sqrt(|w|^2 - (w.n)^2)
-__global__ void k_dgks_decide(const double *__restrict__ ww_old, const double *__restrict__ ww_new, int force,
+// DGKS decision on the device: d[0] = 1 when a second Gram-Schmidt pass is due (|w_new| < dep_tol |w|,
+// dep_tol = 1/sqrt(2), or always when force != 0), else 0; d[1] = |w_final|^2.
+// c2[0..nk) are the second-pass coefficients V^T w_new and c2[nk] = |w_new|^2.  With an orthonormal basis
+// |w_new - V c2|^2 = |w_new|^2 - |c2|^2, and after one classical pass |c2| is at round-off level of |w| (far below
+// |w_new| unless the iteration has broken down, where the clamp to 0 reports the breakdown), so the norm after the
+// second pass needs no further reduction / all-reduce.
+// dn != NULL: the first projected vector is the unit null vector n; the reference measures |w| after its operator
+// removed that component, so the "old" norm is sqrt(|w|^2 - (w.n)^2).
+__global__ void k_dgks_decide(const double *__restrict__ ww_old, const double *__restrict__ c2, int nk, int force,
                               double *__restrict__ d, const double *__restrict__ dn) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double old2 = *ww_old;
     if (dn) old2 = fmax(old2 - dn[0] * dn[0], 0.0);
-    d[0] = (force || sqrt(*ww_new) < M_SQRT1_2 * sqrt(old2)) ? 1.0 : 0.0;
+    const double ww_new = c2[nk];
+    const bool second = force || sqrt(ww_new) < M_SQRT1_2 * sqrt(old2);
+    double s = 0.0;
+    for (int k = 0; k < nk; ++k) s += c2[k] * c2[k];
+    d[0] = second ? 1.0 : 0.0;
+    d[1] = second ? fmax(ww_new - s, 0.0) : ww_new;
   }
-}
-
-// y = x / sqrt(*flag != 0 ? *s1 : *s0)   (next Krylov vector from the norm the DGKS branch produced)
-__global__ void k_scale_copy_sel(int n, const double *__restrict__ x, double *__restrict__ y,
-                                 const double *__restrict__ flag, const double *__restrict__ s1,
-                                 const double *__restrict__ s0) {
-  const double a = 1.0 / sqrt(*flag != 0.0 ? *s1 : *s0);
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    y[i] = a * x[i];
 }
 
 // y = a*x  with a = alpha_host * (inv_sqrt ? 1/sqrt(*s) : (s ? *s : 1))

@@ -243,6 +243,7 @@ inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld,
 // V less.  When vnext != NULL the next basis vector w/|w| is formed on the device as well, so the caller can
 // queue the next preconditioner/operator application before it looks at the scalars.
 // Mailbox: c at SC_DOT.., |w|^2 at SC_DOT+nk; c2 at SC_Y.., |w_new|^2 at SC_Y+nk; flag, |w_final|^2 at SC_ORTHO..
+// (|w_final|^2 = |w_new|^2 - |c2|^2 when the second pass runs: see k_dgks_decide)
 enum { SC_ORTHO = SC_MISC + 20 };
 inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long long ld, double *w, int ortho, double *vnext,
                          bool deflate = false) {
@@ -271,16 +272,14 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh2,
                      (const double *)nullptr);
   ISPH_CHECK(allreduce_inplace(ctx, dh2, nk + 1));
-  hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(64), 0, st, (const double *)(dh1 + nk), (const double *)(dh2 + nk),
+  hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(64), 0, st, (const double *)(dh1 + nk), (const double *)dh2, nk,
                      ortho == 1 ? 1 : 0, dor, deflate ? (const double *)dh1 : (const double *)nullptr);
   const int g2 = stream_grid(n);
   hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, dh2, w, ctx->partial.p,
                      (const double *)dor);
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, 1, g2, ctx->partial.p, dor + 1, (const double *)dor);
-  ISPH_CHECK(allreduce_inplace(ctx, dor + 1, 1));
   if (vnext)
-    hipLaunchKernelGGL(k_scale_copy_sel, dim3(stream_grid(n)), dim3(kBlock), 0, st, n, w, vnext, (const double *)dor,
-                       (const double *)(dor + 1), (const double *)(dh2 + nk));
+    hipLaunchKernelGGL(k_scale_copy, dim3(stream_grid(n)), dim3(kBlock), 0, st, n, (const double *)w, vnext, 1.0,
+                       (const double *)(dor + 1), 1);
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
@@ -289,7 +288,8 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
 inline void ortho_collect(const isph_ctx *ctx, int nk, double *h, double *wnorm) {
   const bool second = ctx->hscal[SC_ORTHO] != 0.0;
   for (int k = 0; k < nk; ++k) h[k] = ctx->hscal[SC_DOT + k] + (second ? ctx->hscal[SC_Y + k] : 0.0);
-  *wnorm = std::sqrt(second ? ctx->hscal[SC_ORTHO + 1] : ctx->hscal[SC_Y + nk]);
+  (void)nk;
+  *wnorm = std::sqrt(ctx->hscal[SC_ORTHO + 1]);
 }
 
 // Belos DGKS / ICGS / IMGS for block size 1. h[0..j] coefficients, returns ||w||.
