@@ -213,6 +213,13 @@ def test_tgv2d_known_answer_table_loose():
     assert abs(h["p_norm"] / ref["p_norm"] - 1) < 1e-3 and abs(h["u_norm"] / ref["u_norm"] - 1) < 1e-3
     assert 0.8 < h["p_err"] / ref["p_err"] < 1.25
     assert 0.1 < h["u_err"] / ref["u_err"] < 3.0
+    # N = 32 row of the same table: norms to 1e-3, pressure error within +-40 %, second-order trend between the rows
+    ref32 = _golden("reference_known_answers.json")["conv_taylor_green_vortex_2d_rev390"]["rows"]["32"]
+    h32 = T.run_tgv2d(32, ref32["step"], antisym=True)[-1]
+    assert abs(h32["time"] - ref32["time"]) < 1e-6
+    assert abs(h32["p_norm"] / ref32["p_norm"] - 1) < 1e-3 and abs(h32["u_norm"] / ref32["u_norm"] - 1) < 1e-3
+    assert 0.6 < h32["p_err"] / ref32["p_err"] < 1.6
+    assert 3.0 < h["p_err"] / h32["p_err"] < 6.5          # the table's own ratio is 4.24
 
 
 def test_shift_serial_in_place_and_pre_shift_state_differ_at_second_order():
