@@ -900,6 +900,7 @@ template <class T>
 inline int stage(isph_ctx *ctx, const T *src, size_t n, int on_device, DevBuf<T> &tmp, const T **out) {
   if (!src) { *out = nullptr; return ISPH_SUCCESS; }
   if (on_device) { *out = src; return ISPH_SUCCESS; }
+  ISPH_REQUIRE(!is_device_pointer(src), "device pointer passed with on_device = 0");
   ISPH_CHECK(tmp.reserve(n > 0 ? n : 1));
   ISPH_CHECK_HIP(hipMemcpyAsync(tmp.p, src, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
   *out = tmp.p;

@@ -123,6 +123,15 @@ struct DevBuf {
   }
 };
 
+// true when p is device memory: a caller that says on_device = 0 but hands over a device pointer would make the host
+// dereference it (a page fault that looks like a hang), so the staging helpers refuse such a pointer
+inline bool is_device_pointer(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // plain host memory
+  return at.type == hipMemoryTypeDevice;
+}
+
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kSlice = 64;         // SELL slice height = one wavefront
 constexpr int kBlock = 256;        // 4 waves

@@ -528,15 +528,31 @@ def compute_corrections(ctx, parts, colmap, vfrac, kernel="wendland"):
     return G, Lc
 
 
+def _out_like(dev, ref, shape):
+    """output buffer on the side the inputs live on (device tensors in -> device tensor out)"""
+    if dev:
+        import torch
+        return torch.zeros(shape, dtype=torch.float64, device=ref.device)
+    return np.zeros(shape)
+
+
+def _same_side(dev, *arrays):
+    """every operand of a call must live on the side the particle arrays live on"""
+    for a in arrays:
+        if a is not None and bool(_is_torch(a)) != bool(dev):
+            raise ValueError("mixing host and device operands in one call")
+
+
 def gradient(ctx, parts, colmap, f, vfrac, antisym=True, alpha=1.0, filt=None, Gc=None, kernel="wendland", kinds=None):
     """isph_gradient: scalar field f [nall] -> [nlocal, 3]."""
     keep = []
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
     f = _f64(f)
-    out = np.zeros((int(parts["nlocal"]), 3))
+    _same_side(dev, f)
+    out = _out_like(dev, f, (int(parts["nlocal"]), 3))
     fi, fj = filt if filt is not None else (127, 127)
     _check(lib().isph_gradient(ctx.h, C.byref(pv), int(antisym), _ptr(f), float(alpha), int(filt is not None), fi, fj,
-                               _ptr(out), 0))
+                               _ptr(out), dev))
     return out
 
 
@@ -545,43 +561,57 @@ def divergence(ctx, parts, colmap, f, vfrac, antisym=True, alpha=1.0, filt=None,
     keep = []
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
     f = _f64(f)
-    out = np.zeros(int(parts["nlocal"]))
+    _same_side(dev, f)
+    out = _out_like(dev, f, (int(parts["nlocal"]),))
     fi, fj = filt if filt is not None else (127, 127)
     _check(lib().isph_divergence(ctx.h, C.byref(pv), int(antisym), _ptr(f), float(alpha), int(filt is not None), fi, fj,
-                                 _ptr(out), 0))
+                                 _ptr(out), dev))
     return out
 
 
 def correct_velocity_pressure(ctx, parts, colmap, dt, rho, dp, vstar, p, vfrac, antisym=True, incremental=True, Gc=None,
                               kernel="wendland"):
-    """in-place on vstar [nall,3] and p [nall] (numpy)."""
+    """in-place on vstar [nall,3] and p [nall] (numpy arrays or device tensors, like the particle arrays)."""
     keep = []
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep)
-    _check(lib().isph_correct_velocity_pressure(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(_f64(rho)),
-                                                _ptr(_f64(dp)), _ptr(vstar), _ptr(p), int(incremental), 0))
+    rho, dp = _f64(rho), _f64(dp)
+    _same_side(dev, rho, dp, vstar, p)
+    _check(lib().isph_correct_velocity_pressure(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(rho), _ptr(dp),
+                                                _ptr(vstar), _ptr(p), int(incremental), dev))
 
 
 def advance_begin(ctx, parts, colmap, dt, p, v, vnp1, vfrac, antisym=True, Gc=None, kernel="wendland"):
     keep = []
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep)
-    out = np.zeros(int(parts["nlocal"]))
-    _check(lib().isph_advance_begin(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(_f64(p)), _ptr(_f64(v)),
-                                    _ptr(_f64(vnp1)), _ptr(out), 0))
+    p, v, vnp1 = _f64(p), _f64(v), _f64(vnp1)
+    _same_side(dev, p, v, vnp1)
+    out = _out_like(dev, p, (int(parts["nlocal"]),))
+    _check(lib().isph_advance_begin(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(p), _ptr(v), _ptr(vnp1), _ptr(out),
+                                    dev))
     return out
 
 
 def advance_end(ctx, count, dim, dt, dp, vnp1, p, x, v):
-    """in-place on p [count], x [count,3], v [count,3] (numpy)."""
-    _check(lib().isph_advance_end(ctx.h, int(count), int(dim), float(dt), _ptr(_f64(dp)), _ptr(_f64(vnp1)), _ptr(p),
-                                  _ptr(x), _ptr(v), 0))
+    """in-place on p [count], x [count,3], v [count,3] (all numpy or all device tensors)."""
+    dp, vnp1 = _f64(dp), _f64(vnp1)
+    dev = int(bool(_is_torch(p)))
+    _same_side(dev, dp, vnp1, p, x, v)
+    _check(lib().isph_advance_end(ctx.h, int(count), int(dim), float(dt), _ptr(dp), _ptr(vnp1), _ptr(p), _ptr(x),
+                                  _ptr(v), dev))
 
 
 def compute_shift(ctx, parts, colmap, alpha, shiftcut, nonfluidweight, kernel="wendland", kinds=None):
     """isph_compute_shift -> dr [nlocal, 3]."""
     keep = []
-    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=np.ones(int(parts["nall"])), keep=keep, kinds=kinds)
-    dr = np.zeros((int(parts["nlocal"]), 3))
-    _check(lib().isph_compute_shift(ctx.h, C.byref(pv), float(alpha), float(shiftcut), float(nonfluidweight), _ptr(dr), 0))
+    if _is_torch(parts["x"]):
+        import torch
+        ones = torch.ones(int(parts["nall"]), dtype=torch.float64, device=parts["x"].device)
+    else:
+        ones = np.ones(int(parts["nall"]))
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=ones, keep=keep, kinds=kinds)
+    dr = _out_like(dev, parts["x"], (int(parts["nlocal"]), 3))
+    _check(lib().isph_compute_shift(ctx.h, C.byref(pv), float(alpha), float(shiftcut), float(nonfluidweight), _ptr(dr),
+                                    dev))
     return dr
 
 
@@ -590,7 +620,9 @@ def apply_shift(ctx, parts, colmap, dr, x, v, p, vfrac, antisym=True, fixed=None
     keep = []
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
     fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.int32)
-    _check(lib().isph_apply_shift(ctx.h, C.byref(pv), int(antisym), _ptr(fx), _ptr(_f64(dr)), _ptr(x), _ptr(v), _ptr(p), 0))
+    dr = _f64(dr)
+    _same_side(dev, dr, x, v, p)
+    _check(lib().isph_apply_shift(ctx.h, C.byref(pv), int(antisym), _ptr(fx), _ptr(dr), _ptr(x), _ptr(v), _ptr(p), dev))
 
 
 def shift_particles(ctx, parts, colmap, shift, shiftcut, nonfluidweight, dt, x, v, p, vfrac, antisym=True, fixed=None,
@@ -600,6 +632,7 @@ def shift_particles(ctx, parts, colmap, shift, shiftcut, nonfluidweight, dt, x, 
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
     fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.int32)
     vmax = C.c_double(0.0)
+    _same_side(dev, x, v, p)
     _check(lib().isph_shift_particles(ctx.h, C.byref(pv), int(antisym), _ptr(fx), float(shift), float(shiftcut),
-                                      float(nonfluidweight), float(dt), _ptr(x), _ptr(v), _ptr(p), C.byref(vmax), 0))
+                                      float(nonfluidweight), float(dt), _ptr(x), _ptr(v), _ptr(p), C.byref(vmax), dev))
     return vmax.value

@@ -1,0 +1,62 @@
+"""Whole pressure-correction time step on the device (theta = 0: the Helmholtz system is the identity), 3-D TGV,
+ncell^3 particles, device-resident arrays: computePre -> Helmholtz RHS -> Poisson assemble + GMRES/ILU(0) -> zero mean ->
+velocity/pressure correction -> advance.  Prints the stage times of a few consecutive steps (ms)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import isph_amd
+from isph_amd import hip, workload, dist
+
+nc = int(os.environ.get("ISPH_NCELL", "100"))
+dev = torch.device("cuda", 0)
+st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
+ctx = hip.Context(0, stream=st.cuda_stream)
+spec = workload.TGVSpec(dim=3, ncell=(nc, nc, nc), brick=(8, 8, 8), mode=workload.ADVECT)
+parts = workload.make_tgv(spec)
+plan = dist.make_plan(parts, None)
+n, nall = parts["nlocal"], parts["nall"]
+dp = dict(parts)
+for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+    dp[k] = torch.from_numpy(np.ascontiguousarray(parts[k])).to(dev)
+colmap = torch.from_numpy(plan.colmap).to(dev)
+own = torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)
+rho = torch.from_numpy(parts["rho"]).to(dev)
+nu = torch.from_numpy(parts["nu"]).to(dev)
+v = torch.from_numpy(np.ascontiguousarray(parts["v"])).to(dev)
+p = torch.zeros(nall, dtype=torch.float64, device=dev)
+zeros3 = torch.zeros((nall, 3), dtype=torch.float64, device=dev)
+g = np.zeros(3)
+dt = spec.dt
+
+
+def sync():
+    torch.cuda.synchronize()
+    return time.perf_counter()
+
+
+for step in range(4):
+    t0 = sync()
+    vf = hip.compute_volumes(ctx, dp, colmap)
+    vfrac = vf[own].contiguous()
+    t1 = sync()
+    # Helmholtz with theta = 0: b is v* (viscous term, body force, -dt/rho grad p)
+    H, bh = hip.assemble_helmholtz(ctx, dp, colmap, dt, 0.0, nu, rho, p, zeros3, g, v, vfrac=vfrac)
+    vstar = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    vstar[:, 0], vstar[:, 1], vstar[:, 2] = bh[:n], bh[n:2 * n], bh[2 * n:3 * n]
+    vstar_all = vstar[own].contiguous()
+    H.close()
+    t2 = sync()
+    A, b = hip.assemble_poisson(ctx, dp, colmap, dt, rho, vstar_all, vfrac=vfrac, ncol=plan.ncol)
+    t3 = sync()
+    M = hip.Precond(ctx, A, "bjacobi-ilu0", 512)
+    dpv = torch.zeros(n, dtype=torch.float64, device=dev)
+    info = hip.solve(ctx, A, b, dpv, prec=M, singular=True)
+    M.close(); A.close()
+    dpv -= dpv.mean()
+    t4 = sync()
+    dp_all = dpv[own].contiguous()
+    hip.correct_velocity_pressure(ctx, dp, colmap, dt, rho, dp_all, vstar_all, p, vfrac)
+    dpa = hip.advance_begin(ctx, dp, colmap, dt, p, v, vstar_all, vfrac)
+    t5 = sync()
+    print("step %d: computePre %.1f  helmholtz-rhs %.1f  poisson-assemble %.1f  solve(+ILU) %.1f [%d its]  correct+advance %.1f  total %.1f ms"
+          % (step, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, info.iters, (t5 - t4) * 1e3, (t5 - t0) * 1e3))

@@ -849,3 +849,37 @@ def test_manufactured_solution_consistency_of_the_assembled_operator(gpu_ctx, an
         r = A.spmv(u) - scale * u
         errs.append(np.sqrt(np.mean(r * r)) / (scale * np.sqrt(np.mean(u * u))))
     assert errs[0] < 0.08 and errs[1] < 0.5 * errs[0]
+
+
+def test_operators_with_device_tensors_and_refusal_of_mislabelled_pointers(gpu_ctx):
+    """The streaming operators take device pointers (on_device = 1) as well; a device pointer handed over as a host
+    pointer is refused instead of being dereferenced on the host."""
+    import ctypes as C
+    import torch
+    pr = Problem(tgv_spec(dim=3, n=10, mode=workload.JITTER))
+    parts, P = pr.parts, pr.P
+    dev = torch.device("cuda", 0)
+    dparts = dict(parts)
+    for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+        dparts[k] = torch.from_numpy(np.ascontiguousarray(parts[k])).to(dev)
+    cm = torch.from_numpy(pr.colmap).to(dev)
+    vf = torch.from_numpy(P.vfrac).to(dev)
+    own = parts["owner_index"]
+    f = np.random.default_rng(2).standard_normal(pr.n)[own]
+    g_host = hip.gradient(gpu_ctx, parts, pr.colmap, f, P.vfrac, filt=(orc.FLUID, orc.FLUID))
+    g_dev = hip.gradient(gpu_ctx, dparts, cm, torch.from_numpy(f).to(dev), vf, filt=(orc.FLUID, orc.FLUID))
+    torch.cuda.synchronize()
+    assert isinstance(g_dev, torch.Tensor) and np.array_equal(g_dev.cpu().numpy(), g_host)
+    u = np.random.default_rng(3).standard_normal((pr.n, 3))[own]
+    d_host = hip.divergence(gpu_ctx, parts, pr.colmap, u, P.vfrac)
+    d_dev = hip.divergence(gpu_ctx, dparts, cm, torch.from_numpy(np.ascontiguousarray(u)).to(dev), vf)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_dev.cpu().numpy(), d_host)
+    # mislabelled: device particle arrays, on_device = 0
+    keep = []
+    pv, isdev, keep = hip.particles_view(dparts, cm, vfrac=vf, keep=keep)
+    out = np.zeros((pr.n, 3))
+    rc = hip.lib().isph_gradient(gpu_ctx.h, C.byref(pv), 1, hip._ptr(f), 1.0, 0, 127, 127, hip._ptr(out), 0)
+    assert rc != 0 and b"on_device = 0" in hip.lib().isph_last_error()
+    with pytest.raises(ValueError):
+        hip.gradient(gpu_ctx, dparts, cm, f, vf)      # host field with device particles
