@@ -651,17 +651,18 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
   if (i >= a.nlocal) {
     const int nslices = (a.nlocal + kSlice - 1) / kSlice;
     const int slice = i >> 6;
-    if (slice < nslices) {
+    if (sval && slice < nslices) {
       const long long off = slice_off[slice];
       const int w = (int)((slice_off[slice + 1] - off) >> 6);
-      for (int k = 0; k < w; ++k) { const long long p = sell_pos(off, lane, k); scol[p] = 0; sval[p] = 0.0; }
+      if (sval)
+        for (int k = 0; k < w; ++k) { const long long p = sell_pos(off, lane, k); scol[p] = 0; sval[p] = 0.0; }
     }
     return;
   }
   const int dim = T.dim, nt1 = T.ntypes + 1, dL = dim * (dim + 1) / 2;
   const int it = a.type[i], ikind = T.kind[it];
-  const long long off = slice_off[i >> 6];
-  const int w = (int)((slice_off[(i >> 6) + 1] - off) >> 6);
+  const long long off = sval ? slice_off[i >> 6] : 0;
+  const int w = sval ? (int)((slice_off[(i >> 6) + 1] - off) >> 6) : 0;
   const int filt_i = KIND_FLUID, filt_j = KIND_ALL;
   const double alpha = a.dt;
   const double invrho = 1.0 / a.rho[i];
@@ -680,8 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
         const int cj = a.colmap[j];
         if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
         const long long p = sell_pos(off, lane, cnt++);
-        scol[p] = cj;
-        sval[p] = 0.0;
+        if (sval) { scol[p] = cj; sval[p] = 0.0; }
       }
     }
     diag_final = 1.0;  // solid rows: unit diagonal, b unchanged (:114-117)
@@ -780,8 +780,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       const int cj = a.colmap[j];
       if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
       const long long p = sell_pos(off, lane, cnt++);
-      scol[p] = cj;
-      sval[p] = aval * (-a.theta);
+      if (sval) { scol[p] = cj; sval[p] = aval * (-a.theta); }
     }
     const double dval = ((diag1 + diag2) * alpha) * invrho;
     for (int k = 0; k < dim; ++k) wv[k] += dval * a.v[3 * (size_t)i + k];
@@ -790,13 +789,11 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
   {
     if (pdiag < 0) pdiag = cnt++;
     const long long p = sell_pos(off, lane, pdiag);
-    scol[p] = ci_own;
-    sval[p] = diag_final;
+    if (sval) { scol[p] = ci_own; sval[p] = diag_final; }
   }
   for (int k = cnt; k < w; ++k) {
     const long long p = sell_pos(off, lane, k);
-    scol[p] = a.colmap[i];
-    sval[p] = 0.0;
+    if (sval) { scol[p] = a.colmap[i]; sval[p] = 0.0; }
   }
   for (int k = 0; k < dim; ++k) {
     double bk = a.v[3 * (size_t)i + k];
@@ -1129,6 +1126,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   AsmTables T;
   HelmholtzArgs a;
   memset(&a, 0, sizeof(a));
+  const bool rhs_only = A_out == nullptr;  // theta = 0 callers only need b (the reference then copies b into x)
   isph_mat *A = new isph_mat();
   DevBuf<double> bdev;
   DevBuf<int> newlen;
@@ -1166,7 +1164,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, a.colmap);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, A_out ? a.colmap : nullptr);
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
       if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);
@@ -1178,16 +1176,19 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   if (rc == ISPH_SUCCESS && !on_device) { rc = bdev.reserve((size_t)lda * dim); db = bdev.p; }
   if (rc == ISPH_SUCCESS && n > 0) {
     const int grid = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_asm_count, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
-    hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
-    rc = sell_finalize_offsets(ctx, M);
+    if (!rhs_only) {
+      hipLaunchKernelGGL(k_asm_count, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
+      hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
+      rc = sell_finalize_offsets(ctx, M);
+    }
     if (rc == ISPH_SUCCESS) {
       a.nlocal = n; a.antisym = antisym; a.incremental = incremental; a.lda = lda; a.dt = dt; a.theta = theta;
       a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
       for (int k = 0; k < 3; ++k) a.g[k] = gvec ? gvec[k] : 0.0;
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
-      hipLaunchKernelGGL(k_asm_helmholtz, dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
-      if (n <= 32768) {
+      hipLaunchKernelGGL(k_asm_helmholtz, dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p,
+                         rhs_only ? (int *)nullptr : M.col.p, rhs_only ? (double *)nullptr : M.val.p, db);
+      if (!rhs_only && n <= 32768) {
         rc = newlen.reserve((size_t)n);
         if (rc == ISPH_SUCCESS) {
           hipLaunchKernelGGL(k_sell_merge_duplicates, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p,
@@ -1197,14 +1198,14 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
         }
       }
       // rows come out column-sorted when the neighbour lists were ordered; merged duplicates break that order
-      if (rc == ISPH_SUCCESS) rc = (T.sorted && n > 32768) ? sell_set_wmax(ctx, M) : sell_sort_rows(ctx, M);
+      if (rc == ISPH_SUCCESS && !rhs_only) rc = (T.sorted && n > 32768) ? sell_set_wmax(ctx, M) : sell_sort_rows(ctx, M);
       if (rc == ISPH_SUCCESS && !on_device &&
           hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)lda * dim, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         rc = fail("copy failed", __FILE__, __LINE__);
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         rc = fail("assembly kernel failed", __FILE__, __LINE__);
     }
-    if (rc == ISPH_SUCCESS) {
+    if (rc == ISPH_SUCCESS && !rhs_only) {
       std::vector<int> len((size_t)n);
       if (hipMemcpy(len.data(), M.rowlen.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail("copy failed", __FILE__, __LINE__);
@@ -1216,7 +1217,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   S.release(); E.release(); snu.release(); sp.release(); sf.release(); sv.release();
   bdev.release();
   newlen.release();
-  if (rc != ISPH_SUCCESS) { A->S.release(); delete A; return rc; }
+  if (rc != ISPH_SUCCESS || rhs_only) { A->S.release(); delete A; return rc; }
   *A_out = A;
   return ISPH_SUCCESS;
 }

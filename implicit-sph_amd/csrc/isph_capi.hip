@@ -712,7 +712,7 @@ int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym,
                             const double *nu, const double *rho, const double *pres, const double *force,
                             const double *g, int incremental_pressure, const double *v, int ncol, isph_mat **A_out,
                             double *b_out, int lda, int on_device) {
-  ISPH_REQUIRE(ctx && P && nu && rho && pres && force && v && A_out && b_out, "NULL argument");
+  ISPH_REQUIRE(ctx && P && nu && rho && pres && force && v && b_out, "NULL argument");  // A_out may be NULL: b only
   return assemble_helmholtz(ctx, P, antisym, dt, theta, nu, rho, pres, force, g, incremental_pressure, v, ncol, A_out,
                             b_out, lda, on_device);
 }

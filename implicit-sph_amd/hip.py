@@ -445,7 +445,7 @@ def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=
 
 def assemble_helmholtz(ctx, parts, colmap, dt, theta, nu, rho, pres, force, g, vel, antisym=True, incremental=True,
                        ncol=None, vfrac=None, Gc=None, Lc=None, kernel="wendland", kinds=None, pnd=None,
-                       morris_safe_coeff=0.43301):
+                       morris_safe_coeff=0.43301, rhs_only=False):
     """isph_assemble_helmholtz == PairISPH_Corrected::computeHelmholtz.  Returns (Matrix, b) with b
     column-major [nlocal x dim] flattened (component k at b[k*nlocal:(k+1)*nlocal])."""
     keep = []
@@ -459,10 +459,11 @@ def assemble_helmholtz(ctx, parts, colmap, dt, theta, nu, rho, pres, force, g, v
         b_out = torch.zeros(nlocal * dim, dtype=torch.float64, device=rho.device)
     else:
         b_out = np.zeros(nlocal * dim)
-    A = Matrix(ctx)
+    A = None if rhs_only else Matrix(ctx)
     _check(lib().isph_assemble_helmholtz(ctx.h, C.byref(pv), int(antisym), float(dt), float(theta), _ptr(nu), _ptr(rho),
                                          _ptr(pres), _ptr(force), _ptr(gv), int(incremental), _ptr(vel),
-                                         nlocal if ncol is None else ncol, C.byref(A.h), _ptr(b_out), nlocal, dev))
+                                         nlocal if ncol is None else ncol, None if rhs_only else C.byref(A.h),
+                                         _ptr(b_out), nlocal, dev))
     return A, b_out
 
 

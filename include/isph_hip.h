@@ -201,7 +201,8 @@ int isph_assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym, d
  * b = v + (1-theta) dt (1/rho) div(nu rho grad v) + dt (f/rho + g) - dt/rho grad p.
  * v, force: [nall][3] (atom->v, atom->f, ghosts included); nu, rho, pres: [nall];
  * g: 3 doubles (host).  b_out: column-major [lda x dim] like the reference's
- * b multivector (pair_isph.cpp:936-946); the result feeds isph_solve(nvec=dim). */
+ * b multivector (pair_isph.cpp:936-946); the result feeds isph_solve(nvec=dim).
+ * A_out == NULL: only b is formed (theta = 0, where the reference copies b into x, pair_isph.cpp:964-966). */
 int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
                             const double *nu, const double *rho, const double *pres, const double *force,
                             const double *g, int incremental_pressure, const double *v, int ncol,

@@ -40,11 +40,10 @@ for step in range(4):
     vfrac = vf[own].contiguous()
     t1 = sync()
     # Helmholtz with theta = 0: b is v* (viscous term, body force, -dt/rho grad p)
-    H, bh = hip.assemble_helmholtz(ctx, dp, colmap, dt, 0.0, nu, rho, p, zeros3, g, v, vfrac=vfrac)
+    H, bh = hip.assemble_helmholtz(ctx, dp, colmap, dt, 0.0, nu, rho, p, zeros3, g, v, vfrac=vfrac, rhs_only=True)
     vstar = torch.zeros((n, 3), dtype=torch.float64, device=dev)
     vstar[:, 0], vstar[:, 1], vstar[:, 2] = bh[:n], bh[n:2 * n], bh[2 * n:3 * n]
     vstar_all = vstar[own].contiguous()
-    H.close()
     t2 = sync()
     A, b = hip.assemble_poisson(ctx, dp, colmap, dt, rho, vstar_all, vfrac=vfrac, ncol=plan.ncol)
     t3 = sync()

@@ -378,6 +378,11 @@ def test_gpu_helmholtz_matches_oracle(gpu_ctx, case, antisym, theta):
     assert np.max(np.abs(v2 - val)) < 1e-12 * max(np.abs(val).max(), 1.0)
     bo = b.ravel()                                            # oracle b is [dim][nlocal] == column-major flattened
     assert np.max(np.abs(bg - bo)) < 1e-12 * np.abs(bo).max()
+    # right-hand side only (theta = 0 callers): same b, no matrix
+    A0, b0 = hip.assemble_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, theta, nu, p["rho"], pres, force, g, vel,
+                                    antisym=antisym, vfrac=pr.P.vfrac, Gc=None if antisym else pr.P.Gc,
+                                    Lc=None if antisym else pr.P.Lc, kernel=pr.spec.kernel, rhs_only=True)
+    assert A0 is None and np.array_equal(b0, bg)
 
 
 def test_helmholtz_solve_three_rhs(gpu_ctx):
