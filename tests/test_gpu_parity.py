@@ -382,7 +382,7 @@ def test_gpu_helmholtz_matches_oracle(gpu_ctx, case, antisym, theta):
     A0, b0 = hip.assemble_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, theta, nu, p["rho"], pres, force, g, vel,
                                     antisym=antisym, vfrac=pr.P.vfrac, Gc=None if antisym else pr.P.Gc,
                                     Lc=None if antisym else pr.P.Lc, kernel=pr.spec.kernel, rhs_only=True)
-    assert A0 is None and np.array_equal(b0, bg)
+    assert A0 is None and np.max(np.abs(b0 - bg)) <= 1e-13 * np.abs(bg).max()   # unsorted neighbour sums: round-off only
 
 
 def test_helmholtz_solve_three_rhs(gpu_ctx):
