@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncell", type=int, default=100, help="lattice cells per axis PER GPU brick edge")
     ap.add_argument("--mode", default="advect", choices=["advect", "jitter", "lattice"])
-    ap.add_argument("--prec", default="bjacobi-ilu0", choices=["none", "jacobi", "bjacobi-ilu0", "sa-amg"])
+    ap.add_argument("--prec", default="bjacobi-ilu0", choices=["none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg"])
     ap.add_argument("--amg-theta", type=float, default=0.0, help='"aggregation: threshold" of the sa-amg variant (ML default 0)')
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
@@ -55,6 +55,8 @@ def parse():
 
 METRIC_NAME = {
     "bjacobi-ilu0": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+block-Jacobi ILU(0), tol 1e-8)",
+    "bjacobi-ilu1": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+block-Jacobi ILU(1), tol 1e-8)",
+    "bjacobi-ilu2": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+block-Jacobi ILU(2), tol 1e-8)",
     "sa-amg": "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+SA-AMG V cycle, tol 1e-8)",
 }
 
@@ -71,14 +73,14 @@ def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters, amg_theta=0.
     n = len(rp) - 1
     t0 = time.perf_counter()
     ilu = None
-    if prec == "bjacobi-ilu0":
+    if prec.startswith("bjacobi-ilu"):
         bp = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
-        ilu = orc.ILU(rp, ci, val, 0, bp)
+        ilu = orc.ILU(rp, ci, val, int(prec[-1]), bp)
     amg = None
     if prec == "sa-amg":
         amg = orc.AMG(rp, ci, val, nullvec=np.full(n, 1.0 / np.sqrt(n)), block=block, theta=amg_theta)
     t_setup = time.perf_counter() - t0
-    pk = {"none": "none", "jacobi": "jacobi", "bjacobi-ilu0": "ilu", "sa-amg": "amg"}[prec]
+    pk = "ilu" if prec.startswith("bjacobi-ilu") else {"none": "none", "jacobi": "jacobi", "sa-amg": "amg"}[prec]
     ts = []
     for it in (max(cpu_iters // 2, 1), cpu_iters):
         t0 = time.perf_counter()
@@ -181,7 +183,7 @@ def main():
                 pinfo.update(levels=[M.level_info(l) for l in range(M.levels)])
         else:
             M = hip.Precond(ctx, A, args.prec, args.block)
-        if not pinfo and args.prec == "bjacobi-ilu0":
+        if not pinfo and args.prec.startswith("bjacobi-ilu"):
             pinfo.update(M.info())
         inf = hip.solve(ctx, A, bwork, x, prec=M, singular=True, params=prm)
         M.close()

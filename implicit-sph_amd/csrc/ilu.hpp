@@ -1,8 +1,8 @@
-// ilu.hpp -- block-Jacobi ILU(0) on the GPU.
+// ilu.hpp -- block-Jacobi ILU(k) on the GPU.
 //
 // Replaces PrecondWrapper_Ifpack::create() + Belos::EpetraPrecOp::Apply
 // (ref: precond_ifpack.h:52-75, solver_lin_belos.h:147-156) for the setting
-// "Precond Type"=ILU, "Overlap Level"=0, "fact: level-of-fill"=0 with one
+// "Precond Type"=ILU, "Overlap Level"=0, "fact: level-of-fill"=k with one
 // additive-Schwarz subdomain per block of B consecutive rows (what Ifpack gives
 // with one MPI rank per block).  Entries that couple different blocks are
 // dropped, exactly like the off-rank columns of the reference's local matrix.
@@ -13,14 +13,16 @@
 //              row i keeps its in-block entries contiguously at
 //              frp[i] .. frp[i]+flen[i], columns ascending, fdiag[i] = slot of the
 //              diagonal.  Strict-L (unit diagonal implied), D and strict-U live in
-//              one pattern == A's in-block pattern.  Row-major because both the
+//              one pattern == A's in-block pattern (k = 0) or the level-of-fill
+//              pattern built by ilu_symbolic (k > 0; then the block regions are
+//              the factor's own, boff[]).  Row-major because both the
 //              factorisation (U-row k is read by every row that depends on k) and
 //              the schedule walk single rows: a row is 3-6 cache lines here, ~60
 //              in the lane-interleaved ELL layout.
 //   stream   : the triangular solves never touch F; they stream a per-block list
 //              of 64-entry chunks laid out in execution order (see k_ilu_schedule).
 //
-// Pipeline per build:  k_ilu_extract -> k_ilu_schedule -> k_ilu_factor
+// Pipeline per build:  k_ilu_extract [-> k x (k_iluk_merge count, write)] -> k_ilu_schedule -> k_ilu_factor
 // Apply:               k_ilu_solve_stream (one wave per block)
 #pragma once
 #include "core.hpp"
@@ -38,7 +40,11 @@ struct isph_ilu {
   isph::DevBuf<int> blkinfo;      // [nblocks][2] chunks in the L / U stream
   isph::DevBuf<int> llev;         // [n] L-level of every row (level-synchronous factorisation)
   isph::DevBuf<double> dinv;      // [n] 1/d_i
+  isph::DevBuf<long long> boff;   // [nblocks+1] first factor entry of every block (multiples of 64)
+  isph::DevBuf<unsigned char> flev;  // level of fill of every factor entry (ILU(k), k > 0 only)
   long long stream_chunks = 0;
+  long long total = 0;      // entries reserved for the factor (ILU(0): A's sliced-ELL size; ILU(k): sum of the blocks)
+  int fill = 0;             // level of fill
   int capf = 0, slack = 0;  // stream capacity rule in force (see kCapFactorSafe)
 };
 
@@ -141,6 +147,181 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
 }
 
 // ---------------------------------------------------------------------------
+// ILU(k) symbolic phase ("fact: level-of-fill" = k > 0, precond_ifpack.h:35; Ifpack_IlukGraph rule
+// lev(i,j) = min over k < min(i,j) of lev(i,k) + lev(k,j) + 1, entries of A at level 0, kept while <= k).
+//
+// The sequential definition walks the rows in order because row i merges the FINAL patterns of the rows it
+// eliminates with.  Here the same levels are reached as the fixed point of
+//     lev_{t+1}(i,j) = min( lev_t(i,j), min_{k<min(i,j)} lev_t(i,k) + lev_t(k,j) + 1 ),   lev_0 = pattern of A:
+// a level-l entry is the sum of two entries of lower level, so after t sweeps every entry of level <= t is exact
+// (induction on the level; the recursion is well-founded in min(i,j), so the fixed point is unique) and K sweeps
+// give the ILU(K) pattern.  Inside a sweep all rows are independent: one wave per row scatters the row into a
+// dense level array of the block's columns in LDS, merges the upper parts of the rows in its lower part (the
+// previous sweep's pattern, read only), and compacts the columns with level <= K.  ILU(1) is a single sweep.
+// Every sweep runs twice: once to count (per-row lengths, in-block offsets, block totals), once to write.
+constexpr int kSymWaves = 8;
+constexpr int kSymPrefetch = 4;
+constexpr int kLevNone = 255;
+
+template <bool FILL>
+__global__ __launch_bounds__(kSymWaves * 64) void k_iluk_merge(
+    int n, int B, int K, const long long *__restrict__ frp, const int *__restrict__ fcol,
+    const unsigned char *__restrict__ flev, const int *__restrict__ flen, const int *__restrict__ fdiag,
+    const double *__restrict__ fval, int *__restrict__ nlen, int *__restrict__ inoff, int *__restrict__ blktot,
+    int *__restrict__ maxlen, const long long *__restrict__ boff, long long *__restrict__ nrp,
+    int *__restrict__ ncol, unsigned char *__restrict__ nlev, int *__restrict__ ndiag, double *__restrict__ nval) {
+  extern __shared__ double lds_m[];
+  long long *rpL = reinterpret_cast<long long *>(lds_m);       // [B]
+  double *dvals = lds_m + B;                                   // [waves][B] values of the row, by local column
+  int *lenL = reinterpret_cast<int *>(dvals + kSymWaves * B);  // [B]
+  int *dgL = lenL + B;                                         // [B]
+  int *cntL = dgL + B;                                         // [B] new row lengths (count pass)
+  int *dlev = cntL + B;                                        // [waves][B] level of the row's entry, by local column
+  unsigned short *mcol = reinterpret_cast<unsigned short *>(dlev + kSymWaves * B);  // [waves][B] the row's columns
+  unsigned char *mlev = reinterpret_cast<unsigned char *>(mcol + kSymWaves * B);    // [waves][B] ... and levels
+  const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int t = threadIdx.x; t < m; t += blockDim.x) {
+    rpL[t] = frp[blo + t];
+    lenL[t] = flen[blo + t];
+    dgL[t] = fdiag[blo + t];
+  }
+  __syncthreads();
+  int *dl = dlev + wave * B;
+  double *dv = dvals + wave * B;
+  unsigned short *mc = mcol + wave * B;
+  unsigned char *ml = mlev + wave * B;
+  const long long bbase = FILL ? boff[b] : 0;
+  for (int r = wave; r < m; r += kSymWaves) {
+    const int i = blo + r;
+    const long long rp = rpL[r];
+    const int len = lenL[r], dg = dgL[r];
+    for (int t = lane; t < m; t += 64) { dl[t] = kLevNone; dv[t] = 0.0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < len; s += 64) {
+      const int c = fcol[rp + s] - blo;
+      const int l = flev[rp + s];
+      dl[c] = l;
+      dv[c] = fval[rp + s];
+      mc[s] = (unsigned short)c;
+      ml[s] = (unsigned char)l;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // merge the upper parts of the rows k in the lower part of row i (prefetched like k_ilu_factor)
+    int pcq[kSymPrefetch], plq[kSymPrefetch], paq[kSymPrefetch];
+    auto request = [&](int s, int &pc, int &pl, int &pa) {
+      pc = -1; pl = 0; pa = kLevNone;
+      if (s < dg) {
+        const int k = mc[s];
+        pa = ml[s];
+        const int t = dgL[k] + 1 + lane;
+        if (pa < K && t < lenL[k]) {
+          const long long p = rpL[k] + t;
+          pc = fcol[p];
+          pl = flev[p];
+        }
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < kSymPrefetch; ++u) request(u, pcq[u], plq[u], paq[u]);
+    for (int s0 = 0; s0 < dg; s0 += kSymPrefetch) {
+#pragma unroll
+      for (int u = 0; u < kSymPrefetch; ++u) {
+        const int s = s0 + u;
+        if (s < dg) {
+          if (pcq[u] >= 0) {
+            const int nl = paq[u] + plq[u] + 1;
+            const int j = pcq[u] - blo;
+            if (nl <= K && nl < dl[j]) dl[j] = nl;
+          }
+          if (paq[u] < K) {  // upper parts wider than one wave
+            const int k = mc[s];
+            for (int t = dgL[k] + 1 + 64 + lane; t < lenL[k]; t += 64) {
+              const long long p = rpL[k] + t;
+              const int nl = paq[u] + (int)flev[p] + 1;
+              const int j = fcol[p] - blo;
+              if (nl <= K && nl < dl[j]) dl[j] = nl;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          request(s + kSymPrefetch, pcq[u], plq[u], paq[u]);
+        }
+      }
+    }
+    // compact the columns with level <= K (ascending by construction)
+    int run = 0;
+    const long long q0 = FILL ? bbase + inoff[i] : 0;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int t = c0 + lane;
+      const int l = t < m ? dl[t] : kLevNone;
+      const bool keep = l <= K;
+      const unsigned long long mask = __ballot(keep);
+      if (FILL && keep) {
+        const int pos = run + __popcll(mask & ((1ull << lane) - 1ull));
+        ncol[q0 + pos] = blo + t;
+        nlev[q0 + pos] = (unsigned char)l;
+        nval[q0 + pos] = dv[t];
+        if (t == r) ndiag[i] = pos;
+      }
+      run += __popcll(mask);
+    }
+    if (lane == 0) {
+      if (FILL) nrp[i] = q0;
+      else cntL[r] = run;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (FILL) return;
+  __syncthreads();
+  if (wave == 0) {  // in-block exclusive scan of the new row lengths
+    const int per = (m + 63) / 64, t0 = lane * per, t1 = min(t0 + per, m);
+    int sum = 0, mx = 0;
+    for (int t = t0; t < t1; ++t) { sum += cntL[t]; mx = max(mx, cntL[t]); }
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    int run = inc - sum;
+    for (int t = t0; t < t1; ++t) {
+      inoff[blo + t] = run;
+      nlen[blo + t] = cntL[t];
+      run += cntL[t];
+    }
+    const int total = __shfl(inc, 63, 64);
+    mx = wave_max_i32(mx);
+    if (lane == 0) {
+      blktot[b] = ((total + 63) / 64) * 64;
+      atomicMax(maxlen, mx);
+    }
+  }
+}
+
+// exclusive scan of the block totals (a few thousand values: one workgroup)
+__global__ __launch_bounds__(1024) void k_iluk_block_offsets(int nblocks, const int *__restrict__ blktot,
+                                                             long long *__restrict__ boff) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x, per = (nblocks + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, nblocks);
+  long long sum = 0;
+  for (int b = b0; b < b1; ++b) sum += blktot[b];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const long long v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  long long run = part[t] - sum;
+  for (int b = b0; b < b1; ++b) { boff[b] = run; run += blktot[b]; }
+  if (t == 1023) boff[nblocks] = part[1023];
+}
+
+// ---------------------------------------------------------------------------
 // Static schedule of the triangular solves (built per factorisation, on the GPU)
 //
 // For each block and each direction (L: dependencies = strictly-lower entries,
@@ -174,11 +355,18 @@ constexpr int kPadChunks = 32;    // per-block tail pad so the prefetch never le
 constexpr int kCapFactor = 2;
 constexpr int kCapFactorSafe = 8;
 
-__device__ __forceinline__ long long ilu_base_chunk(const long long *slice_off, int b, int B, int capf, int slack) {
-  return capf * (slice_off[(long long)b * (B / 64)] >> 6) + (long long)(kPadChunks + slack) * b;
+__device__ __forceinline__ long long ilu_base_chunk(const long long *boff, int b, int capf, int slack) {
+  return capf * (boff[b] >> 6) + (long long)(kPadChunks + slack) * b;
 }
 
-__global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long long *__restrict__ slice_off,
+// ILU(0): a block's factor lives in the entry range of its rows' sliced-ELL region in A
+__global__ void k_ilu_boff0(int nblocks, int B, int nslices, const long long *__restrict__ slice_off,
+                            long long *__restrict__ boff) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= nblocks) boff[b] = slice_off[min((long long)b * (B / 64), (long long)nslices)];
+}
+
+__global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long long *__restrict__ boff,
                                                        const long long *__restrict__ frp,
                                                        const int *__restrict__ fcol, const int *__restrict__ flen,
                                                        const int *__restrict__ fdiag, double *__restrict__ sv,
@@ -207,10 +395,9 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   const int t = threadIdx.x;
   const bool active = t < m;
   const int i = blo + t;
-  const int nslices_blk = (m + 63) / 64;
-  const long long region = slice_off[(long long)b * (B / 64) + nslices_blk] - slice_off[(long long)b * (B / 64)];
+  const long long region = boff[b + 1] - boff[b];
   const long long cap = capf * (region >> 6) + slack;
-  const long long base = ilu_base_chunk(slice_off, b, B, capf, slack);
+  const long long base = ilu_base_chunk(boff, b, capf, slack);
   long long rp = 0;
   int len = 0, dg = 0;
   if (active) {
@@ -545,7 +732,7 @@ __global__ void k_sgs_pivots(int n, const long long *__restrict__ frp, const dou
 // LDS per wave: y[B] and the block's reciprocal pivots.  kPrefetch chunks (values + words) are kept in flight.
 template <int WAVES, int PF>
 __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, int nblocks,
-                                                                 const long long *__restrict__ slice_off,
+                                                                 const long long *__restrict__ boff,
                                                                  const double *__restrict__ sv,
                                                                  const unsigned *__restrict__ sc,
                                                                  const int *__restrict__ blkinfo,
@@ -562,7 +749,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
   double *dv = y + B;  // reciprocal pivots of the block: the U steps must not wait on a global load each
   const int blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   for (int t = lane; t < m; t += 64) { y[t] = r[blo + t]; dv[t] = dinv[blo + t]; }
-  const long long base = ilu_base_chunk(slice_off, b, B, capf, slack);
+  const long long base = ilu_base_chunk(boff, b, capf, slack);
   const int nL = blkinfo[2 * b], nU = blkinfo[2 * b + 1];
   const double *__restrict__ pv = sv + base * 64 + lane;
   const unsigned *__restrict__ pc = sc + base * 64 + lane;
@@ -641,6 +828,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
 inline void ilu_destroy(isph_ilu *F) {
   if (!F) return;
   F->frp.release(); F->fcol.release(); F->flen.release(); F->fdiag.release(); F->err.release(); F->fval.release();
+  F->boff.release(); F->flev.release();
   F->sv.release(); F->sc.release(); F->fdst.release(); F->blkinfo.release(); F->dinv.release(); F->llev.release();
   delete F;
 }
@@ -658,17 +846,90 @@ inline int ilu_check_err(isph_ctx *ctx, isph_ilu *F, const char *what, bool *ove
   return ISPH_SUCCESS;
 }
 
-inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false) {
+// symbolic ILU(k): K sweeps of count + write over the extracted level-0 pattern (see k_iluk_merge); on return the
+// factor arrays hold the ILU(K) pattern (fill entries zero), boff the 64-aligned block offsets
+inline int ilu_symbolic(isph_ctx *ctx, isph_ilu *F, int K) {
+  const int n = F->n, B = F->B, nb = F->nblocks;
+  const size_t n1 = (size_t)n;
+  DevBuf<int> nlen, inoff, blktot, meta;
+  int rc = nlen.reserve(n1);
+  if (rc == ISPH_SUCCESS) rc = inoff.reserve(n1);
+  if (rc == ISPH_SUCCESS) rc = blktot.reserve((size_t)nb);
+  if (rc == ISPH_SUCCESS) rc = meta.reserve(1);
+  if (rc == ISPH_SUCCESS) rc = F->flev.reserve((size_t)(F->total > 0 ? F->total : 1));
+  if (rc == ISPH_SUCCESS && hipMemsetAsync(F->flev.p, 0, (size_t)F->total, ctx->stream) != hipSuccess)
+    rc = fail("memset failed", __FILE__, __LINE__);
+  const size_t Bz = (size_t)B;
+  const size_t lds = 8 * Bz + 8 * kSymWaves * Bz + 4 * 3 * Bz + 4 * kSymWaves * Bz + 2 * kSymWaves * Bz + kSymWaves * Bz;
+  if (rc == ISPH_SUCCESS && lds > 160 * 1024) rc = fail("ILU(k) symbolic phase: block too large for LDS", __FILE__, __LINE__);
+  if (rc == ISPH_SUCCESS &&
+      (hipFuncSetAttribute(reinterpret_cast<const void *>(k_iluk_merge<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           (int)lds) != hipSuccess ||
+       hipFuncSetAttribute(reinterpret_cast<const void *>(k_iluk_merge<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           (int)lds) != hipSuccess))
+    rc = fail("LDS attribute failed", __FILE__, __LINE__);
+  for (int sweep = 0; sweep < K && rc == ISPH_SUCCESS; ++sweep) {
+    if (hipMemsetAsync(meta.p, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
+    hipLaunchKernelGGL((k_iluk_merge<false>), dim3(nb), dim3(kSymWaves * 64), lds, ctx->stream, n, B, K, F->frp.p, F->fcol.p,
+                       F->flev.p, F->flen.p, F->fdiag.p, F->fval.p, nlen.p, inoff.p, blktot.p, meta.p,
+                       (const long long *)nullptr, (long long *)nullptr, (int *)nullptr, (unsigned char *)nullptr,
+                       (int *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_iluk_block_offsets, dim3(1), dim3(1024), 0, ctx->stream, nb, blktot.p, F->boff.p);
+    long long total = 0;
+    int wmax = 0, herr = 0;
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(&total, F->boff.p + nb, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&wmax, meta.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&herr, F->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+      rc = fail("ILU(k) symbolic count failed", __FILE__, __LINE__);
+      break;
+    }
+    if (herr & 1) { rc = fail("matrix row without a diagonal entry: ILU undefined", __FILE__, __LINE__); break; }
+    const size_t tot1 = (size_t)(total > 0 ? total : 1);
+    DevBuf<long long> nrp;
+    DevBuf<int> ncol, ndiag;
+    DevBuf<unsigned char> nlev;
+    DevBuf<double> nval;
+    rc = nrp.reserve(n1);
+    if (rc == ISPH_SUCCESS) rc = ncol.reserve(tot1);
+    if (rc == ISPH_SUCCESS) rc = ndiag.reserve(n1);
+    if (rc == ISPH_SUCCESS) rc = nlev.reserve(tot1);
+    if (rc == ISPH_SUCCESS) rc = nval.reserve(tot1);
+    if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL((k_iluk_merge<true>), dim3(nb), dim3(kSymWaves * 64), lds, ctx->stream, n, B, K, F->frp.p, F->fcol.p,
+                         F->flev.p, F->flen.p, F->fdiag.p, F->fval.p, nlen.p, inoff.p, blktot.p, meta.p,
+                         (const long long *)F->boff.p, nrp.p, ncol.p, nlev.p, ndiag.p, nval.p);
+      if (hipGetLastError() != hipSuccess) rc = fail("ILU(k) symbolic fill failed", __FILE__, __LINE__);
+    }
+    if (rc != ISPH_SUCCESS) { nrp.release(); ncol.release(); ndiag.release(); nlev.release(); nval.release(); break; }
+    // the new pattern replaces the old one (stream order keeps the old buffers alive until the kernel is done:
+    // the pool hands a released block out again only to later work on the same stream)
+    F->frp.release(); F->fcol.release(); F->fdiag.release(); F->flev.release(); F->fval.release(); F->flen.release();
+    F->frp = nrp; F->fcol = ncol; F->fdiag = ndiag; F->flev = nlev; F->fval = nval;
+    F->flen = nlen;
+    nlen = DevBuf<int>();
+    rc = nlen.reserve(n1);
+    F->total = total;
+    F->wmax = wmax;
+  }
+  nlen.release(); inoff.release(); blktot.release(); meta.release();
+  return rc;
+}
+
+inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false, int fill = 0) {
   const Sell &S = A->S;
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
-               "bjacobi-ilu0 block size must be a multiple of 64 in [64,1024]");
+               "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
+  ISPH_REQUIRE(fill >= 0 && fill <= 8 && !(sgs && fill), "level of fill must be in [0,8]");
   isph_ilu *F = new isph_ilu();
-  F->n = S.nrow; F->B = block_size; F->S = &S; F->wmax = S.wmax;
+  F->n = S.nrow; F->B = block_size; F->S = &S; F->wmax = S.wmax; F->fill = fill;
   F->nblocks = (S.nrow + block_size - 1) / block_size;
+  F->total = S.stored;
   const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
   F->capf = kCapFactor; F->slack = 2 * block_size;
   auto size_stream = [&]() {
-    F->stream_chunks = F->capf * (S.stored >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
+    F->stream_chunks = F->capf * (F->total >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
     int r = F->sv.reserve((size_t)F->stream_chunks * 64);
     if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
     if (r == ISPH_SUCCESS && (long long)F->stream_chunks * 64 >= 2147483647LL)
@@ -677,20 +938,16 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   };
   int rc = F->fcol.reserve(stored);
   if (rc == ISPH_SUCCESS) rc = F->fval.reserve(stored);
-  if (rc == ISPH_SUCCESS) rc = F->fdst.reserve(stored);
   if (rc == ISPH_SUCCESS) rc = F->frp.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->flen.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->fdiag.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->dinv.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->llev.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->err.reserve(1);
-  if (rc == ISPH_SUCCESS) rc = size_stream();
+  if (rc == ISPH_SUCCESS) rc = F->boff.reserve((size_t)F->nblocks + 1);
   if (rc == ISPH_SUCCESS) rc = F->blkinfo.reserve((size_t)2 * (F->nblocks > 0 ? F->nblocks : 1));
   if (rc == ISPH_SUCCESS && S.nrow > 0) {
-    const int W = ((S.wmax + 63) / 64) * 64;
     const size_t Bz = (size_t)block_size;
-    const size_t lds_f = 8 * Bz + (size_t)kIluWaves * W * 12 + 8 * Bz + 4 * (5 * Bz + 4) + 2 * Bz + 2 * (size_t)kIluWaves * Bz + 16;
-    if (!sgs && lds_f > 160 * 1024) rc = fail("ILU factor kernel needs too much LDS for this row width", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
       rc = fail("memset failed", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) {
@@ -701,6 +958,20 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       hipLaunchKernelGGL(k_ilu_extract, dim3(F->nblocks), dim3(block_size), lds_e, ctx->stream, S.nrow, block_size,
                          S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, F->frp.p, F->fcol.p, F->fval.p, F->flen.p,
                          F->fdiag.p, F->err.p);
+    }
+    if (rc == ISPH_SUCCESS && fill > 0) {
+      rc = ilu_symbolic(ctx, F, fill);
+    } else if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL(k_ilu_boff0, dim3((F->nblocks + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, F->nblocks,
+                         block_size, S.nslices, S.slice_off.p, F->boff.p);
+    }
+    if (rc == ISPH_SUCCESS) rc = F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1));
+    if (rc == ISPH_SUCCESS) rc = size_stream();
+    const int W = ((F->wmax + 63) / 64) * 64;
+    const size_t lds_f = 8 * Bz + (size_t)kIluWaves * W * 12 + 8 * Bz + 4 * (5 * Bz + 4) + 2 * Bz + 2 * (size_t)kIluWaves * Bz + 16;
+    if (rc == ISPH_SUCCESS && !sgs && lds_f > 160 * 1024)
+      rc = fail("ILU factor kernel needs too much LDS for this row width", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) {
       if (sgs)  // pivots first: the schedule writes the Gauss-Seidel stream values itself
         hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
                            F->fval.p, F->fdiag.p, F->dinv.p);
@@ -711,7 +982,7 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
         rc = fail("LDS attribute failed", __FILE__, __LINE__);
       for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
         hipLaunchKernelGGL(k_ilu_schedule, dim3(F->nblocks), dim3(block_size), lds_s, ctx->stream, S.nrow, block_size,
-                           S.slice_off.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->fdst.p,
+                           F->boff.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->fdst.p,
                            F->blkinfo.p, F->llev.p, ccap, F->capf, F->slack, F->err.p,
                            sgs ? (const double *)F->fval.p : (const double *)nullptr,
                            sgs ? (const double *)F->dinv.p : (const double *)nullptr);
@@ -751,7 +1022,7 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
   static const int pf = []() { const char *e = getenv("ISPH_ILU_PREFETCH"); return e ? atoi(e) : kPrefetch; }();
 #define ISPH_ILU_LAUNCH(PF)                                                                                             \
   hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream,   \
-                     F->n, F->B, F->nblocks, F->S->slice_off.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p, \
+                     F->n, F->B, F->nblocks, F->boff.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p, \
                      F->dinv.p, r, z, F->capf, F->slack)
   if (pf == 12) ISPH_ILU_LAUNCH(12);
   else if (pf == 16) ISPH_ILU_LAUNCH(16);
@@ -774,11 +1045,10 @@ inline long long ilu_nnz(const isph_ilu *F) {
 
 // CSR export (device -> host) for parity tests
 inline int ilu_export(isph_ctx *ctx, const isph_ilu *F, int *rowptr, int *colidx, double *val) {
-  const Sell &S = *F->S;
   std::vector<int> len((size_t)F->n);
   std::vector<long long> rp((size_t)F->n);
-  std::vector<int> col((size_t)S.stored);
-  std::vector<double> v((size_t)S.stored);
+  std::vector<int> col((size_t)F->total);
+  std::vector<double> v((size_t)F->total);
   ISPH_CHECK_HIP(hipMemcpyAsync(len.data(), F->flen.p, sizeof(int) * len.size(), hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipMemcpyAsync(rp.data(), F->frp.p, sizeof(long long) * rp.size(), hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipMemcpyAsync(col.data(), F->fcol.p, sizeof(int) * col.size(), hipMemcpyDeviceToHost, ctx->stream));

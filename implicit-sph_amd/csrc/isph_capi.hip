@@ -395,9 +395,10 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
                          A->S.rowlen.p, A->S.slice_off.p, A->S.col.p, A->S.val.p, M->invdiag.p);
       if (hipGetLastError() != hipSuccess) rc = fail("jacobi setup failed", __FILE__, __LINE__);
     }
-  } else if (!strcmp(type, "bjacobi-ilu0")) {
+  } else if (!strncmp(type, "bjacobi-ilu", 11) && type[11] >= '0' && type[11] <= '8' && type[12] == 0) {
+    // "bjacobi-ilu<k>": "fact: level-of-fill" = k (precond_ifpack.h:35)
     M->type = 2;
-    rc = ilu_create(ctx, A, block_size, &M->ilu);
+    rc = ilu_create(ctx, A, block_size, &M->ilu, /*sgs=*/false, /*fill=*/type[11] - '0');
   } else if (!strcmp(type, "sa-amg")) {
     // PrecondWrapper_ML defaults without a null vector; block_size is the Gauss-Seidel block of the fine level.
     // isph_prec_create_amg takes the full parameter set and the null vector of a singular system.
@@ -407,7 +408,7 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
     M->type = 3;
     rc = amg_create(ctx, A, &prm, nullptr, &M->amg);
   } else {
-    rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu0|sa-amg)", __FILE__, __LINE__);
+    rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu<k>, k = 0..8|sa-amg)", __FILE__, __LINE__);
   }
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
   *Mout = M;

@@ -1,4 +1,4 @@
-// precond_ifpack.h -- PrecondWrapper_Ifpack over the HIP block-Jacobi ILU(0)
+// precond_ifpack.h -- PrecondWrapper_Ifpack over the HIP block-Jacobi ILU(k)
 // (ref: precond_ifpack.h:28-85: same parameter keys and defaults).
 #pragma once
 #include <cstdio>
@@ -40,13 +40,20 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
       std::fprintf(stderr, ">> PrecondWrapper_Ifpack(HIP): Precond Type '%s' is not available; only ILU\n", type.c_str());
       return ISPH_FAILURE;
     }
-    if ((fill != 0 || overlap != 0) && _comm.MyPID() == 0 && !_warned) {
-      std::printf(">> PrecondWrapper_Ifpack(HIP): level-of-fill %d / overlap %d requested; this build provides "
-                  "ILU(0), overlap 0 (block-Jacobi) -- using that\n", fill, overlap);
+    if (fill < 0 || fill > 8) {
+      std::fprintf(stderr, ">> PrecondWrapper_Ifpack(HIP): fact: level-of-fill %d is outside [0,8]\n", fill);
+      return ISPH_FAILURE;
+    }
+    // "Overlap Level" extends an Ifpack subdomain by rows of the neighbouring RANKS (no effect on one rank).  The device
+    // subdomains are blocks of "isph: block rows" rows inside a rank and are not extended: overlap 0 semantics.
+    if (overlap != 0 && _comm.NumProc() > 1 && _comm.MyPID() == 0 && !_warned) {
+      std::printf(">> PrecondWrapper_Ifpack(HIP): Overlap Level %d requested; this build provides overlap 0 "
+                  "(block-Jacobi ILU(%d)) -- using that\n", overlap, fill);
       _warned = true;
     }
     free();
-    return isph_prec_create(ctx, A, "bjacobi-ilu0", _param->get("isph: block rows", 512), &_M);
+    const std::string kind = "bjacobi-ilu" + std::to_string(fill);
+    return isph_prec_create(ctx, A, kind.c_str(), _param->get("isph: block rows", 512), &_M);
   }
   bool _warned = false;
 };

@@ -88,9 +88,11 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
  * Compute (ref: precond_ifpack.h:52-75).  type:
  *   "none"          identity
  *   "jacobi"        point Jacobi (debug)
- *   "bjacobi-ilu0"  block-Jacobi, ILU(0) per block == Ifpack
+ *   "bjacobi-ilu<k>"  k = 0..8: block-Jacobi, ILU(k) per block == Ifpack
  *                   AdditiveSchwarz<ILU>, "Overlap Level"=0,
- *                   "fact: level-of-fill"=0, one block per `block_size` rows
+ *                   "fact: level-of-fill"=k (precond_ifpack.h:35; the reference's
+ *                   default is k = 1), one block per `block_size` rows
+ *                   (k > 0: block_size <= 1024 and the symbolic phase runs on the device)
  *   "sa-amg"        PrecondWrapper_ML::create() with its default parameters and no null vector
  *                   (isph_prec_create_amg takes the parameters and the null vector of a singular system)
  * Rebuilt every solve in the reference (solver_lin_belos.h:153,190). */

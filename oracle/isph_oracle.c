@@ -1106,23 +1106,31 @@ static void ilu_block(orc_ilu *F, int b, const int *arp, const int *aci, const d
       if (!have_diag) { lev[r] = 0; w[r] = 0.0; next[prev] = r; next[r] = m; ++count; }
       head = next[m];
     }
-    /* eliminate with previous rows k < r in increasing order */
+    /* Symbolic pass (Ifpack_IlukGraph::ConstructFilledGraph): merge the level patterns of the rows k < r in
+     * increasing order; the numeric pass below then works on the FINAL pattern of the row, as Ifpack_ILU::Compute
+     * does -- a pivot's update of an entry counts even when that entry only entered the pattern through a later
+     * pivot (a one-pass factorisation with dynamic insertion would drop those updates). */
     for (int k = head; k < r; k = next[k]) {
-      if (lev[k] > lof) continue; /* cannot happen (entries kept have lev<=lof) */
-      const double lik = w[k] / rvals[k][rdiag[k]];
-      w[k] = lik;
       int pos = k; /* insertion cursor in linked list */
       for (int q = rdiag[k] + 1; q < rcnt[k]; ++q) {
         const int j = rcols[k][q];
         const int newlev = lev[k] + rlevs[k][q] + 1;
         if (lev[j] >= 0) {
           if (newlev < lev[j]) lev[j] = newlev;
-          w[j] -= lik * rvals[k][q];
         } else if (newlev <= lof) {
           while (next[pos] < j) pos = next[pos];
           next[j] = next[pos]; next[pos] = j;
-          lev[j] = newlev; w[j] = -lik * rvals[k][q]; ++count;
+          lev[j] = newlev; w[j] = 0.0; ++count;
         }
+      }
+    }
+    /* numeric pass: IKJ on the fixed pattern */
+    for (int k = head; k < r; k = next[k]) {
+      const double lik = w[k] / rvals[k][rdiag[k]];
+      w[k] = lik;
+      for (int q = rdiag[k] + 1; q < rcnt[k]; ++q) {
+        const int j = rcols[k][q];
+        if (lev[j] >= 0) w[j] -= lik * rvals[k][q];
       }
     }
     rcols[r] = (int *)malloc(sizeof(int) * (size_t)count);

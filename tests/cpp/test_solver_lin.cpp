@@ -97,6 +97,7 @@ int main(int argc, char **argv) {
 
   const bool use_ml = argc > 4 && std::string(argv[4]) == "ml";
   const bool use_cg = argc > 4 && std::string(argv[4]) == "cg";
+  const bool ifpack_defaults = argc > 4 && std::string(argv[4]) == "ifpack-defaults";  // level-of-fill 1, overlap 1
   PrecondWrapper_Ifpack prec_ifpack(world);
   PrecondWrapper_ML prec_ml(world);
   PrecondWrapper &prec = use_ml ? static_cast<PrecondWrapper &>(prec_ml) : static_cast<PrecondWrapper &>(prec_ifpack);
@@ -104,7 +105,7 @@ int main(int argc, char **argv) {
   if (use_ml) {  // the keys of precond_ml.h:44-55 are already set; shrink the hierarchy to the test size
     pp->set("coarse: max size", 64);
     pp->set("aggregation: threshold", 0.02);
-  } else {
+  } else if (!ifpack_defaults) {
     pp->set("fact: level-of-fill", 0);
     pp->set("Overlap Level", 0);
   }

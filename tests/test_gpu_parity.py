@@ -247,6 +247,55 @@ def test_gmres_bjacobi_ilu0_matches_oracle(gpu_ctx, case, bs):
     assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
 
 
+ILUK_CASES = [(c, bs, k) for (c, bs) in ILU_CASES[:4] for k in (1, 2)] + [(ILU_CASES[2][0], 64, 3), (ILU_CASES[4][0], 1024, 1),
+                                                                         (ILU_CASES[5][0], 256, 4)]
+
+
+@pytest.mark.parametrize("case,bs,k", ILUK_CASES)
+def test_iluk_pattern_factor_and_apply_match_oracle(gpu_ctx, case, bs, k):
+    """"fact: level-of-fill" = k > 0 (precond_ifpack.h:35, the reference default is 1): the device symbolic phase (level
+    sweeps) must give exactly the level-of-fill pattern of the sequential definition, the numeric factor its values."""
+    pr = Problem(tgv_spec(**case))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    bp = np.arange(0, n + bs, bs).clip(0, n).astype(np.int32)
+    ref = orc.ILU(rp, ci, val, k, bp)
+    frp, fci, fv = ref.export()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu%d" % k, bs)
+    grp, gci, gv = M.export_ilu()
+    assert np.array_equal(grp, frp) and np.array_equal(gci, fci)            # pattern with fill: exact
+    assert grp[-1] > hip.Precond(gpu_ctx, A, "bjacobi-ilu0", bs).export_ilu()[0][-1] or bs == 64 and k == 0
+    assert np.max(np.abs(gv - fv)) <= 1e-10 * np.abs(fv).max()
+    r = np.random.default_rng(5).standard_normal(n)
+    z = M.apply(r)
+    zo = ref.apply(r)
+    assert np.linalg.norm(z - zo) / np.linalg.norm(zo) < 1e-10
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_gmres_bjacobi_iluk_matches_oracle(gpu_ctx, k):
+    pr = Problem(tgv_spec(dim=3, n=16, mode=workload.ADVECT, brick=8))
+    rp, ci, val, b = pr.poisson()
+    n, bs = pr.n, 512
+    bp = np.arange(0, n + bs, bs).clip(0, n).astype(np.int32)
+    xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=orc.ILU(rp, ci, val, k, bp))
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu%d" % k, bs)
+    bg, xg = b.copy(), np.zeros(n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=True)
+    assert info.converged == 1 and abs(info.iters - io.iters) <= 1
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+def test_iluk_rejects_levels_out_of_range(gpu_ctx):
+    pr = Problem(tgv_spec(dim=2, n=16, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    with pytest.raises(hip.IsphError):
+        hip.Precond(gpu_ctx, A, "bjacobi-ilu9", 64)
+
+
 def test_ilu0_one_row_per_level_uses_the_safe_stream_capacity(gpu_ctx):
     """Tridiagonal chain: every level holds one row, so the triangular-solve stream needs one chunk per row and
     direction -- far above the first-attempt capacity; the build must fall back to its proven bound, not fail."""
@@ -314,7 +363,7 @@ def test_rccl_self_halo_spmv_and_solve(gpu_ctx):
 
 
 # ---------------------------------------------------------------- C++ mirror of the reference interface
-@pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml")])
+@pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml"), (1, "ifpack-defaults")])
 def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     """SolverLin_Belos / PrecondWrapper_Ifpack (implicit-sph_amd/host/*.h) driven
     exactly like USER-REAXC-T/fix_qeq_reax.cpp:671-693 drives the reference."""
@@ -335,8 +384,10 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
         rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
         val.tofile(f); b.tofile(f)
     ml = cg == "ml"
-    cg = bool(cg) and not ml
-    r = subprocess.run([exe, str(fin), str(fout), str(singular)] + (["cg"] if cg else ["ml"] if ml else []),
+    fill = 1 if cg == "ifpack-defaults" else 0   # PrecondWrapper_Ifpack's own defaults: "fact: level-of-fill" = 1
+    cg = bool(cg) and not ml and not fill
+    r = subprocess.run([exe, str(fin), str(fout), str(singular)] +
+                       (["cg"] if cg else ["ml"] if ml else ["ifpack-defaults"] if fill else []),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert ">> Belos::Status - Passed!" in r.stdout
@@ -349,7 +400,7 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
         xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="amg", amg=G, params=prm)
     else:
         xo, io, bo = orc.solve(rp, ci, val, b, singular=bool(singular), prec="ilu",
-                               ilu=orc.ILU(rp, ci, val, 0, bp), params=prm)
+                               ilu=orc.ILU(rp, ci, val, fill, bp), params=prm)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
     assert np.allclose(bproj, bo, rtol=0, atol=1e-13 * np.abs(bo).max())   # b view updated in place
 

@@ -182,6 +182,41 @@ def test_ilu0_matches_dense_definition():
     assert np.allclose(orc.ILU(rp, ci, val, 0).apply(r), z, rtol=1e-10)
 
 
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_iluk_matches_dense_definition(k):
+    """ILU(k) as Ifpack builds it: level-of-fill graph first (lev(i,j) = min_p lev(i,p)+lev(p,j)+1 <= k, entries of A at
+    level 0), then IKJ elimination restricted to that FINAL pattern (Ifpack_IlukGraph + Ifpack_ILU::Compute)."""
+    pr = Problem(tgv_spec(dim=2, n=8, mode=workload.JITTER))
+    rp, ci, val, _ = pr.poisson()
+    n = pr.n
+    A = sps.csr_matrix((val, ci, rp), shape=(n, n)).toarray()
+    INF = 10 ** 6
+    lev = np.where(A != 0, 0, INF)
+    lev[np.arange(n), np.arange(n)] = 0
+    for i in range(n):                          # textbook symbolic phase, rows in order
+        for p in range(i):
+            if lev[i, p] <= k:
+                for j in range(p + 1, n):
+                    if lev[p, j] <= k:
+                        lev[i, j] = min(lev[i, j], lev[i, p] + lev[p, j] + 1)
+    pat = lev <= k
+    LU = A.copy()
+    for i in range(1, n):
+        for p in range(i):
+            if pat[i, p]:
+                LU[i, p] /= LU[p, p]
+                for j in range(p + 1, n):
+                    if pat[i, j]:
+                        LU[i, j] -= LU[i, p] * LU[p, j]
+    frp, fci, fv = orc.ILU(rp, ci, val, k).export()
+    got = np.zeros((n, n), bool)
+    for i in range(n):
+        got[i, fci[frp[i]:frp[i + 1]]] = True
+    assert np.array_equal(got, pat) and pat.sum() > (A != 0).sum()
+    F = sps.csr_matrix((fv, fci, frp), shape=(n, n)).toarray()
+    assert np.allclose(F[pat], LU[pat], rtol=1e-11, atol=1e-13)
+
+
 def test_cg_on_symmetric_lattice_system():
     """CG + ILU(0): the USER-REAXC-T / config-1 setting (Block CG, tol 1e-6)."""
     pr = Problem(tgv_spec(dim=2, n=32, mode=workload.LATTICE))
