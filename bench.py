@@ -66,32 +66,45 @@ def pgrid_for(n):
 
 
 def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters, amg_theta=0.0):
-    """Oracle (CPU restatement of Belos FGMRES + Ifpack block-ILU(0)) timed on the
-    host cores on a bounded sample: preconditioner setup + `cpu_iters` of the
-    iterations the full solve needs, extrapolated linearly."""
+    """Oracle (CPU restatement of Belos FGMRES + Ifpack block-ILU(k) / ML SA-AMG) timed on the host cores on a bounded
+    sample: preconditioner setup + `cpu_iters` of the iterations the full solve needs, extrapolated linearly.  Timed twice
+    (SURVEY 8d): on the threads the box gives us, and on ONE thread -- the reference itself has no threading, one MPI rank
+    runs exactly that."""
     import oracle as orc
     n = len(rp) - 1
-    t0 = time.perf_counter()
-    ilu = None
-    if prec.startswith("bjacobi-ilu"):
-        bp = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
-        ilu = orc.ILU(rp, ci, val, int(prec[-1]), bp)
-    amg = None
-    if prec == "sa-amg":
-        amg = orc.AMG(rp, ci, val, nullvec=np.full(n, 1.0 / np.sqrt(n)), block=block, theta=amg_theta)
-    t_setup = time.perf_counter() - t0
-    pk = "ilu" if prec.startswith("bjacobi-ilu") else {"none": "none", "jacobi": "jacobi", "sa-amg": "amg"}[prec]
-    ts = []
-    for it in (max(cpu_iters // 2, 1), cpu_iters):
+
+    def timed(iters):
         t0 = time.perf_counter()
-        orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, amg=amg, params=orc.SolverParams(max_iters=it))
-        ts.append((it, time.perf_counter() - t0))
-    per_iter = (ts[1][1] - ts[0][1]) / max(ts[1][0] - ts[0][0], 1)
-    total = t_setup + ts[1][1] + per_iter * max(iters_gpu - ts[1][0], 0)
-    return dict(value=1.0 / total, unit="solves/s", cores=orc.num_threads(), kind="port",
-                sample="same %d-row system: %s setup (%.2fs) + %d of %d FGMRES iterations (%.2fs), "
-                       "extrapolated at %.3fs/iteration" % (n, prec, t_setup, ts[1][0], iters_gpu, ts[1][1], per_iter),
-                seconds_per_solve=total)
+        ilu = None
+        if prec.startswith("bjacobi-ilu"):
+            bp = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
+            ilu = orc.ILU(rp, ci, val, int(prec[-1]), bp)
+        amg = None
+        if prec == "sa-amg":
+            amg = orc.AMG(rp, ci, val, nullvec=np.full(n, 1.0 / np.sqrt(n)), block=block, theta=amg_theta)
+        t_setup = time.perf_counter() - t0
+        pk = "ilu" if prec.startswith("bjacobi-ilu") else {"none": "none", "jacobi": "jacobi", "sa-amg": "amg"}[prec]
+        ts = []
+        for it in (max(iters // 2, 1), iters):
+            t0 = time.perf_counter()
+            orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, amg=amg, params=orc.SolverParams(max_iters=it))
+            ts.append((it, time.perf_counter() - t0))
+        per_iter = (ts[1][1] - ts[0][1]) / max(ts[1][0] - ts[0][0], 1)
+        total = t_setup + ts[1][1] + per_iter * max(iters_gpu - ts[1][0], 0)
+        return total, ("same %d-row system: %s setup (%.2fs) + %d of %d FGMRES iterations (%.2fs), extrapolated at "
+                       "%.3fs/iteration" % (n, prec, t_setup, ts[1][0], iters_gpu, ts[1][1], per_iter))
+
+    threads = orc.num_threads()
+    total, sample = timed(cpu_iters)
+    out = dict(value=1.0 / total, unit="solves/s", cores=threads, kind="port", sample=sample, seconds_per_solve=total)
+    if threads > 1:
+        orc.set_num_threads(1)
+        try:
+            t1, s1 = timed(max(cpu_iters // 2, 2))
+            out["single_thread"] = dict(value=1.0 / t1, unit="solves/s", cores=1, sample=s1, seconds_per_solve=t1)
+        finally:
+            orc.set_num_threads(threads)
+    return out
 
 
 def main():
@@ -256,6 +269,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, inf.iters, args.prec,
                                                args.cpu_iters, args.amg_theta)
             out["config"]["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if "single_thread" in out["cpu_baseline"]:
+                out["config"]["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["single_thread"]["value"]
         print(json.dumps(out))
     if td is not None:
         td.barrier()

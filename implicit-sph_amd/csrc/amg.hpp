@@ -201,6 +201,106 @@ __global__ void k_mis_decide(int n, unsigned long long *__restrict__ key, const 
   if (votes && (threadIdx.x & 63) == 0) atomicAdd(undecided, __popcll(votes));
 }
 
+// ---- MIS rounds on work lists.  After the first rounds only a few rows are still undecided; a round then needs the
+// neighbourhood maximum t1 only on the rows next to an undecided row and t2 only on the undecided rows themselves.
+// k_mis_decide_list appends the rows it leaves undecided to the next round's list, k_mis_mark collects their
+// neighbourhood (each row once: stamp), and the list kernels read their length from device memory (no extra sync).
+// The lists are filled in atomic order; every value computed from them is order independent.
+constexpr int kMisGrid = 2048;
+
+__global__ __launch_bounds__(256) void k_mis_max_list(const int *__restrict__ cntp, const int *__restrict__ list,
+                                                      const int *__restrict__ rp, const int *__restrict__ sc,
+                                                      const unsigned long long *__restrict__ in,
+                                                      unsigned long long *__restrict__ out) {
+  const int nw = gridDim.x * kAmgWaves, lane = threadIdx.x & 63, cnt = *cntp;
+  for (int w = blockIdx.x * kAmgWaves + (threadIdx.x >> 6); w < cnt; w += nw) {
+    const int i = list[w];
+    unsigned long long m = in[i];
+    for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+      const int j = sc[p];
+      if (j >= 0) { const unsigned long long kj = in[j]; m = kj > m ? kj : m; }
+    }
+    m = wave_max_u64(m);
+    if (lane == 0) out[i] = m;
+  }
+}
+
+constexpr int kMarkBuf = 1024;  // fresh rows a wave collects before it claims list space (one atomic per flush)
+
+__global__ __launch_bounds__(256) void k_mis_mark(const int *__restrict__ cntp, const int *__restrict__ list,
+                                                  const int *__restrict__ rp, const int *__restrict__ sc,
+                                                  int *__restrict__ stamp, int round, int *__restrict__ list1,
+                                                  int *__restrict__ cnt1) {
+  __shared__ int sbuf[kAmgWaves][kMarkBuf];
+  int *buf = sbuf[threadIdx.x >> 6];
+  const int nw = gridDim.x * kAmgWaves, lane = threadIdx.x & 63, cnt = *cntp;
+  int fill = 0;  // wave-uniform
+  auto flush = [&]() {
+    if (fill == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(cnt1, fill);
+    base = __shfl(base, 0, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < fill; k += 64) list1[base + k] = buf[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    fill = 0;
+  };
+  for (int w = blockIdx.x * kAmgWaves + (threadIdx.x >> 6); w < cnt; w += nw) {
+    const int i = list[w];
+    const int lo = rp[i], hi = rp[i + 1];
+    for (int p0 = lo - 1; p0 < hi; p0 += 64) {  // slot lo-1 stands for the row itself
+      const int p = p0 + lane;
+      int j = -1;
+      if (p < hi) j = p < lo ? i : sc[p];
+      bool fresh = false;
+      if (j >= 0 && stamp[j] != round) fresh = atomicExch(&stamp[j], round) != round;
+      const unsigned long long votes = __ballot(fresh);
+      if (votes) {
+        if (fill + 64 > kMarkBuf) flush();
+        if (fresh) buf[fill + __popcll(votes & ((1ull << lane) - 1ull))] = j;
+        fill += __popcll(votes);
+      }
+    }
+  }
+  flush();
+}
+
+// list == nullptr: the identity list 0..n_all-1 (first round)
+__global__ __launch_bounds__(256) void k_mis_decide_list(const int *__restrict__ cntp, const int *__restrict__ list,
+                                                         int n_all, unsigned long long *__restrict__ key,
+                                                         const unsigned long long *__restrict__ t2,
+                                                         int *__restrict__ next, int *__restrict__ nextcnt) {
+  const int total = gridDim.x * blockDim.x, lane = threadIdx.x & 63, cnt = list ? *cntp : n_all;
+  for (int base0 = blockIdx.x * blockDim.x + threadIdx.x - lane; base0 < cnt; base0 += total) {
+    const int idx = base0 + lane;
+    bool und = false;
+    int i = -1;
+    if (idx < cnt) {
+      i = list ? list[idx] : idx;
+      if ((key[i] >> 62) == AMG_UNDECIDED) {
+        const unsigned long long m2 = t2[i];
+        if (m2 == key[i]) key[i] = amg_key(AMG_ROOT, i);
+        else if ((m2 >> 62) == AMG_ROOT) key[i] = amg_key(AMG_COVERED, i);
+        // the largest key within distance 2 belongs to an undecided row m: when m is the largest of ITS distance-2
+        // neighbourhood too (t2[m] == its key == m2) it becomes a root in this very round, and i is covered by it.
+        // (Without this every second round only spreads the "covered" state; the roots are the same either way:
+        // the lexicographically first distance-2 independent set of the priorities.)
+        else if (t2[(int)(m2 & 0x3FFFFFFFull)] == m2) key[i] = amg_key(AMG_COVERED, i);
+        else und = true;
+      }
+    }
+    const unsigned long long votes = __ballot(und);  // every lane takes part in the vote
+    if (votes) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(nextcnt, __popcll(votes));
+      base = __shfl(base, 0, 64);
+      if (und) next[base + __popcll(votes & ((1ull << lane) - 1ull))] = i;
+    }
+  }
+}
+
 __global__ void k_flag_roots(int n, const unsigned long long *__restrict__ key, int *__restrict__ flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) flag[i] = (key[i] >> 62) == AMG_ROOT;
@@ -651,15 +751,21 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   const int n = A.n;
   const double th2 = theta * theta;
   DevBuf<unsigned long long> key, t1, t2;
-  DevBuf<int> flag, id, a1, cnt, scb;
+  DevBuf<int> flag, id, a1, cnt, scb, listA, listB, list1, stamp;
   int rc = key.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = listA.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = listB.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = list1.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS) rc = stamp.reserve((size_t)n);
+  if (rc == ISPH_SUCCESS && hipMemsetAsync(stamp.p, 0, sizeof(int) * (size_t)n, ctx->stream) != hipSuccess)
+    rc = fail("memset failed", __FILE__, __LINE__);
   if (rc == ISPH_SUCCESS) rc = scb.reserve((size_t)(A.nnz > 0 ? A.nnz : 1));
   if (rc == ISPH_SUCCESS) rc = t1.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = t2.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = flag.reserve((size_t)n + 1);
   if (rc == ISPH_SUCCESS) rc = id.reserve((size_t)n + 1);
   if (rc == ISPH_SUCCESS) rc = a1.reserve((size_t)n);
-  if (rc == ISPH_SUCCESS) rc = cnt.reserve(1);
+  if (rc == ISPH_SUCCESS) rc = cnt.reserve(4);
   if (rc == ISPH_SUCCESS) rc = L->agg.reserve((size_t)n);
   const int gw = amg_wave_grid(n), gt = (n + kBlock - 1) / kBlock;
   const int *rp = A.rp.p, *ci = A.ci.p;
@@ -667,15 +773,36 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   if (rc == ISPH_SUCCESS) {
     hipLaunchKernelGGL(k_strong_cols, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, scb.p);
     hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p, key.p);
+    // rounds: t1 = max over the strong neighbourhood, t2 = max of t1 (distance 2), decide.  From the second round on
+    // the sweeps run over work lists (see k_mis_mark)
+    int und = n, cur = 0;
     for (int round = 0; round < 1000 && rc == ISPH_SUCCESS; ++round) {
-      if (hipMemsetAsync(cnt.p, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
-      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
-                         (const unsigned long long *)key.p, t1.p, (const unsigned long long *)nullptr);
-      hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
-                         (const unsigned long long *)t1.p, t2.p, (const unsigned long long *)key.p);
-      hipLaunchKernelGGL(k_mis_decide, dim3(gt), dim3(kBlock), 0, ctx->stream, n, key.p, (const unsigned long long *)t2.p, cnt.p);
-      int und = 0;
-      rc = amg_read_int(ctx, cnt.p, &und);
+      const int *clist = round == 0 ? nullptr : (cur ? listB.p : listA.p);
+      int *nlist = round == 0 ? listA.p : (cur ? listA.p : listB.p);
+      const int *ccnt = cnt.p + cur;
+      int *ncnt = cnt.p + (round == 0 ? 0 : 1 - cur);
+      if (clist && (long long)und * 4 <= n) {
+        if (hipMemsetAsync(cnt.p + 2, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
+        hipLaunchKernelGGL(k_mis_mark, dim3(std::min(kMisGrid, (und + 31) / 32)), dim3(256), 0, ctx->stream, ccnt, clist, rp,
+                           (const int *)scb.p, stamp.p, round, list1.p, cnt.p + 2);
+        hipLaunchKernelGGL(k_mis_max_list, dim3(kMisGrid), dim3(256), 0, ctx->stream, (const int *)(cnt.p + 2),
+                           (const int *)list1.p, rp, (const int *)scb.p, (const unsigned long long *)key.p, t1.p);
+      } else {
+        hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
+                           (const unsigned long long *)key.p, t1.p, (const unsigned long long *)nullptr);
+      }
+      if (clist)
+        hipLaunchKernelGGL(k_mis_max_list, dim3(std::min(kMisGrid, amg_wave_grid(und))), dim3(256), 0, ctx->stream, ccnt, clist,
+                           rp, (const int *)scb.p, (const unsigned long long *)t1.p, t2.p);
+      else
+        hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
+                           (const unsigned long long *)t1.p, t2.p, (const unsigned long long *)key.p);
+      if (hipMemsetAsync(ncnt, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
+      const int nd = clist ? und : n;
+      hipLaunchKernelGGL(k_mis_decide_list, dim3(std::min(kMisGrid, (nd + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                         ccnt, clist, n, key.p, (const unsigned long long *)t2.p, nlist, ncnt);
+      rc = amg_read_int(ctx, ncnt, &und);
+      if (round > 0) cur = 1 - cur;
       if (und == 0) break;
       if (round == 999) rc = fail("MIS did not terminate", __FILE__, __LINE__);
     }
@@ -702,6 +829,7 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("aggregation kernels failed", __FILE__, __LINE__);
   *nagg_out = nroot + nleft;
   key.release(); t1.release(); t2.release(); flag.release(); id.release(); a1.release(); cnt.release(); scb.release();
+  listA.release(); listB.release(); list1.release(); stamp.release();
   return rc;
 }
 

@@ -534,22 +534,37 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
     }
     __syncthreads();
     if ((long long)used + s_nch > cap) return;  // uniform exit; host reports the error
-    if (sched) {
-      const int T = sT[sp], ls = slane[sp], info = sinfo[sp];
-      const int g = (ndep + T - 1) / T;
-      const unsigned needbits = (unsigned)((info >> 1) & 7) << kNeedShift;
-      const long long chunk0 = base + used + choff[sstep[sp]];
-      for (int c = 0; c < T; ++c) {
-        const unsigned endbits = ((c == T - 1) ? kEndBit : 0u) | needbits;
-        for (int q = 0; q < g; ++q) {
-          const int e = c * g + q, lane = ls + q;
-          const long long idx = (chunk0 + c) * 64 + lane;
-          const int segstart = max(ls, lane & ~15);
-          const unsigned flags = endbits | ((unsigned)(lane - segstart) << kPosShift) |
-                                 ((lane >> 4) > (ls >> 4) ? (1u << kContShift) : 0u) |
-                                 (q == g - 1 ? (1u << kTailShift) : 0u) | ((unsigned)t << kRowShift);
-          if (e < ndep) {
-            const long long slot = rp + d0 + e;
+    // ---- emission.  A wave writes the rows of its own 64 threads one after the other, lanes over the row's stream
+    // entries: entry x of a row sits at factor slot rp + d0 + x (consecutive lanes read consecutive slots) and goes to
+    // chunk x / g, lane ls + x % g (runs of g consecutive stream words).  (One thread per row made every access of a
+    // wave hit 64 different cache lines: most of this kernel's time.)
+    {
+      int eT = 0, els = 0, einfo = 0, eg = 0;
+      long long ech0 = 0;
+      if (sched) {
+        eT = sT[sp]; els = slane[sp]; einfo = sinfo[sp];
+        eg = (ndep + eT - 1) / eT;
+        ech0 = base + used + choff[sstep[sp]];
+      }
+      const int lane = t & 63;
+      for (int src = 0; src < 64; ++src) {
+        const int rT = __shfl(eT, src, 64);
+        if (rT == 0) continue;  // row without work in this direction (wave-uniform)
+        const int rls = __shfl(els, src, 64), rinfo = __shfl(einfo, src, 64), rg = __shfl(eg, src, 64);
+        const int rnd = __shfl(ndep, src, 64), rd0 = __shfl(d0, src, 64);
+        const long long rrp = __shfl(rp, src, 64), rch0 = __shfl(ech0, src, 64);
+        const unsigned rowbits = (unsigned)((t & ~63) + src) << kRowShift;
+        const unsigned needbits = (unsigned)((rinfo >> 1) & 7) << kNeedShift;
+        const int tot = rT * rg;
+        for (int x = lane; x < tot; x += 64) {
+          const int c = x / rg, q = x - c * rg, ln = rls + q;
+          const long long idx = (rch0 + c) * 64 + ln;
+          const int segstart = max(rls, ln & ~15);
+          const unsigned flags = ((c == rT - 1) ? kEndBit : 0u) | needbits | ((unsigned)(ln - segstart) << kPosShift) |
+                                 ((ln >> 4) > (rls >> 4) ? (1u << kContShift) : 0u) |
+                                 (q == rg - 1 ? (1u << kTailShift) : 0u) | rowbits;
+          if (x < rnd) {
+            const long long slot = rrp + rd0 + x;
             const int cj = fcol[slot];
             sc[idx] = (unsigned)(cj - blo) | flags;
             fdst[slot] = (int)idx;
@@ -560,12 +575,15 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
             sv[idx] = 0.0;
           }
         }
-        if (info & 1)  // lanes the step does not use
-          for (int lane = (info >> 8) & 127; lane < 64; ++lane) {
-            const long long idx = (chunk0 + c) * 64 + lane;
-            sc[idx] = (kRowInvalid << kRowShift) | endbits;
+        if (rinfo & 1) {  // lanes the step does not use
+          const int first = (rinfo >> 8) & 127, nun = 64 - first;
+          for (int x = lane; x < rT * nun; x += 64) {
+            const int c = x / nun, ln = first + x - c * nun;
+            const long long idx = (rch0 + c) * 64 + ln;
+            sc[idx] = (kRowInvalid << kRowShift) | ((c == rT - 1) ? kEndBit : 0u) | needbits;
             sv[idx] = 0.0;
           }
+        }
       }
     }
     used += s_nch;

@@ -399,3 +399,7 @@ def solve_block(rowptr, colidx, val, b, dim, x0=None, prec="none", ilu=None, amg
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
