@@ -40,6 +40,7 @@ struct AmgLevel {
   isph_mat *Aown = nullptr;  // coarse levels own their SELL matrix
   DCsr P;                    // prolongator (kept in CSR for export)
   isph_mat *Pm = nullptr;
+  isph_mat *APm = nullptr;   // A P of the set-up, kept when the level has no halo: residual update after the coarse correction
   DCsr R;                    // restriction P^T in CSR: its rows are hundreds of entries long, one wave per row
   isph_ilu *sgs = nullptr;   // block-local symmetric Gauss-Seidel in stream form
   DevBuf<int> agg;
@@ -733,6 +734,7 @@ inline void amg_level_destroy(AmgLevel *L) {
   L->A.release(); L->P.release(); L->R.release();
   if (L->Aown) isph_mat_destroy(L->Aown);
   if (L->Pm) isph_mat_destroy(L->Pm);
+  if (L->APm) isph_mat_destroy(L->APm);
   if (L->sgs) ilu_destroy(L->sgs);
   L->agg.release(); L->nv.release(); L->x.release(); L->b.release(); L->r.release(); L->z.release();
   delete L;
@@ -960,6 +962,12 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc == ISPH_SUCCESS && (herr & 2)) rc = fail("AMG: coarse operator row too dense for the SpGEMM table", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, L->P.n, L->P.m, L->P.rp.p, L->P.ci.p, L->P.v.p, L->P.nnz, &L->Pm, /*rows_sorted=*/true);
     if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, Lc->A.n, Lc->A.m, Lc->A.rp.p, Lc->A.ci.p, Lc->A.v.p, Lc->A.nnz, &Lc->Aown);
+    // without ghost columns A (x + P e) = A x + (A P) e: the cycle updates the residual with the product already at hand
+    // (a fifth of A's entries) instead of a second sweep over A
+    if (rc == ISPH_SUCCESS && (L->Am->S.ncol == L->Am->S.nrow || L->Am->local)) {
+      rc = mat_from_device_csr(ctx, AP.n, AP.m, AP.rp.p, AP.ci.p, AP.v.p, AP.nnz, &L->APm, /*rows_sorted=*/true);
+      if (rc == ISPH_SUCCESS) L->APm->local = true;
+    }
     AP.release();
     if (rc != ISPH_SUCCESS) { amg_level_destroy(Lc); break; }
     L->Pm->local = Lc->Aown->local = true;
@@ -1037,10 +1045,21 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const int *)L->R.rp.p,
                      (const int *)L->R.ci.p, (const double *)L->R.v.p, (const double *)L->r.p, Lc->b.p);
   ISPH_CHECK(amg_vcycle(ctx, G, l + 1, Lc->b.p, Lc->x.p));
-  ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, L->r.p, nullptr));
+  ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, L->z.p, nullptr));
   hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
-                     (const double *)L->r.p, x);
-  for (int s = 0; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
+                     (const double *)L->z.p, x);
+  int first = 0;
+  if (L->APm) {
+    // r still holds b - A x of before the correction: r -= (A P) e, then the first post-smoothing sweep uses it
+    ISPH_CHECK(spmv_dev(ctx, L->APm, Lc->x.p, L->z.p, nullptr));
+    hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, -1.0, (const double *)nullptr,
+                       (const double *)L->z.p, L->r.p);
+    ISPH_CHECK(ilu_apply(ctx, L->sgs, L->r.p, L->z.p));
+    hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
+                       (const double *)L->z.p, x);
+    first = 1;
+  }
+  for (int s = first; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
   return ISPH_SUCCESS;
 }
 

@@ -94,13 +94,14 @@ def _worker(rank, world, port, pgrid, dim, n, out):
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize("dim,pgrid,n", [(2, (2, 1, 1), 8), (3, (2, 1, 1), 6), (2, (1, 2, 1), 8)])
+@pytest.mark.parametrize("dim,pgrid,n", [(2, (2, 1, 1), 8), (3, (2, 1, 1), 6), (2, (1, 2, 1), 8),
+                                         (3, (2, 2, 1), 6), (3, (2, 2, 2), 6)])   # bench.py's 4- and 8-GPU brick grids
 def test_two_rank_bricks_match_single_rank(dim, pgrid, n):
     import scipy.sparse as sps
     import scipy.sparse.linalg as spla
     from isph_amd import workload
     import oracle as orc
-    world = 2
+    world = int(np.prod(pgrid))
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
