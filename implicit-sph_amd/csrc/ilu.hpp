@@ -332,10 +332,9 @@ __global__ __launch_bounds__(1024) void k_iluk_block_offsets(int nblocks, const 
 // entries through them, so a step of rows with 5..50 dependencies fills the 64
 // lanes instead of padding every row to the longest one.  Rows of a level are
 // taken longest first; a step grows while its chunk count T stays, or -- when the
-// next row would raise T -- while it is less than 90 % full and stays at least
-// half full afterwards (on the production 3-D matrices this greedy rule reaches
-// the optimal consecutive partition: 1.18 x the entry count instead of 1.73 x for
-// fixed 8-lane groups; scripts/ilu_pack_model.py).
+// next row would raise T -- while it stays at least half full afterwards (on the
+// production 3-D matrices: 1.21 x the entry count instead of 1.73 x for fixed
+// 8-lane groups, and one step per level; scripts/ilu_pack_model.py, ilu_pack_model2.py).
 //   word = local column (11 bits) | local row << 11 | TAIL << 22 | CONT << 23 | p << 24 | need << 28 | END << 31
 // END: last chunk of the step (wave-uniform).  The step ends with a segmented
 // scan in registers: p = distance of the lane from the start of its row's lanes
@@ -502,8 +501,10 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
               lanes2 = 0;
               for (int q = a; q <= e; ++q) lanes2 += (sd[sp + q] + T2 - 1) / T2;
             } while (lanes2 > 64);
-            // a higher chunk count is accepted only while the step is < 90 % full and stays >= 50 % full
-            if (!(10 * S < 9 * 64 * T && 2 * (S + de) >= 64 * T2)) break;
+            // a higher chunk count is accepted while the step stays >= 50 % full: a level then nearly always is ONE
+            // step (the solve is bound by the number of steps, each ends in a scan, as much as by the stream bytes:
+            // 300 -> 175 steps per block for 3 % more chunks; scripts/ilu_pack_model2.py)
+            if (!(2 * (S + de) >= 64 * T2)) break;
           }
           T = T2; lanes = lanes2; S += de; ++e;
         }
