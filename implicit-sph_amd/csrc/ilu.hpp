@@ -35,7 +35,9 @@ struct isph_ilu {
   isph::DevBuf<int> fcol, flen, fdiag, err;
   isph::DevBuf<double> fval;
   isph::DevBuf<double> sv;        // chunk stream values   [nchunks*64]
-  isph::DevBuf<unsigned> sc;      // chunk stream words
+  isph::DevBuf<unsigned short> sc;  // chunk stream words (16 bit per entry)
+  isph::DevBuf<unsigned char> si;   // one byte per chunk: END | need << 1
+  isph::DevBuf<unsigned short> sperm;  // [nblocks][2][B] rows of a block in stream order (L, U)
   isph::DevBuf<int> fdst;         // factor entry -> stream index (-1: diagonal)
   isph::DevBuf<int> blkinfo;      // [nblocks][2] chunks in the L / U stream
   isph::DevBuf<int> llev;         // [n] L-level of every row (level-synchronous factorisation)
@@ -335,20 +337,21 @@ __global__ __launch_bounds__(1024) void k_iluk_block_offsets(int nblocks, const 
 // next row would raise T -- while it stays at least half full afterwards (on the
 // production 3-D matrices: 1.21 x the entry count instead of 1.73 x for fixed
 // 8-lane groups, and one step per level; scripts/ilu_pack_model.py, ilu_pack_model2.py).
-//   word = local column (11 bits) | local row << 11 | TAIL << 22 | CONT << 23 | p << 24 | need << 28 | END << 31
-// END: last chunk of the step (wave-uniform).  The step ends with a segmented
-// scan in registers: p = distance of the lane from the start of its row's lanes
-// inside its 16-lane DPP row (row_shr:1,2,4,8 add when p >= shift), CONT = the
-// row's lanes began in the previous DPP row (row_bcast:15 carries the partial sum
-// over, DPP row by DPP row; `need` says which of the three carries the step
-// uses), TAIL = last lane of the row: it holds the row's sum and updates y.
+//   word (16 bit) = local column (10 bits) | TAIL << 10 | CONT << 11 | p << 12      per entry
+//   info (8 bit)  = END | need << 1                                                per chunk
+// END: last chunk of the step.  The step ends with a segmented scan in registers: p = distance of the lane from
+// the start of its row's lanes inside its 16-lane DPP row (row_shr:1,2,4,8 add when p >= shift), CONT = the row's
+// lanes began in the previous DPP row (row_bcast:15 carries the partial sum over, DPP row by DPP row; `need` says
+// which of the three carries the step uses), TAIL = last lane of the row: it holds the row's sum and updates y.
+// Which row a TAIL lane belongs to is not stored per entry: the rows appear in the stream in the order of the
+// schedule's sorted positions, so the k-th TAIL lane of a direction belongs to row sperm[k] (a 2 x B table of 16-bit
+// row numbers per block that the solve keeps in LDS, with a running count of the rows done).  10 B per stream entry
+// instead of 12: the solve is bound by the stream bytes as much as by its dependency chain.
 // Per chunk one fma against y in LDS; no flags, no waiting.
 // Every step is at least half full or one chunk long, so a block never needs more
 // than (entries/32 + rows per direction) chunks: capacity = 2 x its sliced-ELL
 // region + 2 B, checked by the kernel all the same.
-constexpr unsigned kRowInvalid = 0x7FFu;
-constexpr int kRowShift = 11, kTailShift = 22, kContShift = 23, kPosShift = 24, kNeedShift = 28;
-constexpr unsigned kEndBit = 0x80000000u;
+constexpr int kTail16 = 10, kCont16 = 11, kPos16 = 12;
 constexpr int kPrefetch = 16;     // chunks kept in flight per wave (default; ISPH_ILU_PREFETCH picks 8/12/16/24)
 constexpr int kPadChunks = 32;    // per-block tail pad so the prefetch never leaves the buffer (>= deepest prefetch)
 constexpr int kCapFactor = 2;
@@ -369,7 +372,8 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        const long long *__restrict__ frp,
                                                        const int *__restrict__ fcol, const int *__restrict__ flen,
                                                        const int *__restrict__ fdiag, double *__restrict__ sv,
-                                                       unsigned *__restrict__ sc, int *__restrict__ fdst,
+                                                       unsigned short *__restrict__ sc, unsigned char *__restrict__ si,
+                                                       unsigned short *__restrict__ sperm, int *__restrict__ fdst,
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
                                                        int ccap, int capf, int slack, int *__restrict__ err,
                                                        const double *__restrict__ sgs_fval,
@@ -388,7 +392,8 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   int *sstep = sinfo + B;        // [B] step index
   int *slen = sstep + B;         // [B] row length / diagonal slot / first entry, for the level walk
   int *sdg = slen + B;           // [B]
-  long long *srp = reinterpret_cast<long long *>(sdg + B + (B & 1));  // [B]
+  int *spos = sdg + B;           // [B] position of a row in the current direction's solve order
+  long long *srp = reinterpret_cast<long long *>(spos + B + (B & 1));  // [B]
   __shared__ int s_nlev, s_nsched, s_nch;
   const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   const int t = threadIdx.x;
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
     __syncthreads();
     const bool sched = active && mylev > 0;
     int rk = 0;
-    if (sched) {
+    if (active) {  // rows without dependencies (level 0) are ranked too: they take the positions behind the stream's rows
       const int mykey = skey[t];
       for (int q = 0; q < m; ++q) {
         const int kq = skey[q];
@@ -478,10 +483,15 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
       int run = 0;
       for (int l = 1; l < s_nlev; ++l) { lvoff[l] = run; run += cnt[l]; }
       s_nsched = run;
+      lvoff[0] = run;
     }
     __syncthreads();
-    const int sp = sched ? lvoff[mylev] + rk : 0;
+    const int sp = active ? lvoff[mylev] + rk : 0;  // position of the row in this direction's solve order
     if (sched) sd[sp] = ndep;
+    if (active) {
+      spos[t] = sp;
+      sperm[((size_t)b * 2 + dir) * B + t] = (unsigned short)sp;
+    }
     __syncthreads();
     // ---- steps: the first row of every run of 64 ranks packs its run greedily
     if (sched && (rk & 63) == 0) {
@@ -530,7 +540,8 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
         sstep[q] = step;
       }
       s_nch = run;
-      blkinfo[2 * b + dir] = run;
+      blkinfo[4 * b + dir] = run;
+      blkinfo[4 * b + 2 + dir] = s_nsched;
       if ((long long)used + run > cap) atomicOr(err, 16);  // stream capacity exceeded
     }
     __syncthreads();
@@ -554,34 +565,33 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
         const int rls = __shfl(els, src, 64), rinfo = __shfl(einfo, src, 64), rg = __shfl(eg, src, 64);
         const int rnd = __shfl(ndep, src, 64), rd0 = __shfl(d0, src, 64);
         const long long rrp = __shfl(rp, src, 64), rch0 = __shfl(ech0, src, 64);
-        const unsigned rowbits = (unsigned)((t & ~63) + src) << kRowShift;
-        const unsigned needbits = (unsigned)((rinfo >> 1) & 7) << kNeedShift;
         const int tot = rT * rg;
         for (int x = lane; x < tot; x += 64) {
           const int c = x / rg, q = x - c * rg, ln = rls + q;
           const long long idx = (rch0 + c) * 64 + ln;
           const int segstart = max(rls, ln & ~15);
-          const unsigned flags = ((c == rT - 1) ? kEndBit : 0u) | needbits | ((unsigned)(ln - segstart) << kPosShift) |
-                                 ((ln >> 4) > (rls >> 4) ? (1u << kContShift) : 0u) |
-                                 (q == rg - 1 ? (1u << kTailShift) : 0u) | rowbits;
+          const unsigned flags = ((unsigned)(ln - segstart) << kPos16) | ((ln >> 4) > (rls >> 4) ? (1u << kCont16) : 0u) |
+                                 (q == rg - 1 ? (1u << kTail16) : 0u);
           if (x < rnd) {
             const long long slot = rrp + rd0 + x;
             const int cj = fcol[slot];
-            sc[idx] = (unsigned)(cj - blo) | flags;
+            sc[idx] = (unsigned short)((unsigned)spos[cj - blo] | flags);
             fdst[slot] = (int)idx;
             // Gauss-Seidel mode: the stream values are A's own entries (L part scaled by the column's pivot)
             if (sgs_dinv) sv[idx] = dir == 0 ? sgs_fval[slot] * sgs_dinv[cj] : sgs_fval[slot];
           } else {
-            sc[idx] = flags;
+            sc[idx] = (unsigned short)flags;
             sv[idx] = 0.0;
           }
         }
-        if (rinfo & 1) {  // lanes the step does not use
+        if (rinfo & 1) {  // first row of its step: the chunk info bytes and the lanes the step does not use
+          const unsigned need = (unsigned)((rinfo >> 1) & 7);
+          for (int c = lane; c < rT; c += 64) si[rch0 + c] = (unsigned char)((c == rT - 1 ? 1u : 0u) | (need << 1));
           const int first = (rinfo >> 8) & 127, nun = 64 - first;
           for (int x = lane; x < rT * nun; x += 64) {
             const int c = x / nun, ln = first + x - c * nun;
             const long long idx = (rch0 + c) * 64 + ln;
-            sc[idx] = (kRowInvalid << kRowShift) | ((c == rT - 1) ? kEndBit : 0u) | needbits;
+            sc[idx] = 0;  // position 0, not a TAIL: adds 0 * y[0] to a sum nobody reads
             sv[idx] = 0.0;
           }
         }
@@ -753,80 +763,102 @@ template <int WAVES, int PF>
 __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, int nblocks,
                                                                  const long long *__restrict__ boff,
                                                                  const double *__restrict__ sv,
-                                                                 const unsigned *__restrict__ sc,
+                                                                 const unsigned short *__restrict__ sc,
+                                                                 const unsigned char *__restrict__ si,
+                                                                 const unsigned short *__restrict__ sperm,
                                                                  const int *__restrict__ blkinfo,
-                                                                 const int *__restrict__ flen,
-                                                                 const int *__restrict__ fdiag,
                                                                  const double *__restrict__ dinv,
                                                                  const double *__restrict__ r, double *__restrict__ z,
                                                                  int capf, int slack) {
   extern __shared__ double lds_y[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * WAVES + wave;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);  // wave-uniform: keep what follows scalar
   if (b >= nblocks) return;
-  double *y = lds_y + (size_t)wave * 2 * B;
-  double *dv = y + B;  // reciprocal pivots of the block: the U steps must not wait on a global load each
-  const int blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
-  for (int t = lane; t < m; t += 64) { y[t] = r[blo + t]; dv[t] = dinv[blo + t]; }
+  // per wave: y in the L solve's row order, y in the U solve's row order, the reciprocal pivots in U order (the U
+  // steps must not wait on a global load each)
+  double *yl = lds_y + (size_t)wave * 3 * B;
+  double *yu = yl + B;
+  double *dv = yu + B;
+  const int blo = b * B, m = min(blo + B, n) - blo;
+  const unsigned short *__restrict__ posl = sperm + (size_t)b * 2 * B;  // row -> position in the L / U order
+  const unsigned short *__restrict__ posu = posl + B;
+  for (int t = lane; t < m; t += 64) {
+    yl[posl[t]] = r[blo + t];
+    dv[posu[t]] = dinv[blo + t];
+  }
   const long long base = ilu_base_chunk(boff, b, capf, slack);
-  const int nL = blkinfo[2 * b], nU = blkinfo[2 * b + 1];
+  const int nL = __builtin_amdgcn_readfirstlane(blkinfo[4 * b]), nU = __builtin_amdgcn_readfirstlane(blkinfo[4 * b + 1]);
+  const int nsU = __builtin_amdgcn_readfirstlane(blkinfo[4 * b + 3]);  // rows the U stream completes
   const double *__restrict__ pv = sv + base * 64 + lane;
-  const unsigned *__restrict__ pc = sc + base * 64 + lane;
+  const unsigned short *__restrict__ pc = sc + base * 64 + lane;
+  const unsigned char *__restrict__ pi = si + base;
+  const unsigned long long below = (1ull << lane) - 1ull;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   double vq[PF];
-  unsigned cq[PF];
+  unsigned cq[PF], iq[PF];
   const int ntot = nL + nU;
 #pragma unroll
   for (int u = 0; u < PF; ++u) {  // non-temporal: the stream is read once per apply
     vq[u] = __builtin_nontemporal_load(&pv[(long long)u * 64]);
     cq[u] = __builtin_nontemporal_load(&pc[(long long)u * 64]);
+    iq[u] = pi[u];
   }
+  // L -> U: the rows change places (U order), rows without upper dependencies are finished by their pivot
+  auto to_upper = [&]() {
+    for (int t = lane; t < m; t += 64) yu[posu[t]] = yl[posl[t]];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = nsU + lane; t < m; t += 64) yu[t] *= dv[t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   double acc = 0.0;
   bool upper = false;
+  int done = 0;      // rows of the current direction finished so far (wave-uniform)
+  double *y = yl;
   for (int c0 = 0; c0 < ntot; c0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int c = c0 + u;
       const double v = vq[u];
       const unsigned cw = cq[u];
+      const unsigned iw = __builtin_amdgcn_readfirstlane(iq[u]);
       vq[u] = __builtin_nontemporal_load(&pv[(long long)(c + PF) * 64]);  // stays inside the padded buffer
       cq[u] = __builtin_nontemporal_load(&pc[(long long)(c + PF) * 64]);
+      iq[u] = pi[c + PF];
       if (c < ntot) {
         if (c == nL && !upper) {
-          // switch to the U phase: rows without upper dependencies finish here
           upper = true;
-          for (int t = lane; t < m; t += 64)
-            if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dv[t];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
+          done = 0;
+          to_upper();
+          y = yu;
         }
-        acc = fma(v, y[cw & 0x7FFu], acc);
-        const unsigned cw0 = __builtin_amdgcn_readfirstlane(cw);
-        if (cw0 & kEndBit) {
-          // the row's current value and pivot are fetched before the scan, not after it: they do not depend on it,
-          // and this kernel is bound by the length of the per-step dependency chain (a quarter of the blocks take
-          // as long as all of them), not by bandwidth
-          const unsigned row = (cw >> kRowShift) & 0x7FFu;
-          const bool tail = (cw >> kTailShift) & 1u;
-          const unsigned rsafe = tail ? row : 0u;
-          const double yold = y[rsafe];
-          const double dvr = upper ? dv[rsafe] : 1.0;
+        acc = fma(v, y[cw & 0x3FFu], acc);
+        if (iw & 1u) {
+          // the k-th TAIL lane of a direction finishes the row at position k of that direction's order: no look-up.
+          // The row's current value and pivot are fetched before the scan, not after it: they do not depend on it
+          const bool tail = (cw >> kTail16) & 1u;
+          const unsigned long long tails = __ballot(tail);
+          const int pos = tail ? done + __popcll(tails & below) : 0;
+          done += __popcll(tails);
+          const double yold = y[pos];
+          const double dvr = upper ? dv[pos] : 1.0;
           // segmented inclusive scan towards the last lane of every row (see k_ilu_schedule)
-          const int p = (cw >> kPosShift) & 15;
+          const int p = (cw >> kPos16) & 15;
           double s = acc, q;
           q = dpp_move<0x111>(s); s += p >= 1 ? q : 0.0;  // row_shr:1
           q = dpp_move<0x112>(s); s += p >= 2 ? q : 0.0;  // row_shr:2
           q = dpp_move<0x114>(s); s += p >= 4 ? q : 0.0;  // row_shr:4
           q = dpp_move<0x118>(s); s += p >= 8 ? q : 0.0;  // row_shr:8
-          const unsigned need = (cw0 >> kNeedShift) & 7u;  // wave-uniform
+          const unsigned need = (iw >> 1) & 7u;  // wave-uniform
           if (need) {
-            const bool cont = (cw >> kContShift) & 1u;
+            const bool cont = (cw >> kCont16) & 1u;
             if (need & 1u) { q = dpp_move<0x142, 0x2>(s); s += cont ? q : 0.0; }  // lane 15 -> DPP row 1
             if (need & 2u) { q = dpp_move<0x142, 0x4>(s); s += cont ? q : 0.0; }  // lane 31 -> DPP row 2
             if (need & 4u) { q = dpp_move<0x142, 0x8>(s); s += cont ? q : 0.0; }  // lane 47 -> DPP row 3
           }
-          if (tail) y[row] = (yold - s) * dvr;
+          if (tail) y[pos] = (yold - s) * dvr;
           acc = 0.0;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -834,13 +866,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
       }
     }
   }
-  if (!upper) {  // no U chunks at all (or empty stream): still scale the rows without upper deps
-    for (int t = lane; t < m; t += 64)
-      if (fdiag[blo + t] == flen[blo + t] - 1) y[t] *= dv[t];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  for (int t = lane; t < m; t += 64) z[blo + t] = y[t];
+  if (!upper) to_upper();  // no U chunks at all (or an empty stream)
+  for (int t = lane; t < m; t += 64) z[blo + t] = yu[posu[t]];
 }
 
 // ---------------------------------------------------------------------------
@@ -848,7 +875,7 @@ inline void ilu_destroy(isph_ilu *F) {
   if (!F) return;
   F->frp.release(); F->fcol.release(); F->flen.release(); F->fdiag.release(); F->err.release(); F->fval.release();
   F->boff.release(); F->flev.release();
-  F->sv.release(); F->sc.release(); F->fdst.release(); F->blkinfo.release(); F->dinv.release(); F->llev.release();
+  F->sv.release(); F->sc.release(); F->si.release(); F->sperm.release(); F->fdst.release(); F->blkinfo.release(); F->dinv.release(); F->llev.release();
   delete F;
 }
 
@@ -951,6 +978,7 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
     F->stream_chunks = F->capf * (F->total >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
     int r = F->sv.reserve((size_t)F->stream_chunks * 64);
     if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
+    if (r == ISPH_SUCCESS) r = F->si.reserve((size_t)F->stream_chunks + 64);
     if (r == ISPH_SUCCESS && (long long)F->stream_chunks * 64 >= 2147483647LL)
       r = fail("ILU stream exceeds 32-bit indexing", __FILE__, __LINE__);
     return r;
@@ -964,7 +992,8 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   if (rc == ISPH_SUCCESS) rc = F->llev.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->err.reserve(1);
   if (rc == ISPH_SUCCESS) rc = F->boff.reserve((size_t)F->nblocks + 1);
-  if (rc == ISPH_SUCCESS) rc = F->blkinfo.reserve((size_t)2 * (F->nblocks > 0 ? F->nblocks : 1));
+  if (rc == ISPH_SUCCESS) rc = F->blkinfo.reserve((size_t)4 * (F->nblocks > 0 ? F->nblocks : 1));
+  if (rc == ISPH_SUCCESS) rc = F->sperm.reserve((size_t)2 * block_size * (F->nblocks > 0 ? F->nblocks : 1));
   if (rc == ISPH_SUCCESS && S.nrow > 0) {
     const size_t Bz = (size_t)block_size;
     if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
@@ -994,14 +1023,14 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       if (sgs)  // pivots first: the schedule writes the Gauss-Seidel stream values itself
         hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
                            F->fval.p, F->fdiag.p, F->dinv.p);
-      const size_t lds_s = sizeof(int) * (13 * Bz + 10) + sizeof(long long) * Bz;
+      const size_t lds_s = sizeof(int) * (14 * Bz + 10) + sizeof(long long) * Bz;
       const int ccap = 0;  // (kept in the signature: the level walk no longer caches columns in LDS)
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_s) != hipSuccess)
         rc = fail("LDS attribute failed", __FILE__, __LINE__);
       for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
         hipLaunchKernelGGL(k_ilu_schedule, dim3(F->nblocks), dim3(block_size), lds_s, ctx->stream, S.nrow, block_size,
-                           F->boff.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->fdst.p,
+                           F->boff.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p,
                            F->blkinfo.p, F->llev.p, ccap, F->capf, F->slack, F->err.p,
                            sgs ? (const double *)F->fval.p : (const double *)nullptr,
                            sgs ? (const double *)F->dinv.p : (const double *)nullptr);
@@ -1037,12 +1066,17 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
   if (F->n == 0) return ISPH_SUCCESS;
   constexpr int WV = 4;
-  const size_t lds = sizeof(double) * 2 * (size_t)F->B * WV;
+  const size_t lds = sizeof(double) * 3 * (size_t)F->B * WV;
   static const int pf = []() { const char *e = getenv("ISPH_ILU_PREFETCH"); return e ? atoi(e) : kPrefetch; }();
 #define ISPH_ILU_LAUNCH(PF)                                                                                             \
-  hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream,   \
-                     F->n, F->B, F->nblocks, F->boff.p, F->sv.p, F->sc.p, F->blkinfo.p, F->flen.p, F->fdiag.p, \
-                     F->dinv.p, r, z, F->capf, F->slack)
+  do {                                                                                                                   \
+    if (lds > 48 * 1024)                                                                                                 \
+      ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_solve_stream<WV, PF>),                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
+    hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, \
+                       F->n, F->B, F->nblocks, F->boff.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->blkinfo.p,          \
+                       F->dinv.p, r, z, F->capf, F->slack);                                                             \
+  } while (0)
   if (pf == 12) ISPH_ILU_LAUNCH(12);
   else if (pf == 16) ISPH_ILU_LAUNCH(16);
   else if (pf == 24) ISPH_ILU_LAUNCH(24);

@@ -439,11 +439,11 @@ int isph_prec_info(isph_ctx *ctx, const isph_prec *M, long long info[4]) {
   info[0] = info[1] = info[2] = info[3] = 0;
   if (M->type != 2 || !M->ilu) return ISPH_SUCCESS;
   const isph_ilu *F = M->ilu;
-  std::vector<int> bi((size_t)2 * F->nblocks);
+  std::vector<int> bi((size_t)4 * F->nblocks);  // per block: chunks of the L / U stream, rows in the L / U stream
   ISPH_CHECK_HIP(hipMemcpyAsync(bi.data(), F->blkinfo.p, sizeof(int) * bi.size(), hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   long long used = 0;
-  for (int v : bi) used += v;
+  for (size_t b = 0; b < (size_t)F->nblocks; ++b) used += bi[4 * b] + bi[4 * b + 1];
   info[0] = ilu_nnz(F); info[1] = used; info[2] = F->stream_chunks; info[3] = F->nblocks;
   return ISPH_SUCCESS;
 }
