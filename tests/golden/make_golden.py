@@ -60,6 +60,8 @@ def build():
     ilu = orc.ILU(rp, ci, val, 0, bp)
     frp, fci, fv = ilu.export()
     data["ilu_val"] = fv
+    f1rp, f1ci, f1v = orc.ILU(rp, ci, val, 1, bp).export()      # "fact: level-of-fill" = 1, the reference's default
+    data["ilu1_rowptr"], data["ilu1_colidx"], data["ilu1_val"] = f1rp, f1ci, f1v
     xs, info, _ = orc.solve(rp, ci, val, b, singular=False, prec="ilu", ilu=ilu)
     data["x"], data["iters"] = xs, np.array([info.iters])
     amg = orc.AMG(rp, ci, val, theta=0.05, block=64, coarse_max=16)

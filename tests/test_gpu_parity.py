@@ -851,6 +851,9 @@ def test_gpu_matches_committed_golden_fixture(gpu_ctx):
         if antisym:
             M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 64)
             assert np.max(np.abs(M.export_ilu()[2] - G["ilu_val"])) <= 1e-10 * np.abs(G["ilu_val"]).max()
+            g1rp, g1ci, g1v = hip.Precond(gpu_ctx, A, "bjacobi-ilu1", 64).export_ilu()   # level-of-fill pattern: exact
+            assert np.array_equal(g1rp, G["ilu1_rowptr"]) and np.array_equal(g1ci, G["ilu1_colidx"])
+            assert np.max(np.abs(g1v - G["ilu1_val"])) <= 1e-10 * np.abs(G["ilu1_val"]).max()
             xs = np.zeros(pr.n)
             info = hip.solve(gpu_ctx, A, bg.copy(), xs, prec=M)
             assert info.converged == 1 and abs(info.iters - int(G["iters"][0])) <= 1

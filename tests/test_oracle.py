@@ -336,6 +336,9 @@ def test_oracle_reproduces_committed_golden_fixture():
     bp = np.arange(0, pr.n + 64, 64).clip(0, pr.n).astype(np.int32)
     ilu = orc.ILU(rp, ci, val, 0, bp)
     assert np.max(np.abs(ilu.export()[2] - G["ilu_val"])) <= 1e-12 * np.abs(G["ilu_val"]).max()
+    f1rp, f1ci, f1v = orc.ILU(rp, ci, val, 1, bp).export()
+    assert np.array_equal(f1rp, G["ilu1_rowptr"]) and np.array_equal(f1ci, G["ilu1_colidx"])
+    assert np.max(np.abs(f1v - G["ilu1_val"])) <= 1e-12 * np.abs(G["ilu1_val"]).max()
     x, info, _ = orc.solve(rp, ci, val, b, singular=False, prec="ilu", ilu=ilu)
     assert info.iters == int(G["iters"][0]) and np.linalg.norm(x - G["x"]) <= 1e-9 * np.linalg.norm(G["x"])
     amg = orc.AMG(rp, ci, val, theta=0.05, block=64, coarse_max=16)
