@@ -30,20 +30,19 @@
 
 struct isph_ilu {
   int n = 0, B = 0, nblocks = 0, wmax = 0;
-  const isph::Sell *S = nullptr;  // geometry shared with A (A must outlive the factor)
   isph::DevBuf<long long> frp;    // [n] first entry of row i in fcol/fval
   isph::DevBuf<int> fcol, flen, fdiag, err;
   isph::DevBuf<double> fval;
   isph::DevBuf<double> sv;        // chunk stream values   [nchunks*64]
   isph::DevBuf<unsigned short> sc;  // chunk stream words (16 bit per entry)
   isph::DevBuf<unsigned char> si;   // one byte per chunk: END | need << 1
-  isph::DevBuf<unsigned short> sperm;  // [nblocks][2][B] rows of a block in stream order (L, U)
+  isph::DevBuf<unsigned short> sperm;  // [nblocks][2][B] row -> position in the solve order of the L / U direction
   isph::DevBuf<int> fdst;         // factor entry -> stream index (-1: diagonal)
-  isph::DevBuf<int> blkinfo;      // [nblocks][2] chunks in the L / U stream
+  isph::DevBuf<int> blkinfo;      // [nblocks][4] chunks in the L / U stream, rows the L / U stream completes
   isph::DevBuf<int> llev;         // [n] L-level of every row (level-synchronous factorisation)
   isph::DevBuf<double> dinv;      // [n] 1/d_i
   isph::DevBuf<long long> boff;   // [nblocks+1] first factor entry of every block (multiples of 64)
-  isph::DevBuf<unsigned char> flev;  // level of fill of every factor entry (ILU(k), k > 0 only)
+  isph::DevBuf<unsigned char> flev;  // level of fill of every factor entry (ILU(k) symbolic phase only)
   long long stream_chunks = 0;
   long long total = 0;      // entries reserved for the factor (ILU(0): A's sliced-ELL size; ILU(k): sum of the blocks)
   int fill = 0;             // level of fill
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        unsigned short *__restrict__ sc, unsigned char *__restrict__ si,
                                                        unsigned short *__restrict__ sperm, int *__restrict__ fdst,
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
-                                                       int ccap, int capf, int slack, int *__restrict__ err,
+                                                       int capf, int slack, int *__restrict__ err,
                                                        const double *__restrict__ sgs_fval,
                                                        const double *__restrict__ sgs_dinv) {
   extern __shared__ int lds_i[];
@@ -960,6 +959,7 @@ inline int ilu_symbolic(isph_ctx *ctx, isph_ilu *F, int K) {
     F->wmax = wmax;
   }
   nlen.release(); inoff.release(); blktot.release(); meta.release();
+  F->flev.release();  // only the symbolic sweeps need the levels
   return rc;
 }
 
@@ -969,7 +969,7 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
                "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && !(sgs && fill), "level of fill must be in [0,8]");
   isph_ilu *F = new isph_ilu();
-  F->n = S.nrow; F->B = block_size; F->S = &S; F->wmax = S.wmax; F->fill = fill;
+  F->n = S.nrow; F->B = block_size; F->wmax = S.wmax; F->fill = fill;
   F->nblocks = (S.nrow + block_size - 1) / block_size;
   F->total = S.stored;
   const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
@@ -1024,14 +1024,13 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
         hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
                            F->fval.p, F->fdiag.p, F->dinv.p);
       const size_t lds_s = sizeof(int) * (14 * Bz + 10) + sizeof(long long) * Bz;
-      const int ccap = 0;  // (kept in the signature: the level walk no longer caches columns in LDS)
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_s) != hipSuccess)
         rc = fail("LDS attribute failed", __FILE__, __LINE__);
       for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
         hipLaunchKernelGGL(k_ilu_schedule, dim3(F->nblocks), dim3(block_size), lds_s, ctx->stream, S.nrow, block_size,
                            F->boff.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p,
-                           F->blkinfo.p, F->llev.p, ccap, F->capf, F->slack, F->err.p,
+                           F->blkinfo.p, F->llev.p, F->capf, F->slack, F->err.p,
                            sgs ? (const double *)F->fval.p : (const double *)nullptr,
                            sgs ? (const double *)F->dinv.p : (const double *)nullptr);
         // the factor kernel must not run on a partial schedule: check now (one sync per build)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC counters of one kernel of the default bench (tuning aid).  usage on the GPU box: bash scripts/pmc_kernel.sh "<counters>" tag kernel-substring [bench args]
+set -o pipefail
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+C=$1; T=$2; K=$3; shift 3
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_k_$T -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc_k_$T.log 2>&1 || { tail -5 $OUT/pmc_k_$T.log; exit 1; }
+F=$(ls -t $OUT/pmc_k_$T/*/*counter_collection.csv | head -1)
+python3 - "$F" "$K" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(sys.argv[1])):
+    if sys.argv[2] in r["Kernel_Name"]:
+        a = acc[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+for k, (n, v) in sorted(acc.items()):
+    print("%-28s launches=%4d avg=%16.1f" % (k, n, v / n))
+PY
