@@ -409,6 +409,9 @@ __global__ void k_pack_particles(int nall, const double *__restrict__ x, const d
 
 // One lane per row.  filt = (Fluid, filt_j) per the singular mode
 // (functor_incomp_navier_stokes_poisson.h:70-86); alpha = -dt; material = 1/rho.
+// DIMT / FAM: 0 / -1 = read dimension and operator family at run time; 3 / 1 = the production case (3-D,
+// AntiSymmetric family: G = L = I) compiled with both known, so the correction-tensor loops fold away.
+template <int DIMT, int FAM>
 __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs a,
                                                         const long long *__restrict__ slice_off,
                                                         int *__restrict__ scol, double *__restrict__ sval,
@@ -426,7 +429,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
     }
     return;
   }
-  const int dim = T.dim, nt1 = T.ntypes + 1, dL = dim * (dim + 1) / 2;
+  const int dim = DIMT ? DIMT : T.dim, nt1 = T.ntypes + 1, dL = dim * (dim + 1) / 2;
+  const bool antisym = FAM < 0 ? (a.antisym != 0) : (FAM != 0);
   const int it = a.type[i], ikind = T.kind[it];
   const long long off = slice_off[i >> 6];
   const int w = (int)((slice_off[(i >> 6) + 1] - off) >> 6);
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   } else {
     double G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, L[6] = {1, 0, 1, 0, 0, 1};
     if (dim == 2) { G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 1; L[0] = 1; L[1] = 0; L[2] = 1; }
-    if (!a.antisym) {
+    if (!antisym) {
       for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
       for (int k = 0; k < dL; ++k) L[k] = a.Lc[(size_t)i * dL + k];
     }
@@ -518,18 +522,23 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
       for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
-      const double vfrac = a.antisym ? sqrt(vi * q1.w) : q1.w;
+      const double vfrac = antisym ? sqrt(vi * q1.w) : q1.w;
       const double vjtmp = dwdr * vfrac;
       for (int k2 = 0; k2 < dim; ++k2) {
         double gitmp = 0.0;
-        for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * e[k1];
-        if (ikind & jkind) grad_m[k2] += gitmp * vjtmp * (a.antisym ? (mi + mj) : (mj - mi));
+        if (antisym) gitmp = e[k2];  // G = I: the sum below gives exactly this
+        else for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * e[k1];
+        if (ikind & jkind) grad_m[k2] += gitmp * vjtmp * (antisym ? (mi + mj) : (mj - mi));
       }
       double aij = 0.0;
-      for (int k2 = 0, op = 0; k2 < dim; ++k2)
-        for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      if (antisym) {  // L = I: only the squares survive, summed in the same order
+        for (int k2 = 0; k2 < dim; ++k2) aij += e[k2] * e[k2];
+      } else {
+        for (int k2 = 0, op = 0; k2 < dim; ++k2)
+          for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      }
       aij *= 2.0 * dwdr * vfrac;
-      if (!a.antisym)
+      if (!antisym)
         for (int k = 0; k < dim; ++k) ci[k] += aij * e[k];
       aij *= mi * coeff * rinv;
       diag1 += aij;
@@ -541,9 +550,10 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
         const double vd = dwdr * rinv * vfrac * dcoeff;
         for (int k2 = 0; k2 < dim; ++k2) {
           double gitmp = 0.0;
-          for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
+          if (antisym) gitmp = rij[k2];
+          else for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
           const double fi = vsi[k2], fj = vsj[k2];
-          div += gitmp * (a.antisym ? (fi + fj) : (fj - fi)) * vd;
+          div += gitmp * (antisym ? (fi + fj) : (fj - fi)) * vd;
         }
       }
     }
@@ -571,17 +581,22 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
       for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
-      const double vfrac = a.antisym ? sqrt(vi * q1.w) : q1.w;
+      const double vfrac = antisym ? sqrt(vi * q1.w) : q1.w;
       const double vjtmp = dwdr * vfrac;
       double aij = 0.0;
-      for (int k2 = 0, op = 0; k2 < dim; ++k2)
-        for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      if (antisym) {  // L = I: only the squares survive, summed in the same order
+        for (int k2 = 0; k2 < dim; ++k2) aij += e[k2] * e[k2];
+      } else {
+        for (int k2 = 0, op = 0; k2 < dim; ++k2)
+          for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      }
       aij *= 2.0 * dwdr * vfrac;
       aij *= mi * coeff * rinv;
       double bc = 0.0, bg = 0.0;
       for (int k2 = 0; k2 < dim; ++k2) {
         double bij = 0.0;
-        for (int k1 = 0; k1 < dim; ++k1) bij += G[k2 * dim + k1] * e[k1];
+        if (antisym) bij = e[k2];
+        else for (int k1 = 0; k1 < dim; ++k1) bij += G[k2 * dim + k1] * e[k1];
         bc += bij * ci[k2];
         bg += bij * grad_m[k2];
       }
@@ -640,8 +655,26 @@ struct HelmholtzArgs {
   double dt, theta, g[3], safe;
   const double *x, *vfrac, *Gc, *Lc, *rho, *nu, *p, *f, *v, *pnd;
   const int *type, *nptr, *nidx, *colmap;
+  // per-particle records for the neighbour gathers of the fluid rows (as in PoissonArgs)
+  const double4 *r1;  // x, y, z, vfrac
+  const double4 *r2;  // mu = nu rho, v
+  const int2 *r3;     // type, matrix column
 };
 
+__global__ void k_pack_particles_helmholtz(int nall, const double *__restrict__ x, const double *__restrict__ vfrac,
+                                           const double *__restrict__ nu, const double *__restrict__ rho,
+                                           const double *__restrict__ v, const int *__restrict__ type,
+                                           const int *__restrict__ colmap, double4 *__restrict__ r1,
+                                           double4 *__restrict__ r2, int2 *__restrict__ r3) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nall) return;
+  r1[j] = make_double4(x[3 * (size_t)j], x[3 * (size_t)j + 1], x[3 * (size_t)j + 2], vfrac[j]);
+  r2[j] = make_double4(nu[j] * rho[j], v[3 * (size_t)j], v[3 * (size_t)j + 1], v[3 * (size_t)j + 2]);
+  r3[j] = make_int2(type[j], colmap[j]);
+}
+
+// DIMT / FAM as in k_asm_poisson
+template <int DIMT, int FAM>
 __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, HelmholtzArgs a,
                                                           const long long *__restrict__ slice_off,
                                                           int *__restrict__ scol, double *__restrict__ sval,
@@ -659,7 +692,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
     }
     return;
   }
-  const int dim = T.dim, nt1 = T.ntypes + 1, dL = dim * (dim + 1) / 2;
+  const int dim = DIMT ? DIMT : T.dim, nt1 = T.ntypes + 1, dL = dim * (dim + 1) / 2;
+  const bool antisym = FAM < 0 ? (a.antisym != 0) : (FAM != 0);
   const int it = a.type[i], ikind = T.kind[it];
   const long long off = sval ? slice_off[i >> 6] : 0;
   const int w = sval ? (int)((slice_off[(i >> 6) + 1] - off) >> 6) : 0;
@@ -688,20 +722,31 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
   } else {
     double G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, L[6] = {1, 0, 1, 0, 0, 1};
     if (dim == 2) { G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 1; L[0] = 1; L[1] = 0; L[2] = 1; }
-    if (!a.antisym) {
+    if (!antisym) {
       for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
       for (int k = 0; k < dL; ++k) L[k] = a.Lc[(size_t)i * dL + k];
     }
     const double vi = a.vfrac[i];
     double grad_m[3] = {0, 0, 0}, ci[3] = {0, 0, 0};
     double diag1 = 0.0;
+    const double xi3[3] = {a.x[3 * (size_t)i], a.x[3 * (size_t)i + 1], a.x[3 * (size_t)i + 2]};
+    const double pi = a.incremental ? a.p[i] : 0.0;
     for (int jj = jb; jj < je; ++jj) {  // sweep 1
       const int j = neigh_at(T, i, jj - jb);
-      const int jt = a.type[j], jkind = T.kind[jt];
-      double rij[3];
-      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      const double4 q1 = a.r1[j];
+      const int2 q3 = a.r3[j];
+      const int jt = q3.x, jkind = T.kind[jt];
+      double rij[3] = {0, 0, 0};
+      double rsq = 0.0;
+      {
+        const double xj3[3] = {q1.x, q1.y, q1.z};
+        for (int k = 0; k < dim; ++k) {  // same arithmetic as pair_rsq
+          rij[k] = __dsub_rn(xi3[k], xj3[k]);
+          rsq = __dadd_rn(rsq, __dmul_rn(rij[k], rij[k]));
+        }
+      }
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
-      const double mj = a.nu[j] * a.rho[j];
+      const double mj = a.r2[j].x;
       double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
       if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) {
         coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
@@ -713,18 +758,23 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
       for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
-      const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
+      const double vfrac = antisym ? sqrt(vi * q1.w) : q1.w;
       const double vjtmp = dwdr * vfrac;
       for (int k2 = 0; k2 < dim; ++k2) {
         double gitmp = 0.0;
-        for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * e[k1];
-        if (ikind & jkind) grad_m[k2] += gitmp * vjtmp * (a.antisym ? (mi + mj) : (mj - mi));
+        if (antisym) gitmp = e[k2];  // G = I: the sum below gives exactly this
+        else for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * e[k1];
+        if (ikind & jkind) grad_m[k2] += gitmp * vjtmp * (antisym ? (mi + mj) : (mj - mi));
       }
       double aij = 0.0;
-      for (int k2 = 0, op = 0; k2 < dim; ++k2)
-        for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      if (antisym) {  // L = I: only the squares survive, summed in the same order
+        for (int k2 = 0; k2 < dim; ++k2) aij += e[k2] * e[k2];
+      } else {
+        for (int k2 = 0, op = 0; k2 < dim; ++k2)
+          for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      }
       aij *= 2.0 * dwdr * vfrac;
-      if (!a.antisym)
+      if (!antisym)
         for (int k = 0; k < dim; ++k) ci[k] += aij * e[k];
       aij *= mi * coeff * rinv;
       diag1 += aij;
@@ -733,17 +783,27 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
         const double vd = dwdr * rinv * vfrac;
         for (int k2 = 0; k2 < dim; ++k2) {
           double gitmp = 0.0;
-          for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
-          gp[k2] += gitmp * vd * (a.antisym ? (a.p[i] + a.p[j]) : (a.p[j] - a.p[i]));
+          if (antisym) gitmp = rij[k2];
+          else for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
+          gp[k2] += gitmp * vd * (antisym ? (pi + a.p[j]) : (a.p[j] - pi));
         }
       }
     }
     double diag2 = 0.0;
     for (int jj = jb; jj < je; ++jj) {  // sweep 2
       const int j = neigh_at(T, i, jj - jb);
-      const int jt = a.type[j], jkind = T.kind[jt];
-      double rij[3];
-      const double rsq = pair_rsq(dim, a.x, i, j, rij);
+      const double4 q1 = a.r1[j];
+      const int2 q3 = a.r3[j];
+      const int jt = q3.x, jkind = T.kind[jt];
+      double rij[3] = {0, 0, 0};
+      double rsq = 0.0;
+      {
+        const double xj3[3] = {q1.x, q1.y, q1.z};
+        for (int k = 0; k < dim; ++k) {
+          rij[k] = __dsub_rn(xi3[k], xj3[k]);
+          rsq = __dadd_rn(rsq, __dmul_rn(rij[k], rij[k]));
+        }
+      }
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       // the correction term uses the plain filter coefficient (:225-227); a_ij keeps the
       // mirror-weighted coefficient of the first sweep (:144-146)
@@ -757,17 +817,22 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
       for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
-      const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
+      const double vfrac = antisym ? sqrt(vi * q1.w) : q1.w;
       const double vjtmp = dwdr * vfrac;
       double aij = 0.0;
-      for (int k2 = 0, op = 0; k2 < dim; ++k2)
-        for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      if (antisym) {  // L = I: only the squares survive, summed in the same order
+        for (int k2 = 0; k2 < dim; ++k2) aij += e[k2] * e[k2];
+      } else {
+        for (int k2 = 0, op = 0; k2 < dim; ++k2)
+          for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) aij += L[op] * e[k1] * e[k2] * (k1 == k2 ? 1.0 : 2.0);
+      }
       aij *= 2.0 * dwdr * vfrac;
       aij *= mi * coeff_a * rinv;
       double bc = 0.0, bg = 0.0;
       for (int k2 = 0; k2 < dim; ++k2) {
         double bij = 0.0;
-        for (int k1 = 0; k1 < dim; ++k1) bij += G[k2 * dim + k1] * e[k1];
+        if (antisym) bij = e[k2];
+        else for (int k1 = 0; k1 < dim; ++k1) bij += G[k2 * dim + k1] * e[k1];
         bc += bij * ci[k2];
         bg += bij * grad_m[k2];
       }
@@ -776,8 +841,12 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       v -= tmp;
       diag2 += tmp;
       const double aval = (v * alpha) * invrho;  // SumInto(alpha) then LeftScale(1/rho)
-      for (int k = 0; k < dim; ++k) wv[k] += aval * a.v[3 * (size_t)j + k];
-      const int cj = a.colmap[j];
+      {
+        const double4 q2 = a.r2[j];
+        const double vj3[3] = {q2.y, q2.z, q2.w};
+        for (int k = 0; k < dim; ++k) wv[k] += aval * vj3[k];
+      }
+      const int cj = q3.y;
       if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
       const long long p = sell_pos(off, lane, cnt++);
       if (sval) { scol[p] = cj; sval[p] = aval * (-a.theta); }
@@ -1074,7 +1143,10 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     struct PackRelease { DevBuf<double4> &a, &b; DevBuf<int2> &c; ~PackRelease() { a.release(); b.release(); c.release(); } } pack_release{pk1, pk2, pk3};
     if (rc == ISPH_SUCCESS) {
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
-      hipLaunchKernelGGL(k_asm_poisson, dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+      if (T.dim == 3 && a.antisym)
+        hipLaunchKernelGGL((k_asm_poisson<3, 1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+      else
+        hipLaunchKernelGGL((k_asm_poisson<0, -1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
       if (n <= 32768) {  // tiny boxes may see the same tag twice in a row
         rc = newlen.reserve((size_t)n);
         if (rc == ISPH_SUCCESS) {
@@ -1186,8 +1258,23 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
       a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
       for (int k = 0; k < 3; ++k) a.g[k] = gvec ? gvec[k] : 0.0;
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
-      hipLaunchKernelGGL(k_asm_helmholtz, dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p,
-                         rhs_only ? (int *)nullptr : M.col.p, rhs_only ? (double *)nullptr : M.val.p, db);
+      DevBuf<double4> pk1, pk2;
+      DevBuf<int2> pk3;
+      struct PackRelease { DevBuf<double4> &a, &b; DevBuf<int2> &c; ~PackRelease() { a.release(); b.release(); c.release(); } } pack_release{pk1, pk2, pk3};
+      rc = pk1.reserve((size_t)P->nall);
+      if (rc == ISPH_SUCCESS) rc = pk2.reserve((size_t)P->nall);
+      if (rc == ISPH_SUCCESS) rc = pk3.reserve((size_t)P->nall);
+      if (rc == ISPH_SUCCESS) {
+        hipLaunchKernelGGL(k_pack_particles_helmholtz, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                           P->nall, a.x, a.vfrac, a.nu, a.rho, a.v, a.type, a.colmap, pk1.p, pk2.p, pk3.p);
+        a.r1 = pk1.p; a.r2 = pk2.p; a.r3 = pk3.p;
+        int *mcol = rhs_only ? (int *)nullptr : M.col.p;
+        double *mval = rhs_only ? (double *)nullptr : M.val.p;
+        if (T.dim == 3 && antisym)
+          hipLaunchKernelGGL((k_asm_helmholtz<3, 1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
+        else
+          hipLaunchKernelGGL((k_asm_helmholtz<0, -1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
+      }
       if (!rhs_only && n <= 32768) {
         rc = newlen.reserve((size_t)n);
         if (rc == ISPH_SUCCESS) {
