@@ -26,16 +26,18 @@ struct OpArgs {
 };
 
 // grad_i = alpha sum_j (G^T r_ij) (f_i (+|-) f_j) W'/r V    (scalar field f[nall])
+template <int DIMT, int FAM>  // 0 / -1: dimension and family read at run time; 3 / 1: 3-D AntiSymmetric (G = I) folded
 __global__ __launch_bounds__(kBlock) void k_gradient(AsmTables T, OpArgs a, const double *__restrict__ f,
                                                      double *__restrict__ grad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.nlocal) return;
-  const int dim = T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
+  const int dim = DIMT ? DIMT : T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
+  const bool antisym = FAM < 0 ? (a.antisym != 0) : (FAM != 0);
   double g[3] = {0, 0, 0};
   if (!a.use_filter || (ikind & a.filt_i)) {
     double G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (dim == 2) { G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 1; }
-    if (!a.antisym)
+    if (!antisym)
       for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
     const double vi = a.vfrac[i], fi = f[i];
     const int jb = a.nptr[i], je = a.nptr[i + 1];
@@ -48,12 +50,13 @@ __global__ __launch_bounds__(kBlock) void k_gradient(AsmTables T, OpArgs a, cons
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       const double r = sqrt(rsq) + kEps;
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
-      const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
+      const double vfrac = antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
       const double vjtmp = dwdr / r * vfrac;
-      const double df = a.antisym ? (fi + f[j]) : (f[j] - fi);
+      const double df = antisym ? (fi + f[j]) : (f[j] - fi);
       for (int k2 = 0; k2 < dim; ++k2) {
         double gitmp = 0.0;
-        for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
+        if (antisym) gitmp = rij[k2];  // G = I: the sum below gives exactly this
+        else for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
         g[k2] += gitmp * vjtmp * df;
       }
     }
@@ -62,16 +65,18 @@ __global__ __launch_bounds__(kBlock) void k_gradient(AsmTables T, OpArgs a, cons
 }
 
 // div_i = alpha sum_j (G^T r_ij).(f_i (+|-) f_j) W'/r V     (vector field f[nall][3])
+template <int DIMT, int FAM>  // 0 / -1: dimension and family read at run time; 3 / 1: 3-D AntiSymmetric (G = I) folded
 __global__ __launch_bounds__(kBlock) void k_divergence(AsmTables T, OpArgs a, const double *__restrict__ f,
                                                        double *__restrict__ div) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.nlocal) return;
-  const int dim = T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
+  const int dim = DIMT ? DIMT : T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
+  const bool antisym = FAM < 0 ? (a.antisym != 0) : (FAM != 0);
   double d = 0.0;
   if (!a.use_filter || (ikind & a.filt_i)) {
     double G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (dim == 2) { G[0] = 1; G[1] = 0; G[2] = 0; G[3] = 1; }
-    if (!a.antisym)
+    if (!antisym)
       for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
     const double vi = a.vfrac[i];
     const int jb = a.nptr[i], je = a.nptr[i + 1];
@@ -84,13 +89,14 @@ __global__ __launch_bounds__(kBlock) void k_divergence(AsmTables T, OpArgs a, co
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       const double r = sqrt(rsq) + kEps;
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
-      const double vfrac = a.antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
+      const double vfrac = antisym ? sqrt(vi * a.vfrac[j]) : a.vfrac[j];
       const double vjtmp = dwdr / r * vfrac;
       for (int k2 = 0; k2 < dim; ++k2) {
         double gitmp = 0.0;
-        for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
+        if (antisym) gitmp = rij[k2];  // G = I: the sum below gives exactly this
+        else for (int k1 = 0; k1 < dim; ++k1) gitmp += G[k2 * dim + k1] * rij[k1];
         const double fi = f[3 * (size_t)i + k2], fj = f[3 * (size_t)j + k2];
-        d += gitmp * (a.antisym ? (fi + fj) : (fj - fi)) * vjtmp;
+        d += gitmp * (antisym ? (fi + fj) : (fj - fi)) * vjtmp;
       }
     }
   }
@@ -322,8 +328,11 @@ inline int op_apply(isph_ctx *ctx, const isph_particles *P, int mode, int antisy
   if (rc == ISPH_SUCCESS && n > 0) {
     st.a.alpha = alpha; st.a.use_filter = use_filter; st.a.filt_i = filt_i; st.a.filt_j = filt_j;
     const int grid = (n + kBlock - 1) / kBlock;
-    if (mode == 0) hipLaunchKernelGGL(k_gradient, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
-    else hipLaunchKernelGGL(k_divergence, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    const bool fast = st.T.dim == 3 && st.a.antisym;
+    if (mode == 0 && fast) hipLaunchKernelGGL((k_gradient<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    else if (mode == 0) hipLaunchKernelGGL((k_gradient<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    else if (fast) hipLaunchKernelGGL((k_divergence<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    else hipLaunchKernelGGL((k_divergence<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
     if (!on_device && hipMemcpyAsync(out, dout, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = fail("copy failed", __FILE__, __LINE__);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
@@ -371,7 +380,10 @@ inline int correct_velocity_pressure(isph_ctx *ctx, const isph_particles *P, int
   if (rc == ISPH_SUCCESS && n > 0) {
     st.a.alpha = 1.0; st.a.use_filter = 1; st.a.filt_i = KIND_FLUID; st.a.filt_j = KIND_FLUID;
     const int grid = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_gradient, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
+    if (st.T.dim == 3 && st.a.antisym)
+      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
+    else
+      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
     hipLaunchKernelGGL(k_correct_velocity, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, dt, st.a.type, st.T.kind,
                        drho, (const double *)grad.p, iv.dev);
     hipLaunchKernelGGL(k_correct_pressure, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall,
@@ -402,7 +414,10 @@ inline int advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, do
   if (rc == ISPH_SUCCESS && n > 0) {
     st.a.alpha = 1.0; st.a.use_filter = 1; st.a.filt_i = KIND_FLUID; st.a.filt_j = KIND_FLUID;
     const int grid = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_gradient, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
+    if (st.T.dim == 3 && st.a.antisym)
+      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
+    else
+      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
     hipLaunchKernelGGL(k_advance_begin, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, dt, st.a.type, st.T.kind,
                        (const double *)grad.p, dv, dvn, dout);
     if (!on_device && hipMemcpyAsync(dp_out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
