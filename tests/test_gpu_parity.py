@@ -736,7 +736,7 @@ def test_particle_shifting_matches_oracle(gpu_ctx, dim, antisym):
 
 
 # ---------------------------------------------------------------- small / degenerate inputs
-@pytest.mark.parametrize("prec", ["none", "jacobi", "bjacobi-ilu0", "sa-amg"])
+@pytest.mark.parametrize("prec", ["none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu2", "sa-amg"])
 def test_tiny_systems_with_every_preconditioner(gpu_ctx, prec):
     """3x3 and 1x1 SPD systems: single block, single level, rows shorter than a wave."""
     for dense in (np.array([[4.0, -1.0, 0.0], [-1.0, 4.0, -1.0], [0.0, -1.0, 3.0]]), np.array([[2.5]])):
@@ -750,6 +750,33 @@ def test_tiny_systems_with_every_preconditioner(gpu_ctx, prec):
         info = hip.solve(gpu_ctx, A, b.copy(), x, prec=M)
         assert info.converged == 1
         assert np.allclose(x, np.linalg.solve(dense, b), rtol=1e-8, atol=1e-12)
+
+
+def test_iluk_with_complete_fill_is_a_direct_solve(gpu_ctx):
+    """5-point Laplacian on an 8 x 8 grid in natural order: every fill entry of the complete LU factorisation has level
+    <= 8, so ILU(8) is that factorisation and one application of the preconditioner solves the system (no oracle
+    involved); ILU(k) for smaller k approaches it monotonically."""
+    m = 8
+    T = sps.diags([-1.0, 4.0, -1.0], [-1, 0, 1], shape=(m, m))
+    S = (sps.kron(sps.identity(m), T) + sps.kron(sps.diags([-1.0, -1.0], [-1, 1], shape=(m, m)), sps.identity(m))).tocsr()
+    S.sort_indices()
+    n = m * m
+    A = hip.Matrix.from_csr(gpu_ctx, S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data)
+    b = np.cos(np.arange(n, dtype=float))
+    exact = np.linalg.solve(S.toarray(), b)
+    nnz_prev, err_prev = 0, np.inf
+    for k in (0, 1, 3, 8):
+        M = hip.Precond(gpu_ctx, A, "bjacobi-ilu%d" % k, 64)
+        nnz = M.info()["factor_nnz"]
+        err = np.linalg.norm(M.apply(b) - exact) / np.linalg.norm(exact)
+        assert nnz > nnz_prev and err < err_prev
+        nnz_prev, err_prev = nnz, err
+    assert err_prev < 1e-12
+    D = S.toarray() != 0                                  # pattern of the complete factorisation, textbook elimination
+    for p in range(n):
+        rows = np.nonzero(D[p + 1:, p])[0] + p + 1
+        D[np.ix_(rows, np.nonzero(D[p, p + 1:])[0] + p + 1)] = True
+    assert nnz_prev == int(D.sum())
 
 
 def test_solve_with_zero_right_hand_side(gpu_ctx):
