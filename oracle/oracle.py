@@ -315,7 +315,10 @@ class ILU:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_ilu_destroy(self.h)
+            try:
+                lib().orc_ilu_destroy(self.h)
+            except TypeError:        # interpreter shutdown: the module globals are already gone
+                pass
             self.h = None
 
 
@@ -360,7 +363,10 @@ class AMG:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_amg_destroy(self.h)
+            try:
+                lib().orc_amg_destroy(self.h)
+            except TypeError:        # interpreter shutdown
+                pass
             self.h = None
 
 
