@@ -483,23 +483,38 @@ inline int pcg(const LinOp &op, const double *b, double *x, const isph_solver_pa
   info->rel_res_implicit = r0 / scale;
   info->converged = (r0 / scale <= prm->tol);
   int rz = RZ, rzn = RZN;
+  // One host wait per iteration (the residual norm), and it is taken AFTER the next iteration's preconditioner
+  // application, direction update and operator application have been enqueued: they only write z, p, A p and scalars,
+  // so when the norm says "converged" they are wasted but harmless, and otherwise the GPU never idles while the host
+  // launches (small systems are launch-latency bound: BASELINE configs[0] is 16 k rows).
+  bool have_ap = false;
   while (!info->converged && info->iters < prm->max_iters) {
-    ISPH_CHECK(op.apply(p, ap));
-    ISPH_CHECK(dot_dev(ctx, n, p, ap, nullptr, nullptr, PAP));
+    if (!have_ap) {
+      ISPH_CHECK(op.apply(p, ap));
+      ISPH_CHECK(dot_dev(ctx, n, p, ap, nullptr, nullptr, PAP));
+    }
     const int g = stream_grid(n);
     hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(kBlock), 0, st, n, p, ap, x, r, ds + rz, ds + PAP, ctx->partial.p);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, st, 1, g, ctx->partial.p, ds + RR);
     ISPH_CHECK(allreduce_inplace(ctx, ds + RR, 1));
-    ISPH_CHECK(fetch_scalars(ctx, RR, 1));
+    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->hscal + RR, ds + RR, sizeof(double), hipMemcpyDeviceToHost, st));
+    ISPH_CHECK_HIP(hipEventRecord(ctx->ev_fetch, st));
     ++info->iters;
+    have_ap = false;
+    if (info->iters < prm->max_iters) {  // next iteration's first half, enqueued behind the copy
+      ISPH_CHECK(op.prec(r, z));
+      ISPH_CHECK(dot_dev(ctx, n, r, z, nullptr, nullptr, rzn));
+      hipLaunchKernelGGL(k_cg_update_p, dim3(sg), dim3(kBlock), 0, st, n, z, p, ds + rzn, ds + rz);
+      const int tsw = rz; rz = rzn; rzn = tsw;
+      ISPH_CHECK(op.apply(p, ap));
+      ISPH_CHECK(dot_dev(ctx, n, p, ap, nullptr, nullptr, PAP));
+      have_ap = true;
+    }
+    ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev_fetch));
     info->rel_res_implicit = std::sqrt(ctx->hscal[RR]) / scale;
     if (prm->verbose && ctx->rank == 0 && info->iters % 10 == 0)
       printf(">> isph::cg iter %d  rel res %.3e\n", info->iters, info->rel_res_implicit);
     if (info->rel_res_implicit <= prm->tol) { info->converged = 1; break; }
-    ISPH_CHECK(op.prec(r, z));
-    ISPH_CHECK(dot_dev(ctx, n, r, z, nullptr, nullptr, rzn));
-    hipLaunchKernelGGL(k_cg_update_p, dim3(sg), dim3(kBlock), 0, st, n, z, p, ds + rzn, ds + rz);
-    const int tsw = rz; rz = rzn; rzn = tsw;
   }
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
