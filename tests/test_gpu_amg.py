@@ -69,6 +69,30 @@ def test_amg_hierarchy_cycle_and_solve_match_oracle(gpu_ctx, case, theta, singul
             assert np.linalg.norm(_csr(r1, c1, v1, n1, n1) @ nc) <= 1e-10 * np.abs(v1).max() * np.linalg.norm(nc)
 
 
+@pytest.mark.parametrize("case,theta", [
+    (dict(dim=3, n=24, mode=workload.JITTER, brick=8), 0.0),
+    (dict(dim=3, n=24, mode=workload.ADVECT, brick=8), 0.05),
+    (dict(dim=3, n=18, mode=workload.JITTER, brick=6), 0.2),
+    (dict(dim=2, n=96, mode=workload.JITTER, brick=8), 0.0),
+    (dict(dim=2, n=64, mode=workload.ADVECT, brick=8), 0.1),
+    (dict(dim=3, n=10, mode=workload.JITTER, kernel="quintic", cut_over_h=3.0, brick=5), 0.0),
+])
+def test_amg_aggregates_are_the_oracles_on_every_level(gpu_ctx, case, theta):
+    """The device MIS-2 runs on work lists and decides "covered" in the round a root is chosen; the oracle walks plain
+    rounds.  Both must land on the same roots (the lexicographically first distance-2 independent set of the hashed
+    priorities) and hence the same aggregates, level by level."""
+    pr = Problem(tgv_spec(**case))
+    rp, ci, val, _ = pr.poisson()
+    nv = np.ones(pr.n) / np.sqrt(pr.n)
+    kw = dict(theta=theta, block=128, coarse_max=32)
+    G = orc.AMG(rp, ci, val, nullvec=nv, **kw)
+    M = hip.PrecondAMG(gpu_ctx, hip.Matrix.from_csr(gpu_ctx, rp, ci, val), nullvec=nv, params=hip.AmgParams(**kw))
+    assert M.levels == G.levels
+    for l in range(G.levels - 1):
+        assert np.array_equal(G.aggregates(l), M.aggregates(l))
+        assert G.level_info(l + 1) == M.level_info(l + 1)
+
+
 @pytest.mark.parametrize("kw", [dict(sweeps=2), dict(max_levels=2), dict(max_levels=1), dict(omega=1.0, theta=0.03)])
 def test_amg_parameter_variants_match_oracle(gpu_ctx, kw):
     """"smoother: sweeps", "max levels", damping and threshold follow the oracle through the same code paths."""
