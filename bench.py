@@ -163,18 +163,28 @@ def main():
     rho = torch.from_numpy(parts["rho"]).to(dev)
     vstar = torch.from_numpy(np.ascontiguousarray(parts["v"])).to(dev)
 
-    # computePre: volumes on the GPU + forward comm of ghost volumes
+    # computePre (volumes on the GPU + forward comm of ghost volumes) and the Poisson assembly.  Done twice: the first
+    # pass pays the one-time device allocations, the second is the steady state a time step sees
+    def assemble():
+        vf = hip.compute_volumes(ctx, dparts, colmap, kernel=args.kernel)
+        if world == 1:
+            vfrac = vf[torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)].contiguous()
+        else:
+            vfrac = dist.forward_scalar(plan, vf, td, dev)
+        A, b = hip.assemble_poisson(ctx, dparts, colmap, spec.dt, rho, vstar, vfrac=vfrac, ncol=plan.ncol,
+                                    kernel=args.kernel, rank0=(rank == 0))
+        if plan.npeers:
+            A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+        return A, b
+
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    vf = hip.compute_volumes(ctx, dparts, colmap, kernel=args.kernel)
-    if world == 1:
-        vfrac = vf[torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)].contiguous()
-    else:
-        vfrac = dist.forward_scalar(plan, vf, td, dev)
-    A, b = hip.assemble_poisson(ctx, dparts, colmap, spec.dt, rho, vstar, vfrac=vfrac, ncol=plan.ncol,
-                                kernel=args.kernel, rank0=(rank == 0))
-    if plan.npeers:
-        A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+    A, b = assemble()
+    torch.cuda.synchronize()
+    assemble_first_ms = (time.perf_counter() - t0) * 1e3
+    A.close()
+    t0 = time.perf_counter()
+    A, b = assemble()
     torch.cuda.synchronize()
     assemble_ms = (time.perf_counter() - t0) * 1e3
     info_m = A.info()
@@ -257,7 +267,7 @@ def main():
                        "solver": "FGMRES(50) DGKS tol 1e-8, right prec", "precond": args.prec, "block_rows": args.block,
                        "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
-                       "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms,
+                       "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms, "assemble_first_call_ms": assemble_first_ms,
                        "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo},
             "roofline": {"bound": "hbm", "kernel": "k_sell_spmv", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
