@@ -107,17 +107,27 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(int nk, int nblk, co
 }
 
 // w -= sum_k c[k] V_k ; partial[blockIdx] = sum of the new w.w  (c on device)
+// flag != NULL: flag[0] == 0 means the DGKS test on the device found no second pass due (w stays).
+// vnext != NULL: the normalised vector vnext = w_final / sqrt(flag[1]) is written in the same sweep (flag[1] is
+// |w_final|^2 from k_dgks_decide; the arithmetic of k_scale_copy), second pass or not.
 __global__ __launch_bounds__(kBlock) void k_multi_axpy_norm(int n, int nk, const double *__restrict__ V, long long ld,
                                                             const double *__restrict__ c, double *__restrict__ w,
                                                             double *__restrict__ partial,
-                                                            const double *__restrict__ flag = nullptr) {
+                                                            const double *__restrict__ flag = nullptr,
+                                                            double *__restrict__ vnext = nullptr) {
   __shared__ double sw[4];
-  if (flag && *flag == 0.0) return;  // DGKS decided on the device that no second pass is needed
+  const bool second = !(flag && *flag == 0.0);
+  if (!second && !vnext) return;
+  double a = 1.0;
+  if (vnext) a *= 1.0 / sqrt(flag[1]);
   double ww = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     double s = w[i];
-    for (int k = 0; k < nk; ++k) s = fma(-c[k], V[(long long)k * ld + i], s);
-    w[i] = s;
+    if (second) {
+      for (int k = 0; k < nk; ++k) s = fma(-c[k], V[(long long)k * ld + i], s);
+      w[i] = s;
+    }
+    if (vnext) vnext[i] = a * s;
     ww = fma(s, s, ww);
   }
   ww = wave_sum(ww);

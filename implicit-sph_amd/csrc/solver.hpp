@@ -275,11 +275,9 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
   hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(64), 0, st, (const double *)(dh1 + nk), (const double *)dh2, nk,
                      ortho == 1 ? 1 : 0, dor, deflate ? (const double *)dh1 : (const double *)nullptr);
   const int g2 = stream_grid(n);
+  // the second update and the normalised next basis vector (vnext = w / |w|) leave in one sweep
   hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, dh2, w, ctx->partial.p,
-                     (const double *)dor);
-  if (vnext)
-    hipLaunchKernelGGL(k_scale_copy, dim3(stream_grid(n)), dim3(kBlock), 0, st, n, (const double *)w, vnext, 1.0,
-                       (const double *)(dor + 1), 1);
+                     (const double *)dor, vnext);
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
