@@ -62,6 +62,12 @@ class ParameterList {
 };
 }  // namespace Teuchos
 
+// Thyra types that only appear in PrecondWrapper's signatures (precond.h:22,33-36,45); never instantiated here
+namespace Thyra {
+template <class Scalar> class PhysicallyBlockedLinearOpBase;
+template <class Scalar> class LinearOpBase;
+}  // namespace Thyra
+
 enum Epetra_DataAccess { Copy, View };
 
 class Epetra_MpiComm {

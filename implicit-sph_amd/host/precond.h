@@ -29,6 +29,9 @@ class PrecondWrapper {
   virtual void setMatrix(Epetra_CrsMatrix *A) {
     if (A != NULL) _A = Teuchos::rcp(A, false);
   }
+  // ref: precond.h:33-36.  The blocked operator is assembled from the scalar blocks SolverLin::setBlock was given, so
+  // the Thyra object is accepted for interface compatibility and not used.
+  virtual void setBlockMatrix(Thyra::PhysicallyBlockedLinearOpBase<double> *) { return; }
   virtual Teuchos::ParameterList *setParameters(Teuchos::ParameterList *param = NULL) { return _param.get(); }
   virtual void setNullVector(double *) { return; }  // base no-op, ref: precond.h:40
   // The reference builds the Ifpack/ML object here; the device object needs the
@@ -41,6 +44,9 @@ class PrecondWrapper {
     if (_M) { isph_prec_destroy(_M); _M = nullptr; }
   }
   virtual Epetra_Operator *getPrecondOperator() { return NULL; }
+  // ref: precond.h:45.  No Thyra operator crosses the boundary: solveBlockProblem applies the device preconditioner to
+  // every component itself (precond_ml.h:138-155) and raises the reference's error when there is none.
+  virtual Thyra::LinearOpBase<double> *getBlockPrecondOperator() { return NULL; }
 };
 
 }  // namespace LAMMPS_NS
