@@ -612,7 +612,9 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
 constexpr int kFacPrefetch = 4;
 constexpr int kIluWaves = 8;
 
-template <int WAVES>
+// WIDE: two U-row entries per lane are prefetched (U-rows of up to 128 entries: ILU(k > 0), wide kernels); the narrow
+// variant keeps one (the bench matrix has ~30 upper entries per row and the second queue only costs there).
+template <int WAVES, bool WIDE>
 __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, const long long *__restrict__ frp,
                                                            const int *__restrict__ fcol, double *__restrict__ fval,
                                                            const int *__restrict__ flen,
@@ -684,46 +686,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
       // The prefetch only ISSUES the global loads (column and value of the U-row entry this lane will apply);
       // the column -> slot look-up in LDS happens when the step is applied.  (Looking the slot up inside the
       // request made every request wait for its own global load: no overlap at all.)
-      int pcq[kFacPrefetch];      // column of the prefetched U-row entry (-1: none for this lane)
-      double pvq[kFacPrefetch];   // its value
+      // two entries of the U-row per lane are prefetched (rows of up to 128 upper entries: ILU(1) rows are that wide)
+      int pcq[kFacPrefetch], pcq2[kFacPrefetch];      // column of the prefetched U-row entries (-1: none for this lane)
+      double pvq[kFacPrefetch], pvq2[kFacPrefetch];   // their values
       double pdq[kFacPrefetch];   // 1/d_k of that step
-      auto request = [&](int s, int &pc, double &pvv, double &pdv) {
+      auto request = [&](int s, int &pc, double &pvv, int &pc2, double &pvv2, double &pdv) {
         pc = -1;
+        pc2 = -1;
         pvv = 0.0;
+        pvv2 = 0.0;
         pdv = 0.0;
         if (s < dg) {
           const int k = mc[s];
           pdv = diag[k];
           const int t = dgL[k] + 1 + lane;
+          const long long p = rpL[k] + t;
           if (t < lenL[k]) {
-            const long long p = rpL[k] + t;
             pc = fcol[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
             pvv = fval[p];
+          }
+          if (WIDE && t + 64 < lenL[k]) {
+            pc2 = fcol[p + 64];
+            pvv2 = fval[p + 64];
           }
         }
       };
 #pragma unroll
-      for (int u = 0; u < kFacPrefetch; ++u) request(u, pcq[u], pvq[u], pdq[u]);
+      for (int u = 0; u < kFacPrefetch; ++u) request(u, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
       for (int s0 = 0; s0 < dg; s0 += kFacPrefetch) {
 #pragma unroll
         for (int u = 0; u < kFacPrefetch; ++u) {
           const int s = s0 + u;
           if (s < dg) {
             const int ps = pcq[u] >= 0 ? mp[pcq[u] - blo] : 0;  // slot+1 in row i (0: not in the pattern)
+            const int ps2 = WIDE && pcq2[u] >= 0 ? mp[pcq2[u] - blo] : 0;
             const double lik = mv[s] * pdq[u];   // l_ik = a_ik / d_k (reciprocal stored once per pivot)
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) mv[s] = lik;
             if (ps) mv[ps - 1] -= lik * pvq[u];
+            if (WIDE && ps2) mv[ps2 - 1] -= lik * pvq2[u];
             const int k = mc[s];
-            // U-rows wider than one wave (rare: > 64 in-block upper entries)
-            for (int t = dgL[k] + 1 + 64 + lane; t < lenL[k]; t += 64) {
+            // U-rows wider than the prefetched part
+            for (int t = dgL[k] + 1 + (WIDE ? 128 : 64) + lane; t < lenL[k]; t += 64) {
               const long long p = rpL[k] + t;
-              const int ps2 = mp[fcol[p] - blo];
-              if (ps2) mv[ps2 - 1] -= lik * fval[p];
+              const int ps3 = mp[fcol[p] - blo];
+              if (ps3) mv[ps3 - 1] -= lik * fval[p];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            request(s + kFacPrefetch, pcq[u], pvq[u], pdq[u]);
+            request(s + kFacPrefetch, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
           }
         }
       }
@@ -1046,11 +1057,17 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
     if (rc == ISPH_SUCCESS && sgs) {
       // nothing left to do: k_ilu_schedule filled the stream
     } else if (rc == ISPH_SUCCESS) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_factor<kIluWaves>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess)
+      const bool wide = F->wmax > 128;  // rows this long have U parts beyond one wave
+      const void *fk = wide ? reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, true>)
+                            : reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, false>);
+      if (hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess)
         rc = fail("LDS attribute failed", __FILE__, __LINE__);
+      else if (wide)
+        hipLaunchKernelGGL((k_ilu_factor<kIluWaves, true>), dim3(F->nblocks), dim3(kIluWaves * 64), lds_f, ctx->stream, S.nrow,
+                           block_size, W, F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p,
+                           F->sv.p, F->dinv.p);
       else
-        hipLaunchKernelGGL((k_ilu_factor<kIluWaves>), dim3(F->nblocks), dim3(kIluWaves * 64), lds_f, ctx->stream, S.nrow,
+        hipLaunchKernelGGL((k_ilu_factor<kIluWaves, false>), dim3(F->nblocks), dim3(kIluWaves * 64), lds_f, ctx->stream, S.nrow,
                            block_size, W, F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p,
                            F->sv.p, F->dinv.p);
       if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("ILU factor launch failed", __FILE__, __LINE__);
