@@ -610,6 +610,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
 // frp/flen/fdiag[B], level order + offsets, per wave a row image (values,
 // columns) and a column->slot map.
 constexpr int kFacPrefetch = 4;
+constexpr int kFacPrefetchWide = 8;
 constexpr int kIluWaves = 8;
 
 // WIDE: two U-row entries per lane are prefetched (U-rows of up to 128 entries: ILU(k > 0), wide kernels); the narrow
@@ -681,15 +682,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // software-pipelined elimination: the U-row of step s+kFacPrefetch is
+      constexpr int kPF = WIDE ? kFacPrefetchWide : kFacPrefetch;
+      // software-pipelined elimination: the U-row of step s+kPF is
       // requested while step s is applied (one entry per lane per 64 columns)
       // The prefetch only ISSUES the global loads (column and value of the U-row entry this lane will apply);
       // the column -> slot look-up in LDS happens when the step is applied.  (Looking the slot up inside the
       // request made every request wait for its own global load: no overlap at all.)
       // two entries of the U-row per lane are prefetched (rows of up to 128 upper entries: ILU(1) rows are that wide)
-      int pcq[kFacPrefetch], pcq2[kFacPrefetch];      // column of the prefetched U-row entries (-1: none for this lane)
-      double pvq[kFacPrefetch], pvq2[kFacPrefetch];   // their values
-      double pdq[kFacPrefetch];   // 1/d_k of that step
+      int pcq[kPF], pcq2[kPF];      // column of the prefetched U-row entries (-1: none for this lane)
+      double pvq[kPF], pvq2[kPF];   // their values
+      double pdq[kPF];   // 1/d_k of that step
       auto request = [&](int s, int &pc, double &pvv, int &pc2, double &pvv2, double &pdv) {
         pc = -1;
         pc2 = -1;
@@ -712,10 +714,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
         }
       };
 #pragma unroll
-      for (int u = 0; u < kFacPrefetch; ++u) request(u, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
-      for (int s0 = 0; s0 < dg; s0 += kFacPrefetch) {
+      for (int u = 0; u < kPF; ++u) request(u, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
+      for (int s0 = 0; s0 < dg; s0 += kPF) {
 #pragma unroll
-        for (int u = 0; u < kFacPrefetch; ++u) {
+        for (int u = 0; u < kPF; ++u) {
           const int s = s0 + u;
           if (s < dg) {
             const int ps = pcq[u] >= 0 ? mp[pcq[u] - blo] : 0;  // slot+1 in row i (0: not in the pattern)
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            request(s + kFacPrefetch, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
+            request(s + kPF, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
           }
         }
       }
