@@ -2,23 +2,32 @@
 
 Purpose: pin the oracle's assembly + solve restatement against the reference's
 own recorded known answers, sph-script/conv-taylor-green-vortex-2d-rev390.txt
-("TAYLOR-GREEN-VORTEX-2D.LMP, SINGULAR POISSON NULLSPACE, NO SHIFT", Wendland):
-
-    N = 16  step 3  t=1.767146  pressure l2 error 8.466849370245e-04 (1.23340621e-03)
-                                velocity l2 error 7.500246669496e-04 (4.96568611e-02)
-    N = 32  step 6  t=1.767146  pressure 1.995025956346e-04, velocity 1.695211327348e-04
+(and ...-rev230.txt): four rows N = 16, 32, 64, 128 x (pressure, velocity) l2 error,
+Wendland and Quintic kernels.
 
 It restates, per time step, the pressure-correction scheme of
-PairISPH::computeIncompressibleNavierStokes (pair_isph.cpp:910-1034) with
-theta = 0 (taylor-green-vortex.xml:15):
+PairISPH::computeIncompressibleNavierStokes (pair_isph.cpp:910-1034):
   computePre (volumes [+ G_i, L_i])             pair_isph_corrected.cpp:302-369
-  Helmholtz RHS, theta=0 => v* = b              functor_incomp_navier_stokes_helmholtz.h:52-159
+  Helmholtz  (I - theta dt nu lap) v* = ...     functor_incomp_navier_stokes_helmholtz.h:52-159
   Poisson  A dp = -div v*  (NullSpace)          functor_incomp_navier_stokes_poisson.h:52-181
   zero-mean dp                                  pair_isph.cpp:422-464
   v* -= dt/rho grad dp ; p += dp                functor_correct_velocity.h, functor_correct_pressure.h
   error vs analytic TGV (fix isph/tgv runs before fix isph in final_integrate)   fix_isph_tgv.cpp:43-125
   advanceTime: p += grad p . dx ; x += dx ; v = v*   functor_advance_time_{begin,end}.h
-The time step of that revision is dt = 0.1 h / Umax.
+  [fix isph/shift: computePre, shiftParticles]  fix_isph_shift.cpp:147-160, pair_isph_corrected.cpp:1203-1260
+
+The table does not record theta, the operator family, the pressure form or the fix
+order of the revision that produced it.  oracle/tgv_sweep.py sweeps them; exactly one
+combination reproduces all rows (PINNED below):
+  theta = 0.5 (the code's default, pair_isph.cpp:1753), incremental pressure,
+  the Symmetric (corrected, G_i/L_i) operator family, error on vstar before advanceTime,
+  trapezoidal advance, dt = 0.1 h / Umax, lattice origin 0.5.
+With it p_err and u_err agree with the table to <= 1.5e-3 relative on all rows and both
+kernels.  The position-only norms the table prints in parentheses show that the
+particles of the reference run were additionally shifted (the script's
+`fix isph/shift 0.05`); with the shift of this tree scaled by the mean instead of
+the maximum fluid speed (the alternative left commented at pair_isph_corrected.cpp:1235)
+the errors agree to <= 3e-4 for N >= 32.
 """
 import os
 import sys
@@ -30,14 +39,10 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 import oracle as orc  # noqa: E402
 
-TABLE_REV390_WENDLAND = {
-    16: dict(step=3, time=1.767146, p_err=8.466849370245e-04, p_norm=1.23340621e-03,
-             u_err=7.500246669496e-04, u_norm=4.96568611e-02),
-    32: dict(step=6, time=1.767146, p_err=1.995025956346e-04, p_norm=1.23259792e-03,
-             u_err=1.695211327348e-04, u_norm=4.96687154e-02),
-    64: dict(step=13, time=1.914408, p_err=7.140008948534e-05, p_norm=1.16213433e-03,
-             u_err=3.622266617824e-05, u_norm=4.82266618e-02),
-}
+def known_answers():
+    """the reference's own table rows (data): tests/golden/reference_known_answers.json"""
+    import json
+    return json.load(open(os.path.join(_HERE, "..", "tests", "golden", "reference_known_answers.json")))
 
 
 def periodic_particles(x, L, cut):
@@ -54,14 +59,18 @@ def periodic_particles(x, L, cut):
     xall = np.concatenate(xs)
     own = np.concatenate(owner)
     nall = len(xall)
+    # full neighbour list (all atoms within cut, self excluded), ascending atom index per row
+    from scipy.spatial import cKDTree
+    tree = cKDTree(xall[:, :2])
+    cand = tree.query_ball_point(xall[:n, :2], cut * (1 + 1e-9))
+    cutsq = cut * cut
     ptr = [0]
     idx = []
-    cutsq = cut * cut
     for i in range(n):
-        d = xall[:, :2] - xall[i, :2]
+        nb = np.sort(np.asarray(cand[i], dtype=np.int64))
+        d = xall[nb, :2] - xall[i, :2]
         r2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
-        nb = np.nonzero(r2 < cutsq)[0]
-        nb = nb[nb != i]
+        nb = nb[(r2 < cutsq) & (nb != i)]
         idx.append(nb)
         ptr.append(ptr[-1] + len(nb))
 
@@ -81,47 +90,64 @@ def tgv_exact(x, t, umax, nu, rho):
     return u, p
 
 
-def run_tgv2d(N, nsteps, antisym=True, umax=0.1, nu=0.1, rho0=1.0, kernel="wendland", cut_over_h=2.0,
-              dt=None, prec="ilu", verbose=False, return_state=False):
+PINNED = dict(theta=0.5, incremental=True, antisym=False)          # the combination that reproduces rev390/rev230
+PINNED_SHIFT = dict(shift=0.05, shift_speed="mean")
+
+
+def run_tgv2d(N, nsteps, antisym=True, umax=0.1, nu=0.1, rho0=1.0, kernel="wendland", cut_over_h=None,
+              dt=None, prec="ilu", verbose=False, return_state=False, theta=0.0, incremental=True,
+              origin=0.5, shift=0.0, shift_speed="max", tol=1e-8):
+    """history of fix isph/tgv's four numbers, one record per step."""
     L = 2 * np.pi
     dx = L / N
     h = 1.5 * dx
+    if cut_over_h is None:
+        cut_over_h = 2.0 if kernel == "wendland" else 3.0     # taylor-green-vortex.xml:3, bench-script/hopper/tgv/1728/tgv.xml:2-5
     cut = cut_over_h * h
     dt = 0.1 * h / umax if dt is None else dt
-    g = (np.arange(N) + 0.5) * dx
+    g = (np.arange(N) + origin) * dx
     X, Y = np.meshgrid(g, g, indexing="xy")
     x = np.stack([X.ravel(), Y.ravel(), np.zeros(N * N)], axis=1)
     v, _ = tgv_exact(x, 0.0, umax, nu, rho0)
     p = np.zeros(N * N)
     n = N * N
+    prm = orc.SolverParams(tol=tol)
     hist = []
     for step in range(1, nsteps + 1):
         parts, own = periodic_particles(x, L, cut)
         parts["h"], parts["cut"] = h, cut
         P = orc.Particles(parts, own, kernel=kernel)
         P.precompute(corrections=not antisym)
-        if not antisym:                           # ghosts carry the owner's tensors only through row i: none needed
-            pass
         nall = parts["nall"]
         rho = np.full(nall, rho0)
         ghost = lambda a: np.ascontiguousarray(a[own])     # forward_comm_pair
         vall, pall = ghost(v), ghost(p)
-        # ---- Helmholtz RHS with theta = 0:  v* = v + (dt nu lap v) - dt/rho grad p
-        w = P.laplacian_apply(vall, antisym, dt, material=np.full(nall, nu * rho0), filt=(orc.FLUID, orc.ALL)) / rho0
-        gp = P.gradient(pall, antisym, filt=(orc.FLUID, orc.FLUID))
-        vstar = v + w - dt / rho0 * gp
-        vstar[:, 2] = 0.0
+        graph = P.graph()
+        # ---- Helmholtz (theta scheme); b comes back column-major [dim][nlocal]
+        rp, ci, hval, bh = P.helmholtz(dt, theta, np.full(nall, nu), rho, pall, np.zeros((nall, 3)), np.zeros(3), vall,
+                                       antisym=antisym, incremental=incremental, graph=graph)
+        vstar = np.zeros((n, 3))
+        if abs(theta) < 1e-14:                             # pair_isph.cpp:964-966: *x = *b
+            vstar[:, 0], vstar[:, 1] = bh[0], bh[1]
+        else:
+            ilu_h = orc.ILU(rp, ci, hval, 0) if prec == "ilu" else None
+            for k in range(2):                             # multi-RHS, initial guess v^n (pair_isph.cpp:925-927)
+                xs, info_h, _ = orc.solve(rp, ci, hval, np.ascontiguousarray(bh[k]), x0=np.ascontiguousarray(v[:, k]),
+                                          singular=False, prec=prec, ilu=ilu_h, params=prm)
+                assert info_h.converged, "Helmholtz solve did not converge"
+                vstar[:, k] = xs
         # ---- Poisson
-        rp, ci, val, b = P.poisson(dt, rho, ghost(vstar), antisym=antisym, singular=orc.NULLSPACE)
+        rp, ci, val, b = P.poisson(dt, rho, ghost(vstar), antisym=antisym, singular=orc.NULLSPACE, graph=graph)
         ilu = orc.ILU(rp, ci, val, 0) if prec == "ilu" else None
-        dp, info, _ = orc.solve(rp, ci, val, b, singular=True, prec=prec, ilu=ilu)
+        dp, info, _ = orc.solve(rp, ci, val, b, singular=True, prec=prec, ilu=ilu, params=prm)
         assert info.converged, "Poisson solve did not converge"
-        dp -= dp.mean()                           # computeZeroMeanPressure
+        if incremental:
+            dp -= dp.mean()                                # computeZeroMeanPressure (pair_isph.cpp:1022)
         # ---- corrections
         gdp = P.gradient(ghost(dp), antisym, filt=(orc.FLUID, orc.FLUID))
         vstar = vstar - dt / rho0 * gdp
         vstar[:, 2] = 0.0
-        p = p + dp
+        p = p + dp if incremental else dp.copy()           # functor_correct_pressure.h:37-41
         # ---- fix isph/tgv: error at t = dt*step, positions not yet advanced
         t = dt * step
         uex, pex = tgv_exact(x, t, umax, nu, rho0)
@@ -139,16 +165,30 @@ def run_tgv2d(N, nsteps, antisym=True, umax=0.1, nu=0.1, rho0=1.0, kernel="wendl
         x = x + dxp
         x[:, :2] %= L
         v = vstar
+        # ---- fix isph/shift
+        if shift > 0.0:
+            parts2, own2 = periodic_particles(x, L, cut)
+            parts2["h"], parts2["cut"] = h, cut
+            P2 = orc.Particles(parts2, own2, kernel=kernel)
+            P2.precompute(corrections=not antisym)
+            speed = np.sqrt(np.sum(v * v, axis=1))
+            vshift = speed.max() if shift_speed == "max" else speed.mean()
+            dr = P2.compute_shift(shift * dt * vshift, cut, 0.25)
+            xs, vs, ps = P2.apply_shift(antisym, dr, np.ascontiguousarray(v[own2]), np.ascontiguousarray(p[own2]),
+                                        sequential=True)
+            x, v, p = xs[:n].copy(), vs[:n].copy(), ps[:n].copy()
+            x[:, :2] %= L
     if return_state:
         return hist, dict(x=x, v=v, p=p)
     return hist
 
 
 if __name__ == "__main__":
-    for N in (16, 32):
-        ref = TABLE_REV390_WENDLAND[N]
-        for antisym in (True, False):
-            h = run_tgv2d(N, ref["step"], antisym=antisym)[-1]
-            print("N=%d %s  t=%.6f  p_err %.6e (ref %.6e)  u_err %.6e (ref %.6e)  norms %.6e %.6e" %
-                  (N, "AntiSym" if antisym else "Sym", h["time"], h["p_err"], ref["p_err"], h["u_err"], ref["u_err"],
-                   h["p_norm"], h["u_norm"]))
+    gold = known_answers()
+    for kernel, key in (("wendland", "conv_taylor_green_vortex_2d_rev390"), ("quintic", "conv_taylor_green_vortex_2d_rev390_quintic")):
+        for N, ref in sorted(((int(k), r) for k, r in gold[key]["rows"].items())):
+            for tag, extra in (("no shift", {}), ("shift", PINNED_SHIFT)):
+                hh = run_tgv2d(N, ref["step"], kernel=kernel, **PINNED, **extra)[-1]
+                print("%s N=%3d %-8s p_err %.9e (ref %.9e, %+.1e)  u_err %.9e (ref %.9e, %+.1e)  norms %.8e %.8e (ref %.8e %.8e)" %
+                      (kernel, N, tag, hh["p_err"], ref["p_err"], hh["p_err"] / ref["p_err"] - 1, hh["u_err"], ref["u_err"],
+                       hh["u_err"] / ref["u_err"] - 1, hh["p_norm"], hh["u_norm"], ref["p_norm"], ref["u_norm"]), flush=True)
