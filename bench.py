@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the --gpus ranks as child processes from this one (automatic when --gpus > 1 and no "
+                         "torch.distributed.run environment is present)")
     ap.add_argument("--force-rccl", action="store_true",
                     help="1 GPU only: route the periodic images through the RCCL halo path (send/recv to self)")
     return ap.parse_args()
@@ -107,8 +110,35 @@ def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters, amg_theta=0.
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without torch.distributed.run: this process never touches the GPU; it starts one
+    fresh child per rank (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* like torchrun), waits, and exits non-zero if a rank failed.
+    Rank 0's JSON line goes straight to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc != 0:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        self_launch(args)
     import torch
     import isph_amd  # noqa: F401
     from isph_amd import hip, workload, dist

@@ -120,7 +120,9 @@ static int ctx_create_common(int device, void *stream, isph_ctx **out) {
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
-    ISPH_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // hipStreamDefault: implicitly ordered against the legacy null stream, so a caller that issues its own
+    // work (zero-fills, temporaries) on stream 0 stays ordered with the library's kernels
+    ISPH_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamDefault));
     c->own_stream = true;
   }
   ISPH_CHECK_HIP(hipEventCreate(&c->ev0));

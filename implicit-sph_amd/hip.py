@@ -5,6 +5,7 @@ missing or no GPU is usable, calls raise.  Arrays may be numpy (host) or torch
 CUDA tensors (device pointers are passed straight through).
 """
 import ctypes as C
+import sys
 import os
 
 import numpy as np
@@ -181,11 +182,17 @@ def _on_device(*arrs):
 
 
 def _i32(a):
-    return a if _is_torch(a) else np.ascontiguousarray(a, dtype=np.int32)
+    if _is_torch(a):
+        assert str(a.dtype) == "torch.int32", "int32 tensor expected, got %s" % a.dtype
+        return a
+    return np.ascontiguousarray(a, dtype=np.int32)
 
 
 def _f64(a):
-    return a if _is_torch(a) else np.ascontiguousarray(a, dtype=np.float64)
+    if _is_torch(a):
+        assert str(a.dtype) == "torch.float64", "float64 tensor expected, got %s" % a.dtype
+        return a
+    return np.ascontiguousarray(a, dtype=np.float64)
 
 
 class Context:
@@ -194,6 +201,14 @@ class Context:
     def __init__(self, device=0, stream=None, rank=0, nranks=1, uid=None):
         self.h = C.c_void_p()
         self.rank, self.nranks = rank, nranks
+        if stream is None and "torch" in sys.modules:
+            # default to the stream torch is issuing on, so zero-fills / temporaries of the caller and the
+            # library's kernels are stream-ordered
+            import torch
+            if torch.cuda.is_available():
+                stream = torch.cuda.current_stream(device).cuda_stream
+        # handle 0 is the legacy null stream: the library then creates its own stream with hipStreamDefault,
+        # i.e. one that is implicitly ordered against null-stream work (isph_capi.hip ctx_create_common)
         sp = C.c_void_p(stream) if stream else None
         if nranks > 1 or uid is not None:
             _check(lib().isph_ctx_create_dist(device, sp, rank, nranks, uid, C.byref(self.h)))
@@ -417,7 +432,7 @@ def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=
                     _ptr(x), _ptr(typ), _ptr(kind), _ptr(h), _ptr(cutsq), _ptr(nptr), _ptr(nidx), _ptr(cm),
                     _ptr(vfrac), _ptr(Gc), _ptr(Lc), int(pnd is not None), _ptr(pnd), float(morris_safe_coeff),
                     _ptr(normal), float(solid_normal_diag))
-    return pv, _on_device(x, typ, nptr, nidx, cm), keep
+    return pv, _on_device(x, typ, nptr, nidx, cm, vfrac, Gc, Lc, pnd, normal), keep
 
 
 def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=NULLSPACE, rank0=True,
