@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-ifpack-1rank", action="store_true",
+                    help="also time the reference's 1-rank configuration (whole-matrix ILU(1), one thread): minutes")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--spawn", action="store_true",
                     help="start the --gpus ranks as child processes from this one (automatic when --gpus > 1 and no "
@@ -68,45 +69,64 @@ def pgrid_for(n):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
 
 
-def cpu_baseline(rp, ci, val, b, block, iters_gpu, prec, cpu_iters, amg_theta=0.0):
-    """Oracle (CPU restatement of Belos FGMRES + Ifpack block-ILU(k) / ML SA-AMG) timed on the host cores on a bounded
-    sample: preconditioner setup + `cpu_iters` of the iterations the full solve needs, extrapolated linearly.  Timed twice
-    (SURVEY 8d): on the threads the box gives us, and on ONE thread -- the reference itself has no threading, one MPI rank
-    runs exactly that."""
+def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False):
+    """Oracle (CPU restatement of Belos FGMRES + Ifpack ILU(k) / ML SA-AMG) timed on the host cores, every variant run
+    to convergence (preconditioner set-up + the whole solve, nothing extrapolated):
+      same_blocks     the GPU's own subdomains (`block` rows each), all threads
+      block_per_core  SURVEY 8(d)(ii): one ILU subdomain per core = what `mpirun -np <cores>` of the reference does with
+                      Ifpack AdditiveSchwarz overlap 0; level of fill 0 and the reference's default 1 (precond_ifpack.h:35)
+      single_thread   same_blocks on ONE thread (the reference itself has no threading)
+      ifpack_1rank    the reference on one MPI rank: ILU(1) of the whole matrix, one thread (precond_ifpack.h:35,43;
+                      overlap is a no-op on one rank).  Minutes of CPU time -> only with --cpu-ifpack-1rank; otherwise the
+                      figure measured on this matrix and committed under profiles/ is quoted.
+    `value` = the fastest all-thread variant."""
     import oracle as orc
     n = len(rp) - 1
+    threads = orc.num_threads()
 
-    def timed(iters):
+    def run(lof, bp, label):
         t0 = time.perf_counter()
-        ilu = None
-        if prec.startswith("bjacobi-ilu"):
-            bp = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
-            ilu = orc.ILU(rp, ci, val, int(prec[-1]), bp)
-        amg = None
+        ilu = amg = None
         if prec == "sa-amg":
             amg = orc.AMG(rp, ci, val, nullvec=np.full(n, 1.0 / np.sqrt(n)), block=block, theta=amg_theta)
+        elif prec.startswith("bjacobi-ilu"):
+            ilu = orc.ILU(rp, ci, val, lof, bp)
         t_setup = time.perf_counter() - t0
-        pk = "ilu" if prec.startswith("bjacobi-ilu") else {"none": "none", "jacobi": "jacobi", "sa-amg": "amg"}[prec]
-        ts = []
-        for it in (max(iters // 2, 1), iters):
-            t0 = time.perf_counter()
-            orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, amg=amg, params=orc.SolverParams(max_iters=it))
-            ts.append((it, time.perf_counter() - t0))
-        per_iter = (ts[1][1] - ts[0][1]) / max(ts[1][0] - ts[0][0], 1)
-        total = t_setup + ts[1][1] + per_iter * max(iters_gpu - ts[1][0], 0)
-        return total, ("same %d-row system: %s setup (%.2fs) + %d of %d FGMRES iterations (%.2fs), extrapolated at "
-                       "%.3fs/iteration" % (n, prec, t_setup, ts[1][0], iters_gpu, ts[1][1], per_iter))
+        pk = "ilu" if ilu is not None else {"none": "none", "jacobi": "jacobi", "sa-amg": "amg"}[prec]
+        t0 = time.perf_counter()
+        _, info, _ = orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, amg=amg)
+        t_solve = time.perf_counter() - t0
+        return dict(seconds_per_solve=t_setup + t_solve, setup_s=t_setup, solve_s=t_solve, iterations=int(info.iters),
+                    converged=int(info.converged), cores=orc.num_threads(), config=label, measured=True)
 
-    threads = orc.num_threads()
-    total, sample = timed(cpu_iters)
-    out = dict(value=1.0 / total, unit="solves/s", cores=threads, kind="port", sample=sample, seconds_per_solve=total)
+    lof = int(prec[-1]) if prec.startswith("bjacobi-ilu") else 0
+    same = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
+    percore = np.linspace(0, n, threads + 1).astype(np.int32)
+    variants = {"same_blocks": run(lof, same, "%s, %d-row blocks (the GPU's subdomains)" % (prec, block))}
+    if prec.startswith("bjacobi-ilu"):
+        variants["block_per_core"] = run(0, percore, "ILU(0), one subdomain per core (%d), overlap 0" % threads)
+        variants["block_per_core_ilu1"] = run(1, percore, "ILU(1) = reference default fill, one subdomain per core (%d), overlap 0" % threads)
     if threads > 1:
         orc.set_num_threads(1)
         try:
-            t1, s1 = timed(max(cpu_iters // 2, 2))
-            out["single_thread"] = dict(value=1.0 / t1, unit="solves/s", cores=1, sample=s1, seconds_per_solve=t1)
+            variants["single_thread"] = run(lof, same, "same_blocks on one thread")
+            if ifpack_1rank and prec.startswith("bjacobi-ilu"):
+                variants["ifpack_1rank"] = run(1, None, "ILU(1) of the whole matrix, one thread (reference on 1 MPI rank)")
         finally:
             orc.set_num_threads(threads)
+    if "ifpack_1rank" not in variants:
+        path = os.path.join(ROOT, "profiles", "r02_cpu_ifpack_1rank.json")
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            if rec.get("nrow") == n and rec.get("nnz") == int(rp[-1]):
+                variants["ifpack_1rank"] = dict(rec["ifpack_1rank"], measured="earlier run on this matrix: profiles/r02_cpu_ifpack_1rank.json")
+    multi = {k: v for k, v in variants.items() if v["cores"] == threads and v["converged"]}
+    best = min(multi, key=lambda k: multi[k]["seconds_per_solve"])
+    out = dict(value=1.0 / multi[best]["seconds_per_solve"], unit="solves/s", cores=threads, kind="port",
+               sample="the whole solve (set-up + FGMRES to 1e-8) of the same %d-row system, run to convergence; fastest "
+                      "all-thread variant = %s" % (n, best),
+               seconds_per_solve=multi[best]["seconds_per_solve"], fastest=best)
+    out.update(variants)
     return out
 
 
@@ -222,7 +242,6 @@ def main():
     x = torch.zeros(nlocal, dtype=torch.float64, device=dev)
     bwork = torch.empty_like(b)
     prm = hip.SolverParams()
-    ctx.set_profile(True)
 
     pinfo = {}
     nullvec = torch.full((nlocal,), 1.0 / np.sqrt(float(nlocal * world)), dtype=torch.float64, device=dev)
@@ -251,13 +270,19 @@ def main():
         inf = step()
     barrier()
     t0 = time.perf_counter()
-    spmv_ms, spmv_calls = 0.0, 0
     for _ in range(args.steps):
         inf = step()
-        spmv_ms += inf.spmv_ms
-        spmv_calls += inf.spmv_calls
     barrier()
     elapsed = time.perf_counter() - t0
+    # the per-launch SpMV duration (HIP events on the library's stream around every in-solve SpMV) is taken in
+    # separate, untimed passes so that the event records do not sit inside the timed steps
+    ctx.set_profile(True)
+    spmv_ms, spmv_calls = 0.0, 0
+    for _ in range(2):
+        infp = step()
+        spmv_ms += infp.spmv_ms
+        spmv_calls += infp.spmv_calls
+    barrier()
     if td is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -280,6 +305,10 @@ def main():
             traffic = tj["traffic_bytes_per_launch"]
     avg_ms = spmv_ms / max(spmv_calls, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # what the production kernel (16-bit window columns) is built to move: 10 B per STORED entry (padding included),
+    # the per-slice window table, x once, y once
+    nslices = (info_m["nrow"] + 63) // 64
+    moved_model = 10 * info_m["stored"] + 64 * 4 * nslices + 16 * info_m["nrow"]
 
     if rank == 0:
         out = {
@@ -299,18 +328,26 @@ def main():
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms, "assemble_first_call_ms": assemble_first_ms,
                        "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo},
-            "roofline": {"bound": "hbm", "kernel": "k_sell_spmv", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_sell_spmv16<8,false> (SELL-64, 16-bit window columns)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_moved_model": moved_model,
+                         "achieved_moved_model_GBs": moved_model / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                          "traffic_source": "profiles/r01_spmv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": spmv_calls},
         }
         if world == 1 and not args.no_cpu_baseline:
             rp, ci, val = A.export_csr()
-            out["cpu_baseline"] = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, inf.iters, args.prec,
-                                               args.cpu_iters, args.amg_theta)
-            out["config"]["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            if "single_thread" in out["cpu_baseline"]:
-                out["config"]["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["single_thread"]["value"]
+            cb = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, args.prec, args.amg_theta, args.cpu_ifpack_1rank)
+            out["cpu_baseline"] = cb
+            out["config"]["speedup_vs_cpu"] = out["value"] / cb["value"]            # against the FASTEST CPU variant
+            for k in ("same_blocks", "block_per_core", "block_per_core_ilu1", "single_thread", "ifpack_1rank"):
+                if k in cb:
+                    out["config"]["speedup_vs_cpu_" + k] = out["value"] * cb[k]["seconds_per_solve"]
+            if args.cpu_ifpack_1rank and "ifpack_1rank" in cb:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                json.dump(dict(nrow=info_m["nrow"], nnz=info_m["nnz"], ifpack_1rank=cb["ifpack_1rank"]),
+                          open(os.path.join(ROOT, "gpurun_out", "r02_cpu_ifpack_1rank.json"), "w"))
         print(json.dumps(out))
     if td is not None:
         td.barrier()

@@ -48,27 +48,43 @@ inline int fail(const char *what, const char *file, int line) {
 // time step (the reference deletes A / graph / map after every compute(), pair_isph.cpp:1351-1372); going
 // back to hipMalloc/hipFree for multi-GB buffers each step costs milliseconds and an implicit device sync
 // per call.  Blocks are reused when the request fits within 25 % slack; at most kPoolCapBytes stay cached.
-// release() synchronises the device first (as hipFree would), so a recycled block is never still in use
-// by a kernel of another stream.
+// A released block may still be read by kernels in flight (on any stream of the process), so release() only
+// parks it on a PENDING list without synchronising; the first allocation that finds no ready block drains the
+// device once (one hipDeviceSynchronize for all parked blocks -- in steady state one per solve set-up, none in the
+// Krylov loop) and makes the whole list ready.  Nothing is ever handed out while work that was queued before
+// its release can still touch it, whichever stream that work runs on.
 struct DevPool {
   static constexpr size_t kPoolCapBytes = (size_t)48 << 30;
-  std::multimap<size_t, void *> free_blocks;
+  std::multimap<size_t, void *> free_blocks;   // ready: no kernel can still touch them
+  std::vector<std::pair<size_t, void *>> pending;  // released since the last device synchronisation
   size_t cached = 0;
   std::mutex mu;
   static DevPool &get() {
     static DevPool p;
     return p;
   }
+  void *take_ready(size_t bytes, size_t *got) {
+    auto it = free_blocks.lower_bound(bytes);
+    if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+      void *p = it->second;
+      *got = it->first;
+      cached -= it->first;
+      free_blocks.erase(it);
+      return p;
+    }
+    return nullptr;
+  }
   void *alloc(size_t bytes, size_t *got) {
     {
       std::lock_guard<std::mutex> lk(mu);
-      auto it = free_blocks.lower_bound(bytes);
-      if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
-        void *p = it->second;
-        *got = it->first;
-        cached -= it->first;
-        free_blocks.erase(it);
-        return p;
+      if (void *p = take_ready(bytes, got)) return p;
+      bool fits = false;
+      for (auto &kv : pending) fits = fits || (kv.first >= bytes && kv.first <= bytes + bytes / 4 + 4096);
+      if (fits) {
+        (void)hipDeviceSynchronize();
+        for (auto &kv : pending) free_blocks.emplace(kv.first, kv.second);
+        pending.clear();
+        if (void *p = take_ready(bytes, got)) return p;
       }
     }
     void *p = nullptr;
@@ -81,19 +97,20 @@ struct DevPool {
   }
   void release(void *p, size_t bytes) {
     if (!p) return;
-    (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(mu);
     if (bytes >= 4096 && cached + bytes <= kPoolCapBytes) {
-      free_blocks.emplace(bytes, p);
+      pending.emplace_back(bytes, p);
       cached += bytes;
     } else {
-      (void)hipFree(p);
+      (void)hipFree(p);  // synchronises by itself
     }
   }
   void trim() {
     std::lock_guard<std::mutex> lk(mu);
     for (auto &kv : free_blocks) (void)hipFree(kv.second);
+    for (auto &kv : pending) (void)hipFree(kv.second);
     free_blocks.clear();
+    pending.clear();
     cached = 0;
   }
 };

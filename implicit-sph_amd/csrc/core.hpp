@@ -40,11 +40,13 @@ struct isph_mat {
 
 struct isph_ilu;  // ilu.hpp
 struct isph_amg;  // amg.hpp
+struct isph_schwarz;  // schwarz.hpp
 
 struct isph_prec {
-  int type = 0;  // 0 none, 1 jacobi, 2 bjacobi-ilu0, 3 sa-amg
+  int type = 0;  // 0 none, 1 jacobi, 2 bjacobi-ilu<k> (block stream), 3 sa-amg, 4 additive Schwarz ILU(k) (schwarz.hpp)
   int n = 0;
   isph::DevBuf<double> invdiag;
   isph_ilu *ilu = nullptr;
   isph_amg *amg = nullptr;
+  isph_schwarz *schwarz = nullptr;
 };

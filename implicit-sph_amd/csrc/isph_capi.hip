@@ -12,6 +12,7 @@
 #include "sell.hpp"
 #include "solver.hpp"
 #include "amg.hpp"
+#include "schwarz.hpp"
 
 namespace isph {
 thread_local std::string g_last_error;
@@ -29,6 +30,7 @@ int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z
     return ISPH_SUCCESS;
   }
   if (M->type == 3) return amg_apply(ctx, M->amg, r, z);
+  if (M->type == 4) return schwarz_apply(ctx, M->schwarz, r, z);
   return ilu_apply(ctx, M->ilu, r, z);
 }
 
@@ -401,6 +403,10 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
     // "bjacobi-ilu<k>": "fact: level-of-fill" = k (precond_ifpack.h:35)
     M->type = 2;
     rc = ilu_create(ctx, A, block_size, &M->ilu, /*sgs=*/false, /*fill=*/type[11] - '0');
+  } else if (!strncmp(type, "ilu", 3) && type[3] >= '0' && type[3] <= '8' && type[4] == 0) {
+    // "ilu<k>": ILU(k) of the whole local matrix -- what Ifpack factors on one MPI rank (the overlap is a no-op there)
+    M->type = 4;
+    rc = schwarz_create(ctx, A, type[3] - '0', /*block_size=*/0, /*overlap=*/0, /*combine=*/0, &M->schwarz);
   } else if (!strcmp(type, "sa-amg")) {
     // PrecondWrapper_ML defaults without a null vector; block_size is the Gauss-Seidel block of the fine level.
     // isph_prec_create_amg takes the full parameter set and the null vector of a singular system.
@@ -410,7 +416,7 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
     M->type = 3;
     rc = amg_create(ctx, A, &prm, nullptr, &M->amg);
   } else {
-    rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu<k>, k = 0..8|sa-amg)", __FILE__, __LINE__);
+    rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu<k>|ilu<k>, k = 0..8|sa-amg)", __FILE__, __LINE__);
   }
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
   *Mout = M;
@@ -457,7 +463,39 @@ void isph_prec_destroy(isph_prec *M) {
   M->invdiag.release();
   if (M->ilu) ilu_destroy(M->ilu);
   if (M->amg) amg_destroy(M->amg);
+  if (M->schwarz) schwarz_destroy(M->schwarz);
   delete M;
+}
+
+/* ---- additive Schwarz ILU(k) with the reference's Ifpack semantics ------ */
+
+void isph_schwarz_params_default(isph_schwarz_params *p) {
+  // PrecondWrapper_Ifpack::setParameters(NULL), ref: precond_ifpack.h:30-45
+  p->level_of_fill = 1; p->overlap = 1; p->combine = 0; p->block_size = 0;
+}
+
+int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwarz_params *prm, isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && A && prm && Mout, "NULL argument");
+  isph_prec *M = new isph_prec();
+  M->n = A->S.nrow;
+  M->type = 4;
+  const int rc = schwarz_create(ctx, A, prm->level_of_fill, prm->block_size, prm->overlap, prm->combine, &M->schwarz);
+  if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
+  *Mout = M;
+  return ISPH_SUCCESS;
+}
+
+int isph_prec_schwarz_info(const isph_prec *M, long long info[6]) {
+  ISPH_REQUIRE(M && M->type == 4 && M->schwarz && info, "not a Schwarz preconditioner");
+  const isph_schwarz *S = M->schwarz;
+  info[0] = S->nloc; info[1] = S->nnz; info[2] = S->nsub; info[3] = S->nlev_l; info[4] = S->nlev_u; info[5] = S->maxrow;
+  return ISPH_SUCCESS;
+}
+
+int isph_prec_schwarz_export(isph_ctx *ctx, const isph_prec *M, int *rows, int *loc_ptr, long long *rowptr, int *colidx,
+                             double *val) {
+  ISPH_REQUIRE(ctx && M && M->type == 4 && M->schwarz && rows && loc_ptr && rowptr && colidx && val, "bad argument");
+  return schwarz_export(ctx, M->schwarz, rows, loc_ptr, rowptr, colidx, val);
 }
 
 /* ---- SA-AMG ----------------------------------------------------------- */

@@ -133,6 +133,9 @@ def lib():
                                                     C.c_int]
         L.isph_solve_block.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_prec_create_schwarz.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_prec_schwarz_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.isph_prec_schwarz_export.argtypes = [C.c_void_p] * 7
         L.isph_amg_params_default.argtypes = [C.c_void_p]
         L.isph_prec_create_amg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.isph_prec_amg_levels.argtypes = [C.c_void_p]
@@ -345,6 +348,35 @@ class Precond:
             self.close()
         except Exception:
             pass
+
+
+class SchwarzParams(C.Structure):
+    _fields_ = [("level_of_fill", C.c_int), ("overlap", C.c_int), ("combine", C.c_int), ("block_size", C.c_int)]
+
+
+class PrecondSchwarz(Precond):
+    """isph_prec_create_schwarz: Ifpack_AdditiveSchwarz<ILU(k)> (precond_ifpack.h:28-75).  block_size 0 = one
+    subdomain = the whole local matrix (the reference on one rank); combine "add" (reference) | "zero"."""
+
+    def __init__(self, ctx, A, level_of_fill=1, overlap=1, combine="add", block_size=0):
+        self.ctx, self.h, self.n = ctx, C.c_void_p(), A.info()["nrow"]
+        prm = SchwarzParams(int(level_of_fill), int(overlap), {"add": 0, "zero": 1}[combine], int(block_size))
+        _check(lib().isph_prec_create_schwarz(ctx.h, A.h, C.byref(prm), C.byref(self.h)))
+
+    def schwarz_info(self):
+        a = (C.c_longlong * 6)()
+        _check(lib().isph_prec_schwarz_info(self.h, a))
+        return dict(nloc=a[0], nnz=a[1], nsub=a[2], levels_l=a[3], levels_u=a[4], maxrow=a[5])
+
+    def export(self):
+        i = self.schwarz_info()
+        rows = np.zeros(i["nloc"], dtype=np.int32)
+        lp = np.zeros(i["nsub"] + 1, dtype=np.int32)
+        rp = np.zeros(i["nloc"] + 1, dtype=np.int64)
+        ci = np.zeros(i["nnz"], dtype=np.int32)
+        v = np.zeros(i["nnz"])
+        _check(lib().isph_prec_schwarz_export(self.ctx.h, self.h, _ptr(rows), _ptr(lp), _ptr(rp), _ptr(ci), _ptr(v)))
+        return rows, lp, rp, ci, v
 
 
 def solve_block(ctx, blocks, b, x, prec=None, params=None, lda=None):

@@ -93,11 +93,31 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
  *                   "fact: level-of-fill"=k (precond_ifpack.h:35; the reference's
  *                   default is k = 1), one block per `block_size` rows
  *                   (k > 0: block_size <= 1024 and the symbolic phase runs on the device)
+ *   "ilu<k>"        ILU(k) of the whole local matrix: Ifpack on one MPI rank (precond_ifpack.h:60-74 with
+ *                   Comm.NumProc() == 1); see isph_prec_create_schwarz
  *   "sa-amg"        PrecondWrapper_ML::create() with its default parameters and no null vector
  *                   (isph_prec_create_amg takes the parameters and the null vector of a singular system)
  * Rebuilt every solve in the reference (solver_lin_belos.h:153,190). */
 int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int block_size,
                      isph_prec **M);
+/* Ifpack_AdditiveSchwarz<Ifpack_ILU> with the parameters PrecondWrapper_Ifpack sets (ref: precond_ifpack.h:30-45,
+ * 60-74): "fact: level-of-fill" (default 1), "Overlap Level" (default 1), "schwarz: combine mode" (default "Add" = 0;
+ * 1 = "Zero", restricted additive Schwarz).  block_size = 0: one subdomain = the whole local matrix, which is what
+ * the reference factors on one MPI rank (Ifpack ignores the overlap there); block_size = B > 0: consecutive
+ * subdomains of B rows (any B), each extended by `overlap` layers of the rows its columns reference, like the ranks
+ * of a parallel run.  isph_prec_create(type = "ilu<k>") is the block_size = 0 case.  Level-scheduled on the device
+ * (one launch per dependency level): the fidelity path; "bjacobi-ilu<k>" is the throughput path.
+ * info: [0] extended rows [1] factor entries [2] subdomains [3] L levels [4] U levels [5] longest factor row.
+ * export: rows[nloc] (global row of every local row), loc_ptr[nsub+1], factor CSR in local numbering. */
+typedef struct {
+  int level_of_fill, overlap, combine, block_size;
+} isph_schwarz_params;
+void isph_schwarz_params_default(isph_schwarz_params *p);
+int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwarz_params *prm, isph_prec **M);
+int isph_prec_schwarz_info(const isph_prec *M, long long info[6]);
+int isph_prec_schwarz_export(isph_ctx *ctx, const isph_prec *M, int *rows, int *loc_ptr, long long *rowptr,
+                             int *colidx, double *val);
+
 /* z = M^-1 r (Belos::EpetraPrecOp::Apply -> Ifpack ApplyInverse). */
 int isph_prec_apply(isph_ctx *ctx, const isph_prec *M, const double *r /*[h|d]*/,
                     double *z /*[h|d]*/, int on_device);

@@ -7,7 +7,7 @@ LIB = os.path.join(HERE, "libisph_oracle.so")
 
 
 def build_oracle(force=False):
-    srcs = [os.path.join(HERE, "isph_oracle.c"), os.path.join(HERE, "isph_amg_oracle.c")]
+    srcs = [os.path.join(HERE, f) for f in ("isph_oracle.c", "isph_amg_oracle.c", "isph_schwarz_oracle.c")]
     deps = srcs + [os.path.join(HERE, "isph_oracle.h")]
     stale = force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
     if stale:

@@ -1236,6 +1236,7 @@ typedef struct {
   int prec_type;
   const orc_ilu *F;
   const orc_amg *G;
+  const orc_schwarz *W;
   double *invdiag;
   int ncomp; /* > 1: block-diagonal preconditioner, the same operator on every component (precond_ml.h:138-155) */
 } lin_ctx;
@@ -1259,6 +1260,7 @@ static void prec_apply(const lin_ctx *c, const double *r, double *z) {
   }
   if (c->prec_type == 2 && c->F) orc_ilu_apply(c->F, r, z);
   else if (c->prec_type == 3 && c->G) orc_amg_apply(c->G, r, z);
+  else if (c->prec_type == 4 && c->W) orc_schwarz_apply(c->W, r, z);
   else if (c->prec_type == 1) {
 #pragma omp parallel for schedule(static) if (c->n > 16384)
     for (int i = 0; i < c->n; ++i) z[i] = r[i] * c->invdiag[i];
@@ -1459,6 +1461,7 @@ static int solve_impl(int n, const int *rowptr, const int *colidx, const double 
   c.prec_type = prec_type;
   c.F = prec_type == 2 ? (const orc_ilu *)prec_obj : NULL;
   c.G = prec_type == 3 ? (const orc_amg *)prec_obj : NULL;
+  c.W = prec_type == 4 ? (const orc_schwarz *)prec_obj : NULL;
   double *nvec = NULL;
   if (is_singular) {
     nvec = (double *)malloc(sizeof(double) * (size_t)n);

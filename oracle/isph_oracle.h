@@ -161,7 +161,19 @@ void orc_amg_export(const orc_amg *G, int l, int what /* 0 A_l, 1 P_l */, int *r
 void orc_amg_export_aggregates(const orc_amg *G, int l, int *agg);
 void orc_amg_destroy(orc_amg *G);
 
-/* prec_type: 0 none, 1 jacobi, 2 (block-)ILU(k) (prec_obj = orc_ilu*), 3 SA-AMG (prec_obj = orc_amg*) */
+/* Ifpack_AdditiveSchwarz<ILU(k)> with overlap and combine mode (isph_schwarz_oracle.c; ref: precond_ifpack.h:28-75).
+ * own_ptr[nsub+1]: consecutive owned row ranges; combine 0 = "Add" (the reference), 1 = "Zero" (restricted). */
+typedef struct orc_schwarz orc_schwarz;
+orc_schwarz *orc_schwarz_create(int n, const int *rowptr, const int *colidx, const double *val, int level_of_fill,
+                                int nsub, const int *own_ptr, int overlap, int combine);
+void orc_schwarz_apply(const orc_schwarz *S, const double *r, double *z);
+int  orc_schwarz_nloc(const orc_schwarz *S);
+int  orc_schwarz_nnz(const orc_schwarz *S);
+void orc_schwarz_export(const orc_schwarz *S, int *rows, int *loc_ptr, int *rowptr, int *colidx, double *val);
+void orc_schwarz_destroy(orc_schwarz *S);
+
+/* prec_type: 0 none, 1 jacobi, 2 (block-)ILU(k) (prec_obj = orc_ilu*), 3 SA-AMG (prec_obj = orc_amg*),
+ *            4 additive Schwarz ILU(k) with overlap (prec_obj = orc_schwarz*) */
 int orc_solve(int n, const int *rowptr, const int *colidx, const double *val,
               double *b, double *x, int is_singular, const int *null_mask,
               int prec_type, const void *prec_obj,

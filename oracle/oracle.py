@@ -63,6 +63,13 @@ def lib():
         L.orc_ilu_nnz.argtypes = [C.c_void_p]
         L.orc_ilu_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ilu_destroy.argtypes = [C.c_void_p]
+        L.orc_schwarz_create.restype = C.c_void_p
+        L.orc_schwarz_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_schwarz_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_schwarz_nloc.argtypes = [C.c_void_p]
+        L.orc_schwarz_nnz.argtypes = [C.c_void_p]
+        L.orc_schwarz_export.argtypes = [C.c_void_p] * 6
+        L.orc_schwarz_destroy.argtypes = [C.c_void_p]
         L.orc_amg_create.restype = C.c_void_p
         L.orc_amg_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_double, C.c_int, C.c_int, C.c_double]
@@ -322,6 +329,45 @@ class ILU:
             self.h = None
 
 
+class Schwarz:
+    """Ifpack_AdditiveSchwarz<ILU(k)> with overlap (isph_schwarz_oracle.c).  own_ptr = consecutive owned row ranges
+    (None: one subdomain = the whole matrix, the reference on one MPI rank); combine "add" (reference) | "zero"."""
+
+    def __init__(self, rowptr, colidx, val, level_of_fill=0, own_ptr=None, overlap=0, combine="add"):
+        self.n = len(rowptr) - 1
+        self._keep = (_i32(rowptr), _i32(colidx), _f64(val))
+        op = _i32([0, self.n] if own_ptr is None else own_ptr)
+        self.nsub = len(op) - 1
+        self.h = lib().orc_schwarz_create(self.n, _p(self._keep[0]), _p(self._keep[1]), _p(self._keep[2]),
+                                          int(level_of_fill), self.nsub, _p(op), int(overlap),
+                                          {"add": 0, "zero": 1}[combine])
+
+    def apply(self, r):
+        r = _f64(r)
+        z = np.zeros(self.n)
+        lib().orc_schwarz_apply(self.h, _p(r), _p(z))
+        return z
+
+    def export(self):
+        """(rows[nloc], loc_ptr[nsub+1], factor CSR in local numbering)"""
+        nloc, nnz = lib().orc_schwarz_nloc(self.h), lib().orc_schwarz_nnz(self.h)
+        rows = np.zeros(nloc, dtype=np.int32)
+        lp = np.zeros(self.nsub + 1, dtype=np.int32)
+        rp = np.zeros(nloc + 1, dtype=np.int32)
+        ci = np.zeros(nnz, dtype=np.int32)
+        v = np.zeros(nnz)
+        lib().orc_schwarz_export(self.h, _p(rows), _p(lp), _p(rp), _p(ci), _p(v))
+        return rows, lp, rp, ci, v
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                lib().orc_schwarz_destroy(self.h)
+            except TypeError:
+                pass
+            self.h = None
+
+
 class AMG:
     """Smoothed-aggregation AMG standing in for PrecondWrapper_ML (isph_amg_oracle.c)."""
 
@@ -371,7 +417,7 @@ class AMG:
 
 
 def solve(rowptr, colidx, val, b, x0=None, singular=False, null_mask=None, prec="none", ilu=None,
-          params=None, amg=None):
+          params=None, amg=None, schwarz=None):
     """SolverLin_Belos::solveProblem restatement.  Returns (x, info, b_projected)."""
     n = len(rowptr) - 1
     rowptr, colidx, val = _i32(rowptr), _i32(colidx), _f64(val)
@@ -380,8 +426,8 @@ def solve(rowptr, colidx, val, b, x0=None, singular=False, null_mask=None, prec=
     prm = params or SolverParams()
     info = SolveInfo()
     mask = None if null_mask is None else _i32(null_mask)
-    ptype = {"none": 0, "jacobi": 1, "ilu": 2, "amg": 3}[prec]
-    obj = amg.h if prec == "amg" else (ilu.h if ilu is not None else None)
+    ptype = {"none": 0, "jacobi": 1, "ilu": 2, "amg": 3, "schwarz": 4}[prec]
+    obj = amg.h if prec == "amg" else (schwarz.h if prec == "schwarz" else (ilu.h if ilu is not None else None))
     lib().orc_solve(n, _p(rowptr), _p(colidx), _p(val), _p(b), _p(x), int(singular), _p(mask), ptype,
                     obj, C.byref(prm), C.byref(info))
     return x, info, b

@@ -202,6 +202,40 @@ def test_full_size_properties(gpu_ctx):
     assert abs(x.mean()) < 1e-12 * np.abs(x).max()
 
 
+def test_config1_full_size_100cubed(gpu_ctx):
+    """BASELINE configs[1] at its full size inside the test suite (not only in bench.py): 3-D TGV, 100^3 = 1 M rows,
+    assembled and solved on the GPU with FGMRES(50) + block-Jacobi ILU(0) (512-row blocks).  Size-independent
+    properties: zero row sums, b orthogonal to the null vector after projection, x . n = 0, the residual re-computed
+    on the host with an independent CSR product <= 2e-8, the iteration count bench.py reports (116 +- 2), and the
+    same solution from the Jacobi-preconditioned solve (two different Krylov paths agree to 1e-6)."""
+    sp = tgv_spec(dim=3, n=100, mode=workload.ADVECT)
+    p = workload.make_tgv(sp)
+    colmap = workload.single_rank_colmap(p)
+    n = p["nlocal"]
+    assert n == 10 ** 6
+    vf = hip.compute_volumes(gpu_ctx, p, colmap)
+    vfrac = np.ascontiguousarray(vf[p["owner_index"]])
+    A, b = hip.assemble_poisson(gpu_ctx, p, colmap, sp.dt, p["rho"], np.ascontiguousarray(p["v"]), vfrac=vfrac)
+    info_m = A.info()
+    assert info_m["nrow"] == n and 100 < info_m["nnz"] / n < 108
+    rp, ci, v = A.export_csr()
+    assert np.max(np.abs(A.spmv(np.ones(n)))) < 1e-11 * np.abs(v).max()
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 512)
+    x, bb = np.zeros(n), b.copy()
+    info = hip.solve(gpu_ctx, A, bb, x, prec=M, singular=True)
+    assert info.converged == 1 and abs(info.iters - 116) <= 2, info.iters
+    assert abs(bb.sum()) < 1e-10 * np.abs(bb).sum()                     # b was projected in place
+    assert abs(x.mean()) < 1e-12 * np.abs(x).max()
+    Ah = _csr(rp, ci, v, n)
+    r = bb - Ah @ x
+    r -= r.mean()
+    assert np.linalg.norm(r) / np.linalg.norm(bb) < 2e-8
+    xj, bj = np.zeros(n), b.copy()
+    ij = hip.solve(gpu_ctx, A, bj, xj, prec=hip.Precond(gpu_ctx, A, "jacobi", 0), singular=True)
+    assert ij.converged == 1
+    assert np.linalg.norm(x - xj) / np.linalg.norm(xj) < 1e-6
+
+
 # ---------------------------------------------------------------- block-Jacobi ILU(0)
 ILU_CASES = [
     (dict(dim=2, n=16, mode=workload.JITTER, brick=8), 64),
