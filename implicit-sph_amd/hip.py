@@ -25,6 +25,7 @@ EXPORTS = [
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
+    "isph_schwarz_params_default", "isph_prec_create_schwarz", "isph_prec_schwarz_info", "isph_prec_schwarz_export",
 ]
 
 

@@ -125,3 +125,51 @@ def single_rank_colmap(parts):
     their column is the owner's local id (Epetra LID of the shared tag)."""
     assert np.all(parts["owner_rank"] == parts["spec"].rank)
     return parts["owner_index"].astype(np.int32).copy()
+
+
+FLUID_KIND, SOLID_KIND = 99, 12     # PairISPH::ParticleKind (pair_isph.h:113-138)
+
+
+def make_cavity(nfluid, wall=6, dim=3, pgrid=(1, 1, 1), rank=0, brick=(8, 8, 8), umax=5.0, nu=0.1, rho=1.0, lid_inset=4,
+                jitter=0.0, seed=42):
+    """Closed lid-driven cavity of sph-script/lid-driven-cavity-{2d,3d}.m + .lmp (BASELINE configs[3]): a simple-cubic
+    lattice of (nfluid + 2 wall)^dim sites in a periodic box; the inner nfluid^dim sites are fluid (type 1), the
+    `wall` layers around them solid (type 2), the part of the +y wall above the fluid minus `lid_inset` columns at
+    the x/z rims is the moving lid (type 3, velocity (umax,0,0)) (.m: `type(X.^2 < (box_half_x-4*dx)^2 & ... & Y > 0 &
+    tmp == 2) = 3`, .lmp: `velocity surface set ${Umax} 0 0`).  The script reads a data file written by the .m
+    script; this generator produces the same lattice, labels and velocities directly, in units where the periodic box
+    is [0, 2 pi).  Besides the arrays of make_tgv the dict carries
+      kinds   [FLUID, SOLID, SOLID]  ("type:1 fluid:moving, type:2/3 solid:fixed", lid-driven-cavity.xml)
+      normal  [nall][3] unit normals pointing into the fluid on the solid particles within the cut of the fluid
+              (the reference gets them from computeNormals, out of scope: they are an input here)
+      dt      0.1 h / Umax (.lmp: tstep)
+    wall must cover the cut (wall * dx >= cut) so the fluid never sees its periodic image."""
+    ncell = nfluid + 2 * wall
+    nc = (ncell,) * dim
+    spec = TGVSpec(dim=dim, ncell=nc, pgrid=pgrid, rank=rank, brick=brick[:dim], origin=(0.0,) * dim,
+                   mode=JITTER if jitter > 0 else LATTICE, jitter_amp=jitter, seed=seed, umax=umax, nu=nu, rho=rho)
+    assert wall * spec.dx >= spec.cut - 1e-12, "wall thinner than the kernel support"
+    p = make_tgv(spec)
+    tag0 = p["tag"].astype(np.int64) - 1
+    idx = np.stack([tag0 % ncell, (tag0 // ncell) % ncell, tag0 // (ncell * ncell)], axis=1)[:, :dim]   # lattice site
+    inside = np.all((idx >= wall) & (idx < wall + nfluid), axis=1)
+    typ = np.where(inside, 1, 2).astype(np.int32)
+    rim = np.ones(len(typ), dtype=bool)
+    for a in range(dim):
+        if a != 1:
+            rim &= (idx[:, a] >= wall + lid_inset) & (idx[:, a] < wall + nfluid - lid_inset)
+    typ[(idx[:, 1] >= wall + nfluid) & rim & (typ == 2)] = 3
+    v = np.zeros((p["nall"], 3))
+    v[typ == 3, 0] = umax
+    nrm = np.zeros((p["nall"], 3))
+    reach = int(np.ceil(spec.cut / spec.dx))
+    for a in range(dim):
+        nrm[idx[:, a] < wall, a] = 1.0
+        nrm[idx[:, a] >= wall + nfluid, a] = -1.0
+    near = np.all((idx >= wall - reach) & (idx < wall + nfluid + reach), axis=1) & ~inside
+    nrm[~near] = 0.0
+    ln = np.linalg.norm(nrm, axis=1)
+    nrm[ln > 0] /= ln[ln > 0, None]
+    p.update(type=typ, v=v, normal=nrm, kinds=[FLUID_KIND, SOLID_KIND, SOLID_KIND], dt=0.1 * spec.h / umax,
+             nfluid=nfluid, wall=wall)
+    return p
