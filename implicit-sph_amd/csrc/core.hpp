@@ -23,6 +23,11 @@ struct isph_ctx {
   size_t ev_used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_fetch = nullptr;  // marks the scalar mailbox copy of a Krylov iteration (host waits on it only)
+  // halo exchange overlapped with the interior rows of the SpMV: the grouped send/recv runs on comm_stream between
+  // ev_pack (send buffer packed on `stream`) and ev_halo (ghost values landed in xghost)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+  isph::DevBuf<double> xghost;
 };
 
 struct isph_halo {
@@ -30,6 +35,9 @@ struct isph_halo {
   std::vector<int> peer, send_ptr, recv_ptr;
   isph::DevBuf<int> send_idx;
   int nsend = 0, nrecv = 0;
+  // slices without / with ghost columns (k_sell_flag_ghost_slices), ascending
+  isph::DevBuf<int> list_int, list_bnd;
+  int n_int = 0, n_bnd = 0;
 };
 
 struct isph_mat {

@@ -1085,7 +1085,7 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
   if (F->n == 0) return ISPH_SUCCESS;
   constexpr int WV = 4;
   const size_t lds = sizeof(double) * 3 * (size_t)F->B * WV;
-  static const int pf = []() { const char *e = getenv("ISPH_ILU_PREFETCH"); return e ? atoi(e) : kPrefetch; }();
+  constexpr int pf = kPrefetch;
 #define ISPH_ILU_LAUNCH(PF)                                                                                             \
   do {                                                                                                                   \
     if (lds > 48 * 1024)                                                                                                 \

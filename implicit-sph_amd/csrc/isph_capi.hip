@@ -130,6 +130,9 @@ static int ctx_create_common(int device, void *stream, isph_ctx **out) {
   ISPH_CHECK_HIP(hipEventCreate(&c->ev0));
   ISPH_CHECK_HIP(hipEventCreate(&c->ev1));
   ISPH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
+  ISPH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
+  ISPH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  ISPH_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   ISPH_CHECK(ensure_scalars(c));
   *out = c;
   return ISPH_SUCCESS;
@@ -164,6 +167,10 @@ int isph_ctx_set_profile(isph_ctx *ctx, int on) {
 void isph_ctx_destroy(isph_ctx *c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);
+  if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
+  if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+  c->xghost.release();
   if (c->comm) (void)ncclCommDestroy(c->comm);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
@@ -259,6 +266,27 @@ int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_ra
     ISPH_CHECK_HIP(hipMemcpyAsync(H.send_idx.p, send_idx, sizeof(int) * (size_t)H.nsend, hipMemcpyHostToDevice, ctx->stream));
     ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
+  // interior / boundary slices: the interior ones (no ghost column) run while the exchange is in flight
+  const Sell &S = A->S;
+  H.n_int = H.n_bnd = 0;
+  if (S.nslices > 0) {
+    DevBuf<int> flag;
+    ISPH_CHECK(flag.reserve((size_t)S.nslices));
+    hipLaunchKernelGGL(k_sell_flag_ghost_slices, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices,
+                       (const long long *)S.slice_off.p, (const int *)S.col.p, flag.p);
+    std::vector<int> hf((size_t)S.nslices), li, lb;
+    ISPH_CHECK_HIP(hipMemcpyAsync(hf.data(), flag.p, sizeof(int) * (size_t)S.nslices, hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    flag.release();
+    for (int s = 0; s < S.nslices; ++s) (hf[(size_t)s] ? lb : li).push_back(s);
+    H.n_int = (int)li.size();
+    H.n_bnd = (int)lb.size();
+    ISPH_CHECK(H.list_int.reserve(li.size() > 0 ? li.size() : 1));
+    ISPH_CHECK(H.list_bnd.reserve(lb.size() > 0 ? lb.size() : 1));
+    if (!li.empty()) ISPH_CHECK_HIP(hipMemcpyAsync(H.list_int.p, li.data(), sizeof(int) * li.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!lb.empty()) ISPH_CHECK_HIP(hipMemcpyAsync(H.list_bnd.p, lb.data(), sizeof(int) * lb.size(), hipMemcpyHostToDevice, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
   return ISPH_SUCCESS;
 }
 
@@ -316,6 +344,8 @@ void isph_mat_destroy(isph_mat *A) {
   if (!A) return;
   A->S.release();
   A->halo.send_idx.release();
+  A->halo.list_int.release();
+  A->halo.list_bnd.release();
   delete A;
 }
 
@@ -350,8 +380,17 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
   ISPH_REQUIRE(ctx && A && x_dev && y_dev && avg_ms && reps > 0, "bad argument");
   const Sell &S = A->S;
   ISPH_REQUIRE(S.ncol == S.nrow || A->halo.npeers > 0, "ghost columns without halo plan");
+  if (S.ncol != S.nrow) {  // matrix with a halo: time the production path (exchange + interior/boundary launches)
+    ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r) ISPH_CHECK(spmv_dev(ctx, A, x_dev, y_dev, nullptr));
+    ISPH_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+    float msh = 0.f;
+    ISPH_CHECK_HIP(hipEventElapsedTime(&msh, ctx->ev0, ctx->ev1));
+    *avg_ms = (double)msh / reps;
+    return ISPH_SUCCESS;
+  }
   const double *xuse = x_dev;
-  ISPH_CHECK(halo_exchange(ctx, A, x_dev, &xuse));
   int nbp = 0;
   const int grid = spmv_grid(S.nslices, &nbp);
   // kernel-tuning aid: ISPH_SPMV_VARIANT selects an experimental instantiation for this timing call only

@@ -202,17 +202,29 @@ __global__ void k_sell_to_csr(int nrow, const int *__restrict__ rowlen, const lo
 // x gathered through the XCD-local L2 (xcd_remap keeps an XCD on one
 // contiguous row range).  Optionally accumulates per-slice partials of y.n
 // for the PoissonProjection (ref: solver_lin.h:131-140).
-template <int UNROLL, bool DOT, bool NT = false>
+// LIST: the launch covers the slices slice_list[0..nslices) (interior / boundary split of a matrix with a halo: the
+// interior slices have no ghost column and run while the halo exchange is in flight).  GHOST: columns >= nrow are
+// read from the ghost buffer xg the exchange received into (no copy of x into an extended vector).
+template <bool GHOST>
+__device__ __forceinline__ double x_at(const double *__restrict__ x, const double *__restrict__ xg, int nrow, int c) {
+  if (GHOST) return c < nrow ? x[c] : xg[c - nrow];
+  return x[c];
+}
+
+template <int UNROLL, bool DOT, bool NT = false, bool LIST = false, bool GHOST = false>
 __global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int nblocks_padded,
                                                       const long long *__restrict__ slice_off,
                                                       const int *__restrict__ scol,
                                                       const double *__restrict__ sval,
                                                       const double *__restrict__ x, double *__restrict__ y,
                                                       const double *__restrict__ nvec,
-                                                      double *__restrict__ dot_partial) {
+                                                      double *__restrict__ dot_partial,
+                                                      const int *__restrict__ slice_list = nullptr,
+                                                      const double *__restrict__ xg = nullptr) {
   const int b = xcd_remap(blockIdx.x, nblocks_padded);
-  const int slice = b * (kBlock / kWave) + (threadIdx.x >> 6);
+  int slice = b * (kBlock / kWave) + (threadIdx.x >> 6);
   if (slice >= nslices) return;
+  if (LIST) slice = slice_list[slice];
   const int lane = threadIdx.x & 63;
   const long long off = slice_off[slice];
   const int npair = (int)((slice_off[slice + 1] - off) >> 7);
@@ -238,8 +250,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int
     double xa[UNROLL], xb[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      xa[u] = x[cc[u].x];
-      xb[u] = x[cc[u].y];
+      xa[u] = x_at<GHOST>(x, xg, nrow, cc[u].x);
+      xb[u] = x_at<GHOST>(x, xg, nrow, cc[u].y);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -250,8 +262,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int
   for (; q < npair; ++q) {
     const double2 vv = v[q * 64];
     const int2 cc = c[q * 64];
-    acc0 = fma(vv.x, x[cc.x], acc0);
-    acc1 = fma(vv.y, x[cc.y], acc1);
+    acc0 = fma(vv.x, x_at<GHOST>(x, xg, nrow, cc.x), acc0);
+    acc1 = fma(vv.y, x_at<GHOST>(x, xg, nrow, cc.y), acc1);
   }
   const int row = slice * kSlice + lane;
   const double r = acc0 + acc1;
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_sell_compress_cols(int nslices, cons
   }
 }
 
-template <int UNROLL, bool DOT>
+template <int UNROLL, bool DOT, bool LIST = false, bool GHOST = false>
 __global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, int nblocks_padded,
                                                         const long long *__restrict__ slice_off,
                                                         const unsigned short *__restrict__ c16,
@@ -313,12 +325,15 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, i
                                                         const double *__restrict__ sval,
                                                         const double *__restrict__ x, double *__restrict__ y,
                                                         const double *__restrict__ nvec,
-                                                        double *__restrict__ dot_partial) {
+                                                        double *__restrict__ dot_partial,
+                                                        const int *__restrict__ slice_list = nullptr,
+                                                        const double *__restrict__ xg = nullptr) {
   __shared__ int tab[kBlock / kWave][64];
   const int b = xcd_remap(blockIdx.x, nblocks_padded);
   const int wave = threadIdx.x >> 6;
-  const int slice = b * (kBlock / kWave) + wave;
+  int slice = b * (kBlock / kWave) + wave;
   if (slice >= nslices) return;
+  if (LIST) slice = slice_list[slice];
   const int lane = threadIdx.x & 63;
   tab[wave][lane] = wtab[(long long)slice * 64 + lane] << 10;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -343,8 +358,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, i
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const unsigned lo = cc[u] & 0xffffu, hi = cc[u] >> 16;
-      xa[u] = x[tw[lo >> 10] | (int)(lo & 1023u)];
-      xb[u] = x[tw[hi >> 10] | (int)(hi & 1023u)];
+      xa[u] = x_at<GHOST>(x, xg, nrow, tw[lo >> 10] | (int)(lo & 1023u));
+      xb[u] = x_at<GHOST>(x, xg, nrow, tw[hi >> 10] | (int)(hi & 1023u));
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -356,8 +371,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, i
     const double2 vv = v[q * 64];
     const unsigned cc = c[q * 64];
     const unsigned lo = cc & 0xffffu, hi = cc >> 16;
-    acc0 = fma(vv.x, x[tw[lo >> 10] | (int)(lo & 1023u)], acc0);
-    acc1 = fma(vv.y, x[tw[hi >> 10] | (int)(hi & 1023u)], acc1);
+    acc0 = fma(vv.x, x_at<GHOST>(x, xg, nrow, tw[lo >> 10] | (int)(lo & 1023u)), acc0);
+    acc1 = fma(vv.y, x_at<GHOST>(x, xg, nrow, tw[hi >> 10] | (int)(hi & 1023u)), acc1);
   }
   const int row = slice * kSlice + lane;
   const double r = acc0 + acc1;
@@ -381,6 +396,19 @@ __global__ void k_sell_inv_diag(int nrow, const int *__restrict__ rowlen, const 
     if (scol[p] == row) d += sval[p];
   }
   invdiag[row] = d != 0.0 ? 1.0 / d : 1.0;
+}
+
+// flag[slice] = 1 when the slice reads a ghost column (column >= nrow): boundary slice of a matrix with a halo
+__global__ __launch_bounds__(kBlock) void k_sell_flag_ghost_slices(int nrow, int nslices, const long long *__restrict__ slice_off,
+                                                                   const int *__restrict__ scol, int *__restrict__ flag) {
+  const int slice = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (slice >= nslices) return;
+  const int lane = threadIdx.x & 63;
+  const long long off = slice_off[slice], nent = slice_off[slice + 1] - off;
+  bool g = false;
+  for (long long e = lane; e < nent; e += 64) g = g || (scol[off + e] >= nrow);
+  const unsigned long long m = __ballot(g);
+  if (lane == 0) flag[slice] = m != 0ull;
 }
 
 inline int spmv_grid(int nslices, int *nblocks_padded) {

@@ -47,26 +47,32 @@ __global__ void k_gather(int n, const int *__restrict__ idx, const double *__res
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = x[idx[i]];
 }
 
-// returns the pointer the SpMV kernel should gather from
-inline int halo_exchange(isph_ctx *ctx, const isph_mat *A, const double *x, const double **xuse) {
+// Starts the halo exchange of x for a matrix with ghost columns: the boundary values are packed on the compute stream,
+// the grouped ncclSend/ncclRecv runs on ctx->comm_stream and lands in ctx->xghost; ctx->ev_halo marks its end.  The
+// caller launches the interior slices on the compute stream meanwhile and makes the compute stream wait on ev_halo
+// before the boundary slices.  The communicator is only ever used by one operation at a time: the exchange starts
+// after everything queued before it (ev_pack) and every later collective is queued behind the boundary kernel, which
+// itself waits for ev_halo.  (Ifpack/Epetra do this Import inside Epetra_CrsMatrix::Apply, solver_lin.h:133.)
+inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x) {
   const Sell &S = A->S;
-  if (S.ncol == S.nrow || A->local) { *xuse = x; return ISPH_SUCCESS; }
   const isph_halo &H = A->halo;
   ISPH_REQUIRE(H.nrecv == S.ncol - S.nrow, "matrix has ghost columns but no matching halo plan");
-  ISPH_CHECK(ctx->xext.reserve((size_t)S.ncol));
+  ISPH_REQUIRE(H.n_int + H.n_bnd == S.nslices, "halo plan without the interior/boundary slice lists");
+  ISPH_CHECK(ctx->xghost.reserve((size_t)(H.nrecv > 0 ? H.nrecv : 1)));
   ISPH_CHECK(ctx->sendbuf.reserve((size_t)(H.nsend > 0 ? H.nsend : 1)));
-  ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xext.p, x, sizeof(double) * (size_t)S.nrow, hipMemcpyDeviceToDevice, ctx->stream));
   if (H.nsend > 0)
     hipLaunchKernelGGL(k_gather, dim3(stream_grid(H.nsend)), dim3(kBlock), 0, ctx->stream, H.nsend, H.send_idx.p, x,
                        ctx->sendbuf.p);
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev_pack, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_pack, 0));
   ISPH_CHECK_NCCL(ncclGroupStart());
   for (int p = 0; p < H.npeers; ++p) {
     const int ns = H.send_ptr[p + 1] - H.send_ptr[p], nr = H.recv_ptr[p + 1] - H.recv_ptr[p];
-    if (ns > 0) ISPH_CHECK_NCCL(ncclSend(ctx->sendbuf.p + H.send_ptr[p], (size_t)ns, ncclDouble, H.peer[p], ctx->comm, ctx->stream));
-    if (nr > 0) ISPH_CHECK_NCCL(ncclRecv(ctx->xext.p + S.nrow + H.recv_ptr[p], (size_t)nr, ncclDouble, H.peer[p], ctx->comm, ctx->stream));
+    if (ns > 0) ISPH_CHECK_NCCL(ncclSend(ctx->sendbuf.p + H.send_ptr[p], (size_t)ns, ncclDouble, H.peer[p], ctx->comm, ctx->comm_stream));
+    if (nr > 0) ISPH_CHECK_NCCL(ncclRecv(ctx->xghost.p + H.recv_ptr[p], (size_t)nr, ncclDouble, H.peer[p], ctx->comm, ctx->comm_stream));
   }
   ISPH_CHECK_NCCL(ncclGroupEnd());
-  *xuse = ctx->xext.p;
+  ISPH_CHECK_HIP(hipEventRecord(ctx->ev_halo, ctx->comm_stream));
   return ISPH_SUCCESS;
 }
 
@@ -93,9 +99,8 @@ inline int profile_end(isph_ctx *ctx, size_t slot) {
 // builds the 16-bit column copy of a matrix on first use (see k_sell_compress_cols); returns whether it is usable
 inline bool sell_cols16(isph_ctx *ctx, const Sell &S) {
   if (S.c16_state != 0) return S.c16_state > 0;
-  static const bool off = getenv("ISPH_SPMV_COL32") != nullptr;  // tuning aid: keep the 32-bit kernel
   S.c16_state = -1;
-  if (off || S.nslices == 0 || S.stored == 0) return false;
+  if (S.nslices == 0 || S.stored == 0) return false;
   DevBuf<int> flag;
   if (flag.reserve(1) != ISPH_SUCCESS || S.col16.reserve((size_t)S.stored) != ISPH_SUCCESS ||
       S.wtab.reserve((size_t)S.nslices * 64) != ISPH_SUCCESS) { flag.release(); return false; }
@@ -112,32 +117,43 @@ inline bool sell_cols16(isph_ctx *ctx, const Sell &S) {
   return S.c16_state > 0;
 }
 
+template <bool DOT, bool LIST, bool GHOST>
+inline void spmv_launch(isph_ctx *ctx, const Sell &S, bool c16, int nsl, const int *list, const double *x, const double *xg,
+                        double *y, const double *nvec) {
+  if (nsl <= 0) return;
+  int nbp = 0;
+  const int grid = spmv_grid(nsl, &nbp);
+  double *part = DOT ? ctx->partial.p : nullptr;
+  if (c16)
+    hipLaunchKernelGGL((k_sell_spmv16<8, DOT, LIST, GHOST>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, nsl, nbp,
+                       S.slice_off.p, S.col16.p, S.wtab.p, S.val.p, x, y, nvec, part, list, xg);
+  else
+    hipLaunchKernelGGL((k_sell_spmv<8, DOT, true, LIST, GHOST>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, nsl, nbp,
+                       S.slice_off.p, S.col.p, S.val.p, x, y, nvec, part, list, xg);
+}
+
 // y = A x ; if nvec: also SC_MISC+0 = y.nvec (all-reduced)
 inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, const double *nvec) {
   const Sell &S = A->S;
-  const double *xuse = x;
-  ISPH_CHECK(halo_exchange(ctx, A, x, &xuse));
-  int nbp = 0;
-  const int grid = spmv_grid(S.nslices, &nbp);
+  const bool halo = !(S.ncol == S.nrow || A->local);
   // AMG transfer / coarse operators are small or have very long rows: the window tables do not pay there
   const bool c16 = !A->local && sell_cols16(ctx, S);
   size_t slot = (size_t)-1;
   if (!A->local) ISPH_CHECK(profile_begin(ctx, &slot));  // the SpMV statistics are those of the caller's operator only
-  if (nvec) {
+  if (nvec)
     ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
-    if (c16)
-      hipLaunchKernelGGL((k_sell_spmv16<8, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
-                         S.slice_off.p, S.col16.p, S.wtab.p, S.val.p, xuse, y, nvec, ctx->partial.p);
-    else
-      hipLaunchKernelGGL((k_sell_spmv<8, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
-                         S.slice_off.p, S.col.p, S.val.p, xuse, y, nvec, ctx->partial.p);
+  if (!halo) {
+    if (nvec) spmv_launch<true, false, false>(ctx, S, c16, S.nslices, nullptr, x, nullptr, y, nvec);
+    else spmv_launch<false, false, false>(ctx, S, c16, S.nslices, nullptr, x, nullptr, y, nvec);
   } else {
-    if (c16)
-      hipLaunchKernelGGL((k_sell_spmv16<8, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
-                         S.slice_off.p, S.col16.p, S.wtab.p, S.val.p, xuse, y, (const double *)nullptr, (double *)nullptr);
-    else
-      hipLaunchKernelGGL((k_sell_spmv<8, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
-                         S.slice_off.p, S.col.p, S.val.p, xuse, y, (const double *)nullptr, (double *)nullptr);
+    const isph_halo &H = A->halo;
+    ISPH_CHECK(halo_begin(ctx, A, x));
+    // interior slices (no ghost column) while the exchange is in flight
+    if (nvec) spmv_launch<true, true, false>(ctx, S, c16, H.n_int, H.list_int.p, x, nullptr, y, nvec);
+    else spmv_launch<false, true, false>(ctx, S, c16, H.n_int, H.list_int.p, x, nullptr, y, nvec);
+    ISPH_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));
+    if (nvec) spmv_launch<true, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);
+    else spmv_launch<false, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);
   }
   ISPH_CHECK(profile_end(ctx, slot));
   if (nvec) {
@@ -249,17 +265,14 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
                          bool deflate = false) {
   int g = stream_grid(n);
   // 2 workgroups per CU with two rows per thread in flight: multi-dot 53.6 -> 44.4 us, the 64-wide fused update
-  // 92.8 -> 79.5 us against 4 workgroups per CU, one row (rocprofv3, bench matrix); ISPH_DOT_ROWS / ISPH_DOT_GRID
-  // are tuning switches
+  // 92.8 -> 79.5 us against 4 workgroups per CU, one row (rocprofv3, bench matrix)
   if (g > 1024) g = 1024;
   ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
   hipStream_t st = ctx->stream;
   double *dh1 = ctx->dscal.p + SC_DOT, *dh2 = ctx->dscal.p + SC_Y, *dor = ctx->dscal.p + SC_ORTHO;
-  static const int dot_rows = []() { const char *e = getenv("ISPH_DOT_ROWS"); return e ? atoi(e) : 2; }();
-  static const int dot_grid = []() { const char *e = getenv("ISPH_DOT_GRID"); return e ? atoi(e) : 512; }();
+  constexpr int dot_grid = 512;
   if (g > dot_grid) g = dot_grid;
-  if (dot_rows == 2) hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
-  else hipLaunchKernelGGL((k_multi_dot<1>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+  hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh1,
                      (const double *)nullptr);
   ISPH_CHECK(allreduce_inplace(ctx, dh1, nk + 1));
@@ -322,8 +335,7 @@ inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_
   // to n, so V^T (w - (w.n) n) = V^T w: the projection of PoissonProjection::Apply is folded into the Gram-Schmidt
   // step (n rides along as one more vector of the multi-dot / update), which saves one reduction, one all-reduce
   // and one vector pass per iteration.  IMGS keeps the explicit projection.
-  static const bool no_deflate = getenv("ISPH_NO_DEFLATE") != nullptr;  // tuning aid: explicit projection as in the operator
-  const bool deflate = op.nvec != nullptr && !op.blk && prm->ortho != 2 && !no_deflate;
+  const bool deflate = op.nvec != nullptr && !op.blk && prm->ortho != 2;
   ISPH_CHECK(ctx->V.reserve((size_t)ld * (size_t)(m + 2)));
   if (prm->flexible) ISPH_CHECK(ctx->Z.reserve((size_t)ld * (size_t)m));
   ISPH_CHECK(ctx->wv.reserve((size_t)ld));

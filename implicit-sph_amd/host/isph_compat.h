@@ -113,12 +113,42 @@ class Epetra_Map {
   std::vector<int> gid_;
 };
 
+// The import plan FillComplete builds for the ghost columns (Epetra_Import + its Epetra_MpiDistributor): which owned
+// rows go to which rank (ProcsTo / LengthsTo / ExportLIDs, grouped by destination) and how many ghost values arrive
+// from which rank (ProcsFrom / LengthsFrom; the ghost columns nrow.. are stored grouped by source rank in that order).
+class Epetra_Import {
+ public:
+  Epetra_Import(int nto, const int *procs_to, const int *lengths_to, const int *export_lids, int nfrom,
+                const int *procs_from, const int *lengths_from)
+      : to_(procs_to, procs_to + nto), lto_(lengths_to, lengths_to + nto), from_(procs_from, procs_from + nfrom),
+        lfrom_(lengths_from, lengths_from + nfrom) {
+    int ns = 0;
+    for (int k = 0; k < nto; ++k) ns += lengths_to[k];
+    exp_.assign(export_lids, export_lids + ns);
+    nrem_ = 0;
+    for (int k = 0; k < nfrom; ++k) nrem_ += lengths_from[k];
+  }
+  int NumSends() const { return (int)to_.size(); }
+  const int *ProcsTo() const { return to_.data(); }
+  const int *LengthsTo() const { return lto_.data(); }
+  int NumExportIDs() const { return (int)exp_.size(); }
+  const int *ExportLIDs() const { return exp_.data(); }
+  int NumReceives() const { return (int)from_.size(); }
+  const int *ProcsFrom() const { return from_.data(); }
+  const int *LengthsFrom() const { return lfrom_.data(); }
+  int NumRemoteIDs() const { return nrem_; }
+ private:
+  std::vector<int> to_, lto_, exp_, from_, lfrom_;
+  int nrem_ = 0;
+};
+
 // the filled matrix as Epetra hands it over after FillComplete+OptimizeStorage:
 // contiguous CSR with local column ids (ExtractCrsDataPointers)
 class Epetra_CrsMatrix {
  public:
-  Epetra_CrsMatrix(int nrow, int ncol, int *rowptr, int *colidx, double *val)
-      : nrow_(nrow), ncol_(ncol), rp_(rowptr), ci_(colidx), v_(val) {}
+  Epetra_CrsMatrix(int nrow, int ncol, int *rowptr, int *colidx, double *val, const Epetra_Import *importer = nullptr)
+      : nrow_(nrow), ncol_(ncol), rp_(rowptr), ci_(colidx), v_(val), imp_(importer) {}
+  const Epetra_Import *Importer() const { return imp_; }  // NULL when the matrix has no ghost columns
   int NumMyRows() const { return nrow_; }
   int NumMyCols() const { return ncol_; }
   int NumMyNonzeros() const { return rp_[nrow_]; }
@@ -131,6 +161,7 @@ class Epetra_CrsMatrix {
   int nrow_, ncol_;
   int *rp_, *ci_;
   double *v_;
+  const Epetra_Import *imp_ = nullptr;
 };
 
 // column-major [lda x nvec] view or owned storage (solver_lin.cpp:45-58)

@@ -3,10 +3,13 @@
 // SolverLin_Belos` keeps `typedef class SolverLin_Belos SolverLinear`
 // (pair_isph.h:77) and the USER-REAXC-T call site compiling unchanged.
 #pragma once
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "isph_hip.h"
 #include "solver_lin.h"
@@ -72,6 +75,7 @@ class SolverLin_HIP : public SolverLin {
     _A->ExtractCrsDataPointers(rp, ci, v);
     isph_mat *A = nullptr;
     if (isph_mat_create_csr(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, 0, &A) != ISPH_SUCCESS) return report_failure();
+    if (attachHalo(A, *_A) != ISPH_SUCCESS) { isph_mat_destroy(A); return report_failure(); }
 
     int rc = ISPH_SUCCESS;
     if (prec != NULL) {
@@ -126,6 +130,7 @@ class SolverLin_HIP : public SolverLin {
         double *v = nullptr;
         B->ExtractCrsDataPointers(rp, ci, v);
         rc = isph_mat_create_csr(_ctx, B->NumMyRows(), B->NumMyCols(), rp, ci, v, 0, &blk[i * _dim + j]);
+        if (rc == ISPH_SUCCESS) rc = attachHalo(blk[i * _dim + j], *B);
         cblk[i * _dim + j] = blk[i * _dim + j];
       }
     // diagonal preconditioner: one operator, built from the matrix the wrapper was given (precond_ml.h:138-155:
@@ -139,6 +144,7 @@ class SolverLin_HIP : public SolverLin {
       double *v = nullptr;
       P->ExtractCrsDataPointers(rp, ci, v);
       rc = isph_mat_create_csr(_ctx, P->NumMyRows(), P->NumMyCols(), rp, ci, v, 0, &Aprec);
+      if (rc == ISPH_SUCCESS) rc = attachHalo(Aprec, *P);
       if (rc == ISPH_SUCCESS) rc = prec->createOnDevice(_ctx, Aprec);
       if (rc == ISPH_SUCCESS && !prec->_M) {
         isph_mat_destroy(Aprec);
@@ -169,9 +175,70 @@ class SolverLin_HIP : public SolverLin {
   const isph_solve_info &lastSolveInfo() const { return _last; }
 
  private:
+  // One context per solver object.  More than one rank (SolverLin(MPI_Comm&) is multi-rank by construction,
+  // solver_lin.cpp:30-31; row map = the rank's atoms, pair_isph.cpp:1258-1259), or a matrix that carries ghost
+  // columns, needs the RCCL communicator: rank 0 draws the unique id and broadcasts it over the caller's MPI
+  // communicator.  One GPU per rank: `device` = the rank's local device index (constructor argument).
+  bool needComm() const {
+    if (_comm.NumProc() > 1) return true;
+    if (_A.get() && _A->Importer() != NULL) return true;
+    for (int k = 0; k < 9; ++k)
+      if (_blk[k] && _blk[k]->Importer() != NULL) return true;
+    return false;
+  }
   int ensureContext() {
     if (_ctx) return ISPH_SUCCESS;
-    return isph_ctx_create(_device, nullptr, &_ctx);
+    if (!needComm()) return isph_ctx_create(_device, nullptr, &_ctx);
+    char uid[ISPH_UID_BYTES];
+    std::memset(uid, 0, sizeof(uid));
+    if (_comm.MyPID() == 0 && isph_comm_unique_id(uid) != ISPH_SUCCESS) return ISPH_FAILURE;
+#ifdef ISPH_HAVE_MPI
+    MPI_Bcast(uid, ISPH_UID_BYTES, MPI_BYTE, 0, _comm.Comm());
+#endif
+    return isph_ctx_create_dist(_device, nullptr, _comm.MyPID(), _comm.NumProc(), uid, &_ctx);
+  }
+  // Epetra_Import of the matrix -> isph_mat_set_halo: peers = ProcsTo U ProcsFrom (ascending), per peer the owned rows
+  // to send (ExportLIDs, grouped by destination) and the number of ghost values to receive (ghost columns are stored
+  // grouped by source rank, Epetra's column-map order).
+  int attachHalo(isph_mat *A, const Epetra_CrsMatrix &E) {
+    if (E.NumMyCols() == E.NumMyRows()) return ISPH_SUCCESS;
+#ifdef HAVE_EPETRA
+    const Epetra_Import *imp = E.Importer();
+    if (!imp) return ISPH_FAILURE;
+    const Epetra_MpiDistributor *d = dynamic_cast<const Epetra_MpiDistributor *>(&imp->Distributor());
+    if (!d) return ISPH_FAILURE;
+    const int nto = d->NumSends(), nfrom = d->NumReceives();
+    const int *pto = d->ProcsTo(), *lto = d->LengthsTo(), *pfrom = d->ProcsFrom(), *lfrom = d->LengthsFrom();
+    const int *exp = imp->ExportLIDs();
+#else
+    const Epetra_Import *imp = E.Importer();
+    if (!imp) return ISPH_FAILURE;
+    const int nto = imp->NumSends(), nfrom = imp->NumReceives();
+    const int *pto = imp->ProcsTo(), *lto = imp->LengthsTo(), *pfrom = imp->ProcsFrom(), *lfrom = imp->LengthsFrom();
+    const int *exp = imp->ExportLIDs();
+#endif
+    std::vector<int> peers;
+    for (int k = 0; k < nto; ++k) peers.push_back(pto[k]);
+    for (int k = 0; k < nfrom; ++k) peers.push_back(pfrom[k]);
+    std::sort(peers.begin(), peers.end());
+    peers.erase(std::unique(peers.begin(), peers.end()), peers.end());
+    const int np = (int)peers.size();
+    std::vector<int> send_ptr((size_t)np + 1, 0), recv_ptr((size_t)np + 1, 0), send_idx;
+    std::vector<int> exp_off((size_t)nto + 1, 0);
+    for (int k = 0; k < nto; ++k) exp_off[(size_t)k + 1] = exp_off[(size_t)k] + lto[k];
+    for (int p = 0; p < np; ++p) {
+      for (int k = 0; k < nto; ++k)
+        if (pto[k] == peers[(size_t)p]) send_idx.insert(send_idx.end(), exp + exp_off[(size_t)k], exp + exp_off[(size_t)k + 1]);
+      send_ptr[(size_t)p + 1] = (int)send_idx.size();
+      int nr = 0;
+      for (int k = 0; k < nfrom; ++k)
+        if (pfrom[k] == peers[(size_t)p]) nr += lfrom[k];
+      recv_ptr[(size_t)p + 1] = recv_ptr[(size_t)p] + nr;
+    }
+    // ghost columns must be grouped by source rank in ascending rank order (ProcsFrom is sorted by Epetra)
+    for (int k = 1; k < nfrom; ++k)
+      if (pfrom[k] < pfrom[k - 1]) return ISPH_FAILURE;
+    return isph_mat_set_halo(_ctx, A, np, peers.data(), send_ptr.data(), send_idx.data(), recv_ptr.data());
   }
   int report_failure() {
     if (_comm.MyPID() == 0) std::fprintf(stderr, ">> SolverLin_HIP: %s\n", isph_last_error());

@@ -76,8 +76,57 @@ static int run_block(const char *fin, const char *fout) {
   return info.converged ? 0 : 3;
 }
 
+// "selfhalo": in.bin = n, ncol, nnz, rp, ci (ghost columns >= n), val, b[n], nsend, send_idx[nsend].  The matrix carries
+// an Epetra_Import whose only peer is this rank (periodic images routed through the halo plan): drives
+// isph_ctx_create_dist + isph_mat_set_halo from the C++ surface, i.e. the N > 1 code path of SolverLin(MPI_Comm&).
+static int run_selfhalo(const char *fin, const char *fout) {
+  FILE *f = std::fopen(fin, "rb");
+  if (!f) return 2;
+  int n = 0, ncol = 0, nnz = 0, nsend = 0;
+  if (std::fread(&n, 4, 1, f) != 1 || std::fread(&ncol, 4, 1, f) != 1 || std::fread(&nnz, 4, 1, f) != 1) return 2;
+  std::vector<int> rp((size_t)n + 1), ci((size_t)nnz), gid((size_t)n);
+  std::vector<double> val((size_t)nnz), b((size_t)n), x((size_t)n, 0.0);
+  if (std::fread(rp.data(), 4, rp.size(), f) != rp.size() || std::fread(ci.data(), 4, ci.size(), f) != ci.size() ||
+      std::fread(val.data(), 8, val.size(), f) != val.size() || std::fread(b.data(), 8, b.size(), f) != b.size() ||
+      std::fread(&nsend, 4, 1, f) != 1) return 2;
+  std::vector<int> send_idx((size_t)nsend);
+  if (std::fread(send_idx.data(), 4, send_idx.size(), f) != send_idx.size()) return 2;
+  std::fclose(f);
+  for (int i = 0; i < n; ++i) gid[(size_t)i] = i + 1;
+  MPI_Comm world = 0;
+  Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
+  const int me = 0, nrecv = ncol - n;
+  Epetra_Import importer(1, &me, &nsend, send_idx.data(), 1, &me, &nrecv);
+  Epetra_CrsMatrix AA(n, ncol, rp.data(), ci.data(), val.data(), &importer);
+  PrecondWrapper_Ifpack prec(world);
+  Teuchos::ParameterList *pp = prec.setParameters();
+  pp->set("fact: level-of-fill", 0);
+  pp->set("Overlap Level", 0);
+  pp->set("isph: block rows", 256);
+  SolverLin_Belos li_solver(world);
+  li_solver.setParameters();
+  li_solver.setNodalMap(&nodalmap);
+  li_solver.setMatrix(&AA);
+  prec.setMatrix(&AA);
+  li_solver.createSolutionMultiVector(x.data(), n, 1);
+  li_solver.createLoadMultiVector(b.data(), n, 1);
+  Epetra_IntSerialDenseVector null_mask(n);
+  for (int i = 0; i < n; ++i) null_mask[i] = 1;
+  li_solver.setNullVectorMask(&null_mask);
+  li_solver.setMatrixIsSingular(true);
+  li_solver.setInitialSolution(SolverLin::Zero);
+  if (li_solver.solveProblem(&prec, "self-halo") != LAMMPS_SUCCESS) return 1;
+  const isph_solve_info &info = li_solver.lastSolveInfo();
+  std::printf("converged=%d iters=%d rel=%.3e\n", info.converged, info.iters, info.rel_res_implicit);
+  f = std::fopen(fout, "wb");
+  std::fwrite(x.data(), 8, x.size(), f);
+  std::fclose(f);
+  return info.converged ? 0 : 3;
+}
+
 int main(int argc, char **argv) {
   if (argc > 4 && std::string(argv[4]) == "block") return run_block(argv[1], argv[2]);
+  if (argc > 4 && std::string(argv[4]) == "selfhalo") return run_selfhalo(argv[1], argv[2]);
   if (argc < 4) { std::fprintf(stderr, "usage: %s in.bin out.bin singular(0/1) [cg|ml]\n", argv[0]); return 2; }
   FILE *f = std::fopen(argv[1], "rb");
   if (!f) return 2;

@@ -93,10 +93,12 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
     rho, nu, vel, nrm = t(p["rho"]), t(p["nu"]), t(p["v"]), t(p["normal"])
     vf = hip.compute_volumes(gpu_ctx, dp, colmap)
     vfrac = vf[own].contiguous()
+    G, _ = hip.compute_corrections(gpu_ctx, dp, colmap, vfrac)        # computePre: G_i for the wall terms
+    Gc = G[own].contiguous()
     pres = torch.zeros(nall, dtype=torch.float64, device=dev)
     force = torch.zeros((nall, 3), dtype=torch.float64, device=dev)
     blocks, b = hip.assemble_block_helmholtz(gpu_ctx, dp, colmap, p["dt"], THETA, BETA, nu, rho, pres, force, np.zeros(3),
-                                             vel, normal=nrm, vfrac=vfrac, kinds=p["kinds"])
+                                             vel, normal=nrm, vfrac=vfrac, Gc=Gc, kinds=p["kinds"])
     assert all(blocks[i][j] is not None for i in range(3) for j in range(3))
     x = vel[:n].t().contiguous().reshape(-1).clone()
     M = hip.Precond(gpu_ctx, blocks[0][0], "bjacobi-ilu0", 512)
@@ -126,7 +128,7 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
     vstar = torch.zeros((nall, 3), dtype=torch.float64, device=dev)
     vstar[:n] = vs
     vstar = vstar[own].contiguous()
-    A, bp = hip.assemble_poisson(gpu_ctx, dp, colmap, p["dt"], rho, vstar, vfrac=vfrac, kinds=p["kinds"], normal=nrm)
+    A, bp = hip.assemble_poisson(gpu_ctx, dp, colmap, p["dt"], rho, vstar, vfrac=vfrac, Gc=Gc, kinds=p["kinds"], normal=nrm)
     mask = (p["type"][:n] == 1).astype(np.int32)
     xp = torch.zeros(n, dtype=torch.float64, device=dev)
     bpw = bp.clone()

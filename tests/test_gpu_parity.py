@@ -439,6 +439,36 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     assert np.allclose(bproj, bo, rtol=0, atol=1e-13 * np.abs(bo).max())   # b view updated in place
 
 
+def test_cpp_solver_lin_mirror_with_halo(tmp_path):
+    """The N > 1 code path of the C++ surface on one GPU: the matrix handed to SolverLin_Belos carries ghost columns
+    and an Epetra_Import (periodic images routed as ghosts received from this very rank), so solveProblem goes through
+    isph_comm_unique_id -> isph_ctx_create_dist -> isph_mat_set_halo and the overlapped RCCL exchange.  Must give the
+    folded single-rank solution."""
+    import subprocess
+    from isph_amd import build, dist
+    exe = build.build_cpp_test()
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    plan = dist.make_self_halo_plan(pr.parts)
+    # the same system with the images as ghost columns: oracle graph over the plan's column map
+    Ph = orc.Particles(pr.parts, plan.colmap)
+    Ph.precompute(corrections=False)
+    rph, cih, valh, bh = Ph.poisson(pr.spec.dt, pr.parts["rho"], pr.parts["v"], singular=orc.NULLSPACE)
+    assert cih.max() >= pr.n and np.allclose(bh, b, rtol=0, atol=1e-13 * np.abs(b).max())
+    fin, fout = tmp_path / "sys.bin", tmp_path / "x.bin"
+    with open(fin, "wb") as f:
+        np.array([pr.n, plan.ncol, len(valh)], np.int32).tofile(f)
+        rph.astype(np.int32).tofile(f); cih.astype(np.int32).tofile(f); valh.tofile(f); bh.tofile(f)
+        np.array([len(plan.send_idx)], np.int32).tofile(f)
+        plan.send_idx.astype(np.int32).tofile(f)
+    r = subprocess.run([exe, str(fin), str(fout), "1", "selfhalo"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    x = np.fromfile(fout)
+    bp = np.arange(0, pr.n + 256, 256).clip(0, pr.n).astype(np.int32)
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+
+
 # ---------------------------------------------------------------- Helmholtz builder (SURVEY §8 a8)
 @pytest.mark.parametrize("case", [dict(dim=2, n=20, mode=workload.JITTER), dict(dim=3, n=12, mode=workload.ADVECT),
                                   dict(dim=2, n=4, mode=workload.JITTER, brick=0)])
