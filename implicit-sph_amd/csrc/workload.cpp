@@ -17,6 +17,7 @@ struct Layout {
   int N[3], P[3], rc[3], lo[3], hi[3], n[3], g[3], ext[3], bs[3];
   double dx[3], h, cut, cutn;
   int nlocal, nghost;
+  int nb;  // particles per lattice cell: 1 = simple cubic / square, 2 = bcc (second site at the cell centre)
 };
 
 inline int wrap(int c, int n) { int r = c % n; return r < 0 ? r + n : r; }
@@ -59,6 +60,7 @@ inline double u01(uint64_t seed, uint64_t gid, int axis) {
 bool make_layout(const isph_tgv_spec *s, Layout &L) {
   L.dim = s->dim;
   if (s->dim != 2 && s->dim != 3) return false;
+  L.nb = s->basis == 2 ? 2 : 1;
   double maxdisp = 0.0;
   for (int a = 0; a < 3; ++a) {
     L.N[a] = (a < s->dim) ? s->ncell[a] : 1;
@@ -87,8 +89,9 @@ bool make_layout(const isph_tgv_spec *s, Layout &L) {
     L.nlocal *= L.n[a];
     nall *= L.ext[a];
   }
-  if (nall > 2000000000LL) return false;
-  L.nghost = (int)nall - L.nlocal;
+  if (nall * L.nb > 2000000000LL) return false;
+  L.nghost = (int)(nall - L.nlocal) * L.nb;
+  L.nlocal *= L.nb;
   return true;
 }
 
@@ -100,12 +103,13 @@ inline void tgv_velocity(double umax, const double p[3], double v[3]) {
 
 // position / velocity of the particle born in wrapped global cell gw, placed
 // at unwrapped cell gc (gc == gw for owned cells)
-void particle_state(const isph_tgv_spec *s, const Layout &L, const int gc[3], const int gw[3],
+void particle_state(const isph_tgv_spec *s, const Layout &L, const int gc[3], const int gw[3], int b,
                     double x[3], double v[3]) {
   double base[3], disp[3] = {0, 0, 0};
-  const uint64_t gid = ((uint64_t)gw[2] * L.N[1] + gw[1]) * L.N[0] + gw[0];
+  const uint64_t gid = (((uint64_t)gw[2] * L.N[1] + gw[1]) * L.N[0] + gw[0]) * (uint64_t)L.nb + (uint64_t)b;
+  const double boff = b ? 0.5 : 0.0;  // bcc: the second site sits at the cell centre
   for (int a = 0; a < 3; ++a)
-    base[a] = (a < L.dim) ? (gw[a] + s->origin[a]) * L.dx[a] : 0.0;
+    base[a] = (a < L.dim) ? (gw[a] + s->origin[a] + boff) * L.dx[a] : 0.0;
   if (s->mode == ISPH_TGV_JITTER) {
     for (int a = 0; a < L.dim; ++a) disp[a] = s->jitter_amp * L.h * (2.0 * u01(s->seed, gid, a) - 1.0);
     double p[3] = {base[0] + disp[0], base[1] + disp[1], base[2] + disp[2]};
@@ -116,7 +120,7 @@ void particle_state(const isph_tgv_spec *s, const Layout &L, const int gc[3], co
       for (int a = 0; a < L.dim; ++a) disp[a] = s->advect_dt * v[a];
   }
   for (int a = 0; a < 3; ++a)
-    x[a] = (a < L.dim) ? (gc[a] + s->origin[a]) * L.dx[a] + disp[a] : 0.0;
+    x[a] = (a < L.dim) ? (gc[a] + s->origin[a] + boff) * L.dx[a] + disp[a] : 0.0;
 }
 
 }  // namespace
@@ -128,7 +132,7 @@ extern "C" int isph_tgv_count(const isph_tgv_spec *s, int *nlocal, int *nghost, 
   *nghost = L.nghost;
   long long stencil = 1;
   for (int a = 0; a < 3; ++a) stencil *= (2 * L.g[a] + 1);
-  *neigh_cap = (long long)L.nlocal * (stencil - 1);
+  *neigh_cap = (long long)L.nlocal * (stencil * L.nb - 1);
   return 0;
 }
 
@@ -138,8 +142,9 @@ extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v,
   Layout L;
   if (!make_layout(s, L)) return -1;
   const long long next = (long long)L.ext[0] * L.ext[1] * L.ext[2];
-  std::vector<int> pidx((size_t)next);  // extended cell -> particle index
+  std::vector<int> pidx((size_t)next);  // extended cell -> index of its first particle (nb consecutive particles per cell)
   // owned cells -> brick order, ghosts -> nlocal + running counter
+  const int nb = L.nb;
   int ghost = L.nlocal;
   for (int ez = 0; ez < L.ext[2]; ++ez)
     for (int ey = 0; ey < L.ext[1]; ++ey)
@@ -154,13 +159,14 @@ extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v,
           if (c[a] < 0 || c[a] >= L.n[a]) own = false;
         }
         const long long ec = ((long long)ez * L.ext[1] + ey) * L.ext[0] + ex;
-        int p;
+        int p, orank_p, oidx_p;
         if (own) {
-          p = brick_index(L.n, L.bs, c);
-          owner_rank[p] = s->rank;
-          owner_index[p] = p;
+          p = brick_index(L.n, L.bs, c) * nb;
+          orank_p = s->rank;
+          oidx_p = p;
         } else {
-          p = ghost++;
+          p = ghost;
+          ghost += nb;
           int orc[3], olo[3], ohi[3], on[3], oc[3];
           for (int a = 0; a < 3; ++a) {
             // owner rank coordinate along a: invert split()
@@ -172,12 +178,16 @@ extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v,
             on[a] = ohi[a] - olo[a];
             oc[a] = gw[a] - olo[a];
           }
-          owner_rank[p] = (orc[2] * L.P[1] + orc[1]) * L.P[0] + orc[0];
-          owner_index[p] = brick_index(on, L.bs, oc);
+          orank_p = (orc[2] * L.P[1] + orc[1]) * L.P[0] + orc[0];
+          oidx_p = brick_index(on, L.bs, oc) * nb;
         }
         pidx[(size_t)ec] = p;
-        tag[p] = 1 + (int)(((long long)gw[2] * L.N[1] + gw[1]) * L.N[0] + gw[0]);
-        particle_state(s, L, gc, gw, &x[3 * (size_t)p], &v[3 * (size_t)p]);
+        for (int b = 0; b < nb; ++b) {
+          owner_rank[p + b] = orank_p;
+          owner_index[p + b] = oidx_p + b;
+          tag[p + b] = 1 + (int)((((long long)gw[2] * L.N[1] + gw[1]) * L.N[0] + gw[0]) * nb + b);
+          particle_state(s, L, gc, gw, b, &x[3 * (size_t)(p + b)], &v[3 * (size_t)(p + b)]);
+        }
       }
   // full neighbour list, candidates in ascending extended-cell order
   const double cutnsq = L.cutn * L.cutn;
@@ -193,27 +203,33 @@ extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v,
       for (int cy = 0; cy < L.n[1]; ++cy)
         for (int cx = 0; cx < L.n[0]; ++cx) {
           const int ex = cx + L.g[0], ey = cy + L.g[1], ez = cz + L.g[2];
-          const int i = pidx[(size_t)(((long long)ez * L.ext[1] + ey) * L.ext[0] + ex)];
-          const double *xi = &x[3 * (size_t)i];
-          int cnt = 0;
-          int *out = pass == 1 ? &neigh_idx[neigh_ptr[i]] : nullptr;
-          for (int oz = -L.g[2]; oz <= L.g[2]; ++oz)
-            for (int oy = -L.g[1]; oy <= L.g[1]; ++oy)
-              for (int ox = -L.g[0]; ox <= L.g[0]; ++ox) {
-                if (!ox && !oy && !oz) continue;
-                const int j = pidx[(size_t)(((long long)(ez + oz) * L.ext[1] + (ey + oy)) * L.ext[0] + (ex + ox))];
-                const double *xj = &x[3 * (size_t)j];
-                double rsq = 0.0;
-                for (int a = 0; a < L.dim; ++a) {
-                  const double d = xi[a] - xj[a];
-                  rsq += d * d;
+          const int i0 = pidx[(size_t)(((long long)ez * L.ext[1] + ey) * L.ext[0] + ex)];
+          for (int bi = 0; bi < nb; ++bi) {
+            const int i = i0 + bi;
+            const double *xi = &x[3 * (size_t)i];
+            int cnt = 0;
+            int *out = pass == 1 ? &neigh_idx[neigh_ptr[i]] : nullptr;
+            for (int oz = -L.g[2]; oz <= L.g[2]; ++oz)
+              for (int oy = -L.g[1]; oy <= L.g[1]; ++oy)
+                for (int ox = -L.g[0]; ox <= L.g[0]; ++ox) {
+                  const int j0 = pidx[(size_t)(((long long)(ez + oz) * L.ext[1] + (ey + oy)) * L.ext[0] + (ex + ox))];
+                  for (int bj = 0; bj < nb; ++bj) {
+                    const int j = j0 + bj;
+                    if (j == i) continue;
+                    const double *xj = &x[3 * (size_t)j];
+                    double rsq = 0.0;
+                    for (int a = 0; a < L.dim; ++a) {
+                      const double d = xi[a] - xj[a];
+                      rsq += d * d;
+                    }
+                    if (rsq < cutnsq) {
+                      if (out) out[cnt] = j;
+                      ++cnt;
+                    }
+                  }
                 }
-                if (rsq < cutnsq) {
-                  if (out) out[cnt] = j;
-                  ++cnt;
-                }
-              }
-          if (pass == 0) rowcnt[(size_t)i] = cnt;
+            if (pass == 0) rowcnt[(size_t)i] = cnt;
+          }
         }
   }
   return neigh_ptr[L.nlocal];

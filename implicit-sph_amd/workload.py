@@ -17,7 +17,7 @@ class _Spec(C.Structure):
                 ("brick", C.c_int * 3), ("origin", C.c_double * 3), ("h_over_dx", C.c_double),
                 ("cut_over_h", C.c_double), ("skin", C.c_double), ("mode", C.c_int),
                 ("jitter_amp", C.c_double), ("seed", C.c_ulonglong), ("umax", C.c_double),
-                ("advect_dt", C.c_double)]
+                ("advect_dt", C.c_double), ("basis", C.c_int)]
 
 
 _lib = None
@@ -51,6 +51,7 @@ class TGVSpec:
     kernel: str = "wendland"
     rho: float = 1.0
     nu: float = 0.1
+    basis: int = 1          # 2 = bcc (second particle at the cell centre)
     extra: dict = field(default_factory=dict)
 
     @property
@@ -88,6 +89,7 @@ class TGVSpec:
         s.h_over_dx, s.cut_over_h, s.skin = self.h_over_dx, self.cut_over_h, self.skin
         s.mode, s.jitter_amp, s.seed, s.umax = self.mode, self.jitter_amp, self.seed, self.umax
         s.advect_dt = self.advect_dt if self.advect_dt >= 0 else self.dt
+        s.basis = self.basis
         return s
 
 

@@ -36,6 +36,9 @@ typedef struct {
   unsigned long long seed;
   double umax;           /* 0.1                                               */
   double advect_dt;      /* ADVECT: positions += advect_dt * v_tgv(lattice)   */
+  int basis;             /* particles per cell: 0/1 simple cubic (`lattice sc`), 2 body-centred cubic
+                            (`lattice bcc ${dx}`, sph-script/pore-scale-flow-3d.lmp): second site at the
+                            cell centre; the cell's particles are numbered consecutively */
 } isph_tgv_spec;
 
 /* Sizes needed to allocate the arrays of isph_tgv_fill. */

@@ -40,6 +40,7 @@ typedef struct { int n, m; int *rp, *ci; double *v; } csr_t; /* n rows, m column
 
 struct orc_amg {
   int nlev, block, sweeps, singular;
+  int whole_sgs; /* 1: Gauss-Seidel over the whole level (= ML's processor-local sweep on one rank) */
   csr_t A[AMG_MAXLEV], P[AMG_MAXLEV], R[AMG_MAXLEV];
   int *agg[AMG_MAXLEV];
   double *nv[AMG_MAXLEV];
@@ -137,6 +138,65 @@ static int aggregate(const csr_t *A, double theta, int *agg) {
 static double diag_of(const csr_t *A, int i) {
   for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) if (A->ci[p] == i) return A->v[p];
   return 1.0;
+}
+
+/* ML's "Uncoupled" aggregation as ML defines it (ML_Aggregate_CoarsenUncoupled; Tuminaro & Tong, "Parallel smoothed
+ * aggregation multigrid: aggregation strategies on massively parallel machines", SC 2000, section 3), restated for
+ * one rank, natural ordering:
+ *   phase 1  sweep the nodes in row order; a node whose strong neighbourhood is still entirely unaggregated becomes a
+ *            root and forms an aggregate with ALL its strong neighbours;
+ *   phase 2  every node left over that has a strong neighbour in a phase-1 aggregate joins the aggregate it is most
+ *            strongly coupled to (ties: the first in row order);
+ *   phase 3  what is still left (no aggregated neighbour) is swept in row order: a node forms a new aggregate with its
+ *            unaggregated strong neighbours.
+ * Isolated nodes (no strong neighbour) stay out of every aggregate, like in the MIS-2 variant (Dirichlet-like rows).
+ * This is the sequential algorithm the device's MIS-2 variant departs from; orc_amg_create_ex(aggregation = 1)
+ * selects it so that the iteration-count gap between the two can be measured (tests/test_oracle.py). */
+static int aggregate_ml_uncoupled(const csr_t *A, double theta, int *agg) {
+  const int n = A->n;
+  const double th2 = theta * theta;
+  double *dg = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; ++i) dg[i] = diag_of(A, i);
+  for (int i = 0; i < n; ++i) agg[i] = -1;
+  int nagg = 0;
+  for (int i = 0; i < n; ++i) { /* phase 1 */
+    if (agg[i] >= 0) continue;
+    int deg = 0, free_nb = 1;
+    for (int p = A->rp[i]; p < A->rp[i + 1] && free_nb; ++p) {
+      const int j = A->ci[p];
+      if (!STRONG(p, i, j)) continue;
+      ++deg;
+      if (agg[j] >= 0) free_nb = 0;
+    }
+    if (!deg || !free_nb) continue;
+    agg[i] = nagg;
+    for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) { const int j = A->ci[p]; if (STRONG(p, i, j)) agg[j] = nagg; }
+    ++nagg;
+  }
+  const int nphase1 = nagg;
+  int *a1 = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  memcpy(a1, agg, sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) { /* phase 2: against the phase-1 state only */
+    if (a1[i] >= 0) continue;
+    double best = -1.0;
+    for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) {
+      const int j = A->ci[p];
+      if (!STRONG(p, i, j) || a1[j] < 0 || a1[j] >= nphase1) continue;
+      const double w = fabs(A->v[p]);
+      if (w > best) { best = w; agg[i] = a1[j]; }
+    }
+  }
+  for (int i = 0; i < n; ++i) { /* phase 3 */
+    if (agg[i] >= 0) continue;
+    int deg = 0;
+    for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) deg += STRONG(p, i, A->ci[p]);
+    if (!deg) continue;
+    agg[i] = nagg;
+    for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) { const int j = A->ci[p]; if (STRONG(p, i, j) && agg[j] < 0) agg[j] = nagg; }
+    ++nagg;
+  }
+  free(a1); free(dg);
+  return nagg;
 }
 
 /* P = (I - omega/rho D^-1 A) P_tent, P_tent[i, agg i] = nv_i / |nv restricted to the aggregate| */
@@ -284,7 +344,7 @@ static void sgs_solve(const csr_t *A, const double *dinv, int block, const doubl
 static void smooth(const orc_amg *G, int l, const double *b, double *x, int zero_guess) {
   const csr_t *A = &G->A[l];
   double *r = G->r[l];
-  const int blk = l == 0 ? G->block : AMG_COARSE_BLOCK;
+  const int blk = G->whole_sgs ? (A->n > 0 ? A->n : 1) : (l == 0 ? G->block : AMG_COARSE_BLOCK);
   if (zero_guess) { sgs_solve(A, G->dinv[l], blk, b, x); return; }
   spmv(A, x, r);
   for (int i = 0; i < A->n; ++i) r[i] = b[i] - r[i];
@@ -315,8 +375,16 @@ static void dense_solve(int n, const double *a, const int *piv, double *x) {
 
 orc_amg *orc_amg_create(int n, const int *rowptr, const int *colidx, const double *val, const double *nullvec,
                         int max_levels, int coarse_max, double omega, int block, int sweeps, double theta) {
+  return orc_amg_create_ex(n, rowptr, colidx, val, nullvec, max_levels, coarse_max, omega, block, sweeps, theta, 0, 0);
+}
+
+/* aggregation: 0 = distance-2 MIS (the device algorithm), 1 = ML's sequential Uncoupled sweep;
+ * whole_sgs: 1 = Gauss-Seidel over the whole level (ML on one rank) instead of block-local */
+orc_amg *orc_amg_create_ex(int n, const int *rowptr, const int *colidx, const double *val, const double *nullvec,
+                           int max_levels, int coarse_max, double omega, int block, int sweeps, double theta,
+                           int aggregation, int whole_sgs) {
   orc_amg *G = (orc_amg *)calloc(1, sizeof(orc_amg));
-  G->block = block; G->sweeps = sweeps; G->singular = nullvec != NULL;
+  G->block = block; G->sweeps = sweeps; G->singular = nullvec != NULL; G->whole_sgs = whole_sgs;
   if (max_levels > AMG_MAXLEV) max_levels = AMG_MAXLEV;
   /* level 0: the local square part of A */
   csr_t *A0 = &G->A[0];
@@ -340,7 +408,7 @@ orc_amg *orc_amg_create(int n, const int *rowptr, const int *colidx, const doubl
     const csr_t *A = &G->A[l];
     if (A->n <= coarse_max) break;
     G->agg[l] = (int *)malloc(sizeof(int) * (size_t)A->n);
-    const int nagg = aggregate(A, theta, G->agg[l]);
+    const int nagg = aggregation == 1 ? aggregate_ml_uncoupled(A, theta, G->agg[l]) : aggregate(A, theta, G->agg[l]);
     /* no coarsening, or a coarse space too small to carry anything but the null vector: stop here */
     if (nagg < 8 || nagg >= A->n) { free(G->agg[l]); G->agg[l] = NULL; break; }
     G->nv[l + 1] = (double *)malloc(sizeof(double) * (size_t)nagg);

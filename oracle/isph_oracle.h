@@ -154,6 +154,11 @@ orc_amg *orc_amg_create(int n, const int *rowptr, const int *colidx, const doubl
                         const double *nullvec /* NULL: non-singular, constant near-null space */,
                         int max_levels, int coarse_max, double omega, int block, int sweeps,
                         double theta /* "aggregation: threshold", ML default 0 */);
+/* aggregation 0 = distance-2 MIS roots (device algorithm), 1 = ML's sequential Uncoupled sweep (phases 1-3);
+ * whole_sgs 1 = symmetric Gauss-Seidel over the whole level (ML's processor-local sweep on one rank) */
+orc_amg *orc_amg_create_ex(int n, const int *rowptr, const int *colidx, const double *val, const double *nullvec,
+                           int max_levels, int coarse_max, double omega, int block, int sweeps, double theta,
+                           int aggregation, int whole_sgs);
 void orc_amg_apply(const orc_amg *G, const double *r, double *z);
 int  orc_amg_levels(const orc_amg *G);
 void orc_amg_level_info(const orc_amg *G, int l, int *info /* rows, nnz A_l, nnz P_l */);
