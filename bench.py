@@ -164,6 +164,12 @@ def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         self_launch(args)
+    # stdout carries exactly ONE line, the JSON record.  Libraries write banners to the C-level stdout (RCCL prints its
+    # version block there when a communicator is created), so fd 1 is pointed at stderr for the whole run and the record
+    # is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import isph_amd  # noqa: F401
     from isph_amd import hip, workload, dist
@@ -312,11 +318,13 @@ def main():
     # HBM traffic of the SpMV kernel from the PMC passes committed under profiles/ (rocprofv3
     # cannot run inside this process); only quoted when it was taken on this very matrix.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_spmv_traffic.json")
-    if os.path.exists(tpath):
+    import glob
+    tsrc = None
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_spmv_traffic.json")), reverse=True):  # newest round first
         tj = json.load(open(tpath))
         if tj.get("nrow") == info_m["nrow"] and tj.get("nnz") == info_m["nnz"]:
-            traffic = tj["traffic_bytes_per_launch"]
+            traffic, tsrc = tj["traffic_bytes_per_launch"], os.path.relpath(tpath, ROOT)
+            break
     avg_ms = spmv_ms / max(spmv_calls, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # what the production kernel (16-bit window columns) is built to move: 10 B per STORED entry (padding included),
@@ -347,7 +355,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_moved_model": moved_model,
                          "achieved_moved_model_GBs": moved_model / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                         "traffic_source": "profiles/r01_spmv_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
+                         "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": spmv_calls},
         }
         if world == 1 and not args.no_cpu_baseline and args.prec in ("none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg"):
@@ -362,7 +370,8 @@ def main():
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 json.dump(dict(nrow=info_m["nrow"], nnz=info_m["nnz"], ifpack_1rank=cb["ifpack_1rank"]),
                           open(os.path.join(ROOT, "gpurun_out", "r02_cpu_ifpack_1rank.json"), "w"))
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if td is not None:
         td.barrier()
         td.destroy_process_group()

@@ -175,3 +175,49 @@ def make_cavity(nfluid, wall=6, dim=3, pgrid=(1, 1, 1), rank=0, brick=(8, 8, 8),
     p.update(type=typ, v=v, normal=nrm, kinds=[FLUID_KIND, SOLID_KIND, SOLID_KIND], dt=0.1 * spec.h / umax,
              nfluid=nfluid, wall=wall)
     return p
+
+
+def make_porous_cylinder(nc, wall=5, nbeads=12, rbead_cells=3.0, seed=7, brick=(8, 8, 8), pgrid=(1, 1, 1), rank=0,
+                         jitter=0.0, rho=997.561, nu=8.9087e-07, umax=0.04):
+    """Pore-scale flow through a bead pack in a cylinder (BASELINE configs[4]; sph-script/pore-scale-flow-3d.lmp +
+    compute_isph_cylinder_porous.cpp:195-224): `lattice bcc ${dx}` (2 particles per cell, 749 entries per matrix row
+    with the script's Quintic kernel, cut = 3 h = 4.5 dx), cylinder along y (periodic), labels
+        type 4  outside the cylinder radius (solid wall)          is_coords_in_cylinder, compute_isph_cylinder_porous.h:65-71
+        type 3  inside a bead (solid; beads only in the middle half of the length, :45-63)
+        type 2  buffer fluid (a slab of the length near the inlet, :73-75)
+        type 1  fluid
+    with "type:1/2 fluid, type:3/4 solid:fixed" (pore-scale-flow.xml).  The reference creates atoms only inside the
+    radius r + 4 dx of a non-periodic box; here the lattice fills a periodic cube of nc cells per side whose corners
+    are additional type-4 wall (wall >= cut/dx cells thick so the fluid never sees its periodic image), the bead
+    centres are drawn from a seeded generator instead of the script's data file, and beads are solid throughout
+    (inner radius 0: no deleted particles)."""
+    spec = TGVSpec(dim=3, ncell=(nc, nc, nc), pgrid=pgrid, rank=rank, brick=brick, origin=(0.0, 0.0, 0.0),
+                   mode=JITTER if jitter > 0 else LATTICE, jitter_amp=jitter, seed=seed, umax=umax, nu=nu, rho=rho,
+                   basis=2, kernel="quintic", cut_over_h=3.0)
+    assert wall * spec.dx >= spec.cut - 1e-12, "wall thinner than the kernel support"
+    p = make_tgv(spec)
+    L, dx = 2.0 * math.pi, spec.dx
+    x = p["x"]
+    xw = np.mod(x, L)                                        # labels are periodic: images get their owner's label
+    c = 0.5 * L
+    R = (0.5 * nc - wall) * dx
+    r2 = (xw[:, 0] - c) ** 2 + (xw[:, 2] - c) ** 2
+    typ = np.ones(p["nall"], dtype=np.int32)
+    typ[(xw[:, 1] > 0.05 * L) & (xw[:, 1] < 0.12 * L)] = 2   # buffer slab
+    rng = np.random.default_rng(seed)
+    rb = rbead_cells * dx
+    part = np.zeros(p["nall"], dtype=np.int32)
+    for k in range(nbeads):
+        rad = (R - rb) * math.sqrt(rng.random())
+        ang = 2.0 * math.pi * rng.random()
+        bc = np.array([c + rad * math.cos(ang), (0.25 + 0.5 * rng.random()) * L, c + rad * math.sin(ang)])
+        d2 = np.sum((xw - bc) ** 2, axis=1)
+        hit = (d2 < rb * rb) & (part == 0)
+        typ[hit] = 3
+        part[hit] = k + 1
+    typ[r2 >= R * R] = 4
+    part[r2 >= R * R] = -1
+    v = np.zeros((p["nall"], 3))
+    p.update(type=typ, v=v, part=part, kinds=[FLUID_KIND, FLUID_KIND, SOLID_KIND, SOLID_KIND],
+             g=np.array([0.0, 1.06, 0.0]), dt=0.1 * spec.h / umax, radius=R)
+    return p

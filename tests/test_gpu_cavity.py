@@ -105,7 +105,7 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
     bw = b.clone()
     info = hip.solve_block(gpu_ctx, blocks, bw, x, prec=M)
     assert info.converged == 1
-    res2, bn2, off = 0.0, 0.0, 0.0
+    res2, bn2 = 0.0, 0.0
     for i in range(3):
         r = b[i * n:(i + 1) * n].clone()
         for j in range(3):
@@ -115,7 +115,8 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
                 off += float(y.abs().sum())
         res2 += float((r * r).sum())
         bn2 += float((b[i * n:(i + 1) * n] ** 2).sum())
-    assert off > 0.0
+    ones = torch.ones(n, dtype=torch.float64, device=dev)
+    assert float(blocks[0][1].spmv(ones).abs().max()) > 0.0           # edge/corner wall rows couple the components
     assert np.sqrt(res2 / bn2) < 2e-8
     vs = x.reshape(3, n).t().contiguous()
     typ = dp["type"][:n]

@@ -1,0 +1,97 @@
+"""-m gpu: BASELINE configs[4] -- pore-scale flow through a bead pack in a cylinder (sph-script/pore-scale-flow-3d.lmp,
+compute_isph_cylinder_porous.cpp:195-224): bcc lattice, Quintic kernel cut 3h (749 entries per row), MorrisHolmes
+boundary, NotSingular Poisson, SA-AMG preconditioner.  Oracle parity on a 16 000-particle cylinder, size-independent
+properties on 1.02 M particles (767 M matrix entries).  The configuration's full 4 M particles (3.0e9 entries) exceed the
+32-bit neighbour/CSR offsets of this build (DESIGN.md "Size limits")."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from isph_amd import hip, workload
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_porous_small_matches_oracle(gpu_ctx):
+    p = workload.make_porous_cylinder(20, brick=(4, 4, 4), jitter=0.02)
+    n, nall = p["nlocal"], p["nall"]
+    colmap = workload.single_rank_colmap(p)
+    assert np.diff(p["neigh_ptr"]).max() >= 700                       # bcc + cut 4.5 dx
+    assert all((p["type"][:n] == t).sum() > 0 for t in (1, 2, 3, 4))
+    P0 = orc.Particles(p, colmap, kernel="quintic", kinds=p["kinds"])
+    P0.precompute(corrections=False)
+    pnd = np.ascontiguousarray(1.0 / P0.vfrac)                        # particle number density of the mirror formula
+    P = orc.Particles(p, colmap, kernel="quintic", kinds=p["kinds"], pnd=pnd, morris_safe_coeff=0.43301)
+    P.precompute(corrections=False)
+    vstar = np.zeros((nall, 3))
+    xw = p["x"]
+    vstar[:, 1] = 1e-3 * np.cos(xw[:, 0]) * (p["type"] <= 2)          # some divergence-free-ish fluid motion along the axis
+    vstar[:, 0] = 1e-3 * np.sin(xw[:, 1]) * (p["type"] <= 2)
+    rp, ci, val, b = P.poisson(p["dt"], p["rho"], vstar, singular=orc.NOT_SINGULAR, morris=1)
+    vf = hip.compute_volumes(gpu_ctx, p, colmap, kernel="quintic")
+    assert np.max(np.abs(vf - P.vfrac[:n])) < 1e-13 * np.abs(P.vfrac).max()
+    A, bg = hip.assemble_poisson(gpu_ctx, p, colmap, p["dt"], p["rho"], vstar, singular=hip.NOT_SINGULAR, vfrac=P.vfrac,
+                                 kernel="quintic", kinds=p["kinds"], pnd=pnd)
+    rg, cg, vg = A.export_csr()
+    assert np.array_equal(rg, rp) and np.array_equal(cg, ci)
+    assert np.max(np.abs(vg - val)) <= 1e-12 * np.abs(val).max()
+    assert np.max(np.abs(bg - b)) <= 1e-12 * np.abs(b).max()
+    solid = p["type"][:n] >= 3
+    d = sps.csr_matrix((vg, cg, rg)).diagonal()
+    assert np.all(d[solid] == 1.0) and np.all(bg[solid] == 0.0)
+    # SA-AMG (PrecondWrapper_ML defaults, no null vector: the system is not singular) vs the oracle's hierarchy
+    prm = hip.AmgParams(block=512, coarse_max=128)
+    M = hip.PrecondAMG(gpu_ctx, A, params=prm)
+    G = orc.AMG(rp, ci, val, block=512, coarse_max=128)
+    assert M.levels == G.levels
+    x = np.zeros(n)
+    info = hip.solve(gpu_ctx, A, bg.copy(), x, prec=M, singular=False)
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=False, prec="amg", amg=G)
+    assert info.converged == 1 and io.converged == 1 and abs(info.iters - io.iters) <= 1
+    assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+def test_porous_config4_1M_properties(gpu_ctx):
+    """80^3 bcc cells = 1 024 000 particles, 749 entries per row (767 M entries, 9 GB of sliced-ELL): assembled on the
+    device from torch-resident arrays and solved with FGMRES + SA-AMG.  Properties: row length of the bcc/Quintic
+    stencil, solid rows are identity rows, the solve converges, residual <= 2e-8 re-computed with an independent SpMV,
+    zero pressure on the solid rows."""
+    import torch
+    dev = torch.device("cuda", 0)
+    p = workload.make_porous_cylinder(80, nbeads=40, rbead_cells=6.0)
+    n, nall = p["nlocal"], p["nall"]
+    assert n == 2 * 80 ** 3
+    colmap_h = workload.single_rank_colmap(p)
+    dp = dict(p)
+    for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+        dp[k] = torch.from_numpy(np.ascontiguousarray(p[k])).to(dev)
+    colmap = torch.from_numpy(colmap_h).to(dev)
+    own = torch.from_numpy(p["owner_index"].astype(np.int64)).to(dev)
+    rho = torch.from_numpy(p["rho"]).to(dev)
+    vf = hip.compute_volumes(gpu_ctx, dp, colmap, kernel="quintic")
+    vfrac = vf[own].contiguous()
+    pnd = (1.0 / vfrac).contiguous()
+    x = dp["x"]
+    fluid = (dp["type"] <= 2).to(torch.float64)
+    vstar = torch.zeros((nall, 3), dtype=torch.float64, device=dev)
+    vstar[:, 1] = 1e-3 * torch.cos(x[:, 0]) * fluid
+    vstar[:, 0] = 1e-3 * torch.sin(x[:, 1]) * fluid
+    A, b = hip.assemble_poisson(gpu_ctx, dp, colmap, p["dt"], rho, vstar, singular=hip.NOT_SINGULAR, vfrac=vfrac,
+                                kernel="quintic", kinds=p["kinds"], pnd=pnd)
+    im = A.info()
+    assert im["nrow"] == n and 745 < im["nnz"] / n <= 749
+    solid = dp["type"][:n] >= 3
+    e = torch.zeros(n, dtype=torch.float64, device=dev)
+    e[solid] = 1.0
+    y = A.spmv(e)                                              # identity rows: (A e)_i = 1 on the solid rows themselves
+    assert float((y[solid] - 1.0).abs().max()) == 0.0 and float(b[solid].abs().max()) == 0.0
+    M = hip.PrecondAMG(gpu_ctx, A, params=hip.AmgParams(block=512))
+    assert M.levels >= 2
+    xs = torch.zeros(n, dtype=torch.float64, device=dev)
+    bw = b.clone()
+    info = hip.solve(gpu_ctx, A, bw, xs, prec=M, singular=False)
+    assert info.converged == 1
+    r = b - A.spmv(xs)
+    assert float(r.norm() / b.norm()) < 2e-8
+    assert float(xs[solid].abs().max()) <= 1e-12 * float(xs.abs().max())
