@@ -51,6 +51,8 @@ struct AmgLevel {
 
 struct isph_amg {
   int nlev = 0, block = 512, sweeps = 1, singular = 0;
+  int coarse_smooth = 0;  // coarsest level solved by the smoother: singular system (precond_ml.h:97-127) or a level too
+                          // large for the dense inverse (no coarsening possible: isolated / Dirichlet rows dominate)
   std::vector<isph::AmgLevel *> L;
   isph::DevBuf<double> cinv;  // dense inverse of the coarsest operator (non-singular case)
   int nc = 0;
@@ -572,6 +574,7 @@ __global__ __launch_bounds__(256) void k_csr_spmv_wave(int n, const int *__restr
   if (lane == 0) y[i] = s;
 }
 
+constexpr int kAmgDenseMax = 2048;  // largest coarsest level the dense inverse is formed for
 // ---- dense direct solve of the coarsest level (non-singular case) ---------------------------------------
 __global__ void k_dense_from_csr(int n, const int *__restrict__ rp, const int *__restrict__ ci,
                                  const double *__restrict__ v, double *__restrict__ aug) {
@@ -1006,19 +1009,19 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     ++G->nlev;
   }
   // smoothers, work vectors, coarse solve
+  G->coarse_smooth = G->singular || G->L.back()->A.n > kAmgDenseMax;
   for (int l = 0; l < G->nlev && rc == ISPH_SUCCESS; ++l) {
     AmgLevel *L = G->L[(size_t)l];
     rc = amg_level_buffers(L);
     const bool last = l == G->nlev - 1;
     // coarse levels are small: 64-row blocks keep enough waves busy (an 8-block level ran its sweeps on 8 waves)
-    if (rc == ISPH_SUCCESS && (!last || G->singular))
+    if (rc == ISPH_SUCCESS && (!last || G->coarse_smooth))
       rc = ilu_create(ctx, L->Am, l == 0 ? G->block : kAmgCoarseBlock, &L->sgs, /*sgs=*/true);
   }
-  if (rc == ISPH_SUCCESS && !G->singular) {
+  if (rc == ISPH_SUCCESS && !G->coarse_smooth) {
     AmgLevel *L = G->L.back();
     const int nc = L->A.n;
     G->nc = nc;
-    if (nc > 2048) rc = fail("AMG: coarsest level too large for the dense direct solve", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) rc = G->cinv.reserve((size_t)2 * nc * nc + (size_t)nc + 1);
     if (rc == ISPH_SUCCESS && nc > 0) {
       hipLaunchKernelGGL(k_dense_from_csr, dim3(nc), dim3(kBlock), 0, ctx->stream, nc, (const int *)L->A.rp.p,
@@ -1059,7 +1062,7 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   AmgLevel *L = G->L[(size_t)l];
   const int n = L->A.n;
   if (l == G->nlev - 1) {
-    if (G->singular) {
+    if (G->coarse_smooth) {
       ISPH_CHECK(amg_smooth(ctx, G, l, b, x, true));
       for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
     } else if (n > 0) {

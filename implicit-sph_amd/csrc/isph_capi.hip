@@ -13,6 +13,7 @@
 #include "solver.hpp"
 #include "amg.hpp"
 #include "schwarz.hpp"
+#include "gcrodr.hpp"
 
 namespace isph {
 thread_local std::string g_last_error;
@@ -611,7 +612,7 @@ int isph_prec_amg_aggregates(isph_ctx *ctx, const isph_prec *M, int level, int *
 void isph_solver_params_default(isph_solver_params *p) {
   // SolverLin_Belos::setParameters(NULL), ref: solver_lin_belos.h:226-240
   p->solver_type = 0; p->flexible = 1; p->num_blocks = 50; p->max_iters = 500; p->max_restarts = 15;
-  p->tol = 1.0e-8; p->ortho = 0; p->verbose = 0;
+  p->tol = 1.0e-8; p->ortho = 0; p->verbose = 0; p->num_recycled = 50;
 }
 
 int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, double *x, int nvec, int lda,
@@ -665,6 +666,7 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
     isph_solve_info ci;
     memset(&ci, 0, sizeof(ci));
     if (prm.solver_type == 1) ISPH_CHECK(pcg(op, bc, xc, &prm, &ci));
+    else if (prm.solver_type == 2) ISPH_CHECK(gcrodr(op, bc, xc, &prm, &ci));
     else ISPH_CHECK(gmres(op, bc, xc, &prm, &ci));
     {  // ||b - A x|| / ||b|| with the unprojected A (:201-212)
       ISPH_CHECK(ctx->wv.reserve((size_t)n + 64));
@@ -751,7 +753,9 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
   op.dim = dim; op.nloc = n; op.blk = blocks; op.tmp = tmp.p;
   isph_solve_info ci;
   memset(&ci, 0, sizeof(ci));
-  int rc = prm.solver_type == 1 ? pcg(op, ctx->bdev.p, ctx->xdev.p, &prm, &ci) : gmres(op, ctx->bdev.p, ctx->xdev.p, &prm, &ci);
+  int rc = prm.solver_type == 1 ? pcg(op, ctx->bdev.p, ctx->xdev.p, &prm, &ci)
+           : prm.solver_type == 2 ? gcrodr(op, ctx->bdev.p, ctx->xdev.p, &prm, &ci)
+                                  : gmres(op, ctx->bdev.p, ctx->xdev.p, &prm, &ci);
   if (rc == ISPH_SUCCESS) rc = res.reserve(nt + 64);
   if (rc == ISPH_SUCCESS) rc = op.apply(ctx->xdev.p, res.p);
   if (rc == ISPH_SUCCESS) {

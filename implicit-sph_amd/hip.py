@@ -46,11 +46,12 @@ class SolverParams(C.Structure):
     (ref: solver_lin_belos.h:224-264)."""
     _fields_ = [("solver_type", C.c_int), ("flexible", C.c_int), ("num_blocks", C.c_int),
                 ("max_iters", C.c_int), ("max_restarts", C.c_int), ("tol", C.c_double),
-                ("ortho", C.c_int), ("verbose", C.c_int)]
+                ("ortho", C.c_int), ("verbose", C.c_int), ("num_recycled", C.c_int)]
 
     def __init__(self, solver_type=0, flexible=1, num_blocks=50, max_iters=500, max_restarts=15, tol=1e-8,
-                 ortho=0, verbose=0):
-        super().__init__(solver_type, flexible, num_blocks, max_iters, max_restarts, tol, ortho, verbose)
+                 ortho=0, verbose=0, num_recycled=50):
+        """solver_type 0 "Block GMRES", 1 "Block CG", 2 "Recycling GMRES" (GCRO-DR(num_blocks, num_recycled))"""
+        super().__init__(solver_type, flexible, num_blocks, max_iters, max_restarts, tol, ortho, verbose, num_recycled)
 
 
 class SolveInfo(C.Structure):

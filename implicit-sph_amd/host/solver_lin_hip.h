@@ -50,8 +50,10 @@ class SolverLin_HIP : public SolverLin {
     isph_solver_params_default(&p);
     const std::string type = _param->get("Solver Type", "Block GMRES");
     if (type == "Block CG") p.solver_type = 1;
+    else if (type == "Recycling GMRES") p.solver_type = 2;  // Belos::GCRODRSolMgr, solver_lin_belos.h:178-179
     else if (type != "Block GMRES" && _comm.MyPID() == 0)
       std::printf(">> SolverLin_HIP: Solver Type '%s' not available, using Block GMRES\n", type.c_str());
+    p.num_recycled = _param->get("Num Recycled Blocks", 50);
     p.flexible = _param->get("Flexible Gmres", true) ? 1 : 0;
     p.num_blocks = _param->get("Num Blocks", 50);
     p.max_iters = _param->get("Maximum Iterations", 500);

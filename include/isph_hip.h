@@ -135,7 +135,8 @@ void isph_prec_destroy(isph_prec *M);
 /* Same keys and defaults as SolverLin_Belos::setParameters
  * (ref: solver_lin_belos.h:224-264). */
 typedef struct {
-  int solver_type;   /* 0 "Block GMRES" (default), 1 "Block CG"            */
+  int solver_type;   /* 0 "Block GMRES" (default), 1 "Block CG", 2 "Recycling GMRES" = GCRO-DR(num_blocks,
+                        num_recycled) (solver_lin_belos.h:173-181)           */
   int flexible;      /* "Flexible Gmres" (default 1)                        */
   int num_blocks;    /* "Num Blocks" (50)                                   */
   int max_iters;     /* "Maximum Iterations" (500)                          */
@@ -143,6 +144,8 @@ typedef struct {
   double tol;        /* "Convergence Tolerance" (1e-8)                      */
   int ortho;         /* "Orthogonalization": 0 DGKS (default), 1 ICGS, 2 IMGS */
   int verbose;       /* rank-0 status lines like Belos "Verbosity"          */
+  int num_recycled;  /* "Num Recycled Blocks" (50, solver_lin_belos.h:240); solver_type 2 needs
+                        0 < num_recycled < num_blocks, as Belos::GCRODRSolMgr does */
 } isph_solver_params;
 void isph_solver_params_default(isph_solver_params *p);
 

@@ -34,12 +34,14 @@
 #include "isph_oracle.h"
 
 #define AMG_MAXLEV 8
+#define AMG_DENSE_MAX 2048 /* largest coarsest level the dense LU is formed for (shared with the GPU) */
 #define AMG_COARSE_BLOCK 64 /* rows the Gauss-Seidel sweeps are local to on levels >= 1 (shared with the GPU) */
 
 typedef struct { int n, m; int *rp, *ci; double *v; } csr_t; /* n rows, m columns */
 
 struct orc_amg {
   int nlev, block, sweeps, singular;
+  int coarse_smooth; /* coarsest level solved by the smoother: singular, or larger than AMG_DENSE_MAX rows */
   int whole_sgs; /* 1: Gauss-Seidel over the whole level (= ML's processor-local sweep on one rank) */
   csr_t A[AMG_MAXLEV], P[AMG_MAXLEV], R[AMG_MAXLEV];
   int *agg[AMG_MAXLEV];
@@ -428,7 +430,8 @@ orc_amg *orc_amg_create_ex(int n, const int *rowptr, const int *colidx, const do
     G->dinv[l] = (double *)malloc(sizeof(double) * m);
     for (int i = 0; i < G->A[l].n; ++i) G->dinv[l][i] = 1.0 / diag_of(&G->A[l], i);
   }
-  if (!G->singular) {
+  G->coarse_smooth = G->singular || G->A[G->nlev - 1].n > AMG_DENSE_MAX;
+  if (!G->coarse_smooth) {
     const csr_t *A = &G->A[G->nlev - 1];
     const int m = A->n;
     G->lu = (double *)calloc((size_t)m * (size_t)m + 1, sizeof(double));
@@ -442,7 +445,7 @@ orc_amg *orc_amg_create_ex(int n, const int *rowptr, const int *colidx, const do
 static void vcycle(const orc_amg *G, int l, const double *b, double *x) {
   const csr_t *A = &G->A[l];
   if (l == G->nlev - 1) {
-    if (G->singular) {
+    if (G->coarse_smooth) {
       smooth(G, l, b, x, 1);
       for (int s = 1; s < G->sweeps; ++s) smooth(G, l, b, x, 0);
     } else {
