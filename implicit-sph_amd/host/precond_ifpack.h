@@ -21,8 +21,9 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
       _param->set("schwarz: combine mode", "Add"); // :39
       _param->set("Precond Type", "ILU");          // :42
       _param->set("Overlap Level", 1);             // :43
-      // device-side extension: rows per additive-Schwarz subdomain (one Ifpack
-      // rank's worth of rows).  Not a reference key.
+      // device-side extension (not a reference key): rows per additive-Schwarz subdomain inside a rank.  512 = the
+      // block stream of csrc/ilu.hpp (throughput path); 0 = one subdomain per rank = the whole local matrix, what the
+      // reference factors (level-scheduled, csrc/schwarz.hpp); > 1024 = large subdomains with "Overlap Level" layers.
       _param->set("isph: block rows", 512);
     } else if (_param.get() != param) {
       _param = Teuchos::rcp(param, false);
@@ -44,16 +45,38 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
       std::fprintf(stderr, ">> PrecondWrapper_Ifpack(HIP): fact: level-of-fill %d is outside [0,8]\n", fill);
       return ISPH_FAILURE;
     }
-    // "Overlap Level" extends an Ifpack subdomain by rows of the neighbouring RANKS (no effect on one rank).  The device
-    // subdomains are blocks of "isph: block rows" rows inside a rank and are not extended: overlap 0 semantics.
-    if (overlap != 0 && _comm.NumProc() > 1 && _comm.MyPID() == 0 && !_warned) {
-      std::printf(">> PrecondWrapper_Ifpack(HIP): Overlap Level %d requested; this build provides overlap 0 "
-                  "(block-Jacobi ILU(%d)) -- using that\n", overlap, fill);
+    free();
+    const int block = _param->get("isph: block rows", 512);
+    const std::string mode = _param->get("schwarz: combine mode", "Add");
+    // "isph: block rows" = 0: the reference's own decomposition -- one subdomain per rank = the whole local matrix,
+    // ILU(fill) level-scheduled on the device (isph_prec_create_schwarz).  "Overlap Level" extends a subdomain by rows
+    // of the neighbouring RANKS (Ifpack ignores it on one rank); the matrix-row halo that needs is not built, so with
+    // more than one rank the subdomains stay un-overlapped and the notice below says so.
+    if (block == 0 || block > 1024) {
+      isph_schwarz_params sp;
+      isph_schwarz_params_default(&sp);
+      sp.level_of_fill = fill;
+      sp.block_size = block;
+      sp.overlap = block == 0 ? 0 : overlap;    // subdomains inside one rank can be extended; rank subdomains cannot yet
+      sp.combine = (mode == "Zero") ? 1 : 0;
+      if (block == 0 && overlap != 0 && _comm.NumProc() > 1 && _comm.MyPID() == 0 && !_warned) {
+        std::printf(">> PrecondWrapper_Ifpack(HIP): Overlap Level %d across ranks is not available; rank subdomains "
+                    "are factored without overlap (ILU(%d))\n", overlap, fill);
+        _warned = true;
+      }
+      return isph_prec_create_schwarz(ctx, A, &sp, &_M);
+    }
+    // default: the throughput path -- block-Jacobi ILU(fill) on subdomains of `block` rows inside the rank, overlap 0.
+    // This is NOT what the reference factors (one subdomain per rank, overlap 1): iteration counts differ (on the 100^3
+    // TGV system 116 iterations against 49 for the whole-matrix ILU(0)); the notice is printed once, on every build.
+    if (_comm.MyPID() == 0 && !_warned) {
+      std::printf(">> PrecondWrapper_Ifpack(HIP): block-Jacobi ILU(%d) on %d-row subdomains, overlap 0 (reference: one "
+                  "subdomain per rank, Overlap Level %d); set \"isph: block rows\" = 0 for the reference's decomposition\n",
+                  fill, block, overlap);
       _warned = true;
     }
-    free();
     const std::string kind = "bjacobi-ilu" + std::to_string(fill);
-    return isph_prec_create(ctx, A, kind.c_str(), _param->get("isph: block rows", 512), &_M);
+    return isph_prec_create(ctx, A, kind.c_str(), block, &_M);
   }
   bool _warned = false;
 };

@@ -147,6 +147,8 @@ int main(int argc, char **argv) {
   const bool use_ml = argc > 4 && std::string(argv[4]) == "ml";
   const bool use_cg = argc > 4 && std::string(argv[4]) == "cg";
   const bool ifpack_defaults = argc > 4 && std::string(argv[4]) == "ifpack-defaults";  // level-of-fill 1, overlap 1
+  const bool ifpack_reference = argc > 4 && std::string(argv[4]) == "ifpack-reference";  // + one subdomain = the whole matrix
+  const bool recycling = argc > 4 && std::string(argv[4]) == "recycling";  // "Solver Type" = "Recycling GMRES"
   PrecondWrapper_Ifpack prec_ifpack(world);
   PrecondWrapper_ML prec_ml(world);
   PrecondWrapper &prec = use_ml ? static_cast<PrecondWrapper &>(prec_ml) : static_cast<PrecondWrapper &>(prec_ifpack);
@@ -154,11 +156,11 @@ int main(int argc, char **argv) {
   if (use_ml) {  // the keys of precond_ml.h:44-55 are already set; shrink the hierarchy to the test size
     pp->set("coarse: max size", 64);
     pp->set("aggregation: threshold", 0.02);
-  } else if (!ifpack_defaults) {
+  } else if (!ifpack_defaults && !ifpack_reference) {
     pp->set("fact: level-of-fill", 0);
     pp->set("Overlap Level", 0);
   }
-  pp->set("isph: block rows", 256);
+  pp->set("isph: block rows", ifpack_reference ? 0 : 256);
 
   SolverLin_Belos li_solver(world);
   li_solver.setParameters();
@@ -168,6 +170,14 @@ int main(int argc, char **argv) {
     cgp.set("Convergence Tolerance", 1.0e-8);
     cgp.set("Maximum Iterations", 500);
     li_solver.setParameters(&cgp);
+  }
+  Teuchos::ParameterList rcp_;
+  if (recycling) {  // GCRO-DR(20, 5): the keys of solver_lin_belos.h:224-264 with a valid recycle size
+    rcp_.set("Solver Type", "Recycling GMRES");
+    rcp_.set("Num Blocks", 20);
+    rcp_.set("Num Recycled Blocks", 5);
+    rcp_.set("Convergence Tolerance", 1.0e-8);
+    li_solver.setParameters(&rcp_);
   }
   li_solver.setNodalMap(&nodalmap);
   li_solver.setMatrix(&AA);

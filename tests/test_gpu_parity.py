@@ -397,7 +397,8 @@ def test_rccl_self_halo_spmv_and_solve(gpu_ctx):
 
 
 # ---------------------------------------------------------------- C++ mirror of the reference interface
-@pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml"), (1, "ifpack-defaults")])
+@pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml"), (1, "ifpack-defaults"), (1, "ifpack-reference"),
+                                         (1, "recycling")])
 def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     """SolverLin_Belos / PrecondWrapper_Ifpack (implicit-sph_amd/host/*.h) driven
     exactly like USER-REAXC-T/fix_qeq_reax.cpp:671-693 drives the reference."""
@@ -418,10 +419,10 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
         rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
         val.tofile(f); b.tofile(f)
     ml = cg == "ml"
-    fill = 1 if cg == "ifpack-defaults" else 0   # PrecondWrapper_Ifpack's own defaults: "fact: level-of-fill" = 1
-    cg = bool(cg) and not ml and not fill
-    r = subprocess.run([exe, str(fin), str(fout), str(singular)] +
-                       (["cg"] if cg else ["ml"] if ml else ["ifpack-defaults"] if fill else []),
+    mode = cg if isinstance(cg, str) else None
+    fill = 1 if mode in ("ifpack-defaults", "ifpack-reference") else 0   # PrecondWrapper_Ifpack's own defaults: fill 1
+    cg = bool(cg) and mode is None
+    r = subprocess.run([exe, str(fin), str(fout), str(singular)] + (["cg"] if cg else [mode] if mode else []),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert ">> Belos::Status - Passed!" in r.stdout
@@ -432,6 +433,14 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     if ml:   # PrecondWrapper_ML mirror: setNullVector reaches the AMG through solveProblem (solver_lin_belos.h:149-151)
         G = orc.AMG(rp, ci, val, nullvec=np.full(pr.n, 1.0 / np.sqrt(pr.n)), coarse_max=64, theta=0.02, block=256)
         xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="amg", amg=G, params=prm)
+    elif mode == "ifpack-reference":   # "isph: block rows" = 0: ILU(1) of the whole matrix, the reference on one rank
+        xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=orc.ILU(rp, ci, val, 1), params=prm)
+        assert "iters=%d" % io.iters in r.stdout or "iters=%d" % (io.iters + 1) in r.stdout or "iters=%d" % (io.iters - 1) in r.stdout
+    elif mode == "recycling":          # "Solver Type" = "Recycling GMRES" -> GCRO-DR(20, 5) with block-Jacobi ILU(0)
+        import gcrodr as gcro
+        xo, ig = gcro.solve(rp, ci, val, b, singular=True, prec=orc.ILU(rp, ci, val, 0, bp).apply, num_blocks=20, num_recycled=5)
+        bo = b - b.mean()
+        assert ig["converged"]
     else:
         xo, io, bo = orc.solve(rp, ci, val, b, singular=bool(singular), prec="ilu",
                                ilu=orc.ILU(rp, ci, val, fill, bp), params=prm)
