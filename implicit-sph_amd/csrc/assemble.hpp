@@ -169,14 +169,27 @@ __device__ inline double kernel_dval(int kernel, double r, double hinv, double C
 // r_ij and |r_ij|^2 with the reference's operation order and NO fma
 // contraction, so the strict `rsq < cutsq` test (functor_graph.h:84,
 // functor_laplacian_matrix.h:142) selects the same pairs as the CPU.
-__device__ __forceinline__ double pair_rsq(int dim, const double *__restrict__ x, int i, int j, double rij[3]) {
+// NOTE: ROCm's __dsub_rn/__dmul_rn/__dadd_rn are plain operators (clang/__clang_hip_math.h), so under hipcc's default
+// -ffp-contract=fast the compiler may fuse x*x + s into an fma in one kernel and not in another: the counting pass
+// and the fill pass then disagree on pairs that sit EXACTLY on the cut radius (exact lattices: |(3,0,0)| = |(2,2,1)|
+// = cut), the row gets padding inside its counted length, the padding carries the row's own column, and everything
+// that walks rows (ILU extraction) sees the diagonal several times.  Contraction is therefore switched off inside the
+// one function every pass calls.
+__device__ __forceinline__ double rsq_nofma(int dim, const double xi[3], const double xj[3], double rij[3]) {
+#pragma clang fp contract(off)
   double rsq = 0.0;
   rij[0] = rij[1] = rij[2] = 0.0;
   for (int k = 0; k < dim; ++k) {
-    rij[k] = __dsub_rn(x[3 * (size_t)i + k], x[3 * (size_t)j + k]);
-    rsq = __dadd_rn(rsq, __dmul_rn(rij[k], rij[k]));
+    rij[k] = xi[k] - xj[k];
+    const double sq = rij[k] * rij[k];
+    rsq = rsq + sq;
   }
   return rsq;
+}
+__device__ __forceinline__ double pair_rsq(int dim, const double *__restrict__ x, int i, int j, double rij[3]) {
+  const double xi[3] = {x[3 * (size_t)i], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]};
+  const double xj[3] = {x[3 * (size_t)j], x[3 * (size_t)j + 1], x[3 * (size_t)j + 2]};
+  return rsq_nofma(dim, xi, xj, rij);
 }
 
 // MirrorMorrisHolmes::computeMirrorCoefficient (ref: mirror_morris_holmes.h:39-52)
@@ -502,15 +515,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       const double4 q1 = a.r1[j];
       const int2 q3 = a.r3[j];
       const int jt = q3.x, jkind = T.kind[jt];
-      double rij[3] = {0, 0, 0};
-      double rsq = 0.0;
-      {
-        const double xj3[3] = {q1.x, q1.y, q1.z};
-        for (int k = 0; k < dim; ++k) {  // same arithmetic as pair_rsq
-          rij[k] = __dsub_rn(xi3[k], xj3[k]);
-          rsq = __dadd_rn(rsq, __dmul_rn(rij[k], rij[k]));
-        }
-      }
+      double rij[3];
+      const double xj3[3] = {q1.x, q1.y, q1.z};
+      const double rsq = rsq_nofma(dim, xi3, xj3, rij);  // the same arithmetic as pair_rsq / k_asm_count
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       const double4 q2 = a.r2[j];
       const double vsj[3] = {q2.y, q2.z, q2.w};
@@ -564,15 +571,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       const double4 q1 = a.r1[j];
       const int2 q3 = a.r3[j];
       const int jt = q3.x, jkind = T.kind[jt];
-      double rij[3] = {0, 0, 0};
-      double rsq = 0.0;
-      {
-        const double xj3[3] = {q1.x, q1.y, q1.z};
-        for (int k = 0; k < dim; ++k) {
-          rij[k] = __dsub_rn(xi3[k], xj3[k]);
-          rsq = __dadd_rn(rsq, __dmul_rn(rij[k], rij[k]));
-        }
-      }
+      double rij[3];
+      const double xj3[3] = {q1.x, q1.y, q1.z};
+      const double rsq = rsq_nofma(dim, xi3, xj3, rij);  // the same arithmetic as pair_rsq / k_asm_count
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
       if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
@@ -736,15 +737,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       const double4 q1 = a.r1[j];
       const int2 q3 = a.r3[j];
       const int jt = q3.x, jkind = T.kind[jt];
-      double rij[3] = {0, 0, 0};
-      double rsq = 0.0;
-      {
-        const double xj3[3] = {q1.x, q1.y, q1.z};
-        for (int k = 0; k < dim; ++k) {  // same arithmetic as pair_rsq
-          rij[k] = __dsub_rn(xi3[k], xj3[k]);
-          rsq = __dadd_rn(rsq, __dmul_rn(rij[k], rij[k]));
-        }
-      }
+      double rij[3];
+      const double xj3[3] = {q1.x, q1.y, q1.z};
+      const double rsq = rsq_nofma(dim, xi3, xj3, rij);  // the same arithmetic as pair_rsq / k_asm_count
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       const double mj = a.r2[j].x;
       double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
@@ -795,15 +790,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       const double4 q1 = a.r1[j];
       const int2 q3 = a.r3[j];
       const int jt = q3.x, jkind = T.kind[jt];
-      double rij[3] = {0, 0, 0};
-      double rsq = 0.0;
-      {
-        const double xj3[3] = {q1.x, q1.y, q1.z};
-        for (int k = 0; k < dim; ++k) {
-          rij[k] = __dsub_rn(xi3[k], xj3[k]);
-          rsq = __dadd_rn(rsq, __dmul_rn(rij[k], rij[k]));
-        }
-      }
+      double rij[3];
+      const double xj3[3] = {q1.x, q1.y, q1.z};
+      const double rsq = rsq_nofma(dim, xi3, xj3, rij);  // the same arithmetic as pair_rsq / k_asm_count
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       // the correction term uses the plain filter coefficient (:225-227); a_ij keeps the
       // mirror-weighted coefficient of the first sweep (:144-146)

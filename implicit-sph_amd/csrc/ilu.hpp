@@ -82,13 +82,18 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
     off = slice_off[i >> 6];
     lane = i & 63;
     len = rowlen[i];
+    int prevc = -1;
+    bool disorder = false;
     for (int k = 0; k < len; ++k) {
       const int c = scol[sell_pos(off, lane, k)];
       if (c >= blo && c < bhi) {
+        if (c <= prevc) disorder = true;  // every later stage relies on strictly ascending columns (one diagonal)
+        prevc = c;
         if (c == i) dg = cnt;
         ++cnt;
       }
     }
+    if (disorder) atomicOr(err, 32);
   }
   // exclusive scan of cnt over the workgroup
   int s = cnt;
@@ -394,6 +399,9 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   int *spos = sdg + B;           // [B] position of a row in the current direction's solve order
   long long *srp = reinterpret_cast<long long *>(spos + B + (B & 1));  // [B]
   __shared__ int s_nlev, s_nsched, s_nch;
+  // rows without a diagonal or with duplicate / unsorted columns (flagged by k_ilu_extract) would send the level
+  // walk through uninitialised levels: leave the block alone, the host reports the error
+  if (*err & (1 | 32)) return;
   const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   const int t = threadIdx.x;
   const bool active = t < m;
@@ -898,6 +906,7 @@ inline int ilu_check_err(isph_ctx *ctx, isph_ilu *F, const char *what, bool *ove
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     return fail(what, __FILE__, __LINE__);
   if (herr & 1) return fail("matrix row without a diagonal entry: ILU(0) undefined", __FILE__, __LINE__);
+  if (herr & 32) return fail("matrix row with duplicate or unsorted columns: ILU pattern undefined", __FILE__, __LINE__);
   if ((herr & 16) && overflow) { *overflow = true; return ISPH_SUCCESS; }
   if (herr & 16) return fail("ILU triangular-solve stream capacity exceeded", __FILE__, __LINE__);
   if (herr) return fail(what, __FILE__, __LINE__);

@@ -9,23 +9,21 @@
  * Every function cites the reference file:line (relative to
  * /root/reference/IMPLICIT-SPH/) whose algorithm it restates.
  *
- * PARITY PINNING STATUS
- *   - assembly half: restated from the reference functors.  Pinned by (1) the
- *     one output of the reference's own functor recorded in SURVEY.md
- *     Appendix A (8x8 lattice row: diag 3.6692e-02, 25 nnz, row sum ~1e-18;
- *     reproduced to all printed digits) and (2) analytic invariants
- *     (tests/test_oracle.py).  The reference's end-to-end 2-D TGV table
- *     (sph-script/conv-taylor-green-vortex-2d-rev390.txt) is reproduced through
- *     oracle/tgv_driver.py only loosely (norms to 4e-4, pressure error within
- *     20 %): that table comes from an older revision whose scheme details are
- *     not recorded.
- *   - solve half: the arithmetic lives in Trilinos (Belos/Ifpack/Epetra,
- *     un-vendored, no pinned version: README:9-11).  The reference holds no
- *     numeric vectors at that boundary, so the Krylov/ILU restatement follows
- *     the published Belos/Ifpack algorithm definitions and is cross-checked
- *     against SciPy only: solver parity is UNPINNED.
- *   - the reference itself cannot be built here (needs Trilinos + LAMMPS
- *     headers): there is no oracle/_ref.
+ * PARITY PINNING STATUS (round 2)
+ *   - PINNED to numbers the reference itself recorded: the 2-D Taylor-Green tables
+ *     sph-script/conv-taylor-green-vortex-2d-rev390.txt / -rev230.txt (fix_isph_tgv.cpp:43-125).  With the one
+ *     combination of unrecorded settings that fits (oracle/tgv_sweep.py: theta 1/2, incremental pressure,
+ *     Symmetric corrected operators, error on vstar before advanceTime) the chain computePre -> Helmholtz
+ *     assembly + GMRES/ILU(0) -> Poisson assembly + null-space GMRES/ILU(0) -> corrections -> advanceTime
+ *     (oracle/tgv_driver.py) reproduces BOTH error columns of all rows N = 16..128, both kernels, both revisions
+ *     to 3 significant digits (<= 2.5e-3; <= 2.1e-4 for N >= 32 with the script's particle shift):
+ *     tests/test_oracle.py::test_tgv2d_known_answer_table_pinned, DESIGN.md section 4.
+ *   - secondary: the functor row recorded in SURVEY.md Appendix A (all printed digits), analytic invariants,
+ *     SciPy/LAPACK as an independent opinion for the linear-algebra half.
+ *   - not covered by reference numbers (Trilinos is un-vendored, no vectors at those boundaries): SA-AMG
+ *     (isph_amg_oracle.c), Schwarz overlap > 0 (isph_schwarz_oracle.c), GCRO-DR (gcrodr.py), and entry-level values
+ *     of the AntiSymmetric operator family (the tables' revision ran the Symmetric one).
+ *   - the reference itself cannot be built here (needs Trilinos + LAMMPS headers): there is no oracle/_ref.
  */
 #ifndef ISPH_ORACLE_H
 #define ISPH_ORACLE_H

@@ -236,6 +236,39 @@ def test_config1_full_size_100cubed(gpu_ctx):
     assert np.linalg.norm(x - xj) / np.linalg.norm(xj) < 1e-6
 
 
+def test_exact_lattice_ties_count_and_fill_agree(gpu_ctx):
+    """Regression (round 2): on an exact lattice 30 neighbours of every particle sit EXACTLY on the cut radius
+    (|(3,0,0)| = |(2,2,1)| = 3 dx = cut).  ROCm's __dmul_rn/__dadd_rn are plain operators, so the compiler fused
+    x*x + s into an fma in the fill kernel but not in the counting kernel: rows got padding inside their counted
+    length (the row's own column, several times), and above the 32 768-row duplicate-merge threshold the ILU level
+    walk ran through uninitialised levels -> GPU memory fault.  r^2 now comes from one function with contraction off.
+    64^3 lattice (n > 32768): every row has its own column exactly once, strictly ascending columns, the pattern is
+    the one IEEE arithmetic without fma gives (numpy), ILU(0) builds and the solve converges."""
+    sp = tgv_spec(dim=3, n=64, mode=workload.LATTICE)
+    p = workload.make_tgv(sp)
+    n = p["nlocal"]
+    colmap = workload.single_rank_colmap(p)
+    vf = hip.compute_volumes(gpu_ctx, p, colmap)
+    vfrac = np.ascontiguousarray(vf[p["owner_index"]])
+    v = np.zeros((p["nall"], 3))
+    v[:, 0] = np.sin(p["x"][:, 1])
+    A, b = hip.assemble_poisson(gpu_ctx, p, colmap, sp.dt, p["rho"], v, vfrac=vfrac)
+    rp, ci, val = A.export_csr()
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    assert np.all(np.diff(ci)[np.diff(rows) == 0] > 0)                 # strictly ascending inside every row
+    assert np.array_equal(np.bincount(rows[ci == rows], minlength=n), np.ones(n, dtype=np.int64))
+    x, ptr, idx = p["x"], p["neigh_ptr"], p["neigh_idx"]
+    io = np.repeat(np.arange(n), np.diff(ptr))
+    d = x[io] - x[idx]
+    r2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]   # same order, no fma
+    expect = np.bincount(io[r2 < float(p["cut"]) ** 2], minlength=n) + 1
+    assert np.array_equal(np.diff(rp), expect) and expect.max() > 93   # ties are really there
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 512)
+    xs = np.zeros(n)
+    info = hip.solve(gpu_ctx, A, b.copy(), xs, prec=M, singular=True)
+    assert info.converged == 1
+
+
 # ---------------------------------------------------------------- block-Jacobi ILU(0)
 ILU_CASES = [
     (dict(dim=2, n=16, mode=workload.JITTER, brick=8), 64),
