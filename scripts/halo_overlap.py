@@ -10,7 +10,7 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 is_int = lambda n: "k_sell_spmv16<8, false, true, false>" in n or "k_sell_spmv<8, false, true, true, false>" in n
 is_bnd = lambda n: "k_sell_spmv16<8, false, true, true>" in n or "k_sell_spmv<8, false, true, true, true>" in n
-is_rccl = lambda n: "ccl" in n.lower() and "sendrecv" in n.lower().replace("_", "") or "SendRecv" in n
+is_rccl = lambda n: "rcclGenericKernel" in n or "ncclDevKernel" in n or "SendRecv" in n
 ints = [r for r in rows if is_int(r[2])]
 bnds = [r for r in rows if is_bnd(r[2])]
 rccl = [r for r in rows if is_rccl(r[2])]
