@@ -133,7 +133,16 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
     assert ip.converged == 1
     m = torch.from_numpy(mask.astype(np.float64)).to(dev)
     nvec = m / m.norm()
+    # The solver solves P A x = P b (P = I - n n^T, PoissonProjection) and then, like the reference
+    # (solver_lin_belos.h:215-219), returns x - (x.n) n.  With wall Neumann rows n = mask/|mask| is not an exact null
+    # vector of A (those rows couple to fluid columns), so the returned x differs from the Krylov solution by a
+    # multiple of n and its projected residual lies along q = P A n: remove that one direction, the rest is <= 2e-8.
     r = bpw - A.spmv(xp)
     r -= (r @ nvec) * nvec
+    an = A.spmv(nvec)
+    an -= (an @ nvec) * nvec
+    if float(an.norm()) > 0.0:
+        q = an / an.norm()
+        r -= (r @ q) * q
     assert float(r.norm() / bpw.norm()) < 2e-8
     assert abs(float(xp @ nvec)) < 1e-10 * float(xp.abs().max())
