@@ -42,6 +42,8 @@ struct AsmTables {  // small per-type tables, device resident
   // kernels read it with coalesced 256-B wave loads instead of 64 scattered lines
   const long long *noff;
   const int *nt;
+  const int *nlen;  // [nlocal] neighbours of row i (numneigh); the row kernels never see the CSR offsets, so the
+                    // flattened list may be indexed with 32- or 64-bit offsets (neigh_ptr / neigh_ptr64)
   // 1: every row's neighbours are ordered by matrix column (k_neigh_sort), so the row kernels can emit column-sorted
   // rows directly (the diagonal takes its slot on the way) and the SELL row sort is skipped
   int sorted;
@@ -52,21 +54,24 @@ __device__ __forceinline__ int neigh_at(const AsmTables &T, int i, int k) {
 }
 
 // numneigh per row (for the slice widths of the transposed list)
-__global__ void k_numneigh(int n, const int *__restrict__ nptr, int *__restrict__ len) {
+template <class OFF>
+__global__ void k_numneigh(int n, const OFF *__restrict__ nptr, int *__restrict__ len) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) len[i] = nptr[i + 1] - nptr[i];
+  if (i < n) len[i] = (int)(nptr[i + 1] - nptr[i]);
 }
 
 // Orders every row's neighbour ids by their matrix column (stable: equal columns -- periodic images -- keep their
 // list order).  One wave per row, keys in LDS, rank by counting.
 constexpr int kNeighSortCap = 1024;
-__global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const int *__restrict__ nptr, const int *__restrict__ nidx,
+template <class OFF>
+__global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restrict__ nptr, const int *__restrict__ nidx,
                                                        const int *__restrict__ colmap, int *__restrict__ out) {
   __shared__ int keys[kBlock / 64][kNeighSortCap];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kBlock / 64) + wave;
   if (row >= n) return;
-  const int jb = nptr[row], len = nptr[row + 1] - jb;
+  const OFF jb = nptr[row];
+  const int len = (int)(nptr[row + 1] - jb);
   int *kw = keys[wave];
   for (int k = lane; k < len; k += 64) kw[k] = colmap[nidx[jb + k]];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -84,7 +89,8 @@ __global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const int *__restr
 
 // CSR neighbour list -> lane-interleaved slices.  One wave per slice; 64 rows x 16 ids are staged
 // through LDS: the CSR side is read in 64-B row segments, the ELL side written as 256-B wave stores.
-__global__ __launch_bounds__(kBlock) void k_neigh_transpose(int n, const int *__restrict__ nptr,
+template <class OFF>
+__global__ __launch_bounds__(kBlock) void k_neigh_transpose(int n, const OFF *__restrict__ nptr,
                                                             const int *__restrict__ nidx,
                                                             const long long *__restrict__ noff, int *__restrict__ nt) {
   __shared__ int lds[kBlock / 64][64 * 17];
@@ -94,15 +100,15 @@ __global__ __launch_bounds__(kBlock) void k_neigh_transpose(int n, const int *__
   if (slice >= nslices) return;
   int *wl = lds[wave];
   const int row = slice * 64 + lane;
-  const int jb = row < n ? nptr[row] : 0, je = row < n ? nptr[row + 1] : 0;
+  const long long jb = row < n ? (long long)nptr[row] : 0, je = row < n ? (long long)nptr[row + 1] : 0;
   const long long off = noff[slice];
   const int w = (int)((noff[slice + 1] - off) >> 6);
   for (int c0 = 0; c0 < w; c0 += 16) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int r = s * 4 + (lane >> 4), t = lane & 15;
-      const int rb = __shfl(jb, r, 64), re = __shfl(je, r, 64);
-      const int p = rb + c0 + t;
+      const long long rb = __shfl(jb, r, 64), re = __shfl(je, r, 64);
+      const long long p = rb + c0 + t;
       wl[r * 17 + t] = p < re ? nidx[p] : 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -209,8 +215,8 @@ __global__ void k_volumes(AsmTables T, int nlocal, const double *__restrict__ x,
   if (i >= nlocal) return;
   const int it = type[i], nt1 = T.ntypes + 1;
   double w = kernel_val(T.kernel, 0.0, T.hinv[it * nt1 + it], T.knorm[it * nt1 + it]);
-  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {
-    const int j = neigh_at(T, i, jj - nptr[i]);
+  for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {
+    const int j = neigh_at(T, i, jj);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(T.dim, x, i, j, rij);
@@ -232,8 +238,8 @@ __global__ void k_gradient_correction(AsmTables T, int nlocal, const double *__r
   if (i >= nlocal) return;
   const int dim = T.dim, nt1 = T.ntypes + 1, it = type[i];
   double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {
-    const int j = neigh_at(T, i, jj - nptr[i]);
+  for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {
+    const int j = neigh_at(T, i, jj);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(dim, x, i, j, rij);
@@ -286,8 +292,8 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
   for (int k = 0; k < 27; ++k) A[k] = 0.0;
   for (int k = 0; k < 36; ++k) L[k] = 0.0;
   for (int k = 0; k < d2; ++k) G[k] = Gc[(size_t)i * d2 + k];
-  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {  // third-order tensor A^{kmn}
-    const int j = neigh_at(T, i, jj - nptr[i]);
+  for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {  // third-order tensor A^{kmn}
+    const int j = neigh_at(T, i, jj);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(dim, x, i, j, rij);
@@ -305,8 +311,8 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
           for (int k1 = 0; k1 < k2 + 1; ++k1) A[k3 * d2 + k2 * dim + k1] += aij[k3] * rij[k1] * rij[k2];
     }
   }
-  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {  // linear system
-    const int j = neigh_at(T, i, jj - nptr[i]);
+  for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {  // linear system
+    const int j = neigh_at(T, i, jj);
     const int jt = type[j];
     double rij[3];
     const double rsq = pair_rsq(dim, x, i, j, rij);
@@ -383,8 +389,8 @@ __global__ void k_asm_count(AsmTables T, int nlocal, const double *__restrict__ 
   if (i >= nlocal) return;
   const int it = type[i], nt1 = T.ntypes + 1;
   int cnt = 1;
-  for (int jj = nptr[i]; jj < nptr[i + 1]; ++jj) {
-    const int j = neigh_at(T, i, jj - nptr[i]);
+  for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {
+    const int j = neigh_at(T, i, jj);
     double rij[3];
     const double rsq = pair_rsq(T.dim, x, i, j, rij);
     if (rsq < T.cutsq[it * nt1 + type[j]]) ++cnt;
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
   const int filt_j = a.singular_mode == 0 ? KIND_ALL : KIND_FLUID;
   const double alpha = -a.dt;
   const double mi = a.invrho[i];
-  const int jb = a.nptr[i], je = a.nptr[i + 1];
+  const int jb = 0, je = T.nlen[i];
   int cnt = 0, pdiag = -1;  // pdiag: slot of the diagonal (sorted lists: where the row's own column belongs)
   const int ci_own = a.colmap[i];
   double diag_final;
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
   const double alpha = a.dt;
   const double invrho = 1.0 / a.rho[i];
   const double mi = a.nu[i] * a.rho[i];
-  const int jb = a.nptr[i], je = a.nptr[i + 1];
+  const int jb = 0, je = T.nlen[i];
   int cnt = 0, pdiag = -1;
   const int ci_own = a.colmap[i];
   double diag_final;
@@ -901,7 +907,9 @@ __global__ void k_sell_merge_duplicates(int nrow, const int *__restrict__ rowlen
 struct StagedParticles {
   DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar, pnd, hinv, knorm, kdnorm, invrho, normal;
   DevBuf<int> type, kind, nptr, nidx, colmap, first;
+  DevBuf<long long> nptr64;
   void release() {
+    nptr64.release();
     x.release(); vfrac.release(); Gc.release(); Lc.release(); h.release(); cutsq.release(); rho.release();
     vstar.release(); pnd.release(); hinv.release(); knorm.release(); kdnorm.release(); invrho.release(); normal.release(); type.release(); kind.release(); nptr.release(); nidx.release(); colmap.release(); first.release();
   }
@@ -914,15 +922,24 @@ struct NeighEll {
   void release() { off.release(); idx.release(); len.release(); sorted.release(); }
 };
 
+// the flattened neighbour list's offsets as the caller gave them: 32-bit (LAMMPS-like numneigh/firstneigh, up to 2^31
+// list entries) or 64-bit (isph_particles::neigh_ptr64: BASELINE configs[4] has 4 M x 748 = 3e9 entries)
+struct NeighPtr {
+  const int *p32 = nullptr;
+  const long long *p64 = nullptr;
+};
+
 // builds the lane-interleaved neighbour list and hooks it into T
-inline int build_neigh_ell(isph_ctx *ctx, int n, const int *dnptr, const int *dnidx, NeighEll &E, AsmTables &T,
-                           const int *dcolmap = nullptr) {
+template <class OFF>
+inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *dnidx, NeighEll &E, AsmTables &T,
+                             const int *dcolmap) {
   const int nslices = (n + kSlice - 1) / kSlice;
   ISPH_CHECK(E.len.reserve((size_t)(n > 0 ? n : 1)));
   ISPH_CHECK(E.off.reserve((size_t)nslices + 1));
+  T.nlen = E.len.p;
   if (n == 0) { T.noff = E.off.p; T.nt = nullptr; return ISPH_SUCCESS; }
   const int grid = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_numneigh, dim3(grid), dim3(kBlock), 0, ctx->stream, n, dnptr, E.len.p);
+  hipLaunchKernelGGL(k_numneigh<OFF>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, dnptr, E.len.p);
   hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, E.len.p, E.off.p);
   hipLaunchKernelGGL(k_exclusive_scan_ll, dim3(1), dim3(1024), 0, ctx->stream, nslices, E.off.p, E.off.p);
   long long total = 0;
@@ -938,17 +955,22 @@ inline int build_neigh_ell(isph_ctx *ctx, int n, const int *dnptr, const int *dn
     for (int s = 0; s < nslices; ++s) wmax = std::max(wmax, (so[(size_t)s + 1] - so[(size_t)s]) >> 6);
     if (wmax <= kNeighSortCap) {
       ISPH_CHECK(E.sorted.reserve((size_t)(total > 0 ? total : 1)));
-      hipLaunchKernelGGL(k_neigh_sort, dim3((n + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, dcolmap, E.sorted.p);
+      hipLaunchKernelGGL(k_neigh_sort<OFF>, dim3((n + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, dcolmap, E.sorted.p);
       dnidx = E.sorted.p;
       T.sorted = 1;
     }
   }
-  hipLaunchKernelGGL(k_neigh_transpose, dim3((nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, E.off.p,
+  hipLaunchKernelGGL(k_neigh_transpose<OFF>, dim3((nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, E.off.p,
                      E.idx.p);
   ISPH_CHECK_HIP(hipGetLastError());
   T.noff = E.off.p;
   T.nt = E.idx.p;
   return ISPH_SUCCESS;
+}
+inline int build_neigh_ell(isph_ctx *ctx, int n, const NeighPtr &np, const int *dnidx, NeighEll &E, AsmTables &T,
+                           const int *dcolmap = nullptr) {
+  if (np.p64) return build_neigh_ell_t<long long>(ctx, n, np.p64, dnidx, E, T, dcolmap);
+  return build_neigh_ell_t<int>(ctx, n, np.p32, dnidx, E, T, dcolmap);
 }
 
 template <class T>
@@ -959,6 +981,34 @@ inline int stage(isph_ctx *ctx, const T *src, size_t n, int on_device, DevBuf<T>
   ISPH_CHECK(tmp.reserve(n > 0 ? n : 1));
   ISPH_CHECK_HIP(hipMemcpyAsync(tmp.p, src, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
   *out = tmp.p;
+  return ISPH_SUCCESS;
+}
+
+// stages the neighbour-list offsets (neigh_ptr64 wins over neigh_ptr) and returns the number of list entries
+struct StagedParticles;
+inline int stage_neigh_ptr(isph_ctx *ctx, const isph_particles *P, int n, int on_device, DevBuf<int> &b32,
+                           DevBuf<long long> &b64, NeighPtr &np, long long *nnb) {
+  ISPH_REQUIRE(P->neigh_ptr || P->neigh_ptr64, "neighbour list offsets missing");
+  if (P->neigh_ptr64) {
+    ISPH_CHECK(stage(ctx, P->neigh_ptr64, (size_t)n + 1, on_device, b64, &np.p64));
+    if (on_device) {
+      ISPH_CHECK_HIP(hipMemcpyAsync(nnb, P->neigh_ptr64 + n, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+      ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+      *nnb = P->neigh_ptr64[n];
+    }
+  } else {
+    ISPH_CHECK(stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, b32, &np.p32));
+    int last = 0;
+    if (on_device) {
+      ISPH_CHECK_HIP(hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+      last = P->neigh_ptr[n];
+    }
+    *nnb = last;
+  }
+  ISPH_REQUIRE(*nnb >= 0, "negative neighbour count");
   return ISPH_SUCCESS;
 }
 
@@ -987,7 +1037,7 @@ inline int stage_tables(isph_ctx *ctx, const isph_particles *P, StagedParticles 
 
 inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device) {
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
-  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx, "particle arrays missing");
+  ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx, "particle arrays missing");
   StagedParticles S;
   AsmTables T;
   int rc = stage_tables(ctx, P, S, T);
@@ -995,18 +1045,12 @@ inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac
   long long nnb = 0;
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->x, (size_t)P->nall * 3, on_device, S.x, &dx);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->type, (size_t)P->nall, on_device, S.type, &dt);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)P->nlocal + 1, on_device, S.nptr, &dp);
-  if (rc == ISPH_SUCCESS) {
-    if (on_device) {
-      int last = 0;
-      if (hipMemcpyAsync(&last, P->neigh_ptr + P->nlocal, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("neigh_ptr read failed", __FILE__, __LINE__);
-      nnb = last;
-    } else nnb = P->neigh_ptr[P->nlocal];
-  }
+  NeighPtr np;
+  if (rc == ISPH_SUCCESS) rc = stage_neigh_ptr(ctx, P, P->nlocal, on_device, S.nptr, S.nptr64, np, &nnb);
+  dp = np.p32;
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &di);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, P->nlocal, dp, di, E, T);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, P->nlocal, np, di, E, T);
   DevBuf<double> out;
   double *dout = vfrac_out;
   if (rc == ISPH_SUCCESS && !on_device) { rc = out.reserve((size_t)(P->nlocal > 0 ? P->nlocal : 1)); dout = out.p; }
@@ -1029,7 +1073,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
                             const double *vstar, int singular_mode, int is_rank0, int ncol, isph_mat **A_out,
                             double *b_out, int on_device) {
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
-  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx && P->colmap, "particle arrays missing");
+  ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx && P->colmap, "particle arrays missing");
   ISPH_REQUIRE(antisym || (P->Gc && P->Lc), "Symmetric family needs Gc and Lc");
   ISPH_REQUIRE(P->vfrac, "vfrac is required (isph_compute_volumes + forward comm first)");
   ISPH_REQUIRE(singular_mode >= 0 && singular_mode <= 3, "bad singular mode");
@@ -1061,15 +1105,11 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     else rc = stage(ctx, P->normal, (size_t)P->nall * 3, on_device, S.normal, &a.normal);
     if (rc == ISPH_SUCCESS && !a.Gc) rc = stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, S.Gc, &a.Gc);
   }
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &a.nptr);
+  NeighPtr np;
+  if (rc == ISPH_SUCCESS) rc = stage_neigh_ptr(ctx, P, n, on_device, S.nptr, S.nptr64, np, &nnb);
+  a.nptr = np.p32;
   if (rc == ISPH_SUCCESS) {
-    if (on_device) {
-      int last = 0;
-      if (hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("neigh_ptr read failed", __FILE__, __LINE__);
-      nnb = last;
-    } else {
-      nnb = P->neigh_ptr[n];
+    if (!on_device) {
       // host-side shape check before any kernel indexes with these
       for (long long k = 0; k < nnb && rc == ISPH_SUCCESS; ++k)
         if (P->neigh_idx[k] < 0 || P->neigh_idx[k] >= P->nall) rc = fail("neighbour index out of range", __FILE__, __LINE__);
@@ -1079,7 +1119,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, a.colmap);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, np, a.nidx, E, T, a.colmap);
   // kinds present: refuse what this build does not restate
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
@@ -1177,7 +1217,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
                               const double *gvec, int incremental, const double *vel, int ncol, isph_mat **A_out,
                               double *b_out, int lda, int on_device) {
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
-  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx && P->colmap, "particle arrays missing");
+  ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx && P->colmap, "particle arrays missing");
   ISPH_REQUIRE(antisym || (P->Gc && P->Lc), "Symmetric family needs Gc and Lc");
   ISPH_REQUIRE(P->vfrac, "vfrac is required (isph_compute_volumes + forward comm first)");
   ISPH_REQUIRE(ncol >= P->nlocal && lda >= P->nlocal, "need ncol >= nlocal and lda >= nlocal");
@@ -1208,15 +1248,11 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
     if (!P->pnd) rc = fail("MorrisHolmes needs pnd", __FILE__, __LINE__);
     else rc = stage(ctx, P->pnd, (size_t)P->nall, on_device, S.pnd, &a.pnd);
   }
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &a.nptr);
+  NeighPtr np;
+  if (rc == ISPH_SUCCESS) rc = stage_neigh_ptr(ctx, P, n, on_device, S.nptr, S.nptr64, np, &nnb);
+  a.nptr = np.p32;
   if (rc == ISPH_SUCCESS) {
-    if (on_device) {
-      int last = 0;
-      if (hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("neigh_ptr read failed", __FILE__, __LINE__);
-      nnb = last;
-    } else {
-      nnb = P->neigh_ptr[n];
+    if (!on_device) {
       for (long long k = 0; k < nnb && rc == ISPH_SUCCESS; ++k)
         if (P->neigh_idx[k] < 0 || P->neigh_idx[k] >= P->nall) rc = fail("neighbour index out of range", __FILE__, __LINE__);
       for (int j = 0; j < P->nall && rc == ISPH_SUCCESS; ++j)
@@ -1225,7 +1261,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, A_out ? a.colmap : nullptr);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, np, a.nidx, E, T, A_out ? a.colmap : nullptr);
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
       if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);
@@ -1301,7 +1337,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
 // FunctorOuterGradientCorrection + FunctorOuterLaplacianCorrection for the owned particles
 inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *Gc_out, double *Lc_out, int on_device) {
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
-  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx && P->vfrac, "particle arrays missing (vfrac incl. ghosts)");
+  ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx && P->vfrac, "particle arrays missing (vfrac incl. ghosts)");
   const int n = P->nlocal, dim = P->dim, d2 = dim * dim, dL = dim * (dim + 1) / 2;
   StagedParticles S;
   AsmTables T;
@@ -1312,18 +1348,12 @@ inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *G
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->x, (size_t)P->nall * 3, on_device, S.x, &dx);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->type, (size_t)P->nall, on_device, S.type, &dt);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->vfrac, (size_t)P->nall, on_device, S.vfrac, &dvf);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &dp);
-  if (rc == ISPH_SUCCESS) {
-    if (on_device) {
-      int last = 0;
-      if (hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("neigh_ptr read failed", __FILE__, __LINE__);
-      nnb = last;
-    } else nnb = P->neigh_ptr[n];
-  }
+  NeighPtr np;
+  if (rc == ISPH_SUCCESS) rc = stage_neigh_ptr(ctx, P, n, on_device, S.nptr, S.nptr64, np, &nnb);
+  dp = np.p32;
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &di);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, dp, di, E, T);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, np, di, E, T);
   DevBuf<double> g, l;
   DevBuf<int> nf;
   double *dG = Gc_out, *dLc = Lc_out;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_block_helmholtz(AsmTables T, Blo
   const int w = (int)((slice_off[(i >> 6) + 1] - off) >> 6);
   const double alpha = a.dt;
   const double mi = a.nu[i];
-  const int jb0 = a.nptr[i], je = a.nptr[i + 1];
+  const int jb0 = 0, je = T.nlen[i];
   const int ci_own = a.colmap[i];
   int cnt = 0, pdiag = -1;
 
@@ -274,7 +274,7 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
                                     const double *force, const double *gvec, int incremental, const double *vel,
                                     const double *normal, int lda, isph_mat **blocks_out, double *b_out, int on_device) {
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
-  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx && P->colmap, "particle arrays missing");
+  ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx && P->colmap, "particle arrays missing");
   ISPH_REQUIRE(antisym || (P->Gc && P->Lc), "Symmetric family needs Gc and Lc");
   ISPH_REQUIRE(!normal || P->Gc, "the Navier-slip wall terms need Gc");
   ISPH_REQUIRE(P->vfrac, "vfrac is required (isph_compute_volumes + forward comm first)");
@@ -307,15 +307,11 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
     if (!P->pnd) rc = fail("MorrisHolmes needs pnd", __FILE__, __LINE__);
     else rc = stage(ctx, P->pnd, (size_t)P->nall, on_device, S.pnd, &a.pnd);
   }
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, S.nptr, &a.nptr);
+  NeighPtr np;
+  if (rc == ISPH_SUCCESS) rc = stage_neigh_ptr(ctx, P, n, on_device, S.nptr, S.nptr64, np, &nnb);
+  a.nptr = np.p32;
   if (rc == ISPH_SUCCESS) {
-    if (on_device) {
-      int last = 0;
-      if (hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("neigh_ptr read failed", __FILE__, __LINE__);
-      nnb = last;
-    } else {
-      nnb = P->neigh_ptr[n];
+    if (!on_device) {
       for (long long k = 0; k < nnb && rc == ISPH_SUCCESS; ++k)
         if (P->neigh_idx[k] < 0 || P->neigh_idx[k] >= P->nall) rc = fail("neighbour index out of range", __FILE__, __LINE__);
       for (int j = 0; j < P->nall && rc == ISPH_SUCCESS; ++j)
@@ -324,7 +320,7 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
   }
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &a.nidx);
   NeighEll E;
-  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, a.nptr, a.nidx, E, T, a.colmap);
+  if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, np, a.nidx, E, T, a.colmap);
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
       if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void k_gradient(AsmTables T, OpArgs a, cons
     if (!antisym)
       for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
     const double vi = a.vfrac[i], fi = f[i];
-    const int jb = a.nptr[i], je = a.nptr[i + 1];
+    const int jb = 0, je = T.nlen[i];
     for (int jj = jb; jj < je; ++jj) {
       const int j = neigh_at(T, i, jj - jb);
       const int jt = a.type[j], jkind = T.kind[jt];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void k_divergence(AsmTables T, OpArgs a, co
     if (!antisym)
       for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
     const double vi = a.vfrac[i];
-    const int jb = a.nptr[i], je = a.nptr[i + 1];
+    const int jb = 0, je = T.nlen[i];
     for (int jj = jb; jj < je; ++jj) {
       const int j = neigh_at(T, i, jj - jb);
       const int jt = a.type[j], jkind = T.kind[jt];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_compute_shift(AsmTables T, OpArgs a,
   double d[3] = {0, 0, 0};
   if (ikind & KIND_FLUID) {
     const double alpha = scale ? alpha0 * scale[0] : alpha0;
-    const int jb = a.nptr[i], je = a.nptr[i + 1];
+    const int jb = 0, je = T.nlen[i];
     int cnt = 0;
     double ri = 0.0;
     for (int jj = jb; jj < je; ++jj) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_shift(AsmTables T, OpArgs a, c
     if (!a.antisym)
       for (int k = 0; k < dim * dim; ++k) G[k] = a.Gc[(size_t)i * dim * dim + k];
     const double vfi = a.vfrac[i];
-    const int jb = a.nptr[i], je = a.nptr[i + 1];
+    const int jb = 0, je = T.nlen[i];
     for (int jj = jb; jj < je; ++jj) {
       const int j = neigh_at(T, i, jj - jb);
       const int jt = a.type[j];
@@ -285,7 +285,7 @@ struct OpStage {
 
 inline int op_stage(isph_ctx *ctx, const isph_particles *P, int antisym, int on_device, OpStage &st) {
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
-  ISPH_REQUIRE(P->x && P->type && P->neigh_ptr && P->neigh_idx && P->vfrac, "particle arrays missing");
+  ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx && P->vfrac, "particle arrays missing");
   ISPH_REQUIRE(antisym || P->Gc, "Symmetric family needs Gc");
   const int n = P->nlocal, dim = P->dim;
   memset(&st.a, 0, sizeof(st.a));
@@ -296,19 +296,15 @@ inline int op_stage(isph_ctx *ctx, const isph_particles *P, int antisym, int on_
   ISPH_CHECK(stage(ctx, P->type, (size_t)P->nall, on_device, st.S.type, &st.a.type));
   ISPH_CHECK(stage(ctx, P->vfrac, (size_t)P->nall, on_device, st.S.vfrac, &st.a.vfrac));
   ISPH_CHECK(stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, st.S.Gc, &st.a.Gc));
-  ISPH_CHECK(stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, st.S.nptr, &st.a.nptr));
-  if (on_device) {
-    int last = 0;
-    ISPH_CHECK_HIP(hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    nnb = last;
-  } else {
-    nnb = P->neigh_ptr[n];
+  NeighPtr np;
+  ISPH_CHECK(stage_neigh_ptr(ctx, P, n, on_device, st.S.nptr, st.S.nptr64, np, &nnb));
+  st.a.nptr = np.p32;
+  if (!on_device) {
     for (long long k = 0; k < nnb; ++k)
       ISPH_REQUIRE(P->neigh_idx[k] >= 0 && P->neigh_idx[k] < P->nall, "neighbour index out of range");
   }
   ISPH_CHECK(stage(ctx, P->neigh_idx, (size_t)nnb, on_device, st.S.nidx, &di));
-  ISPH_CHECK(build_neigh_ell(ctx, n, st.a.nptr, di, st.E, st.T));
+  ISPH_CHECK(build_neigh_ell(ctx, n, np, di, st.E, st.T));
   st.a.nlocal = n;
   st.a.antisym = antisym;
   return ISPH_SUCCESS;

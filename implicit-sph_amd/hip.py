@@ -67,7 +67,7 @@ class _Particles(C.Structure):
                 ("h", C.c_void_p), ("cutsq", C.c_void_p), ("neigh_ptr", C.c_void_p), ("neigh_idx", C.c_void_p),
                 ("colmap", C.c_void_p), ("vfrac", C.c_void_p), ("Gc", C.c_void_p), ("Lc", C.c_void_p),
                 ("morris_holmes", C.c_int), ("pnd", C.c_void_p), ("morris_safe_coeff", C.c_double),
-                ("normal", C.c_void_p), ("solid_normal_diag", C.c_double)]
+                ("normal", C.c_void_p), ("solid_normal_diag", C.c_double), ("neigh_ptr64", C.c_void_p)]
 
 
 _lib = None
@@ -458,14 +458,17 @@ def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=
     h = np.full((ntypes + 1, ntypes + 1), float(parts["h"]))
     cutsq = np.full((ntypes + 1, ntypes + 1), float(parts["cut"]) ** 2)
     x, typ = _f64(parts["x"]), _i32(parts["type"])
-    nptr, nidx, cm = _i32(parts["neigh_ptr"]), _i32(parts["neigh_idx"]), _i32(colmap)
+    nidx, cm = _i32(parts["neigh_idx"]), _i32(colmap)
+    nptr_raw = parts["neigh_ptr"]
+    wide = str(nptr_raw.dtype) in ("int64", "torch.int64")        # 64-bit list offsets -> isph_particles::neigh_ptr64
+    nptr = (nptr_raw if _is_torch(nptr_raw) else np.ascontiguousarray(nptr_raw)) if wide else _i32(nptr_raw)
     pnd = None if pnd is None else _f64(pnd)
     normal = None if normal is None else _f64(normal)
     keep += [kind, h, cutsq, x, typ, nptr, nidx, cm, vfrac, Gc, Lc, pnd, normal]
     pv = _Particles(int(parts["dim"]), int(parts["nlocal"]), int(parts["nall"]), ntypes, KERNELS[kernel],
-                    _ptr(x), _ptr(typ), _ptr(kind), _ptr(h), _ptr(cutsq), _ptr(nptr), _ptr(nidx), _ptr(cm),
+                    _ptr(x), _ptr(typ), _ptr(kind), _ptr(h), _ptr(cutsq), None if wide else _ptr(nptr), _ptr(nidx), _ptr(cm),
                     _ptr(vfrac), _ptr(Gc), _ptr(Lc), int(pnd is not None), _ptr(pnd), float(morris_safe_coeff),
-                    _ptr(normal), float(solid_normal_diag))
+                    _ptr(normal), float(solid_normal_diag), _ptr(nptr) if wide else None)
     return pv, _on_device(x, typ, nptr, nidx, cm, vfrac, Gc, Lc, pnd, normal), keep
 
 

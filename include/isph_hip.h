@@ -206,6 +206,10 @@ typedef struct {
    * same step, 0 if only block matrices were built. */
   const double *normal;
   double solid_normal_diag;
+  /* 64-bit offsets of the flattened neighbour list, used instead of neigh_ptr when non-NULL: the reference's
+   * largest configuration (bcc lattice, Quintic cut 3h: 748 neighbours x 4 M particles = 3e9 list entries,
+   * sph-script/pore-scale-flow-3d.lmp) does not fit 32-bit offsets.  neigh_ptr may be NULL then. */
+  const long long *neigh_ptr64;
 } isph_particles;
 
 /* Replaces PairISPH_Corrected::computePoisson -> FunctorOuterIncompNavierStokesPoisson

@@ -236,6 +236,30 @@ def test_config1_full_size_100cubed(gpu_ctx):
     assert np.linalg.norm(x - xj) / np.linalg.norm(xj) < 1e-6
 
 
+def test_neigh_ptr64_gives_the_same_system(gpu_ctx):
+    """isph_particles::neigh_ptr64 (64-bit offsets of the flattened neighbour list, for lists beyond 2^31 entries)
+    against the 32-bit neigh_ptr: volumes, correction tensors, Poisson matrix and right-hand side bit for bit."""
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER), antisym=False)
+    p32 = pr.parts
+    p64 = dict(p32)
+    p64["neigh_ptr"] = p32["neigh_ptr"].astype(np.int64)
+    out = []
+    for p in (p32, p64):
+        vf = hip.compute_volumes(gpu_ctx, p, pr.colmap)
+        vfrac = np.ascontiguousarray(vf[p["owner_index"]])
+        G, L = hip.compute_corrections(gpu_ctx, p, pr.colmap, vfrac)
+        Gc = np.ascontiguousarray(G[p["owner_index"]]); Lc = np.ascontiguousarray(L[p["owner_index"]])
+        A, b = hip.assemble_poisson(gpu_ctx, p, pr.colmap, pr.spec.dt, p["rho"], np.ascontiguousarray(p["v"]),
+                                    antisym=False, vfrac=vfrac, Gc=Gc, Lc=Lc)
+        g = hip.gradient(gpu_ctx, p, pr.colmap, np.cos(p["x"][:, 0]), vfrac, antisym=False, Gc=Gc)
+        out.append((vf, G, L, A.export_csr(), b, g))
+    for a32, a64 in zip(out[0], out[1]):
+        if isinstance(a32, tuple):
+            assert all(np.array_equal(u, w) for u, w in zip(a32, a64))
+        else:
+            assert np.array_equal(a32, a64)
+
+
 def test_exact_lattice_ties_count_and_fill_agree(gpu_ctx):
     """Regression (round 2): on an exact lattice 30 neighbours of every particle sit EXACTLY on the cut radius
     (|(3,0,0)| = |(2,2,1)| = 3 dx = cut).  ROCm's __dmul_rn/__dadd_rn are plain operators, so the compiler fused
