@@ -40,7 +40,7 @@ def _headers():
 def build_host(force=False):
     srcs = [os.path.join(CSRC, s) for s in HOST_SRCS]
     if force or _stale(HOST_LIB, srcs + _headers()):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INC, "-o", HOST_LIB] + srcs)
+        _run(["g++", "-O2", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-I", INC, "-o", HOST_LIB] + srcs)
     return HOST_LIB
 
 

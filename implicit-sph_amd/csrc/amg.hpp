@@ -22,14 +22,21 @@
 
 int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const int *dci, const double *dv, long long nnz,
                         isph_mat **Aout, bool rows_sorted = false);  // isph_capi.hip
+int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const long long *drp, const int *dci, const double *dv,
+                        long long nnz, isph_mat **Aout, bool rows_sorted = false);
 void isph_mat_destroy(isph_mat *A);
 
 namespace isph {
 
+// row offsets of every device CSR of the set-up are 64-bit: the fine-level copy of the operator can exceed 2^31
+// entries (BASELINE configs[4]: 4 M rows x 749); the derived operators are small but share the kernels
+typedef long long rp_t;
+
 struct DCsr {
   int n = 0, m = 0;
   long long nnz = 0;
-  DevBuf<int> rp, ci;
+  DevBuf<rp_t> rp;
+  DevBuf<int> ci;
   DevBuf<double> v;
   void release() { rp.release(); ci.release(); v.release(); n = m = 0; nnz = 0; }
 };
@@ -99,11 +106,12 @@ constexpr int kCsrChunk = 8;
 __global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__restrict__ rowlen,
                                                          const long long *__restrict__ slice_off,
                                                          const int *__restrict__ scol, const double *__restrict__ sval,
-                                                         const int *__restrict__ rowptr, int *__restrict__ colidx,
+                                                         const rp_t *__restrict__ rowptr, int *__restrict__ colidx,
                                                          double *__restrict__ cval) {
   __shared__ int stc[4][64][kCsrChunk];
   __shared__ double stv[4][64][kCsrChunk];
-  __shared__ int slen[4][64], sbeg[4][64];
+  __shared__ int slen[4][64];
+  __shared__ rp_t sbeg[4][64];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slice = blockIdx.x * 4 + wv;
   const int row = slice * 64 + lane;
@@ -138,13 +146,13 @@ __global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__
   }
 }
 
-__global__ __launch_bounds__(256) void k_amg_diag(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+__global__ __launch_bounds__(256) void k_amg_diag(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                                   const double *__restrict__ v, double *__restrict__ dg) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   double d = 0.0;
   bool found = false;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64)
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64)
     if (ci[p] == i && !found) { d = v[p]; found = true; }
   const unsigned long long any = __ballot(found);
   if (any) d = __shfl(d, __ffsll((long long)any) - 1, 64);
@@ -153,28 +161,28 @@ __global__ __launch_bounds__(256) void k_amg_diag(int n, const int *__restrict__
 
 // sc[p] = column of entry p when it is a strong off-diagonal coupling, -1 otherwise: the ~30 graph sweeps of the
 // aggregation then read 4 B per entry instead of column + value + two diagonal gathers
-__global__ void k_strong_cols(int n, const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ v,
+__global__ void k_strong_cols(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ v,
                               const double *__restrict__ dg, double th2, int *__restrict__ sc) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
     const int j = ci[p];
     sc[p] = AMG_STRONG(v[p], i, j) ? j : -1;
   }
 }
 
-__global__ __launch_bounds__(256) void k_mis_init(int n, const int *__restrict__ rp, const int *__restrict__ sc,
+__global__ __launch_bounds__(256) void k_mis_init(int n, const rp_t *__restrict__ rp, const int *__restrict__ sc,
                                                   unsigned long long *__restrict__ key) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   bool strong = false;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) strong |= sc[p] >= 0;
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) strong |= sc[p] >= 0;
   const bool any_strong = __ballot(strong) != 0;  // every lane takes part in the vote
   if (lane == 0) key[i] = amg_key(any_strong ? AMG_UNDECIDED : AMG_COVERED, i);
 }
 
 // out[i] = max(in[i], max over strong neighbours in[j])
-__global__ __launch_bounds__(256) void k_mis_max(int n, const int *__restrict__ rp, const int *__restrict__ sc,
+__global__ __launch_bounds__(256) void k_mis_max(int n, const rp_t *__restrict__ rp, const int *__restrict__ sc,
                                                  const unsigned long long *__restrict__ in,
                                                  unsigned long long *__restrict__ out,
                                                  const unsigned long long *__restrict__ only_undecided) {
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void k_mis_max(int n, const int *__restrict__ 
   // second sweep: only undecided rows read their result
   if (only_undecided && (only_undecided[i] >> 62) != AMG_UNDECIDED) return;
   unsigned long long m = in[i];
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
     const int j = sc[p];
     if (j >= 0) { const unsigned long long kj = in[j]; m = kj > m ? kj : m; }
   }
@@ -212,14 +220,14 @@ __global__ void k_mis_decide(int n, unsigned long long *__restrict__ key, const 
 constexpr int kMisGrid = 2048;
 
 __global__ __launch_bounds__(256) void k_mis_max_list(const int *__restrict__ cntp, const int *__restrict__ list,
-                                                      const int *__restrict__ rp, const int *__restrict__ sc,
+                                                      const rp_t *__restrict__ rp, const int *__restrict__ sc,
                                                       const unsigned long long *__restrict__ in,
                                                       unsigned long long *__restrict__ out) {
   const int nw = gridDim.x * kAmgWaves, lane = threadIdx.x & 63, cnt = *cntp;
   for (int w = blockIdx.x * kAmgWaves + (threadIdx.x >> 6); w < cnt; w += nw) {
     const int i = list[w];
     unsigned long long m = in[i];
-    for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+    for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
       const int j = sc[p];
       if (j >= 0) { const unsigned long long kj = in[j]; m = kj > m ? kj : m; }
     }
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) void k_mis_max_list(const int *__restrict__ cn
 constexpr int kMarkBuf = 1024;  // fresh rows a wave collects before it claims list space (one atomic per flush)
 
 __global__ __launch_bounds__(256) void k_mis_mark(const int *__restrict__ cntp, const int *__restrict__ list,
-                                                  const int *__restrict__ rp, const int *__restrict__ sc,
+                                                  const rp_t *__restrict__ rp, const int *__restrict__ sc,
                                                   int *__restrict__ stamp, int round, int *__restrict__ list1,
                                                   int *__restrict__ cnt1) {
   __shared__ int sbuf[kAmgWaves][kMarkBuf];
@@ -252,9 +260,9 @@ __global__ __launch_bounds__(256) void k_mis_mark(const int *__restrict__ cntp, 
   };
   for (int w = blockIdx.x * kAmgWaves + (threadIdx.x >> 6); w < cnt; w += nw) {
     const int i = list[w];
-    const int lo = rp[i], hi = rp[i + 1];
-    for (int p0 = lo - 1; p0 < hi; p0 += 64) {  // slot lo-1 stands for the row itself
-      const int p = p0 + lane;
+    const rp_t lo = rp[i], hi = rp[i + 1];
+    for (rp_t p0 = lo - 1; p0 < hi; p0 += 64) {  // slot lo-1 stands for the row itself
+      const rp_t p = p0 + lane;
       int j = -1;
       if (p < hi) j = p < lo ? i : sc[p];
       bool fresh = false;
@@ -310,14 +318,14 @@ __global__ void k_flag_roots(int n, const unsigned long long *__restrict__ key, 
 }
 
 // pass 1: roots take their scan id, a non-root takes the id of the first strong neighbour that is a root
-__global__ __launch_bounds__(256) void k_agg_pass1(int n, const int *__restrict__ rp, const int *__restrict__ sc,
+__global__ __launch_bounds__(256) void k_agg_pass1(int n, const rp_t *__restrict__ rp, const int *__restrict__ sc,
                                                    const unsigned long long *__restrict__ key,
                                                    const int *__restrict__ rootid, int *__restrict__ a1) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   if ((key[i] >> 62) == AMG_ROOT) { if (lane == 0) a1[i] = rootid[i]; return; }
   int best = 0x7fffffff;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
     const int j = sc[p];
     if (j >= 0 && (key[j] >> 62) == AMG_ROOT && p < best) best = p;
   }
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void k_agg_pass1(int n, const int *__restrict_
 }
 
 // pass 2: the rest joins the pass-1 neighbour it is most strongly coupled to (ties: first in the row)
-__global__ __launch_bounds__(256) void k_agg_pass2(int n, const int *__restrict__ rp, const int *__restrict__ sc,
+__global__ __launch_bounds__(256) void k_agg_pass2(int n, const rp_t *__restrict__ rp, const int *__restrict__ sc,
                                                    const double *__restrict__ v, const int *__restrict__ a1, int *__restrict__ agg,
                                                    int *__restrict__ leftover) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(256) void k_agg_pass2(int n, const int *__restrict_
   double bw = -1.0;
   int bp = 0x7fffffff;
   bool strong = false;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
     const int j = sc[p];
     if (j < 0) continue;
     strong = true;
@@ -398,13 +406,13 @@ __global__ void k_ptent(int n, const int *__restrict__ agg, const double *__rest
 }
 
 // rho = max_i sum_j |a_ij| / |a_ii|  (bit pattern of a non-negative double orders like the number)
-__global__ __launch_bounds__(256) void k_amg_rho(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+__global__ __launch_bounds__(256) void k_amg_rho(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ v, const double *__restrict__ dg,
                                                  volatile unsigned long long *rho_bits) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   double s = 0.0;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64)
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64)
     if (ci[p] < n) s += fabs(v[p]);
   s = wave_sum(s) / fabs(dg[i]);
   // one atomic per row would serialise a million updates of one word: only candidates above the running maximum try
@@ -419,11 +427,11 @@ __global__ __launch_bounds__(256) void k_amg_rho(int n, const int *__restrict__ 
 constexpr int kProlongSlots = 8;
 
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_prolong(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+__global__ __launch_bounds__(256) void k_prolong(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ v, const double *__restrict__ dg,
                                                  const int *__restrict__ agg, const double *__restrict__ pt, double damp,
-                                                 int *__restrict__ prp, int *__restrict__ pci, double *__restrict__ pv,
-                                                 int *__restrict__ err) {
+                                                 int *__restrict__ pcnt, const rp_t *__restrict__ prp,
+                                                 int *__restrict__ pci, double *__restrict__ pv, int *__restrict__ err) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   int tkey[kProlongSlots], cnt = 0;
@@ -433,8 +441,8 @@ __global__ __launch_bounds__(256) void k_prolong(int n, const int *__restrict__ 
   const int ai = agg[i];
   if (ai >= 0) { if (lane == 0) { tkey[0] = ai; tval[0] = pt[i]; } cnt = 1; }
   const double f = damp / dg[i];
-  for (int p0 = rp[i]; p0 < rp[i + 1]; p0 += 64) {
-    const int p = p0 + lane;
+  for (rp_t p0 = rp[i]; p0 < rp[i + 1]; p0 += 64) {
+    const rp_t p = p0 + lane;
     int a = -1;
     double term = 0.0;
     if (p < rp[i + 1]) {
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256) void k_prolong(int n, const int *__restrict__ 
       live &= ~__ballot(mine);
     }
   }
-  if (!FILL) { if (lane == 0) prp[i] = cnt; return; }
+  if (!FILL) { if (lane == 0) pcnt[i] = cnt; return; }
   // rank sort by aggregate id (ascending columns)
   int rank[kProlongSlots];
 #pragma unroll
@@ -493,11 +501,11 @@ __global__ void k_count_cols(long long nnz, const int *__restrict__ ci, int *__r
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < nnz) atomicAdd(&cnt[ci[p]], 1);
 }
-__global__ void k_transpose_keys(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+__global__ void k_transpose_keys(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                  unsigned long long *__restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int p = rp[i]; p < rp[i + 1]; ++p) keys[p] = ((unsigned long long)ci[p] << 32) | (unsigned)i;
+  for (rp_t p = rp[i]; p < rp[i + 1]; ++p) keys[p] = ((unsigned long long)ci[p] << 32) | (unsigned)i;
 }
 __global__ void k_low32(long long nnz, const unsigned long long *__restrict__ keys, int *__restrict__ out) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,11 +516,12 @@ __global__ void k_low32(long long nnz, const unsigned long long *__restrict__ ke
 // addressing otherwise.  Thread t walks entries t, t+BS, .. of X's row and the whole Y row behind each.
 // FILL = false counts the row's entries.  Output columns are in table order (the SELL conversion sorts rows).
 template <int TABLE, int BS, bool FILL>
-__global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, const int *__restrict__ xrp,
+__global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, const rp_t *__restrict__ xrp,
                                                const int *__restrict__ xci, const double *__restrict__ xv,
-                                               const int *__restrict__ yrp, const int *__restrict__ yci,
-                                               const double *__restrict__ yv, int *__restrict__ crp,
-                                               int *__restrict__ cci, double *__restrict__ cv, int *__restrict__ err) {
+                                               const rp_t *__restrict__ yrp, const int *__restrict__ yci,
+                                               const double *__restrict__ yv, int *__restrict__ ccnt,
+                                               const rp_t *__restrict__ crp, int *__restrict__ cci,
+                                               double *__restrict__ cv, int *__restrict__ err) {
   __shared__ int tk[TABLE];
   __shared__ double tv[TABLE];
   __shared__ int s_cnt;
@@ -522,11 +531,11 @@ __global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, cons
   for (int s = threadIdx.x; s < TABLE; s += BS) { tk[s] = -1; if (FILL) tv[s] = 0.0; }
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
-  for (int p = xrp[i] + threadIdx.x; p < xrp[i + 1]; p += BS) {
+  for (rp_t p = xrp[i] + threadIdx.x; p < xrp[i + 1]; p += BS) {
     const int k = xci[p];
     if (k >= yrows) continue;
     const double xa = xv[p];
-    for (int q = yrp[k]; q < yrp[k + 1]; ++q) {
+    for (rp_t q = yrp[k]; q < yrp[k + 1]; ++q) {
       const int c = yci[q];
       int slot = dense ? c : (int)((amg_hash32((unsigned)c)) & (TABLE - 1));
       if (dense) {
@@ -550,10 +559,10 @@ __global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, cons
     for (int s = threadIdx.x; s < TABLE; s += BS) c += tk[s] >= 0;
     if (c) atomicAdd(&s_cnt, c);
     __syncthreads();
-    if (threadIdx.x == 0) crp[i] = s_cnt;
+    if (threadIdx.x == 0) ccnt[i] = s_cnt;
     return;
   }
-  const int beg = crp[i];
+  const rp_t beg = crp[i];
   for (int s = threadIdx.x; s < TABLE; s += BS)
     if (tk[s] >= 0) {
       const int pos = atomicAdd(&s_cnt, 1);
@@ -563,26 +572,26 @@ __global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, cons
 }
 
 // y = R x for a CSR matrix with long rows: one wave per row, coalesced reads of the row, fixed-order wave sum
-__global__ __launch_bounds__(256) void k_csr_spmv_wave(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+__global__ __launch_bounds__(256) void k_csr_spmv_wave(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                                        const double *__restrict__ v, const double *__restrict__ x,
                                                        double *__restrict__ y) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   double s = 0.0;
-  for (int p = rp[i] + lane; p < rp[i + 1]; p += 64) s = fma(v[p], x[ci[p]], s);
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) s = fma(v[p], x[ci[p]], s);
   s = wave_sum(s);
   if (lane == 0) y[i] = s;
 }
 
 constexpr int kAmgDenseMax = 2048;  // largest coarsest level the dense inverse is formed for
 // ---- dense direct solve of the coarsest level (non-singular case) ---------------------------------------
-__global__ void k_dense_from_csr(int n, const int *__restrict__ rp, const int *__restrict__ ci,
+__global__ void k_dense_from_csr(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                  const double *__restrict__ v, double *__restrict__ aug) {
   // aug = [A | I], row-major n x 2n
   const int i = blockIdx.x;
   for (int c = threadIdx.x; c < 2 * n; c += blockDim.x) aug[(size_t)i * 2 * n + c] = c == n + i ? 1.0 : 0.0;
   __syncthreads();
-  for (int p = rp[i] + threadIdx.x; p < rp[i + 1]; p += blockDim.x)
+  for (rp_t p = rp[i] + threadIdx.x; p < rp[i + 1]; p += blockDim.x)
     if (ci[p] < n) aug[(size_t)i * 2 * n + ci[p]] = v[p];
 }
 // Gauss-Jordan with partial pivoting (first maximal row), one elimination step per launch pair; the right half of
@@ -639,6 +648,15 @@ __global__ __launch_bounds__(256) void k_dense_apply(int n, const double *__rest
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
+inline int amg_scan(isph_ctx *ctx, const int *in, rp_t *out, int n, DevBuf<char> &tmp) {
+  size_t bytes = 0;
+  ISPH_CHECK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (rp_t)0, (size_t)n, rocprim::plus<rp_t>(), ctx->stream));
+  ISPH_CHECK(tmp.reserve(bytes > 0 ? bytes : 1));
+  ISPH_CHECK_HIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, (rp_t)0, (size_t)n, rocprim::plus<rp_t>(), ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+// int -> int scan (ids, flags)
 inline int amg_scan(isph_ctx *ctx, const int *in, int *out, int n, DevBuf<char> &tmp) {
   size_t bytes = 0;
   ISPH_CHECK_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), ctx->stream));
@@ -653,12 +671,17 @@ inline int amg_read_int(isph_ctx *ctx, const int *dev, int *host) {
   return ISPH_SUCCESS;
 }
 
+inline int amg_read_off(isph_ctx *ctx, const rp_t *dev, long long *host) {
+  ISPH_CHECK_HIP(hipMemcpyAsync(host, dev, sizeof(rp_t), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return ISPH_SUCCESS;
+}
+
 inline int amg_wave_grid(int n) { return (n + kAmgWaves - 1) / kAmgWaves; }
 
 // device CSR copy of a SELL matrix (rows stay column-sorted)
 inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char> &tmp) {
   A.n = S.nrow; A.m = S.ncol; A.nnz = S.nnz;
-  ISPH_REQUIRE(S.nnz < 2147483647LL, "matrix too large for 32-bit CSR offsets");
   ISPH_CHECK(A.rp.reserve((size_t)S.nrow + 1));
   ISPH_CHECK(A.ci.reserve((size_t)(S.nnz > 0 ? S.nnz : 1)));
   ISPH_CHECK(A.v.reserve((size_t)(S.nnz > 0 ? S.nnz : 1)));
@@ -670,7 +693,7 @@ inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char>
   int rc = amg_scan(ctx, len1.p, A.rp.p, S.nrow + 1, tmp);
   if (rc == ISPH_SUCCESS && S.nrow > 0)
     hipLaunchKernelGGL(k_sell_to_csr_i32, dim3((S.nslices + 3) / 4), dim3(256), 0, ctx->stream, S.nrow,
-                       S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, (const int *)A.rp.p, A.ci.p, A.v.p);
+                       S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, (const rp_t *)A.rp.p, A.ci.p, A.v.p);
   if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("SELL->CSR failed", __FILE__, __LINE__);
   len1.release();
   return rc;
@@ -694,7 +717,7 @@ inline int amg_transpose(isph_ctx *ctx, const DCsr &P, DCsr &R, DevBuf<char> &tm
     const int gn = (int)((P.nnz + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_count_cols, dim3(gn), dim3(kBlock), 0, ctx->stream, P.nnz, (const int *)P.ci.p, cnt.p);
     hipLaunchKernelGGL(k_transpose_keys, dim3((P.n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P.n,
-                       (const int *)P.rp.p, (const int *)P.ci.p, k0.p);
+                       (const rp_t *)P.rp.p, (const int *)P.ci.p, k0.p);
     size_t bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, bytes, k0.p, k1.p, P.v.p, R.v.p, (size_t)P.nnz, 0, 64, ctx->stream) != hipSuccess)
       rc = fail("radix sort sizing failed", __FILE__, __LINE__);
@@ -718,19 +741,19 @@ inline int amg_spgemm_t(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C, De
   ISPH_CHECK(cnt.reserve((size_t)C.n + 1));
   ISPH_CHECK_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)C.n + 1), ctx->stream));
   if (C.n > 0)
-    hipLaunchKernelGGL((k_spgemm<TABLE, BS, false>), dim3(C.n), dim3(BS), 0, ctx->stream, X.n, Y.m, Y.n, (const int *)X.rp.p,
-                       (const int *)X.ci.p, (const double *)X.v.p, (const int *)Y.rp.p, (const int *)Y.ci.p,
-                       (const double *)Y.v.p, cnt.p, (int *)nullptr, (double *)nullptr, derr);
+    hipLaunchKernelGGL((k_spgemm<TABLE, BS, false>), dim3(C.n), dim3(BS), 0, ctx->stream, X.n, Y.m, Y.n, (const rp_t *)X.rp.p,
+                       (const int *)X.ci.p, (const double *)X.v.p, (const rp_t *)Y.rp.p, (const int *)Y.ci.p,
+                       (const double *)Y.v.p, cnt.p, (const rp_t *)nullptr, (int *)nullptr, (double *)nullptr, derr);
   int rc = amg_scan(ctx, cnt.p, C.rp.p, C.n + 1, tmp);
-  int nnz = 0;
-  if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, C.rp.p + C.n, &nnz);
+  long long nnz = 0;
+  if (rc == ISPH_SUCCESS) rc = amg_read_off(ctx, C.rp.p + C.n, &nnz);
   C.nnz = nnz;
   if (rc == ISPH_SUCCESS) rc = C.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
   if (rc == ISPH_SUCCESS) rc = C.v.reserve((size_t)(nnz > 0 ? nnz : 1));
   if (rc == ISPH_SUCCESS && C.n > 0)
-    hipLaunchKernelGGL((k_spgemm<TABLE, BS, true>), dim3(C.n), dim3(BS), 0, ctx->stream, X.n, Y.m, Y.n, (const int *)X.rp.p,
-                       (const int *)X.ci.p, (const double *)X.v.p, (const int *)Y.rp.p, (const int *)Y.ci.p,
-                       (const double *)Y.v.p, C.rp.p, C.ci.p, C.v.p, derr);
+    hipLaunchKernelGGL((k_spgemm<TABLE, BS, true>), dim3(C.n), dim3(BS), 0, ctx->stream, X.n, Y.m, Y.n, (const rp_t *)X.rp.p,
+                       (const int *)X.ci.p, (const double *)X.v.p, (const rp_t *)Y.rp.p, (const int *)Y.ci.p,
+                       (const double *)Y.v.p, (int *)nullptr, (const rp_t *)C.rp.p, C.ci.p, C.v.p, derr);
   if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("SpGEMM launch failed", __FILE__, __LINE__);
   cnt.release();
   return rc;
@@ -803,7 +826,8 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   if (rc == ISPH_SUCCESS) rc = cnt.reserve(4);
   if (rc == ISPH_SUCCESS) rc = L->agg.reserve((size_t)n);
   const int gw = amg_wave_grid(n), gt = (n + kBlock - 1) / kBlock;
-  const int *rp = A.rp.p, *ci = A.ci.p;
+  const rp_t *rp = A.rp.p;
+  const int *ci = A.ci.p;
   const double *v = A.v.p;
   if (rc == ISPH_SUCCESS) {
     hipLaunchKernelGGL(k_strong_cols, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, scb.p);
@@ -902,7 +926,7 @@ inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, int nag
     hipLaunchKernelGGL(k_ptent, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const int *)L->agg.p, (const double *)L->nv.p,
                        (const double *)nvc.p, pt.p);
     if (hipMemsetAsync(rho.p, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
-    hipLaunchKernelGGL(k_amg_rho, dim3(gw), dim3(256), 0, ctx->stream, n, (const int *)A.rp.p, (const int *)A.ci.p,
+    hipLaunchKernelGGL(k_amg_rho, dim3(gw), dim3(256), 0, ctx->stream, n, (const rp_t *)A.rp.p, (const int *)A.ci.p,
                        (const double *)A.v.p, dg, rho.p);
     if (rc == ISPH_SUCCESS &&
         (hipMemcpyAsync(&rho_h, rho.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -915,19 +939,20 @@ inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, int nag
   if (rc == ISPH_SUCCESS) rc = P.rp.reserve((size_t)n + 1);
   if (rc == ISPH_SUCCESS) {
     if (hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)n + 1), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
-    hipLaunchKernelGGL((k_prolong<false>), dim3(gw), dim3(256), 0, ctx->stream, n, (const int *)A.rp.p, (const int *)A.ci.p,
-                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, cnt.p, (int *)nullptr,
-                       (double *)nullptr, derr);
+    hipLaunchKernelGGL((k_prolong<false>), dim3(gw), dim3(256), 0, ctx->stream, n, (const rp_t *)A.rp.p, (const int *)A.ci.p,
+                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, cnt.p, (const rp_t *)nullptr,
+                       (int *)nullptr, (double *)nullptr, derr);
   }
   if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, P.rp.p, n + 1, tmp);
-  int nnz = 0;
-  if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, P.rp.p + n, &nnz);
+  long long nnz = 0;
+  if (rc == ISPH_SUCCESS) rc = amg_read_off(ctx, P.rp.p + n, &nnz);
   P.nnz = nnz;
   if (rc == ISPH_SUCCESS) rc = P.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
   if (rc == ISPH_SUCCESS) rc = P.v.reserve((size_t)(nnz > 0 ? nnz : 1));
   if (rc == ISPH_SUCCESS)
-    hipLaunchKernelGGL((k_prolong<true>), dim3(gw), dim3(256), 0, ctx->stream, n, (const int *)A.rp.p, (const int *)A.ci.p,
-                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, P.rp.p, P.ci.p, P.v.p, derr);
+    hipLaunchKernelGGL((k_prolong<true>), dim3(gw), dim3(256), 0, ctx->stream, n, (const rp_t *)A.rp.p, (const int *)A.ci.p,
+                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, (int *)nullptr, (const rp_t *)P.rp.p,
+                       P.ci.p, P.v.p, derr);
   if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("prolongator kernels failed", __FILE__, __LINE__);
   k0.release(); k1.release(); start.release(); cnt.release(); pt.release(); rho.release();
   return rc;
@@ -975,7 +1000,7 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (n <= prm->coarse_max) break;
     rc = dg.reserve((size_t)n);
     if (rc != ISPH_SUCCESS) break;
-    hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const int *)L->A.rp.p,
+    hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const rp_t *)L->A.rp.p,
                        (const int *)L->A.ci.p, (const double *)L->A.v.p, dg.p);
     int nagg = 0;
     rc = amg_aggregate(ctx, L, dg.p, prm->theta, tmp, &nagg);
@@ -1024,7 +1049,7 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     G->nc = nc;
     if (rc == ISPH_SUCCESS) rc = G->cinv.reserve((size_t)2 * nc * nc + (size_t)nc + 1);
     if (rc == ISPH_SUCCESS && nc > 0) {
-      hipLaunchKernelGGL(k_dense_from_csr, dim3(nc), dim3(kBlock), 0, ctx->stream, nc, (const int *)L->A.rp.p,
+      hipLaunchKernelGGL(k_dense_from_csr, dim3(nc), dim3(kBlock), 0, ctx->stream, nc, (const rp_t *)L->A.rp.p,
                          (const int *)L->A.ci.p, (const double *)L->A.v.p, G->cinv.p);
       double *colk = G->cinv.p + (size_t)2 * nc * nc;
       for (int k = 0; k < nc; ++k) {
@@ -1075,7 +1100,7 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
   ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
   hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
-  hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const int *)L->R.rp.p,
+  hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const rp_t *)L->R.rp.p,
                      (const int *)L->R.ci.p, (const double *)L->R.v.p, (const double *)L->r.p, Lc->b.p);
   ISPH_CHECK(amg_vcycle(ctx, G, l + 1, Lc->b.p, Lc->x.p));
   ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, L->z.p, nullptr));

@@ -37,7 +37,7 @@ struct isph_ilu {
   isph::DevBuf<unsigned short> sc;  // chunk stream words (16 bit per entry)
   isph::DevBuf<unsigned char> si;   // one byte per chunk: END | need << 1
   isph::DevBuf<unsigned short> sperm;  // [nblocks][2][B] row -> position in the solve order of the L / U direction
-  isph::DevBuf<int> fdst;         // factor entry -> stream index (-1: diagonal)
+  isph::DevBuf<int> fdst;         // factor entry -> stream index RELATIVE to the block's first stream entry (-1: diagonal)
   isph::DevBuf<int> blkinfo;      // [nblocks][4] chunks in the L / U stream, rows the L / U stream completes
   isph::DevBuf<int> llev;         // [n] L-level of every row (level-synchronous factorisation)
   isph::DevBuf<double> dinv;      // [n] 1/d_i
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
             const long long slot = rrp + rd0 + x;
             const int cj = fcol[slot];
             sc[idx] = (unsigned short)((unsigned)spos[cj - blo] | flags);
-            fdst[slot] = (int)idx;
+            fdst[slot] = (int)(idx - base * 64);  // block-relative: the stream as a whole may exceed 2^31 entries
             // Gauss-Seidel mode: the stream values are A's own entries (L part scaled by the column's pivot)
             if (sgs_dinv) sv[idx] = dir == 0 ? sgs_fval[slot] * sgs_dinv[cj] : sgs_fval[slot];
           } else {
@@ -629,7 +629,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
                                                            const int *__restrict__ flen,
                                                            const int *__restrict__ fdiag, const int *__restrict__ fdst,
                                                            const int *__restrict__ llev, double *__restrict__ sv,
-                                                           double *__restrict__ dinv) {
+                                                           double *__restrict__ dinv, const long long *__restrict__ boff,
+                                                           int capf, int slack) {
   extern __shared__ double lds_f[];
   double *diag = lds_f;                                   // [B] 1/d_k of the finished rows
   double *wval = diag + B;                                // [WAVES][W]
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
   __shared__ int s_nlev;
   const int blo = blockIdx.x * B, bhi = min(blo + B, n), m = bhi - blo;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *svb = sv + ilu_base_chunk(boff, blockIdx.x, capf, slack) * 64;  // this block's part of the solve stream
   if (threadIdx.x == 0) s_nlev = 0;
   for (int t = threadIdx.x; t <= B; t += blockDim.x) lcnt[t] = 0;
   for (int t = threadIdx.x; t < WAVES * B; t += blockDim.x) pos[t] = 0;
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
       for (int s = lane; s < len; s += 64) {
         fval[rp + s] = mv[s];
         const int d = fdst[rp + s];
-        if (d >= 0) sv[d] = mv[s];  // triangular-solve stream
+        if (d >= 0) svb[d] = mv[s];  // triangular-solve stream
         mp[mc[s]] = 0;
       }
       if (lane == 0) {
@@ -1001,8 +1003,6 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
     int r = F->sv.reserve((size_t)F->stream_chunks * 64);
     if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
     if (r == ISPH_SUCCESS) r = F->si.reserve((size_t)F->stream_chunks + 64);
-    if (r == ISPH_SUCCESS && (long long)F->stream_chunks * 64 >= 2147483647LL)
-      r = fail("ILU stream exceeds 32-bit indexing", __FILE__, __LINE__);
     return r;
   };
   int rc = F->fcol.reserve(stored);
@@ -1076,11 +1076,11 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       else if (wide)
         hipLaunchKernelGGL((k_ilu_factor<kIluWaves, true>), dim3(F->nblocks), dim3(kIluWaves * 64), lds_f, ctx->stream, S.nrow,
                            block_size, W, F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p,
-                           F->sv.p, F->dinv.p);
+                           F->sv.p, F->dinv.p, F->boff.p, F->capf, F->slack);
       else
         hipLaunchKernelGGL((k_ilu_factor<kIluWaves, false>), dim3(F->nblocks), dim3(kIluWaves * 64), lds_f, ctx->stream, S.nrow,
                            block_size, W, F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p,
-                           F->sv.p, F->dinv.p);
+                           F->sv.p, F->dinv.p, F->boff.p, F->capf, F->slack);
       if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("ILU factor launch failed", __FILE__, __LINE__);
     }
   }

@@ -191,8 +191,9 @@ void isph_ctx_destroy(isph_ctx *c) {
 }  // extern "C"
 
 // CSR (device pointers, any shape) -> sliced-ELL matrix; rows end up column-sorted
-int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const int *dci, const double *dv, long long nnz,
-                        isph_mat **Aout, bool rows_sorted) {
+template <class OFF>
+static int mat_from_device_csr_t(isph_ctx *ctx, int nrow, int ncol, const OFF *drp, const int *dci, const double *dv,
+                                 long long nnz, isph_mat **Aout, bool rows_sorted) {
   isph_mat *A = new isph_mat();
   Sell &S = A->S;
   S.nrow = nrow; S.ncol = ncol; S.nnz = nnz;
@@ -200,11 +201,11 @@ int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const
   int rc = S.slice_off.reserve((size_t)S.nslices + 1);
   if (rc == ISPH_SUCCESS) rc = S.rowlen.reserve((size_t)(nrow > 0 ? nrow : 1));
   if (rc == ISPH_SUCCESS && nrow > 0) {
-    hipLaunchKernelGGL(k_csr_rowlen_slicew, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, drp,
+    hipLaunchKernelGGL(k_csr_rowlen_slicew<OFF>, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, drp,
                        S.rowlen.p, S.slice_off.p);
     rc = sell_finalize_offsets(ctx, S);
     if (rc == ISPH_SUCCESS) {
-      hipLaunchKernelGGL(k_csr_to_sell, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
+      hipLaunchKernelGGL(k_csr_to_sell<OFF>, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
                          S.slice_off.p, S.col.p, S.val.p);
       rc = rows_sorted ? sell_set_wmax(ctx, S) : sell_sort_rows(ctx, S);
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
@@ -214,6 +215,14 @@ int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const
   if (rc != ISPH_SUCCESS) { isph_mat_destroy(A); return rc; }
   *Aout = A;
   return ISPH_SUCCESS;
+}
+int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const int *dci, const double *dv, long long nnz,
+                        isph_mat **Aout, bool rows_sorted) {
+  return mat_from_device_csr_t<int>(ctx, nrow, ncol, drp, dci, dv, nnz, Aout, rows_sorted);
+}
+int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const long long *drp, const int *dci, const double *dv,
+                        long long nnz, isph_mat **Aout, bool rows_sorted) {
+  return mat_from_device_csr_t<long long>(ctx, nrow, ncol, drp, dci, dv, nnz, Aout, rows_sorted);
 }
 
 extern "C" {

@@ -40,12 +40,13 @@ __device__ __forceinline__ long long sell_pos(long long off, int lane, int k) {
 }
 
 // ---- CSR -> SELL ---------------------------------------------------------
-__global__ void k_csr_rowlen_slicew(int nrow, const int *__restrict__ rowptr, int *__restrict__ rowlen,
+template <class OFF>
+__global__ void k_csr_rowlen_slicew(int nrow, const OFF *__restrict__ rowptr, int *__restrict__ rowlen,
                                     long long *__restrict__ slice_cnt) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   int len = 0;
   if (row < nrow) {
-    len = rowptr[row + 1] - rowptr[row];
+    len = (int)(rowptr[row + 1] - rowptr[row]);
     rowlen[row] = len;
   }
   const int w = wave_max_i32(len);
@@ -89,7 +90,8 @@ __global__ void k_exclusive_scan_ll(int n, const long long *in, long long *out) 
   if (threadIdx.x == 0) out[n] = carry;
 }
 
-__global__ void k_csr_to_sell(int nrow, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+template <class OFF>
+__global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const int *__restrict__ colidx,
                               const double *__restrict__ cval, const long long *__restrict__ slice_off,
                               int *__restrict__ scol, double *__restrict__ sval) {
   const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -99,10 +101,11 @@ __global__ void k_csr_to_sell(int nrow, const int *__restrict__ rowptr, const in
   if (slice >= nslices) return;
   const long long off = slice_off[slice];
   const int w = (int)((slice_off[slice + 1] - off) >> 6);
-  int beg = 0, len = 0;
+  OFF beg = 0;
+  int len = 0;
   if (row < nrow) {
     beg = rowptr[row];
-    len = rowptr[row + 1] - beg;
+    len = (int)(rowptr[row + 1] - beg);
   }
   // padding repeats a column the row already reads (always in range, also for rectangular operators)
   const int padcol = len > 0 ? colidx[beg] : 0;

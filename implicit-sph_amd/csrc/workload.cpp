@@ -136,9 +136,10 @@ extern "C" int isph_tgv_count(const isph_tgv_spec *s, int *nlocal, int *nghost, 
   return 0;
 }
 
-extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v, int *tag,
-                                   int *owner_rank, int *owner_index,
-                                   int *neigh_ptr, int *neigh_idx) {
+namespace {
+template <class OFF>
+long long tgv_fill_t(const isph_tgv_spec *s, double *x, double *v, int *tag, int *owner_rank, int *owner_index,
+                     OFF *neigh_ptr, int *neigh_idx) {
   Layout L;
   if (!make_layout(s, L)) return -1;
   const long long next = (long long)L.ext[0] * L.ext[1] * L.ext[2];
@@ -197,8 +198,10 @@ extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v,
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1) {
       neigh_ptr[0] = 0;
-      for (int i = 0; i < L.nlocal; ++i) neigh_ptr[i + 1] = neigh_ptr[i] + rowcnt[(size_t)i];
+      for (int i = 0; i < L.nlocal; ++i) neigh_ptr[i + 1] = neigh_ptr[i] + (OFF)rowcnt[(size_t)i];
+      if (!neigh_idx) break;  // count-only call: the caller sizes neigh_idx from neigh_ptr[nlocal]
     }
+#pragma omp parallel for schedule(static)
     for (int cz = 0; cz < L.n[2]; ++cz)
       for (int cy = 0; cy < L.n[1]; ++cy)
         for (int cx = 0; cx < L.n[0]; ++cx) {
@@ -232,5 +235,16 @@ extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v,
           }
         }
   }
-  return neigh_ptr[L.nlocal];
+  return (long long)neigh_ptr[L.nlocal];
+}
+}  // namespace
+
+extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v, int *tag, int *owner_rank,
+                                   int *owner_index, int *neigh_ptr, int *neigh_idx) {
+  return tgv_fill_t<int>(s, x, v, tag, owner_rank, owner_index, neigh_ptr, neigh_idx);
+}
+
+extern "C" long long isph_tgv_fill64(const isph_tgv_spec *s, double *x, double *v, int *tag, int *owner_rank,
+                                     int *owner_index, long long *neigh_ptr, int *neigh_idx) {
+  return tgv_fill_t<long long>(s, x, v, tag, owner_rank, owner_index, neigh_ptr, neigh_idx);
 }

@@ -29,6 +29,7 @@ def _host():
         _lib = C.CDLL(_build.build_host())
         _lib.isph_tgv_count.restype = C.c_int
         _lib.isph_tgv_fill.restype = C.c_longlong
+        _lib.isph_tgv_fill64.restype = C.c_longlong
     return _lib
 
 
@@ -108,13 +109,17 @@ def make_tgv(spec: TGVSpec):
     tag = np.zeros(nall, dtype=np.int32)
     orank = np.zeros(nall, dtype=np.int32)
     oidx = np.zeros(nall, dtype=np.int32)
-    nptr = np.zeros(nlocal + 1, dtype=np.int32)
-    nidx = np.zeros(cap.value, dtype=np.int32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    nn = lib.isph_tgv_fill(C.byref(cs), p(x), p(v), p(tag), p(orank), p(oidx), p(nptr), p(nidx))
+    # count pass first (64-bit offsets), then a list of exactly that size: the stencil bound `cap` is 3-4x the list
+    nptr = np.zeros(nlocal + 1, dtype=np.int64)
+    nn = lib.isph_tgv_fill64(C.byref(cs), p(x), p(v), p(tag), p(orank), p(oidx), p(nptr), None)
     if nn < 0:
-        raise RuntimeError("isph_tgv_fill failed")
-    nidx = nidx[:nn].copy()
+        raise RuntimeError("isph_tgv_fill64 failed")
+    nidx = np.zeros(max(int(nn), 1), dtype=np.int32)
+    nn = lib.isph_tgv_fill64(C.byref(cs), p(x), p(v), p(tag), p(orank), p(oidx), p(nptr), p(nidx))
+    nidx = nidx[:nn]
+    if nn < 2 ** 31 - 1:
+        nptr = nptr.astype(np.int32)     # LAMMPS-like 32-bit offsets whenever they fit; int64 -> neigh_ptr64
     return dict(spec=spec, dim=spec.dim, nlocal=nlocal, nall=nall, x=x, v=v, tag=tag,
                 type=np.ones(nall, dtype=np.int32), owner_rank=orank, owner_index=oidx,
                 neigh_ptr=nptr, neigh_idx=nidx,

@@ -51,6 +51,11 @@ int isph_tgv_count(const isph_tgv_spec *s, int *nlocal, int *nghost, long long *
 long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v, int *tag,
                         int *owner_rank, int *owner_index,
                         int *neigh_ptr, int *neigh_idx);
+/* Same with 64-bit list offsets (lists beyond 2^31 entries: bcc lattice + Quintic cut 3h at 4 M particles).
+ * neigh_idx == NULL: only neigh_ptr is filled (count pass), so the caller can size neigh_idx exactly. */
+long long isph_tgv_fill64(const isph_tgv_spec *s, double *x, double *v, int *tag,
+                          int *owner_rank, int *owner_index,
+                          long long *neigh_ptr, int *neigh_idx);
 
 #ifdef __cplusplus
 }
