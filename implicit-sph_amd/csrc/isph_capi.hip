@@ -587,12 +587,15 @@ int isph_prec_amg_export(isph_ctx *ctx, const isph_prec *M, int level, int what,
   ISPH_REQUIRE(ctx && M && M->type == 3 && M->amg && rowptr && colidx && val, "not an AMG preconditioner");
   ISPH_REQUIRE(level >= 0 && level < M->amg->nlev && (what == 0 || (what == 1 && level < M->amg->nlev - 1)), "level out of range");
   const DCsr &C = what == 0 ? M->amg->L[(size_t)level]->A : M->amg->L[(size_t)level]->P;
+  ISPH_REQUIRE(C.nnz < 2147483647LL, "level too large for the 32-bit test export");
   std::vector<int> ci((size_t)C.nnz);
   std::vector<double> v((size_t)C.nnz);
-  ISPH_CHECK_HIP(hipMemcpyAsync(rowptr, C.rp.p, sizeof(int) * ((size_t)C.n + 1), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<long long> rp64((size_t)C.n + 1);
+  ISPH_CHECK_HIP(hipMemcpyAsync(rp64.data(), C.rp.p, sizeof(long long) * ((size_t)C.n + 1), hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipMemcpyAsync(ci.data(), C.ci.p, sizeof(int) * (size_t)C.nnz, hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipMemcpyAsync(v.data(), C.v.p, sizeof(double) * (size_t)C.nnz, hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i <= C.n; ++i) rowptr[i] = (int)rp64[(size_t)i];
   std::vector<int> perm;
   for (int i = 0; i < C.n; ++i) {  // coarse rows come out of the SpGEMM in table order: sort for the caller
     const int b = rowptr[i], e = rowptr[i + 1];
