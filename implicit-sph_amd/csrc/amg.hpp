@@ -324,13 +324,14 @@ __global__ __launch_bounds__(256) void k_agg_pass1(int n, const rp_t *__restrict
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   if ((key[i] >> 62) == AMG_ROOT) { if (lane == 0) a1[i] = rootid[i]; return; }
-  int best = 0x7fffffff;
-  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+  int best = 0x7fffffff;  // position within the row
+  const rp_t lo = rp[i];
+  for (rp_t p = lo + lane; p < rp[i + 1]; p += 64) {
     const int j = sc[p];
-    if (j >= 0 && (key[j] >> 62) == AMG_ROOT && p < best) best = p;
+    if (j >= 0 && (key[j] >> 62) == AMG_ROOT && (int)(p - lo) < best) best = (int)(p - lo);
   }
   best = wave_min_i32(best);
-  if (lane == 0) a1[i] = best == 0x7fffffff ? -1 : rootid[sc[best]];
+  if (lane == 0) a1[i] = best == 0x7fffffff ? -1 : rootid[sc[lo + best]];
 }
 
 // pass 2: the rest joins the pass-1 neighbour it is most strongly coupled to (ties: first in the row)
@@ -343,19 +344,20 @@ __global__ __launch_bounds__(256) void k_agg_pass2(int n, const rp_t *__restrict
   double bw = -1.0;
   int bp = 0x7fffffff;
   bool strong = false;
-  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+  const rp_t lo = rp[i];
+  for (rp_t p = lo + lane; p < rp[i + 1]; p += 64) {
     const int j = sc[p];
     if (j < 0) continue;
     strong = true;
     if (a1[j] < 0) continue;
     const double w = fabs(v[p]);
-    if (w > bw) { bw = w; bp = p; }
+    if (w > bw) { bw = w; bp = (int)(p - lo); }
   }
   const double wmax = wave_max_f64(bw);
   const int pbest = wave_min_i32((bw == wmax && wmax >= 0.0) ? bp : 0x7fffffff);
   const bool any_strong = __ballot(strong) != 0;
   if (lane == 0) {
-    const int a = pbest == 0x7fffffff ? -1 : a1[sc[pbest]];
+    const int a = pbest == 0x7fffffff ? -1 : a1[sc[lo + pbest]];
     agg[i] = a;
     leftover[i] = (a < 0 && any_strong) ? 1 : 0;  // unsymmetric patterns only: becomes a singleton (pass 3)
   }
@@ -1033,6 +1035,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     G->L.push_back(Lc);
     ++G->nlev;
   }
+  // the fine-level CSR copy only serves the set-up (the cycle runs on the SELL matrix): 12 B per entry go back to the
+  // pool before the smoother is built; isph_prec_amg_export rebuilds it on demand
+  if (G->nlev > 1) { L0->A.ci.release(); L0->A.v.release(); L0->A.rp.release(); }
   // smoothers, work vectors, coarse solve
   G->coarse_smooth = G->singular || G->L.back()->A.n > kAmgDenseMax;
   for (int l = 0; l < G->nlev && rc == ISPH_SUCCESS; ++l) {

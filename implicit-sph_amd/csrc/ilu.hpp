@@ -1066,7 +1066,9 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
       }
     }
     if (rc == ISPH_SUCCESS && sgs) {
-      // nothing left to do: k_ilu_schedule filled the stream
+      // nothing left to do: k_ilu_schedule filled the stream; the row-major copy is not read again (no export of a
+      // smoother) and is 16 B per stored entry -- 48 GB on the 4 M x 749 operator of BASELINE configs[4]
+      F->fcol.release(); F->fval.release(); F->fdst.release();
     } else if (rc == ISPH_SUCCESS) {
       const bool wide = F->wmax > 128;  // rows this long have U parts beyond one wave
       const void *fk = wide ? reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, true>)

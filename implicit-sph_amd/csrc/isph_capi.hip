@@ -586,8 +586,16 @@ int isph_prec_amg_info(isph_ctx *ctx, const isph_prec *M, int level, long long i
 int isph_prec_amg_export(isph_ctx *ctx, const isph_prec *M, int level, int what, int *rowptr, int *colidx, double *val) {
   ISPH_REQUIRE(ctx && M && M->type == 3 && M->amg && rowptr && colidx && val, "not an AMG preconditioner");
   ISPH_REQUIRE(level >= 0 && level < M->amg->nlev && (what == 0 || (what == 1 && level < M->amg->nlev - 1)), "level out of range");
-  const DCsr &C = what == 0 ? M->amg->L[(size_t)level]->A : M->amg->L[(size_t)level]->P;
-  ISPH_REQUIRE(C.nnz < 2147483647LL, "level too large for the 32-bit test export");
+  const DCsr &Ck = what == 0 ? M->amg->L[(size_t)level]->A : M->amg->L[(size_t)level]->P;
+  ISPH_REQUIRE(Ck.nnz < 2147483647LL, "level too large for the 32-bit test export");
+  DCsr fine;  // the fine-level copy is dropped after the set-up: rebuilt from the SELL matrix here
+  DevBuf<char> tmp;
+  if (!Ck.ci.p && Ck.nnz > 0) {
+    ISPH_REQUIRE(level == 0 && what == 0, "level operator not resident");
+    ISPH_CHECK(amg_csr_from_sell(ctx, M->amg->L[0]->Am->S, fine, tmp));
+  }
+  struct Drop { DCsr &c; DevBuf<char> &t; ~Drop() { c.release(); t.release(); } } drop{fine, tmp};
+  const DCsr &C = fine.ci.p ? fine : Ck;
   std::vector<int> ci((size_t)C.nnz);
   std::vector<double> v((size_t)C.nnz);
   std::vector<long long> rp64((size_t)C.n + 1);

@@ -1,7 +1,8 @@
 """-m gpu: BASELINE configs[4] -- pore-scale flow through a bead pack in a cylinder (sph-script/pore-scale-flow-3d.lmp,
 compute_isph_cylinder_porous.cpp:195-224): bcc lattice, Quintic kernel cut 3h (749 entries per row), MorrisHolmes
 boundary, NotSingular Poisson, SA-AMG preconditioner.  Oracle parity on a 43 904-particle cylinder, size-independent
-properties on 1.02 M particles (767 M matrix entries) and on 2.96 M particles (2.22e9 entries: 64-bit offsets)."""
+properties on 1.02 M particles (767 M matrix entries), on 2.96 M particles (2.22e9 entries: 64-bit offsets) and at the
+configuration's own size, 4.0 M particles (3.0e9 entries, 36 GB of sliced-ELL on one GPU)."""
 import numpy as np
 import pytest
 import scipy.sparse as sps
@@ -51,12 +52,12 @@ def test_porous_small_matches_oracle(gpu_ctx):
     assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
 
 
-@pytest.mark.parametrize("nc", [80, 114])
+@pytest.mark.parametrize("nc", [80, 114, 126])
 def test_porous_config4_properties_at_size(gpu_ctx, nc):
     """nc = 80: 2 x 80^3 = 1 024 000 particles, 749 entries per row (767 M entries, 9 GB of sliced-ELL).
     nc = 114: 2 x 114^3 = 2 963 088 particles, 2.22e9 matrix entries -- beyond 2^31: the neighbour list goes in through
-    isph_particles::neigh_ptr64 and the AMG set-up / Gauss-Seidel stream run on 64-bit offsets (the configuration's
-    4 M particles = 3.0e9 entries use the same code; they need ~230 GB for matrix + CSR copy + smoother stream).
+    isph_particles::neigh_ptr64 and the AMG set-up / Gauss-Seidel stream run on 64-bit offsets.
+    nc = 126: 2 x 126^3 = 4 000 752 particles, 3.0e9 entries -- BASELINE configs[4] at its own size on ONE GPU.
     Assembled on the device from torch-resident arrays and solved with FGMRES + SA-AMG.  Properties: row length of the
     bcc/Quintic stencil, solid rows are identity rows, the solve converges, residual <= 2e-8 re-computed with an
     independent SpMV, zero pressure on the solid rows."""
@@ -65,7 +66,8 @@ def test_porous_config4_properties_at_size(gpu_ctx, nc):
     p = workload.make_porous_cylinder(nc, nbeads=40, rbead_cells=6.0)
     n, nall = p["nlocal"], p["nall"]
     assert n == 2 * nc ** 3
-    assert (p["neigh_ptr"].dtype == np.int64) == (nc == 114)          # 64-bit list offsets exactly when needed
+    assert (p["neigh_ptr"].dtype == np.int64) == (nc >= 114)          # 64-bit list offsets exactly when needed
+    torch.cuda.empty_cache()
     colmap_h = workload.single_rank_colmap(p)
     dp = dict(p)
     for k in ("x", "type", "neigh_ptr", "neigh_idx"):
@@ -85,6 +87,9 @@ def test_porous_config4_properties_at_size(gpu_ctx, nc):
                                 kernel="quintic", kinds=p["kinds"], pnd=pnd)
     im = A.info()
     assert im["nrow"] == n and 745 < im["nnz"] / n <= 749
+    del dp["neigh_idx"], dp["neigh_ptr"]                       # the list (12 GB at 4 M particles) is not needed any more
+    p.pop("neigh_idx")
+    torch.cuda.empty_cache()
     solid = dp["type"][:n] >= 3
     e = torch.zeros(n, dtype=torch.float64, device=dev)
     e[solid] = 1.0
@@ -99,3 +104,5 @@ def test_porous_config4_properties_at_size(gpu_ctx, nc):
     r = b - A.spmv(xs)
     assert float(r.norm() / b.norm()) < 2e-8
     assert float(xs[solid].abs().max()) <= 1e-12 * float(xs.abs().max())
+    del M, A
+    torch.cuda.empty_cache()
