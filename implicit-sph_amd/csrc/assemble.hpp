@@ -211,7 +211,7 @@ __device__ __forceinline__ double mirror_coeff(const double *__restrict__ pnd, c
 // FunctorOuterVolume: V_i = 1/(W(0) + sum_j W(r_ij))
 __global__ void k_volumes(AsmTables T, int nlocal, const double *__restrict__ x, const int *__restrict__ type,
                           const int *__restrict__ nptr, const int *__restrict__ nidx, double *__restrict__ vfrac) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
   const int it = type[i], nt1 = T.ntypes + 1;
   double w = kernel_val(T.kernel, 0.0, T.hinv[it * nt1 + it], T.knorm[it * nt1 + it]);
@@ -234,7 +234,7 @@ __global__ void k_gradient_correction(AsmTables T, int nlocal, const double *__r
                                       const int *__restrict__ type, const int *__restrict__ nptr,
                                       const int *__restrict__ nidx, const double *__restrict__ vfrac,
                                       double *__restrict__ Gc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
   const int dim = T.dim, nt1 = T.ntypes + 1, it = type[i];
   double G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -285,7 +285,7 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
                                        const int *__restrict__ type, const int *__restrict__ nptr,
                                        const int *__restrict__ nidx, const double *__restrict__ vfrac,
                                        const double *__restrict__ Gc, double *__restrict__ Lc, int *__restrict__ nfail) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
   const int dim = T.dim, d2 = dim * dim, dL = dim * (dim + 1) / 2, nt1 = T.ntypes + 1, it = type[i];
   double A[27], L[36], G[9];
@@ -385,7 +385,7 @@ __global__ void k_reciprocal(int n, const double *__restrict__ a, double *__rest
 // FunctorOuterGraph row lengths: in-cut neighbours + self
 __global__ void k_asm_count(AsmTables T, int nlocal, const double *__restrict__ x, const int *__restrict__ type,
                             const int *__restrict__ nptr, const int *__restrict__ nidx, int *__restrict__ rowlen) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
   const int it = type[i], nt1 = T.ntypes + 1;
   int cnt = 1;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
                                                         const long long *__restrict__ slice_off,
                                                         int *__restrict__ scol, double *__restrict__ sval,
                                                         double *__restrict__ b) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   if (i >= a.nlocal) {
     // pad the tail slice: rows >= nlocal of the last slice keep zeros
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
                                                           const long long *__restrict__ slice_off,
                                                           int *__restrict__ scol, double *__restrict__ sval,
                                                           double *__restrict__ b) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   if (i >= a.nlocal) {
     const int nslices = (a.nlocal + kSlice - 1) / kSlice;
@@ -1055,7 +1055,7 @@ inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac
   double *dout = vfrac_out;
   if (rc == ISPH_SUCCESS && !on_device) { rc = out.reserve((size_t)(P->nlocal > 0 ? P->nlocal : 1)); dout = out.p; }
   if (rc == ISPH_SUCCESS && P->nlocal > 0) {
-    hipLaunchKernelGGL(k_volumes, dim3((P->nlocal + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, T, P->nlocal, dx,
+    hipLaunchKernelGGL(k_volumes, dim3(xcd_grid((P->nlocal + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, T, P->nlocal, dx,
                        dt, dp, di, dout);
     if (!on_device &&
         hipMemcpyAsync(vfrac_out, dout, sizeof(double) * (size_t)P->nlocal, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
@@ -1133,7 +1133,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   if (rc == ISPH_SUCCESS && !on_device) { rc = bdev.reserve((size_t)(n > 0 ? n : 1)); db = bdev.p; }
   if (rc == ISPH_SUCCESS && n > 0) {
     const int grid = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_asm_count, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
+    hipLaunchKernelGGL(k_asm_count, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
     hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
     rc = sell_finalize_offsets(ctx, M);
     if (rc == ISPH_SUCCESS) {
@@ -1173,9 +1173,9 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
     if (rc == ISPH_SUCCESS) {
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
       if (T.dim == 3 && a.antisym)
-        hipLaunchKernelGGL((k_asm_poisson<3, 1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+        hipLaunchKernelGGL((k_asm_poisson<3, 1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
       else
-        hipLaunchKernelGGL((k_asm_poisson<0, -1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+        hipLaunchKernelGGL((k_asm_poisson<0, -1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
       if (n <= 32768) {  // tiny boxes may see the same tag twice in a row
         rc = newlen.reserve((size_t)n);
         if (rc == ISPH_SUCCESS) {
@@ -1274,7 +1274,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   if (rc == ISPH_SUCCESS && n > 0) {
     const int grid = (n + kBlock - 1) / kBlock;
     if (!rhs_only) {
-      hipLaunchKernelGGL(k_asm_count, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
+      hipLaunchKernelGGL(k_asm_count, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
       hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
       rc = sell_finalize_offsets(ctx, M);
     }
@@ -1296,9 +1296,9 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
         int *mcol = rhs_only ? (int *)nullptr : M.col.p;
         double *mval = rhs_only ? (double *)nullptr : M.val.p;
         if (T.dim == 3 && antisym)
-          hipLaunchKernelGGL((k_asm_helmholtz<3, 1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
+          hipLaunchKernelGGL((k_asm_helmholtz<3, 1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
         else
-          hipLaunchKernelGGL((k_asm_helmholtz<0, -1>), dim3(gridp), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
+          hipLaunchKernelGGL((k_asm_helmholtz<0, -1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
       }
       if (!rhs_only && n <= 32768) {
         rc = newlen.reserve((size_t)n);
@@ -1367,8 +1367,8 @@ inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *G
   if (rc == ISPH_SUCCESS && n > 0) {
     const int grid = (n + kBlock - 1) / kBlock;
     if (hipMemsetAsync(nf.p, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
-    hipLaunchKernelGGL(k_gradient_correction, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf, dG);
-    hipLaunchKernelGGL(k_laplacian_correction, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf,
+    hipLaunchKernelGGL(k_gradient_correction, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf, dG);
+    hipLaunchKernelGGL(k_laplacian_correction, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf,
                        (const double *)dG, dLc, nf.p);
     if (!on_device) {
       if (hipMemcpyAsync(Gc_out, dG, sizeof(double) * (size_t)n * d2, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

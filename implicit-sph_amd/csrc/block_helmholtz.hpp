@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_block_helmholtz(AsmTables T, Blo
                                                                 const long long *__restrict__ slice_off,
                                                                 double *__restrict__ b) {
   const HelmholtzArgs &a = A.h;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int dim = T.dim, d2 = dim * dim;
   if (i >= a.nlocal) {
@@ -339,7 +339,7 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
   if (rc == ISPH_SUCCESS && n > 0) {
     Sell &M = A0->S;
     const int grid = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_asm_count, dim3(grid), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
+    hipLaunchKernelGGL(k_asm_count, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
     hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
     rc = sell_finalize_offsets(ctx, M);
     for (int q = 1; q < d2 && rc == ISPH_SUCCESS; ++q) {
@@ -366,7 +366,7 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
       A.beta = beta;
       for (int k = 0; k < 3; ++k) a.g[k] = gvec ? gvec[k] : 0.0;
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
-      hipLaunchKernelGGL(k_asm_block_helmholtz, dim3(gridp), dim3(kBlock), 0, ctx->stream, T, A, M.slice_off.p, db);
+      hipLaunchKernelGGL(k_asm_block_helmholtz, dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, A, M.slice_off.p, db);
       for (int q = 0; q < d2 && rc == ISPH_SUCCESS; ++q) {
         if (!blk[q]) continue;
         Sell &B = blk[q]->S;

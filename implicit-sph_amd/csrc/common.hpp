@@ -203,4 +203,11 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks_padded) {
   return (b % kXcd) * per + (b / kXcd);
 }
 
+// row kernels of the assembly: launched on xcd_grid(blocks) workgroups, block index through xcd_block().  The rows an
+// XCD works on at one time are then neighbours in space, and the neighbour records they gather (72 B per particle,
+// +-2 lattice planes around the active rows) fit its 4 MB L2; dealt round-robin the eight XCDs each sweep the whole
+// domain at once and every gather misses.
+__device__ __forceinline__ int xcd_block() { return xcd_remap((int)blockIdx.x, (int)gridDim.x); }
+inline int xcd_grid(int blocks) { return (blocks + kXcd - 1) / kXcd * kXcd; }
+
 }  // namespace isph

@@ -29,7 +29,7 @@ struct OpArgs {
 template <int DIMT, int FAM>  // 0 / -1: dimension and family read at run time; 3 / 1: 3-D AntiSymmetric (G = I) folded
 __global__ __launch_bounds__(kBlock) void k_gradient(AsmTables T, OpArgs a, const double *__restrict__ f,
                                                      double *__restrict__ grad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= a.nlocal) return;
   const int dim = DIMT ? DIMT : T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
   const bool antisym = FAM < 0 ? (a.antisym != 0) : (FAM != 0);
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_gradient(AsmTables T, OpArgs a, cons
 template <int DIMT, int FAM>  // 0 / -1: dimension and family read at run time; 3 / 1: 3-D AntiSymmetric (G = I) folded
 __global__ __launch_bounds__(kBlock) void k_divergence(AsmTables T, OpArgs a, const double *__restrict__ f,
                                                        double *__restrict__ div) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= a.nlocal) return;
   const int dim = DIMT ? DIMT : T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
   const bool antisym = FAM < 0 ? (a.antisym != 0) : (FAM != 0);
@@ -164,7 +164,7 @@ __global__ void k_max_fluid_speed(int nlocal, int dim, const int *__restrict__ t
 __global__ __launch_bounds__(kBlock) void k_compute_shift(AsmTables T, OpArgs a, double alpha0,
                                                           const double *__restrict__ scale, double shiftcutsq,
                                                           double nonfluidweight, double *__restrict__ dr) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= a.nlocal) return;
   const int dim = T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
   double d[3] = {0, 0, 0};
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_shift(AsmTables T, OpArgs a, c
                                                         const double *__restrict__ v, const double *__restrict__ p,
                                                         double *__restrict__ xn, double *__restrict__ vn,
                                                         double *__restrict__ pn) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= a.nlocal) return;
   const int dim = T.dim, nt1 = T.ntypes + 1, it = a.type[i], ikind = T.kind[it];
   double gp[3] = {0, 0, 0}, gv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -325,10 +325,10 @@ inline int op_apply(isph_ctx *ctx, const isph_particles *P, int mode, int antisy
     st.a.alpha = alpha; st.a.use_filter = use_filter; st.a.filt_i = filt_i; st.a.filt_j = filt_j;
     const int grid = (n + kBlock - 1) / kBlock;
     const bool fast = st.T.dim == 3 && st.a.antisym;
-    if (mode == 0 && fast) hipLaunchKernelGGL((k_gradient<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
-    else if (mode == 0) hipLaunchKernelGGL((k_gradient<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
-    else if (fast) hipLaunchKernelGGL((k_divergence<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
-    else hipLaunchKernelGGL((k_divergence<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    if (mode == 0 && fast) hipLaunchKernelGGL((k_gradient<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    else if (mode == 0) hipLaunchKernelGGL((k_gradient<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    else if (fast) hipLaunchKernelGGL((k_divergence<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    else hipLaunchKernelGGL((k_divergence<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
     if (!on_device && hipMemcpyAsync(out, dout, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = fail("copy failed", __FILE__, __LINE__);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
@@ -377,9 +377,9 @@ inline int correct_velocity_pressure(isph_ctx *ctx, const isph_particles *P, int
     st.a.alpha = 1.0; st.a.use_filter = 1; st.a.filt_i = KIND_FLUID; st.a.filt_j = KIND_FLUID;
     const int grid = (n + kBlock - 1) / kBlock;
     if (st.T.dim == 3 && st.a.antisym)
-      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
+      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
     else
-      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
+      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
     hipLaunchKernelGGL(k_correct_velocity, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, dt, st.a.type, st.T.kind,
                        drho, (const double *)grad.p, iv.dev);
     hipLaunchKernelGGL(k_correct_pressure, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall,
@@ -411,9 +411,9 @@ inline int advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, do
     st.a.alpha = 1.0; st.a.use_filter = 1; st.a.filt_i = KIND_FLUID; st.a.filt_j = KIND_FLUID;
     const int grid = (n + kBlock - 1) / kBlock;
     if (st.T.dim == 3 && st.a.antisym)
-      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
+      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
     else
-      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
+      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
     hipLaunchKernelGGL(k_advance_begin, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, dt, st.a.type, st.T.kind,
                        (const double *)grad.p, dv, dvn, dout);
     if (!on_device && hipMemcpyAsync(dp_out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
@@ -459,7 +459,7 @@ inline int compute_shift(isph_ctx *ctx, const isph_particles *P, double alpha, d
   double *dout = dr;
   if (rc == ISPH_SUCCESS && !on_device) { rc = st.out.reserve((size_t)(n > 0 ? n : 1) * 3); dout = st.out.p; }
   if (rc == ISPH_SUCCESS && n > 0) {
-    hipLaunchKernelGGL(k_compute_shift, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, st.T, st.a, alpha,
+    hipLaunchKernelGGL(k_compute_shift, dim3(xcd_grid((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, st.T, st.a, alpha,
                        (const double *)nullptr, shiftcut * shiftcut, nonfluidweight, dout);
     if (!on_device && hipMemcpyAsync(dr, dout, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = fail("copy failed", __FILE__, __LINE__);
@@ -507,7 +507,7 @@ inline int shift_apply(isph_ctx *ctx, const isph_particles *P, int antisym, cons
       if (ctx->comm && ncclAllReduce(scal.p, scal.p, 1, ncclDouble, ncclMax, ctx->comm, ctx->stream) != ncclSuccess)
         rc = fail("ncclAllReduce(max) failed", __FILE__, __LINE__);
       if (n > 0)
-        hipLaunchKernelGGL(k_compute_shift, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, shift * dt,
+        hipLaunchKernelGGL(k_compute_shift, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, shift * dt,
                            (const double *)scal.p, shiftcut * shiftcut, nonfluidweight, sdr.p);
       ddr = sdr.p;
       if (vmax_out && hipMemcpyAsync(&vmax, scal.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
@@ -515,7 +515,7 @@ inline int shift_apply(isph_ctx *ctx, const isph_particles *P, int antisym, cons
     }
   }
   if (rc == ISPH_SUCCESS && n > 0) {
-    hipLaunchKernelGGL(k_apply_shift, dim3(grid), dim3(kBlock), 0, ctx->stream, st.T, st.a, dfix, ddr,
+    hipLaunchKernelGGL(k_apply_shift, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, dfix, ddr,
                        (const double *)ix.dev, (const double *)iv.dev, (const double *)ip.dev, xn.p, vn.p, pn.p);
     hipLaunchKernelGGL(k_shift_commit, dim3(grid), dim3(kBlock), 0, ctx->stream, n, (const double *)xn.p,
                        (const double *)vn.p, (const double *)pn.p, ix.dev, iv.dev, ip.dev);

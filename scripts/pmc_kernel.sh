@@ -8,11 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_k_$T -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc_k_$T.log 2>&1 || { tail -5 $OUT/pmc_k_$T.log; exit 1; }
 F=$(ls -t $OUT/pmc_k_$T/*/*counter_collection.csv | head -1)
 python3 - "$F" "$K" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 acc = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(sys.argv[1])):
-    if sys.argv[2] in r["Kernel_Name"]:
-        a = acc[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
-for k, (n, v) in sorted(acc.items()):
-    print("%-28s launches=%4d avg=%16.1f" % (k, n, v / n))
+    if re.search(sys.argv[2], r["Kernel_Name"]):
+        a = acc[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])]; a[0] += 1; a[1] += float(r["Counter_Value"])
+for (kn, c), (n, v) in sorted(acc.items()):
+    print("%-40s %-20s launches=%4d avg=%16.1f" % (kn, c, n, v / n))
 PY
