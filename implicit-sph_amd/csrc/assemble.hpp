@@ -61,29 +61,43 @@ __global__ void k_numneigh(int n, const OFF *__restrict__ nptr, int *__restrict_
 }
 
 // Orders every row's neighbour ids by their matrix column (stable: equal columns -- periodic images -- keep their
-// list order).  One wave per row, keys in LDS, rank by counting.
+// list order).  One wave per row.  The keys (column << 10 | list position: unique, so ranks need no tie rule) go to
+// LDS; a row that is already in order -- most rows of a list built cell by cell -- is copied through, any other row
+// is ranked by counting, two keys per 16-B LDS broadcast read.
 constexpr int kNeighSortCap = 1024;
 template <class OFF>
 __global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restrict__ nptr, const int *__restrict__ nidx,
                                                        const int *__restrict__ colmap, int *__restrict__ out) {
-  __shared__ int keys[kBlock / 64][kNeighSortCap];
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[kBlock / 64][kNeighSortCap + 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kBlock / 64) + wave;
   if (row >= n) return;
   const OFF jb = nptr[row];
   const int len = (int)(nptr[row + 1] - jb);
-  int *kw = keys[wave];
-  for (int k = lane; k < len; k += 64) kw[k] = colmap[nidx[jb + k]];
+  unsigned long long *kw = keys[wave];
+  for (int k = lane; k < len; k += 64) kw[k] = ((unsigned long long)(unsigned)colmap[nidx[jb + k]] << 10) | (unsigned)k;
+  if (lane < 2) kw[len + lane] = ~0ull;  // pad: the pair reads below may run one key past the end
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (int k = lane; k < len; k += 64) {
-    const int c = kw[k];
-    int rank = 0;
-    for (int q = 0; q < len; ++q) {
-      const int cq = kw[q];
-      rank += (cq < c) || (cq == c && q < k);
+  bool disorder = false;
+  for (int k = lane; k + 1 < len; k += 64) disorder |= kw[k + 1] < kw[k];
+  if (__ballot(disorder) == 0) {
+    for (int k = lane; k < len; k += 64) out[jb + k] = nidx[jb + k];
+    return;
+  }
+  const ulonglong2 *kw2 = reinterpret_cast<const ulonglong2 *>(kw);
+  const int npair = (len + 1) >> 1;
+  for (int k0 = 0; k0 < len; k0 += 128) {  // two own keys per lane and sweep: the LDS reads are shared
+    const int ka = k0 + lane, kb = k0 + 64 + lane;
+    const unsigned long long ca = ka < len ? kw[ka] : 0ull, cb = kb < len ? kw[kb] : 0ull;
+    int ra = 0, rb = 0;
+    for (int q = 0; q < npair; ++q) {
+      const ulonglong2 t = kw2[q];
+      ra += (t.x < ca) + (t.y < ca);
+      rb += (t.x < cb) + (t.y < cb);
     }
-    out[jb + rank] = nidx[jb + k];
+    if (ka < len) out[jb + ra] = nidx[jb + ka];
+    if (kb < len) out[jb + rb] = nidx[jb + kb];
   }
 }
 

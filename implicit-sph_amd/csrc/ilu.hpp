@@ -112,27 +112,27 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
     fdiag[i] = dg;
     if (dg < 0) atomicOr(err, 1);  // structurally missing diagonal
   }
-  // copy: a lane walks its own row in A (coalesced across the wave), but the row-major destination is written by
-  // the wave together -- kExtChunk entries of every row are staged in LDS, then kExtChunk consecutive lanes write
-  // one row's piece (64-B / 32-B segments instead of 64 scattered 8-B stores per instruction)
+  // copy: the wave walks its 64 rows of A column slot by column slot (every load is one coalesced wave access of the
+  // sliced-ELL image); a lane keeps the in-block entries of its row in an LDS buffer of kExtChunk entries, and as soon
+  // as one lane's buffer is full the wave writes all buffers out together -- kExtChunk consecutive lanes write one
+  // row's piece of the row-major destination (64-B / 32-B segments instead of 64 scattered 8-B stores).
   const int wv = t >> 6, ln = t & 63;
   int *scnt = &stage_cnt[wv][0];
   long long *sstart = &stage_start[wv][0];
   sstart[ln] = start;
-  int kpos = 0, done = 0;
-  const int rounds = (wave_max_i32(cnt) + kExtChunk - 1) / kExtChunk;
-  for (int r = 0; r < rounds; ++r) {
-    int got = 0;
-    while (got < kExtChunk && kpos < len) {
-      const long long p = sell_pos(off, lane, kpos);
+  int got = 0;
+  const int lenmax = wave_max_i32(len);
+  for (int k = 0; k < lenmax; ++k) {
+    if (k < len) {
+      const long long p = sell_pos(off, lane, k);
       const int c = scol[p];
       if (c >= blo && c < bhi) {
         stage_col[wv][ln][got] = c;
         stage_val[wv][ln][got] = sval[p];
         ++got;
       }
-      ++kpos;
     }
+    if (__ballot(got == kExtChunk) == 0 && k + 1 < lenmax) continue;  // wave-uniform
     scnt[ln] = got;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -140,16 +140,16 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
     for (int it = 0; it < kExtChunk; ++it) {
       const int e = ln + 64 * it, row = e / kExtChunk, slot = e % kExtChunk;
       if (slot < scnt[row]) {
-        const long long q = sstart[row] + (long long)r * kExtChunk + slot;
+        const long long q = sstart[row] + slot;
         fcol[q] = stage_col[wv][row][slot];
         fval[q] = stage_val[wv][row][slot];
       }
     }
-    done += got;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    sstart[ln] += got;  // read again only behind the next flush's barrier
+    got = 0;
   }
-  (void)done;
 }
 
 // ---------------------------------------------------------------------------

@@ -568,6 +568,25 @@ int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params
   int rc = nullvec ? stage_in(ctx, nullvec, (size_t)M->n, on_device, tn, &dn) : ISPH_SUCCESS;
   if (rc == ISPH_SUCCESS) rc = amg_create(ctx, A, prm, dn, &M->amg);
   tn.release();
+  if (ctx->comm && ctx->nranks > 1) {
+    // The hierarchy is built per rank (Uncoupled); only the fine level exchanges halos inside the cycle, and how often
+    // depends on whether a rank coarsened at all and on its coarse solver.  Ranks that disagree would wait for each
+    // other forever: agree here, once per set-up, and fail on every rank together instead.
+    double h[3] = {rc == ISPH_SUCCESS ? 1.0 : 0.0, (rc == ISPH_SUCCESS && M->amg->nlev > 1) ? 1.0 : 0.0,
+                   (rc == ISPH_SUCCESS && M->amg->coarse_smooth) ? 1.0 : 0.0};
+    DevBuf<double> d;
+    int rc2 = d.reserve(3);
+    if (rc2 == ISPH_SUCCESS && hipMemcpyAsync(d.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc2 = ISPH_FAILURE;
+    if (rc2 == ISPH_SUCCESS) rc2 = allreduce_inplace(ctx, d.p, 3);
+    if (rc2 == ISPH_SUCCESS && (hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                                hipStreamSynchronize(ctx->stream) != hipSuccess)) rc2 = ISPH_FAILURE;
+    d.release();
+    const double nr = (double)ctx->nranks;
+    if (rc2 != ISPH_SUCCESS) rc = fail("AMG: set-up consensus between the ranks failed", __FILE__, __LINE__);
+    else if (h[0] != nr) rc = rc != ISPH_SUCCESS ? rc : fail("AMG: set-up failed on another rank", __FILE__, __LINE__);
+    else if ((h[1] != 0.0 && h[1] != nr) || (h[1] == 0.0 && h[2] != 0.0 && h[2] != nr))
+      rc = fail("AMG: the ranks built hierarchies of different depth; their fine-level halo exchanges would not match", __FILE__, __LINE__);
+  }
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
   *Mout = M;
   return ISPH_SUCCESS;
