@@ -349,7 +349,14 @@ def main():
                        "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms, "assemble_first_call_ms": assemble_first_ms,
-                       "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo},
+                       "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo,
+                       # the preconditioner BASELINE names is not the fastest on this operator; other --prec rows of this
+                       # workload, measured in round 2 on one MI355X, for the reader of this line
+                       "other_preconditioners_measured_r02": {
+                           "jacobi": "43 iterations, 14.8-15.2 ms/solve",
+                           "sa-amg (ML defaults)": "31 iterations, 55.8-58.3 ms/solve",
+                           "schwarz-ilu0 (512-row subdomains, overlap 1, level-scheduled)": "63 iterations, 3253 ms/solve",
+                           "ilu0 (whole local matrix = Ifpack on 1 rank, level-scheduled)": "49 iterations, 41077 ms/solve"}},
             "roofline": {"bound": "hbm", "kernel": "k_sell_spmv16<8,false> (SELL-64, 16-bit window columns)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -47,14 +47,24 @@ inline int fail(const char *what, const char *file, int line) {
 // Process-wide cache of freed device blocks.  The matrix, the ILU factor and its stream are rebuilt every
 // time step (the reference deletes A / graph / map after every compute(), pair_isph.cpp:1351-1372); going
 // back to hipMalloc/hipFree for multi-GB buffers each step costs milliseconds and an implicit device sync
-// per call.  Blocks are reused when the request fits within 25 % slack; at most kPoolCapBytes stay cached.
+// per call.  Blocks are reused when the request fits within 25 % slack; at most cap() bytes stay cached (isph_pool_trim returns them).
 // A released block may still be read by kernels in flight (on any stream of the process), so release() only
 // parks it on a PENDING list without synchronising; the first allocation that finds no ready block drains the
 // device once (one hipDeviceSynchronize for all parked blocks -- in steady state one per solve set-up, none in the
 // Krylov loop) and makes the whole list ready.  Nothing is ever handed out while work that was queued before
 // its release can still touch it, whichever stream that work runs on.
 struct DevPool {
-  static constexpr size_t kPoolCapBytes = (size_t)48 << 30;
+  // freed blocks are kept for the next set-up (the preconditioner is rebuilt every solve) up to 80 % of the device's
+  // memory: a fresh hipMalloc of tens of GB costs seconds (1.7 s for 48 GB on MI355X), and the BASELINE configs[4]
+  // operator (36 GB) needs several such blocks per set-up
+  size_t cap_bytes = 0;
+  size_t cap() {
+    if (cap_bytes == 0) {
+      size_t fr = 0, tot = 0;
+      cap_bytes = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? tot / 5 * 4 : ((size_t)48 << 30);
+    }
+    return cap_bytes;
+  }
   std::multimap<size_t, void *> free_blocks;   // ready: no kernel can still touch them
   std::vector<std::pair<size_t, void *>> pending;  // released since the last device synchronisation
   size_t cached = 0;
@@ -98,7 +108,7 @@ struct DevPool {
   void release(void *p, size_t bytes) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(mu);
-    if (bytes >= 4096 && cached + bytes <= kPoolCapBytes) {
+    if (bytes >= 4096 && cached + bytes <= cap()) {
       pending.emplace_back(bytes, p);
       cached += bytes;
     } else {

@@ -165,6 +165,18 @@ int isph_ctx_set_profile(isph_ctx *ctx, int on) {
   return ISPH_SUCCESS;
 }
 
+int isph_pool_trim(void) {
+  if (hipDeviceSynchronize() != hipSuccess) return fail("device synchronisation failed", __FILE__, __LINE__);
+  DevPool::get().trim();
+  return ISPH_SUCCESS;
+}
+
+long long isph_pool_cached_bytes(void) {
+  DevPool &p = DevPool::get();
+  std::lock_guard<std::mutex> lk(p.mu);
+  return (long long)p.cached;
+}
+
 void isph_ctx_destroy(isph_ctx *c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);

@@ -17,7 +17,7 @@ NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
 KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
-    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy",
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_cached_bytes",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
@@ -99,6 +99,9 @@ def lib():
         L.isph_ctx_create_dist.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
         L.isph_ctx_sync.argtypes = [C.c_void_p]
         L.isph_ctx_destroy.argtypes = [C.c_void_p]
+        L.isph_pool_trim.argtypes = []
+        L.isph_pool_cached_bytes.argtypes = []
+        L.isph_pool_cached_bytes.restype = C.c_longlong
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.isph_mat_create_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]
@@ -198,6 +201,15 @@ def _f64(a):
         assert str(a.dtype) == "torch.float64", "float64 tensor expected, got %s" % a.dtype
         return a
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def pool_trim():
+    """Return the device buffers the library keeps for the next set-up to the driver (isph_pool_trim)."""
+    _check(lib().isph_pool_trim())
+
+
+def pool_cached_bytes():
+    return int(lib().isph_pool_cached_bytes())
 
 
 class Context:

@@ -47,6 +47,12 @@ int isph_ctx_create_dist(int device, void *stream, int rank, int nranks,
                          const char *uid, isph_ctx **ctx);
 int isph_ctx_sync(isph_ctx *ctx);
 void isph_ctx_destroy(isph_ctx *ctx);
+/* Device buffers released by the library are kept for the next set-up (the reference rebuilds matrix and preconditioner
+ * every time step, pair_isph.cpp:1257-1287,1363) up to 80 % of the device's memory (a failed allocation trims them first).  isph_pool_trim() synchronises the
+ * device and returns them to the driver; isph_pool_cached_bytes() reports how much is held.  No reference counterpart
+ * (the reference has no device memory). */
+int isph_pool_trim(void);
+long long isph_pool_cached_bytes(void);
 const char *isph_last_error(void);
 
 /* ---- matrix ----------------------------------------------------------- */

@@ -106,3 +106,5 @@ def test_porous_config4_properties_at_size(gpu_ctx, nc):
     assert float(xs[solid].abs().max()) <= 1e-12 * float(xs.abs().max())
     del M, A
     torch.cuda.empty_cache()
+    hip.pool_trim()                                            # hand the tens of GB back before the next test module
+    assert hip.pool_cached_bytes() == 0
