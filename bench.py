@@ -226,12 +226,14 @@ def main():
 
     # computePre (volumes on the GPU + forward comm of ghost volumes) and the Poisson assembly.  Done twice: the first
     # pass pays the one-time device allocations, the second is the steady state a time step sees
+    fwd = hip.HaloForward(ctx, nlocal, plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr) if plan.npeers else None
+
     def assemble():
         vf = hip.compute_volumes(ctx, dparts, colmap, kernel=args.kernel)
-        if world == 1:
+        if fwd is None:
             vfrac = vf[torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)].contiguous()
         else:
-            vfrac = dist.forward_scalar(plan, vf, td, dev)
+            vfrac = dist.forward_scalar_rccl(fwd, plan, vf)   # forward_comm_pair of Vfrac over the library's RCCL comm
         A, b = hip.assemble_poisson(ctx, dparts, colmap, spec.dt, rho, vstar, vfrac=vfrac, ncol=plan.ncol,
                                     kernel=args.kernel, rank0=(rank == 0))
         if plan.npeers:

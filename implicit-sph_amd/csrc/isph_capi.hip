@@ -270,6 +270,99 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, co
   return ISPH_SUCCESS;
 }
 
+struct isph_halo_plan {
+  isph_halo H;
+  int nlocal = 0;
+};
+
+__global__ void k_gather_atoms(int n, int ncomp, const int *__restrict__ idx, const double *__restrict__ x,
+                               double *__restrict__ out) {
+  const long long total = (long long)n * ncomp;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(e / ncomp), c = (int)(e % ncomp);
+    out[e] = x[(long long)idx[i] * ncomp + c];
+  }
+}
+
+int isph_halo_create(isph_ctx *ctx, int nlocal, int npeers, const int *peer_rank, const int *send_ptr,
+                     const int *send_idx, const int *recv_ptr, isph_halo_plan **plan) {
+  ISPH_REQUIRE(ctx && plan && nlocal >= 0 && npeers >= 0, "NULL or negative argument");
+  ISPH_REQUIRE(npeers == 0 || (peer_rank && send_ptr && recv_ptr), "NULL halo lists");
+  ISPH_REQUIRE(npeers == 0 || ctx->comm, "a halo plan with peers needs a context made by isph_ctx_create_dist");
+  isph_halo_plan *P = new isph_halo_plan();
+  P->nlocal = nlocal;
+  isph_halo &H = P->H;
+  H.npeers = npeers;
+  H.peer.assign(peer_rank, peer_rank + npeers);
+  if (npeers > 0) {
+    H.send_ptr.assign(send_ptr, send_ptr + npeers + 1);
+    H.recv_ptr.assign(recv_ptr, recv_ptr + npeers + 1);
+  } else {
+    H.send_ptr.assign(1, 0);
+    H.recv_ptr.assign(1, 0);
+  }
+  H.nsend = H.send_ptr[(size_t)npeers];
+  H.nrecv = H.recv_ptr[(size_t)npeers];
+  int rc = ISPH_SUCCESS;
+  for (int p = 0; p < npeers && rc == ISPH_SUCCESS; ++p) {
+    if (peer_rank[p] < 0 || peer_rank[p] >= ctx->nranks) rc = fail("peer rank out of range", __FILE__, __LINE__);
+    else if (H.send_ptr[(size_t)p + 1] < H.send_ptr[(size_t)p] || H.recv_ptr[(size_t)p + 1] < H.recv_ptr[(size_t)p])
+      rc = fail("halo offsets must not decrease", __FILE__, __LINE__);
+  }
+  for (int k = 0; k < H.nsend && rc == ISPH_SUCCESS; ++k)
+    if (send_idx[k] < 0 || send_idx[k] >= nlocal) rc = fail("send index out of range", __FILE__, __LINE__);
+  if (rc == ISPH_SUCCESS) rc = H.send_idx.reserve((size_t)(H.nsend > 0 ? H.nsend : 1));
+  if (rc == ISPH_SUCCESS && H.nsend > 0 &&
+      (hipMemcpyAsync(H.send_idx.p, send_idx, sizeof(int) * (size_t)H.nsend, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+       hipStreamSynchronize(ctx->stream) != hipSuccess))
+    rc = fail("copy of the send list failed", __FILE__, __LINE__);
+  if (rc != ISPH_SUCCESS) { isph_halo_destroy(P); return rc; }
+  *plan = P;
+  return ISPH_SUCCESS;
+}
+
+void isph_halo_destroy(isph_halo_plan *P) {
+  if (!P) return;
+  P->H.send_idx.release();
+  delete P;
+}
+
+int isph_halo_forward(isph_ctx *ctx, const isph_halo_plan *P, const double *x, double *ghosts, int ncomp, int on_device) {
+  ISPH_REQUIRE(ctx && P && ncomp >= 1 && ncomp <= 16, "NULL plan or ncomp outside [1,16]");
+  const isph_halo &H = P->H;
+  if (H.nrecv == 0 && H.nsend == 0) return ISPH_SUCCESS;
+  ISPH_REQUIRE(x && ghosts, "NULL field");
+  ISPH_REQUIRE(ctx->comm, "no communicator");
+  DevBuf<double> tx, tg;
+  const double *dx = nullptr;
+  int rc = stage_in(ctx, x, (size_t)P->nlocal * ncomp, on_device, tx, &dx);
+  double *dg = ghosts;
+  if (rc == ISPH_SUCCESS && !on_device) { rc = tg.reserve((size_t)(H.nrecv > 0 ? H.nrecv : 1) * ncomp); dg = tg.p; }
+  if (rc == ISPH_SUCCESS && on_device && H.nrecv > 0 && !is_device_pointer(ghosts)) rc = fail("ghosts is not device memory (on_device = 1)", __FILE__, __LINE__);
+  if (rc == ISPH_SUCCESS) rc = ctx->sendbuf.reserve((size_t)(H.nsend > 0 ? H.nsend : 1) * ncomp);
+  if (rc == ISPH_SUCCESS) {
+    if (H.nsend > 0)
+      hipLaunchKernelGGL(k_gather_atoms, dim3(stream_grid((long long)H.nsend * ncomp)), dim3(kBlock), 0, ctx->stream, H.nsend,
+                         ncomp, (const int *)H.send_idx.p, dx, ctx->sendbuf.p);
+    ncclResult_t nr = ncclGroupStart();
+    for (int p = 0; p < H.npeers && nr == ncclSuccess; ++p) {
+      const size_t ns = (size_t)(H.send_ptr[(size_t)p + 1] - H.send_ptr[(size_t)p]) * ncomp;
+      const size_t nrv = (size_t)(H.recv_ptr[(size_t)p + 1] - H.recv_ptr[(size_t)p]) * ncomp;
+      if (ns > 0) nr = ncclSend(ctx->sendbuf.p + (size_t)H.send_ptr[(size_t)p] * ncomp, ns, ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
+      if (nr == ncclSuccess && nrv > 0)
+        nr = ncclRecv(dg + (size_t)H.recv_ptr[(size_t)p] * ncomp, nrv, ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
+    }
+    const ncclResult_t ne = ncclGroupEnd();
+    if (nr != ncclSuccess || ne != ncclSuccess) rc = fail("RCCL halo exchange failed", __FILE__, __LINE__);
+  }
+  if (rc == ISPH_SUCCESS && !on_device && H.nrecv > 0 &&
+      hipMemcpyAsync(ghosts, dg, sizeof(double) * (size_t)H.nrecv * ncomp, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+    rc = fail("copy of the ghost values failed", __FILE__, __LINE__);
+  if (rc == ISPH_SUCCESS && !on_device && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("halo exchange failed", __FILE__, __LINE__);
+  tx.release(); tg.release();
+  return rc;
+}
+
 int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_rank, const int *send_ptr,
                       const int *send_idx, const int *recv_ptr) {
   ISPH_REQUIRE(ctx && A, "NULL argument");

@@ -135,3 +135,14 @@ def forward_scalar(plan, owned, td, device=None):
     ext = exchange(plan, owned, td, device)
     cm = torch.from_numpy(plan.colmap.astype(np.int64)).to(ext.device)
     return ext[cm].contiguous()
+
+
+def forward_scalar_rccl(fwd, plan, owned):
+    """forward_scalar through the library's own communicator (hip.HaloForward made from this plan): the [nall] array
+    with every ghost holding its owner's value.  owned: torch tensor on the device or numpy array, [>= nlocal]."""
+    import torch
+    ghosts = fwd.forward(owned[:plan.nlocal].contiguous() if isinstance(owned, torch.Tensor) else np.ascontiguousarray(owned[:plan.nlocal]))
+    if isinstance(owned, torch.Tensor):
+        ext = torch.cat([owned[:plan.nlocal], ghosts])
+        return ext[torch.from_numpy(plan.colmap.astype(np.int64)).to(ext.device)].contiguous()
+    return np.concatenate([owned[:plan.nlocal], ghosts])[plan.colmap]

@@ -17,7 +17,7 @@ NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
 KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
-    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_cached_bytes",
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
@@ -100,6 +100,10 @@ def lib():
         L.isph_ctx_sync.argtypes = [C.c_void_p]
         L.isph_ctx_destroy.argtypes = [C.c_void_p]
         L.isph_pool_trim.argtypes = []
+        L.isph_halo_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.isph_halo_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.isph_halo_destroy.argtypes = [C.c_void_p]
+        L.isph_halo_destroy.restype = None
         L.isph_pool_cached_bytes.argtypes = []
         L.isph_pool_cached_bytes.restype = C.c_longlong
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
@@ -247,6 +251,45 @@ class Context:
     def close(self):
         if self.h:
             lib().isph_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HaloForward:
+    """Stand-alone halo plan: forward comm of per-atom fields over the context's RCCL communicator
+    (isph_halo_create / isph_halo_forward; LAMMPS' comm->forward_comm_pair for PairISPH, pair_isph.cpp:1924-2110)."""
+
+    def __init__(self, ctx, nlocal, peers, send_ptr, send_idx, recv_ptr):
+        self.ctx, self.nlocal = ctx, int(nlocal)
+        peers, send_ptr, send_idx, recv_ptr = (np.ascontiguousarray(a, dtype=np.int32) for a in (peers, send_ptr, send_idx, recv_ptr))
+        self.nrecv = int(recv_ptr[-1]) if len(recv_ptr) else 0
+        self.h = C.c_void_p()
+        _check(lib().isph_halo_create(ctx.h, self.nlocal, len(peers), _ptr(peers), _ptr(send_ptr), _ptr(send_idx), _ptr(recv_ptr),
+                                      C.byref(self.h)))
+
+    def forward(self, x, ncomp=1):
+        """x: [nlocal] or [nlocal, ncomp] (numpy on the host or torch on the device) -> ghost values [nrecv(, ncomp)]
+        in ghost-column order, on the same side as x."""
+        dev = _on_device(x)
+        x = _f64(x)
+        assert x.shape[0] >= self.nlocal and (x.ndim == 1) == (ncomp == 1) and (x.ndim == 1 or x.shape[1] == ncomp)
+        shape = (self.nrecv,) if ncomp == 1 else (self.nrecv, ncomp)
+        if dev:
+            import torch
+            g = torch.empty(shape, dtype=torch.float64, device=x.device)
+        else:
+            g = np.empty(shape, dtype=np.float64)
+        _check(lib().isph_halo_forward(self.ctx.h, self.h, _ptr(x), _ptr(g), int(ncomp), 1 if dev else 0))
+        return g
+
+    def close(self):
+        if self.h:
+            lib().isph_halo_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

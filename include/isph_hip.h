@@ -71,6 +71,18 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[
  * and receive the ghost columns nrow+recv_ptr[p] .. nrow+recv_ptr[p+1]. */
 int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_rank,
                       const int *send_ptr, const int *send_idx, const int *recv_ptr);
+/* The same plan as a stand-alone object, for per-atom fields that are not matrix columns yet: LAMMPS'
+ * comm->forward_comm_pair(this) with PairISPH::pack_forward_comm / unpack_forward_comm (ref: pair_isph.cpp:1924-2110;
+ * call sites functor_volume.h:78-80 for Vfrac, pair_isph.cpp:977-979 Vstar, :1017-1019 DeltaP, :1123-1125 Pressure,
+ * :1161-1163 Velocity).  isph_halo_forward sends ncomp doubles per listed owned atom (x is [nlocal][ncomp], the layout
+ * of atom->v / the pair's per-atom arrays) and returns the ghost values in ghost-column order: ghosts is
+ * [recv_ptr[npeers]][ncomp].  Runs on the context's stream over its RCCL communicator (grouped ncclSend/ncclRecv). */
+typedef struct isph_halo_plan isph_halo_plan;
+int isph_halo_create(isph_ctx *ctx, int nlocal, int npeers, const int *peer_rank, const int *send_ptr,
+                     const int *send_idx, const int *recv_ptr, isph_halo_plan **plan);
+int isph_halo_forward(isph_ctx *ctx, const isph_halo_plan *plan, const double *x /*[h|d]*/, double *ghosts /*[h|d]*/,
+                      int ncomp, int on_device);
+void isph_halo_destroy(isph_halo_plan *plan);
 /* sizes: [0]=nrow [1]=ncol [2]=nnz [3]=number of 64-row slices
  *        [4]=stored (padded) entries [5]=bytes of the sliced-ELL arrays */
 int isph_mat_info(const isph_mat *A, long long info[6]);

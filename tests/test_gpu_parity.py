@@ -453,6 +453,42 @@ def test_rccl_self_halo_spmv_and_solve(gpu_ctx):
         ctx.close()
 
 
+def test_rccl_forward_comm_of_per_atom_fields(gpu_ctx):
+    """isph_halo_create / isph_halo_forward = comm->forward_comm_pair for the pair's per-atom arrays
+    (pair_isph.cpp:1924-2110): scalars (Vfrac) and 3-vectors (Vstar) from host and from device memory, through the
+    self-peer plan on one GPU.  Index work: ghost values must equal their owners' bit for bit."""
+    import torch
+    from isph_amd import dist
+    pr = Problem(tgv_spec(dim=3, n=10, mode=workload.JITTER))
+    ctx = hip.Context(0, rank=0, nranks=1, uid=hip.Context.unique_id())
+    try:
+        plan = dist.make_self_halo_plan(pr.parts)
+        nl, nall = pr.parts["nlocal"], pr.parts["nall"]
+        fwd = hip.HaloForward(ctx, nl, plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+        assert fwd.nrecv == plan.ncol - nl
+        own = pr.parts["owner_index"].astype(np.int64)
+        rng = np.random.default_rng(3)
+        s = rng.standard_normal(nl)
+        v = rng.standard_normal((nl, 3))
+        g = fwd.forward(s)
+        assert np.array_equal(np.concatenate([s, g])[plan.colmap], s[own])          # every ghost holds its owner's value
+        gv = fwd.forward(v, ncomp=3)
+        assert np.array_equal(np.concatenate([v, gv])[plan.colmap], v[own])
+        dev = torch.device("cuda", 0)
+        gd = fwd.forward(torch.from_numpy(v).to(dev), ncomp=3)
+        assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), gv)
+        full = dist.forward_scalar_rccl(fwd, plan, torch.from_numpy(s).to(dev))
+        assert full.shape[0] == nall and np.array_equal(full.cpu().numpy(), s[own])
+        with pytest.raises(hip.IsphError):
+            hip.HaloForward(ctx, nl, plan.peers, plan.send_ptr, plan.send_idx + nl, plan.recv_ptr)   # send index out of range
+        fwd.close()
+        # a plan without peers is a no-op on any context
+        f0 = hip.HaloForward(gpu_ctx, nl, [], [0], [], [0])
+        assert f0.forward(s).shape == (0,)
+    finally:
+        ctx.close()
+
+
 # ---------------------------------------------------------------- C++ mirror of the reference interface
 @pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml"), (1, "ifpack-defaults"), (1, "ifpack-reference"),
                                          (1, "recycling")])
