@@ -62,8 +62,8 @@ __global__ void k_numneigh(int n, const OFF *__restrict__ nptr, int *__restrict_
 
 // Orders every row's neighbour ids by their matrix column (stable: equal columns -- periodic images -- keep their
 // list order).  One wave per row.  The keys (column << 10 | list position: unique, so ranks need no tie rule) go to
-// LDS; a row that is already in order -- most rows of a list built cell by cell -- is copied through, any other row
-// is ranked by counting, two keys per 16-B LDS broadcast read.
+// LDS; a row that is already in order -- most rows of a list built cell by cell -- is copied through, a short row is
+// ranked by counting (two keys per 16-B LDS broadcast read), a long one goes through a bitonic network.
 constexpr int kNeighSortCap = 1024;
 template <class OFF>
 __global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restrict__ nptr, const int *__restrict__ nidx,
@@ -83,6 +83,26 @@ __global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restr
   for (int k = lane; k + 1 < len; k += 64) disorder |= kw[k + 1] < kw[k];
   if (__ballot(disorder) == 0) {
     for (int k = lane; k < len; k += 64) out[jb + k] = nidx[jb + k];
+    return;
+  }
+  if (len > 128) {
+    // long rows (Quintic on a bcc lattice: 748 neighbours): bitonic network over the next power of two, in LDS
+    int P = 256;
+    while (P < len) P <<= 1;
+    for (int k = len + lane; k < P; k += 64) kw[k] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int t = lane; t < (P >> 1); t += 64) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+          const unsigned long long a = kw[i], b = kw[p];
+          if ((a > b) == ((i & k2) == 0)) { kw[i] = b; kw[p] = a; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    for (int k = lane; k < len; k += 64) out[jb + k] = nidx[jb + (int)(kw[k] & 1023ull)];
     return;
   }
   const ulonglong2 *kw2 = reinterpret_cast<const ulonglong2 *>(kw);
