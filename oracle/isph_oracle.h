@@ -10,6 +10,11 @@
  * /root/reference/IMPLICIT-SPH/) whose algorithm it restates.
  *
  * PARITY PINNING STATUS (round 2)
+ *   - PINNED to 10-14 significant digits by sph-script/conv-poisson-boltzmann-harmonic-2d-rev390.txt
+ *     (fix_isph_error.cpp:188-345): total volume, l2 error of psi and of grad psi, N = 16..256, reproduced by
+ *     oracle/pb_harmonic.py on this library's kernel, volumes, G_i, L_i, Symmetric-family Laplacian rows and
+ *     corrected gradient (tests/test_oracle.py::test_pb_harmonic_known_answer_table_pinned; the device path against
+ *     the same rows up to N = 1024: tests/test_gpu_reference_tables.py).
  *   - PINNED to numbers the reference itself recorded: the 2-D Taylor-Green tables
  *     sph-script/conv-taylor-green-vortex-2d-rev390.txt / -rev230.txt (fix_isph_tgv.cpp:43-125).  With the one
  *     combination of unrecorded settings that fits (oracle/tgv_sweep.py: theta 1/2, incremental pressure,

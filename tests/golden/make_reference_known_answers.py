@@ -1,5 +1,5 @@
-"""Regenerates the TGV rows of reference_known_answers.json from the two text tables the
-reference keeps (sph-script/conv-taylor-green-vortex-2d-rev{390,230}.txt).  Runs only where
+"""Regenerates the rows of reference_known_answers.json from the text tables the reference keeps
+(sph-script/conv-taylor-green-vortex-2d-rev{390,230}.txt, conv-poisson-boltzmann-harmonic-2d-rev390.txt).  Runs only where
 /root/reference exists (the build container); the JSON it writes is data: expected outputs."""
 import json
 import os
@@ -30,6 +30,23 @@ def parse(fn):
     return out
 
 
+def parse_pb(fn):
+    """conv-poisson-boltzmann-harmonic-2d-rev390.txt: per N the numbers fix isph/error prints (fix_isph_error.cpp:318-340)"""
+    out, N = {}, None
+    keys = {"total # of particles": "particles", "total volume": "volume", "sol.psi.norm2": "sol_psi",
+            "err.psi.norm2": "err_psi", "sol.psi.grad.norm2": "sol_grad", "err.psi.grad.norm2": "err_grad"}
+    for line in open(fn).read().splitlines():
+        m = re.match(r"\s*N = (\d+)", line)
+        if m:
+            N = m.group(1)
+            out[N] = {}
+        m = re.match(r"\s*([a-z0-9.# ]+?)\s*=\s*([\d.e+-]+)", line)
+        if m and N and m.group(1).strip() in keys:
+            k = keys[m.group(1).strip()]
+            out[N][k] = int(m.group(2)) if k == "particles" else float(m.group(2))
+    return out
+
+
 if __name__ == "__main__":
     path = os.path.join(HERE, "reference_known_answers.json")
     g = json.load(open(path))
@@ -40,4 +57,9 @@ if __name__ == "__main__":
     g["conv_taylor_green_vortex_2d_rev390_quintic"]["rows"] = keep(r390["quintic"])
     g["conv_taylor_green_vortex_2d_rev230"]["rows"] = keep(r230["wendland"])
     g["conv_taylor_green_vortex_2d_rev230_quintic"]["rows"] = keep(r230["quintic"])
+    g["conv_poisson_boltzmann_harmonic_2d_rev390"] = {
+        "file": "sph-script/conv-poisson-boltzmann-harmonic-2d-rev390.txt",
+        "setting": "poisson-boltzmann-harmonic-2d.lmp + poisson-boltzmann-harmonic.xml: periodic [-pi,pi)^2, lattice sq dx "
+                   "origin 0, h = 1.5 dx, Wendland cut 2h, corrected (Symmetric) operators, psi = sin x cos y",
+        "rows": parse_pb(REF + "conv-poisson-boltzmann-harmonic-2d-rev390.txt")}
     json.dump(g, open(path, "w"), indent=1)

@@ -441,3 +441,21 @@ def test_amg_ml_uncoupled_aggregation_and_whole_level_sgs_gap():
         its[(agg, whole)] = info.iters
     assert abs(its[("mis2", False)] - its[("ml", False)]) <= 2 and abs(its[("mis2", True)] - its[("ml", True)]) <= 2
     assert its[("ml", True)] <= its[("mis2", False)] <= 1.5 * its[("ml", True)] + 1
+
+
+# ------------------------------------------------------------------ second pin: the reference's Poisson-Boltzmann table
+@pytest.mark.parametrize("N", [16, 32, 64, 128])
+def test_pb_harmonic_known_answer_table_pinned(N):
+    """sph-script/conv-poisson-boltzmann-harmonic-2d-rev390.txt (fix isph/error, fix_isph_error.cpp:188-345): the
+    numbers the reference printed for the manufactured Poisson-Boltzmann problem depend on nothing but the kernel, the
+    volumes V_i, the correction tensors G_i / L_i, the corrected (Symmetric-family) Laplacian and the corrected gradient
+    (oracle/pb_harmonic.py).  The oracle reproduces total volume to 14 digits and both error norms to >= 10."""
+    import pb_harmonic
+    ref = pb_harmonic.known_answers()[N]
+    r = pb_harmonic.run(N)
+    assert ref["particles"] == N * N
+    assert abs(r["volume"] - ref["volume"]) <= 1e-13 * ref["volume"]
+    assert abs(r["sol_psi"] - ref["sol_psi"]) <= 1e-13 and abs(r["sol_grad"] - ref["sol_grad"]) <= 1e-13
+    assert abs(r["err_psi"] - ref["err_psi"]) <= 1e-10 * ref["err_psi"]
+    assert abs(r["err_grad"] - ref["err_grad"]) <= 1e-10 * ref["err_grad"]
+    assert r["operator_vs_matrix"] <= 1e-11          # functor_laplacian.h's operator form == the assembled rows
