@@ -259,6 +259,29 @@ __global__ void k_volumes(AsmTables T, int nlocal, const double *__restrict__ x,
   vfrac[i] = 1.0 / w;
 }
 
+// Particle number density of the MorrisHolmes mirror (FunctorOuterNormal's pnd, functor_normal.h:57-133, as called by
+// PairISPH_Corrected::computeNormals with the filters (Fluid,Solid) and (Solid,Fluid), pair_isph_corrected.cpp:396-419):
+// pnd_i = sum_j W(r_ij) over the neighbours that are NOT of the opposite phase + W(0), so that pnd_i V_i is the
+// fraction of the kernel support filled by i's own phase (1 in the bulk, 1/2 at a flat wall).
+__global__ void k_pnd(AsmTables T, int nlocal, const double *__restrict__ x, const int *__restrict__ type,
+                      double *__restrict__ pnd) {
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const int it = type[i], nt1 = T.ntypes + 1, ikind = T.kind[it];
+  if (!(ikind & (KIND_FLUID | KIND_SOLID))) { pnd[i] = 0.0; return; }
+  const int opposite = (ikind & KIND_SOLID) ? KIND_FLUID : KIND_SOLID;
+  double w = 0.0;
+  for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {
+    const int j = neigh_at(T, i, jj);
+    const int jt = type[j];
+    double rij[3];
+    const double rsq = pair_rsq(T.dim, x, i, j, rij);
+    if (rsq < T.cutsq[it * nt1 + jt] && !(T.kind[jt] & opposite))
+      w += kernel_val(T.kernel, sqrt(rsq) + kEps, T.hinv[it * nt1 + jt], T.knorm[it * nt1 + jt]);
+  }
+  pnd[i] = w + kernel_val(T.kernel, 0.0, T.hinv[it * nt1 + it], T.knorm[it * nt1 + it]);
+}
+
 
 // ---------------------------------------------------------------------------
 // computePre tensors of the Symmetric (consistent) family, one lane per particle.
@@ -1069,7 +1092,7 @@ inline int stage_tables(isph_ctx *ctx, const isph_particles *P, StagedParticles 
   return ISPH_SUCCESS;
 }
 
-inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device) {
+inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device, bool pnd = false) {
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
   ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx, "particle arrays missing");
   StagedParticles S;
@@ -1089,8 +1112,12 @@ inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac
   double *dout = vfrac_out;
   if (rc == ISPH_SUCCESS && !on_device) { rc = out.reserve((size_t)(P->nlocal > 0 ? P->nlocal : 1)); dout = out.p; }
   if (rc == ISPH_SUCCESS && P->nlocal > 0) {
-    hipLaunchKernelGGL(k_volumes, dim3(xcd_grid((P->nlocal + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, T, P->nlocal, dx,
-                       dt, dp, di, dout);
+    if (pnd)
+      hipLaunchKernelGGL(k_pnd, dim3(xcd_grid((P->nlocal + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, T, P->nlocal, dx,
+                         dt, dout);
+    else
+      hipLaunchKernelGGL(k_volumes, dim3(xcd_grid((P->nlocal + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, T, P->nlocal, dx,
+                         dt, dp, di, dout);
     if (!on_device &&
         hipMemcpyAsync(vfrac_out, dout, sizeof(double) * (size_t)P->nlocal, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = fail("copy failed", __FILE__, __LINE__);

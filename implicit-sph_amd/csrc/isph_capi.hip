@@ -960,6 +960,11 @@ int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_o
   return compute_volumes(ctx, P, vfrac_out, on_device);
 }
 
+int isph_compute_pnd(isph_ctx *ctx, const isph_particles *P, double *pnd_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && pnd_out, "NULL argument");
+  return compute_volumes(ctx, P, pnd_out, on_device, /*pnd=*/true);
+}
+
 int isph_compute_corrections(isph_ctx *ctx, const isph_particles *P, double *Gc_out, double *Lc_out, int on_device) {
   ISPH_REQUIRE(ctx && P && Gc_out && Lc_out, "NULL argument");
   return compute_corrections(ctx, P, Gc_out, Lc_out, on_device);

@@ -21,7 +21,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
@@ -126,6 +126,7 @@ def lib():
         L.isph_assemble_poisson.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_compute_volumes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_compute_pnd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_compute_corrections.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         for fn in (L.isph_gradient, L.isph_divergence):
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int,
@@ -616,6 +617,20 @@ def compute_volumes(ctx, parts, colmap, kernel="wendland"):
     else:
         out = np.zeros(nlocal)
     _check(lib().isph_compute_volumes(ctx.h, C.byref(pv), _ptr(out), dev))
+    return out
+
+
+def compute_pnd(ctx, parts, colmap, kernel="wendland", kinds=None):
+    """isph_compute_pnd: particle number density of the MorrisHolmes mirror (functor_normal.h:57-133); [nlocal]."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, keep=keep, kinds=kinds)
+    nlocal = int(parts["nlocal"])
+    if dev:
+        import torch
+        out = torch.zeros(nlocal, dtype=torch.float64, device=parts["x"].device)
+    else:
+        out = np.zeros(nlocal)
+    _check(lib().isph_compute_pnd(ctx.h, C.byref(pv), _ptr(out), dev))
     return out
 
 

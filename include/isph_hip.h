@@ -269,6 +269,10 @@ int isph_assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int an
                                   int on_device);
 /* FunctorOuterVolume (ref: functor_volume.h:40-80); vfrac_out [nlocal]. */
 int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device);
+/* Particle number density of the MorrisHolmes mirror, the `pnd` member of isph_particles: W(0) + sum of W(r_ij) over the
+ * neighbours that are not of the opposite phase (FunctorOuterNormal, ref: functor_normal.h:57-133, called by
+ * PairISPH_Corrected::computeNormals, pair_isph_corrected.cpp:396-419); pnd_out [nlocal], ghosts by forward comm. */
+int isph_compute_pnd(isph_ctx *ctx, const isph_particles *P, double *pnd_out, int on_device);
 
 /* FunctorOuterGradientCorrection + FunctorOuterLaplacianCorrection
  * (ref: functor_gradient_correction.h:23-71, functor_laplacian_correction.h:24-153,

@@ -174,6 +174,34 @@ void orc_compute_volumes(const orc_particles *P) {
   orc_forward_comm(P, P->vfrac, 1); /* functor_volume.h:76-80 */
 }
 
+/* Particle number density of the MorrisHolmes mirror: the pnd part of FunctorOuterNormal::operator()
+ * (ref: functor_normal.h:57-133) as PairISPH_Corrected::computeNormals runs it, once with the filter (Fluid,Solid)
+ * and once with (Solid,Fluid) (pair_isph_corrected.cpp:396-419): a neighbour inside the cut that does NOT pass the
+ * pair filter -- i.e. is not of the opposite phase -- adds W(r), the particle itself W(0) last (:109,:115). */
+void orc_compute_pnd(const orc_particles *P, double *pnd) {
+  const int dim = P->dim;
+  for (int i = 0; i < P->nlocal; ++i) {
+    const int it = P->type[i], ikind = kind_of(P, i);
+    pnd[i] = 0.0;
+    if (!(ikind & (ORC_KIND_FLUID | ORC_KIND_SOLID))) continue;
+    const int opposite = (ikind & ORC_KIND_SOLID) ? ORC_KIND_FLUID : ORC_KIND_SOLID;
+    double w = 0.0;
+    for (int jj = P->neigh_ptr[i]; jj < P->neigh_ptr[i + 1]; ++jj) {
+      const int j = P->neigh_idx[jj];
+      const int jt = P->type[j];
+      double rsq = 0.0;
+      for (int k = 0; k < dim; ++k) {
+        const double r = P->x[3 * i + k] - P->x[3 * j + k];
+        rsq += r * r;
+      }
+      if (rsq < tab(P, P->cutsq, it, jt) && !(kind_of(P, j) & opposite))
+        w += orc_kernel_val(P->kernel, dim, sqrt(rsq) + ORC_EPS, tab(P, P->h, it, jt));
+    }
+    pnd[i] = w + orc_kernel_val(P->kernel, dim, 0.0, tab(P, P->h, it, it));
+  }
+  orc_forward_comm(P, pnd, 1); /* pair_isph_corrected.cpp:1360,1374: pnd travels with the normal */
+}
+
 /* dense LU with partial pivoting, column-major n x n, nrhs right-hand sides
  * (what LAPACK dgesv computes; ref: utils_reference.cpp:398-407). */
 static int dense_gesv(int n, double *A, int nrhs, double *B) {
@@ -499,6 +527,11 @@ int orc_laplacian_matrix(const orc_particles *P, int antisym, double alpha,
           double coeff = fyes2(filt_i, filt_j, ikind, ikind);
           if (!(ikind & ORC_KIND_SOLID) && (jkind & ORC_KIND_SOLID))
             coeff = fyes2(filt_i, filt_j, ikind, jkind);
+          /* morris_holmes == 2: the OPERATOR form FunctorOuterLaplacian_MorrisHolmes (functor_laplacian.h:143-160,
+           * 240-243) carries the mirror coefficient in its gradient part too; the matrix functor does not (:225-227).
+           * Only used to reproduce the reference's Poisson-Boltzmann channel table (oracle/pb_channel.py). */
+          if (morris_holmes == 2 && !(ikind & ORC_KIND_SOLID) && (jkind & ORC_KIND_SOLID) && coeff != 0.0)
+            coeff = mirror_coeff(P, morris_holmes, i, j, sqrt(tab(P, P->cutsq, it, jt)));
           const double r = sqrt(rsq) + ORC_EPS;
           const double dwdr = orc_kernel_dval(P->kernel, dim, r, tab(P, P->h, it, jt));
           const double vfrac = antisym ? sqrt(P->vfrac[i] * P->vfrac[j]) : P->vfrac[j];

@@ -15,6 +15,10 @@
  *     oracle/pb_harmonic.py on this library's kernel, volumes, G_i, L_i, Symmetric-family Laplacian rows and
  *     corrected gradient (tests/test_oracle.py::test_pb_harmonic_known_answer_table_pinned; the device path against
  *     the same rows up to N = 1024: tests/test_gpu_reference_tables.py).
+ *   - PINNED to 10-14 digits with walls: sph-script/conv-channel-edl-potential-2d-morrisholmes-rev722.txt, sections
+ *     MorrisHolmes and ConstExtension, N = 32..1024 (oracle/pb_channel.py): mirror coefficient, particle number density
+ *     (orc_compute_pnd), fluid-solid columns, Dirichlet solid rows (tests/test_oracle.py::
+ *     test_pb_channel_known_answer_table_pinned; device: tests/test_gpu_reference_tables.py).
  *   - PINNED to numbers the reference itself recorded: the 2-D Taylor-Green tables
  *     sph-script/conv-taylor-green-vortex-2d-rev390.txt / -rev230.txt (fix_isph_tgv.cpp:43-125).  With the one
  *     combination of unrecorded settings that fits (oracle/tgv_sweep.py: theta 1/2, incremental pressure,
@@ -89,6 +93,7 @@ double orc_kernel_dval(int kernel, int dim, double r, double h);
  *      functor_laplacian_correction.h) ---- */
 void orc_forward_comm(const orc_particles *P, double *arr, int ncomp);
 void orc_compute_volumes(const orc_particles *P);
+void orc_compute_pnd(const orc_particles *P, double *pnd /* [nall] */);
 void orc_compute_gradient_correction(const orc_particles *P);
 int  orc_compute_laplacian_correction(const orc_particles *P);
 

@@ -171,6 +171,12 @@ class Particles:
             L.orc_compute_laplacian_correction(self.ref())
         return self
 
+    def compute_pnd(self):
+        """particle number density of the MorrisHolmes mirror ([nall], ghosts filled): functor_normal.h:57-133"""
+        pnd = np.zeros(self.nall)
+        lib().orc_compute_pnd(self.ref(), _p(pnd))
+        return pnd
+
     def graph(self):
         cap = int(self.neigh_ptr[-1]) + self.nlocal
         rowptr = np.zeros(self.nlocal + 1, dtype=np.int32)

@@ -15,3 +15,14 @@ for N in (16, 32, 64, 128, 256, 512, 1024):
     print("N = %4d  newton %d, FGMRES+SA-AMG iterations %s, |F| %.1e" % (N, r["newton"], r["gmres"], r["residual"]))
     for name, key in (("total volume", "volume"), ("err.psi.norm2", "err_psi"), ("err.psi.grad.norm2", "err_grad")):
         print("    %-20s device %.15e   reference %.15e   rel. diff %.1e" % (name, r[key], ref[N][key], abs(r[key] - ref[N][key]) / ref[N][key]))
+
+from test_gpu_reference_tables import device_channel
+import pb_channel
+for boundary in ("MorrisHolmes", "ConstExtension"):
+    refc = pb_channel.known_answers(boundary)
+    print("conv-channel-edl-potential-2d-morrisholmes-rev722.txt, section", boundary)
+    for N in (32, 64, 128, 256, 512, 1024):
+        r = device_channel(ctx, N, boundary)
+        print("N = %4d  %d fluid particles, FGMRES+SA-AMG iterations %d" % (N, r["particles"], r["iters"]))
+        for name, key in (("total volume", "volume"), ("err.psi.norm2", "err_psi")):
+            print("    %-20s device %.15e   reference %.15e   rel. diff %.1e" % (name, r[key], refc[N][key], abs(r[key] - refc[N][key]) / refc[N][key]))

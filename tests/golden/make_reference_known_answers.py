@@ -1,5 +1,5 @@
 """Regenerates the rows of reference_known_answers.json from the text tables the reference keeps
-(sph-script/conv-taylor-green-vortex-2d-rev{390,230}.txt, conv-poisson-boltzmann-harmonic-2d-rev390.txt).  Runs only where
+(sph-script/conv-taylor-green-vortex-2d-rev{390,230}.txt, conv-poisson-boltzmann-harmonic-2d-rev390.txt, conv-channel-edl-potential-2d-morrisholmes-rev722.txt).  Runs only where
 /root/reference exists (the build container); the JSON it writes is data: expected outputs."""
 import json
 import os
@@ -30,12 +30,21 @@ def parse(fn):
     return out
 
 
-def parse_pb(fn):
+def parse_pb(fn, section=None):
     """conv-poisson-boltzmann-harmonic-2d-rev390.txt: per N the numbers fix isph/error prints (fix_isph_error.cpp:318-340)"""
     out, N = {}, None
+    if section is not None:      # keep only the lines between the title `section` and the next title
+        lines, on = [], False
+        for line in open(fn).read().splitlines():
+            if re.match(r"[A-Z][A-Za-z]+\s*$", line):
+                on = line.strip() == section
+            elif on:
+                lines.append(line)
+    else:
+        lines = open(fn).read().splitlines()
     keys = {"total # of particles": "particles", "total volume": "volume", "sol.psi.norm2": "sol_psi",
             "err.psi.norm2": "err_psi", "sol.psi.grad.norm2": "sol_grad", "err.psi.grad.norm2": "err_grad"}
-    for line in open(fn).read().splitlines():
+    for line in lines:
         m = re.match(r"\s*N = (\d+)", line)
         if m:
             N = m.group(1)
@@ -62,4 +71,10 @@ if __name__ == "__main__":
         "setting": "poisson-boltzmann-harmonic-2d.lmp + poisson-boltzmann-harmonic.xml: periodic [-pi,pi)^2, lattice sq dx "
                    "origin 0, h = 1.5 dx, Wendland cut 2h, corrected (Symmetric) operators, psi = sin x cos y",
         "rows": parse_pb(REF + "conv-poisson-boltzmann-harmonic-2d-rev390.txt")}
+    g["conv_channel_edl_potential_2d_morrisholmes_rev722"] = {
+        "file": "sph-script/conv-channel-edl-potential-2d-morrisholmes-rev722.txt",
+        "setting": "channel-edl-potential-2d.lmp: channel |y| < 1 between solid walls with psi = 1, periodic in x, lattice sq "
+                   "dx origin 0.5, h = 1.2 dx, Wendland cut 2h, MorrisHolmes boundary, linearised Poisson-Boltzmann kappa^2 = 100",
+        "rows": parse_pb(REF + "conv-channel-edl-potential-2d-morrisholmes-rev722.txt", "MorrisHolmes"),
+        "rows_const_extension": parse_pb(REF + "conv-channel-edl-potential-2d-morrisholmes-rev722.txt", "ConstExtension")}
     json.dump(g, open(path, "w"), indent=1)

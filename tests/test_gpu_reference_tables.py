@@ -11,6 +11,8 @@ import pytest
 
 from isph_amd import hip, workload
 import pb_harmonic
+import pb_channel
+import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -68,3 +70,60 @@ def test_device_chain_reproduces_reference_pb_harmonic_table(gpu_ctx, N):
     # against the round-off-converged oracle); >= 8 significant digits hold on every row
     assert abs(r["err_psi"] - ref["err_psi"]) <= 1e-8 * ref["err_psi"], (r, ref)
     assert abs(r["err_grad"] - ref["err_grad"]) <= 1e-8 * ref["err_grad"], (r, ref)
+
+
+# ---------------------------------------------------------------- conv-channel-edl-potential-2d-morrisholmes-rev722.txt
+def device_channel(ctx, N, boundary):
+    """The linearised Poisson-Boltzmann channel problem  -lap_h psi + kappa^2 psi = 0, psi = 1 on the wall particles, IS a
+    Helmholtz system of the hot path: (I - theta dt nu lap_h) psi = b with theta = 1, dt nu = 1 / kappa^2, b = 0 on the
+    fluid rows and the wall value on the solid (identity) rows -- isph_assemble_helmholtz with the MorrisHolmes mirror
+    (functor_boundary_morris_holmes.h:49-64) and isph_solve, nothing on the host but the error norm."""
+    parts, own = pb_channel.channel(N)
+    n, nall = parts["nlocal"], parts["nall"]
+    colmap = own.astype(np.int32)
+    kinds = pb_channel.KINDS
+    vf = hip.compute_volumes(ctx, parts, colmap)
+    vfrac = np.ascontiguousarray(vf[own])
+    pnd = np.ascontiguousarray(hip.compute_pnd(ctx, parts, colmap, kinds=kinds)[own]) if boundary == "MorrisHolmes" else None
+    Gc, Lc = hip.compute_corrections(ctx, parts, colmap, vfrac)
+    solid = parts["type"] == 2
+    vel = np.zeros((nall, 3))
+    vel[solid, 0] = 1.0                                   # wall potential, carried by the identity rows
+    H, b = hip.assemble_helmholtz(ctx, parts, colmap, 1.0 / pb_channel.KAPPA ** 2, 1.0, np.ones(nall), np.ones(nall),
+                                  np.zeros(nall), np.zeros((nall, 3)), np.zeros(3), vel, antisym=False, incremental=True,
+                                  vfrac=vfrac, Gc=Gc, Lc=Lc, kinds=kinds, pnd=pnd, morris_safe_coeff=0.0)
+    rhs = np.ascontiguousarray(b[:n])
+    assert np.array_equal(rhs, solid[:n].astype(float))
+    M = hip.PrecondAMG(ctx, H, params=hip.AmgParams(block=512))
+    psi = np.zeros(n)
+    info = hip.solve(ctx, H, rhs.copy(), psi, prec=M, singular=False, params=hip.SolverParams(tol=1e-13, max_iters=500))
+    assert info.converged == 1
+    fl = ~solid[:n]
+    ex = pb_channel.exact(parts["x"][:n, 1][fl])
+    return dict(particles=int(fl.sum()), volume=float(vf[:n][fl].sum()), err_psi=float(np.sqrt(np.mean((psi[fl] - ex) ** 2))),
+                wall=float(np.max(np.abs(psi[~fl] - 1.0))), iters=info.iters)
+
+
+@pytest.mark.parametrize("boundary", ["MorrisHolmes", "ConstExtension"])
+@pytest.mark.parametrize("N", [32, 64, 128, 256, 512, 1024])
+def test_device_chain_reproduces_reference_channel_table(gpu_ctx, N, boundary):
+    ref = pb_channel.known_answers(boundary)[N]
+    r = device_channel(gpu_ctx, N, boundary)
+    assert r["particles"] == ref["particles"] and r["wall"] <= 1e-12
+    assert abs(r["volume"] - ref["volume"]) <= 2e-12 * ref["volume"]
+    # the smallest error of the table (MorrisHolmes, N = 1024: 9.5e-6) is where the reference's own solver tolerance
+    # shows first (1.4e-8 against the round-off-converged oracle)
+    assert abs(r["err_psi"] - ref["err_psi"]) <= 1e-7 * ref["err_psi"], (r, ref)
+
+
+def test_device_pnd_matches_oracle(gpu_ctx):
+    """isph_compute_pnd vs the oracle's restatement of functor_normal.h:57-133 on the channel geometry"""
+    parts, own = pb_channel.channel(64)
+    n = parts["nlocal"]
+    P = orc.Particles(parts, own, kernel="wendland", kinds=pb_channel.KINDS)
+    po = P.compute_pnd()
+    pg = hip.compute_pnd(gpu_ctx, parts, own.astype(np.int32), kinds=pb_channel.KINDS)
+    assert np.max(np.abs(pg - po[:n])) <= 1e-13 * np.abs(po).max()
+    P.precompute(corrections=False)
+    xi = po[:n] * P.vfrac[:n]
+    assert abs(xi[np.abs(parts["x"][:n, 1]) < 0.5].max() - 1.0) < 1e-13 and 0.5 < xi.min() < 1.0   # half a spacing from the wall: 0.81

@@ -459,3 +459,20 @@ def test_pb_harmonic_known_answer_table_pinned(N):
     assert abs(r["err_psi"] - ref["err_psi"]) <= 1e-10 * ref["err_psi"]
     assert abs(r["err_grad"] - ref["err_grad"]) <= 1e-10 * ref["err_grad"]
     assert r["operator_vs_matrix"] <= 1e-11          # functor_laplacian.h's operator form == the assembled rows
+
+
+@pytest.mark.parametrize("boundary", ["MorrisHolmes", "ConstExtension"])
+@pytest.mark.parametrize("N", [32, 64, 128])
+def test_pb_channel_known_answer_table_pinned(N, boundary):
+    """sph-script/conv-channel-edl-potential-2d-morrisholmes-rev722.txt, both sections (oracle/pb_channel.py): the
+    double layer between two charged walls.  Pins the MorrisHolmes mirror coefficient, the particle number density it
+    measures distances with, and the solid (Dirichlet) columns of the corrected Laplacian rows to the reference's
+    printed digits; "ConstExtension" is the same problem without the mirror."""
+    import pb_channel
+    ref = pb_channel.known_answers(boundary)[N]
+    r = pb_channel.run(N, boundary)
+    assert r["particles"] == ref["particles"]
+    assert abs(r["volume"] - ref["volume"]) <= 2e-13 * ref["volume"]
+    assert abs(r["sol_psi"] - ref["sol_psi"]) <= 1e-14
+    assert abs(r["err_psi"] - ref["err_psi"]) <= 1e-10 * ref["err_psi"]
+    assert 0.5 < r["xi_min"] < 1.0                   # near-wall fluid: between half and all of the support is fluid
