@@ -338,16 +338,25 @@ __global__ void k_gradient_correction(AsmTables T, int nlocal, const double *__r
 
 // L_i from the dimL x dimL system of functor_laplacian_correction.h:24-153, solved by
 // LU with partial pivoting (what LAPACK dgesv does for the reference, utils_reference.cpp:398-407).
-__global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__restrict__ x,
-                                       const int *__restrict__ type, const int *__restrict__ nptr,
-                                       const int *__restrict__ nidx, const double *__restrict__ vfrac,
-                                       const double *__restrict__ Gc, double *__restrict__ Lc, int *__restrict__ nfail) {
+// DIM is a template parameter: with the dimension known every index below is a compile-time constant, the tensors
+// (A 27, L 36, C 9 doubles) stay in registers and the 6 x 6 elimination is straight-line code with predicated row swaps.
+// (With a run-time dimension the same code indexed its local arrays dynamically: 736 B of scratch per lane, 12x slower.)
+template <int DIM>
+__global__ __launch_bounds__(kBlock) void k_laplacian_correction(AsmTables T, int nlocal, const double *__restrict__ x,
+                                                                 const int *__restrict__ type, const int *__restrict__ nptr,
+                                                                 const int *__restrict__ nidx, const double *__restrict__ vfrac,
+                                                                 const double *__restrict__ Gc, double *__restrict__ Lc,
+                                                                 int *__restrict__ nfail) {
   const int i = xcd_block() * blockDim.x + threadIdx.x;
   if (i >= nlocal) return;
-  const int dim = T.dim, d2 = dim * dim, dL = dim * (dim + 1) / 2, nt1 = T.ntypes + 1, it = type[i];
-  double A[27], L[36], G[9];
-  for (int k = 0; k < 27; ++k) A[k] = 0.0;
-  for (int k = 0; k < 36; ++k) L[k] = 0.0;
+  constexpr int dim = DIM, d2 = DIM * DIM, dL = DIM * (DIM + 1) / 2;
+  const int nt1 = T.ntypes + 1, it = type[i];
+  double A[DIM * DIM * DIM], L[dL * dL], G[d2];
+#pragma unroll
+  for (int k = 0; k < DIM * DIM * DIM; ++k) A[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < dL * dL; ++k) L[k] = 0.0;
+#pragma unroll
   for (int k = 0; k < d2; ++k) G[k] = Gc[(size_t)i * d2 + k];
   for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {  // third-order tensor A^{kmn}
     const int j = neigh_at(T, i, jj);
@@ -358,13 +367,19 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
       const double r = sqrt(rsq) + kEps;
       const double rinv = 1.0 / r;
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
-      double aij[3] = {0, 0, 0};
+      double aij[DIM];
+#pragma unroll
       for (int k2 = 0; k2 < dim; ++k2) {
+        aij[k2] = 0.0;
+#pragma unroll
         for (int k1 = 0; k1 < dim; ++k1) aij[k2] += G[k2 * dim + k1] * rij[k1];
         aij[k2] *= dwdr * rinv * vfrac[j];
       }
+#pragma unroll
       for (int k3 = 0; k3 < dim; ++k3)
+#pragma unroll
         for (int k2 = 0; k2 < dim; ++k2)
+#pragma unroll
           for (int k1 = 0; k1 < k2 + 1; ++k1) A[k3 * d2 + k2 * dim + k1] += aij[k3] * rij[k1] * rij[k2];
     }
   }
@@ -377,59 +392,90 @@ __global__ void k_laplacian_correction(AsmTables T, int nlocal, const double *__
       const double r = sqrt(rsq) + kEps;
       const double rinv = 1.0 / r;
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
-      double e[3] = {0, 0, 0};
+      double e[DIM];
+#pragma unroll
       for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
-      double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double C[d2];
+#pragma unroll
+      for (int k = 0; k < d2; ++k) C[k] = 0.0;
+#pragma unroll
       for (int k3 = 0; k3 < dim; ++k3)
+#pragma unroll
         for (int k2 = 0; k2 < dim; ++k2)
+#pragma unroll
           for (int k1 = 0; k1 < k2 + 1; ++k1) C[k2 * dim + k1] += A[k3 * d2 + k2 * dim + k1] * e[k3];
+#pragma unroll
       for (int k2 = 0; k2 < dim; ++k2)
+#pragma unroll
         for (int k1 = 0; k1 < k2 + 1; ++k1) {
           C[k2 * dim + k1] += rij[k1] * e[k2];
           C[k2 * dim + k1] *= dwdr * vfrac[j];
         }
-      for (int k4 = 0, op = 0; k4 < dim; ++k4)
-        for (int k3 = 0; k3 < k4 + 1; ++k3, ++op)
-          for (int k2 = 0, mn = 0; k2 < dim; ++k2)
-            for (int k1 = 0; k1 < k2 + 1; ++k1, ++mn)
+#pragma unroll
+      for (int k4 = 0; k4 < dim; ++k4)
+#pragma unroll
+        for (int k3 = 0; k3 < k4 + 1; ++k3) {
+          const int op = k4 * (k4 + 1) / 2 + k3;
+#pragma unroll
+          for (int k2 = 0; k2 < dim; ++k2)
+#pragma unroll
+            for (int k1 = 0; k1 < k2 + 1; ++k1) {
+              const int mn = k2 * (k2 + 1) / 2 + k1;
               L[op * dL + mn] += C[k2 * dim + k1] * e[k3] * e[k4] * (k3 == k4 ? 1.0 : 2.0);
+            }
+        }
     }
   }
-  double rhs[6];
-  for (int k2 = 0, op = 0; k2 < dim; ++k2)
-    for (int k1 = 0; k1 < k2 + 1; ++k1, ++op) rhs[op] = -(double)(k1 == k2);
-  // LU with partial pivoting, column-major L[col*dL + row]
+  double rhs[dL];
+#pragma unroll
+  for (int k2 = 0; k2 < dim; ++k2)
+#pragma unroll
+    for (int k1 = 0; k1 < k2 + 1; ++k1) rhs[k2 * (k2 + 1) / 2 + k1] = -(double)(k1 == k2);
+  // LU with partial pivoting (first largest entry of the column), column-major L[col*dL + row]
   bool singular = false;
+#pragma unroll
   for (int k = 0; k < dL; ++k) {
     int pv = k;
     double amax = fabs(L[k * dL + k]);
-    for (int r2 = k + 1; r2 < dL; ++r2)
-      if (fabs(L[k * dL + r2]) > amax) { amax = fabs(L[k * dL + r2]); pv = r2; }
-    if (amax == 0.0) { singular = true; break; }
-    if (pv != k) {
-      for (int c = 0; c < dL; ++c) { const double t = L[c * dL + k]; L[c * dL + k] = L[c * dL + pv]; L[c * dL + pv] = t; }
-      const double t = rhs[k]; rhs[k] = rhs[pv]; rhs[pv] = t;
+#pragma unroll
+    for (int r2 = k + 1; r2 < dL; ++r2) {
+      const double a = fabs(L[k * dL + r2]);
+      if (a > amax) { amax = a; pv = r2; }
     }
+    if (amax == 0.0) singular = true;
+#pragma unroll
+    for (int r2 = k + 1; r2 < dL; ++r2)
+      if (pv == r2) {  // swap rows k and r2
+#pragma unroll
+        for (int c = 0; c < dL; ++c) { const double t = L[c * dL + k]; L[c * dL + k] = L[c * dL + r2]; L[c * dL + r2] = t; }
+        const double t = rhs[k]; rhs[k] = rhs[r2]; rhs[r2] = t;
+      }
     const double piv = 1.0 / L[k * dL + k];
+#pragma unroll
     for (int r2 = k + 1; r2 < dL; ++r2) {
       const double l = L[k * dL + r2] * piv;
       L[k * dL + r2] = l;
       if (l != 0.0) {
+#pragma unroll
         for (int c = k + 1; c < dL; ++c) L[c * dL + r2] -= l * L[c * dL + k];
         rhs[r2] -= l * rhs[k];
       }
     }
   }
-  if (singular) {
+  if (singular) {  // a zero pivot column: the entries computed past it are meaningless and dropped
     atomicAdd(nfail, 1);
+#pragma unroll
     for (int k = 0; k < dL; ++k) Lc[(size_t)i * dL + k] = 0.0;
     return;
   }
+#pragma unroll
   for (int r2 = dL - 1; r2 >= 0; --r2) {
     double sacc = rhs[r2];
+#pragma unroll
     for (int c = r2 + 1; c < dL; ++c) sacc -= L[c * dL + r2] * rhs[c];
     rhs[r2] = sacc / L[r2 * dL + r2];
   }
+#pragma unroll
   for (int k = 0; k < dL; ++k) Lc[(size_t)i * dL + k] = rhs[k];
 }
 
@@ -1429,7 +1475,11 @@ inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *G
     const int grid = (n + kBlock - 1) / kBlock;
     if (hipMemsetAsync(nf.p, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
     hipLaunchKernelGGL(k_gradient_correction, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf, dG);
-    hipLaunchKernelGGL(k_laplacian_correction, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf,
+    if (P->dim == 3)
+      hipLaunchKernelGGL((k_laplacian_correction<3>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf,
+                       (const double *)dG, dLc, nf.p);
+    else
+      hipLaunchKernelGGL((k_laplacian_correction<2>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, dx, dt, dp, di, dvf,
                        (const double *)dG, dLc, nf.p);
     if (!on_device) {
       if (hipMemcpyAsync(Gc_out, dG, sizeof(double) * (size_t)n * d2, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
