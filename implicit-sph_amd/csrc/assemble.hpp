@@ -1281,6 +1281,8 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
       if (T.dim == 3 && a.antisym)
         hipLaunchKernelGGL((k_asm_poisson<3, 1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+      else if (T.dim == 3)  // 3-D, Symmetric (corrected) family: G_i / L_i loops with compile-time bounds
+        hipLaunchKernelGGL((k_asm_poisson<3, 0>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
       else
         hipLaunchKernelGGL((k_asm_poisson<0, -1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
       if (n <= 32768) {  // tiny boxes may see the same tag twice in a row
@@ -1404,6 +1406,8 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
         double *mval = rhs_only ? (double *)nullptr : M.val.p;
         if (T.dim == 3 && antisym)
           hipLaunchKernelGGL((k_asm_helmholtz<3, 1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
+        else if (T.dim == 3)
+          hipLaunchKernelGGL((k_asm_helmholtz<3, 0>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
         else
           hipLaunchKernelGGL((k_asm_helmholtz<0, -1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, mcol, mval, db);
       }

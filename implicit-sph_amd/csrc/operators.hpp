@@ -311,6 +311,22 @@ inline int op_stage(isph_ctx *ctx, const isph_particles *P, int antisym, int on_
 }
 
 // mode 0: gradient of a scalar [nall] -> [nlocal][3]; mode 1: divergence of a vector [nall][3] -> [nlocal]
+
+// family / dimension dispatch of the two row operators: 3-D with the family known at compile time (the correction-tensor
+// loops fold away or unroll), everything else through the run-time variant
+template <class ARGS>
+inline void launch_gradient(isph_ctx *ctx, const AsmTables &T, const ARGS &a, int grid, const double *f, double *out) {
+  if (T.dim == 3 && a.antisym) hipLaunchKernelGGL((k_gradient<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, a, f, out);
+  else if (T.dim == 3) hipLaunchKernelGGL((k_gradient<3, 0>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, a, f, out);
+  else hipLaunchKernelGGL((k_gradient<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, a, f, out);
+}
+template <class ARGS>
+inline void launch_divergence(isph_ctx *ctx, const AsmTables &T, const ARGS &a, int grid, const double *f, double *out) {
+  if (T.dim == 3 && a.antisym) hipLaunchKernelGGL((k_divergence<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, a, f, out);
+  else if (T.dim == 3) hipLaunchKernelGGL((k_divergence<3, 0>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, a, f, out);
+  else hipLaunchKernelGGL((k_divergence<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, a, f, out);
+}
+
 inline int op_apply(isph_ctx *ctx, const isph_particles *P, int mode, int antisym, const double *f, double alpha,
                     int use_filter, int filt_i, int filt_j, double *out, int on_device) {
   OpStage st;
@@ -324,11 +340,8 @@ inline int op_apply(isph_ctx *ctx, const isph_particles *P, int mode, int antisy
   if (rc == ISPH_SUCCESS && n > 0) {
     st.a.alpha = alpha; st.a.use_filter = use_filter; st.a.filt_i = filt_i; st.a.filt_j = filt_j;
     const int grid = (n + kBlock - 1) / kBlock;
-    const bool fast = st.T.dim == 3 && st.a.antisym;
-    if (mode == 0 && fast) hipLaunchKernelGGL((k_gradient<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
-    else if (mode == 0) hipLaunchKernelGGL((k_gradient<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
-    else if (fast) hipLaunchKernelGGL((k_divergence<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
-    else hipLaunchKernelGGL((k_divergence<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, df, dout);
+    if (mode == 0) launch_gradient(ctx, st.T, st.a, grid, df, dout);
+    else launch_divergence(ctx, st.T, st.a, grid, df, dout);
     if (!on_device && hipMemcpyAsync(out, dout, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = fail("copy failed", __FILE__, __LINE__);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
@@ -376,10 +389,7 @@ inline int correct_velocity_pressure(isph_ctx *ctx, const isph_particles *P, int
   if (rc == ISPH_SUCCESS && n > 0) {
     st.a.alpha = 1.0; st.a.use_filter = 1; st.a.filt_i = KIND_FLUID; st.a.filt_j = KIND_FLUID;
     const int grid = (n + kBlock - 1) / kBlock;
-    if (st.T.dim == 3 && st.a.antisym)
-      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
-    else
-      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, ddp, grad.p);
+    launch_gradient(ctx, st.T, st.a, grid, ddp, grad.p);
     hipLaunchKernelGGL(k_correct_velocity, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, dt, st.a.type, st.T.kind,
                        drho, (const double *)grad.p, iv.dev);
     hipLaunchKernelGGL(k_correct_pressure, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall,
@@ -410,10 +420,7 @@ inline int advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, do
   if (rc == ISPH_SUCCESS && n > 0) {
     st.a.alpha = 1.0; st.a.use_filter = 1; st.a.filt_i = KIND_FLUID; st.a.filt_j = KIND_FLUID;
     const int grid = (n + kBlock - 1) / kBlock;
-    if (st.T.dim == 3 && st.a.antisym)
-      hipLaunchKernelGGL((k_gradient<3, 1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
-    else
-      hipLaunchKernelGGL((k_gradient<0, -1>), dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, dpp, grad.p);
+    launch_gradient(ctx, st.T, st.a, grid, dpp, grad.p);
     hipLaunchKernelGGL(k_advance_begin, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, dt, st.a.type, st.T.kind,
                        (const double *)grad.p, dv, dvn, dout);
     if (!on_device && hipMemcpyAsync(dp_out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
