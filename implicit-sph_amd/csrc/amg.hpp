@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void k_amg_rho(int n, const rp_t *__restrict__
   double s = 0.0;
   for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64)
     if (ci[p] < n) s += fabs(v[p]);
+  if (dg[i] == 0.0) return;  // empty row of a coarse operator (wave-uniform: see k_sgs_pivots)
   s = wave_sum(s) / fabs(dg[i]);
   // one atomic per row would serialise a million updates of one word: only candidates above the running maximum try
   const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256) void k_prolong(int n, const rp_t *__restrict__
   for (int t = 0; t < kProlongSlots; ++t) { tkey[t] = 0x7fffffff; tval[t] = 0.0; }
   const int ai = agg[i];
   if (ai >= 0) { if (lane == 0) { tkey[0] = ai; tval[0] = pt[i]; } cnt = 1; }
-  const double f = damp / dg[i];
+  const double f = dg[i] != 0.0 ? damp / dg[i] : 0.0;
   for (rp_t p0 = rp[i]; p0 < rp[i + 1]; p0 += 64) {
     const rp_t p = p0 + lane;
     int a = -1;

@@ -776,7 +776,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
 __global__ void k_sgs_pivots(int n, const long long *__restrict__ frp, const double *__restrict__ fval,
                              const int *__restrict__ fdiag, double *__restrict__ dinv) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dinv[i] = 1.0 / fval[frp[i] + fdiag[i]];
+  // an empty row (a coarse unknown whose aggregate carries none of a masked null vector: zero column in P, zero row
+  // in R A P) keeps its unknown at zero instead of dividing by its zero pivot
+  if (i < n) { const double d = fval[frp[i] + fdiag[i]]; dinv[i] = d != 0.0 ? 1.0 / d : 0.0; }
 }
 // ---------------------------------------------------------------------------
 // z = U^-1 D^-1 L^-1 r : one wave per block streams the block's chunk list.

@@ -214,7 +214,9 @@ static void build_prolongator(const csr_t *A, const int *agg, int nagg, const do
   for (int i = 0; i < n; ++i) {
     double s = 0.0;
     for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) if (A->ci[p] < n) s += fabs(A->v[p]);
-    s /= fabs(diag_of(A, i));
+    const double d = fabs(diag_of(A, i));
+    if (d == 0.0) continue; /* empty row of a coarse operator (see the smoother's pivots) */
+    s /= d;
     if (s > rho) rho = s;
   }
   const double damp = rho > 0.0 ? omega / rho : 0.0;
@@ -237,7 +239,7 @@ static void build_prolongator(const csr_t *A, const int *agg, int nagg, const do
       if (j >= n || agg[j] < 0) continue;
       const int a = agg[j];
       if (mark[a] != i) { mark[a] = i; P->ci[nnz++] = a; acc[a] = 0.0; }
-      acc[a] -= damp / di * A->v[p] * pt[j];
+      acc[a] -= (di != 0.0 ? damp / di : 0.0) * A->v[p] * pt[j];
     }
     /* ascending columns */
     for (int p = start + 1; p < nnz; ++p) {
@@ -428,7 +430,9 @@ orc_amg *orc_amg_create_ex(int n, const int *rowptr, const int *colidx, const do
     G->b[l] = (double *)calloc(m, sizeof(double));
     G->r[l] = (double *)calloc(m, sizeof(double));
     G->dinv[l] = (double *)malloc(sizeof(double) * m);
-    for (int i = 0; i < G->A[l].n; ++i) G->dinv[l][i] = 1.0 / diag_of(&G->A[l], i);
+    /* a coarse unknown whose aggregate carries none of the null vector (a masked null vector: solid rows) has an
+     * empty column in P and an empty row in R A P: it stays at zero instead of dividing by its zero pivot */
+    for (int i = 0; i < G->A[l].n; ++i) { const double d = diag_of(&G->A[l], i); G->dinv[l][i] = d != 0.0 ? 1.0 / d : 0.0; }
   }
   G->coarse_smooth = G->singular || G->A[G->nlev - 1].n > AMG_DENSE_MAX;
   if (!G->coarse_smooth) {

@@ -72,6 +72,38 @@ def test_cavity_small_matches_oracle(gpu_ctx, antisym):
     assert np.linalg.norm(xp - xpo) <= 1e-6 * np.linalg.norm(xpo)
 
 
+def test_cavity_poisson_sa_amg_with_masked_null_vector(gpu_ctx):
+    """lid-driven-cavity.xml:30-32 selects ML.  The singular pressure system hands ML the null vector masked to the fluid
+    rows (pair_isph.cpp:996-1003, precond_ml.h:97-127): aggregates made of wall particles only carry none of it, their
+    column of P and their row of R A P are empty.  Those coarse unknowns stay at zero (no division by the zero pivot) --
+    before that guard the cycle produced NaN and FGMRES ran into its iteration limit.  Device vs oracle: same hierarchy,
+    iterations +-1, x <= 1e-6; and the preconditioner beats block ILU(0) on this system."""
+    p = workload.make_cavity(14, wall=4, brick=(4, 4, 4), jitter=0.02)
+    colmap = workload.single_rank_colmap(p)
+    n, nall = p["nlocal"], p["nall"]
+    P = _oracle_particles(p, colmap)
+    rng = np.random.default_rng(5)
+    vstar = np.zeros((nall, 3))
+    vstar[:n] = rng.standard_normal((n, 3)) * (p["type"][:n, None] == 1)
+    vstar = np.ascontiguousarray(vstar[colmap])
+    rp, ci, val, b = P.poisson(p["dt"], p["rho"], vstar, antisym=True, singular=orc.NULLSPACE, normal=p["normal"])
+    mask = (p["type"][:n] == 1).astype(np.int32)
+    nv = mask / np.sqrt(float(mask.sum()))
+    G = orc.AMG(rp, ci, val, nullvec=nv, block=512)
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=True, null_mask=mask, prec="amg", amg=G)
+    bp = np.arange(0, n + 512, 512).clip(0, n).astype(np.int32)
+    _, ii, _ = orc.solve(rp, ci, val, b, singular=True, null_mask=mask, prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
+    assert io.converged == 1 and ii.converged == 1 and io.iters < ii.iters
+    A, bg = hip.assemble_poisson(gpu_ctx, p, colmap, p["dt"], p["rho"], vstar, antisym=True, vfrac=P.vfrac, Gc=P.Gc,
+                                 kinds=p["kinds"], normal=p["normal"])
+    M = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(block=512))
+    assert M.levels == G.levels and M.levels >= 2
+    x = np.zeros(n)
+    info = hip.solve(gpu_ctx, A, bg.copy(), x, prec=M, singular=True, null_mask=mask)
+    assert info.converged == 1 and abs(info.iters - io.iters) <= 1
+    assert np.all(np.isfinite(x)) and np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
 def test_cavity_config3_full_size_properties(gpu_ctx):
     """126^3 = 2 000 376 particles (114^3 fluid + 6 wall layers, the .m script's nn = 6): the 3x3 block Helmholtz system
     and the pressure Poisson system of one time step, assembled and solved on the device with torch-resident arrays.
