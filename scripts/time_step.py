@@ -71,5 +71,10 @@ for step in range(4):
     hip.correct_velocity_pressure(ctx, dp, colmap, dt, rho, dp_all, vstar_all, p, vfrac)
     dpa = hip.advance_begin(ctx, dp, colmap, dt, p, v, vstar_all, vfrac)
     t5 = sync()
+    if os.environ.get("ISPH_SHIFT"):              # fix isph/shift 0.05 (taylor-green-vortex-3d.lmp): timed on copies
+        xs, vs_, ps = dp["x"].clone(), v.clone(), p.clone()
+        t6 = sync()
+        hip.shift_particles(ctx, dp, colmap, 0.05, spec.cut, 0.1, dt, xs, vs_, ps, vfrac)
+        print("        particle shift %.1f ms" % ((sync() - t6) * 1e3))
     print("step %d: computePre %.1f  helmholtz %.1f [%d its]  poisson-assemble %.1f  solve(+ILU) %.1f [%d its]  correct+advance %.1f  total %.1f ms"
           % (step, (t1 - t0) * 1e3, (t2 - t1) * 1e3, hits, (t3 - t2) * 1e3, (t4 - t3) * 1e3, info.iters, (t5 - t4) * 1e3, (t5 - t0) * 1e3))
