@@ -104,6 +104,47 @@ def test_cavity_poisson_sa_amg_with_masked_null_vector(gpu_ctx):
     assert np.all(np.isfinite(x)) and np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
 
 
+@pytest.mark.parametrize("prec", ["bjacobi-ilu0", "sa-amg"])
+@pytest.mark.parametrize("morris", [False, True])
+@pytest.mark.parametrize("singular", ["NullSpace", "PinZero", "DoubleDiag", "NotSingular"])
+def test_wall_bounded_poisson_every_singular_mode_and_preconditioner(gpu_ctx, singular, morris, prec):
+    """The combinations the reference's scripts select for wall-bounded flows (sph-script/*.xml: "Singular Poisson" in
+    {NullSpace, PinZero, NotSingular}, boundary MorrisHolmes or none, Ifpack or ML) on a 36^3 closed box without wall
+    normals (solid rows are identity rows): every one must converge to 1e-8 with a finite solution, and the residual
+    re-computed with an independent SpMV must agree."""
+    p = workload.make_cavity(28, wall=4)
+    colmap = workload.single_rank_colmap(p)
+    n, nall = p["nlocal"], p["nall"]
+    mode = {"NullSpace": hip.NULLSPACE, "PinZero": hip.PINZERO, "DoubleDiag": hip.DOUBLEDIAG, "NotSingular": hip.NOT_SINGULAR}[singular]
+    vf = hip.compute_volumes(gpu_ctx, p, colmap)
+    vfrac = np.ascontiguousarray(vf[colmap])
+    pnd = np.ascontiguousarray(hip.compute_pnd(gpu_ctx, p, colmap, kinds=p["kinds"])[colmap]) if morris else None
+    rng = np.random.default_rng(11)
+    vstar = np.zeros((nall, 3))
+    vstar[:n] = 0.1 * rng.standard_normal((n, 3)) * (p["type"][:n, None] == 1)
+    vstar = np.ascontiguousarray(vstar[colmap])
+    A, b = hip.assemble_poisson(gpu_ctx, p, colmap, p["dt"], p["rho"], vstar, antisym=True, singular=mode, vfrac=vfrac,
+                                kinds=p["kinds"], pnd=pnd)
+    null = singular == "NullSpace"
+    mask = (p["type"][:n] == 1).astype(np.int32) if null else None
+    if prec == "sa-amg":
+        nv = mask / np.sqrt(float(mask.sum())) if null else None
+        M = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(block=512))
+    else:
+        M = hip.Precond(gpu_ctx, A, prec, 512)
+    x = np.zeros(n)
+    bw = b.copy()
+    info = hip.solve(gpu_ctx, A, bw, x, prec=M, singular=null, null_mask=mask)
+    assert info.converged == 1 and np.all(np.isfinite(x)), (singular, morris, prec, info.iters)
+    r = bw - A.spmv(x)
+    if null:                                             # solved in the complement of the masked null vector
+        nvv = mask / np.sqrt(float(mask.sum()))
+        r -= (r @ nvv) * nvv
+    assert np.linalg.norm(r) <= 5e-8 * np.linalg.norm(bw)
+    solid = p["type"][:n] >= 2
+    assert np.max(np.abs(x[solid])) <= 1e-12 * max(np.max(np.abs(x)), 1e-300)   # identity rows with b = 0
+
+
 def test_cavity_config3_full_size_properties(gpu_ctx):
     """126^3 = 2 000 376 particles (114^3 fluid + 6 wall layers, the .m script's nn = 6): the 3x3 block Helmholtz system
     and the pressure Poisson system of one time step, assembled and solved on the device with torch-resident arrays.
