@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ncell", type=int, default=100, help="lattice cells per axis PER GPU brick edge")
     ap.add_argument("--mode", default="advect", choices=["advect", "jitter", "lattice"])
-    ap.add_argument("--prec", default="bjacobi-ilu0", choices=["none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg", "ilu0", "ilu1",
+    ap.add_argument("--prec", default="bjacobi-ilu0", choices=["none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg", "ilu0", "ilu1", "overlap-ilu0", "overlap-ilu1",
                              "schwarz-ilu0", "schwarz-ilu1"],
                     help="bjacobi-ilu<k>: block stream (production); ilu<k>: ILU(k) of the whole local matrix = Ifpack on one "
                          "rank; schwarz-ilu<k>: --block rows per subdomain + --overlap layers, level-scheduled (fidelity path)")
@@ -275,6 +275,16 @@ def main():
             M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(args.prec[-1]), overlap=0, block_size=0)
             if not pinfo:
                 pinfo.update(M.schwarz_info())
+        elif args.prec.startswith("overlap-ilu"):
+            # Ifpack on N ranks with "Overlap Level" 1: this rank's rows + the rows of its ghost columns, one ILU(k) block
+            assert plan.npeers, "overlap-ilu<k> needs ghost columns (--gpus > 1 or --force-rccl)"
+            rpl, cil, vall = A.export_csr()
+            rpe, cie, ve = dist.extend_rows(plan, rpl, cil, vall, td)
+            Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
+            M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=int(args.prec[-1]), combine=args.combine)
+            Aext.close()
+            if not pinfo:
+                pinfo.update(extended_rows=len(rpe) - 1, extended_nnz=int(rpe[-1]))
         else:
             M = hip.Precond(ctx, A, args.prec, args.block)
         if not pinfo and args.prec.startswith("bjacobi-ilu"):

@@ -49,12 +49,15 @@ struct isph_mat {
 struct isph_ilu;  // ilu.hpp
 struct isph_amg;  // amg.hpp
 struct isph_schwarz;  // schwarz.hpp
+struct isph_overlap;  // isph_capi.hip: overlap-1 Schwarz across ranks
 
 struct isph_prec {
-  int type = 0;  // 0 none, 1 jacobi, 2 bjacobi-ilu<k> (block stream), 3 sa-amg, 4 additive Schwarz ILU(k) (schwarz.hpp)
+  int type = 0;  // 0 none, 1 jacobi, 2 bjacobi-ilu<k> (block stream), 3 sa-amg, 4 additive Schwarz ILU(k) (schwarz.hpp),
+                 // 5 ILU(k) of the rank's rows + one layer of the neighbours' rows (isph_prec_create_overlap)
   int n = 0;
   isph::DevBuf<double> invdiag;
   isph_ilu *ilu = nullptr;
   isph_amg *amg = nullptr;
   isph_schwarz *schwarz = nullptr;
+  isph_overlap *ovl = nullptr;
 };

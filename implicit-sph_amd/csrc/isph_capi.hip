@@ -18,6 +18,74 @@
 namespace isph {
 thread_local std::string g_last_error;
 
+}  // namespace isph (reopened below)
+
+// Ifpack_AdditiveSchwarz<ILU(k)> with "Overlap Level" 1 on more than one rank (precond_ifpack.h:43,60-74): the rank's
+// subdomain is its own rows plus the rows of its ghost columns (Ifpack_OverlappingRowMatrix); the extended matrix is
+// built by the caller (Epetra_Import of the rows; dist.extend_rows in the Python plumbing) and factored as one block by
+// the level-scheduled path of schwarz.hpp.  An application gathers the ghost part of r with the matrix' halo plan,
+// solves on the extended vector and -- combine mode Add, the wrapper's default -- sends the ghost part of the result
+// back to its owners, who add it; Zero keeps the owned part only (restricted additive Schwarz).
+struct isph_overlap {
+  int n = 0, next = 0, combine = 0;
+  isph_schwarz *inner = nullptr;
+  isph_halo H;
+  isph::DevBuf<double> rext, zext, sbuf, rbuf;
+};
+
+namespace isph {
+
+__global__ void k_scatter_add(int n, const int *__restrict__ idx, const double *__restrict__ v, double *__restrict__ z) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) z[idx[i]] += v[i];
+}
+
+inline void overlap_destroy(isph_overlap *O) {
+  if (!O) return;
+  if (O->inner) schwarz_destroy(O->inner);
+  O->H.send_idx.release();
+  O->rext.release(); O->zext.release(); O->sbuf.release(); O->rbuf.release();
+  delete O;
+}
+
+inline int overlap_exchange(isph_ctx *ctx, const isph_halo &H, const double *send, double *recv, bool reverse) {
+  // forward: send[send range p] -> peer p, recv[recv range p] <- peer p; reverse: the two roles swapped
+  if (H.npeers == 0) return ISPH_SUCCESS;
+  ISPH_REQUIRE(ctx->comm, "no communicator");
+  ncclResult_t nr = ncclGroupStart();
+  for (int p = 0; p < H.npeers && nr == ncclSuccess; ++p) {
+    const int s0 = reverse ? H.recv_ptr[(size_t)p] : H.send_ptr[(size_t)p], s1 = reverse ? H.recv_ptr[(size_t)p + 1] : H.send_ptr[(size_t)p + 1];
+    const int r0 = reverse ? H.send_ptr[(size_t)p] : H.recv_ptr[(size_t)p], r1 = reverse ? H.send_ptr[(size_t)p + 1] : H.recv_ptr[(size_t)p + 1];
+    if (s1 > s0) nr = ncclSend(send + s0, (size_t)(s1 - s0), ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
+    if (nr == ncclSuccess && r1 > r0) nr = ncclRecv(recv + r0, (size_t)(r1 - r0), ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
+  }
+  const ncclResult_t ne = ncclGroupEnd();
+  if (nr != ncclSuccess || ne != ncclSuccess) return fail("RCCL exchange of the overlap rows failed", __FILE__, __LINE__);
+  return ISPH_SUCCESS;
+}
+
+inline int overlap_apply(isph_ctx *ctx, const isph_overlap *O, const double *r, double *z) {
+  const isph_halo &H = O->H;
+  const int n = O->n;
+  ISPH_CHECK_HIP(hipMemcpyAsync(O->rext.p, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  if (H.nsend > 0)
+    hipLaunchKernelGGL(k_gather, dim3(stream_grid(H.nsend)), dim3(kBlock), 0, ctx->stream, H.nsend, (const int *)H.send_idx.p, r,
+                       O->sbuf.p);
+  ISPH_CHECK(overlap_exchange(ctx, H, O->sbuf.p, O->rext.p + n, false));
+  ISPH_CHECK(schwarz_apply(ctx, O->inner, O->rext.p, O->zext.p));
+  ISPH_CHECK_HIP(hipMemcpyAsync(z, O->zext.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  if (O->combine == 0 && H.nrecv > 0) {  // Add: the neighbours' corrections of my rows come home
+    ISPH_CHECK(overlap_exchange(ctx, H, O->zext.p + n, O->rbuf.p, true));
+    for (int p = 0; p < H.npeers; ++p) {  // one launch per peer: a row can be in several peers' lists, never twice in one
+      const int s0 = H.send_ptr[(size_t)p], cnt = H.send_ptr[(size_t)p + 1] - s0;
+      if (cnt > 0)
+        hipLaunchKernelGGL(k_scatter_add, dim3(stream_grid(cnt)), dim3(kBlock), 0, ctx->stream, cnt, (const int *)H.send_idx.p + s0,
+                           (const double *)O->rbuf.p + s0, z);
+    }
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
 int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z) {
   ISPH_REQUIRE(M != nullptr, "preconditioner is NULL");
   const int n = M->n;
@@ -32,6 +100,7 @@ int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z
   }
   if (M->type == 3) return amg_apply(ctx, M->amg, r, z);
   if (M->type == 4) return schwarz_apply(ctx, M->schwarz, r, z);
+  if (M->type == 5) return overlap_apply(ctx, M->ovl, r, z);
   return ilu_apply(ctx, M->ilu, r, z);
 }
 
@@ -618,6 +687,7 @@ void isph_prec_destroy(isph_prec *M) {
   if (M->ilu) ilu_destroy(M->ilu);
   if (M->amg) amg_destroy(M->amg);
   if (M->schwarz) schwarz_destroy(M->schwarz);
+  if (M->ovl) overlap_destroy(M->ovl);
   delete M;
 }
 
@@ -650,6 +720,45 @@ int isph_prec_schwarz_export(isph_ctx *ctx, const isph_prec *M, int *rows, int *
                              double *val) {
   ISPH_REQUIRE(ctx && M && M->type == 4 && M->schwarz && rows && loc_ptr && rowptr && colidx && val, "bad argument");
   return schwarz_export(ctx, M->schwarz, rows, loc_ptr, rowptr, colidx, val);
+}
+
+int isph_prec_create_overlap(isph_ctx *ctx, const isph_mat *Aext, int nlocal, int level_of_fill, int combine, int npeers,
+                             const int *peer_rank, const int *send_ptr, const int *send_idx, const int *recv_ptr,
+                             isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && Aext && Mout && nlocal >= 0 && npeers >= 0 && (combine == 0 || combine == 1), "bad argument");
+  ISPH_REQUIRE(npeers == 0 || (peer_rank && send_ptr && send_idx && recv_ptr), "NULL halo lists");
+  ISPH_REQUIRE(npeers == 0 || ctx->comm, "overlap across ranks needs a context made by isph_ctx_create_dist");
+  const int nrecv = npeers > 0 ? recv_ptr[npeers] : 0, nsend = npeers > 0 ? send_ptr[npeers] : 0;
+  ISPH_REQUIRE(Aext->S.nrow == nlocal + nrecv && Aext->S.ncol == Aext->S.nrow,
+               "the extended matrix must be square with nlocal + (number of ghost columns) rows");
+  for (int p = 0; p < npeers; ++p) ISPH_REQUIRE(peer_rank[p] >= 0 && peer_rank[p] < ctx->nranks, "peer rank out of range");
+  for (int k = 0; k < nsend; ++k) ISPH_REQUIRE(send_idx[k] >= 0 && send_idx[k] < nlocal, "send index out of range");
+  isph_prec *M = new isph_prec();
+  M->n = nlocal;
+  M->type = 5;
+  isph_overlap *O = new isph_overlap();
+  M->ovl = O;
+  O->n = nlocal; O->next = nlocal + nrecv; O->combine = combine;
+  isph_halo &H = O->H;
+  H.npeers = npeers;
+  H.peer.assign(peer_rank, peer_rank + npeers);
+  H.send_ptr.assign(1, 0); H.recv_ptr.assign(1, 0);
+  if (npeers > 0) { H.send_ptr.assign(send_ptr, send_ptr + npeers + 1); H.recv_ptr.assign(recv_ptr, recv_ptr + npeers + 1); }
+  H.nsend = nsend; H.nrecv = nrecv;
+  int rc = H.send_idx.reserve((size_t)(nsend > 0 ? nsend : 1));
+  if (rc == ISPH_SUCCESS && nsend > 0 &&
+      hipMemcpyAsync(H.send_idx.p, send_idx, sizeof(int) * (size_t)nsend, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    rc = fail("copy of the send list failed", __FILE__, __LINE__);
+  if (rc == ISPH_SUCCESS) rc = O->rext.reserve((size_t)(O->next > 0 ? O->next : 1));
+  if (rc == ISPH_SUCCESS) rc = O->zext.reserve((size_t)(O->next > 0 ? O->next : 1));
+  if (rc == ISPH_SUCCESS) rc = O->sbuf.reserve((size_t)(nsend > 0 ? nsend : 1));
+  if (rc == ISPH_SUCCESS) rc = O->rbuf.reserve((size_t)(nsend > 0 ? nsend : 1));
+  // one subdomain = the whole extended matrix, no further layers inside it
+  if (rc == ISPH_SUCCESS) rc = schwarz_create(ctx, Aext, level_of_fill, /*block_size=*/0, /*overlap=*/0, /*combine=*/1, &O->inner);
+  if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("overlap set-up failed", __FILE__, __LINE__);
+  if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
+  *Mout = M;
+  return ISPH_SUCCESS;
 }
 
 /* ---- SA-AMG ----------------------------------------------------------- */

@@ -28,6 +28,7 @@ class HaloPlan:
     send_idx: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     recv_ptr: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
     ghost_col_of: np.ndarray = None   # [nall-nlocal] column of each ghost particle
+    recv_idx: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))   # owner-local row of every ghost column
 
     @property
     def npeers(self):
@@ -49,6 +50,7 @@ def make_self_halo_plan(parts):
     plan = HaloPlan(me, 1, nlocal, nlocal + len(uidx), colmap, np.asarray([me], np.int32),
                     np.asarray([0, len(uidx)], np.int32), uidx.astype(np.int32), np.asarray([0, len(uidx)], np.int32))
     plan.ghost_col_of = colmap[nlocal:].copy()
+    plan.recv_idx = uidx.astype(np.int32)
     return plan
 
 
@@ -95,6 +97,8 @@ def make_plan(parts, td=None):
                     np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32),
                     np.asarray(recv_ptr, np.int32))
     plan.ghost_col_of = colmap[nlocal:].copy()
+    plan.recv_idx = np.concatenate([np.asarray(want.get(p, np.zeros(0, np.int32)), dtype=np.int32) for p in peers]) \
+        if peers else np.zeros(0, np.int32)
     return plan
 
 
@@ -146,3 +150,78 @@ def forward_scalar_rccl(fwd, plan, owned):
         ext = torch.cat([owned[:plan.nlocal], ghosts])
         return ext[torch.from_numpy(plan.colmap.astype(np.int64)).to(ext.device)].contiguous()
     return np.concatenate([owned[:plan.nlocal], ghosts])[plan.colmap]
+
+
+def extend_rows(plan, rowptr, colidx, val, td=None):
+    """The matrix of this rank's subdomain extended by one layer ("Overlap Level" 1 across ranks,
+    precond_ifpack.h:43,63: Ifpack_OverlappingRowMatrix): rows [0, nlocal) are the local rows as they are, row
+    nlocal + g is the row of ghost column g, received from its owner and restricted to this rank's extended column set
+    (owned + ghost columns); entries that point further out are dropped.  Returns CSR (rowptr, colidx, val) of the
+    square (nlocal + nghost) matrix, columns ascending.  td: torch.distributed, or None for a single-rank plan whose
+    only peer is the rank itself (make_self_halo_plan: the ghost rows are then copies of owned rows; they couple to
+    the image columns where an image exists and to the owned columns otherwise).  The numeric factorisation and the application live in the library (isph_prec_create_overlap)."""
+    n, ncol = int(plan.nlocal), int(plan.ncol)
+    rowptr, colidx, val = np.asarray(rowptr, dtype=np.int64), np.asarray(colidx, dtype=np.int64), np.asarray(val, dtype=np.float64)
+    me = int(plan.rank)
+    if td is None:
+        assert all(int(p) == me for p in plan.peers), "remote peers need torch.distributed"
+        off = {me: 0}
+    else:
+        sizes = [None] * td.get_world_size()
+        td.all_gather_object(sizes, n)
+        off = {r: int(sum(sizes[:r])) for r in range(len(sizes))}
+    gcol = np.empty(ncol, dtype=np.int64)                      # global id of every local column
+    gcol[:n] = off[me] + np.arange(n)
+    for k, p in enumerate(plan.peers):
+        r0, r1 = int(plan.recv_ptr[k]), int(plan.recv_ptr[k + 1])
+        gcol[n + r0:n + r1] = off[int(p)] + plan.recv_idx[r0:r1].astype(np.int64)
+    out = {}
+    for k, p in enumerate(plan.peers):                         # the rows each peer holds as ghost columns
+        rows = plan.send_idx[int(plan.send_ptr[k]):int(plan.send_ptr[k + 1])].astype(np.int64)
+        lens = rowptr[rows + 1] - rowptr[rows]
+        take = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in rows]) if len(rows) else np.zeros(0, np.int64)
+        out[int(p)] = (lens, gcol[colidx[take]], val[take])
+    if td is None:
+        incoming = {me: out.get(me)}
+    else:
+        allout = [None] * td.get_world_size()
+        td.all_gather_object(allout, out)
+        incoming = {int(p): allout[int(p)].get(me) for p in plan.peers}
+    # global id -> extended index: owned columns by arithmetic, ghost columns by a sorted look-up
+    gg = gcol[n:]
+    order = np.argsort(gg, kind="stable")
+    gsorted = gg[order]
+
+    def ext_index(g):
+        # ghost columns first, then owned ones: between different ranks a global id is one or the other; with the
+        # self-peer plan a ghost is an image of an owned row, and the image rows couple to the images where there are any
+        e = np.full(len(g), -1, dtype=np.int64)
+        if len(g) and len(gsorted):
+            pos = np.searchsorted(gsorted, g)
+            pos[pos >= len(gsorted)] = len(gsorted) - 1
+            hit = gsorted[pos] == g
+            e[hit] = n + order[pos[hit]]
+        own = (e < 0) & (g >= off[me]) & (g < off[me] + n)
+        e[own] = g[own] - off[me]
+        return e
+
+    grp, gci, gv = [int(rowptr[n])], [], []
+    for k, p in enumerate(plan.peers):
+        lens, gids, vals = incoming[int(p)]
+        assert len(lens) == int(plan.recv_ptr[k + 1]) - int(plan.recv_ptr[k]), "peer sent a different number of rows"
+        e = ext_index(np.asarray(gids, dtype=np.int64))
+        start = 0
+        for ln in lens:
+            ee, vv = e[start:start + ln], vals[start:start + ln]
+            keep = ee >= 0
+            ee, vv = ee[keep], vv[keep]
+            o = np.argsort(ee, kind="stable")
+            gci.append(ee[o])
+            gv.append(vv[o])
+            grp.append(grp[-1] + int(keep.sum()))
+            start += int(ln)
+    rp_ext = np.concatenate([rowptr[:n + 1], np.asarray(grp[1:], dtype=np.int64)])
+    ci_ext = np.concatenate([colidx[:rowptr[n]]] + gci) if gci else colidx[:rowptr[n]]
+    v_ext = np.concatenate([val[:rowptr[n]]] + gv) if gv else val[:rowptr[n]]
+    assert rp_ext[-1] < 2 ** 31
+    return rp_ext.astype(np.int32), ci_ext.astype(np.int32), v_ext

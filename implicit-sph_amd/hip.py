@@ -17,7 +17,7 @@ NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
 KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
-    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy",
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
@@ -104,6 +104,8 @@ def lib():
         L.isph_halo_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.isph_halo_destroy.argtypes = [C.c_void_p]
         L.isph_halo_destroy.restype = None
+        L.isph_prec_create_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.isph_pool_cached_bytes.argtypes = []
         L.isph_pool_cached_bytes.restype = C.c_longlong
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
@@ -435,6 +437,18 @@ class PrecondSchwarz(Precond):
         v = np.zeros(i["nnz"])
         _check(lib().isph_prec_schwarz_export(self.ctx.h, self.h, _ptr(rows), _ptr(lp), _ptr(rp), _ptr(ci), _ptr(v)))
         return rows, lp, rp, ci, v
+
+
+class PrecondOverlap(Precond):
+    """isph_prec_create_overlap: ILU(k) of this rank's rows plus one layer of its neighbours' rows ("Overlap Level" 1 on
+    more than one rank).  Aext: hip.Matrix of the extended subdomain (dist.extend_rows), plan: dist.HaloPlan."""
+
+    def __init__(self, ctx, Aext, plan, level_of_fill=1, combine="add"):
+        self.ctx, self.n = ctx, int(plan.nlocal)
+        self.h = C.c_void_p()
+        peers, sp, si, rp_ = (np.ascontiguousarray(a, dtype=np.int32) for a in (plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr))
+        _check(lib().isph_prec_create_overlap(ctx.h, Aext.h, self.n, int(level_of_fill), {"add": 0, "zero": 1}[combine],
+                                              len(peers), _ptr(peers), _ptr(sp), _ptr(si), _ptr(rp_), C.byref(self.h)))
 
 
 def solve_block(ctx, blocks, b, x, prec=None, params=None, lda=None):

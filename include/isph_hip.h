@@ -135,6 +135,17 @@ int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwar
 int isph_prec_schwarz_info(const isph_prec *M, long long info[6]);
 int isph_prec_schwarz_export(isph_ctx *ctx, const isph_prec *M, int *rows, int *loc_ptr, long long *rowptr,
                              int *colidx, double *val);
+/* Ifpack_AdditiveSchwarz<ILU(k)> with "Overlap Level" 1 across ranks (ref: precond_ifpack.h:43,60-74; Ifpack builds an
+ * Ifpack_OverlappingRowMatrix from the matrix' Epetra_Import).  Aext is the square matrix of this rank's extended
+ * subdomain: rows/columns [0,nlocal) = owned, [nlocal, nlocal + nghost) = the rows of the ghost columns in ghost-column
+ * order, entries outside the extended column set dropped (the adapter imports those rows with the matrix' importer;
+ * dist.extend_rows does it for the Python plumbing).  The halo lists are the ones of isph_mat_set_halo for the
+ * un-extended matrix.  apply: gather the ghost part of r from its owners, ILU(k) solve on the extended vector (one
+ * subdomain, level-scheduled path), and with combine 0 = "Add" (the wrapper's default, precond_ifpack.h:37) send the
+ * ghost part of the result back to the owners, who add it; 1 = "Zero" keeps the owned part (restricted Schwarz). */
+int isph_prec_create_overlap(isph_ctx *ctx, const isph_mat *Aext, int nlocal, int level_of_fill, int combine, int npeers,
+                             const int *peer_rank, const int *send_ptr, const int *send_idx, const int *recv_ptr,
+                             isph_prec **M);
 
 /* z = M^-1 r (Belos::EpetraPrecOp::Apply -> Ifpack ApplyInverse). */
 int isph_prec_apply(isph_ctx *ctx, const isph_prec *M, const double *r /*[h|d]*/,

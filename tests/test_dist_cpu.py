@@ -145,3 +145,109 @@ def test_two_rank_bricks_match_single_rank(dim, pgrid, n):
     aug = sps.bmat([[A, nv[:, None]], [nv[None, :], None]]).tocsc()
     xs = spla.spsolve(aug, np.concatenate([bp, [0.0]]))[:N]
     assert np.linalg.norm(xg - xs) / np.linalg.norm(xs) < 1e-5
+
+
+# ------------------------------------------------------------------ "Overlap Level" 1 across ranks
+def _worker_overlap(rank, world, port, pgrid, dim, n, out):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["ISPH_ORACLE_THREADS"] = "1"
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import isph_amd  # noqa: F401
+        from isph_amd import dist, workload
+        import oracle as orc
+        ncell = tuple(n * g for g in pgrid[:dim])
+        spec = workload.TGVSpec(dim=dim, ncell=ncell, pgrid=pgrid[:dim], rank=rank, brick=(4,) * dim,
+                                origin=(0.5,) * dim if dim == 2 else (0.0,) * 3, mode=workload.JITTER)
+        parts = workload.make_tgv(spec)
+        plan = dist.make_plan(parts, td)
+        nl = parts["nlocal"]
+        P = orc.Particles(parts, plan.colmap, kernel=spec.kernel)
+        orc.lib().orc_compute_volumes(P.ref())
+        P.vfrac[:] = dist.forward_scalar(plan, P.vfrac[:nl].copy(), td).numpy()
+        rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True, rank0=(rank == 0))
+        rpe, cie, ve = dist.extend_rows(plan, rp, ci, val, td)
+        col_tag = np.zeros(plan.ncol, dtype=np.int64)
+        col_tag[plan.colmap] = parts["tag"]                       # tag of every extended row / column
+        # application of the overlapped subdomain solve with the exact inverse of the extended matrix in place of ILU:
+        # gather ghosts, solve, send the ghost part home and add (what isph_prec_create_overlap does with RCCL)
+        import scipy.sparse as sps
+        import scipy.sparse.linalg as spla
+        next_ = plan.ncol
+        Aext = sps.csr_matrix((ve, cie, rpe), shape=(next_, next_)).tocsc()
+        r = np.cos(0.37 * parts["tag"][:nl].astype(np.float64))
+        rext = dist.exchange(plan, r, td).numpy()
+        zext = spla.spsolve(Aext + 1e-3 * sps.eye(next_).tocsc(), rext)     # shifted: the Neumann operator is singular
+        # reverse exchange with Add: ghost part back to the owners
+        sidx = plan.send_idx.astype(np.int64)
+        ops, keep = [], []
+        for k, p in enumerate(plan.peers):
+            s0, s1 = int(plan.send_ptr[k]), int(plan.send_ptr[k + 1])
+            r0, r1 = int(plan.recv_ptr[k]), int(plan.recv_ptr[k + 1])
+            if r1 > r0:
+                ops.append(td.P2POp(td.isend, torch.from_numpy(np.ascontiguousarray(zext[nl + r0:nl + r1])), int(p)))
+            if s1 > s0:
+                buf = torch.empty(s1 - s0, dtype=torch.float64)
+                keep.append((s0, s1, buf))
+                ops.append(td.P2POp(td.irecv, buf, int(p)))
+        for w in td.batch_isend_irecv(ops):
+            w.wait()
+        z = zext[:nl].copy()
+        for s0, s1, buf in keep:
+            np.add.at(z, sidx[s0:s1], buf.numpy())
+        out.put((rank, col_tag, (rpe, cie, ve), nl, r, z))
+    finally:
+        td.barrier()
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("dim,pgrid,n", [(2, (2, 1, 1), 8), (3, (2, 1, 1), 6)])
+def test_two_rank_extended_subdomains_are_the_global_rows_of_one_overlap_layer(dim, pgrid, n):
+    """dist.extend_rows (Ifpack_OverlappingRowMatrix, Overlap Level 1): on every rank the extended matrix must be the
+    global matrix restricted to (owned + ghost) rows and columns, and the overlapped additive-Schwarz application
+    (exact subdomain solves, combine Add) must equal  sum_r R_r^T (R_r A R_r^T)^-1 R_r  applied to the global vector."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    from isph_amd import workload
+    import oracle as orc
+    world = int(np.prod(pgrid))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, pgrid, dim, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ncell = tuple(n * g for g in pgrid[:dim])
+    spec = workload.TGVSpec(dim=dim, ncell=ncell, brick=(4,) * dim, origin=(0.5,) * dim if dim == 2 else (0.0,) * 3,
+                            mode=workload.JITTER)
+    parts = workload.make_tgv(spec)
+    P = orc.Particles(parts, workload.single_rank_colmap(parts)).precompute(corrections=False)
+    rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True)
+    N = parts["nlocal"]
+    A = sps.csr_matrix((val, ci, rp), shape=(N, N))
+    pos = np.zeros(N + 1, dtype=np.int64)
+    pos[parts["tag"][:N].astype(np.int64)] = np.arange(N)
+    rglob, zsum = np.zeros(N), np.zeros(N)
+    scale = np.abs(val).max()
+    for rank, col_tag, (rpe, cie, ve), nl, r, z in res:
+        ext = pos[col_tag]                                             # global row of every extended row
+        assert len(np.unique(ext)) == len(ext) and len(ext) > nl
+        Ae = sps.csr_matrix((ve, cie, rpe), shape=(len(ext), len(ext)))
+        sub = A[ext][:, ext]
+        assert abs(Ae - sub).max() <= 1e-12 * scale                   # the restriction of the global operator, exactly
+        rglob[ext[:nl]] = r
+    for rank, col_tag, (rpe, cie, ve), nl, r, z in res:
+        ext = pos[col_tag]
+        sub = (A[ext][:, ext] + 1e-3 * sps.eye(len(ext))).tocsc()
+        zsum[ext] += spla.spsolve(sub, rglob[ext])
+    for rank, col_tag, (rpe, cie, ve), nl, r, z in res:
+        ext = pos[col_tag]
+        assert np.max(np.abs(z - zsum[ext[:nl]])) <= 1e-9 * np.abs(zsum).max()

@@ -95,3 +95,49 @@ def test_config0_2d_tgv_cg_whole_matrix_ilu0(gpu_ctx):
                           params=orc.SolverParams(solver_type=1, tol=1e-6))
     assert info.converged == 1 and io.converged == 1 and abs(info.iters - io.iters) <= 1, (info.iters, io.iters)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-6
+
+
+@pytest.mark.parametrize("fill,combine", [(0, "add"), (1, "add"), (0, "zero")])
+def test_overlap_level_one_across_ranks_through_the_self_peer_plan(fill, combine):
+    """isph_prec_create_overlap = Ifpack_AdditiveSchwarz<ILU(k)> with "Overlap Level" 1 on more than one rank
+    (precond_ifpack.h:43,60-74).  One GPU: the periodic images are ghost columns received from the rank itself, so the
+    whole machinery runs -- row extension (dist.extend_rows; against the global operator in tests/test_dist_cpu.py),
+    RCCL gather of the ghost part of r, ILU(k) of the extended matrix on the level-scheduled path, RCCL return of the
+    ghost corrections with combine Add.  Reference: the same composition with the oracle's ILU(k) and numpy indexing."""
+    from isph_amd import dist
+    from problems import Problem, tgv_spec
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER))
+    rpf, cif, valf, b = pr.poisson()
+    ctx = hip.Context(0, rank=0, nranks=1, uid=hip.Context.unique_id())
+    try:
+        plan = dist.make_self_halo_plan(pr.parts)
+        n, next_ = pr.n, plan.ncol
+        A, bg = hip.assemble_poisson(ctx, pr.parts, plan.colmap, pr.spec.dt, pr.parts["rho"],
+                                     np.ascontiguousarray(pr.parts["v"]), vfrac=pr.P.vfrac, ncol=plan.ncol)
+        A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+        rp, ci, val = A.export_csr()
+        rpe, cie, ve = dist.extend_rows(plan, rp, ci, val, None)
+        assert len(rpe) == next_ + 1 and cie.max() < next_ and np.array_equal(rpe[:n + 1], rp)
+        Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
+        M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=fill, combine=combine)
+        F = orc.ILU(rpe, cie, ve, fill)                                   # the extended subdomain as one block
+        ridx, sidx = plan.recv_idx.astype(np.int64), plan.send_idx.astype(np.int64)
+
+        def reference(r):
+            zext = F.apply(np.concatenate([r, r[ridx]]))
+            z = zext[:n].copy()
+            if combine == "add":
+                np.add.at(z, sidx, zext[n:])
+            return z
+
+        r = np.random.default_rng(5).standard_normal(n)
+        zo = reference(r)
+        zg = M.apply(r)
+        assert np.max(np.abs(zg - zo)) <= 1e-10 * np.abs(zo).max()
+        x = np.zeros(n)
+        info = hip.solve(ctx, A, bg.copy(), x, prec=M, singular=True)
+        xo, io, _ = orc.solve(rpf, cif, valf, b, singular=True, prec="none")
+        assert info.converged == 1 and info.iters < io.iters              # it is a preconditioner
+        assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+    finally:
+        ctx.close()
