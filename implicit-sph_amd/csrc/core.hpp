@@ -23,6 +23,7 @@ struct isph_ctx {
   size_t ev_used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_fetch = nullptr;  // marks the scalar mailbox copy of a Krylov iteration (host waits on it only)
+  std::vector<hipEvent_t> ev_ls;  // one such mark per right-hand side of a lockstep solve (solver.hpp gmres_lockstep)
   // halo exchange overlapped with the interior rows of the SpMV: the grouped send/recv runs on comm_stream between
   // ev_pack (send buffer packed on `stream`) and ev_halo (ghost values landed in xghost)
   hipStream_t comm_stream = nullptr;

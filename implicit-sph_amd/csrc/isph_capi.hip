@@ -258,6 +258,7 @@ void isph_ctx_destroy(isph_ctx *c) {
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   if (c->ev_fetch) (void)hipEventDestroy(c->ev_fetch);
+  for (hipEvent_t e : c->ev_ls) (void)hipEventDestroy(e);
   c->partial.release(); c->dscal.release(); c->V.release(); c->Z.release(); c->wv.release(); c->tv.release();
   c->rv.release(); c->pv.release(); c->nvec.release(); c->xext.release(); c->sendbuf.release();
   c->bdev.release(); c->xdev.release(); c->imask.release();
@@ -913,12 +914,24 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
   LinOp op{ctx, A, M, nv, n};
   int iters = 0, restarts = 0, conv = 1;
   double worst_imp = 0.0, worst_exp = 0.0;
+  // several right-hand sides of a non-singular system (the Helmholtz solve: one per velocity component) advance
+  // together and share their matrix sweeps; the result is the one of solving them one after the other
+  const bool lockstep = gmres_lockstep_ok(op, &prm, nvec);
+  isph_solve_info cls[kMaxLockstep];
+  memset(cls, 0, sizeof(cls));
+  if (lockstep) {
+    const double *bs[kMaxLockstep];
+    double *xs[kMaxLockstep];
+    for (int c = 0; c < nvec; ++c) { bs[c] = db + (size_t)c * lda; xs[c] = dx + (size_t)c * lda; }
+    ISPH_CHECK(gmres_lockstep(op, nvec, bs, xs, &prm, cls));
+  }
   for (int c = 0; c < nvec; ++c) {
     double *bc = db + (size_t)c * lda, *xc = dx + (size_t)c * lda;
     if (nv) ISPH_CHECK(project_dev(ctx, n, nv, bc));  // b -= (b.n) n   (:141-143)
     isph_solve_info ci;
     memset(&ci, 0, sizeof(ci));
-    if (prm.solver_type == 1) ISPH_CHECK(pcg(op, bc, xc, &prm, &ci));
+    if (lockstep) ci = cls[c];
+    else if (prm.solver_type == 1) ISPH_CHECK(pcg(op, bc, xc, &prm, &ci));
     else if (prm.solver_type == 2) ISPH_CHECK(gcrodr(op, bc, xc, &prm, &ci));
     else ISPH_CHECK(gmres(op, bc, xc, &prm, &ci));
     {  // ||b - A x|| / ||b|| with the unprojected A (:201-212)

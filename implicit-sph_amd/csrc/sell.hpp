@@ -386,6 +386,81 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, i
   }
 }
 
+// y_k = A x_k for NV vectors in one sweep of the matrix (the Helmholtz system has one right-hand side per velocity
+// component and one matrix: SURVEY section 7 step 9).  Same accumulation order per vector as k_sell_spmv16 -- the
+// results are bit-identical to NV separate products.
+struct SpmmVecs {
+  const double *x[4];
+  double *y[4];
+};
+template <int NV>
+__global__ __launch_bounds__(kBlock) void k_sell_spmm16(int nrow, int nslices, int nblocks_padded,
+                                                        const long long *__restrict__ slice_off,
+                                                        const unsigned short *__restrict__ c16,
+                                                        const int *__restrict__ wtab, const double *__restrict__ sval,
+                                                        SpmmVecs V) {
+  constexpr int UNROLL = 4;  // 426 us for three vectors of the 1 M-row matrix (8: 467 us); one vector alone takes 190 us:
+                             // the NV gathers per entry, not the matrix stream, set the pace
+  __shared__ int tab[kBlock / kWave][64];
+  const int b = xcd_remap(blockIdx.x, nblocks_padded);
+  const int wave = threadIdx.x >> 6;
+  const int slice = b * (kBlock / kWave) + wave;
+  if (slice >= nslices) return;
+  const int lane = threadIdx.x & 63;
+  tab[wave][lane] = wtab[(long long)slice * 64 + lane] << 10;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int *__restrict__ tw = tab[wave];
+  const long long off = slice_off[slice];
+  const int npair = (int)((slice_off[slice + 1] - off) >> 7);
+  const double2 *__restrict__ v = reinterpret_cast<const double2 *>(sval + off) + lane;
+  const unsigned *__restrict__ c = reinterpret_cast<const unsigned *>(c16 + off) + lane;
+  double acc0[NV], acc1[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { acc0[k] = 0.0; acc1[k] = 0.0; }
+  int q = 0;
+  for (; q + UNROLL <= npair; q += UNROLL) {
+    double2 vv[UNROLL];
+    int ca[UNROLL], cb[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      vv[u].x = __builtin_nontemporal_load(&v[(q + u) * 64].x);
+      vv[u].y = __builtin_nontemporal_load(&v[(q + u) * 64].y);
+      const unsigned cc = __builtin_nontemporal_load(&c[(q + u) * 64]);
+      const unsigned lo = cc & 0xffffu, hi = cc >> 16;
+      ca[u] = tw[lo >> 10] | (int)(lo & 1023u);
+      cb[u] = tw[hi >> 10] | (int)(hi & 1023u);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double xa[UNROLL], xb[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) { xa[u] = V.x[k][ca[u]]; xb[u] = V.x[k][cb[u]]; }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        acc0[k] = fma(vv[u].x, xa[u], acc0[k]);
+        acc1[k] = fma(vv[u].y, xb[u], acc1[k]);
+      }
+    }
+  }
+  for (; q < npair; ++q) {
+    const double2 vv = v[q * 64];
+    const unsigned cc = c[q * 64];
+    const unsigned lo = cc & 0xffffu, hi = cc >> 16;
+    const int ca = tw[lo >> 10] | (int)(lo & 1023u), cb = tw[hi >> 10] | (int)(hi & 1023u);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      acc0[k] = fma(vv.x, V.x[k][ca], acc0[k]);
+      acc1[k] = fma(vv.y, V.x[k][cb], acc1[k]);
+    }
+  }
+  const int row = slice * kSlice + lane;
+  if (row < nrow) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) V.y[k][row] = acc0[k] + acc1[k];
+  }
+}
+
 // invdiag[row] = 1 / A(row,row)  (point-Jacobi debug preconditioner)
 __global__ void k_sell_inv_diag(int nrow, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
                                 const int *__restrict__ scol, const double *__restrict__ sval,

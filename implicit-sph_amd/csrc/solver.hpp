@@ -23,13 +23,15 @@ inline int allreduce_inplace(isph_ctx *ctx, double *d, int count) {
 // device scalar mailbox layout
 enum { SC_DOT = 0 /* SC_DOT..SC_DOT+63: multi-dot results */, SC_Y = 64 /* 64 ys */, SC_MISC = 128, SC_COUNT = 160 };
 
+constexpr int kMaxLockstep = 4;  // right-hand sides a lockstep solve advances together (one mailbox each)
+
 inline int ensure_scalars(isph_ctx *ctx) {
-  ISPH_CHECK(ctx->dscal.reserve(SC_COUNT));
+  ISPH_CHECK(ctx->dscal.reserve(SC_COUNT * kMaxLockstep));
   ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
-  if (ctx->hscal_cap < SC_COUNT) {
+  if (ctx->hscal_cap < (size_t)SC_COUNT * kMaxLockstep) {
     if (ctx->hscal) (void)hipHostFree(ctx->hscal);
-    ISPH_CHECK_HIP(hipHostMalloc((void **)&ctx->hscal, SC_COUNT * sizeof(double)));
-    ctx->hscal_cap = SC_COUNT;
+    ISPH_CHECK_HIP(hipHostMalloc((void **)&ctx->hscal, (size_t)SC_COUNT * kMaxLockstep * sizeof(double)));
+    ctx->hscal_cap = (size_t)SC_COUNT * kMaxLockstep;
   }
   return ISPH_SUCCESS;
 }
@@ -165,6 +167,37 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
   return ISPH_SUCCESS;
 }
 
+// y_k = A x_k, k < K: one sweep of the matrix for all vectors when the matrix has no ghost columns and its 16-bit
+// columns exist (k_sell_spmm16), otherwise one product after the other.  Same bits either way.
+inline int spmm_dev(isph_ctx *ctx, const isph_mat *A, int K, const double *const *xs, double *const *ys) {
+  const Sell &S = A->S;
+  const bool halo = !(S.ncol == S.nrow || A->local);
+  if (K < 2 || K > 4 || halo || A->local || !sell_cols16(ctx, S)) {
+    for (int k = 0; k < K; ++k) ISPH_CHECK(spmv_dev(ctx, A, xs[k], ys[k], nullptr));
+    return ISPH_SUCCESS;
+  }
+  size_t slot = (size_t)-1;
+  ISPH_CHECK(profile_begin(ctx, &slot));
+  SpmmVecs V;
+  for (int k = 0; k < 4; ++k) { V.x[k] = xs[k < K ? k : 0]; V.y[k] = ys[k < K ? k : 0]; }
+  int nbp = 0;
+  const int grid = spmv_grid(S.nslices, &nbp);
+  if (S.nslices > 0) {
+    if (K == 2)
+      hipLaunchKernelGGL((k_sell_spmm16<2>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp, S.slice_off.p,
+                         S.col16.p, S.wtab.p, S.val.p, V);
+    else if (K == 3)
+      hipLaunchKernelGGL((k_sell_spmm16<3>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp, S.slice_off.p,
+                         S.col16.p, S.wtab.p, S.val.p, V);
+    else
+      hipLaunchKernelGGL((k_sell_spmm16<4>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp, S.slice_off.p,
+                         S.col16.p, S.wtab.p, S.val.p, V);
+  }
+  ISPH_CHECK(profile_end(ctx, slot));
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
 struct LinOp {
   isph_ctx *ctx;
   const isph_mat *A;
@@ -262,14 +295,14 @@ inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld,
 // (|w_final|^2 = |w_new|^2 - |c2|^2 when the second pass runs: see k_dgks_decide)
 enum { SC_ORTHO = SC_MISC + 20 };
 inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long long ld, double *w, int ortho, double *vnext,
-                         bool deflate = false) {
+                         bool deflate = false, int mb = 0) {
   int g = stream_grid(n);
   // 2 workgroups per CU with two rows per thread in flight: multi-dot 53.6 -> 44.4 us, the 64-wide fused update
   // 92.8 -> 79.5 us against 4 workgroups per CU, one row (rocprofv3, bench matrix)
   if (g > 1024) g = 1024;
   ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
   hipStream_t st = ctx->stream;
-  double *dh1 = ctx->dscal.p + SC_DOT, *dh2 = ctx->dscal.p + SC_Y, *dor = ctx->dscal.p + SC_ORTHO;
+  double *dh1 = ctx->dscal.p + mb + SC_DOT, *dh2 = ctx->dscal.p + mb + SC_Y, *dor = ctx->dscal.p + mb + SC_ORTHO;  // mb: mailbox of this right-hand side
   constexpr int dot_grid = 512;
   if (g > dot_grid) g = dot_grid;
   hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
@@ -296,11 +329,11 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
 }
 
 // host side of ortho_enqueue, once the mailbox is in hscal
-inline void ortho_collect(const isph_ctx *ctx, int nk, double *h, double *wnorm) {
-  const bool second = ctx->hscal[SC_ORTHO] != 0.0;
-  for (int k = 0; k < nk; ++k) h[k] = ctx->hscal[SC_DOT + k] + (second ? ctx->hscal[SC_Y + k] : 0.0);
-  (void)nk;
-  *wnorm = std::sqrt(ctx->hscal[SC_ORTHO + 1]);
+inline void ortho_collect(const isph_ctx *ctx, int nk, double *h, double *wnorm, int mb = 0) {
+  const double *hs = ctx->hscal + mb;
+  const bool second = hs[SC_ORTHO] != 0.0;
+  for (int k = 0; k < nk; ++k) h[k] = hs[SC_DOT + k] + (second ? hs[SC_Y + k] : 0.0);
+  *wnorm = std::sqrt(hs[SC_ORTHO + 1]);
 }
 
 // Belos DGKS / ICGS / IMGS for block size 1. h[0..j] coefficients, returns ||w||.
@@ -460,6 +493,163 @@ inline int gmres(const LinOp &op, const double *b, double *x, const isph_solver_
     ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 4, 1));
     beta = std::sqrt(ctx->hscal[SC_MISC + 4]);
     if (beta == 0.0) { info->converged = 1; break; }
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+// K right-hand sides of one matrix (the Helmholtz system: one per velocity component, pair_isph.cpp:925-966) advanced
+// together: Belos solves them one after the other (block size 1), and so does every Krylov space here -- own basis,
+// own Hessenberg, own convergence test and restarts, the arithmetic of gmres() above vector by vector --, but the K
+// operator applications of an iteration share one sweep of the matrix (spmm_dev), and while the host waits for one
+// system's Gram-Schmidt scalars the device already works on the next system's.  Flexible GMRES, DGKS / ICGS,
+// non-singular, un-blocked operators; everything else goes through gmres() per right-hand side.
+inline bool gmres_lockstep_ok(const LinOp &op, const isph_solver_params *prm, int K) {
+  return K >= 2 && K <= kMaxLockstep && !op.nvec && !op.blk && prm->flexible && prm->ortho != 2 && prm->solver_type == 0;
+}
+
+inline int gmres_lockstep(const LinOp &op, int K, const double *const *bs, double *const *xs, const isph_solver_params *prm,
+                          isph_solve_info *infos) {
+  isph_ctx *ctx = op.ctx;
+  const int n = op.n, m = prm->num_blocks;
+  ISPH_REQUIRE(m >= 1 && m <= 62, "Num Blocks must be in [1,62]");
+  const long long ld = ((long long)n + 63) / 64 * 64;
+  ISPH_CHECK(ctx->V.reserve((size_t)ld * (size_t)(m + 2) * (size_t)K));
+  ISPH_CHECK(ctx->Z.reserve((size_t)ld * (size_t)m * (size_t)K));
+  ISPH_CHECK(ctx->wv.reserve((size_t)ld * (size_t)K));
+  while ((int)ctx->ev_ls.size() < K) {
+    hipEvent_t e;
+    ISPH_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->ev_ls.push_back(e);
+  }
+  struct Sys {
+    double *V, *Z, *w;
+    std::vector<double> H, cs, sn, g, y;
+    double beta = 0.0, scale = 1.0;
+    int j = 0;
+    bool in_cycle = false, done = false;
+  };
+  std::vector<Sys> sys((size_t)K);
+  const int sg = stream_grid(n);
+  hipStream_t st = ctx->stream;
+  const double *xin[kMaxLockstep];
+  double *yout[kMaxLockstep];
+  for (int k = 0; k < K; ++k) {
+    Sys &s = sys[(size_t)k];
+    s.V = ctx->V.p + (size_t)k * ld * (size_t)(m + 2);
+    s.Z = ctx->Z.p + (size_t)k * ld * (size_t)m;
+    s.w = ctx->wv.p + (size_t)k * ld;
+    s.H.assign((size_t)(m + 1) * (size_t)m, 0.0);
+    s.cs.assign((size_t)m, 0.0); s.sn.assign((size_t)m, 0.0); s.g.assign((size_t)m + 1, 0.0); s.y.assign((size_t)m, 0.0);
+    infos[k].iters = 0; infos[k].restarts = 0; infos[k].converged = 0;
+    xin[k] = xs[k]; yout[k] = s.w;
+  }
+  // r0 = b - A x for every system
+  ISPH_CHECK(spmm_dev(ctx, op.A, K, xin, yout));
+  for (int k = 0; k < K; ++k) {
+    Sys &s = sys[(size_t)k];
+    hipLaunchKernelGGL(k_residual, dim3(sg), dim3(kBlock), 0, st, n, bs[k], s.w);
+    ISPH_CHECK(dot_dev(ctx, n, s.w, s.w, nullptr, nullptr, SC_MISC + 4));
+    ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 4, 1));
+    s.beta = std::sqrt(ctx->hscal[SC_MISC + 4]);
+    s.scale = s.beta == 0.0 ? 1.0 : s.beta;
+    infos[k].rel_res_implicit = s.beta / s.scale;
+    if (s.beta / s.scale <= prm->tol) { infos[k].converged = 1; s.done = true; }
+  }
+  auto start_cycle = [&](int k) {
+    Sys &s = sys[(size_t)k];
+    hipLaunchKernelGGL(k_scale_copy, dim3(sg), dim3(kBlock), 0, st, n, s.w, s.V, 1.0 / s.beta, (const double *)nullptr, 0);
+    std::fill(s.g.begin(), s.g.end(), 0.0);
+    s.g[0] = s.beta;
+    s.j = 0;
+    s.in_cycle = true;
+  };
+  // end of a cycle of system k: x += Z y, then either done or the residual of the restart
+  auto end_cycle = [&](int k) -> int {
+    Sys &s = sys[(size_t)k];
+    isph_solve_info &inf = infos[k];
+    const int j = s.j, mb = k * SC_COUNT;
+    for (int q = j - 1; q >= 0; --q) {
+      double acc = s.g[(size_t)q];
+      for (int l = q + 1; l < j; ++l) acc -= s.H[(size_t)l * (size_t)(m + 1) + q] * s.y[(size_t)l];
+      s.y[(size_t)q] = acc / s.H[(size_t)q * (size_t)(m + 1) + q];
+    }
+    for (int q = 0; q < j; ++q) ctx->hscal[mb + SC_Y + q] = s.y[(size_t)q];
+    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->dscal.p + mb + SC_Y, ctx->hscal + mb + SC_Y, sizeof(double) * (size_t)j, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_multi_axpy, dim3(sg), dim3(kBlock), 0, st, n, j, s.Z, ld, ctx->dscal.p + mb + SC_Y, xs[k]);
+    ISPH_CHECK_HIP(hipStreamSynchronize(st));  // the H2D source must not be rewritten before the copy has run
+    s.in_cycle = false;
+    if (inf.converged || inf.iters >= prm->max_iters || inf.restarts >= prm->max_restarts) { s.done = true; return ISPH_SUCCESS; }
+    ++inf.restarts;
+    ISPH_CHECK(op.apply(xs[k], s.w));
+    hipLaunchKernelGGL(k_residual, dim3(sg), dim3(kBlock), 0, st, n, bs[k], s.w);
+    ISPH_CHECK(dot_dev(ctx, n, s.w, s.w, nullptr, nullptr, SC_MISC + 4));
+    ISPH_CHECK(fetch_scalars(ctx, SC_MISC + 4, 1));
+    s.beta = std::sqrt(ctx->hscal[SC_MISC + 4]);
+    if (s.beta == 0.0) { inf.converged = 1; s.done = true; return ISPH_SUCCESS; }
+    start_cycle(k);
+    return ISPH_SUCCESS;
+  };
+  for (int k = 0; k < K; ++k)
+    if (!sys[(size_t)k].done) {
+      if (infos[k].iters < prm->max_iters) start_cycle(k);
+      else sys[(size_t)k].done = true;
+    }
+  int act[kMaxLockstep];
+  while (true) {
+    int na = 0;
+    for (int k = 0; k < K; ++k)
+      if (!sys[(size_t)k].done && sys[(size_t)k].in_cycle) act[na++] = k;
+    if (na == 0) break;
+    // z = M^-1 v_j, system by system; w = A z for all of them in one sweep
+    for (int a = 0; a < na; ++a) {
+      Sys &s = sys[(size_t)act[a]];
+      ISPH_CHECK(op.prec(s.V + (long long)s.j * ld, s.Z + (long long)s.j * ld));
+      xin[a] = s.Z + (long long)s.j * ld;
+      yout[a] = s.w;
+    }
+    ISPH_CHECK(spmm_dev(ctx, op.A, na, xin, yout));
+    // Gram-Schmidt of every system on the device, its scalars on their way to the system's own mailbox
+    for (int a = 0; a < na; ++a) {
+      const int k = act[a], mb = k * SC_COUNT;
+      Sys &s = sys[(size_t)k];
+      ISPH_CHECK(ortho_enqueue(ctx, n, s.j + 1, s.V, ld, s.w, prm->ortho, s.V + (long long)(s.j + 1) * ld, false, mb));
+      ISPH_CHECK_HIP(hipMemcpyAsync(ctx->hscal + mb, ctx->dscal.p + mb, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, st));
+      ISPH_CHECK_HIP(hipEventRecord(ctx->ev_ls[(size_t)k], st));
+    }
+    for (int a = 0; a < na; ++a) {
+      const int k = act[a], mb = k * SC_COUNT;
+      Sys &s = sys[(size_t)k];
+      isph_solve_info &inf = infos[k];
+      ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev_ls[(size_t)k]));
+      const int j = s.j;
+      double *h = &s.H[(size_t)j * (size_t)(m + 1)];
+      double wn = 0.0;
+      for (int q = 0; q <= j; ++q) h[q] = 0.0;
+      ortho_collect(ctx, j + 1, h, &wn, mb);
+      h[j + 1] = wn;
+      for (int q = 0; q < j; ++q) {
+        const double t = s.cs[(size_t)q] * h[q] + s.sn[(size_t)q] * h[q + 1];
+        h[q + 1] = -s.sn[(size_t)q] * h[q] + s.cs[(size_t)q] * h[q + 1];
+        h[q] = t;
+      }
+      {
+        const double t = h[j], bb = h[j + 1], rr = std::hypot(t, bb);
+        s.cs[(size_t)j] = rr == 0.0 ? 1.0 : t / rr;
+        s.sn[(size_t)j] = rr == 0.0 ? 0.0 : bb / rr;
+        h[j] = rr;
+        h[j + 1] = 0.0;
+        s.g[(size_t)j + 1] = -s.sn[(size_t)j] * s.g[(size_t)j];
+        s.g[(size_t)j] = s.cs[(size_t)j] * s.g[(size_t)j];
+      }
+      ++s.j;
+      ++inf.iters;
+      inf.rel_res_implicit = std::fabs(s.g[(size_t)s.j]) / s.scale;
+      if (prm->verbose && ctx->rank == 0 && inf.iters % 10 == 0)
+        printf(">> isph::gmres[%d] iter %d  rel res %.3e\n", k, inf.iters, inf.rel_res_implicit);
+      if (inf.rel_res_implicit <= prm->tol) inf.converged = 1;
+      if (inf.converged || inf.iters >= prm->max_iters || s.j >= m) ISPH_CHECK(end_cycle(k));
+    }
   }
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;

@@ -623,6 +623,37 @@ def test_helmholtz_solve_three_rhs(gpu_ctx):
         assert np.linalg.norm(xg[k * n:(k + 1) * n] - xo) / nrm <= 1e-6 or np.linalg.norm(xo) < 1e-12
 
 
+@pytest.mark.parametrize("prec", ["bjacobi-ilu0", "jacobi", "sa-amg"])
+@pytest.mark.parametrize("restart", [50, 4])
+def test_lockstep_right_hand_sides_equal_one_solve_after_the_other(gpu_ctx, prec, restart):
+    """nvec > 1 on a non-singular system advances the Krylov spaces together (one matrix sweep for all operator
+    applications of an iteration, SURVEY section 7 step 9).  Belos solves the right-hand sides one after the other;
+    every vector must come out with the bits of its own separate solve, iterations and restarts included."""
+    pr = Problem(tgv_spec(dim=3, n=14, mode=workload.JITTER))
+    p = pr.parts
+    nall, n = p["nall"], pr.n
+    zeros = np.zeros(nall)
+    vel = np.ascontiguousarray(p["v"])
+    A, bg = hip.assemble_helmholtz(gpu_ctx, p, pr.colmap, pr.spec.dt, 0.5, p["nu"], p["rho"], zeros,
+                                   np.zeros((nall, 3)), np.zeros(3), vel, vfrac=pr.P.vfrac)
+    bg[2 * n:3 * n] = np.sin(np.arange(n))                                 # w = 0 in the 2-D vortex: give it a right-hand side
+    M = hip.PrecondAMG(gpu_ctx, A) if prec == "sa-amg" else hip.Precond(gpu_ctx, A, prec, 256)
+    prm = hip.SolverParams(num_blocks=restart, max_restarts=40)
+    x3 = np.ascontiguousarray(vel[:n].T).ravel().copy()
+    i3 = hip.solve(gpu_ctx, A, bg.copy(), x3, prec=M, nvec=3, lda=n, params=prm)
+    its, rst = 0, 0
+    for k in range(3):
+        xk = vel[:n, k].copy()
+        ik = hip.solve(gpu_ctx, A, bg[k * n:(k + 1) * n].copy(), xk, prec=M, params=prm)
+        assert ik.converged == 1
+        assert np.array_equal(xk, x3[k * n:(k + 1) * n])
+        its += ik.iters
+        rst += ik.restarts
+    assert i3.converged == 1 and i3.iters == its and i3.restarts == rst
+    if restart == 4 and prec != "sa-amg":
+        assert rst > 0                                                     # the restart path of a single system was taken
+
+
 # ---------------------------------------------------------------- solid particles + MorrisHolmes mirror (SURVEY §8 a4)
 from problems import wall_types, fake_pnd  # noqa: E402
 
