@@ -67,8 +67,13 @@ bool make_layout(const isph_tgv_spec *s, Layout &L) {
     L.P[a] = (a < s->dim) ? (s->pgrid[a] > 0 ? s->pgrid[a] : 1) : 1;
     L.bs[a] = (a < s->dim) ? s->brick[a] : 0;
     if (L.N[a] < 1 || L.P[a] > L.N[a]) return false;
-    L.dx[a] = 2.0 * M_PI / L.N[a];
   }
+  // one lattice spacing in every direction: dx = 2 pi / (fewest cells of a side), so a box of (2N, N, N) cells is 4 pi x
+  // 2 pi x 2 pi (every side a whole number of periods of the vortex) -- weak scaling over 2 or 4 bricks keeps the
+  // stencil of the single brick instead of stretching the lattice along the short sides
+  int nmin = L.N[0];
+  for (int a = 1; a < s->dim; ++a) nmin = std::min(nmin, L.N[a]);
+  for (int a = 0; a < 3; ++a) L.dx[a] = 2.0 * M_PI / nmin;
   int r = s->rank;
   if (r < 0 || r >= L.P[0] * L.P[1] * L.P[2]) return false;
   L.rc[0] = r % L.P[0]; r /= L.P[0];

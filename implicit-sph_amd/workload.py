@@ -57,7 +57,7 @@ class TGVSpec:
 
     @property
     def dx(self):
-        return 2.0 * math.pi / self.ncell[0]
+        return 2.0 * math.pi / min(self.ncell[:self.dim])     # one spacing in every direction (csrc/workload.cpp make_layout)
 
     @property
     def h(self):
@@ -183,7 +183,7 @@ def make_cavity(nfluid, wall=6, dim=3, pgrid=(1, 1, 1), rank=0, brick=(8, 8, 8),
 
 
 def make_porous_cylinder(nc, wall=5, nbeads=12, rbead_cells=3.0, seed=7, brick=(8, 8, 8), pgrid=(1, 1, 1), rank=0,
-                         jitter=0.0, rho=997.561, nu=8.9087e-07, umax=0.04):
+                         jitter=0.0, rho=997.561, nu=8.9087e-07, umax=0.04, bead_pack=None):
     """Pore-scale flow through a bead pack in a cylinder (BASELINE configs[4]; sph-script/pore-scale-flow-3d.lmp +
     compute_isph_cylinder_porous.cpp:195-224): `lattice bcc ${dx}` (2 particles per cell, 749 entries per matrix row
     with the script's Quintic kernel, cut = 3 h = 4.5 dx), cylinder along y (periodic), labels
@@ -195,8 +195,20 @@ def make_porous_cylinder(nc, wall=5, nbeads=12, rbead_cells=3.0, seed=7, brick=(
     radius r + 4 dx of a non-periodic box; here the lattice fills a periodic cube of nc cells per side whose corners
     are additional type-4 wall (wall >= cut/dx cells thick so the fluid never sees its periodic image), the bead
     centres are drawn from a seeded generator instead of the script's data file, and beads are solid throughout
-    (inner radius 0: no deleted particles)."""
-    spec = TGVSpec(dim=3, ncell=(nc, nc, nc), pgrid=pgrid, rank=rank, brick=brick, origin=(0.0, 0.0, 0.0),
+    (inner radius 0: no deleted particles).
+
+    bead_pack: the script's own bead pack (tests/golden/pore_scale_flow_bead_centeroids_3d.npz: the 6864 centres of
+    pore-scale-flow-bead-centeroids-3d.dat with the script's r, half length, bead radius and buffer slab).  The box then
+    has the script's aspect ratio (length / diameter = 1.634, periodic along y like `boundary f p f`), the beads whose
+    centre lies in the middle half of the length are solid (:49-52), lengths scaled so that the cylinder radius is
+    (nc/2 - wall) cells.  Beads stay solid throughout here as well: the reference deletes the particles deeper than
+    one cut inside a bead, which at <= 8 cells per bead radius is nothing or a handful."""
+    ncy = nc
+    if bead_pack is not None:
+        r_phys, hl_phys = float(bead_pack["r"]), float(bead_pack["half_length"])
+        ncy = int(round(hl_phys / r_phys * (nc - 2 * wall)))
+        ncy += ncy % 2                                       # whole bricks of the lattice along y
+    spec = TGVSpec(dim=3, ncell=(nc, ncy, nc), pgrid=pgrid, rank=rank, brick=brick, origin=(0.0, 0.0, 0.0),
                    mode=JITTER if jitter > 0 else LATTICE, jitter_amp=jitter, seed=seed, umax=umax, nu=nu, rho=rho,
                    basis=2, kernel="quintic", cut_over_h=3.0)
     assert wall * spec.dx >= spec.cut - 1e-12, "wall thinner than the kernel support"
@@ -208,10 +220,28 @@ def make_porous_cylinder(nc, wall=5, nbeads=12, rbead_cells=3.0, seed=7, brick=(
     R = (0.5 * nc - wall) * dx
     r2 = (xw[:, 0] - c) ** 2 + (xw[:, 2] - c) ** 2
     typ = np.ones(p["nall"], dtype=np.int32)
-    typ[(xw[:, 1] > 0.05 * L) & (xw[:, 1] < 0.12 * L)] = 2   # buffer slab
-    rng = np.random.default_rng(seed)
-    rb = rbead_cells * dx
     part = np.zeros(p["nall"], dtype=np.int32)
+    if bead_pack is not None:
+        from scipy.spatial import cKDTree
+        Ly = ncy * dx
+        xw[:, 1] = np.mod(x[:, 1], Ly)
+        scale = R / r_phys
+        b0, b1 = (float(t) * scale for t in bead_pack["buffer"])
+        typ[(xw[:, 1] > b0) & (xw[:, 1] < b1)] = 2           # buffer slab behind the inlet (:73-75)
+        ctr = np.asarray(bead_pack["centres"], dtype=np.float64)
+        mid = np.abs(ctr[:, 1]) < 0.5 * hl_phys               # beadlo < y < beadhi (pore-scale-flow-3d.lmp:122-123)
+        ctr = ctr[mid]
+        bc = np.stack([c + scale * ctr[:, 0], scale * (ctr[:, 1] + hl_phys), c + scale * ctr[:, 2]], axis=1)
+        rb = float(bead_pack["rbead"]) * scale
+        dist, idx = cKDTree(bc).query(xw, distance_upper_bound=rb)
+        hit = np.isfinite(dist)
+        typ[hit] = 3
+        part[hit] = idx[hit] + 1
+        nbeads = 0
+    else:
+        typ[(xw[:, 1] > 0.05 * L) & (xw[:, 1] < 0.12 * L)] = 2   # buffer slab
+        rb = rbead_cells * dx
+    rng = np.random.default_rng(seed)
     for k in range(nbeads):
         rad = (R - rb) * math.sqrt(rng.random())
         ang = 2.0 * math.pi * rng.random()

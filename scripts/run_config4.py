@@ -25,7 +25,10 @@ def stage(msg):
     print("[%7.1fs] %s | device memory in use %.1f GB" % (time.time() - T0, msg, (torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9), flush=True)
 
 
-p = workload.make_porous_cylinder(nc, nbeads=40, rbead_cells=6.0)
+if os.environ.get("ISPH_REFERENCE_BEADS"):   # the script's own bead pack and aspect ratio (tests/golden/...npz)
+    p = workload.make_porous_cylinder(nc, bead_pack=np.load(os.path.join(ROOT, "tests", "golden", "pore_scale_flow_bead_centeroids_3d.npz")))
+else:
+    p = workload.make_porous_cylinder(nc, nbeads=40, rbead_cells=6.0)
 n, nall = p["nlocal"], p["nall"]
 stage("generated n=%d list entries=%d offsets %s" % (n, int(p["neigh_ptr"][-1]), p["neigh_ptr"].dtype))
 colmap_h = workload.single_rank_colmap(p)

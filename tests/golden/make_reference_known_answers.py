@@ -78,3 +78,10 @@ if __name__ == "__main__":
         "rows": parse_pb(REF + "conv-channel-edl-potential-2d-morrisholmes-rev722.txt", "MorrisHolmes"),
         "rows_const_extension": parse_pb(REF + "conv-channel-edl-potential-2d-morrisholmes-rev722.txt", "ConstExtension")}
     json.dump(g, open(path, "w"), indent=1)
+    # the bead pack of BASELINE configs[4]: an INPUT data file of the reference's script (pore-scale-flow-3d.lmp:125 reads
+    # it through compute isph/cylinder/porous), kept as a fixture so that the configuration can be generated faithfully
+    import numpy as np
+    beads = np.loadtxt(REF + "pore-scale-flow-bead-centeroids-3d.dat")
+    np.savez_compressed(os.path.join(HERE, "pore_scale_flow_bead_centeroids_3d.npz"), centres=beads,
+                        r=0.0044, half_length=0.00719, rbead=2.5e-4, buffer=np.array([1.5e-4, 3.5e-4]),
+                        source="sph-script/pore-scale-flow-bead-centeroids-3d.dat + pore-scale-flow-3d.lmp:15-22,120-125")

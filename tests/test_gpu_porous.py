@@ -52,21 +52,29 @@ def test_porous_small_matches_oracle(gpu_ctx):
     assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
 
 
-@pytest.mark.parametrize("nc", [80, 114, 126])
-def test_porous_config4_properties_at_size(gpu_ctx, nc):
+@pytest.mark.parametrize("nc,reference_beads", [(80, False), (114, False), (112, True)])
+def test_porous_config4_properties_at_size(gpu_ctx, nc, reference_beads):
     """nc = 80: 2 x 80^3 = 1 024 000 particles, 749 entries per row (767 M entries, 9 GB of sliced-ELL).
     nc = 114: 2 x 114^3 = 2 963 088 particles, 2.22e9 matrix entries -- beyond 2^31: the neighbour list goes in through
     isph_particles::neigh_ptr64 and the AMG set-up / Gauss-Seidel stream run on 64-bit offsets.
-    nc = 126: 2 x 126^3 = 4 000 752 particles, 3.0e9 entries -- BASELINE configs[4] at its own size on ONE GPU.
+    nc = 112 with the reference's own bead pack (tests/golden/pore_scale_flow_bead_centeroids_3d.npz = the script's
+    pore-scale-flow-bead-centeroids-3d.dat: 3807 beads in the middle half of a cylinder of aspect ratio 1.634):
+    2 x 112 x 168 x 112 = 4 214 784 particles, 3.16e9 entries -- BASELINE configs[4] at its own size on ONE GPU.
     Assembled on the device from torch-resident arrays and solved with FGMRES + SA-AMG.  Properties: row length of the
     bcc/Quintic stencil, solid rows are identity rows, the solve converges, residual <= 2e-8 re-computed with an
     independent SpMV, zero pressure on the solid rows."""
     import torch
     dev = torch.device("cuda", 0)
-    p = workload.make_porous_cylinder(nc, nbeads=40, rbead_cells=6.0)
+    if reference_beads:
+        import os
+        bp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pore_scale_flow_bead_centeroids_3d.npz"))
+        p = workload.make_porous_cylinder(nc, bead_pack=bp)
+        assert p["spec"].ncell == (112, 168, 112) and len(np.unique(p["part"][p["type"] == 3])) == 3807
+    else:
+        p = workload.make_porous_cylinder(nc, nbeads=40, rbead_cells=6.0)
     n, nall = p["nlocal"], p["nall"]
-    assert n == 2 * nc ** 3
-    assert (p["neigh_ptr"].dtype == np.int64) == (nc >= 114)          # 64-bit list offsets exactly when needed
+    assert n == 2 * int(np.prod(p["spec"].ncell))
+    assert (p["neigh_ptr"].dtype == np.int64) == (n * 748 >= 2 ** 31)      # 64-bit list offsets exactly when needed
     torch.cuda.empty_cache()
     colmap_h = workload.single_rank_colmap(p)
     dp = dict(p)
