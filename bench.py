@@ -151,12 +151,18 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
-    if rc != 0:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    live = list(procs)
+    while live:                                   # a rank that dies must not leave the others waiting in a collective
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or code
+                for q in live:
+                    q.kill()                      # exact children of this process, by handle
     sys.exit(rc)
 
 
