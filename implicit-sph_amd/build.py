@@ -13,7 +13,7 @@ INC = os.path.join(ROOT, "include")
 HOST_LIB = os.path.join(PKG, "libisph_host.so")
 HIP_LIB = os.path.join(PKG, "libisph_hip.so")
 
-HOST_SRCS = ["workload.cpp"]
+HOST_SRCS = ["workload.cpp", "lammps_formats.cpp"]
 HIP_SRCS = ["isph_capi.hip"]
 
 

@@ -34,8 +34,44 @@ def test_every_declared_symbol_is_exported(hiplib):
 
 def test_host_library_exports():
     lib = ctypes.CDLL(build.build_host())
-    for n in _declared("isph_workload.h"):
+    for n in _declared("isph_workload.h") + _declared("isph_lammps.h"):
         assert hasattr(lib, n)
+
+
+def test_lammps_format_converters():
+    """include/isph_lammps.h: LAMMPS' full neighbour list (ilist / numneigh / int** firstneigh with special-bond bits in
+    the top two bits of every index, functor.h:83-86, `jlist[jj] & NEIGHMASK`) -> the CSR of isph_particles, and the
+    tag -> matrix-column map Epetra builds in FillComplete (functor_graph.h:61-97).  Index work: exact."""
+    import numpy as np
+    C = ctypes
+    lib = C.CDLL(build.build_host())
+    lib.isph_flatten_neighbor_list.restype = C.c_longlong
+    rng = np.random.default_rng(3)
+    nlocal, nall = 7, 11
+    rows = [rng.choice(nall, size=rng.integers(0, 6), replace=False).astype(np.int32) for _ in range(nall)]
+    bits = [((rng.integers(0, 4, size=len(r)).astype(np.int64) << 30) | r).astype(np.uint32).view(np.int32) for r in rows]
+    numneigh = np.array([len(r) for r in rows], dtype=np.int32)
+    first = (C.POINTER(C.c_int) * nall)(*[b.ctypes.data_as(C.POINTER(C.c_int)) for b in bits])
+    ilist = rng.permutation(nlocal).astype(np.int32)                        # LAMMPS lists the owned atoms in bin order
+    ptr, ptr64 = np.zeros(nlocal + 1, np.int32), np.zeros(nlocal + 1, np.int64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    tot = lib.isph_flatten_neighbor_list(nlocal, p(ilist), p(numneigh), first, nlocal, nall, p(ptr), p(ptr64), None)
+    assert tot == int(numneigh[:nlocal].sum()) and np.array_equal(ptr64, np.concatenate([[0], np.cumsum(numneigh[:nlocal])]))
+    idx = np.zeros(tot, np.int32)
+    assert lib.isph_flatten_neighbor_list(nlocal, p(ilist), p(numneigh), first, nlocal, nall, p(ptr), p(ptr64), p(idx)) == tot
+    assert np.array_equal(ptr, ptr64)
+    for i in range(nlocal):
+        assert np.array_equal(idx[ptr[i]:ptr[i + 1]], rows[i])             # the bond bits are gone, the order is kept
+    bad = ilist.copy()
+    bad[1] = bad[0]
+    assert lib.isph_flatten_neighbor_list(nlocal, p(bad), p(numneigh), first, nlocal, nall, p(ptr), p(ptr64), None) == -1
+    # tags: owned 10..16, ghosts: a periodic image of an owned atom, two remote atoms, one of them seen twice
+    tag = np.array([10, 11, 12, 13, 14, 15, 16, 12, 40, 41, 40], dtype=np.int32)
+    colmap, gt = np.zeros(nall, np.int32), np.zeros(nall, np.int32)
+    ncol = lib.isph_colmap_from_tags(nlocal, nall, p(tag), p(colmap), p(gt))
+    assert ncol == 9 and list(colmap) == [0, 1, 2, 3, 4, 5, 6, 2, 7, 8, 7] and list(gt[:2]) == [40, 41]
+    tag[3] = 10
+    assert lib.isph_colmap_from_tags(nlocal, nall, p(tag), p(colmap), None) == -1   # two owned atoms with one tag
 
 
 def test_no_gpu_means_loud_failure_not_fallback(hiplib):
