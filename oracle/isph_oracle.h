@@ -32,7 +32,9 @@
  *   - not covered by reference numbers (Trilinos is un-vendored, no vectors at those boundaries): SA-AMG
  *     (isph_amg_oracle.c), Schwarz overlap > 0 (isph_schwarz_oracle.c), GCRO-DR (gcrodr.py), and entry-level values
  *     of the AntiSymmetric operator family (the tables' revision ran the Symmetric one).
- *   - the reference itself cannot be built here (needs Trilinos + LAMMPS headers): there is no oracle/_ref.
+ *   - of the reference itself only the kernel classes build here (kernel*.h need the standard library alone):
+ *     oracle/_ref/libisph_refkernels.so (oracle/build.py::build_ref) checks orc_kernel_val / orc_kernel_dval against
+ *     the real code; everything else needs Trilinos + LAMMPS headers.
  */
 #ifndef ISPH_ORACLE_H
 #define ISPH_ORACLE_H

@@ -129,3 +129,45 @@ def test_device_pnd_matches_oracle(gpu_ctx):
     P.precompute(corrections=False)
     xi = po[:n] * P.vfrac[:n]
     assert abs(xi[np.abs(parts["x"][:n, 1]) < 0.5].max() - 1.0) < 1e-13 and 0.5 < xi.min() < 1.0   # half a spacing from the wall: 0.81
+
+
+# ---------------------------------------------------------------- the reference's own kernel classes (oracle/_ref)
+@pytest.mark.parametrize("kernel,knum,support", [("wendland", 0, 2.0), ("quintic", 1, 3.0), ("cubic", 2, 2.0)])
+@pytest.mark.parametrize("dim", [2, 3])
+def test_device_kernel_values_equal_the_reference_kernel_classes(gpu_ctx, kernel, knum, support, dim):
+    """oracle/_ref/libisph_refkernels.so is the reference's KernelFuncWendland / Quintic / Cubic compiled from its own
+    headers (built in the build container by oracle/build.py, shipped with the tree).  Device side: isolated pairs of
+    particles -- FunctorOuterVolume gives V = 1 / (W(0) + W(r)), so W(r) comes back through isph_compute_volumes."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libisph_refkernels.so")
+    assert os.path.exists(path), "oracle/_ref travels with the tree (built where /root/reference exists)"
+    ref = ctypes.CDLL(path)
+    ref.ref_kernel_table.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p]
+    ref.ref_kernel_val.restype = ctypes.c_double
+    ref.ref_kernel_val.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    h = 0.0942
+    cut = support * h
+    s = np.concatenate([np.random.default_rng(2).uniform(0.02, support, 500), np.arange(0.5, support, 0.5),
+                        support + np.array([1e-9, 0.1, 0.4])])     # the last three: listed neighbours outside the cut
+    r = np.ascontiguousarray(s * h)
+    npair = len(r)
+    x = np.zeros((2 * npair, 3))
+    x[0::2, 0] = 10.0 * np.arange(npair)                              # pairs far apart from each other
+    x[1::2, 0] = x[0::2, 0] + r
+    ptr = np.arange(2 * npair + 1, dtype=np.int32)
+    idx = np.arange(2 * npair, dtype=np.int32) ^ 1                    # each particle's only neighbour is its partner
+    parts = dict(dim=dim, nlocal=2 * npair, nall=2 * npair, x=x, type=np.ones(2 * npair, np.int32), neigh_ptr=ptr,
+                 neigh_idx=idx, h=h, cut=cut)
+    colmap = np.arange(2 * npair, dtype=np.int32)
+    vf = hip.compute_volumes(gpu_ctx, parts, colmap, kernel=kernel)
+    w0 = ref.ref_kernel_val(knum, dim, 0.0, h)
+    w, dw = np.zeros(npair), np.zeros(npair)
+    rr = np.ascontiguousarray(x[1::2, 0] - x[0::2, 0])                # the distance the device sees
+    ref.ref_kernel_table(knum, dim, h, npair, rr.ctypes.data, w.ctypes.data, dw.ctypes.data)
+    inside = rr * rr < cut * cut
+    assert inside.sum() >= 500 and (~inside).sum() == 3
+    wdev = 1.0 / vf[0::2] - w0
+    assert np.max(np.abs(wdev[inside] - w[inside])) <= 1e-15 * w0 * 4      # W(r) to round-off of 1/V - W(0)
+    assert np.max(np.abs(1.0 / vf[0::2][~inside] - w0)) <= 1e-15 * w0 * 4  # outside the cut: the self term only

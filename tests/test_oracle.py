@@ -499,3 +499,38 @@ def test_amg_with_null_vector_masked_to_the_fluid_rows():
     bp = np.arange(0, n + 512, 512).clip(0, n).astype(np.int32)
     _, ii, _ = orc.solve(rp, ci, val, b, singular=True, null_mask=mask, prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
     assert ia.converged == 1 and ii.converged == 1 and ia.iters < ii.iters
+
+
+def test_oracle_kernels_equal_the_reference_kernel_classes():
+    """oracle/_ref/libisph_refkernels.so = the reference's OWN KernelFuncWendland / Quintic / Cubic (kernel*.h, the only
+    sources of the path that build without Trilinos and LAMMPS), compiled where they lie by oracle/build.py.  The oracle's
+    W and dW/dr must be those functions: same value to the last bit or two over the whole support, both dimensions,
+    including the breakpoints and the cut radius."""
+    import ctypes
+    import importlib.util
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_oracle_build", os.path.join(ROOT, "oracle", "build.py"))
+    ob = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ob)
+    path = ob.build_ref()
+    assert path and os.path.exists(path), "oracle/_ref is built wherever /root/reference exists and travels with the tree"
+    ref = ctypes.CDLL(path)
+    ref.ref_kernel_table.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(1)
+    for kernel, name, support in ((0, "wendland", 2.0), (1, "quintic", 3.0), (2, "cubic", 2.0)):
+        for dim in (2, 3):
+            for h in (1.5 * 2 * np.pi / 100, 0.037, 1.0):
+                s = np.concatenate([rng.uniform(0.0, support + 0.3, 400), np.arange(0.0, support + 0.51, 0.5),
+                                    np.nextafter(np.arange(1.0, support + 0.1, 1.0), 0.0)])
+                r = np.ascontiguousarray(s * h)
+                w, dw = np.zeros_like(r), np.zeros_like(r)
+                ref.ref_kernel_table(kernel, dim, h, len(r), r.ctypes.data, w.ctypes.data, dw.ctypes.data)
+                wo = np.array([orc.kernel_val(name, dim, float(x), h) for x in r])
+                dwo = np.array([orc.kernel_dval(name, dim, float(x), h) for x in r])
+                scale_w, scale_d = np.abs(w).max(), np.abs(dw).max()
+                assert np.max(np.abs(wo - w)) <= 4e-16 * scale_w, (name, dim, h)
+                assert np.max(np.abs(dwo - dw)) <= 4e-16 * scale_d, (name, dim, h)
+                out = np.abs(r / h) >= support                     # the ratio the kernels themselves form
+                assert np.all(w[out] == 0.0) and np.all(wo[out] == 0.0) and out.sum() > 5
