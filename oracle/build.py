@@ -25,13 +25,13 @@ REF_LIB = os.path.join(REF_DIR, "libisph_refkernels.so")
 
 def build_ref(force=False):
     """oracle/_ref: the part of the reference that compiles from its own sources with nothing but the standard library
-    -- the three SPH kernel classes -- built where the sources lie (never copied), for checking the oracle against the
+    -- the three SPH kernel classes and the particle-kind filter -- built where the sources lie (never copied), for checking the oracle against the
     real code.  Only possible where /root/reference exists (the build container); elsewhere the prebuilt library is
     used if it travelled along.  Returns the path or None."""
     shim = os.path.join(HERE, "ref_kernels_shim.cpp")
     if not os.path.isdir(REF_SRC):
         return REF_LIB if os.path.exists(REF_LIB) else None
-    deps = [shim] + [os.path.join(REF_SRC, h) for h in ("kernel.h", "kernel_wendland.h", "kernel_quintic.h", "kernel_cubic.h")]
+    deps = [shim] + [os.path.join(REF_SRC, h) for h in ("kernel.h", "kernel_wendland.h", "kernel_quintic.h", "kernel_cubic.h", "filter.h")]
     stale = force or not os.path.exists(REF_LIB) or any(os.path.getmtime(d) > os.path.getmtime(REF_LIB) for d in deps)
     if stale:
         os.makedirs(REF_DIR, exist_ok=True)

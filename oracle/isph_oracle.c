@@ -121,6 +121,9 @@ static inline int fyes1(int fi, int ikind) { return (ikind & fi) != 0; }
 static inline int fyes2(int fi, int fj, int ikind, int jkind) {
   return (ikind & fi) && (jkind & fj);
 }
+/* the two tests as the functors see them, for the check against the reference's FilterBinary (oracle/_ref) */
+int orc_filter_yes1(int filt_i, int ikind) { return fyes1(filt_i, ikind); }
+int orc_filter_yes2(int filt_i, int filt_j, int ikind, int jkind) { return fyes2(filt_i, filt_j, ikind, jkind); }
 /* sphOperator<AntiSymmetric>, ref: functor.h:9-20 */
 static inline double sph_op(int antisym, double fi, double fj) {
   return antisym ? (fi + fj) : (fj - fi);

@@ -1,12 +1,13 @@
 // TEST INFRASTRUCTURE.  C entry points around the reference's OWN kernel classes, compiled from the sources where they
-// lie under /root/reference (kernel.h, kernel_wendland.h, kernel_quintic.h, kernel_cubic.h: the only files of the path
-// that need nothing but the standard library).  Built by oracle/build.py into oracle/_ref/libisph_refkernels.so when
+// lie under /root/reference (kernel.h, kernel_wendland.h, kernel_quintic.h, kernel_cubic.h and filter.h: the only files
+// of the path that need nothing but the standard library).  Built by oracle/build.py into oracle/_ref/libisph_refkernels.so when
 // /root/reference is present; nothing of the reference is copied into the repository -- the headers are found through
 // the compiler's include path.  The library is a checker for the oracle's and the device's W and dW/dr
 // (tests/test_oracle.py, tests/test_gpu_reference_tables.py); everything else of the reference needs Trilinos + LAMMPS.
 #include "kernel_wendland.h"
 #include "kernel_quintic.h"
 #include "kernel_cubic.h"
+#include "filter.h"
 
 namespace {
 LAMMPS_NS::KernelFunction *make(int kernel, int dim) {
@@ -19,6 +20,17 @@ LAMMPS_NS::KernelFunction *make(int kernel, int dim) {
 }  // namespace
 
 extern "C" {
+// FilterBinary with setPairYes(filt_i, filt_j): the particle-kind tests every functor makes (filter.h:33-57)
+int ref_filter_yes1(int filt_i, int ikind) {
+  LAMMPS_NS::FilterBinary f;
+  f.setPairYes(filt_i);
+  return f.yes(ikind) ? 1 : 0;
+}
+int ref_filter_yes2(int filt_i, int filt_j, int ikind, int jkind) {
+  LAMMPS_NS::FilterBinary f;
+  f.setPairYes(filt_i, filt_j);
+  return f.yes(ikind, jkind) ? 1 : 0;
+}
 // kernel: 0 Wendland, 1 Quintic, 2 Cubic (the oracle's numbering); the calls the functors make: kernel->val(r, h)
 double ref_kernel_val(int kernel, int dim, double r, double h) {
   LAMMPS_NS::KernelFunction *k = make(kernel, dim);

@@ -518,6 +518,14 @@ def test_oracle_kernels_equal_the_reference_kernel_classes():
     ref = ctypes.CDLL(path)
     ref.ref_kernel_table.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p]
+    # the particle-kind filter of every functor (filter.h:33-57) over all kinds of pair_isph.h:113-138 and all filters in use
+    kinds = [99, 12, 127, 1, 2, 4, 8, 32, 64]
+    for fi in (99, 12, 127):
+        for ik in kinds:
+            assert ref.ref_filter_yes1(fi, ik) == orc.lib().orc_filter_yes1(fi, ik)
+            for fj in (99, 12, 127):
+                for jk in kinds:
+                    assert ref.ref_filter_yes2(fi, fj, ik, jk) == orc.lib().orc_filter_yes2(fi, fj, ik, jk)
     rng = np.random.default_rng(1)
     for kernel, name, support in ((0, "wendland", 2.0), (1, "quintic", 3.0), (2, "cubic", 2.0)):
         for dim in (2, 3):
