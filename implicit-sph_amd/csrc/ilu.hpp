@@ -1093,6 +1093,178 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   return ISPH_SUCCESS;
 }
 
+// The same sweep for NV right-hand sides at once (the lockstep Helmholtz solve, solver.hpp gmres_lockstep): the stream
+// -- values, column words, step flags -- is read once and applied to NV vectors; every vector goes through exactly the
+// operations of k_ilu_solve_stream, in the same order, so the results are bit-identical to NV separate applications.
+// LDS per wave: y[NV][B] (the L -> U reordering happens in place, through registers) + the pivots in U order.
+struct IluVecs {
+  const double *r[4];
+  double *z[4];
+};
+template <int WAVES, int PF, int NV>
+__global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream_multi(int n, int B, int nblocks,
+                                                                       const long long *__restrict__ boff,
+                                                                       const double *__restrict__ sv,
+                                                                       const unsigned short *__restrict__ sc,
+                                                                       const unsigned char *__restrict__ si,
+                                                                       const unsigned short *__restrict__ sperm,
+                                                                       const int *__restrict__ blkinfo,
+                                                                       const double *__restrict__ dinv, IluVecs X,
+                                                                       int capf, int slack) {
+  extern __shared__ double lds_y[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
+  if (b >= nblocks) return;
+  double *yb = lds_y + (size_t)wave * (NV + 1) * B;  // y[k] = yb + k * B
+  double *dv = yb + (size_t)NV * B;
+  const int blo = b * B, m = min(blo + B, n) - blo;
+  const unsigned short *__restrict__ posl = sperm + (size_t)b * 2 * B;
+  const unsigned short *__restrict__ posu = posl + B;
+  for (int t = lane; t < m; t += 64) {
+    const int pl = posl[t];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) yb[k * B + pl] = X.r[k][blo + t];
+    dv[posu[t]] = dinv[blo + t];
+  }
+  const long long base = ilu_base_chunk(boff, b, capf, slack);
+  const int nL = __builtin_amdgcn_readfirstlane(blkinfo[4 * b]), nU = __builtin_amdgcn_readfirstlane(blkinfo[4 * b + 1]);
+  const int nsU = __builtin_amdgcn_readfirstlane(blkinfo[4 * b + 3]);
+  const double *__restrict__ pv = sv + base * 64 + lane;
+  const unsigned short *__restrict__ pc = sc + base * 64 + lane;
+  const unsigned char *__restrict__ pi = si + base;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  double vq[PF];
+  unsigned cq[PF], iq[PF];
+  const int ntot = nL + nU;
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    vq[u] = __builtin_nontemporal_load(&pv[(long long)u * 64]);
+    cq[u] = __builtin_nontemporal_load(&pc[(long long)u * 64]);
+    iq[u] = pi[u];
+  }
+  // L -> U: every vector changes from the L order to the U order in place (values through registers: B <= 1024 is at
+  // most 16 per lane), rows without upper dependencies are finished by their pivot
+  auto to_upper = [&]() {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double hold[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int t = lane + 64 * q;
+        hold[q] = t < m ? yb[k * B + posl[t]] : 0.0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int t = lane + 64 * q;
+        if (t < m) yb[k * B + posu[t]] = hold[q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = nsU + lane; t < m; t += 64) {
+      const double d = dv[t];
+#pragma unroll
+      for (int k = 0; k < NV; ++k) yb[k * B + t] *= d;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  double acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+  bool upper = false;
+  int done = 0;
+  for (int c0 = 0; c0 < ntot; c0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int c = c0 + u;
+      const double v = vq[u];
+      const unsigned cw = cq[u];
+      const unsigned iw = __builtin_amdgcn_readfirstlane(iq[u]);
+      vq[u] = __builtin_nontemporal_load(&pv[(long long)(c + PF) * 64]);
+      cq[u] = __builtin_nontemporal_load(&pc[(long long)(c + PF) * 64]);
+      iq[u] = pi[c + PF];
+      if (c < ntot) {
+        if (c == nL && !upper) {
+          upper = true;
+          done = 0;
+          to_upper();
+        }
+        const int col = (int)(cw & 0x3FFu);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] = fma(v, yb[k * B + col], acc[k]);
+        if (iw & 1u) {
+          const bool tail = (cw >> kTail16) & 1u;
+          const unsigned long long tails = __ballot(tail);
+          const int pos = tail ? done + __popcll(tails & below) : 0;
+          done += __popcll(tails);
+          const double dvr = upper ? dv[pos] : 1.0;
+          const int p = (cw >> kPos16) & 15;
+          const unsigned need = (iw >> 1) & 7u;
+          const bool cont = (cw >> kCont16) & 1u;
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {
+            const double yold = yb[k * B + pos];
+            double s = acc[k], q;
+            q = dpp_move<0x111>(s); s += p >= 1 ? q : 0.0;
+            q = dpp_move<0x112>(s); s += p >= 2 ? q : 0.0;
+            q = dpp_move<0x114>(s); s += p >= 4 ? q : 0.0;
+            q = dpp_move<0x118>(s); s += p >= 8 ? q : 0.0;
+            if (need) {
+              if (need & 1u) { q = dpp_move<0x142, 0x2>(s); s += cont ? q : 0.0; }
+              if (need & 2u) { q = dpp_move<0x142, 0x4>(s); s += cont ? q : 0.0; }
+              if (need & 4u) { q = dpp_move<0x142, 0x8>(s); s += cont ? q : 0.0; }
+            }
+            if (tail) yb[k * B + pos] = (yold - s) * dvr;
+            acc[k] = 0.0;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+  if (!upper) to_upper();
+  for (int t = lane; t < m; t += 64) {
+    const int pu = posu[t];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) X.z[k][blo + t] = yb[k * B + pu];
+  }
+}
+
+// z_k = U^-1 D^-1 L^-1 r_k for K = 2..4 vectors in one sweep of the factor stream (falls back to K sweeps otherwise)
+inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z);
+inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double *const *rs, double *const *zs) {
+  ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
+  if (F->n == 0) return ISPH_SUCCESS;
+  constexpr int WV = 4;
+  const size_t lds = sizeof(double) * (size_t)(K + 1) * (size_t)F->B * WV;
+  if (K < 2 || K > 4 || lds > 160 * 1024) {
+    for (int k = 0; k < K; ++k) ISPH_CHECK(ilu_apply(ctx, F, rs[k], zs[k]));
+    return ISPH_SUCCESS;
+  }
+  IluVecs X;
+  for (int k = 0; k < 4; ++k) { X.r[k] = rs[k < K ? k : 0]; X.z[k] = zs[k < K ? k : 0]; }
+#define ISPH_ILU_LAUNCH_MULTI(NV)                                                                                          \
+  do {                                                                                                                      \
+    ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_solve_stream_multi<WV, kPrefetch, NV>),         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+    hipLaunchKernelGGL((k_ilu_solve_stream_multi<WV, kPrefetch, NV>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, \
+                       ctx->stream, F->n, F->B, F->nblocks, F->boff.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p,               \
+                       F->blkinfo.p, F->dinv.p, X, F->capf, F->slack);                                                      \
+  } while (0)
+  if (K == 2) ISPH_ILU_LAUNCH_MULTI(2);
+  else if (K == 3) ISPH_ILU_LAUNCH_MULTI(3);
+  else ISPH_ILU_LAUNCH_MULTI(4);
+#undef ISPH_ILU_LAUNCH_MULTI
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
 inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z) {
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
   if (F->n == 0) return ISPH_SUCCESS;

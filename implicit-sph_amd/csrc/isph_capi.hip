@@ -104,6 +104,14 @@ int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z
   return ilu_apply(ctx, M->ilu, r, z);
 }
 
+// K applications of one preconditioner: block ILU(k) sweeps its factor stream once for all vectors
+int prec_apply_multi_dev(isph_ctx *ctx, const isph_prec *M, int K, const double *const *rs, double *const *zs) {
+  ISPH_REQUIRE(M != nullptr, "preconditioner is NULL");
+  if (M->type == 2 && M->ilu) return ilu_apply_multi(ctx, M->ilu, K, rs, zs);
+  for (int k = 0; k < K; ++k) ISPH_CHECK(prec_apply_dev(ctx, M, rs[k], zs[k]));
+  return ISPH_SUCCESS;
+}
+
 // upload helper: returns device pointer (either the caller's or a staged copy)
 template <class T>
 int stage_in(isph_ctx *ctx, const T *src, size_t n, int on_device, DevBuf<T> &tmp, const T **out) {

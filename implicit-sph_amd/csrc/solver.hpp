@@ -14,6 +14,7 @@
 namespace isph {
 
 int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z);  // isph_capi.hip
+int prec_apply_multi_dev(isph_ctx *ctx, const isph_prec *M, int K, const double *const *rs, double *const *zs);  // isph_capi.hip
 
 inline int allreduce_inplace(isph_ctx *ctx, double *d, int count) {
   if (ctx->comm) ISPH_CHECK_NCCL(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
@@ -240,9 +241,11 @@ struct LinOp {
       ISPH_CHECK_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
       return ISPH_SUCCESS;
     }
-    if (blk) {
-      for (int i = 0; i < dim; ++i) ISPH_CHECK(prec_apply_dev(ctx, M, r + (size_t)i * nloc, z + (size_t)i * nloc));
-      return ISPH_SUCCESS;
+    if (blk) {  // block-diagonal with the same operator on every component: one sweep for all of them where that exists
+      const double *rs[4];
+      double *zs[4];
+      for (int i = 0; i < dim && i < 4; ++i) { rs[i] = r + (size_t)i * nloc; zs[i] = z + (size_t)i * nloc; }
+      return prec_apply_multi_dev(ctx, M, dim, rs, zs);
     }
     return prec_apply_dev(ctx, M, r, z);
   }
@@ -601,12 +604,20 @@ inline int gmres_lockstep(const LinOp &op, int K, const double *const *bs, doubl
     for (int k = 0; k < K; ++k)
       if (!sys[(size_t)k].done && sys[(size_t)k].in_cycle) act[na++] = k;
     if (na == 0) break;
-    // z = M^-1 v_j, system by system; w = A z for all of them in one sweep
-    for (int a = 0; a < na; ++a) {
-      Sys &s = sys[(size_t)act[a]];
-      ISPH_CHECK(op.prec(s.V + (long long)s.j * ld, s.Z + (long long)s.j * ld));
-      xin[a] = s.Z + (long long)s.j * ld;
-      yout[a] = s.w;
+    // z = M^-1 v_j and w = A z for all active systems: one sweep of the factor stream, one of the matrix
+    {
+      const double *vin[kMaxLockstep];
+      double *zout[kMaxLockstep];
+      for (int a = 0; a < na; ++a) {
+        Sys &s = sys[(size_t)act[a]];
+        vin[a] = s.V + (long long)s.j * ld;
+        zout[a] = s.Z + (long long)s.j * ld;
+        xin[a] = zout[a];
+        yout[a] = s.w;
+      }
+      if (op.M) ISPH_CHECK(prec_apply_multi_dev(ctx, op.M, na, vin, zout));
+      else
+        for (int a = 0; a < na; ++a) ISPH_CHECK(op.prec(vin[a], zout[a]));
     }
     ISPH_CHECK(spmm_dev(ctx, op.A, na, xin, yout));
     // Gram-Schmidt of every system on the device, its scalars on their way to the system's own mailbox
