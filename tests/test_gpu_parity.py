@@ -1166,3 +1166,26 @@ def test_operators_with_device_tensors_and_refusal_of_mislabelled_pointers(gpu_c
     assert rc != 0 and b"on_device = 0" in hip.lib().isph_last_error()
     with pytest.raises(ValueError):
         hip.gradient(gpu_ctx, dparts, cm, f, vf)      # host field with device particles
+
+
+def test_repeated_setups_do_not_grow_device_memory(gpu_ctx):
+    """The reference rebuilds matrix and preconditioner every time step; here the released buffers go back to the
+    library's pool and the next set-up takes them from there: device memory in use must be flat from round to round
+    (scripts/soak.py is the 200-round version at 100^3)."""
+    import torch
+    pr = Problem(tgv_spec(dim=3, n=32, mode=workload.JITTER))
+    used = []
+    for r in range(8):
+        A, b = hip.assemble_poisson(gpu_ctx, pr.parts, pr.colmap, pr.spec.dt, pr.parts["rho"],
+                                    np.ascontiguousarray(pr.parts["v"]), vfrac=pr.P.vfrac)
+        M = hip.PrecondAMG(gpu_ctx, A, nullvec=np.full(pr.n, 1.0 / np.sqrt(pr.n))) if r % 2 else hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 512)
+        x = np.zeros(pr.n)
+        info = hip.solve(gpu_ctx, A, b.copy(), x, prec=M, singular=True)
+        assert info.converged == 1
+        M.close()
+        A.close()
+        gpu_ctx.sync()
+        fr, tot = torch.cuda.mem_get_info()
+        used.append(tot - fr)
+    assert max(used[3:]) - min(used[3:]) <= 8 << 20, used          # after both kinds ran once: flat to within 8 MB
+    assert hip.pool_cached_bytes() > 0
