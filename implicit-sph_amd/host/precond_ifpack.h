@@ -3,7 +3,9 @@
 #pragma once
 #include <cstdio>
 #include <string>
+#include <vector>
 
+#include "halo_lists.h"
 #include "precond.h"
 
 namespace LAMMPS_NS {
@@ -50,20 +52,37 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     const std::string mode = _param->get("schwarz: combine mode", "Add");
     // "isph: block rows" = 0: the reference's own decomposition -- one subdomain per rank = the whole local matrix,
     // ILU(fill) level-scheduled on the device (isph_prec_create_schwarz).  "Overlap Level" extends a subdomain by rows
-    // of the neighbouring RANKS (Ifpack ignores it on one rank); the matrix-row halo that needs is not built, so with
-    // more than one rank the subdomains stay un-overlapped and the notice below says so.
+    // of the neighbouring RANKS (Ifpack ignores it on one rank): level 1 = the rows of the matrix' ghost columns,
+    // fetched with the matrix' importer (halo_lists.h) and factored with the rank's own (isph_prec_create_overlap);
+    // levels above 1 are factored as level 1 and the notice below says so.
+    if (block == 0 && overlap >= 1 && _A.get() != NULL && _A->NumMyCols() > _A->NumMyRows()) {
+      HaloLists H;
+      std::vector<int> rp, ci;
+      std::vector<double> v;
+      if (halo_lists_from_import(*_A, H) != ISPH_SUCCESS || extend_rows_one_layer(*_A, _comm, H, rp, ci, v) != ISPH_SUCCESS) {
+        std::fprintf(stderr, ">> PrecondWrapper_Ifpack(HIP): cannot import the rows of the ghost columns (Overlap Level %d)\n", overlap);
+        return ISPH_FAILURE;
+      }
+      if (overlap > 1 && _comm.MyPID() == 0 && !_warned) {
+        std::printf(">> PrecondWrapper_Ifpack(HIP): Overlap Level %d across ranks is factored as Overlap Level 1\n", overlap);
+        _warned = true;
+      }
+      const int next = (int)rp.size() - 1;
+      isph_mat *Aext = NULL;
+      int ierr = isph_mat_create_csr(ctx, next, next, rp.data(), ci.data(), v.data(), 0, &Aext);
+      if (ierr != ISPH_SUCCESS) return ierr;
+      ierr = isph_prec_create_overlap(ctx, Aext, _A->NumMyRows(), fill, (mode == "Zero") ? 1 : 0, H.npeers(), H.peers.data(),
+                                      H.send_ptr.data(), H.send_idx.data(), H.recv_ptr.data(), &_M);
+      isph_mat_destroy(Aext);
+      return ierr;
+    }
     if (block == 0 || block > 1024) {
       isph_schwarz_params sp;
       isph_schwarz_params_default(&sp);
       sp.level_of_fill = fill;
       sp.block_size = block;
-      sp.overlap = block == 0 ? 0 : overlap;    // subdomains inside one rank can be extended; rank subdomains cannot yet
+      sp.overlap = block == 0 ? 0 : overlap;    // subdomains inside one rank are extended by schwarz.hpp itself
       sp.combine = (mode == "Zero") ? 1 : 0;
-      if (block == 0 && overlap != 0 && _comm.NumProc() > 1 && _comm.MyPID() == 0 && !_warned) {
-        std::printf(">> PrecondWrapper_Ifpack(HIP): Overlap Level %d across ranks is not available; rank subdomains "
-                    "are factored without overlap (ILU(%d))\n", overlap, fill);
-        _warned = true;
-      }
       return isph_prec_create_schwarz(ctx, A, &sp, &_M);
     }
     // default: the throughput path -- block-Jacobi ILU(fill) on subdomains of `block` rows inside the rank, overlap 0.

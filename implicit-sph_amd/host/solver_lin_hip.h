@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "halo_lists.h"
 #include "isph_hip.h"
 #include "solver_lin.h"
 
@@ -204,43 +205,9 @@ class SolverLin_HIP : public SolverLin {
   // grouped by source rank, Epetra's column-map order).
   int attachHalo(isph_mat *A, const Epetra_CrsMatrix &E) {
     if (E.NumMyCols() == E.NumMyRows()) return ISPH_SUCCESS;
-#ifdef HAVE_EPETRA
-    const Epetra_Import *imp = E.Importer();
-    if (!imp) return ISPH_FAILURE;
-    const Epetra_MpiDistributor *d = dynamic_cast<const Epetra_MpiDistributor *>(&imp->Distributor());
-    if (!d) return ISPH_FAILURE;
-    const int nto = d->NumSends(), nfrom = d->NumReceives();
-    const int *pto = d->ProcsTo(), *lto = d->LengthsTo(), *pfrom = d->ProcsFrom(), *lfrom = d->LengthsFrom();
-    const int *exp = imp->ExportLIDs();
-#else
-    const Epetra_Import *imp = E.Importer();
-    if (!imp) return ISPH_FAILURE;
-    const int nto = imp->NumSends(), nfrom = imp->NumReceives();
-    const int *pto = imp->ProcsTo(), *lto = imp->LengthsTo(), *pfrom = imp->ProcsFrom(), *lfrom = imp->LengthsFrom();
-    const int *exp = imp->ExportLIDs();
-#endif
-    std::vector<int> peers;
-    for (int k = 0; k < nto; ++k) peers.push_back(pto[k]);
-    for (int k = 0; k < nfrom; ++k) peers.push_back(pfrom[k]);
-    std::sort(peers.begin(), peers.end());
-    peers.erase(std::unique(peers.begin(), peers.end()), peers.end());
-    const int np = (int)peers.size();
-    std::vector<int> send_ptr((size_t)np + 1, 0), recv_ptr((size_t)np + 1, 0), send_idx;
-    std::vector<int> exp_off((size_t)nto + 1, 0);
-    for (int k = 0; k < nto; ++k) exp_off[(size_t)k + 1] = exp_off[(size_t)k] + lto[k];
-    for (int p = 0; p < np; ++p) {
-      for (int k = 0; k < nto; ++k)
-        if (pto[k] == peers[(size_t)p]) send_idx.insert(send_idx.end(), exp + exp_off[(size_t)k], exp + exp_off[(size_t)k + 1]);
-      send_ptr[(size_t)p + 1] = (int)send_idx.size();
-      int nr = 0;
-      for (int k = 0; k < nfrom; ++k)
-        if (pfrom[k] == peers[(size_t)p]) nr += lfrom[k];
-      recv_ptr[(size_t)p + 1] = recv_ptr[(size_t)p] + nr;
-    }
-    // ghost columns must be grouped by source rank in ascending rank order (ProcsFrom is sorted by Epetra)
-    for (int k = 1; k < nfrom; ++k)
-      if (pfrom[k] < pfrom[k - 1]) return ISPH_FAILURE;
-    return isph_mat_set_halo(_ctx, A, np, peers.data(), send_ptr.data(), send_idx.data(), recv_ptr.data());
+    HaloLists H;
+    if (halo_lists_from_import(E, H) != ISPH_SUCCESS) return ISPH_FAILURE;
+    return isph_mat_set_halo(_ctx, A, H.npeers(), H.peers.data(), H.send_ptr.data(), H.send_idx.data(), H.recv_ptr.data());
   }
   int report_failure() {
     if (_comm.MyPID() == 0) std::fprintf(stderr, ">> SolverLin_HIP: %s\n", isph_last_error());

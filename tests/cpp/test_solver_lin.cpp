@@ -76,10 +76,10 @@ static int run_block(const char *fin, const char *fout) {
   return info.converged ? 0 : 3;
 }
 
-// "selfhalo": in.bin = n, ncol, nnz, rp, ci (ghost columns >= n), val, b[n], nsend, send_idx[nsend].  The matrix carries
+// "selfhalo" / "selfhalo-overlap": in.bin = n, ncol, nnz, rp, ci (ghost columns >= n), val, b[n], nsend, send_idx[nsend].  The matrix carries
 // an Epetra_Import whose only peer is this rank (periodic images routed through the halo plan): drives
 // isph_ctx_create_dist + isph_mat_set_halo from the C++ surface, i.e. the N > 1 code path of SolverLin(MPI_Comm&).
-static int run_selfhalo(const char *fin, const char *fout) {
+static int run_selfhalo(const char *fin, const char *fout, bool overlap, bool extend_only = false) {
   FILE *f = std::fopen(fin, "rb");
   if (!f) return 2;
   int n = 0, ncol = 0, nnz = 0, nsend = 0;
@@ -98,11 +98,25 @@ static int run_selfhalo(const char *fin, const char *fout) {
   const int me = 0, nrecv = ncol - n;
   Epetra_Import importer(1, &me, &nsend, send_idx.data(), 1, &me, &nrecv);
   Epetra_CrsMatrix AA(n, ncol, rp.data(), ci.data(), val.data(), &importer);
+  if (extend_only) {   // no device: out.bin = next, nnz, rp, ci, val of the overlapped subdomain (host/halo_lists.h)
+    HaloLists H;
+    std::vector<int> erp, eci;
+    std::vector<double> ev;
+    if (halo_lists_from_import(AA, H) != ISPH_SUCCESS || extend_rows_one_layer(AA, Epetra_MpiComm(world), H, erp, eci, ev) != ISPH_SUCCESS) return 1;
+    const int next = (int)erp.size() - 1, ennz = (int)eci.size();
+    f = std::fopen(fout, "wb");
+    std::fwrite(&next, 4, 1, f); std::fwrite(&ennz, 4, 1, f);
+    std::fwrite(erp.data(), 4, erp.size(), f); std::fwrite(eci.data(), 4, eci.size(), f); std::fwrite(ev.data(), 8, ev.size(), f);
+    std::fclose(f);
+    return 0;
+  }
   PrecondWrapper_Ifpack prec(world);
   Teuchos::ParameterList *pp = prec.setParameters();
   pp->set("fact: level-of-fill", 0);
-  pp->set("Overlap Level", 0);
-  pp->set("isph: block rows", 256);
+  // "selfhalo-overlap": the reference's decomposition -- one subdomain per rank, Overlap Level 1: the rows of the ghost
+  // columns come through the matrix' importer (host/halo_lists.h) and isph_prec_create_overlap factors the extension
+  pp->set("Overlap Level", overlap ? 1 : 0);
+  pp->set("isph: block rows", overlap ? 0 : 256);
   SolverLin_Belos li_solver(world);
   li_solver.setParameters();
   li_solver.setNodalMap(&nodalmap);
@@ -126,7 +140,9 @@ static int run_selfhalo(const char *fin, const char *fout) {
 
 int main(int argc, char **argv) {
   if (argc > 4 && std::string(argv[4]) == "block") return run_block(argv[1], argv[2]);
-  if (argc > 4 && std::string(argv[4]) == "selfhalo") return run_selfhalo(argv[1], argv[2]);
+  if (argc > 4 && std::string(argv[4]) == "selfhalo") return run_selfhalo(argv[1], argv[2], false);
+  if (argc > 4 && std::string(argv[4]) == "selfhalo-overlap") return run_selfhalo(argv[1], argv[2], true);
+  if (argc > 4 && std::string(argv[4]) == "selfhalo-extend") return run_selfhalo(argv[1], argv[2], true, true);
   if (argc < 4) { std::fprintf(stderr, "usage: %s in.bin out.bin singular(0/1) [cg|ml]\n", argv[0]); return 2; }
   FILE *f = std::fopen(argv[1], "rb");
   if (!f) return 2;

@@ -251,3 +251,36 @@ def test_two_rank_extended_subdomains_are_the_global_rows_of_one_overlap_layer(d
     for rank, col_tag, (rpe, cie, ve), nl, r, z in res:
         ext = pos[col_tag]
         assert np.max(np.abs(z - zsum[ext[:nl]])) <= 1e-9 * np.abs(zsum).max()
+
+
+def test_cpp_adapter_row_import_equals_the_python_plumbing(tmp_path):
+    """host/halo_lists.h (what PrecondWrapper_Ifpack uses for "Overlap Level" 1 when the matrix carries an Epetra_Import)
+    builds the same overlapped subdomain as dist.extend_rows; no device involved (driver mode "selfhalo-extend")."""
+    import subprocess
+    from isph_amd import build, dist, workload
+    import oracle as orc
+    exe = build.build_cpp_test()
+    spec = workload.TGVSpec(dim=3, ncell=(8, 8, 8), brick=(4, 4, 4), mode=workload.JITTER)
+    parts = workload.make_tgv(spec)
+    plan = dist.make_self_halo_plan(parts)
+    P = orc.Particles(parts, plan.colmap).precompute(corrections=False)
+    rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True)
+    n = parts["nlocal"]
+    assert ci.max() >= n
+    fin, fout = tmp_path / "sys.bin", tmp_path / "ext.bin"
+    with open(fin, "wb") as f:
+        np.array([n, plan.ncol, len(val)], np.int32).tofile(f)
+        rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f); val.tofile(f); b.tofile(f)
+        np.array([len(plan.send_idx)], np.int32).tofile(f)
+        plan.send_idx.astype(np.int32).tofile(f)
+    r = subprocess.run([exe, str(fin), str(fout), "1", "selfhalo-extend"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with open(fout, "rb") as f:
+        nxt, nnz = np.fromfile(f, np.int32, 2)
+        rpc = np.fromfile(f, np.int32, nxt + 1); cic = np.fromfile(f, np.int32, nnz); vc = np.fromfile(f, np.float64, nnz)
+    rpe, cie, ve = dist.extend_rows(plan, rp, ci, val, None)
+    assert nxt == plan.ncol and np.array_equal(rpc, rpe)
+    import scipy.sparse as sps
+    Ac = sps.csr_matrix((vc, cic, rpc), shape=(nxt, nxt))
+    Ap = sps.csr_matrix((ve, cie, rpe), shape=(nxt, nxt))
+    assert abs(Ac - Ap).max() == 0.0

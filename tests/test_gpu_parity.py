@@ -571,6 +571,49 @@ def test_cpp_solver_lin_mirror_with_halo(tmp_path):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
 
 
+def test_cpp_ifpack_overlap_level_one_through_the_importer(tmp_path):
+    """PrecondWrapper_Ifpack with "isph: block rows" = 0 and the reference's default "Overlap Level" 1 on a matrix that
+    carries an Epetra_Import (precond_ifpack.h:43,60-74): the adapter imports the rows of the ghost columns
+    (host/halo_lists.h) and factors the extended subdomain (isph_prec_create_overlap).  Same iteration count and solution
+    as the Python plumbing of the same preconditioner (dist.extend_rows + hip.PrecondOverlap, pinned against the oracle in
+    tests/test_gpu_schwarz.py)."""
+    import subprocess
+    from isph_amd import build, dist
+    exe = build.build_cpp_test()
+    pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    plan = dist.make_self_halo_plan(pr.parts)
+    Ph = orc.Particles(pr.parts, plan.colmap)
+    Ph.precompute(corrections=False)
+    rph, cih, valh, bh = Ph.poisson(pr.spec.dt, pr.parts["rho"], pr.parts["v"], singular=orc.NULLSPACE)
+    fin, fout = tmp_path / "sys.bin", tmp_path / "x.bin"
+    with open(fin, "wb") as f:
+        np.array([pr.n, plan.ncol, len(valh)], np.int32).tofile(f)
+        rph.astype(np.int32).tofile(f); cih.astype(np.int32).tofile(f); valh.tofile(f); bh.tofile(f)
+        np.array([len(plan.send_idx)], np.int32).tofile(f)
+        plan.send_idx.astype(np.int32).tofile(f)
+    r = subprocess.run([exe, str(fin), str(fout), "1", "selfhalo-overlap"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    x = np.fromfile(fout)
+    it_cpp = int(r.stdout.split("iters=")[1].split()[0])
+    ctx = hip.Context(0, rank=0, nranks=1, uid=hip.Context.unique_id())
+    try:
+        A = hip.Matrix.from_csr(ctx, rph.astype(np.int32), cih.astype(np.int32), valh, ncol=plan.ncol)
+        A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+        rpe, cie, ve = dist.extend_rows(plan, rph, cih, valh, None)
+        Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
+        M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=0, combine="add")
+        xp = np.zeros(pr.n)
+        info = hip.solve(ctx, A, bh.copy(), xp, prec=M, singular=True)
+    finally:
+        ctx.close()
+    assert info.converged == 1 and abs(info.iters - it_cpp) <= 1, (info.iters, it_cpp)
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=True, prec="none")
+    assert it_cpp < io.iters
+    assert np.linalg.norm(x - xp) <= 1e-6 * np.linalg.norm(xp)
+    assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
 # ---------------------------------------------------------------- Helmholtz builder (SURVEY §8 a8)
 @pytest.mark.parametrize("case", [dict(dim=2, n=20, mode=workload.JITTER), dict(dim=3, n=12, mode=workload.ADVECT),
                                   dict(dim=2, n=4, mode=workload.JITTER, brick=0)])
