@@ -27,7 +27,7 @@ int sell_sort_rows(isph_ctx *ctx, Sell &S);         // isph_capi.hip
 int sell_set_wmax(isph_ctx *ctx, Sell &S);          // isph_capi.hip
 
 constexpr double kEps = 1.0e-24;  // ISPH_EPSILON, ref: macrodef.h:6
-enum { KIND_FLUID = 99, KIND_SOLID = 12, KIND_ALL = 127 };
+enum { KIND_FLUID = 99, KIND_SOLID = 12, KIND_BUFFER_DIRICHLET = 32, KIND_BUFFER_NEUMANN = 64, KIND_ALL = 127 };  // pair_isph.h:113-124
 
 struct AsmTables {  // small per-type tables, device resident
   const int *kind;      // [ntypes+1]
@@ -760,8 +760,16 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
 //   b_ik = v_ik + w_ik + dt (f_ik/rho_i + g_k) - dt/rho_i (grad p)_k
 // One lane per row like k_asm_poisson; w is accumulated while the row is built
 // (the reference forms it with Epetra's Multiply on the assembled matrix).
+// The same rows serve the two scalar callers of the path (MODE template parameter of k_asm_helmholtz):
+//   MODE 1, solute transport (ref: functor_solute_transport.h:47-138): Laplacian(dt dcoeff), FilterMatchBinary
+//     (Fluid, Fluid - BufferNeumann) -- rows of kind == Fluid only --, w = (1-theta) A c, A <- -theta A,
+//     diag = 1 + A_ii on Fluid rows and 1 on Solid / Buffer rows, b = c (+ w on Fluid rows);
+//   MODE 2, applied electric potential (ref: functor_applied_electric_potential.h:36-98): Laplacian(-1, sigma),
+//     FilterMatchBinary (Fluid, Fluid), no theta scaling, diag = 1 on Solid / Buffer rows, b = phi on Buffer rows, else 0.
+// The scalar field (c or phi) travels in r2.y, the material (1 or sigma) in r2.x; dt holds the Laplacian's alpha.
 struct HelmholtzArgs {
   int nlocal, antisym, incremental, lda, morris;
+  int filt_i, filt_j;  // MODE != 0: row kind to match exactly, neighbour-kind mask
   double dt, theta, g[3], safe;
   const double *x, *vfrac, *Gc, *Lc, *rho, *nu, *p, *f, *v, *pnd;
   const int *type, *nptr, *nidx, *colmap;
@@ -783,8 +791,19 @@ __global__ void k_pack_particles_helmholtz(int nall, const double *__restrict__ 
   r3[j] = make_int2(type[j], colmap[j]);
 }
 
-// DIMT / FAM as in k_asm_poisson
-template <int DIMT, int FAM>
+__global__ void k_pack_particles_scalar(int nall, const double *__restrict__ x, const double *__restrict__ vfrac,
+                                        const double *__restrict__ material, const double *__restrict__ field,
+                                        const int *__restrict__ type, const int *__restrict__ colmap,
+                                        double4 *__restrict__ r1, double4 *__restrict__ r2, int2 *__restrict__ r3) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nall) return;
+  r1[j] = make_double4(x[3 * (size_t)j], x[3 * (size_t)j + 1], x[3 * (size_t)j + 2], vfrac[j]);
+  r2[j] = make_double4(material ? material[j] : 1.0, field[j], 0.0, 0.0);
+  r3[j] = make_int2(type[j], colmap[j]);
+}
+
+// DIMT / FAM as in k_asm_poisson; MODE: 0 velocity Helmholtz, 1 solute transport, 2 applied electric potential
+template <int DIMT, int FAM, int MODE = 0>
 __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, HelmholtzArgs a,
                                                           const long long *__restrict__ slice_off,
                                                           int *__restrict__ scol, double *__restrict__ sval,
@@ -807,17 +826,20 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
   const int it = a.type[i], ikind = T.kind[it];
   const long long off = sval ? slice_off[i >> 6] : 0;
   const int w = sval ? (int)((slice_off[(i >> 6) + 1] - off) >> 6) : 0;
-  const int filt_i = KIND_FLUID, filt_j = KIND_ALL;
+  const int filt_i = MODE ? a.filt_i : KIND_FLUID, filt_j = MODE ? a.filt_j : KIND_ALL;
+  const bool row_ok = MODE ? (ikind == filt_i) : ((ikind & filt_i) != 0);   // FilterMatchBinary | FilterBinary
+  const int nf = MODE ? 1 : dim;                                            // right-hand-side columns
   const double alpha = a.dt;
-  const double invrho = 1.0 / a.rho[i];
-  const double mi = a.nu[i] * a.rho[i];
+  const double invrho = MODE ? 1.0 : 1.0 / a.rho[i];
+  const double mi = MODE ? a.r2[i].x : a.nu[i] * a.rho[i];
+  const double vscale = MODE == 2 ? 1.0 : -a.theta;                         // what multiplies the Laplacian in A
   const int jb = 0, je = T.nlen[i];
   int cnt = 0, pdiag = -1;
   const int ci_own = a.colmap[i];
   double diag_final;
   double wv[3] = {0, 0, 0}, gp[3] = {0, 0, 0};
 
-  if (!(ikind & filt_i)) {
+  if (!row_ok) {
     for (int jj = jb; jj < je; ++jj) {
       const int j = neigh_at(T, i, jj - jb);
       double rij[3];
@@ -851,9 +873,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       const double rsq = rsq_nofma(dim, xi3, xj3, rij);  // the same arithmetic as pair_rsq / k_asm_count
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       const double mj = a.r2[j].x;
-      double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
+      double coeff = (row_ok && (ikind & filt_j)) ? 1.0 : 0.0;
       if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) {
-        coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
+        coeff = (row_ok && (jkind & filt_j)) ? 1.0 : 0.0;
         if (a.morris && coeff != 0.0)  // FunctorOuterLaplacianMatrix_MorrisHolmes (functor_boundary_morris_holmes.h:49-64)
           coeff = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
       }
@@ -883,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       aij *= mi * coeff * rinv;
       diag1 += aij;
       // gradient of p, filter (Fluid, Fluid) (functor_gradient.h:120-150)
-      if (a.incremental && (ikind & KIND_FLUID) && (jkind & KIND_FLUID)) {
+      if (MODE == 0 && a.incremental && (ikind & KIND_FLUID) && (jkind & KIND_FLUID)) {
         const double vd = dwdr * rinv * vfrac;
         for (int k2 = 0; k2 < dim; ++k2) {
           double gitmp = 0.0;
@@ -905,8 +927,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       if (!(rsq < T.cutsq[it * nt1 + jt])) continue;
       // the correction term uses the plain filter coefficient (:225-227); a_ij keeps the
       // mirror-weighted coefficient of the first sweep (:144-146)
-      double coeff = ((ikind & filt_i) && (ikind & filt_j)) ? 1.0 : 0.0;
-      if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = ((ikind & filt_i) && (jkind & filt_j)) ? 1.0 : 0.0;
+      double coeff = (row_ok && (ikind & filt_j)) ? 1.0 : 0.0;
+      if (!(ikind & KIND_SOLID) && (jkind & KIND_SOLID)) coeff = (row_ok && (jkind & filt_j)) ? 1.0 : 0.0;
       double coeff_a = coeff;
       if (a.morris && coeff != 0.0 && !(ikind & KIND_SOLID) && (jkind & KIND_SOLID))
         coeff_a = mirror_coeff(a.pnd, a.vfrac, a.safe, T.h[it * nt1 + jt], i, j, sqrt(T.cutsq[it * nt1 + jt]));
@@ -942,16 +964,17 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
       {
         const double4 q2 = a.r2[j];
         const double vj3[3] = {q2.y, q2.z, q2.w};
-        for (int k = 0; k < dim; ++k) wv[k] += aval * vj3[k];
+        for (int k = 0; k < nf; ++k) wv[k] += aval * vj3[k];
       }
       const int cj = q3.y;
       if (T.sorted && pdiag < 0 && cj > ci_own) pdiag = cnt++;
       const long long p = sell_pos(off, lane, cnt++);
-      if (sval) { scol[p] = cj; sval[p] = aval * (-a.theta); }
+      if (sval) { scol[p] = cj; sval[p] = aval * vscale; }
     }
     const double dval = ((diag1 + diag2) * alpha) * invrho;
-    for (int k = 0; k < dim; ++k) wv[k] += dval * a.v[3 * (size_t)i + k];
-    diag_final = 1.0 + dval * (-a.theta);
+    if (MODE) wv[0] += dval * a.r2[i].y;
+    else for (int k = 0; k < dim; ++k) wv[k] += dval * a.v[3 * (size_t)i + k];
+    diag_final = MODE == 2 ? dval : 1.0 + dval * (-a.theta);
   }
   {
     if (pdiag < 0) pdiag = cnt++;
@@ -962,14 +985,22 @@ __global__ __launch_bounds__(kBlock) void k_asm_helmholtz(AsmTables T, Helmholtz
     const long long p = sell_pos(off, lane, k);
     if (sval) { scol[p] = a.colmap[i]; sval[p] = 0.0; }
   }
-  for (int k = 0; k < dim; ++k) {
-    double bk = a.v[3 * (size_t)i + k];
-    if (ikind & filt_i) {
-      bk += wv[k] * (1.0 - a.theta);
-      bk += a.dt * (a.f[3 * (size_t)i + k] / a.rho[i] + a.g[k]);
-      if (a.incremental) bk += a.dt * (-1.0 / a.rho[i] * gp[k]);
+  if (MODE == 1) {         // b = c (+ w on Fluid rows), functor_solute_transport.h:111-121
+    double bk = a.r2[i].y;
+    if (row_ok) bk += wv[0] * (1.0 - a.theta);
+    b[i] = bk;
+  } else if (MODE == 2) {  // b = phi on the buffers, 0 elsewhere, functor_applied_electric_potential.h:76-90
+    b[i] = (ikind == KIND_BUFFER_DIRICHLET || ikind == KIND_BUFFER_NEUMANN) ? a.r2[i].y : 0.0;
+  } else {
+    for (int k = 0; k < dim; ++k) {
+      double bk = a.v[3 * (size_t)i + k];
+      if (ikind & filt_i) {
+        bk += wv[k] * (1.0 - a.theta);
+        bk += a.dt * (a.f[3 * (size_t)i + k] / a.rho[i] + a.g[k]);
+        if (a.incremental) bk += a.dt * (-1.0 / a.rho[i] * gp[k]);
+      }
+      b[(size_t)k * a.lda + i] = bk;
     }
-    b[(size_t)k * a.lda + i] = bk;
   }
 }
 
@@ -1324,7 +1355,10 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
 inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
                               const double *nu, const double *rho, const double *pres, const double *force,
                               const double *gvec, int incremental, const double *vel, int ncol, isph_mat **A_out,
-                              double *b_out, int lda, int on_device) {
+                              double *b_out, int lda, int on_device, int mode = 0, const double *field = nullptr,
+                              const double *material = nullptr) {
+  // mode 1 / 2: the scalar callers (HelmholtzArgs); dt then carries the Laplacian's alpha, field = c or phi [nall]
+  ISPH_REQUIRE(mode == 0 || (field && A_out), "scalar assembly needs the field and a matrix handle");
   ISPH_REQUIRE(P->dim == 2 || P->dim == 3, "dim must be 2 or 3");
   ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx && P->colmap, "particle arrays missing");
   ISPH_REQUIRE(antisym || (P->Gc && P->Lc), "Symmetric family needs Gc and Lc");
@@ -1348,11 +1382,16 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->vfrac, (size_t)P->nall, on_device, S.vfrac, &a.vfrac);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, S.Gc, &a.Gc);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nall * dL, on_device, S.Lc, &a.Lc);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, rho, (size_t)P->nall, on_device, S.rho, &a.rho);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, nu, (size_t)P->nall, on_device, snu, &a.nu);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, pres, (size_t)P->nall, on_device, sp, &a.p);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, force, (size_t)P->nall * 3, on_device, sf, &a.f);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, vel, (size_t)P->nall * 3, on_device, sv, &a.v);
+  if (mode == 0) {
+    if (rc == ISPH_SUCCESS) rc = stage(ctx, rho, (size_t)P->nall, on_device, S.rho, &a.rho);
+    if (rc == ISPH_SUCCESS) rc = stage(ctx, nu, (size_t)P->nall, on_device, snu, &a.nu);
+    if (rc == ISPH_SUCCESS) rc = stage(ctx, pres, (size_t)P->nall, on_device, sp, &a.p);
+    if (rc == ISPH_SUCCESS) rc = stage(ctx, force, (size_t)P->nall * 3, on_device, sf, &a.f);
+    if (rc == ISPH_SUCCESS) rc = stage(ctx, vel, (size_t)P->nall * 3, on_device, sv, &a.v);
+  } else {
+    if (rc == ISPH_SUCCESS) rc = stage(ctx, material, (size_t)P->nall, on_device, snu, &a.nu);   // NULL stays NULL
+    if (rc == ISPH_SUCCESS) rc = stage(ctx, field, (size_t)P->nall, on_device, sv, &a.v);
+  }
   if (rc == ISPH_SUCCESS && P->morris_holmes) {
     if (!P->pnd) rc = fail("MorrisHolmes needs pnd", __FILE__, __LINE__);
     else rc = stage(ctx, P->pnd, (size_t)P->nall, on_device, S.pnd, &a.pnd);
@@ -1373,13 +1412,16 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, np, a.nidx, E, T, A_out ? a.colmap : nullptr);
   if (rc == ISPH_SUCCESS)
     for (int t = 1; t <= P->ntypes; ++t)
-      if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID) rc = fail("only fluid/solid particle kinds are supported", __FILE__, __LINE__);
+      if (P->kind[t] != KIND_FLUID && P->kind[t] != KIND_SOLID &&
+          !(mode != 0 && (P->kind[t] == KIND_BUFFER_DIRICHLET || P->kind[t] == KIND_BUFFER_NEUMANN)))
+        rc = fail(mode ? "only fluid/solid/buffer particle kinds are supported" : "only fluid/solid particle kinds are supported", __FILE__, __LINE__);
   Sell &M = A->S;
   M.nrow = n; M.ncol = ncol; M.nslices = (n + kSlice - 1) / kSlice;
   if (rc == ISPH_SUCCESS) rc = M.rowlen.reserve((size_t)(n > 0 ? n : 1));
   if (rc == ISPH_SUCCESS) rc = M.slice_off.reserve((size_t)M.nslices + 1);
   double *db = b_out;
-  if (rc == ISPH_SUCCESS && !on_device) { rc = bdev.reserve((size_t)lda * dim); db = bdev.p; }
+  const int nrhs = mode ? 1 : dim;
+  if (rc == ISPH_SUCCESS && !on_device) { rc = bdev.reserve((size_t)lda * nrhs); db = bdev.p; }
   if (rc == ISPH_SUCCESS && n > 0) {
     const int grid = (n + kBlock - 1) / kBlock;
     if (!rhs_only) {
@@ -1398,7 +1440,17 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
       rc = pk1.reserve((size_t)P->nall);
       if (rc == ISPH_SUCCESS) rc = pk2.reserve((size_t)P->nall);
       if (rc == ISPH_SUCCESS) rc = pk3.reserve((size_t)P->nall);
-      if (rc == ISPH_SUCCESS) {
+      if (rc == ISPH_SUCCESS && mode != 0) {
+        hipLaunchKernelGGL(k_pack_particles_scalar, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                           P->nall, a.x, a.vfrac, a.nu, a.v, a.type, a.colmap, pk1.p, pk2.p, pk3.p);
+        a.r1 = pk1.p; a.r2 = pk2.p; a.r3 = pk3.p;
+        a.filt_i = KIND_FLUID;
+        a.filt_j = mode == 1 ? KIND_FLUID - KIND_BUFFER_NEUMANN : KIND_FLUID;
+        if (mode == 1)
+          hipLaunchKernelGGL((k_asm_helmholtz<0, -1, 1>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+        else
+          hipLaunchKernelGGL((k_asm_helmholtz<0, -1, 2>), dim3(xcd_grid(gridp)), dim3(kBlock), 0, ctx->stream, T, a, M.slice_off.p, M.col.p, M.val.p, db);
+      } else if (rc == ISPH_SUCCESS) {
         hipLaunchKernelGGL(k_pack_particles_helmholtz, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
                            P->nall, a.x, a.vfrac, a.nu, a.rho, a.v, a.type, a.colmap, pk1.p, pk2.p, pk3.p);
         a.r1 = pk1.p; a.r2 = pk2.p; a.r3 = pk3.p;
@@ -1423,7 +1475,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
       // rows come out column-sorted when the neighbour lists were ordered; merged duplicates break that order
       if (rc == ISPH_SUCCESS && !rhs_only) rc = (T.sorted && n > 32768) ? sell_set_wmax(ctx, M) : sell_sort_rows(ctx, M);
       if (rc == ISPH_SUCCESS && !on_device &&
-          hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)lda * dim, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+          hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)lda * nrhs, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         rc = fail("copy failed", __FILE__, __LINE__);
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         rc = fail("assembly kernel failed", __FILE__, __LINE__);

@@ -1075,6 +1075,21 @@ int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym,
                             b_out, lda, on_device);
 }
 
+int isph_assemble_solute_transport(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                                   double dcoeff, const double *conc, int ncol, isph_mat **A_out, double *b_out,
+                                   int on_device) {
+  ISPH_REQUIRE(ctx && P && conc && A_out && b_out, "NULL argument");
+  return assemble_helmholtz(ctx, P, antisym, dt * dcoeff, theta, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, ncol,
+                            A_out, b_out, P->nlocal, on_device, 1, conc, nullptr);
+}
+
+int isph_assemble_applied_potential(isph_ctx *ctx, const isph_particles *P, int antisym, const double *sigma,
+                                    const double *phi, int ncol, isph_mat **A_out, double *b_out, int on_device) {
+  ISPH_REQUIRE(ctx && P && phi && A_out && b_out, "NULL argument");
+  return assemble_helmholtz(ctx, P, antisym, -1.0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, ncol, A_out,
+                            b_out, P->nlocal, on_device, 2, phi, sigma);
+}
+
 int isph_assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
                                   double beta, const double *nu, const double *rho, const double *pres,
                                   const double *force, const double *g, int incremental_pressure, const double *v,

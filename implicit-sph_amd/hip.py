@@ -21,7 +21,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
@@ -163,6 +163,10 @@ def lib():
         L.isph_assemble_helmholtz.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.isph_assemble_solute_transport.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.isph_assemble_applied_potential.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                      C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -586,6 +590,43 @@ def assemble_helmholtz(ctx, parts, colmap, dt, theta, nu, rho, pres, force, g, v
                                          _ptr(pres), _ptr(force), _ptr(gv), int(incremental), _ptr(vel),
                                          nlocal if ncol is None else ncol, None if rhs_only else C.byref(A.h),
                                          _ptr(b_out), nlocal, dev))
+    return A, b_out
+
+
+def assemble_solute_transport(ctx, parts, colmap, dt, theta, dcoeff, conc, antisym=True, ncol=None, vfrac=None, Gc=None,
+                              Lc=None, kernel="wendland", kinds=None):
+    """isph_assemble_solute_transport == PairISPH_Corrected::computeSoluteTransportSpecies.  Returns (Matrix, b[nlocal])."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, Lc=Lc, keep=keep, kinds=kinds)
+    conc = _f64(conc)
+    nlocal = int(parts["nlocal"])
+    if dev:
+        import torch
+        b_out = torch.zeros(nlocal, dtype=torch.float64, device=conc.device)
+    else:
+        b_out = np.zeros(nlocal)
+    A = Matrix(ctx)
+    _check(lib().isph_assemble_solute_transport(ctx.h, C.byref(pv), int(antisym), float(dt), float(theta), float(dcoeff),
+                                                _ptr(conc), nlocal if ncol is None else ncol, C.byref(A.h), _ptr(b_out), dev))
+    return A, b_out
+
+
+def assemble_applied_potential(ctx, parts, colmap, sigma, phi, antisym=True, ncol=None, vfrac=None, Gc=None, Lc=None,
+                               kernel="wendland", kinds=None):
+    """isph_assemble_applied_potential == PairISPH_Corrected::computeAppliedElectricPotential.  Returns (Matrix, b[nlocal])."""
+    keep = []
+    pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, Lc=Lc, keep=keep, kinds=kinds)
+    phi = _f64(phi)
+    sg = None if sigma is None else _f64(sigma)
+    nlocal = int(parts["nlocal"])
+    if dev:
+        import torch
+        b_out = torch.zeros(nlocal, dtype=torch.float64, device=phi.device)
+    else:
+        b_out = np.zeros(nlocal)
+    A = Matrix(ctx)
+    _check(lib().isph_assemble_applied_potential(ctx.h, C.byref(pv), int(antisym), _ptr(sg), _ptr(phi),
+                                                 nlocal if ncol is None else ncol, C.byref(A.h), _ptr(b_out), dev))
     return A, b_out
 
 

@@ -265,6 +265,24 @@ int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym,
                             const double *nu, const double *rho, const double *pres, const double *force,
                             const double *g, int incremental_pressure, const double *v, int ncol,
                             isph_mat **A_out, double *b_out /*[h|d]*/, int lda, int on_device);
+/* The two scalar callers of the same solver objects, built on the same Laplacian rows:
+ * PairISPH_Corrected::computeSoluteTransportSpecies -> FunctorOuterSoluteTransport (ref: pair_isph_corrected.cpp:844-861,
+ * functor_solute_transport.h:47-138; solved at pair_isph.cpp:811-835):  (I - theta dt D lap) c_new = c + (1-theta) dt D lap c
+ * on the rows of kind Fluid, unit rows for Solid / BufferDirichlet / BufferNeumann particles (b = c there); the Laplacian
+ * couples a Fluid row to Fluid and buffer neighbours, not to Solid ones (FilterMatchBinary(Fluid, Fluid - BufferNeumann):
+ * the neighbour mask is only consulted for Solid neighbours, functor_laplacian_matrix.h:143-146).  conc: [nall];
+ * b_out: [nlocal].  Kinds in P->kind may be 99 Fluid, 12 Solid, 32 BufferDirichlet, 64 BufferNeumann (pair_isph.h:113-124). */
+int isph_assemble_solute_transport(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                                   double dcoeff, const double *conc /*[h|d]*/, int ncol, isph_mat **A_out,
+                                   double *b_out /*[h|d]*/, int on_device);
+/* PairISPH_Corrected::computeAppliedElectricPotential -> FunctorOuterAppliedElectricPotential (ref:
+ * pair_isph_corrected.cpp:569-620, functor_applied_electric_potential.h:36-98; solved at pair_isph.cpp:635-657):
+ * -div(sigma grad phi) = 0 on the Fluid rows (FilterMatchBinary(Fluid, Fluid)), unit rows with b = phi on the buffer
+ * particles (the Dirichlet data), unit rows with b = 0 on Solid ones.  sigma: [nall] conductivity or NULL (= 1);
+ * phi: [nall]; b_out: [nlocal]. */
+int isph_assemble_applied_potential(isph_ctx *ctx, const isph_particles *P, int antisym, const double *sigma /*[h|d]*/,
+                                    const double *phi /*[h|d]*/, int ncol, isph_mat **A_out, double *b_out /*[h|d]*/,
+                                    int on_device);
 /* Replaces PairISPH_Corrected::computeBlockHelmholtz -> FunctorOuterIncompNavierStokesBlockHelmholtz
  * (ref: pair_isph_corrected.cpp:941-964, functor_incomp_navier_stokes_block_helmholtz.h:57-187) with the block branch
  * of the Laplacian functor (functor_laplacian_matrix.h:269-314) and FunctorOuterBoundaryNavierSlip

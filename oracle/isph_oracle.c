@@ -116,9 +116,14 @@ static inline int kind_of(const orc_particles *P, int i) { return P->kind[P->typ
 static inline double tab(const orc_particles *P, const double *T, int it, int jt) {
   return T[it * (P->ntypes + 1) + jt];
 }
-/* FilterBinary::yes, ref: filter.h:47-53 */
-static inline int fyes1(int fi, int ikind) { return (ikind & fi) != 0; }
+/* FilterBinary::yes, ref: filter.h:47-53; with ORC_FILTER_MATCH set in fi: FilterMatchBinary::yes, ref: filter.h:97-103
+ * (the row kind must EQUAL the first kind, the neighbour kind is still a mask) */
+static inline int fyes1(int fi, int ikind) {
+  if (fi & ORC_FILTER_MATCH) return ikind == (fi & ~ORC_FILTER_MATCH);
+  return (ikind & fi) != 0;
+}
 static inline int fyes2(int fi, int fj, int ikind, int jkind) {
+  if (fi & ORC_FILTER_MATCH) return ikind == (fi & ~ORC_FILTER_MATCH) && (jkind & fj);
   return (ikind & fi) && (jkind & fj);
 }
 /* the two tests as the functors see them, for the check against the reference's FilterBinary (oracle/_ref) */
@@ -936,6 +941,69 @@ int orc_helmholtz(const orc_particles *P, int antisym, int morris_holmes, double
     }
   }
   free(vext); free(grad);
+  return 0;
+}
+
+/* FunctorOuterSoluteTransport, ref: functor_solute_transport.h:47-138 (called by
+ * PairISPH_Corrected::computeSoluteTransportSpecies, pair_isph_corrected.cpp:844-861):
+ *   A = Laplacian(dt*dcoeff), FilterMatchBinary(Fluid, Fluid - BufferNeumann)           (:60-67)
+ *   w = (1-theta) A b  with b = the concentration (Epetra Multiply: ghost columns carry the owners' values)  (:85-87)
+ *   A *= -theta                                                                        (:90)
+ *   Fluid rows: diag = 1 + A_ii, b += w;  Solid / BufferDirichlet / BufferNeumann rows: diag = 1        (:106-124)
+ * conc: [nall]; b: [nlocal], returned. */
+int orc_solute_transport(const orc_particles *P, int antisym, double dt, double theta, double dcoeff, const double *conc,
+                         const int *rowptr, const int *colidx, double *val, double *b) {
+  const int n = P->nlocal;
+  memset(val, 0, sizeof(double) * (size_t)rowptr[n]);
+  if (orc_laplacian_matrix(P, antisym, dt * dcoeff, NULL, ORC_KIND_FLUID | ORC_FILTER_MATCH,
+                           ORC_KIND_FLUID - ORC_KIND_BUFFER_NEUMANN, 0, rowptr, colidx, val)) return -1;
+  int ncol = 0;
+  for (int j = 0; j < P->nall; ++j) if (P->colmap[j] + 1 > ncol) ncol = P->colmap[j] + 1;
+  double *cext = (double *)calloc((size_t)ncol, sizeof(double));
+  for (int j = 0; j < P->nall; ++j) cext[P->colmap[j]] = conc[j];
+  for (int i = 0; i < n; ++i) {
+    const int ikind = kind_of(P, i);
+    double w = 0.0;
+    int pd = -1;
+    for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+      w += val[q] * cext[colidx[q]];
+      val[q] *= -theta;
+      if (colidx[q] == P->colmap[i]) pd = q;
+    }
+    if (pd < 0) { free(cext); return -1; }
+    b[i] = conc[i];
+    if (ikind == ORC_KIND_FLUID) {
+      val[pd] = 1.0 + val[pd];
+      b[i] += w * (1.0 - theta);
+    } else if (ikind == ORC_KIND_SOLID || ikind == ORC_KIND_BUFFER_DIRICHLET || ikind == ORC_KIND_BUFFER_NEUMANN) {
+      val[pd] = 1.0;
+    } else { free(cext); return -2; }   /* "Particle types are not supported" */
+  }
+  free(cext);
+  return 0;
+}
+
+/* FunctorOuterAppliedElectricPotential, ref: functor_applied_electric_potential.h:36-98 (called by
+ * PairISPH_Corrected::computeAppliedElectricPotential, pair_isph_corrected.cpp:569-620):
+ *   A = Laplacian(-1, sigma), FilterMatchBinary(Fluid, Fluid)                                          (:49-58)
+ *   b = 0; Solid rows: diag = 1; BufferNeumann / BufferDirichlet rows: diag = 1, b = phi; Fluid rows as assembled (:72-90)
+ * sigma: [nall] or NULL; phi: [nall]. */
+int orc_applied_potential(const orc_particles *P, int antisym, const double *sigma, const double *phi,
+                          const int *rowptr, const int *colidx, double *val, double *b) {
+  const int n = P->nlocal;
+  memset(val, 0, sizeof(double) * (size_t)rowptr[n]);
+  if (orc_laplacian_matrix(P, antisym, -1.0, sigma, ORC_KIND_FLUID | ORC_FILTER_MATCH, ORC_KIND_FLUID, 0, rowptr, colidx, val))
+    return -1;
+  for (int i = 0; i < n; ++i) {
+    const int ikind = kind_of(P, i);
+    int pd = -1;
+    for (int q = rowptr[i]; q < rowptr[i + 1]; ++q)
+      if (colidx[q] == P->colmap[i]) pd = q;
+    if (pd < 0) return -1;
+    b[i] = 0.0;
+    if (ikind == ORC_KIND_SOLID) val[pd] = 1.0;
+    else if (ikind == ORC_KIND_BUFFER_DIRICHLET || ikind == ORC_KIND_BUFFER_NEUMANN) { val[pd] = 1.0; b[i] = phi[i]; }
+  }
   return 0;
 }
 

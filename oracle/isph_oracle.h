@@ -45,7 +45,8 @@ extern "C" {
 
 /* particle kinds, pair_isph.h:113-123 */
 enum { ORC_KIND_FLUID = 99, ORC_KIND_SOLID = 12, ORC_KIND_ALL = 127,
-       ORC_KIND_BUFFER_DIRICHLET = 32, ORC_KIND_BUFFER_NEUMANN = 64 };
+       ORC_KIND_BUFFER_DIRICHLET = 32, ORC_KIND_BUFFER_NEUMANN = 64,
+       ORC_FILTER_MATCH = 0x1000 /* or-ed into filt_i: FilterMatchBinary (filter.h:83-104) instead of FilterBinary */ };
 /* SingularPoisson, pair_isph.h:134-138 */
 enum { ORC_NOT_SINGULAR = 0, ORC_NULLSPACE = 1, ORC_PINZERO = 2, ORC_DOUBLEDIAG = 3 };
 /* kernels */
@@ -137,6 +138,13 @@ int  orc_helmholtz(const orc_particles *P, int antisym, int morris_holmes, doubl
                    const double *f, const double *g, int incremental_pressure,
                    const double *vall, const int *rowptr, const int *colidx,
                    double *val, double *b, int lda, double *work);
+
+/* the scalar callers of the solver: solute transport (functor_solute_transport.h:47-138) and the applied electric
+ * potential (functor_applied_electric_potential.h:36-98); conc / sigma / phi [nall], b [nlocal] */
+int  orc_solute_transport(const orc_particles *P, int antisym, double dt, double theta, double dcoeff, const double *conc,
+                          const int *rowptr, const int *colidx, double *val, double *b);
+int  orc_applied_potential(const orc_particles *P, int antisym, const double *sigma, const double *phi,
+                           const int *rowptr, const int *colidx, double *val, double *b);
 
 /* block Helmholtz (functor_incomp_navier_stokes_block_helmholtz.h:57-187): dim x dim blocks on the scalar pattern,
  * vals[(ib*dim+jb)*nnz + q]; normal [nall][3] or NULL; b column-major [lda x dim] holding v^n on entry */

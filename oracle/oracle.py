@@ -97,6 +97,10 @@ def lib():
                                   C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
         L.orc_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_solute_transport.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_applied_potential.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
         L.orc_helmholtz.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
@@ -266,6 +270,36 @@ def _helmholtz(self, dt, theta, nu, rho, p, f, g, vall, antisym=True, incrementa
 
 
 Particles.helmholtz = _helmholtz
+
+
+FILTER_MATCH = 0x1000   # or-ed into filt[0]: FilterMatchBinary instead of FilterBinary (isph_oracle.h)
+BUFFER_DIRICHLET, BUFFER_NEUMANN = 32, 64
+
+
+def _solute_transport(self, dt, theta, dcoeff, conc, antisym=True, graph=None):
+    """computeSoluteTransportSpecies: returns (rowptr, colidx, val, b[nlocal])."""
+    rowptr, colidx = graph if graph is not None else self.graph()
+    val = np.zeros(len(colidx))
+    b = np.zeros(self.nlocal)
+    rc = lib().orc_solute_transport(self.ref(), int(antisym), float(dt), float(theta), float(dcoeff), _p(_f64(conc)),
+                                    _p(rowptr), _p(colidx), _p(val), _p(b))
+    assert rc == 0, "orc_solute_transport rc=%d" % rc
+    return rowptr, colidx, val, b
+
+
+def _applied_potential(self, sigma, phi, antisym=True, graph=None):
+    """computeAppliedElectricPotential: returns (rowptr, colidx, val, b[nlocal])."""
+    rowptr, colidx = graph if graph is not None else self.graph()
+    val = np.zeros(len(colidx))
+    b = np.zeros(self.nlocal)
+    sg = None if sigma is None else _f64(sigma)
+    rc = lib().orc_applied_potential(self.ref(), int(antisym), _p(sg), _p(_f64(phi)), _p(rowptr), _p(colidx), _p(val), _p(b))
+    assert rc == 0, "orc_applied_potential rc=%d" % rc
+    return rowptr, colidx, val, b
+
+
+Particles.solute_transport = _solute_transport
+Particles.applied_potential = _applied_potential
 
 
 def _block_helmholtz(self, dt, theta, beta, nu, rho, p, f, g, vall, normal=None, antisym=True, incremental=True,

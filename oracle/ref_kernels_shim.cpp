@@ -31,6 +31,17 @@ int ref_filter_yes2(int filt_i, int filt_j, int ikind, int jkind) {
   f.setPairYes(filt_i, filt_j);
   return f.yes(ikind, jkind) ? 1 : 0;
 }
+// FilterMatchBinary (filter.h:83-104): what the solute-transport and applied-potential functors use
+int ref_filter_match_yes1(int filt_i, int ikind) {
+  LAMMPS_NS::FilterMatchBinary f;
+  f.setPairYes(filt_i);
+  return f.yes(ikind) ? 1 : 0;
+}
+int ref_filter_match_yes2(int filt_i, int filt_j, int ikind, int jkind) {
+  LAMMPS_NS::FilterMatchBinary f;
+  f.setPairYes(filt_i, filt_j);
+  return f.yes(ikind, jkind) ? 1 : 0;
+}
 // kernel: 0 Wendland, 1 Quintic, 2 Cubic (the oracle's numbering); the calls the functors make: kernel->val(r, h)
 double ref_kernel_val(int kernel, int dim, double r, double h) {
   LAMMPS_NS::KernelFunction *k = make(kernel, dim);

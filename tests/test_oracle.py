@@ -527,6 +527,13 @@ def test_oracle_kernels_equal_the_reference_kernel_classes():
             for fj in (99, 12, 127):
                 for jk in kinds:
                     assert ref.ref_filter_yes2(fi, fj, ik, jk) == orc.lib().orc_filter_yes2(fi, fj, ik, jk)
+    # FilterMatchBinary (filter.h:83-104) of the solute-transport / applied-potential functors: (Fluid, Fluid - BufferNeumann), (Fluid, Fluid)
+    for fi in (99, 12):
+        for ik in kinds:
+            assert ref.ref_filter_match_yes1(fi, ik) == orc.lib().orc_filter_yes1(fi | orc.FILTER_MATCH, ik)
+            for fj in (99, 99 - 64, 127):
+                for jk in kinds:
+                    assert ref.ref_filter_match_yes2(fi, fj, ik, jk) == orc.lib().orc_filter_yes2(fi | orc.FILTER_MATCH, fj, ik, jk)
     rng = np.random.default_rng(1)
     for kernel, name, support in ((0, "wendland", 2.0), (1, "quintic", 3.0), (2, "cubic", 2.0)):
         for dim in (2, 3):
