@@ -183,8 +183,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("ISPH_BENCH_SINGLE_DEVICE"):      # rehearsal only: all ranks share GPU 0
-        local_rank = 0
     ngpu = args.gpus
     assert world == ngpu, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (ngpu, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
