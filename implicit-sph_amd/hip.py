@@ -527,7 +527,12 @@ def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=
     """Builds the isph_particles struct over host (numpy) or device (torch)
     arrays.  `keep` collects references so the buffers outlive the call."""
     keep = keep if keep is not None else []
-    ntypes = int(np.max(parts["type"])) if not _is_torch(parts["type"]) else int(parts["type"].max().item())
+    if kinds is not None:
+        ntypes = len(kinds)
+    elif int(parts["nall"]) == 0:                                  # a rank without particles (LAMMPS allows empty subdomains)
+        ntypes = 1
+    else:
+        ntypes = int(np.max(parts["type"])) if not _is_torch(parts["type"]) else int(parts["type"].max().item())
     kind = np.ascontiguousarray([0] + list(kinds if kinds is not None else [99] * ntypes), dtype=np.int32)
     h = np.full((ntypes + 1, ntypes + 1), float(parts["h"]))
     cutsq = np.full((ntypes + 1, ntypes + 1), float(parts["cut"]) ** 2)

@@ -56,6 +56,28 @@ def test_empty_and_tiny_matrices(gpu_ctx):
         hip.Matrix.from_csr(gpu_ctx, rp, np.array([0, 0, 7], np.int32), v)     # column out of range
 
 
+def test_rank_without_particles(gpu_ctx):
+    """LAMMPS subdomains may be empty: nlocal = nall = 0 goes through computePre, the assembly, every preconditioner
+    set-up and the solve (which still takes part in the collectives) and comes back converged after 0 iterations."""
+    spec = tgv_spec(dim=3, n=8, mode=workload.JITTER)
+    e = dict(workload.make_tgv(spec))
+    e.update(nlocal=0, nall=0, x=np.zeros((0, 3)), type=np.zeros(0, np.int32), neigh_ptr=np.zeros(1, np.int32),
+             neigh_idx=np.zeros(0, np.int32))
+    colmap = np.zeros(0, np.int32)
+    assert hip.compute_volumes(gpu_ctx, e, colmap).shape == (0,)
+    A, b = hip.assemble_poisson(gpu_ctx, e, colmap, spec.dt, np.zeros(0), np.zeros((0, 3)), vfrac=np.zeros(0))
+    assert A.info()["nrow"] == 0 and A.info()["nnz"] == 0 and b.shape == (0,)
+    for make in (lambda: hip.Precond(gpu_ctx, A, "jacobi", 512), lambda: hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 512),
+                 lambda: hip.Precond(gpu_ctx, A, "bjacobi-ilu1", 512), lambda: hip.PrecondAMG(gpu_ctx, A, nullvec=np.zeros(0))):
+        M = make()
+        info = hip.solve(gpu_ctx, A, b, np.zeros(0), prec=M, singular=True)
+        assert info.converged == 1 and info.iters == 0
+        M.close()
+    Ah, bh = hip.assemble_helmholtz(gpu_ctx, e, colmap, spec.dt, 0.5, np.zeros(0), np.zeros(0), np.zeros(0), np.zeros((0, 3)),
+                                    np.zeros(3), np.zeros((0, 3)), vfrac=np.zeros(0))
+    assert Ah.info()["nrow"] == 0 and bh.shape == (0,)
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("antisym", [True, False])
 def test_gpu_assembly_matches_oracle(gpu_ctx, case, antisym):
