@@ -107,19 +107,42 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(int nk, int nblk, co
 }
 
 // w -= sum_k c[k] V_k ; partial[blockIdx] = sum of the new w.w  (c on device)
-// flag != NULL: flag[0] == 0 means the DGKS test on the device found no second pass due (w stays).
-// vnext != NULL: the normalised vector vnext = w_final / sqrt(flag[1]) is written in the same sweep (flag[1] is
-// |w_final|^2 from k_dgks_decide; the arithmetic of k_scale_copy), second pass or not.
+// dec_old != NULL: the DGKS test is taken here, by every workgroup for itself, from the reduced scalars of the two
+// passes -- dec_old = |w_old|^2 (minus dec_dn[0]^2, the null-vector component, with deflation), c[0..nk) = c2,
+// c[nk] = |w_new|^2: second pass when force (ICGS) or |w_new| < |w_old| / sqrt(2); |w_final|^2 = |w_new|^2 - |c2|^2
+// then, |w_new|^2 otherwise (Pythagoras: c2 is the projection of w_new on span V).  Workgroup 0 leaves the flag and
+// |w_final|^2 in dec_out[0..1] for the host.  Without a second pass w stays.
+// vnext != NULL: the normalised vector vnext = w_final / |w_final| is written in the same sweep, second pass or not.
 __global__ __launch_bounds__(kBlock) void k_multi_axpy_norm(int n, int nk, const double *__restrict__ V, long long ld,
                                                             const double *__restrict__ c, double *__restrict__ w,
                                                             double *__restrict__ partial,
-                                                            const double *__restrict__ flag = nullptr,
+                                                            const double *__restrict__ dec_old = nullptr,
+                                                            const double *__restrict__ dec_dn = nullptr, int dec_force = 0,
+                                                            double *__restrict__ dec_out = nullptr,
                                                             double *__restrict__ vnext = nullptr) {
   __shared__ double sw[4];
-  const bool second = !(flag && *flag == 0.0);
+  __shared__ double sdec[2];
+  bool second = true;
+  double wfinal2 = 1.0;
+  if (dec_old) {
+    if (threadIdx.x == 0) {
+      double old2 = *dec_old;
+      if (dec_dn) old2 = fmax(old2 - dec_dn[0] * dec_dn[0], 0.0);
+      const double ww_new = c[nk];
+      const bool sec = dec_force || sqrt(ww_new) < M_SQRT1_2 * sqrt(old2);
+      double s2 = 0.0;
+      for (int k = 0; k < nk; ++k) s2 += c[k] * c[k];
+      sdec[0] = sec ? 1.0 : 0.0;
+      sdec[1] = sec ? fmax(ww_new - s2, 0.0) : ww_new;
+      if (blockIdx.x == 0) { dec_out[0] = sdec[0]; dec_out[1] = sdec[1]; }
+    }
+    __syncthreads();
+    second = sdec[0] != 0.0;
+    wfinal2 = sdec[1];
+  }
   if (!second && !vnext) return;
   double a = 1.0;
-  if (vnext) a *= 1.0 / sqrt(flag[1]);
+  if (vnext) a *= 1.0 / sqrt(wfinal2);
   double ww = 0.0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     double s = w[i];
@@ -210,30 +233,6 @@ __global__ __launch_bounds__(kBlock) void k_dot2(int n, const double *__restrict
   if (threadIdx.x == 0) {
     partial[blockIdx.x] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
     partial[gridDim.x + blockIdx.x] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-  }
-}
-
-// DGKS decision on the device: d[0] = 1 when a second Gram-Schmidt pass is due (|w_new| < dep_tol |w|,
-// dep_tol = 1/sqrt(2), or always when force != 0), else 0
-// DGKS decision on the device: d[0] = 1 when a second Gram-Schmidt pass is due (|w_new| < dep_tol |w|,
-// dep_tol = 1/sqrt(2), or always when force != 0), else 0; d[1] = |w_final|^2.
-// c2[0..nk) are the second-pass coefficients V^T w_new and c2[nk] = |w_new|^2.  With an orthonormal basis
-// |w_new - V c2|^2 = |w_new|^2 - |c2|^2, and after one classical pass |c2| is at round-off level of |w| (far below
-// |w_new| unless the iteration has broken down, where the clamp to 0 reports the breakdown), so the norm after the
-// second pass needs no further reduction / all-reduce.
-// dn != NULL: the first projected vector is the unit null vector n; the reference measures |w| after its operator
-// removed that component, so the "old" norm is sqrt(|w|^2 - (w.n)^2).
-__global__ void k_dgks_decide(const double *__restrict__ ww_old, const double *__restrict__ c2, int nk, int force,
-                              double *__restrict__ d, const double *__restrict__ dn) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double old2 = *ww_old;
-    if (dn) old2 = fmax(old2 - dn[0] * dn[0], 0.0);
-    const double ww_new = c2[nk];
-    const bool second = force || sqrt(ww_new) < M_SQRT1_2 * sqrt(old2);
-    double s = 0.0;
-    for (int k = 0; k < nk; ++k) s += c2[k] * c2[k];
-    d[0] = second ? 1.0 : 0.0;
-    d[1] = second ? fmax(ww_new - s, 0.0) : ww_new;
   }
 }
 

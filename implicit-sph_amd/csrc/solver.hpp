@@ -290,12 +290,12 @@ inline int cgs_pass(isph_ctx *ctx, int n, int nk, const double *V, long long ld,
 
 // DGKS / ICGS step without any host round trip.  Pass 1: c = V^T w; then ONE kernel applies w -= V c and
 // already accumulates the second pass's projection c2 = V^T w_new and |w_new|^2 while the rows of V are in
-// registers; the DGKS test (dep_tol = 1/sqrt(2); ICGS: always) is taken on the device and the second update
+// registers; the DGKS test (dep_tol = 1/sqrt(2); ICGS: always) is taken on the device, inside the second update's kernel, and that update
 // w -= V c2 (+ its norm) skips itself when it is not due.  Same arithmetic as two separate passes, one read of
 // V less.  When vnext != NULL the next basis vector w/|w| is formed on the device as well, so the caller can
 // queue the next preconditioner/operator application before it looks at the scalars.
 // Mailbox: c at SC_DOT.., |w|^2 at SC_DOT+nk; c2 at SC_Y.., |w_new|^2 at SC_Y+nk; flag, |w_final|^2 at SC_ORTHO..
-// (|w_final|^2 = |w_new|^2 - |c2|^2 when the second pass runs: see k_dgks_decide)
+// (|w_final|^2 = |w_new|^2 - |c2|^2 when the second pass runs: see k_multi_axpy_norm)
 enum { SC_ORTHO = SC_MISC + 20 };
 inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long long ld, double *w, int ortho, double *vnext,
                          bool deflate = false, int mb = 0) {
@@ -321,12 +321,12 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh2,
                      (const double *)nullptr);
   ISPH_CHECK(allreduce_inplace(ctx, dh2, nk + 1));
-  hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(64), 0, st, (const double *)(dh1 + nk), (const double *)dh2, nk,
-                     ortho == 1 ? 1 : 0, dor, deflate ? (const double *)dh1 : (const double *)nullptr);
   const int g2 = stream_grid(n);
-  // the second update and the normalised next basis vector (vnext = w / |w|) leave in one sweep
-  hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, dh2, w, ctx->partial.p,
-                     (const double *)dor, vnext);
+  // the DGKS decision (taken by the kernel itself from the reduced scalars), the second update and the normalised next
+  // basis vector (vnext = w / |w|) leave in one sweep
+  hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, (const double *)dh2, w, ctx->partial.p,
+                     (const double *)(dh1 + nk), deflate ? (const double *)dh1 : (const double *)nullptr, ortho == 1 ? 1 : 0,
+                     dor, vnext);
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
