@@ -16,6 +16,12 @@ section, "ConstExtension", is the same problem without the mirror (the wall valu
     total # of particles = fluid particles,  total volume = sum of V_i over them
     err.psi.norm2 = sqrt( sum_fluid (psi_i - psi_exact)^2 / n_fluid )
 
+A fourth, weaker pin: conv-channel-edl-potential-2d-morrisholmes-rev406.txt, the same channel at an earlier revision with
+"h = 1.02 dx".  With that h the total volume of its rows N = 32 and 64 comes out to 15 digits (kernel + volume functor in
+another h/dx regime) and err.psi.norm2 to 4 (4.2e-5 and 2.6e-4 relative: that revision's solve is not the one rev722
+records to 10 digits); from N = 128 on the table's volumes leave the exact scale invariance of the lattice in the 8th
+digit and earlier, i.e. its h was no longer exactly 1.02 dx, and those rows are not used.
+
 usage: python oracle/pb_channel.py [N ...]"""
 import os
 import sys
@@ -33,9 +39,11 @@ KINDS = [orc.FLUID, orc.SOLID, orc.FLUID]     # type 1 flow, 2 wall ("solid:fixe
 
 
 def known_answers(boundary="MorrisHolmes"):
-    """rows of the table's "MorrisHolmes" or "ConstExtension" section (data)"""
+    """rows of the table's "MorrisHolmes" or "ConstExtension" section (data); "rev406": the earlier table with h = 1.02 dx"""
     import json
     g = json.load(open(os.path.join(_HERE, "..", "tests", "golden", "reference_known_answers.json")))
+    if boundary == "rev406":
+        return {int(k): v for k, v in g["conv_channel_edl_potential_2d_morrisholmes_rev406"]["rows"].items()}
     key = "rows" if boundary == "MorrisHolmes" else "rows_const_extension"
     return {int(k): v for k, v in g["conv_channel_edl_potential_2d_morrisholmes_rev722"][key].items()}
 
@@ -104,10 +112,10 @@ def solve_rows(rp, ci, val, typ_local):
     return psi, fl
 
 
-def run(N, boundary="MorrisHolmes"):
+def run(N, boundary="MorrisHolmes", h_over_dx=1.2):
     """boundary "ConstExtension": the wall particles carry psi0 and enter the rows like any neighbour (no mirror,
-    pair_isph_corrected.cpp:451-460)"""
-    parts, own = channel(N)
+    pair_isph_corrected.cpp:451-460).  h_over_dx = 1.02: the setting of conv-channel-edl-potential-2d-morrisholmes-rev406.txt"""
+    parts, own = channel(N, h_over_dx)
     n, nall = parts["nlocal"], parts["nall"]
     P0 = orc.Particles(parts, own, kernel="wendland", kinds=KINDS)
     pnd = P0.compute_pnd()

@@ -1,5 +1,5 @@
 """Regenerates the rows of reference_known_answers.json from the text tables the reference keeps
-(sph-script/conv-taylor-green-vortex-2d-rev{390,230}.txt, conv-poisson-boltzmann-harmonic-2d-rev390.txt, conv-channel-edl-potential-2d-morrisholmes-rev722.txt).  Runs only where
+(sph-script/conv-taylor-green-vortex-2d-rev{390,230}.txt, conv-poisson-boltzmann-harmonic-2d-rev390.txt, conv-channel-edl-potential-2d-morrisholmes-rev722.txt and -rev406.txt).  Runs only where
 /root/reference exists (the build container); the JSON it writes is data: expected outputs."""
 import json
 import os
@@ -77,6 +77,10 @@ if __name__ == "__main__":
                    "dx origin 0.5, h = 1.2 dx, Wendland cut 2h, MorrisHolmes boundary, linearised Poisson-Boltzmann kappa^2 = 100",
         "rows": parse_pb(REF + "conv-channel-edl-potential-2d-morrisholmes-rev722.txt", "MorrisHolmes"),
         "rows_const_extension": parse_pb(REF + "conv-channel-edl-potential-2d-morrisholmes-rev722.txt", "ConstExtension")}
+    g["conv_channel_edl_potential_2d_morrisholmes_rev406"] = {
+        "file": "sph-script/conv-channel-edl-potential-2d-morrisholmes-rev406.txt",
+        "setting": "the same channel at an earlier revision, \"MorrisHolmes with h = 1.02 dx\" (Wendland, cut 2h)",
+        "rows": parse_pb(REF + "conv-channel-edl-potential-2d-morrisholmes-rev406.txt")}
     json.dump(g, open(path, "w"), indent=1)
     # the bead pack of BASELINE configs[4]: an INPUT data file of the reference's script (pore-scale-flow-3d.lmp:125 reads
     # it through compute isph/cylinder/porous), kept as a fixture so that the configuration can be generated faithfully

@@ -75,12 +75,12 @@ def test_device_chain_reproduces_reference_pb_harmonic_table(gpu_ctx, N):
 
 
 # ---------------------------------------------------------------- conv-channel-edl-potential-2d-morrisholmes-rev722.txt
-def device_channel(ctx, N, boundary):
+def device_channel(ctx, N, boundary, h_over_dx=1.2):
     """The linearised Poisson-Boltzmann channel problem  -lap_h psi + kappa^2 psi = 0, psi = 1 on the wall particles, IS a
     Helmholtz system of the hot path: (I - theta dt nu lap_h) psi = b with theta = 1, dt nu = 1 / kappa^2, b = 0 on the
     fluid rows and the wall value on the solid (identity) rows -- isph_assemble_helmholtz with the MorrisHolmes mirror
     (functor_boundary_morris_holmes.h:49-64) and isph_solve, nothing on the host but the error norm."""
-    parts, own = pb_channel.channel(N)
+    parts, own = pb_channel.channel(N, h_over_dx)
     n, nall = parts["nlocal"], parts["nall"]
     colmap = own.astype(np.int32)
     kinds = pb_channel.KINDS
@@ -116,6 +116,17 @@ def test_device_chain_reproduces_reference_channel_table(gpu_ctx, N, boundary):
     # the smallest error of the table (MorrisHolmes, N = 1024: 9.5e-6) is where the reference's own solver tolerance
     # shows first (1.4e-8 against the round-off-converged oracle)
     assert abs(r["err_psi"] - ref["err_psi"]) <= 1e-7 * ref["err_psi"], (r, ref)
+
+
+@pytest.mark.parametrize("N", [32, 64])
+def test_device_chain_on_the_earlier_channel_table_with_h_102(gpu_ctx, N):
+    """conv-channel-edl-potential-2d-morrisholmes-rev406.txt ("h = 1.02 dx"): volume to the table's digits on the device,
+    err.psi to the 4 digits that revision shares with the current operators (tests/test_oracle.py, oracle/pb_channel.py)"""
+    ref = pb_channel.known_answers("rev406")[N]
+    r = device_channel(gpu_ctx, N, "MorrisHolmes", h_over_dx=1.02)
+    assert r["particles"] == ref["particles"] and r["wall"] <= 1e-12
+    assert abs(r["volume"] - ref["volume"]) <= 2e-12 * ref["volume"]
+    assert abs(r["err_psi"] - ref["err_psi"]) <= 5e-4 * ref["err_psi"], (r, ref)
 
 
 def test_device_pnd_matches_oracle(gpu_ctx):

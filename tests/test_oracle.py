@@ -478,6 +478,21 @@ def test_pb_channel_known_answer_table_pinned(N, boundary):
     assert 0.5 < r["xi_min"] < 1.0                   # near-wall fluid: between half and all of the support is fluid
 
 
+@pytest.mark.parametrize("N", [32, 64])
+def test_pb_channel_earlier_table_with_h_102(N):
+    """sph-script/conv-channel-edl-potential-2d-morrisholmes-rev406.txt ("MorrisHolmes with h = 1.02 dx"): the same
+    channel in another h/dx regime.  Particle count exact, total volume to the table's digits, sol.psi to 1e-14;
+    err.psi.norm2 to 4 digits only (that revision's solve is not the one rev722 records; oracle/pb_channel.py says
+    which rows are used and why)."""
+    import pb_channel
+    ref = pb_channel.known_answers("rev406")[N]
+    r = pb_channel.run(N, "MorrisHolmes", h_over_dx=1.02)
+    assert r["particles"] == ref["particles"]
+    assert abs(r["volume"] - ref["volume"]) <= 5e-14 * ref["volume"]
+    assert abs(r["sol_psi"] - ref["sol_psi"]) <= 1e-14
+    assert abs(r["err_psi"] - ref["err_psi"]) <= 5e-4 * ref["err_psi"]
+
+
 def test_amg_with_null_vector_masked_to_the_fluid_rows():
     """cavity Poisson system (wall Neumann rows, null vector = fluid mask): aggregates of wall particles have an empty
     coarse row; the smoother must leave them at zero.  Converges, and in fewer iterations than block ILU(0)."""
