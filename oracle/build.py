@@ -31,7 +31,7 @@ def build_ref(force=False):
     shim = os.path.join(HERE, "ref_kernels_shim.cpp")
     if not os.path.isdir(REF_SRC):
         return REF_LIB if os.path.exists(REF_LIB) else None
-    deps = [shim] + [os.path.join(REF_SRC, h) for h in ("kernel.h", "kernel_wendland.h", "kernel_quintic.h", "kernel_cubic.h", "filter.h")]
+    deps = [shim] + [os.path.join(REF_SRC, h) for h in ("kernel.h", "kernel_wendland.h", "kernel_quintic.h", "kernel_cubic.h", "filter.h", "functor.h", "mirror.h")]
     stale = force or not os.path.exists(REF_LIB) or any(os.path.getmtime(d) > os.path.getmtime(REF_LIB) for d in deps)
     if stale:
         os.makedirs(REF_DIR, exist_ok=True)

@@ -134,6 +134,8 @@ static inline double sph_op(int antisym, double fi, double fj) {
   return antisym ? (fi + fj) : (fj - fi);
 }
 
+double orc_sph_operator(int antisym, double fi, double fj) { return sph_op(antisym, fi, fj); }  /* for the check against oracle/_ref */
+
 /* MirrorMorrisHolmes::computeMirrorCoefficient, ref: mirror_morris_holmes.h:39-52
  *   d = 2 cut (pnd V - 1/2) + eps ; coeff = 1 + d_j / max(d_i, safe*h) */
 static double mirror_coeff(const orc_particles *P, int morris, int i, int j, double cut) {

@@ -97,6 +97,7 @@ double orc_kernel_dval(int kernel, int dim, double r, double h);
 void orc_forward_comm(const orc_particles *P, double *arr, int ncomp);
 int orc_filter_yes1(int filt_i, int ikind);                       /* FilterBinary::yes(itype), filter.h:50-52 */
 int orc_filter_yes2(int filt_i, int filt_j, int ikind, int jkind);  /* FilterBinary::yes(itype, jtype), :53-56 */
+double orc_sph_operator(int antisym, double fi, double fj);          /* sphOperator<AntiSymmetric>, functor.h:9-20 */
 void orc_compute_volumes(const orc_particles *P);
 void orc_compute_pnd(const orc_particles *P, double *pnd /* [nall] */);
 void orc_compute_gradient_correction(const orc_particles *P);

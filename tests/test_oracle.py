@@ -549,6 +549,17 @@ def test_oracle_kernels_equal_the_reference_kernel_classes():
             for fj in (99, 99 - 64, 127):
                 for jk in kinds:
                     assert ref.ref_filter_match_yes2(fi, fj, ik, jk) == orc.lib().orc_filter_yes2(fi | orc.FILTER_MATCH, fj, ik, jk)
+    # the pair operator of every gradient / divergence / Laplacian functor (functor.h:9-20) and MirrorNothing (mirror.h:19)
+    ref.ref_sph_operator.restype = ctypes.c_double
+    ref.ref_sph_operator.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    ref.ref_mirror_nothing.restype = ctypes.c_double
+    ref.ref_mirror_nothing.argtypes = [ctypes.c_double]
+    orc.lib().orc_sph_operator.restype = ctypes.c_double
+    orc.lib().orc_sph_operator.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    for fi, fj in ((1.5, -0.25), (0.0, 3.0), (-2.0, -2.0), (1e-300, 1e300)):
+        for a in (0, 1):
+            assert ref.ref_sph_operator(a, fi, fj) == orc.lib().orc_sph_operator(a, fi, fj)
+    assert ref.ref_mirror_nothing(0.3) == 1.0
     rng = np.random.default_rng(1)
     for kernel, name, support in ((0, "wendland", 2.0), (1, "quintic", 3.0), (2, "cubic", 2.0)):
         for dim in (2, 3):
