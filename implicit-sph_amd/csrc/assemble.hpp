@@ -1230,8 +1230,8 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->type, (size_t)P->nall, on_device, S.type, &a.type);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->colmap, (size_t)P->nall, on_device, S.colmap, &a.colmap);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->vfrac, (size_t)P->nall, on_device, S.vfrac, &a.vfrac);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, S.Gc, &a.Gc);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nall * dL, on_device, S.Lc, &a.Lc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nlocal * dim * dim, on_device, S.Gc, &a.Gc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nlocal * dL, on_device, S.Lc, &a.Lc);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, rho, (size_t)P->nall, on_device, S.rho, &a.rho);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, vstar, (size_t)P->nall * 3, on_device, S.vstar, &a.vstar);
   if (rc == ISPH_SUCCESS && P->morris_holmes) {
@@ -1241,7 +1241,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   if (rc == ISPH_SUCCESS && P->normal && singular_mode != 0) {
     if (!P->Gc) rc = fail("wall normals need Gc (gradient-operator rows use G_i)", __FILE__, __LINE__);
     else rc = stage(ctx, P->normal, (size_t)P->nall * 3, on_device, S.normal, &a.normal);
-    if (rc == ISPH_SUCCESS && !a.Gc) rc = stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, S.Gc, &a.Gc);
+    if (rc == ISPH_SUCCESS && !a.Gc) rc = stage(ctx, P->Gc, (size_t)P->nlocal * dim * dim, on_device, S.Gc, &a.Gc);
   }
   NeighPtr np;
   if (rc == ISPH_SUCCESS) rc = stage_neigh_ptr(ctx, P, n, on_device, S.nptr, S.nptr64, np, &nnb);
@@ -1380,8 +1380,8 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->type, (size_t)P->nall, on_device, S.type, &a.type);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->colmap, (size_t)P->nall, on_device, S.colmap, &a.colmap);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->vfrac, (size_t)P->nall, on_device, S.vfrac, &a.vfrac);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, S.Gc, &a.Gc);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nall * dL, on_device, S.Lc, &a.Lc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nlocal * dim * dim, on_device, S.Gc, &a.Gc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nlocal * dL, on_device, S.Lc, &a.Lc);
   if (mode == 0) {
     if (rc == ISPH_SUCCESS) rc = stage(ctx, rho, (size_t)P->nall, on_device, S.rho, &a.rho);
     if (rc == ISPH_SUCCESS) rc = stage(ctx, nu, (size_t)P->nall, on_device, snu, &a.nu);

@@ -298,8 +298,8 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->type, (size_t)P->nall, on_device, S.type, &a.type);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->colmap, (size_t)P->nall, on_device, S.colmap, &a.colmap);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->vfrac, (size_t)P->nall, on_device, S.vfrac, &a.vfrac);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nall * d2, on_device, S.Gc, &a.Gc);
-  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nall * dL, on_device, S.Lc, &a.Lc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Gc, (size_t)P->nlocal * d2, on_device, S.Gc, &a.Gc);
+  if (rc == ISPH_SUCCESS) rc = stage(ctx, P->Lc, (size_t)P->nlocal * dL, on_device, S.Lc, &a.Lc);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, rho, (size_t)P->nall, on_device, S.rho, &a.rho);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, nu, (size_t)P->nall, on_device, snu, &a.nu);
   if (rc == ISPH_SUCCESS) rc = stage(ctx, pres, (size_t)P->nall, on_device, sp, &a.p);

@@ -295,7 +295,7 @@ inline int op_stage(isph_ctx *ctx, const isph_particles *P, int antisym, int on_
   ISPH_CHECK(stage(ctx, P->x, (size_t)P->nall * 3, on_device, st.S.x, &st.a.x));
   ISPH_CHECK(stage(ctx, P->type, (size_t)P->nall, on_device, st.S.type, &st.a.type));
   ISPH_CHECK(stage(ctx, P->vfrac, (size_t)P->nall, on_device, st.S.vfrac, &st.a.vfrac));
-  ISPH_CHECK(stage(ctx, P->Gc, (size_t)P->nall * dim * dim, on_device, st.S.Gc, &st.a.Gc));
+  ISPH_CHECK(stage(ctx, P->Gc, (size_t)P->nlocal * dim * dim, on_device, st.S.Gc, &st.a.Gc));
   NeighPtr np;
   ISPH_CHECK(stage_neigh_ptr(ctx, P, n, on_device, st.S.nptr, st.S.nptr64, np, &nnb));
   st.a.nptr = np.p32;

@@ -522,6 +522,15 @@ def solve(ctx, A, b, x, prec=None, singular=False, null_mask=None, params=None, 
     return info
 
 
+def _need(a, count, what):
+    """operand of a C-ABI call: at least `count` elements (None passes)"""
+    if a is None:
+        return
+    have = int(a.numel()) if _is_torch(a) else int(np.asarray(a).size)
+    if have < count:
+        raise ValueError("%s: %d elements given, %d needed" % (what, have, count))
+
+
 def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=None, Lc=None, keep=None,
                    pnd=None, morris_safe_coeff=0.43301, normal=None, solid_normal_diag=1.0):
     """Builds the isph_particles struct over host (numpy) or device (torch)
@@ -544,6 +553,12 @@ def particles_view(parts, colmap, kernel="wendland", kinds=None, vfrac=None, Gc=
     pnd = None if pnd is None else _f64(pnd)
     normal = None if normal is None else _f64(normal)
     keep += [kind, h, cutsq, x, typ, nptr, nidx, cm, vfrac, Gc, Lc, pnd, normal]
+    nl, na, dm = int(parts["nlocal"]), int(parts["nall"]), int(parts["dim"])
+    # the C ABI takes bare pointers: a short array would be read past its end
+    _need(x, 3 * na, "x [nall][3]"); _need(typ, na, "type [nall]"); _need(cm, na, "colmap [nall]")
+    _need(nptr, nl + 1, "neigh_ptr [nlocal+1]"); _need(vfrac, na, "vfrac [nall]"); _need(pnd, na, "pnd [nall]")
+    _need(Gc, nl * dm * dm, "Gc [nlocal][dim*dim]"); _need(Lc, nl * dm * (dm + 1) // 2, "Lc [nlocal][dimL]")
+    _need(normal, 3 * na, "normal [nall][3]")
     pv = _Particles(int(parts["dim"]), int(parts["nlocal"]), int(parts["nall"]), ntypes, KERNELS[kernel],
                     _ptr(x), _ptr(typ), _ptr(kind), _ptr(h), _ptr(cutsq), None if wide else _ptr(nptr), _ptr(nidx), _ptr(cm),
                     _ptr(vfrac), _ptr(Gc), _ptr(Lc), int(pnd is not None), _ptr(pnd), float(morris_safe_coeff),
@@ -561,6 +576,7 @@ def assemble_poisson(ctx, parts, colmap, dt, rho, vstar, antisym=True, singular=
                                    solid_normal_diag=solid_normal_diag)
     rho, vstar = _f64(rho), _f64(vstar)
     nlocal = int(parts["nlocal"])
+    _need(rho, int(parts["nall"]), "rho [nall]"); _need(vstar, 3 * int(parts["nall"]), "vstar [nall][3]")
     if b_out is None:
         if dev:
             import torch
@@ -585,6 +601,10 @@ def assemble_helmholtz(ctx, parts, colmap, dt, theta, nu, rho, pres, force, g, v
     nu, rho, pres, force, vel = map(_f64, (nu, rho, pres, force, vel))
     gv = np.ascontiguousarray(g, dtype=np.float64)
     nlocal, dim = int(parts["nlocal"]), int(parts["dim"])
+    na = int(parts["nall"])
+    for a_, c_, w_ in ((nu, na, "nu [nall]"), (rho, na, "rho [nall]"), (pres, na, "pres [nall]"), (force, 3 * na, "force [nall][3]"),
+                       (vel, 3 * na, "v [nall][3]")):
+        _need(a_, c_, w_)
     if dev:
         import torch
         b_out = torch.zeros(nlocal * dim, dtype=torch.float64, device=rho.device)
@@ -605,6 +625,7 @@ def assemble_solute_transport(ctx, parts, colmap, dt, theta, dcoeff, conc, antis
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, Lc=Lc, keep=keep, kinds=kinds)
     conc = _f64(conc)
     nlocal = int(parts["nlocal"])
+    _need(conc, int(parts["nall"]), "conc [nall]")
     if dev:
         import torch
         b_out = torch.zeros(nlocal, dtype=torch.float64, device=conc.device)
@@ -624,6 +645,7 @@ def assemble_applied_potential(ctx, parts, colmap, sigma, phi, antisym=True, nco
     phi = _f64(phi)
     sg = None if sigma is None else _f64(sigma)
     nlocal = int(parts["nlocal"])
+    _need(phi, int(parts["nall"]), "phi [nall]"); _need(sg, int(parts["nall"]), "sigma [nall]")
     if dev:
         import torch
         b_out = torch.zeros(nlocal, dtype=torch.float64, device=phi.device)
@@ -645,6 +667,10 @@ def assemble_block_helmholtz(ctx, parts, colmap, dt, theta, beta, nu, rho, pres,
                                    pnd=pnd, morris_safe_coeff=morris_safe_coeff)
     nu, rho, pres, force, vel = map(_f64, (nu, rho, pres, force, vel))
     nrm = None if normal is None else _f64(normal)
+    na = int(parts["nall"])
+    for a_, c_, w_ in ((nu, na, "nu [nall]"), (rho, na, "rho [nall]"), (pres, na, "pres [nall]"), (force, 3 * na, "force [nall][3]"),
+                       (vel, 3 * na, "v [nall][3]"), (nrm, 3 * na, "normal [nall][3]")):
+        _need(a_, c_, w_)
     gv = np.ascontiguousarray(g, dtype=np.float64)
     nlocal, dim = int(parts["nlocal"]), int(parts["dim"])
     if dev:
@@ -732,6 +758,7 @@ def gradient(ctx, parts, colmap, f, vfrac, antisym=True, alpha=1.0, filt=None, G
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
     f = _f64(f)
     _same_side(dev, f)
+    _need(f, int(parts["nall"]), "f [nall]")
     out = _out_like(dev, f, (int(parts["nlocal"]), 3))
     fi, fj = filt if filt is not None else (127, 127)
     _check(lib().isph_gradient(ctx.h, C.byref(pv), int(antisym), _ptr(f), float(alpha), int(filt is not None), fi, fj,
@@ -745,6 +772,7 @@ def divergence(ctx, parts, colmap, f, vfrac, antisym=True, alpha=1.0, filt=None,
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep, kinds=kinds)
     f = _f64(f)
     _same_side(dev, f)
+    _need(f, 3 * int(parts["nall"]), "f [nall][3]")
     out = _out_like(dev, f, (int(parts["nlocal"]),))
     fi, fj = filt if filt is not None else (127, 127)
     _check(lib().isph_divergence(ctx.h, C.byref(pv), int(antisym), _ptr(f), float(alpha), int(filt is not None), fi, fj,
@@ -759,6 +787,8 @@ def correct_velocity_pressure(ctx, parts, colmap, dt, rho, dp, vstar, p, vfrac, 
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep)
     rho, dp = _f64(rho), _f64(dp)
     _same_side(dev, rho, dp, vstar, p)
+    na = int(parts["nall"])
+    _need(rho, na, "rho [nall]"); _need(dp, na, "dp [nall]"); _need(vstar, 3 * na, "vstar [nall][3]"); _need(p, na, "p [nall]")
     _check(lib().isph_correct_velocity_pressure(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(rho), _ptr(dp),
                                                 _ptr(vstar), _ptr(p), int(incremental), dev))
 
@@ -768,6 +798,8 @@ def advance_begin(ctx, parts, colmap, dt, p, v, vnp1, vfrac, antisym=True, Gc=No
     pv, dev, keep = particles_view(parts, colmap, kernel=kernel, vfrac=vfrac, Gc=Gc, keep=keep)
     p, v, vnp1 = _f64(p), _f64(v), _f64(vnp1)
     _same_side(dev, p, v, vnp1)
+    na = int(parts["nall"])
+    _need(p, na, "p [nall]"); _need(v, 3 * na, "v [nall][3]"); _need(vnp1, 3 * na, "vnp1 [nall][3]")
     out = _out_like(dev, p, (int(parts["nlocal"]),))
     _check(lib().isph_advance_begin(ctx.h, C.byref(pv), int(antisym), float(dt), _ptr(p), _ptr(v), _ptr(vnp1), _ptr(out),
                                     dev))
@@ -805,6 +837,8 @@ def apply_shift(ctx, parts, colmap, dr, x, v, p, vfrac, antisym=True, fixed=None
     fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.int32)
     dr = _f64(dr)
     _same_side(dev, dr, x, v, p)
+    na = int(parts["nall"])
+    _need(dr, 3 * int(parts["nlocal"]), "dr [nlocal][3]"); _need(x, 3 * na, "x [nall][3]"); _need(v, 3 * na, "v [nall][3]"); _need(p, na, "p [nall]")
     _check(lib().isph_apply_shift(ctx.h, C.byref(pv), int(antisym), _ptr(fx), _ptr(dr), _ptr(x), _ptr(v), _ptr(p), dev))
 
 
@@ -816,6 +850,8 @@ def shift_particles(ctx, parts, colmap, shift, shiftcut, nonfluidweight, dt, x, 
     fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.int32)
     vmax = C.c_double(0.0)
     _same_side(dev, x, v, p)
+    na = int(parts["nall"])
+    _need(x, 3 * na, "x [nall][3]"); _need(v, 3 * na, "v [nall][3]"); _need(p, na, "p [nall]")
     _check(lib().isph_shift_particles(ctx.h, C.byref(pv), int(antisym), _ptr(fx), float(shift), float(shiftcut),
                                       float(nonfluidweight), float(dt), _ptr(x), _ptr(v), _ptr(p), C.byref(vmax), dev))
     return vmax.value

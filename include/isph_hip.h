@@ -219,8 +219,10 @@ typedef struct {
   const int *neigh_idx;    /* neighbour indices into [0,nall)                 */
   const int *colmap;       /* [nall] matrix column of particle j              */
   const double *vfrac;     /* [nall] atom->vfrac (NULL: computed on device)   */
-  const double *Gc;        /* [nall][dim*dim] or NULL (AntiSymmetric family)  */
-  const double *Lc;        /* [nall][dimL]    or NULL                         */
+  const double *Gc;        /* [nlocal][dim*dim] or NULL (AntiSymmetric family): only the rows of owned particles are
+                            * read (the reference's Gc[nmax] holds nothing else: computePre fills local rows and
+                            * does no forward comm of them, pair_isph_corrected.cpp:302-369)                        */
+  const double *Lc;        /* [nlocal][dimL]    or NULL                         */
   /* ns.boundary == MorrisHolmes (pair_isph.h:125-132): fluid-solid pairs are weighted by
    * MirrorMorrisHolmes::computeMirrorCoefficient (mirror_morris_holmes.h:39-52) -- in the
    * divergence of the Poisson RHS and in the Laplacian of the Helmholtz matrix */

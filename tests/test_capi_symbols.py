@@ -95,3 +95,27 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".hpp", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "isph_oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_python_plumbing_refuses_operands_shorter_than_the_abi_reads():
+    """The C ABI takes bare pointers; a per-particle array shorter than what the entry point reads ([nall] fields,
+    [nlocal] rows of Gc / Lc) would be read past its end.  The ctypes layer checks the element counts before the call
+    (no device needed: the check comes first)."""
+    import numpy as np
+    import isph_amd  # noqa: F401
+    from isph_amd import hip, workload
+    spec = workload.TGVSpec(dim=2, ncell=(8, 8), brick=(4, 4), origin=(0.5, 0.5), mode=workload.JITTER)
+    p = workload.make_tgv(spec)
+    n, nall = p["nlocal"], p["nall"]
+    assert nall > n
+    colmap = workload.single_rank_colmap(p)
+    ok = dict(vfrac=np.ones(nall), Gc=np.zeros((n, 4)), Lc=np.zeros((n, 3)))
+    hip.particles_view(p, colmap, **ok)                                    # the sizes the ABI documents
+    for bad in (dict(ok, vfrac=np.ones(n)), dict(ok, Gc=np.zeros((n - 1, 4))), dict(ok, Lc=np.zeros((n, 2))),
+                dict(ok, pnd=np.ones(n)), dict(ok, normal=np.zeros((n, 3)))):
+        with pytest.raises(ValueError):
+            hip.particles_view(p, colmap, **bad)
+    with pytest.raises(ValueError):
+        hip.particles_view(p, colmap[:n], **ok)
+    with pytest.raises(ValueError):                                        # rho given for the owned particles only
+        hip.assemble_poisson(None, p, colmap, spec.dt, np.ones(n), np.zeros((nall, 3)), vfrac=np.ones(nall))
