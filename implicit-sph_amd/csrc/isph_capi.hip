@@ -893,7 +893,9 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, st));
 
   double *db = b, *dx = x;
-  const size_t tot = (size_t)lda * (size_t)nvec;
+  // a [lda x nvec] column-major view owns lda (nvec - 1) + n elements (Epetra_MultiVector(View, map, ptr, lda, nvec)): the
+  // tail lda - n of the last column is not the caller's to give
+  const size_t tot = (size_t)lda * (size_t)(nvec - 1) + (size_t)n;
   if (!on_device) {
     ISPH_CHECK(ctx->bdev.reserve(tot));
     ISPH_CHECK(ctx->xdev.reserve(tot));

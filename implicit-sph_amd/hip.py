@@ -327,6 +327,7 @@ class Matrix:
                                                   (peers, send_ptr, send_idx, recv_ptr))
         _check(lib().isph_mat_set_halo(self.ctx.h, self.h, len(peers), _ptr(peers), _ptr(send_ptr), _ptr(send_idx),
                                        _ptr(recv_ptr)))
+        self._halo = True
 
     def info(self):
         a = (C.c_longlong * 6)()
@@ -343,6 +344,10 @@ class Matrix:
 
     def spmv(self, x, y=None):
         x = _f64(x)
+        inf = self.info()
+        # ghost columns without a halo plan: the caller supplies all ncol entries; otherwise the nrow owned ones
+        _need(x, inf["ncol"] if (inf["ncol"] > inf["nrow"] and not getattr(self, "_halo", False)) else inf["nrow"], "x")
+        _need(y, inf["nrow"], "y [nrow]")
         if y is None:
             n = self.info()["nrow"]
             if _is_torch(x):
@@ -380,6 +385,7 @@ class Precond:
 
     def apply(self, r, z=None):
         r = _f64(r)
+        _need(r, self.n, "r [n]"); _need(z, self.n, "z [n]")
         if z is None:
             if _is_torch(r):
                 import torch
@@ -516,6 +522,8 @@ def solve(ctx, A, b, x, prec=None, singular=False, null_mask=None, params=None, 
     info = SolveInfo()
     n = A.info()["nrow"]
     mask = None if null_mask is None else np.ascontiguousarray(null_mask, dtype=np.int32)
+    ld = n if lda is None else lda
+    _need(b, ld * (nvec - 1) + n, "b [lda x nvec]"); _need(x, ld * (nvec - 1) + n, "x [lda x nvec]"); _need(mask, n, "null_mask [n]")
     _check(lib().isph_solve(ctx.h, A.h, prec.h if prec is not None else None, _ptr(b), _ptr(x), nvec,
                             n if lda is None else lda, int(singular), _ptr(mask), C.byref(prm), C.byref(info),
                             _on_device(b, x)))

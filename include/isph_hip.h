@@ -91,8 +91,8 @@ int isph_mat_export_csr(isph_ctx *ctx, const isph_mat *A, int *rowptr, int *coli
 void isph_mat_destroy(isph_mat *A);
 
 /* y = A x  (Epetra_CrsMatrix::Apply incl. the ghost Import; ref: solver_lin.h:133).
- * x: ncol entries if on one rank all ghosts are local images (ncol == nrow),
- * otherwise nrow owned entries (ghosts are fetched).  y: nrow entries. */
+ * x: nrow owned entries -- the ghost columns are fetched through the halo plan; a matrix WITH ghost columns (ncol >
+ * nrow) but WITHOUT a plan (isph_mat_set_halo not called) reads all ncol entries from the caller.  y: nrow entries. */
 int isph_spmv(isph_ctx *ctx, const isph_mat *A, const double *x /*[h|d]*/,
               double *y /*[h|d]*/, int on_device);
 /* Time `reps` back-to-back SpMV launches with HIP events on the library
