@@ -1,0 +1,94 @@
+"""Run by tests/test_gpu_parity.py::test_entry_points_read_no_more_than_the_abi_documents in a child process.
+
+Every host operand of the main entry points is placed so that it ENDS at an unreadable page (anonymous mmap + mprotect):
+an entry point that reads one element more than include/isph_hip.h documents dies with SIGSEGV here instead of reading
+whatever follows the caller's buffer (the [nall]-for-[nlocal] staging of Gc / Lc did exactly that, intermittently).
+Exit code 0 = every call came back."""
+import ctypes
+import mmap
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import isph_amd  # noqa: F401,E402
+from isph_amd import hip, workload  # noqa: E402
+
+_libc = ctypes.CDLL(None, use_errno=True)
+_keep = []
+
+
+def guarded(a):
+    a = np.ascontiguousarray(a)
+    if a.size == 0:
+        return a
+    page = mmap.PAGESIZE
+    npages = (a.nbytes + page - 1) // page
+    m = mmap.mmap(-1, (npages + 1) * page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    assert _libc.mprotect(ctypes.c_void_p(base + npages * page), ctypes.c_size_t(page), 0) == 0     # PROT_NONE
+    g = np.frombuffer(m, dtype=a.dtype, count=a.size, offset=npages * page - a.nbytes).reshape(a.shape)
+    g[...] = a
+    _keep.append(m)
+    return g
+
+
+def main():
+    ctx = hip.Context(0)
+    spec = workload.TGVSpec(dim=3, ncell=(10, 10, 10), brick=(4, 4, 4), mode=workload.JITTER)
+    p = dict(workload.make_tgv(spec))
+    n, nall = p["nlocal"], p["nall"]
+    own = p["owner_index"].astype(np.int64)
+    typ = np.ones(n, np.int32)
+    typ[(p["x"][:n, 1] % (2 * np.pi)) < 0.9] = 2                    # a solid slab: walls, normals, pnd
+    p["type"] = typ[own]
+    kinds = [99, 12]
+    for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+        p[k] = guarded(p[k])
+    colmap = guarded(workload.single_rank_colmap(p))
+    G = guarded
+
+    vf = hip.compute_volumes(ctx, p, colmap)
+    vfrac = G(vf[own])
+    pnd = G(hip.compute_pnd(ctx, p, colmap, kinds=kinds)[own])
+    Gc, Lc = hip.compute_corrections(ctx, p, colmap, vfrac)
+    Gc, Lc = G(Gc), G(Lc)                                              # [nlocal] rows, as the ABI documents
+    rho, nu = G(np.ones(nall)), G(np.full(nall, 0.1))
+    vel = G(np.ascontiguousarray(p["v"]))
+    pres, force, g3 = G(np.cos(p["x"][:, 0])), G(np.zeros((nall, 3))), np.zeros(3)
+    nrm = np.zeros((nall, 3))
+    nrm[np.asarray(p["type"]) == 2, 1] = 1.0
+    nrm = G(nrm)
+
+    for antisym in (True, False):
+        kw = dict(vfrac=vfrac, kinds=kinds, Gc=None if antisym else Gc, Lc=None if antisym else Lc)
+        A, b = hip.assemble_poisson(ctx, p, colmap, spec.dt, rho, vel, antisym=antisym, **kw)
+        hip.assemble_poisson(ctx, p, colmap, spec.dt, rho, vel, antisym=antisym, vfrac=vfrac, kinds=kinds, Gc=Gc, Lc=Lc, pnd=pnd,
+                             normal=nrm)
+        H, bh = hip.assemble_helmholtz(ctx, p, colmap, spec.dt, 0.5, nu, rho, pres, force, g3, vel, antisym=antisym, pnd=pnd, **kw)
+        hip.assemble_block_helmholtz(ctx, p, colmap, spec.dt, 0.5, 0.1, nu, rho, pres, force, g3, vel, normal=nrm, antisym=antisym,
+                                     vfrac=vfrac, kinds=kinds, Gc=Gc, Lc=Lc)
+        hip.assemble_solute_transport(ctx, p, colmap, spec.dt, 0.5, 0.3, pres, antisym=antisym, **kw)
+        hip.assemble_applied_potential(ctx, p, colmap, nu, pres, antisym=antisym, **kw)
+        hip.gradient(ctx, p, colmap, pres, vfrac, antisym=antisym, Gc=kw["Gc"], kinds=kinds)
+        hip.divergence(ctx, p, colmap, vel, vfrac, antisym=antisym, Gc=kw["Gc"], kinds=kinds)
+        # the solves: three right-hand sides in one [lda x 3] view, SpMV, preconditioner application
+        M = hip.Precond(ctx, H, "bjacobi-ilu0", 256)
+        xg, bg = G(np.zeros(3 * n)), G(np.asarray(bh))
+        info = hip.solve(ctx, H, bg, xg, prec=M, nvec=3, lda=n)
+        assert info.converged == 1
+        H.spmv(G(np.ones(n)))
+        M.apply(G(np.ones(n)))
+        Ms = hip.PrecondAMG(ctx, A, nullvec=G(np.full(n, 1.0 / np.sqrt(n))))
+        x1, b1 = G(np.zeros(n)), G(np.asarray(b))
+        assert hip.solve(ctx, A, b1, x1, prec=Ms, singular=True, null_mask=G(np.ones(n, np.int32))).converged == 1
+        rp, ci, val = A.export_csr()
+        hip.Matrix.from_csr(ctx, G(rp), G(ci), G(val)).spmv(G(np.ones(n)))
+    print("guarded operands: every entry point stayed inside its buffers")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

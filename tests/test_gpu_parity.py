@@ -56,6 +56,19 @@ def test_empty_and_tiny_matrices(gpu_ctx):
         hip.Matrix.from_csr(gpu_ctx, rp, np.array([0, 0, 7], np.int32), v)     # column out of range
 
 
+def test_entry_points_read_no_more_than_the_abi_documents():
+    """tests/guarded_operands.py in a child process: every host operand ends at an unreadable page, so an entry point
+    that reads past the element counts of include/isph_hip.h dies with SIGSEGV there (return code -11) instead of
+    passing by luck."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "guarded_operands.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "rc %d\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    assert "every entry point stayed inside its buffers" in r.stdout
+
+
 def test_rank_without_particles(gpu_ctx):
     """LAMMPS subdomains may be empty: nlocal = nall = 0 goes through computePre, the assembly, every preconditioner
     set-up and the solve (which still takes part in the collectives) and comes back converged after 0 iterations."""
