@@ -86,6 +86,20 @@ def main():
         assert hip.solve(ctx, A, b1, x1, prec=Ms, singular=True, null_mask=G(np.ones(n, np.int32))).converged == 1
         rp, ci, val = A.export_csr()
         hip.Matrix.from_csr(ctx, G(rp), G(ci), G(val)).spmv(G(np.ones(n)))
+        # the streaming operators either side of the solve (in place on their [nall] operands)
+        vs, pp = G(np.ascontiguousarray(p["v"])), G(np.asarray(pres).copy())
+        hip.correct_velocity_pressure(ctx, p, colmap, 0.01, rho, pres, vs, pp, vfrac, antisym=antisym, Gc=kw["Gc"])
+        dpa = hip.advance_begin(ctx, p, colmap, 0.01, pres, vel, vs, vfrac, antisym=antisym, Gc=kw["Gc"])
+        xg2, vg2, pg2 = G(np.ascontiguousarray(p["x"][:n])), G(np.ascontiguousarray(p["v"][:n])), G(np.asarray(pres)[:n].copy())
+        hip.advance_end(ctx, n, 3, 0.01, G(dpa), G(np.ascontiguousarray(vs[:n])), pg2, xg2, vg2)
+        xs, vsh, psh = G(np.array(p["x"])), G(np.ascontiguousarray(p["v"])), G(np.asarray(pres).copy())
+        hip.shift_particles(ctx, p, colmap, 0.05, 0.8 * p["cut"], 0.7, spec.dt, xs, vsh, psh, vfrac, antisym=antisym, Gc=kw["Gc"],
+                            kinds=kinds, fixed=[0, 0, 1])
+        # the reference's own decomposition (one subdomain, level-scheduled) and the recycling solver
+        Mw = hip.PrecondSchwarz(ctx, H, level_of_fill=0, overlap=0, block_size=0)
+        Mw.apply(G(np.ones(n)))
+        xr, br = G(np.zeros(n)), G(np.asarray(bh)[:n].copy())
+        assert hip.solve(ctx, H, br, xr, prec=M, params=hip.SolverParams(solver_type=2, num_blocks=20, num_recycled=5)).converged == 1
     print("guarded operands: every entry point stayed inside its buffers")
     ctx.close()
 
