@@ -79,6 +79,15 @@ def main():
         xg, bg = G(np.zeros(3 * n)), G(np.asarray(bh))
         info = hip.solve(ctx, H, bg, xg, prec=M, nvec=3, lda=n)
         assert info.converged == 1
+        # a padded view: lda > n, the arrays own exactly lda (nvec - 1) + n elements
+        lda = n + 5
+        bpad, xpad = np.zeros(2 * lda + n), np.zeros(2 * lda + n)
+        for k in range(3):
+            bpad[k * lda:k * lda + n] = np.asarray(bh)[k * n:(k + 1) * n]
+        bpad, xpad = G(bpad), G(xpad)
+        assert hip.solve(ctx, H, bpad, xpad, prec=M, nvec=3, lda=lda).converged == 1
+        for k in range(3):
+            assert np.max(np.abs(xpad[k * lda:k * lda + n] - xg[k * n:(k + 1) * n])) <= 1e-12 * max(np.abs(xg).max(), 1e-300)
         H.spmv(G(np.ones(n)))
         M.apply(G(np.ones(n)))
         Ms = hip.PrecondAMG(ctx, A, nullvec=G(np.full(n, 1.0 / np.sqrt(n))))
