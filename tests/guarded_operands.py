@@ -3,7 +3,8 @@
 Every host operand of the main entry points is placed so that it ENDS at an unreadable page (anonymous mmap + mprotect):
 an entry point that reads one element more than include/isph_hip.h documents dies with SIGSEGV here instead of reading
 whatever follows the caller's buffer (the [nall]-for-[nlocal] staging of Gc / Lc did exactly that, intermittently).
-Exit code 0 = every call came back."""
+Exit code 0 = every call came back.  `--negative-control`: a call that IS one element short, to show the guard bites.
+"""
 import ctypes
 import mmap
 import os
@@ -113,5 +114,16 @@ def main():
     ctx.close()
 
 
+def negative_control():
+    """one element short on purpose, past the element-count check of the ctypes layer: must die with SIGSEGV"""
+    import ctypes as C
+    ctx = hip.Context(0)
+    n = 5000
+    A = hip.Matrix.from_csr(ctx, np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n))
+    x, y = guarded(np.ones(n - 1)), np.zeros(n)
+    rc = hip.lib().isph_spmv(ctx.h, A.h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), 0)
+    print("over-read went unnoticed, rc", rc)
+
+
 if __name__ == "__main__":
-    main()
+    negative_control() if "--negative-control" in sys.argv else main()

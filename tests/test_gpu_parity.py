@@ -67,6 +67,10 @@ def test_entry_points_read_no_more_than_the_abi_documents():
     r = subprocess.run([sys.executable, os.path.join(here, "guarded_operands.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "rc %d\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     assert "every entry point stayed inside its buffers" in r.stdout
+    # the guard itself: an operand that is one element short must kill the child (SIGSEGV)
+    r = subprocess.run([sys.executable, os.path.join(here, "guarded_operands.py"), "--negative-control"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == -11 and "unnoticed" not in r.stdout, (r.returncode, r.stdout[-500:])
 
 
 def test_rank_without_particles(gpu_ctx):
