@@ -117,6 +117,8 @@ def main():
 def negative_control():
     """one element short on purpose, past the element-count check of the ctypes layer: must die with SIGSEGV"""
     import ctypes as C
+    import resource
+    resource.setrlimit(resource.RLIMIT_CORE, (0, 0))      # the crash is the point; no core file
     ctx = hip.Context(0)
     n = 5000
     A = hip.Matrix.from_csr(ctx, np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n))
