@@ -127,26 +127,54 @@ struct DevPool {
 
 // grow-only device buffer backed by the pool (never allocates inside the Krylov loop:
 // workspaces are sized once per solve)
+// ISPH_POOL_CANARY=1 (debugging aid; the GPU address sanitizer is not available on every system): every device buffer is
+// followed by kCanaryBytes of a known pattern that is checked, after a device synchronisation, when the buffer goes back
+// to the pool -- a kernel that wrote past the end of what was reserved aborts the process there.  Buffers then hold
+// exactly the requested element count (no pool slack), so growing re-allocates.
+constexpr size_t kCanaryBytes = 256;
+inline bool pool_canary() {
+  static const bool on = [] { const char *e = getenv("ISPH_POOL_CANARY"); return e && e[0] == '1'; }();
+  return on;
+}
+inline void canary_arm(void *p, size_t at) { (void)hipMemset(static_cast<char *>(p) + at, 0xA5, kCanaryBytes); }
+inline void canary_check(const void *p, size_t at) {
+  unsigned char h[kCanaryBytes];
+  (void)hipDeviceSynchronize();
+  if (hipMemcpy(h, static_cast<const char *>(p) + at, kCanaryBytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+  for (size_t k = 0; k < kCanaryBytes; ++k)
+    if (h[k] != 0xA5) {
+      fprintf(stderr, "ISPH_POOL_CANARY: a kernel wrote %zu bytes past the end of a %zu-byte device buffer\n", k + 1, at);
+      abort();
+    }
+}
+
 template <class T>
 struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;       // elements usable
   size_t bytes = 0;     // size of the underlying block
+  size_t guard_at = 0;  // canary mode: offset of the pattern (= bytes requested, rounded up to 8)
   int reserve(size_t n) {
     if (n <= cap) return ISPH_SUCCESS;
     release();
     size_t got = 0;
-    p = static_cast<T *>(DevPool::get().alloc(n * sizeof(T), &got));
+    const bool canary = pool_canary();
+    const size_t want = (n * sizeof(T) + 7) / 8 * 8;
+    p = static_cast<T *>(DevPool::get().alloc(canary ? want + kCanaryBytes : n * sizeof(T), &got));
     if (!p) return ::isph::fail("device allocation failed", __FILE__, __LINE__);
     bytes = got;
-    cap = got / sizeof(T);
+    cap = canary ? n : got / sizeof(T);
+    guard_at = canary ? want : 0;
+    if (canary) canary_arm(p, guard_at);
     return ISPH_SUCCESS;
   }
   void release() {
+    if (p && guard_at) canary_check(p, guard_at);
     if (p) DevPool::get().release(p, bytes);
     p = nullptr;
     cap = 0;
     bytes = 0;
+    guard_at = 0;
   }
 };
 

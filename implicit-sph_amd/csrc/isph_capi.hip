@@ -216,7 +216,18 @@ static int ctx_create_common(int device, void *stream, isph_ctx **out) {
   return ISPH_SUCCESS;
 }
 
-int isph_ctx_create(int device, void *stream, isph_ctx **ctx) { return ctx_create_common(device, stream, ctx); }
+int isph_ctx_create(int device, void *stream, isph_ctx **ctx) {
+  ISPH_CHECK(ctx_create_common(device, stream, ctx));
+  // ISPH_POOL_CANARY=1 ISPH_POOL_CANARY_SELFTEST=1: one byte is written behind a 100-byte buffer on purpose; giving the
+  // buffer back must abort the process (tests/test_gpu_parity.py shows the check bites)
+  if (pool_canary() && getenv("ISPH_POOL_CANARY_SELFTEST")) {
+    DevBuf<char> t;
+    ISPH_CHECK(t.reserve(100));
+    ISPH_CHECK_HIP(hipMemset(t.p + 104, 0, 1));
+    t.release();
+  }
+  return ISPH_SUCCESS;
+}
 
 int isph_ctx_create_dist(int device, void *stream, int rank, int nranks, const char *uid, isph_ctx **ctx) {
   ISPH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && uid, "bad rank/nranks/uid");

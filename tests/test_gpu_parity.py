@@ -10,6 +10,7 @@ import oracle as orc
 from problems import Problem, tgv_spec
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 
 CASES = [
     dict(dim=2, n=16, mode=workload.JITTER),
@@ -71,6 +72,24 @@ def test_entry_points_read_no_more_than_the_abi_documents():
     r = subprocess.run([sys.executable, os.path.join(here, "guarded_operands.py"), "--negative-control"], capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == -11 and "unnoticed" not in r.stdout, (r.returncode, r.stdout[-500:])
+
+
+def test_device_buffer_canary_mode_bites():
+    """ISPH_POOL_CANARY=1 (csrc/common.hpp): every pooled device buffer carries a pattern behind its last element that
+    is checked when the buffer is given back -- the stand-in for the GPU address sanitizer this pool does not offer;
+    the whole -m gpu suite runs clean under it.  Here: the mode's own self-test, a deliberate one-byte
+    overrun, must abort the child process, and the same child without the overrun must not."""
+    import os
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); import isph_amd; from isph_amd import hip; c = hip.Context(0); c.close(); print('alive')" % ROOT_DIR
+    env = dict(os.environ, ISPH_POOL_CANARY="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "alive" in r.stdout, r.stderr[-2000:]
+    env["ISPH_POOL_CANARY_SELFTEST"] = "1"
+    r = subprocess.run([sys.executable, "-c", "import resource; resource.setrlimit(resource.RLIMIT_CORE, (0, 0)); " + code],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == -6 and "ISPH_POOL_CANARY: a kernel wrote" in r.stderr and "alive" not in r.stdout, (r.returncode, r.stderr[-500:])
 
 
 def test_rank_without_particles(gpu_ctx):
