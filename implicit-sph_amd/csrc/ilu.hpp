@@ -356,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_iluk_block_offsets(int nblocks, const 
 // than (entries/32 + rows per direction) chunks: capacity = 2 x its sliced-ELL
 // region + 2 B, checked by the kernel all the same.
 constexpr int kTail16 = 10, kCont16 = 11, kPos16 = 12;
-constexpr int kPrefetch = 16;     // chunks kept in flight per wave (default; ISPH_ILU_PREFETCH picks 8/12/16/24)
+constexpr int kPrefetch = 16;     // chunks kept in flight per wave (8, 12 and 24 measured slower or equal)
 constexpr int kPadChunks = 32;    // per-block tail pad so the prefetch never leaves the buffer (>= deepest prefetch)
 constexpr int kCapFactor = 2;
 constexpr int kCapFactorSafe = 8;
