@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the SolverLin drop-in leg (host CSR through the C++ mirror)")
     ap.add_argument("--cpu-ifpack-1rank", action="store_true",
                     help="also time the reference's 1-rank configuration (whole-matrix ILU(1), one thread): minutes")
     ap.add_argument("--spmv-reps", type=int, default=50)
@@ -82,8 +83,8 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False)
                       Ifpack AdditiveSchwarz overlap 0; level of fill 0 and the reference's default 1 (precond_ifpack.h:35)
       single_thread   same_blocks on ONE thread (the reference itself has no threading)
       ifpack_1rank    the reference on one MPI rank: ILU(1) of the whole matrix, one thread (precond_ifpack.h:35,43;
-                      overlap is a no-op on one rank).  Minutes of CPU time -> only with --cpu-ifpack-1rank; otherwise the
-                      figure measured on this matrix and committed under profiles/ is quoted.
+                      overlap is a no-op on one rank).  Minutes of CPU time -> only with --cpu-ifpack-1rank (the record
+                      contains nothing this run did not measure).
     `value` = the fastest all-thread variant."""
     import oracle as orc
     n = len(rp) - 1
@@ -119,12 +120,6 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False)
                 variants["ifpack_1rank"] = run(1, None, "ILU(1) of the whole matrix, one thread (reference on 1 MPI rank)")
         finally:
             orc.set_num_threads(threads)
-    if "ifpack_1rank" not in variants:
-        path = os.path.join(ROOT, "profiles", "r02_cpu_ifpack_1rank.json")
-        if os.path.exists(path):
-            rec = json.load(open(path))
-            if rec.get("nrow") == n and rec.get("nnz") == int(rp[-1]):
-                variants["ifpack_1rank"] = dict(rec["ifpack_1rank"], measured="earlier run on this matrix: profiles/r02_cpu_ifpack_1rank.json")
     multi = {k: v for k, v in variants.items() if v["cores"] == threads and v["converged"]}
     best = min(multi, key=lambda k: multi[k]["seconds_per_solve"])
     out = dict(value=1.0 / multi[best]["seconds_per_solve"], unit="solves/s", cores=threads, kind="port",
@@ -133,6 +128,40 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False)
                seconds_per_solve=multi[best]["seconds_per_solve"], fastest=best)
     out.update(variants)
     return out
+
+
+def dropin_leg(A, b, repeat=5):
+    """The path `north_star` names, unchanged: the matrix as a HOST Epetra CSR handed to SolverLin_Belos::solveProblem
+    (pair_isph.cpp:924-926,988-1011 -> host/solver_lin_hip.h) with PrecondWrapper_Ifpack (fill 0, overlap 0, 512-row
+    subdomains = the headline preconditioner).  The C++ driver of the mirror classes (tests/cpp/test_solver_lin.cpp, mode
+    "timed") reads the exported system from a file, repeats setMatrix / solveProblem and reports the median wall time per
+    call split into ingress (host CSR -> device, PCIe inclusive) / preconditioner set-up / Krylov (+ b, x transfers)."""
+    import subprocess
+    import tempfile
+    from isph_amd import build
+    exe = build.build_cpp_test()
+    rp, ci, val = A.export_csr()
+    bh = b.cpu().numpy()
+    n = len(rp) - 1
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=base) as td_:
+        fin, fout = os.path.join(td_, "sys.bin"), os.path.join(td_, "x.bin")
+        with open(fin, "wb") as f:
+            np.array([n, len(val)], np.int32).tofile(f)
+            rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
+            val.tofile(f); bh.tofile(f)
+        r = subprocess.run([exe, fin, fout, "1", "timed", str(repeat)], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-400:]}
+        rec = None
+        for line in r.stdout.splitlines():
+            if line.startswith('{"dropin"'):
+                rec = json.loads(line)["dropin"]
+        if rec is None:
+            return {"error": "no record from the driver: " + r.stdout[-300:]}
+        xd = np.fromfile(fout)[:n]
+    rec["path"] = "SolverLin_Belos::solveProblem(PrecondWrapper_Ifpack) on a host CSR, C++ mirror, median of %d calls" % repeat
+    return rec, xd
 
 
 def self_launch(args):
@@ -365,14 +394,7 @@ def main():
                        "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms, "assemble_first_call_ms": assemble_first_ms,
-                       "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo,
-                       # the preconditioner BASELINE names is not the fastest on this operator; other --prec rows of this
-                       # workload, measured in round 2 on one MI355X, for the reader of this line
-                       "other_preconditioners_measured_r02": {
-                           "jacobi": "43 iterations, 14.8-15.2 ms/solve",
-                           "sa-amg (ML defaults)": "31 iterations, 55.8-58.3 ms/solve",
-                           "schwarz-ilu0 (512-row subdomains, overlap 1, level-scheduled)": "63 iterations, 3253 ms/solve",
-                           "ilu0 (whole local matrix = Ifpack on 1 rank, level-scheduled)": "49 iterations, 41077 ms/solve"}},
+                       "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo},
             "roofline": {"bound": "hbm", "kernel": "k_sell_spmv16<8,false> (SELL-64, 16-bit window columns)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -381,6 +403,18 @@ def main():
                          "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": spmv_calls},
         }
+        if world == 1 and not args.no_dropin and not args.force_rccl and args.prec == "bjacobi-ilu0" and args.block == 512:
+            # the unchanged SolverLin drop-in (host CSR in, host x out) beside the device-resident figure above
+            d = dropin_leg(A, b)
+            if isinstance(d, tuple):
+                rec, xd = d
+                xr = x.cpu().numpy()
+                rec["x_rel_diff_vs_device_resident"] = float(np.linalg.norm(xd - xr) / np.linalg.norm(xr))
+                rec["iterations_device_resident"] = inf.iters
+                rec["ratio_to_device_resident"] = rec["ms_per_solve"] / (elapsed / args.steps * 1e3)
+                out["dropin"] = rec
+            else:
+                out["dropin"] = d
         if world == 1 and not args.no_cpu_baseline and args.prec in ("none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg"):
             rp, ci, val = A.export_csr()
             cb = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, args.prec, args.amg_theta, args.cpu_ifpack_1rank)

@@ -3,6 +3,8 @@
 #include "common.hpp"
 #include "sell.hpp"
 
+namespace isph { struct HostStager; }  // ingress.hpp: pinned ring of the host CSR ingress
+
 struct isph_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -29,6 +31,7 @@ struct isph_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
   isph::DevBuf<double> xghost;
+  isph::HostStager *stager = nullptr;  // created by the first host-side isph_mat_create_csr
 };
 
 struct isph_halo {

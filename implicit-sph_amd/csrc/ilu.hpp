@@ -63,7 +63,7 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
                                                       const int *__restrict__ scol, const double *__restrict__ sval,
                                                       long long *__restrict__ frp, int *__restrict__ fcol,
                                                       double *__restrict__ fval, int *__restrict__ flen,
-                                                      int *__restrict__ fdiag, int *__restrict__ err) {
+                                                      int *__restrict__ fdiag, int *__restrict__ err, int b0) {
   __shared__ int wsum[16];
   extern __shared__ double ext_lds[];
   const int nwv = blockDim.x >> 6;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
   int (*stage_col)[64][kExtChunk] = reinterpret_cast<int (*)[64][kExtChunk]>(ext_lds + (size_t)nwv * 64 * (kExtChunk + 1));
   int (*stage_cnt)[64] = reinterpret_cast<int (*)[64]>(reinterpret_cast<int *>(ext_lds + (size_t)nwv * 64 * (kExtChunk + 1)) +
                                                        (size_t)nwv * 64 * kExtChunk);
-  const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n);
+  const int b = blockIdx.x + b0, blo = b * B, bhi = min(blo + B, n);  // b0: first block of a ranged launch
   const int t = threadIdx.x, i = blo + t;
   const bool active = i < bhi;
   const long long base = slice_off[(long long)b * (B / 64)];
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
                                                        int capf, int slack, int *__restrict__ err,
                                                        const double *__restrict__ sgs_fval,
-                                                       const double *__restrict__ sgs_dinv) {
+                                                       const double *__restrict__ sgs_dinv, int b0) {
   extern __shared__ int lds_i[];
   int *levL = lds_i;             // [B] level of every row in the L solve
   int *levU = levL + B;          // [B] ... in the U solve
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   // rows without a diagonal or with duplicate / unsorted columns (flagged by k_ilu_extract) would send the level
   // walk through uninitialised levels: leave the block alone, the host reports the error
   if (*err & (1 | 32)) return;
-  const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
+  const int b = blockIdx.x + b0, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   const int t = threadIdx.x;
   const bool active = t < m;
   const int i = blo + t;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
                                                            const int *__restrict__ fdiag, const int *__restrict__ fdst,
                                                            const int *__restrict__ llev, double *__restrict__ sv,
                                                            double *__restrict__ dinv, const long long *__restrict__ boff,
-                                                           int capf, int slack) {
+                                                           int capf, int slack, int b0, const int *__restrict__ err) {
   extern __shared__ double lds_f[];
   double *diag = lds_f;                                   // [B] 1/d_k of the finished rows
   double *wval = diag + B;                                // [WAVES][W]
@@ -644,9 +644,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
   unsigned short *order = reinterpret_cast<unsigned short *>(levs + B);  // [B] rows sorted by (level,row)
   unsigned short *pos = order + B;                        // [WAVES][B] slot+1 of a column in the current row
   __shared__ int s_nlev;
-  const int blo = blockIdx.x * B, bhi = min(blo + B, n), m = bhi - blo;
+  // a ranged launch (host CSR ingress, ingress.hpp) queues this kernel before the host has seen the schedule's error
+  // word: a failed extraction or an overflowed stream leaves the blocks alone and the host redoes the set-up
+  if (err != nullptr && (*err & (1 | 16 | 32))) return;
+  const int bid = blockIdx.x + b0;
+  const int blo = bid * B, bhi = min(blo + B, n), m = bhi - blo;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double *svb = sv + ilu_base_chunk(boff, blockIdx.x, capf, slack) * 64;  // this block's part of the solve stream
+  double *svb = sv + ilu_base_chunk(boff, bid, capf, slack) * 64;  // this block's part of the solve stream
   if (threadIdx.x == 0) s_nlev = 0;
   for (int t = threadIdx.x; t <= B; t += blockDim.x) lcnt[t] = 0;
   for (int t = threadIdx.x; t < WAVES * B; t += blockDim.x) pos[t] = 0;
@@ -989,8 +993,19 @@ inline int ilu_symbolic(isph_ctx *ctx, isph_ilu *F, int K) {
   return rc;
 }
 
-inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false, int fill = 0) {
-  const Sell &S = A->S;
+// ---- set-up in pieces: allocations that only need the matrix' SHAPE (ilu_begin), then extract / schedule / factor over
+// ranges of blocks.  ilu_create runs them over all blocks with the host check between schedule and factorisation; the
+// host CSR ingress (ingress.hpp) queues them range by range behind the rows that have arrived over PCIe.
+inline int ilu_size_stream(isph_ilu *F) {
+  F->stream_chunks = F->capf * (F->total >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
+  int r = F->sv.reserve((size_t)F->stream_chunks * 64);
+  if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
+  if (r == ISPH_SUCCESS) r = F->si.reserve((size_t)F->stream_chunks + 64);
+  return r;
+}
+
+// needs S.nrow, S.stored, S.wmax, S.nslices and S.slice_off on the device (stream-ordered); not S.col / S.val
+inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int fill, isph_ilu **out) {
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
                "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && !(sgs && fill), "level of fill must be in [0,8]");
@@ -1000,13 +1015,6 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   F->total = S.stored;
   const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
   F->capf = kCapFactor; F->slack = 2 * block_size;
-  auto size_stream = [&]() {
-    F->stream_chunks = F->capf * (F->total >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
-    int r = F->sv.reserve((size_t)F->stream_chunks * 64);
-    if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
-    if (r == ISPH_SUCCESS) r = F->si.reserve((size_t)F->stream_chunks + 64);
-    return r;
-  };
   int rc = F->fcol.reserve(stored);
   if (rc == ISPH_SUCCESS) rc = F->fval.reserve(stored);
   if (rc == ISPH_SUCCESS) rc = F->frp.reserve(n1);
@@ -1018,75 +1026,114 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
   if (rc == ISPH_SUCCESS) rc = F->boff.reserve((size_t)F->nblocks + 1);
   if (rc == ISPH_SUCCESS) rc = F->blkinfo.reserve((size_t)4 * (F->nblocks > 0 ? F->nblocks : 1));
   if (rc == ISPH_SUCCESS) rc = F->sperm.reserve((size_t)2 * block_size * (F->nblocks > 0 ? F->nblocks : 1));
+  if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
+    rc = fail("memset failed", __FILE__, __LINE__);
   if (rc == ISPH_SUCCESS && S.nrow > 0) {
-    const size_t Bz = (size_t)block_size;
+    const size_t lds_e = (size_t)(block_size / 64) * 64 * ((kExtChunk + 1) * 8 + (kExtChunk + 1) * 4);
+    const size_t lds_s = sizeof(int) * (14 * (size_t)block_size + 10) + sizeof(long long) * (size_t)block_size;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_e) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_s) != hipSuccess)
+      rc = fail("LDS attribute failed", __FILE__, __LINE__);
+  }
+  if (rc != ISPH_SUCCESS) { ilu_destroy(F); return rc; }
+  *out = F;
+  return ISPH_SUCCESS;
+}
+
+// ILU(0) only: block regions = the sliced-ELL regions of the blocks' rows, the stream sized from them
+inline int ilu_begin_fill0(isph_ctx *ctx, isph_ilu *F, const Sell &S) {
+  if (S.nrow == 0) return ISPH_SUCCESS;
+  hipLaunchKernelGGL(k_ilu_boff0, dim3((F->nblocks + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, F->nblocks,
+                     F->B, S.nslices, (const long long *)S.slice_off.p, F->boff.p);
+  ISPH_CHECK(F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1)));
+  return ilu_size_stream(F);
+}
+
+// st: the stream of a ranged launch (ingress.hpp runs consecutive ranges on alternating streams); default ctx->stream
+inline void ilu_launch_extract(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, hipStream_t st = nullptr) {
+  const size_t lds_e = (size_t)(F->B / 64) * 64 * ((kExtChunk + 1) * 8 + (kExtChunk + 1) * 4);
+  hipLaunchKernelGGL(k_ilu_extract, dim3(nb), dim3(F->B), lds_e, st ? st : ctx->stream, S.nrow, F->B, (const int *)S.rowlen.p,
+                     (const long long *)S.slice_off.p, (const int *)S.col.p, (const double *)S.val.p, F->frp.p, F->fcol.p,
+                     F->fval.p, F->flen.p, F->fdiag.p, F->err.p, b0);
+}
+
+inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, bool sgs, hipStream_t st = nullptr) {
+  const size_t Bz = (size_t)F->B;
+  const size_t lds_s = sizeof(int) * (14 * Bz + 10) + sizeof(long long) * Bz;
+  hipLaunchKernelGGL(k_ilu_schedule, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->boff.p, F->frp.p, F->fcol.p,
+                     F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p, F->blkinfo.p, F->llev.p, F->capf,
+                     F->slack, F->err.p, sgs ? (const double *)F->fval.p : (const double *)nullptr,
+                     sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0);
+}
+
+// err_dev != nullptr: the kernel itself skips its blocks when the set-up so far has raised an error (ranged launches)
+inline int ilu_launch_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, const int *err_dev, hipStream_t st_in = nullptr) {
+  hipStream_t st = st_in ? st_in : ctx->stream;
+  const size_t Bz = (size_t)F->B;
+  const int W = ((F->wmax + 63) / 64) * 64;
+  const size_t lds_f = 8 * Bz + (size_t)kIluWaves * W * 12 + 8 * Bz + 4 * (5 * Bz + 4) + 2 * Bz + 2 * (size_t)kIluWaves * Bz + 16;
+  ISPH_REQUIRE(lds_f <= 160 * 1024, "ILU factor kernel needs too much LDS for this row width");
+  const bool wide = F->wmax > 128;  // rows this long have U parts beyond one wave
+  const void *fk = wide ? reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, true>)
+                        : reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, false>);
+  ISPH_CHECK_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+  if (wide)
+    hipLaunchKernelGGL((k_ilu_factor<kIluWaves, true>), dim3(nb), dim3(kIluWaves * 64), lds_f, st, S.nrow, F->B, W,
+                       F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->boff.p,
+                       F->capf, F->slack, b0, err_dev);
+  else
+    hipLaunchKernelGGL((k_ilu_factor<kIluWaves, false>), dim3(nb), dim3(kIluWaves * 64), lds_f, st, S.nrow, F->B, W,
+                       F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->boff.p,
+                       F->capf, F->slack, b0, err_dev);
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+// schedule (all blocks) with the host check and the one retry at the proven stream capacity, then the factorisation
+// (or, for the Gauss-Seidel stream, nothing more).  Expects the extraction (and the symbolic phase) queued.
+inline int ilu_schedule_and_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, bool sgs) {
+  int rc = ISPH_SUCCESS;
+  if (sgs)  // pivots first: the schedule writes the Gauss-Seidel stream values itself
+    hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
+                       F->fval.p, F->fdiag.p, F->dinv.p);
+  for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
+    ilu_launch_schedule(ctx, F, S, 0, F->nblocks, sgs);
+    // the factor kernel must not run on a partial schedule: check now (one sync per build)
+    bool overflow = false;
+    rc = ilu_check_err(ctx, F, "ILU extract/schedule kernel failed", attempt == 0 ? &overflow : nullptr);
+    if (!overflow) break;
+    F->capf = kCapFactorSafe; F->slack = 2 * F->B;  // proven bound, see kCapFactorSafe
+    rc = ilu_size_stream(F);
     if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
       rc = fail("memset failed", __FILE__, __LINE__);
-    if (rc == ISPH_SUCCESS) {
-      const size_t lds_e = (size_t)(block_size / 64) * 64 * ((kExtChunk + 1) * 8 + (kExtChunk + 1) * 4);
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_e) != hipSuccess)
-        rc = fail("LDS attribute failed", __FILE__, __LINE__);
-      hipLaunchKernelGGL(k_ilu_extract, dim3(F->nblocks), dim3(block_size), lds_e, ctx->stream, S.nrow, block_size,
-                         S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, F->frp.p, F->fcol.p, F->fval.p, F->flen.p,
-                         F->fdiag.p, F->err.p);
-    }
-    if (rc == ISPH_SUCCESS && fill > 0) {
+  }
+  if (rc == ISPH_SUCCESS && sgs) {
+    // nothing left to do: k_ilu_schedule filled the stream; the row-major copy is not read again (no export of a
+    // smoother) and is 16 B per stored entry -- 48 GB on the 4 M x 749 operator of BASELINE configs[4]
+    F->fcol.release(); F->fval.release(); F->fdst.release();
+  } else if (rc == ISPH_SUCCESS) {
+    rc = ilu_launch_factor(ctx, F, S, 0, F->nblocks, nullptr);
+  }
+  return rc;
+}
+
+inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false, int fill = 0) {
+  const Sell &S = A->S;
+  isph_ilu *F = nullptr;
+  ISPH_CHECK(ilu_begin(ctx, S, block_size, sgs, fill, &F));
+  int rc = ISPH_SUCCESS;
+  if (S.nrow > 0) {
+    ilu_launch_extract(ctx, F, S, 0, F->nblocks);
+    if (fill > 0) {
       rc = ilu_symbolic(ctx, F, fill);
-    } else if (rc == ISPH_SUCCESS) {
-      hipLaunchKernelGGL(k_ilu_boff0, dim3((F->nblocks + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, F->nblocks,
-                         block_size, S.nslices, S.slice_off.p, F->boff.p);
+      if (rc == ISPH_SUCCESS) rc = F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1));
+      if (rc == ISPH_SUCCESS) rc = ilu_size_stream(F);
+    } else {
+      rc = ilu_begin_fill0(ctx, F, S);
     }
-    if (rc == ISPH_SUCCESS) rc = F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1));
-    if (rc == ISPH_SUCCESS) rc = size_stream();
-    const int W = ((F->wmax + 63) / 64) * 64;
-    const size_t lds_f = 8 * Bz + (size_t)kIluWaves * W * 12 + 8 * Bz + 4 * (5 * Bz + 4) + 2 * Bz + 2 * (size_t)kIluWaves * Bz + 16;
-    if (rc == ISPH_SUCCESS && !sgs && lds_f > 160 * 1024)
-      rc = fail("ILU factor kernel needs too much LDS for this row width", __FILE__, __LINE__);
-    if (rc == ISPH_SUCCESS) {
-      if (sgs)  // pivots first: the schedule writes the Gauss-Seidel stream values itself
-        hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
-                           F->fval.p, F->fdiag.p, F->dinv.p);
-      const size_t lds_s = sizeof(int) * (14 * Bz + 10) + sizeof(long long) * Bz;
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_s) != hipSuccess)
-        rc = fail("LDS attribute failed", __FILE__, __LINE__);
-      for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
-        hipLaunchKernelGGL(k_ilu_schedule, dim3(F->nblocks), dim3(block_size), lds_s, ctx->stream, S.nrow, block_size,
-                           F->boff.p, F->frp.p, F->fcol.p, F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p,
-                           F->blkinfo.p, F->llev.p, F->capf, F->slack, F->err.p,
-                           sgs ? (const double *)F->fval.p : (const double *)nullptr,
-                           sgs ? (const double *)F->dinv.p : (const double *)nullptr);
-        // the factor kernel must not run on a partial schedule: check now (one sync per build)
-        bool overflow = false;
-        rc = ilu_check_err(ctx, F, "ILU extract/schedule kernel failed", attempt == 0 ? &overflow : nullptr);
-        if (!overflow) break;
-        F->capf = kCapFactorSafe; F->slack = 2 * block_size;  // proven bound, see kCapFactorSafe
-        rc = size_stream();
-        if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
-          rc = fail("memset failed", __FILE__, __LINE__);
-      }
-    }
-    if (rc == ISPH_SUCCESS && sgs) {
-      // nothing left to do: k_ilu_schedule filled the stream; the row-major copy is not read again (no export of a
-      // smoother) and is 16 B per stored entry -- 48 GB on the 4 M x 749 operator of BASELINE configs[4]
-      F->fcol.release(); F->fval.release(); F->fdst.release();
-    } else if (rc == ISPH_SUCCESS) {
-      const bool wide = F->wmax > 128;  // rows this long have U parts beyond one wave
-      const void *fk = wide ? reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, true>)
-                            : reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, false>);
-      if (hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f) != hipSuccess)
-        rc = fail("LDS attribute failed", __FILE__, __LINE__);
-      else if (wide)
-        hipLaunchKernelGGL((k_ilu_factor<kIluWaves, true>), dim3(F->nblocks), dim3(kIluWaves * 64), lds_f, ctx->stream, S.nrow,
-                           block_size, W, F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p,
-                           F->sv.p, F->dinv.p, F->boff.p, F->capf, F->slack);
-      else
-        hipLaunchKernelGGL((k_ilu_factor<kIluWaves, false>), dim3(F->nblocks), dim3(kIluWaves * 64), lds_f, ctx->stream, S.nrow,
-                           block_size, W, F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p,
-                           F->sv.p, F->dinv.p, F->boff.p, F->capf, F->slack);
-      if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("ILU factor launch failed", __FILE__, __LINE__);
-    }
+    if (rc == ISPH_SUCCESS) rc = ilu_schedule_and_factor(ctx, F, S, sgs);
   }
   if (rc != ISPH_SUCCESS) { ilu_destroy(F); return rc; }
   *out = F;

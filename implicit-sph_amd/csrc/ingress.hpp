@@ -1,0 +1,377 @@
+// ingress.hpp -- host CSR (the three arrays of Epetra_CrsMatrix::ExtractCrsDataPointers, pageable memory owned by the
+// caller) -> sliced-ELL on the device, as a pipeline.  This is the drop-in path of SolverLin_HIP::solveProblem
+// (ref: solver_lin_belos.h:130-222 receives the matrix PairISPH filled on the host, pair_isph.cpp:924-926,988-1011):
+// everything here is inside what the reference times as "ISPH: solvePoisson", so the 12 B per stored entry have to
+// cross PCIe at the link's rate and nothing else may be on the critical path.
+//
+//   worker threads : pageable -> pinned ring slot (memcpy; the column range check rides along in the same pass)
+//   main thread    : slot -> device CSR image (hipMemcpyAsync on a copy stream), event per slot;
+//                    compute stream waits on the event and converts the slices whose rows have fully arrived
+//                    (k_csr_to_sell over a slice range), so only the last chunk's conversion is exposed;
+//   hooks          : work that only needs the rows that are already there is queued behind the conversion --
+//                    the 16-bit column windows of the SpMV and the block-Jacobi ILU(0) set-up (extract, schedule,
+//                    factorisation per range of 512-row blocks) run while the rest of the matrix is still on the link
+//                    (csr_ingress_host_bjacobi = isph_mat_create_csr_bjacobi).
+//
+// Slice widths/offsets come from the host row pointers (no device round trip); rows that are already column-sorted
+// (Epetra's OptimizeStorage order) are detected on the device while they are converted and skip the row sort.
+// Measured on the MI355X box (scripts/pcie_probe.hip, profiles/r03_pcie_probe.txt): pinned H2D 57.6 GB/s with >= 12 MiB
+// per copy (41 GB/s with 4 MiB copies), one memcpy thread moves 34 GB/s pageable -> pinned.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <thread>
+
+#include "core.hpp"
+#include "ilu.hpp"
+
+namespace isph {
+
+struct HostStager {
+  static constexpr size_t kChunk = (size_t)4 << 20;  // entries per ring slot: 16 MiB of columns + 32 MiB of values
+  int nslots = 0, nthreads = 0;
+  int *pcol = nullptr;      // pinned [nslots][kChunk]
+  double *pval = nullptr;   // pinned [nslots][kChunk]
+  hipStream_t copy_stream = nullptr;
+  static constexpr int kAux = 2;
+  hipStream_t aux[kAux] = {nullptr, nullptr};  // set-up batches of the fused path, round robin
+  hipEvent_t ev_conv = nullptr, ev_aux[kAux] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ev;  // per slot: its last H2D pair has completed
+  DevBuf<int> flag;            // [0] some row was not column-sorted, [1] a slice has more than 64 column windows
+  // wall-clock milestones of the last ingress in ms since its start (isph_ingress_info): [0] workers started and device
+  // buffers reserved, [1] all chunks queued on the copy stream, [2] copy stream drained, [3] compute stream drained
+  // (conversion + hooks), [4] end (incl. row sort), [5] of which the main thread waited for staged chunks, [6] chunks, [7] threads
+  double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ~HostStager() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    for (int k = 0; k < kAux; ++k) {
+      if (aux[k]) (void)hipStreamDestroy(aux[k]);
+      if (ev_aux[k]) (void)hipEventDestroy(ev_aux[k]);
+    }
+    if (ev_conv) (void)hipEventDestroy(ev_conv);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (pcol) (void)hipHostFree(pcol);
+    if (pval) (void)hipHostFree(pval);
+    flag.release();
+  }
+};
+
+inline int stager_get(isph_ctx *ctx, HostStager **out) {
+  if (!ctx->stager) {
+    HostStager *S = new HostStager();
+    const unsigned hc = std::thread::hardware_concurrency();
+    S->nthreads = (int)std::min(4u, std::max(1u, hc / 2));  // 4 x 34 GB/s against a 57.6 GB/s link
+    S->nslots = S->nthreads + 2;
+    bool ok = hipHostMalloc((void **)&S->pcol, sizeof(int) * HostStager::kChunk * (size_t)S->nslots, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void **)&S->pval, sizeof(double) * HostStager::kChunk * (size_t)S->nslots, hipHostMallocDefault) == hipSuccess &&
+              hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int s = 0; ok && s < S->nslots; ++s) {
+      hipEvent_t e = nullptr;
+      ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+      if (ok) S->ev.push_back(e);
+    }
+    for (int k = 0; ok && k < HostStager::kAux; ++k)
+      ok = hipStreamCreateWithFlags(&S->aux[k], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&S->ev_aux[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&S->ev_conv, hipEventDisableTiming) == hipSuccess;
+    ok = ok && S->flag.reserve(2) == ISPH_SUCCESS;
+    if (!ok) { delete S; return fail("pinned staging ring for the host CSR ingress could not be created", __FILE__, __LINE__); }
+    ctx->stager = S;
+  }
+  *out = ctx->stager;
+  return ISPH_SUCCESS;
+}
+
+int sell_sort_rows(isph_ctx *ctx, Sell &S);  // isph_capi.hip
+
+struct IngressHooks {
+  // the matrix has its shape, its buffers and (stream-ordered) its slice offsets and row lengths; no entries yet
+  std::function<int(isph_mat *)> begin;
+  // the conversion of slices [s0, s1) has been queued on the stream; s1 == nslices on the last call
+  std::function<int(isph_mat *, int, int)> slices;
+};
+
+// host CSR -> isph_mat.  The caller's arrays are only read while this function runs.  was_unsorted: the rows had to be
+// column-sorted after the conversion (what the hooks queued for the unsorted image is then void).
+inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
+                            isph_mat **Aout, const IngressHooks *hooks = nullptr, bool *was_unsorted = nullptr) {
+  ISPH_REQUIRE(!is_device_pointer(rowptr) && !is_device_pointer(colidx) && !is_device_pointer(val),
+               "device pointer passed with on_device = 0");
+  ISPH_REQUIRE(rowptr[0] >= 0 && rowptr[nrow] >= rowptr[0], "rowptr not monotone");
+  const long long nnz = rowptr[nrow];
+  HostStager *H = nullptr;
+  ISPH_CHECK(stager_get(ctx, &H));
+  const std::chrono::steady_clock::time_point t_start = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+  double wait_fill = 0.0;
+
+  // ---- the workers start on the caller's arrays at once; everything below overlaps with their first chunks
+  // chunk sizes ramp up (1/8, 1/4, 1/2 of a slot, then whole slots): the link starts after 0.2 ms of staging instead of 1.4
+  std::vector<long long> cstart(1, 0);
+  for (long long sz = (long long)HostStager::kChunk / 8; cstart.back() < nnz; sz = std::min<long long>(2 * sz, (long long)HostStager::kChunk))
+    cstart.push_back(std::min(nnz, cstart.back() + sz));
+  const long long nchunks = (long long)cstart.size() - 1;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<char> filled((size_t)nchunks, 0), recorded((size_t)nchunks, 0);
+  std::atomic<long long> next(0);
+  std::atomic<int> bad_col(0), hip_err(0);
+  auto worker = [&]() {
+    (void)hipSetDevice(ctx->device);
+    for (;;) {
+      const long long c = next.fetch_add(1);
+      if (c >= nchunks) break;
+      const int slot = (int)(c % H->nslots);
+      if (c >= H->nslots) {  // the slot's previous chunk must have left it
+        char state = 0;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return recorded[(size_t)(c - H->nslots)] != 0; });
+          state = recorded[(size_t)(c - H->nslots)];
+        }
+        if (state == 1 && hipEventSynchronize(H->ev[(size_t)slot]) != hipSuccess) hip_err.store(1);
+      }
+      const long long p0 = cstart[(size_t)c];
+      const size_t cnt = (size_t)(cstart[(size_t)c + 1] - p0);
+      int *dc = H->pcol + (size_t)slot * HostStager::kChunk;
+      const int *sc = colidx + p0;
+      unsigned over = 0;
+      for (size_t k = 0; k < cnt; ++k) {  // copy + range check in one pass
+        const int cc = sc[k];
+        over |= (unsigned)((unsigned)cc >= (unsigned)ncol);
+        dc[k] = cc;
+      }
+      if (over) bad_col.store(1);
+      memcpy(H->pval + (size_t)slot * HostStager::kChunk, val + p0, sizeof(double) * cnt);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        filled[(size_t)c] = 1;
+      }
+      cv.notify_all();
+    }
+  };
+  struct Pool {  // joins on every exit path; the workers always run to the end of the chunk list
+    std::vector<std::thread> th;
+    std::mutex &mu;
+    std::condition_variable &cv;
+    std::vector<char> &recorded;
+    ~Pool() {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        for (char &r : recorded) if (r == 0) r = 2;  // nothing will be recorded any more: do not wait for it
+      }
+      cv.notify_all();
+      for (std::thread &t : th) t.join();
+    }
+  } pool{{}, mu, cv, recorded};
+  const int nthreads = (int)std::min<long long>(H->nthreads, nchunks);
+  for (int t = 0; t < nthreads; ++t) pool.th.emplace_back(worker);
+
+  struct Guard {  // every early return gives the matrix and the device CSR image back
+    isph_mat *A = nullptr;
+    DevBuf<int> drp, dci;
+    DevBuf<double> dv;
+    hipStream_t copy_stream = nullptr;
+    ~Guard() {
+      (void)hipStreamSynchronize(copy_stream);  // no copy may still read the ring when the next call refills it
+      drp.release(); dci.release(); dv.release();
+      if (A) isph_mat_destroy(A);
+    }
+  } g;
+  g.copy_stream = H->copy_stream;
+  g.A = new isph_mat();
+  Sell &S = g.A->S;
+  S.nrow = nrow; S.ncol = ncol; S.nnz = nnz;
+  S.nslices = (nrow + kSlice - 1) / kSlice;
+
+  // slice offsets and the widest slice from the host row pointers (and their monotonicity on the way)
+  std::vector<long long> so((size_t)S.nslices + 1, 0);
+  int wmax = 0, wmin = 0;
+  for (int s = 0; s < S.nslices; ++s) {
+    int w = 0;
+    const int r1 = std::min(nrow, (s + 1) * kSlice);
+    for (int r = s * kSlice; r < r1; ++r) {
+      const int len = rowptr[r + 1] - rowptr[r];
+      w = std::max(w, len);
+      wmin = std::min(wmin, len);
+    }
+    w = (w + 1) & ~1;
+    wmax = std::max(wmax, w);
+    so[(size_t)s + 1] = so[(size_t)s] + (long long)w * kSlice;
+  }
+  ISPH_REQUIRE(wmin >= 0, "rowptr not monotone");
+  S.stored = so[(size_t)S.nslices];
+  S.wmax = wmax;
+  ISPH_CHECK(S.slice_off.reserve((size_t)S.nslices + 1));
+  ISPH_CHECK(S.rowlen.reserve((size_t)(nrow > 0 ? nrow : 1)));
+  ISPH_CHECK(S.col.reserve((size_t)(S.stored > 0 ? S.stored : 1)));
+  ISPH_CHECK(S.val.reserve((size_t)(S.stored > 0 ? S.stored : 1)));
+  ISPH_CHECK(g.drp.reserve((size_t)nrow + 1));
+  ISPH_CHECK(g.dci.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  ISPH_CHECK(g.dv.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  // small operands (synchronous copies of pageable memory: 4 MB + 125 kB at 1 M rows)
+  ISPH_CHECK_HIP(hipMemcpyAsync(g.drp.p, rowptr, sizeof(int) * ((size_t)nrow + 1), hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(S.slice_off.p, so.data(), sizeof(long long) * so.size(), hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK_HIP(hipMemsetAsync(H->flag.p, 0, 2 * sizeof(int), ctx->stream));
+  if (nrow > 0)
+    hipLaunchKernelGGL(k_csr_rowlen, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, (const int *)g.drp.p, S.rowlen.p);
+  if (hooks && hooks->begin) ISPH_CHECK(hooks->begin(g.A));
+  H->stats[0] = since();
+
+  int rc = ISPH_SUCCESS;
+  int slices_done = 0;
+  auto convert_upto = [&](long long entries_arrived) {
+    // slices whose 64 rows end at or before the last uploaded entry
+    int lo = slices_done, hi = S.nslices;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) / 2;
+      if ((long long)rowptr[std::min(nrow, mid * kSlice)] <= entries_arrived) lo = mid; else hi = mid - 1;
+    }
+    if (lo > slices_done) {
+      const int cnt = lo - slices_done;
+      hipLaunchKernelGGL(k_csr_to_sell<int>, dim3((cnt + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, (const int *)g.drp.p,
+                         (const int *)g.dci.p, (const double *)g.dv.p, (const long long *)S.slice_off.p, S.col.p, S.val.p,
+                         slices_done, lo, H->flag.p);
+      const int s0 = slices_done;
+      slices_done = lo;
+      if (hooks && hooks->slices && rc == ISPH_SUCCESS) rc = hooks->slices(g.A, s0, lo);
+    }
+  };
+  for (long long c = 0; c < nchunks; ++c) {
+    {
+      const double w0 = since();
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return filled[(size_t)c] != 0; });
+      wait_fill += since() - w0;
+    }
+    const int slot = (int)(c % H->nslots);
+    const long long p0 = cstart[(size_t)c];
+    const size_t cnt = (size_t)(cstart[(size_t)c + 1] - p0);
+    char state = 1;  // 1: event recorded, 2: nothing to wait for (a HIP call failed; workers must not block on the event)
+    if (rc == ISPH_SUCCESS) {
+      if (hipMemcpyAsync(g.dci.p + p0, H->pcol + (size_t)slot * HostStager::kChunk, sizeof(int) * cnt, hipMemcpyHostToDevice, H->copy_stream) != hipSuccess ||
+          hipMemcpyAsync(g.dv.p + p0, H->pval + (size_t)slot * HostStager::kChunk, sizeof(double) * cnt, hipMemcpyHostToDevice, H->copy_stream) != hipSuccess ||
+          hipEventRecord(H->ev[(size_t)slot], H->copy_stream) != hipSuccess ||
+          hipStreamWaitEvent(ctx->stream, H->ev[(size_t)slot], 0) != hipSuccess)
+        rc = fail("upload of a CSR chunk failed", __FILE__, __LINE__);
+      else
+        convert_upto(p0 + (long long)cnt);
+    }
+    if (rc != ISPH_SUCCESS) state = 2;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      recorded[(size_t)c] = state;
+    }
+    cv.notify_all();
+  }
+  if (rc == ISPH_SUCCESS) convert_upto(nnz);  // rows without entries at the end, or nnz == 0
+  if (rc == ISPH_SUCCESS && slices_done < S.nslices) rc = fail("row pointers and entry count disagree", __FILE__, __LINE__);
+  // the ring is reused by the next call and the caller may free its arrays: wait for the copies; the flags travel back
+  // behind everything queued so far (conversion and hooks), which is the one synchronisation of the ingress
+  int flags[2] = {0, 0};
+  H->stats[1] = since();
+  const bool copies_ok = hipStreamSynchronize(H->copy_stream) == hipSuccess;
+  H->stats[2] = since();
+  if (!copies_ok ||
+      hipMemcpyAsync(flags, H->flag.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess || hip_err.load())
+    if (rc == ISPH_SUCCESS) rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);
+  H->stats[3] = since();
+  ISPH_CHECK(rc);
+  ISPH_REQUIRE(!bad_col.load(), "column index out of range");
+  if (flags[0]) {
+    ISPH_CHECK(sell_sort_rows(ctx, S));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (was_unsorted) *was_unsorted = flags[0] != 0;
+  if (S.col16.p != nullptr) {  // a hook built the 16-bit columns slice by slice
+    S.c16_state = flags[1] ? -1 : flags[0] ? 0 : 1;  // unsorted rows were permuted afterwards: rebuilt on first use
+    if (S.c16_state != 1) { S.col16.release(); S.wtab.release(); }
+  }
+  ISPH_CHECK_HIP(hipGetLastError());
+  H->stats[4] = since(); H->stats[5] = wait_fill; H->stats[6] = (double)nchunks; H->stats[7] = (double)nthreads;
+  *Aout = g.A;
+  g.A = nullptr;
+  return ISPH_SUCCESS;
+}
+
+// Host CSR ingress fused with the set-up of the block-Jacobi ILU(0) preconditioner (block_size rows per subdomain):
+// the 16-bit column windows and the ILU extraction / schedule / factorisation of a range of blocks are queued as soon
+// as the range's rows have been converted, in batches of 1/kBatchDiv of the blocks on two alternating side streams (a
+// factorisation launch lives ~2 ms whatever its size -- the per-block dependency chain -- while a twelfth of the 100^3
+// matrix takes 1.9 ms on the link: on one stream the batches queue up behind each other).  Measured at 100^3
+// (profiles/r03_dropin.txt): copies done after 24.3 ms, set-up done 3.1 ms later for every batch size from 1/8 to 1/24;
+// with more side streams than hardware queues (HIP maps its streams onto 4) the copy stream ends up sharing a queue with
+// a 2 ms factorisation kernel and the link idles: 32-38 ms.
+constexpr int kBatchDiv = 12;
+inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
+                                    int block_size, isph_mat **Aout, isph_ilu **Fout) {
+  ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
+               "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
+  HostStager *H = nullptr;
+  ISPH_CHECK(stager_get(ctx, &H));
+  isph_ilu *F = nullptr;
+  int blocks_done = 0, nbatch = 0;
+  const int spb = block_size / 64;
+  IngressHooks hooks;
+  hooks.begin = [&](isph_mat *A) -> int {
+    const Sell &S = A->S;
+    if (S.nrow == 0) return ISPH_SUCCESS;
+    ISPH_CHECK(S.col16.reserve((size_t)(S.stored > 0 ? S.stored : 1)));
+    ISPH_CHECK(S.wtab.reserve((size_t)S.nslices * 64));
+    ISPH_CHECK(ilu_begin(ctx, S, block_size, false, 0, &F));
+    return ilu_begin_fill0(ctx, F, S);
+  };
+  hooks.slices = [&](isph_mat *A, int s0, int s1) -> int {
+    const Sell &S = A->S;
+    hipLaunchKernelGGL(k_sell_compress_cols, dim3((s1 - s0 + 3) / 4), dim3(kBlock), 0, ctx->stream, s0, s1,
+                       (const long long *)S.slice_off.p, (const int *)S.col.p, S.col16.p, S.wtab.p, H->flag.p + 1);
+    const int ready = s1 == S.nslices ? F->nblocks : s1 / spb;
+    const int batch = std::max(1, F->nblocks / kBatchDiv);
+    if (ready > blocks_done && (ready - blocks_done >= batch || s1 == S.nslices)) {
+      // consecutive batches run on alternating side streams behind the conversion of their rows, so their
+      // dependency-chain latencies overlap each other and the link
+      const int nb = ready - blocks_done;
+      hipStream_t st = H->aux[nbatch % HostStager::kAux];
+      ISPH_CHECK_HIP(hipEventRecord(H->ev_conv, ctx->stream));
+      ISPH_CHECK_HIP(hipStreamWaitEvent(st, H->ev_conv, 0));
+      ilu_launch_extract(ctx, F, S, blocks_done, nb, st);
+      ilu_launch_schedule(ctx, F, S, blocks_done, nb, false, st);
+      ISPH_CHECK(ilu_launch_factor(ctx, F, S, blocks_done, nb, F->err.p, st));
+      blocks_done = ready;
+      ++nbatch;
+    }
+    if (s1 == S.nslices)  // the main stream (flags, the caller's next work) continues behind every batch
+      for (int k = 0; k < HostStager::kAux; ++k) {
+        ISPH_CHECK_HIP(hipEventRecord(H->ev_aux[k], H->aux[k]));
+        ISPH_CHECK_HIP(hipStreamWaitEvent(ctx->stream, H->ev_aux[k], 0));
+      }
+    return ISPH_SUCCESS;
+  };
+  isph_mat *A = nullptr;
+  bool unsorted = false;
+  int rc = csr_ingress_host(ctx, nrow, ncol, rowptr, colidx, val, &A, &hooks, &unsorted);
+  bool redo = unsorted;
+  if (rc == ISPH_SUCCESS && F && !unsorted && nrow > 0) {
+    bool overflow = false;
+    rc = ilu_check_err(ctx, F, "ILU set-up during the matrix ingress failed", &overflow);
+    redo = overflow;
+  }
+  if (rc == ISPH_SUCCESS && (redo || !F)) {  // sorted now / stream at its proven capacity: the plain set-up
+    if (F) ilu_destroy(F);
+    F = nullptr;
+    rc = ilu_create(ctx, A, block_size, &F, false, 0);
+  }
+  if (rc != ISPH_SUCCESS) {
+    if (F) ilu_destroy(F);
+    if (A) isph_mat_destroy(A);
+    return rc;
+  }
+  *Aout = A;
+  *Fout = F;
+  return ISPH_SUCCESS;
+}
+
+}  // namespace isph

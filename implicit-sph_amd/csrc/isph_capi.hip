@@ -14,6 +14,7 @@
 #include "amg.hpp"
 #include "schwarz.hpp"
 #include "gcrodr.hpp"
+#include "ingress.hpp"
 
 namespace isph {
 thread_local std::string g_last_error;
@@ -210,7 +211,8 @@ static int ctx_create_common(int device, void *stream, isph_ctx **out) {
   ISPH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
   ISPH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming));
   ISPH_CHECK_HIP(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
-  ISPH_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  // the halo stream only exists on contexts with a communicator: HIP multiplexes its streams onto a handful of hardware
+  // queues, and an idle extra stream costs the host ingress (ingress.hpp) a queue of its own
   ISPH_CHECK(ensure_scalars(c));
   *out = c;
   return ISPH_SUCCESS;
@@ -237,6 +239,7 @@ int isph_ctx_create_dist(int device, void *stream, int rank, int nranks, const c
   c->nranks = nranks;
   ncclUniqueId id;
   memcpy(&id, uid, sizeof(id));
+  ISPH_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   ISPH_CHECK_NCCL(ncclCommInitRank(&c->comm, nranks, id, rank));
   return ISPH_SUCCESS;
 }
@@ -282,6 +285,7 @@ void isph_ctx_destroy(isph_ctx *c) {
   c->rv.release(); c->pv.release(); c->nvec.release(); c->xext.release(); c->sendbuf.release();
   c->bdev.release(); c->xdev.release(); c->imask.release();
   if (c->hscal) (void)hipHostFree(c->hscal);
+  delete c->stager;
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
   DevPool::get().trim();  // cached device blocks go back to the driver with the context
@@ -307,7 +311,7 @@ static int mat_from_device_csr_t(isph_ctx *ctx, int nrow, int ncol, const OFF *d
     rc = sell_finalize_offsets(ctx, S);
     if (rc == ISPH_SUCCESS) {
       hipLaunchKernelGGL(k_csr_to_sell<OFF>, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
-                         S.slice_off.p, S.col.p, S.val.p);
+                         (const long long *)S.slice_off.p, S.col.p, S.val.p, 0, S.nslices, (int *)nullptr);
       rc = rows_sorted ? sell_set_wmax(ctx, S) : sell_sort_rows(ctx, S);
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);
@@ -332,30 +336,35 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, co
                         const double *val, int on_device, isph_mat **Aout) {
   ISPH_REQUIRE(ctx && Aout && rowptr && colidx && val, "NULL argument");
   ISPH_REQUIRE(nrow >= 0 && ncol >= nrow, "need 0 <= nrow <= ncol");
-  DevBuf<int> trp, tci;
-  DevBuf<double> tv;
-  const int *drp, *dci;
-  const double *dv;
-  long long nnz = 0;
-  ISPH_CHECK(stage_in(ctx, rowptr, (size_t)nrow + 1, on_device, trp, &drp));
-  if (on_device) {
-    int last = 0;
-    ISPH_CHECK_HIP(hipMemcpyAsync(&last, rowptr + nrow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    nnz = last;
-  } else {
-    nnz = rowptr[nrow];
-    // host-side validation of the operand shapes the kernels assume
-    for (int i = 0; i < nrow; ++i) ISPH_REQUIRE(rowptr[i + 1] >= rowptr[i], "rowptr not monotone");
-    for (long long p = 0; p < nnz; ++p) ISPH_REQUIRE(colidx[p] >= 0 && colidx[p] < ncol, "column index out of range");
-  }
-  ISPH_CHECK(stage_in(ctx, colidx, (size_t)nnz, on_device, tci, &dci));
-  ISPH_CHECK(stage_in(ctx, val, (size_t)nnz, on_device, tv, &dv));
+  if (!on_device) return csr_ingress_host(ctx, nrow, ncol, rowptr, colidx, val, Aout);  // pipelined, ingress.hpp
+  int last = 0;
+  ISPH_CHECK_HIP(hipMemcpyAsync(&last, rowptr + nrow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   isph_mat *A = nullptr;
-  const int rc = mat_from_device_csr(ctx, nrow, ncol, drp, dci, dv, nnz, &A);
-  trp.release(); tci.release(); tv.release();
-  if (rc != ISPH_SUCCESS) return rc;
+  ISPH_CHECK(mat_from_device_csr(ctx, nrow, ncol, rowptr, colidx, val, (long long)last, &A));
   *Aout = A;
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_create_csr_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
+                                int block_size, isph_mat **Aout, isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && Aout && Mout && rowptr && colidx && val, "NULL argument");
+  ISPH_REQUIRE(nrow >= 0 && ncol >= nrow, "need 0 <= nrow <= ncol");
+  isph_mat *A = nullptr;
+  isph_ilu *F = nullptr;
+  ISPH_CHECK(csr_ingress_host_bjacobi(ctx, nrow, ncol, rowptr, colidx, val, block_size, &A, &F));
+  isph_prec *M = new isph_prec();
+  M->n = nrow;
+  M->type = 2;
+  M->ilu = F;
+  *Aout = A;
+  *Mout = M;
+  return ISPH_SUCCESS;
+}
+
+int isph_ingress_info(const isph_ctx *ctx, double info[8]) {
+  ISPH_REQUIRE(ctx && info, "NULL argument");
+  for (int k = 0; k < 8; ++k) info[k] = ctx->stager ? ctx->stager->stats[k] : 0.0;
   return ISPH_SUCCESS;
 }
 

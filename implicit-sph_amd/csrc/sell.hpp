@@ -90,15 +90,22 @@ __global__ void k_exclusive_scan_ll(int n, const long long *in, long long *out) 
   if (threadIdx.x == 0) out[n] = carry;
 }
 
+// rowlen only (the host ingress knows the slice offsets from the host row pointers)
+__global__ void k_csr_rowlen(int nrow, const int *__restrict__ rowptr, int *__restrict__ rowlen) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < nrow) rowlen[row] = rowptr[row + 1] - rowptr[row];
+}
+
+// slices [slice_begin, slice_end); unsorted (optional) is raised when a row's columns are not ascending
 template <class OFF>
 __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const int *__restrict__ colidx,
                               const double *__restrict__ cval, const long long *__restrict__ slice_off,
-                              int *__restrict__ scol, double *__restrict__ sval) {
-  const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+                              int *__restrict__ scol, double *__restrict__ sval, int slice_begin, int slice_end,
+                              int *__restrict__ unsorted) {
+  const int slice = slice_begin + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int row = slice * kSlice + lane;
-  const int nslices = (nrow + kSlice - 1) / kSlice;
-  if (slice >= nslices) return;
+  if (slice >= slice_end) return;
   const long long off = slice_off[slice];
   const int w = (int)((slice_off[slice + 1] - off) >> 6);
   OFF beg = 0;
@@ -109,16 +116,22 @@ __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const in
   }
   // padding repeats a column the row already reads (always in range, also for rectangular operators)
   const int padcol = len > 0 ? colidx[beg] : 0;
+  int prev = -1;
+  bool desc = false;
   for (int k = 0; k < w; ++k) {
     const long long p = sell_pos(off, lane, k);
     if (k < len) {
-      scol[p] = colidx[beg + k];
+      const int c = colidx[beg + k];
+      desc = desc || c < prev;
+      prev = c;
+      scol[p] = c;
       sval[p] = cval[beg + k];
     } else {
       scol[p] = padcol;
       sval[p] = 0.0;
     }
   }
+  if (unsorted != nullptr && __ballot(desc) != 0ull && lane == 0) atomicOr(unsorted, 1);
 }
 
 // ---- row sort: columns ascending inside every row (Epetra OptimizeStorage order)
@@ -282,15 +295,16 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int
 // columns fall into a few dozen aligned windows of 1024 indices (the bricks around them), so a per-slice table of
 // <= 64 window numbers plus 6+10 bits per entry carries the same information in 2 B: 10 B instead of 12 B per
 // entry for the HBM-bound kernel.  One wave per slice builds the table (LDS set with atomicCAS) and re-encodes.
-__global__ __launch_bounds__(kBlock) void k_sell_compress_cols(int nslices, const long long *__restrict__ slice_off,
+__global__ __launch_bounds__(kBlock) void k_sell_compress_cols(int slice_begin, int slice_end,
+                                                               const long long *__restrict__ slice_off,
                                                                const int *__restrict__ scol,
                                                                unsigned short *__restrict__ c16, int *__restrict__ wtab,
                                                                int *__restrict__ fail) {
   __shared__ int tab[kBlock / kWave][64];
   __shared__ int cnt[kBlock / kWave];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slice = blockIdx.x * (kBlock / kWave) + wave;
-  if (slice >= nslices) return;
+  const int slice = slice_begin + blockIdx.x * (kBlock / kWave) + wave;
+  if (slice >= slice_end) return;
   tab[wave][lane] = -1;
   if (lane == 0) cnt[wave] = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -57,6 +57,7 @@ __global__ void k_gather(int n, const int *__restrict__ idx, const double *__res
 // after everything queued before it (ev_pack) and every later collective is queued behind the boundary kernel, which
 // itself waits for ev_halo.  (Ifpack/Epetra do this Import inside Epetra_CrsMatrix::Apply, solver_lin.h:133.)
 inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x) {
+  ISPH_REQUIRE(ctx->comm && ctx->comm_stream, "a matrix with a halo needs a context made by isph_ctx_create_dist");
   const Sell &S = A->S;
   const isph_halo &H = A->halo;
   ISPH_REQUIRE(H.nrecv == S.ncol - S.nrow, "matrix has ghost columns but no matching halo plan");
@@ -109,7 +110,7 @@ inline bool sell_cols16(isph_ctx *ctx, const Sell &S) {
       S.wtab.reserve((size_t)S.nslices * 64) != ISPH_SUCCESS) { flag.release(); return false; }
   int h = 0;
   if (hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream) == hipSuccess) {
-    hipLaunchKernelGGL(k_sell_compress_cols, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, S.nslices,
+    hipLaunchKernelGGL(k_sell_compress_cols, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, 0, S.nslices,
                        (const long long *)S.slice_off.p, (const int *)S.col.p, S.col16.p, S.wtab.p, flag.p);
     if (hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
         hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess && h == 0)

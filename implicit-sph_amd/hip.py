@@ -18,7 +18,7 @@ KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
     "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
-    "isph_last_error", "isph_mat_create_csr", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
+    "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
@@ -111,6 +111,8 @@ def lib():
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.isph_mat_create_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]
+        L.isph_mat_create_csr_bjacobi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_void_p, C.c_void_p]
         L.isph_mat_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
         L.isph_mat_info.argtypes = [C.c_void_p, C.c_void_p]
@@ -321,6 +323,21 @@ class Matrix:
         _check(lib().isph_mat_create_csr(ctx.h, nrow, nrow if ncol is None else ncol, _ptr(rowptr), _ptr(colidx),
                                          _ptr(val), _on_device(rowptr, colidx, val), C.byref(m.h)))
         return m
+
+    @classmethod
+    def from_host_csr_with_bjacobi(cls, ctx, rowptr, colidx, val, block_size=512, ncol=None):
+        """isph_mat_create_csr_bjacobi: host CSR ingress fused with the block-Jacobi ILU(0) set-up (the drop-in path of
+        SolverLin_Belos::solveProblem with PrecondWrapper_Ifpack).  Returns (Matrix, Precond)."""
+        rowptr, colidx, val = _i32(rowptr), _i32(colidx), _f64(val)
+        if _is_torch(rowptr) or _is_torch(colidx) or _is_torch(val):
+            raise IsphError("isph_mat_create_csr_bjacobi takes host arrays")
+        nrow = int(rowptr.shape[0]) - 1
+        m = cls(ctx)
+        M = Precond.__new__(Precond)
+        M.ctx, M.n, M.h = ctx, nrow, C.c_void_p()
+        _check(lib().isph_mat_create_csr_bjacobi(ctx.h, nrow, nrow if ncol is None else ncol, _ptr(rowptr), _ptr(colidx),
+                                                 _ptr(val), block_size, C.byref(m.h), C.byref(M.h)))
+        return m, M
 
     def set_halo(self, peers, send_ptr, send_idx, recv_ptr):
         peers, send_ptr, send_idx, recv_ptr = map(lambda a: np.ascontiguousarray(a, dtype=np.int32),

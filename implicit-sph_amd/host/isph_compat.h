@@ -23,7 +23,9 @@
 #include <string>
 #include <vector>
 
-#ifndef ISPH_HAVE_MPI
+#ifdef ISPH_HAVE_MPI
+#include <mpi.h>
+#else
 typedef int MPI_Comm;  // single-process builds: the communicator is a placeholder
 #endif
 
@@ -70,14 +72,37 @@ template <class Scalar> class LinearOpBase;
 
 enum Epetra_DataAccess { Copy, View };
 
+// With -DISPH_HAVE_MPI (and <mpi.h> on the include path) the communicator is real: rank, size and the reductions the
+// mirror classes need.  Without it this is a single-process build: one rank, and anything that needs a second rank
+// fails loudly (SolverLin_HIP refuses NumProc() > 1, halo_lists.h returns an error for a foreign peer).
 class Epetra_MpiComm {
  public:
+#ifdef ISPH_HAVE_MPI
+  explicit Epetra_MpiComm(MPI_Comm c = MPI_COMM_WORLD) : comm_(c) {
+    MPI_Comm_rank(comm_, &rank_);
+    MPI_Comm_size(comm_, &size_);
+  }
+  double SumAll(double x) const {
+    double g = 0.0;
+    MPI_Allreduce(&x, &g, 1, MPI_DOUBLE, MPI_SUM, comm_);
+    return g;
+  }
+  int MaxAll(int x) const {
+    int g = 0;
+    MPI_Allreduce(&x, &g, 1, MPI_INT, MPI_MAX, comm_);
+    return g;
+  }
+#else
   explicit Epetra_MpiComm(MPI_Comm c = 0) : comm_(c) {}
-  int MyPID() const { return 0; }
-  int NumProc() const { return 1; }
+  double SumAll(double x) const { return x; }
+  int MaxAll(int x) const { return x; }
+#endif
+  int MyPID() const { return rank_; }
+  int NumProc() const { return size_; }
   MPI_Comm Comm() const { return comm_; }
  private:
   MPI_Comm comm_;
+  int rank_ = 0, size_ = 1;
 };
 
 class Epetra_IntSerialDenseVector {

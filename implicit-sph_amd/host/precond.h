@@ -21,6 +21,11 @@ class PrecondWrapper {
   friend class SolverLin_HIP;
   // hook used by SolverLin_HIP: build the device preconditioner for matrix A
   virtual int createOnDevice(isph_ctx *, const isph_mat *) { return ISPH_SUCCESS; }
+  // > 0: this wrapper's device object is the block-Jacobi ILU(0) on subdomains of that many rows, which the host matrix
+  // ingress can set up while the matrix is still crossing PCIe (isph_mat_create_csr_bjacobi); SolverLin_HIP then hands
+  // the finished object over with adoptDevice() instead of calling createOnDevice()
+  virtual int fusedIngressBlockRows() { return 0; }
+  void adoptDevice(isph_prec *M) { free(); _M = M; }
 
  public:
   PrecondWrapper(MPI_Comm comm) : _comm(comm) {}

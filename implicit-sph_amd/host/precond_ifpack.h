@@ -34,6 +34,23 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
   }
 
  protected:
+  // the throughput path (block-Jacobi ILU(0), overlap 0 inside the rank) can be built during the matrix ingress
+  virtual int fusedIngressBlockRows() {
+    setParameters(_param.get());
+    const int block = _param->get("isph: block rows", 512);
+    if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0) return 0;
+    if (block < 64 || block > 1024 || block % 64 != 0) return 0;
+    noticeOnce(0, block, _param->get("Overlap Level", 1));
+    return block;
+  }
+  void noticeOnce(int fill, int block, int overlap) {
+    if (_comm.MyPID() == 0 && !_warned) {
+      std::printf(">> PrecondWrapper_Ifpack(HIP): block-Jacobi ILU(%d) on %d-row subdomains, overlap 0 (reference: one "
+                  "subdomain per rank, Overlap Level %d); set \"isph: block rows\" = 0 for the reference's decomposition\n",
+                  fill, block, overlap);
+      _warned = true;
+    }
+  }
   virtual int createOnDevice(isph_ctx *ctx, const isph_mat *A) {
     setParameters(_param.get());
     const std::string type = _param->get("Precond Type", "ILU");
@@ -88,12 +105,7 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     // default: the throughput path -- block-Jacobi ILU(fill) on subdomains of `block` rows inside the rank, overlap 0.
     // This is NOT what the reference factors (one subdomain per rank, overlap 1): iteration counts differ (on the 100^3
     // TGV system 116 iterations against 49 for the whole-matrix ILU(0)); the notice is printed once, on every build.
-    if (_comm.MyPID() == 0 && !_warned) {
-      std::printf(">> PrecondWrapper_Ifpack(HIP): block-Jacobi ILU(%d) on %d-row subdomains, overlap 0 (reference: one "
-                  "subdomain per rank, Overlap Level %d); set \"isph: block rows\" = 0 for the reference's decomposition\n",
-                  fill, block, overlap);
-      _warned = true;
-    }
+    noticeOnce(fill, block, overlap);
     const std::string kind = "bjacobi-ilu" + std::to_string(fill);
     return isph_prec_create(ctx, A, kind.c_str(), block, &_M);
   }

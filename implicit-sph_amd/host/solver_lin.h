@@ -42,21 +42,22 @@ class SolverLin {
                      : Teuchos::rcp(new Epetra_MultiVector(View, *_map, x, lda, num_vectors));
     return LAMMPS_SUCCESS;
   }
-  // n = mask (or ones) / ||.||_2, ref: solver_lin.cpp:59-77
+  // n = mask (or ones) / ||.||_2, ref: solver_lin.cpp:59-77.  The norm is the GLOBAL one (Epetra's Norm2 is an
+  // all-reduce, solver_lin.cpp:72-74): with unequal local counts -- any masked null vector -- a rank-local norm would
+  // scale the pieces differently and the result would not be in the null space.  The vector is kept between solves
+  // (8 MB of first-touch page faults per solve at 10^6 rows otherwise).
   int createNullVector() {
-    _n = Teuchos::rcp(new Epetra_Vector(*_map, true));
+    if (!_n || _n->MyLength() != _map->NumMyElements()) _n = Teuchos::rcp(new Epetra_Vector(*_map, true));
     double *v = _n->Values();
     const int len = _n->MyLength();
-    if (!_null_mask) {
-      for (int i = 0; i < len; ++i) v[i] = 1.0;
-    } else {
-      const int m = std::min(_null_mask->Length(), len);
-      for (int i = 0; i < m; ++i) v[i] = _null_mask->Values()[i];
-    }
-    double nrm = 0.0;
-    for (int i = 0; i < len; ++i) nrm += v[i] * v[i];
-    nrm = std::sqrt(nrm);
-    for (int i = 0; i < len; ++i) v[i] /= nrm;
+    const int m = _null_mask ? std::min(_null_mask->Length(), len) : len;
+    const int *mask = _null_mask ? _null_mask->Values() : NULL;
+    double sum = 0.0;
+    for (int i = 0; i < m; ++i) { const double a = mask ? (double)mask[i] : 1.0; sum += a * a; }
+    sum = _comm.SumAll(sum);
+    const double inv = 1.0 / std::sqrt(sum);
+    for (int i = 0; i < m; ++i) v[i] = (mask ? (double)mask[i] : 1.0) * inv;
+    for (int i = m; i < len; ++i) v[i] = 0.0;
     return LAMMPS_SUCCESS;
   }
   int createBlockMatrix(const int dim, const char *) { _dim = dim; return LAMMPS_SUCCESS; }

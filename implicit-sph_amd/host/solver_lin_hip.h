@@ -4,6 +4,7 @@
 // (pair_isph.h:77) and the USER-REAXC-T call site compiling unchanged.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -77,26 +78,42 @@ class SolverLin_HIP : public SolverLin {
     double *v = nullptr;
     _A->ExtractCrsDataPointers(rp, ci, v);
     isph_mat *A = nullptr;
-    if (isph_mat_create_csr(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, 0, &A) != ISPH_SUCCESS) return report_failure();
-    if (attachHalo(A, *_A) != ISPH_SUCCESS) { isph_mat_destroy(A); return report_failure(); }
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    // a preconditioner that is local to 512-row subdomains is set up while the matrix is still on the link
+    const int fused = prec != NULL ? prec->fusedIngressBlockRows() : 0;
+    isph_prec *Mfused = nullptr;
+    if ((fused > 0 ? isph_mat_create_csr_bjacobi(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, fused, &A, &Mfused)
+                   : isph_mat_create_csr(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, 0, &A)) != ISPH_SUCCESS)
+      return report_failure();
+    if (attachHalo(A, *_A) != ISPH_SUCCESS) { isph_mat_destroy(A); isph_prec_destroy(Mfused); return report_failure(); }
+    const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();  // the ingress returns synchronised
 
     int rc = ISPH_SUCCESS;
     if (prec != NULL) {
       if (_is_singular) { createNullVector(); prec->setNullVector(_n->Values()); }  // :149-151
       prec->create();
-      rc = prec->createOnDevice(_ctx, A);  // Ifpack Initialize+Compute happen here (:153)
+      if (fused > 0) prec->adoptDevice(Mfused);
+      else rc = prec->createOnDevice(_ctx, A);  // Ifpack Initialize+Compute happen here (:153)
     }
+    if (_timing && rc == ISPH_SUCCESS) rc = isph_ctx_sync(_ctx);  // only to attribute the set-up; the solve queues behind it anyway
+    const std::chrono::steady_clock::time_point t2 = std::chrono::steady_clock::now();
     isph_solver_params p = solverParams();
 
     isph_solve_info info;
     if (rc == ISPH_SUCCESS)
       rc = isph_solve(_ctx, A, prec ? prec->_M : nullptr, _b->Values(), _x->Values(), _x->NumVectors(), _x->Stride(),
                       _is_singular ? 1 : 0, _null_mask ? _null_mask->Values() : nullptr, &p, &info, 0);
+    const std::chrono::steady_clock::time_point t3 = std::chrono::steady_clock::now();
     if (prec != NULL) {
       if (_is_singular) prec->setNullVector(NULL);
       prec->free();  // :186-191
     }
     isph_mat_destroy(A);
+    const std::chrono::steady_clock::time_point t4 = std::chrono::steady_clock::now();
+    _ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    _ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    _ms[2] = std::chrono::duration<double, std::milli>(t3 - t2).count();
+    _ms[3] = std::chrono::duration<double, std::milli>(t4 - t3).count();
     if (rc != ISPH_SUCCESS) return report_failure();
     _last = info;
     if (_comm.MyPID() == 0) {  // :194-213: non-convergence is reported, never raised
@@ -176,6 +193,12 @@ class SolverLin_HIP : public SolverLin {
   }
 
   const isph_solve_info &lastSolveInfo() const { return _last; }
+  // wall time of the last solveProblem in milliseconds: [0] matrix ingress (host CSR -> device), [1] preconditioner
+  // set-up, [2] Krylov solve incl. the transfers of b and x, [3] release.  [1] and [2] are only separated when
+  // setTiming(true) put a synchronisation between them (not a reference method; diagnostics of the drop-in path)
+  const double *lastTimingsMs() const { return _ms; }
+  int lastIngressInfo(double info[8]) const { return _ctx ? isph_ingress_info(_ctx, info) : ISPH_FAILURE; }
+  void setTiming(bool on) { _timing = on; }
 
  private:
   // One context per solver object.  More than one rank (SolverLin(MPI_Comm&) is multi-rank by construction,
@@ -216,6 +239,8 @@ class SolverLin_HIP : public SolverLin {
   isph_ctx *_ctx;
   int _device;
   isph_solve_info _last{};
+  double _ms[4] = {0.0, 0.0, 0.0, 0.0};
+  bool _timing = false;
 };
 
 typedef SolverLin_HIP SolverLin_Belos;  // pair_isph.h:77 keeps compiling

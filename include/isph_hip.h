@@ -66,6 +66,22 @@ const char *isph_last_error(void);
 int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h|d]*/,
                         const int *colidx /*[h|d]*/, const double *val /*[h|d]*/,
                         int on_device, isph_mat **A);
+/* The same ingress from HOST arrays, fused with the set-up of the block-Jacobi ILU(0)
+ * preconditioner ("bjacobi-ilu0", block_size rows per subdomain): the matrix crosses PCIe in
+ * chunks, and the set-up of the blocks whose rows have arrived runs while the rest is still on
+ * the link.  What SolverLin_Belos::solveProblem does between receiving the host matrix and
+ * starting Belos -- prec->create() = Ifpack Initialize + Compute (ref: solver_lin_belos.h:147-156,
+ * precond_ifpack.h:60-74) -- with the result of isph_mat_create_csr(on_device = 0) followed by
+ * isph_prec_create(A, "bjacobi-ilu0", block_size), bit for bit. */
+int isph_mat_create_csr_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h]*/,
+                                const int *colidx /*[h]*/, const double *val /*[h]*/, int block_size,
+                                isph_mat **A, isph_prec **M);
+/* Diagnostics of the last host-side ingress on this context (milliseconds since its start):
+ * [0] staging threads started, device buffers reserved  [1] all chunks queued on the copy stream
+ * [2] copy stream drained  [3] compute stream drained (conversion + fused set-up)  [4] end
+ * [5] time the queueing thread waited for staged chunks  [6] chunks  [7] staging threads.
+ * No reference counterpart. */
+int isph_ingress_info(const isph_ctx *ctx, double info[8]);
 /* Halo plan = what Epetra builds inside FillComplete (column map + Import,
  * ref: functor_graph.h:97).  For peer p: send x[send_idx[send_ptr[p]..send_ptr[p+1])]
  * and receive the ghost columns nrow+recv_ptr[p] .. nrow+recv_ptr[p+1]. */

@@ -2,6 +2,8 @@
 // (ref: USER-REAXC-T/fix_qeq_reax.cpp:671-693): SolverLin_Belos li_solver(world);
 // setParameters(); setNodalMap; setMatrix; prec.setMatrix; create*MultiVector;
 // solveProblem(&prec, "...").  Reads a CSR system from a binary file, writes x.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -165,6 +167,7 @@ int main(int argc, char **argv) {
   const bool ifpack_defaults = argc > 4 && std::string(argv[4]) == "ifpack-defaults";  // level-of-fill 1, overlap 1
   const bool ifpack_reference = argc > 4 && std::string(argv[4]) == "ifpack-reference";  // + one subdomain = the whole matrix
   const bool recycling = argc > 4 && std::string(argv[4]) == "recycling";  // "Solver Type" = "Recycling GMRES"
+  const bool timed = argc > 4 && std::string(argv[4]) == "timed";  // repeat the solve, report wall time per phase
   PrecondWrapper_Ifpack prec_ifpack(world);
   PrecondWrapper_ML prec_ml(world);
   PrecondWrapper &prec = use_ml ? static_cast<PrecondWrapper &>(prec_ml) : static_cast<PrecondWrapper &>(prec_ifpack);
@@ -176,7 +179,7 @@ int main(int argc, char **argv) {
     pp->set("fact: level-of-fill", 0);
     pp->set("Overlap Level", 0);
   }
-  pp->set("isph: block rows", ifpack_reference ? 0 : 256);
+  pp->set("isph: block rows", ifpack_reference ? 0 : timed ? 512 : 256);
 
   SolverLin_Belos li_solver(world);
   li_solver.setParameters();
@@ -207,7 +210,43 @@ int main(int argc, char **argv) {
     li_solver.setMatrixIsSingular(true);
   }
   li_solver.setInitialSolution(SolverLin::Zero);
-  const int rc = li_solver.solveProblem(&prec, "test_solver_lin");
+  if (timed) {
+    // the per-step sequence of PairISPH::computePoisson's caller (pair_isph.cpp:988-1011) repeated on one host matrix:
+    // setMatrix / setInitialSolution / solveProblem, wall time per call split into ingress / set-up / Krylov
+    const int repeat = argc > 5 ? std::atoi(argv[5]) : 5;
+    const std::vector<double> b0 = b;  // solveProblem projects b in place
+    li_solver.setTiming(true);
+    std::vector<double> t[5];
+    int iters = 0, conv = 1;
+    for (int k = 0; k < repeat + 1; ++k) {
+      b = b0;
+      li_solver.setMatrix(&AA);
+      prec.setMatrix(&AA);
+      li_solver.setInitialSolution(SolverLin::Zero);
+      const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
+      if (li_solver.solveProblem(&prec, NULL) != LAMMPS_SUCCESS) return 1;
+      const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+      if (k == 0) continue;  // first call: context, pinned ring and device pool are created
+      const double *ms = li_solver.lastTimingsMs();
+      for (int q = 0; q < 4; ++q) t[q].push_back(ms[q]);
+      t[4].push_back(wall);
+      iters = li_solver.lastSolveInfo().iters;
+      conv = conv && li_solver.lastSolveInfo().converged;
+    }
+    for (int q = 0; q < 5; ++q) std::sort(t[q].begin(), t[q].end());
+    const size_t mid = t[4].size() / 2;
+    std::printf("{\"dropin\": {\"rows\": %d, \"entries\": %d, \"repeat\": %d, \"iterations\": %d, \"converged\": %d, "
+                "\"ms_per_solve\": %.3f, \"ingress_ms\": %.3f, \"setup_ms\": %.3f, \"krylov_ms\": %.3f, \"release_ms\": %.3f, "
+                "\"ingress_GBps\": %.2f}}\n",
+                n, nnz, repeat, iters, conv, t[4][mid], t[0][mid], t[1][mid], t[2][mid], t[3][mid],
+                (12.0 * nnz + 4.0 * (n + 1)) / t[0][mid] * 1e-6);
+    double gi[8];
+    if (li_solver.lastIngressInfo(gi) == ISPH_SUCCESS)
+      std::printf("{\"ingress_last_call\": {\"staged_ms\": %.3f, \"queued_ms\": %.3f, \"copied_ms\": %.3f, \"device_done_ms\": %.3f, "
+                  "\"end_ms\": %.3f, \"waited_for_staging_ms\": %.3f, \"chunks\": %.0f, \"threads\": %.0f}}\n",
+                  gi[0], gi[1], gi[2], gi[3], gi[4], gi[5], gi[6], gi[7]);
+  }
+  const int rc = timed ? LAMMPS_SUCCESS : li_solver.solveProblem(&prec, "test_solver_lin");
   if (rc != LAMMPS_SUCCESS) return 1;
   const isph_solve_info &info = li_solver.lastSolveInfo();
   std::printf("converged=%d iters=%d rel=%.3e\n", info.converged, info.iters, info.rel_res_implicit);
