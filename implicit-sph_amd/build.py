@@ -76,5 +76,44 @@ def build_cpp_test(force=False):
     return CPP_TEST
 
 
+MPI_INC, MPI_LIB = "/opt/conda/include", "/opt/conda/lib"
+MPIEXEC = "/opt/conda/bin/mpiexec"
+CPP_TEST_MPI = os.path.join(ROOT, "tests", "cpp", "test_solver_lin_mpi")
+CPP_MPI_HOST = os.path.join(ROOT, "tests", "cpp", "test_mpi_host")
+
+
+def have_mpi():
+    """The image ships MPICH under /opt/conda (its `mpicxx` wrapper is broken, plain g++ with -I/-L works)."""
+    return os.path.exists(os.path.join(MPI_INC, "mpi.h")) and os.path.exists(MPIEXEC)
+
+
+def build_cpp_mpi(force=False):
+    """The multi-rank build of the C++ mirror (-DISPH_HAVE_MPI): the same driver as build_cpp_test with the real
+    communicator, and the host-only MPI test of the row import / null vector.  Returns (driver, host_test) or None
+    when no MPI is installed."""
+    if not have_mpi():
+        return None
+    host = os.path.join(PKG, "host")
+    hdeps = [os.path.join(host, f) for f in os.listdir(host)] + [os.path.join(INC, "isph_hip.h")]
+    flags = ["-O2", "-std=c++17", "-DISPH_HAVE_MPI", "-I", MPI_INC, "-I", INC, "-I", host]
+    # conda's lib directory also holds an older libstdc++ that must not shadow the system's (libisph_hip / ROCm need the
+    # newer one): link libmpi by path and let the loader find it and its two conda-only dependencies through a private
+    # directory of symlinks
+    mpilib = os.path.join(ROOT, "tests", "cpp", "mpilib")
+    os.makedirs(mpilib, exist_ok=True)
+    for so in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+        link = os.path.join(mpilib, so)
+        if os.path.exists(os.path.join(MPI_LIB, so)) and not os.path.lexists(link):
+            os.symlink(os.path.join(MPI_LIB, so), link)
+    libs = ["-L", PKG, "-lisph_hip", os.path.join(MPI_LIB, "libmpi.so"), "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib",
+            "-Wl,-rpath," + mpilib]
+    for target, src in ((CPP_TEST_MPI, "test_solver_lin.cpp"), (CPP_MPI_HOST, "test_mpi_host.cpp")):
+        src = os.path.join(ROOT, "tests", "cpp", src)
+        if force or _stale(target, [src] + hdeps):
+            build_hip()
+            _run(["g++"] + flags + ["-o", target, src] + libs)
+    return CPP_TEST_MPI, CPP_MPI_HOST
+
+
 def build_all(force=False):
-    return build_host(force), build_hip(force), build_cpp_test(force)
+    return build_host(force), build_hip(force), build_cpp_test(force), build_cpp_mpi(force)

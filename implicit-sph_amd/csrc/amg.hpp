@@ -689,7 +689,7 @@ inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char>
   ISPH_CHECK(A.ci.reserve((size_t)(S.nnz > 0 ? S.nnz : 1)));
   ISPH_CHECK(A.v.reserve((size_t)(S.nnz > 0 ? S.nnz : 1)));
   // exclusive scan over n+1 entries: the last input is ignored by giving the scan n+1 items of a padded copy
-  DevBuf<int> len1;
+  DevTmp<int> len1;
   ISPH_CHECK(len1.reserve((size_t)S.nrow + 1));
   ISPH_CHECK_HIP(hipMemcpyAsync(len1.p, S.rowlen.p, sizeof(int) * (size_t)S.nrow, hipMemcpyDeviceToDevice, ctx->stream));
   ISPH_CHECK_HIP(hipMemsetAsync(len1.p + S.nrow, 0, sizeof(int), ctx->stream));
@@ -709,8 +709,8 @@ inline int amg_transpose(isph_ctx *ctx, const DCsr &P, DCsr &R, DevBuf<char> &tm
   ISPH_CHECK(R.rp.reserve((size_t)R.n + 1));
   ISPH_CHECK(R.ci.reserve(nnz1));
   ISPH_CHECK(R.v.reserve(nnz1));
-  DevBuf<unsigned long long> k0, k1;
-  DevBuf<int> cnt;
+  DevTmp<unsigned long long> k0, k1;
+  DevTmp<int> cnt;
   int rc = k0.reserve(nnz1);
   if (rc == ISPH_SUCCESS) rc = k1.reserve(nnz1);
   if (rc == ISPH_SUCCESS) rc = cnt.reserve((size_t)R.n + 1);
@@ -740,7 +740,7 @@ template <int TABLE, int BS>
 inline int amg_spgemm_t(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C, DevBuf<char> &tmp, int *derr) {
   C.n = X.n; C.m = Y.m;
   ISPH_CHECK(C.rp.reserve((size_t)C.n + 1));
-  DevBuf<int> cnt;
+  DevTmp<int> cnt;
   ISPH_CHECK(cnt.reserve((size_t)C.n + 1));
   ISPH_CHECK_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)C.n + 1), ctx->stream));
   if (C.n > 0)
@@ -811,8 +811,8 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   const DCsr &A = L->A;
   const int n = A.n;
   const double th2 = theta * theta;
-  DevBuf<unsigned long long> key, t1, t2;
-  DevBuf<int> flag, id, a1, cnt, scb, listA, listB, list1, stamp;
+  DevTmp<unsigned long long> key, t1, t2;
+  DevTmp<int> flag, id, a1, cnt, scb, listA, listB, list1, stamp;
   int rc = key.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = listA.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = listB.reserve((size_t)n);
@@ -900,10 +900,10 @@ inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, int nag
                            DevBuf<char> &tmp, int *derr) {
   const DCsr &A = L->A;
   const int n = A.n;
-  DevBuf<unsigned long long> k0, k1;
-  DevBuf<int> start, cnt;
-  DevBuf<double> pt;
-  DevBuf<unsigned long long> rho;
+  DevTmp<unsigned long long> k0, k1;
+  DevTmp<int> start, cnt;
+  DevTmp<double> pt;
+  DevTmp<unsigned long long> rho;
   int rc = k0.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = k1.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = start.reserve((size_t)nagg + 1);
@@ -977,9 +977,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   ISPH_REQUIRE(prm->sweeps >= 1, "smoother sweeps must be >= 1");
   isph_amg *G = new isph_amg();
   G->block = prm->block; G->sweeps = prm->sweeps; G->singular = nullvec_dev != nullptr;
-  DevBuf<char> tmp;
-  DevBuf<int> derr;
-  DevBuf<double> dg;
+  DevTmp<char> tmp;
+  DevTmp<int> derr;
+  DevTmp<double> dg;
   int rc = derr.reserve(1);
   if (rc == ISPH_SUCCESS && hipMemsetAsync(derr.p, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
   AmgLevel *L0 = new AmgLevel();

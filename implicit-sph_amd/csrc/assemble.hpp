@@ -1185,7 +1185,7 @@ inline int compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &di);
   NeighEll E;
   if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, P->nlocal, np, di, E, T);
-  DevBuf<double> out;
+  DevTmp<double> out;
   double *dout = vfrac_out;
   if (rc == ISPH_SUCCESS && !on_device) { rc = out.reserve((size_t)(P->nlocal > 0 ? P->nlocal : 1)); dout = out.p; }
   if (rc == ISPH_SUCCESS && P->nlocal > 0) {
@@ -1222,8 +1222,8 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   PoissonArgs a;
   memset(&a, 0, sizeof(a));
   isph_mat *A = new isph_mat();
-  DevBuf<double> bdev;
-  DevBuf<int> newlen;
+  DevTmp<double> bdev;
+  DevTmp<int> newlen;
   int rc = stage_tables(ctx, P, S, T);
   long long nnb = 0;
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->x, (size_t)P->nall * 3, on_device, S.x, &a.x);
@@ -1366,14 +1366,14 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
   ISPH_REQUIRE(ncol >= P->nlocal && lda >= P->nlocal, "need ncol >= nlocal and lda >= nlocal");
   const int n = P->nlocal, dim = P->dim, dL = dim * (dim + 1) / 2;
   StagedParticles S;
-  DevBuf<double> snu, sp, sf, sv;
+  DevTmp<double> snu, sp, sf, sv;
   AsmTables T;
   HelmholtzArgs a;
   memset(&a, 0, sizeof(a));
   const bool rhs_only = A_out == nullptr;  // theta = 0 callers only need b (the reference then copies b into x)
   isph_mat *A = new isph_mat();
-  DevBuf<double> bdev;
-  DevBuf<int> newlen;
+  DevTmp<double> bdev;
+  DevTmp<int> newlen;
   int rc = stage_tables(ctx, P, S, T);
   long long nnb = 0;
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->x, (size_t)P->nall * 3, on_device, S.x, &a.x);
@@ -1517,8 +1517,8 @@ inline int compute_corrections(isph_ctx *ctx, const isph_particles *P, double *G
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->neigh_idx, (size_t)nnb, on_device, S.nidx, &di);
   NeighEll E;
   if (rc == ISPH_SUCCESS) rc = build_neigh_ell(ctx, n, np, di, E, T);
-  DevBuf<double> g, l;
-  DevBuf<int> nf;
+  DevTmp<double> g, l;
+  DevTmp<int> nf;
   double *dG = Gc_out, *dLc = Lc_out;
   if (rc == ISPH_SUCCESS && !on_device) {
     rc = g.reserve((size_t)(n > 0 ? n : 1) * d2);

@@ -284,14 +284,14 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
   ISPH_REQUIRE(ncol >= P->nlocal && lda >= P->nlocal, "need ncol >= nlocal and lda >= nlocal");
   const int n = P->nlocal, dim = P->dim, d2 = dim * dim, dL = dim * (dim + 1) / 2;
   StagedParticles S;
-  DevBuf<double> snu, sp, sf, sv, sn;
+  DevTmp<double> snu, sp, sf, sv, sn;
   AsmTables T;
   BlockHelmholtzArgs A;
   memset(&A, 0, sizeof(A));
   HelmholtzArgs &a = A.h;
   isph_mat *blk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  DevBuf<double> bdev;
-  DevBuf<int> newlen;
+  DevTmp<double> bdev;
+  DevTmp<int> newlen;
   int rc = stage_tables(ctx, P, S, T);
   long long nnb = 0;
   if (rc == ISPH_SUCCESS) rc = stage(ctx, P->x, (size_t)P->nall * 3, on_device, S.x, &a.x);

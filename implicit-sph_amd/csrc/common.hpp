@@ -54,14 +54,17 @@ inline int fail(const char *what, const char *file, int line) {
 // Krylov loop) and makes the whole list ready.  Nothing is ever handed out while work that was queued before
 // its release can still touch it, whichever stream that work runs on.
 struct DevPool {
-  // freed blocks are kept for the next set-up (the preconditioner is rebuilt every solve) up to 80 % of the device's
-  // memory: a fresh hipMalloc of tens of GB costs seconds (1.7 s for 48 GB on MI355X), and the BASELINE configs[4]
-  // operator (36 GB) needs several such blocks per set-up
+  // freed blocks are kept for the next set-up (the preconditioner is rebuilt every solve): a fresh hipMalloc of tens of
+  // GB costs seconds (1.7 s for 48 GB on MI355X), and the BASELINE configs[4] operator (36 GB) needs several such blocks
+  // per set-up.  The cache may hold up to 80 % of the memory that was FREE when the library first released a block --
+  // not of the device's total: torch, RCCL and other contexts of the process own memory this pool cannot see, and they
+  // meet an out-of-memory error, not this pool's trim-and-retry.  isph_pool_set_cap() overrides the limit and
+  // isph_pool_trim() gives everything back (call it before another allocator of the process needs the room).
   size_t cap_bytes = 0;
   size_t cap() {
     if (cap_bytes == 0) {
       size_t fr = 0, tot = 0;
-      cap_bytes = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) ? tot / 5 * 4 : ((size_t)48 << 30);
+      cap_bytes = (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) ? (fr + cached) / 5 * 4 : ((size_t)48 << 30);
     }
     return cap_bytes;
   }
@@ -176,6 +179,18 @@ struct DevBuf {
     bytes = 0;
     guard_at = 0;
   }
+};
+
+// function-local temporary: gives its block back when the scope ends, on every path (an ISPH_CHECK that returns early
+// from a set-up with ten work arrays would otherwise leak them exactly when memory is short).  release() stays
+// available for giving a large buffer back before the scope ends.  Not copyable: buffers that move into an object
+// (factor arrays, matrix storage) are plain DevBuf members released by the object's destroy function.
+template <class T>
+struct DevTmp : DevBuf<T> {
+  DevTmp() = default;
+  DevTmp(const DevTmp &) = delete;
+  DevTmp &operator=(const DevTmp &) = delete;
+  ~DevTmp() { this->release(); }
 };
 
 // true when p is device memory: a caller that says on_device = 0 but hands over a device pointer would make the host

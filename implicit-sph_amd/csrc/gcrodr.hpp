@@ -51,7 +51,7 @@ inline int gcrodr(const LinOp &op, const double *b, double *x, const isph_solver
                                 "reference's default list 50/50 as well)");
   const long long ld = ((long long)n + 63) / 64 * 64;
   const int kc = k + 1;  // a complex pair that straddles the k-th slot is kept whole
-  DevBuf<double> Vb, Cb, Ub, Cn, Un, tb, rb, wb, zb, cbuf;
+  DevTmp<double> Vb, Cb, Ub, Cn, Un, tb, rb, wb, zb, cbuf;
   ISPH_CHECK(Vb.reserve((size_t)ld * (size_t)(m + 1)));
   ISPH_CHECK(Cb.reserve((size_t)ld * (size_t)kc));
   ISPH_CHECK(Ub.reserve((size_t)ld * (size_t)kc));
@@ -243,8 +243,8 @@ inline int gcrodr(const LinOp &op, const double *b, double *x, const isph_solver
       if (rc == ISPH_SUCCESS) rc = combine(ctx, n, pr - kk, V, ld, cu.data() + kk, un, kk > 0, cbuf);
     }
     if (rc != ISPH_SUCCESS) break;
-    std::swap(Cb, Cn);
-    std::swap(Ub, Un);
+    std::swap(static_cast<DevBuf<double> &>(Cb), static_cast<DevBuf<double> &>(Cn));  // both stay owned by their scope guards
+    std::swap(static_cast<DevBuf<double> &>(Ub), static_cast<DevBuf<double> &>(Un));
     C = Cb.p;
     U = Ub.p;
     kk = knew;

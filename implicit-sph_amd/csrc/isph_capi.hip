@@ -262,6 +262,16 @@ int isph_pool_trim(void) {
   return ISPH_SUCCESS;
 }
 
+int isph_pool_set_cap(long long bytes) {
+  DevPool &p = DevPool::get();
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.cap_bytes = bytes > 0 ? (size_t)bytes : 0;  // 0: back to the default (80 % of the free memory at the next release)
+  }
+  if (bytes > 0 && (long long)p.cached > bytes) return isph_pool_trim();
+  return ISPH_SUCCESS;
+}
+
 long long isph_pool_cached_bytes(void) {
   DevPool &p = DevPool::get();
   std::lock_guard<std::mutex> lk(p.mu);
@@ -431,7 +441,7 @@ int isph_halo_forward(isph_ctx *ctx, const isph_halo_plan *P, const double *x, d
   if (H.nrecv == 0 && H.nsend == 0) return ISPH_SUCCESS;
   ISPH_REQUIRE(x && ghosts, "NULL field");
   ISPH_REQUIRE(ctx->comm, "no communicator");
-  DevBuf<double> tx, tg;
+  DevTmp<double> tx, tg;
   const double *dx = nullptr;
   int rc = stage_in(ctx, x, (size_t)P->nlocal * ncomp, on_device, tx, &dx);
   double *dg = ghosts;
@@ -483,7 +493,7 @@ int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_ra
   const Sell &S = A->S;
   H.n_int = H.n_bnd = 0;
   if (S.nslices > 0) {
-    DevBuf<int> flag;
+    DevTmp<int> flag;
     ISPH_CHECK(flag.reserve((size_t)S.nslices));
     hipLaunchKernelGGL(k_sell_flag_ghost_slices, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices,
                        (const long long *)S.slice_off.p, (const int *)S.col.p, flag.p);
@@ -520,9 +530,9 @@ int isph_mat_export_csr(isph_ctx *ctx, const isph_mat *A, int *rowptr, int *coli
   for (int i = 0; i < S.nrow; ++i) rp[(size_t)i + 1] = rp[(size_t)i] + len[(size_t)i];
   const long long nnz = rp[(size_t)S.nrow];
   ISPH_REQUIRE(nnz < 2147483647LL, "nnz exceeds 32-bit CSR export");
-  DevBuf<long long> drp;
-  DevBuf<int> dci;
-  DevBuf<double> dv;
+  DevTmp<long long> drp;
+  DevTmp<int> dci;
+  DevTmp<double> dv;
   ISPH_CHECK(drp.reserve((size_t)S.nrow + 1));
   ISPH_CHECK(dci.reserve((size_t)(nnz > 0 ? nnz : 1)));
   ISPH_CHECK(dv.reserve((size_t)(nnz > 0 ? nnz : 1)));
@@ -724,7 +734,7 @@ void isph_prec_destroy(isph_prec *M) {
 
 void isph_schwarz_params_default(isph_schwarz_params *p) {
   // PrecondWrapper_Ifpack::setParameters(NULL), ref: precond_ifpack.h:30-45
-  p->level_of_fill = 1; p->overlap = 1; p->combine = 0; p->block_size = 0;
+  p->level_of_fill = 1; p->overlap = 1; p->combine = 0; p->block_size = 0; p->level_launches = 0;
 }
 
 int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwarz_params *prm, isph_prec **Mout) {
@@ -732,7 +742,8 @@ int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwar
   isph_prec *M = new isph_prec();
   M->n = A->S.nrow;
   M->type = 4;
-  const int rc = schwarz_create(ctx, A, prm->level_of_fill, prm->block_size, prm->overlap, prm->combine, &M->schwarz);
+  const int rc = schwarz_create(ctx, A, prm->level_of_fill, prm->block_size, prm->overlap, prm->combine, &M->schwarz,
+                                /*syncfree=*/prm->level_launches == 0);
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
   *Mout = M;
   return ISPH_SUCCESS;
@@ -806,7 +817,7 @@ int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params
   isph_prec *M = new isph_prec();
   M->n = A->S.nrow;
   M->type = 3;
-  DevBuf<double> tn;
+  DevTmp<double> tn;
   const double *dn = nullptr;
   int rc = nullvec ? stage_in(ctx, nullvec, (size_t)M->n, on_device, tn, &dn) : ISPH_SUCCESS;
   if (rc == ISPH_SUCCESS) rc = amg_create(ctx, A, prm, dn, &M->amg);
@@ -817,7 +828,7 @@ int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params
     // other forever: agree here, once per set-up, and fail on every rank together instead.
     double h[3] = {rc == ISPH_SUCCESS ? 1.0 : 0.0, (rc == ISPH_SUCCESS && M->amg->nlev > 1) ? 1.0 : 0.0,
                    (rc == ISPH_SUCCESS && M->amg->coarse_smooth) ? 1.0 : 0.0};
-    DevBuf<double> d;
+    DevTmp<double> d;
     int rc2 = d.reserve(3);
     if (rc2 == ISPH_SUCCESS && hipMemcpyAsync(d.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc2 = ISPH_FAILURE;
     if (rc2 == ISPH_SUCCESS) rc2 = allreduce_inplace(ctx, d.p, 3);
@@ -851,7 +862,7 @@ int isph_prec_amg_export(isph_ctx *ctx, const isph_prec *M, int level, int what,
   const DCsr &Ck = what == 0 ? M->amg->L[(size_t)level]->A : M->amg->L[(size_t)level]->P;
   ISPH_REQUIRE(Ck.nnz < 2147483647LL, "level too large for the 32-bit test export");
   DCsr fine;  // the fine-level copy is dropped after the set-up: rebuilt from the SELL matrix here
-  DevBuf<char> tmp;
+  DevTmp<char> tmp;
   if (!Ck.ci.p && Ck.nnz > 0) {
     ISPH_REQUIRE(level == 0 && what == 0, "level operator not resident");
     ISPH_CHECK(amg_csr_from_sell(ctx, M->amg->L[0]->Am->S, fine, tmp));
@@ -1043,7 +1054,7 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
     ISPH_CHECK_HIP(hipMemcpyAsync(ctx->bdev.p + (size_t)k * n, b + (size_t)k * lda, sizeof(double) * (size_t)n, in, st));
     ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p + (size_t)k * n, x + (size_t)k * lda, sizeof(double) * (size_t)n, in, st));
   }
-  DevBuf<double> tmp, res;
+  DevTmp<double> tmp, res;
   ISPH_CHECK(tmp.reserve((size_t)n + 64));
   LinOp op{ctx, nullptr, M, nullptr, (int)nt};
   op.dim = dim; op.nloc = n; op.blk = blocks; op.tmp = tmp.p;

@@ -279,7 +279,7 @@ struct OpStage {
   NeighEll E;
   AsmTables T;
   OpArgs a;
-  DevBuf<double> fin, out;
+  DevTmp<double> fin, out;
   void release() { S.release(); E.release(); fin.release(); out.release(); }
 };
 
@@ -353,7 +353,7 @@ inline int op_apply(isph_ctx *ctx, const isph_particles *P, int mode, int antisy
 
 // in/out staging for operands that are updated in place
 struct InOut {
-  DevBuf<double> buf;
+  DevTmp<double> buf;
   double *host = nullptr, *dev = nullptr;
   size_t n = 0;
   int open(isph_ctx *ctx, double *p, size_t count, int on_device) {
@@ -378,7 +378,7 @@ inline int correct_velocity_pressure(isph_ctx *ctx, const isph_particles *P, int
   OpStage st;
   int rc = op_stage(ctx, P, antisym, on_device, st);
   const int n = P->nlocal;
-  DevBuf<double> grad, srho, sdp;
+  DevTmp<double> grad, srho, sdp;
   InOut iv, ip;
   const double *drho = nullptr, *ddp = nullptr;
   if (rc == ISPH_SUCCESS) rc = grad.reserve((size_t)(n > 0 ? n : 1) * 3);
@@ -409,7 +409,7 @@ inline int advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, do
   OpStage st;
   int rc = op_stage(ctx, P, antisym, on_device, st);
   const int n = P->nlocal;
-  DevBuf<double> grad, sp, sv, svn, sout;
+  DevTmp<double> grad, sp, sv, svn, sout;
   const double *dpp = nullptr, *dv = nullptr, *dvn = nullptr;
   double *dout = dp_out;
   if (rc == ISPH_SUCCESS) rc = grad.reserve((size_t)(n > 0 ? n : 1) * 3);
@@ -438,7 +438,7 @@ inline int advance_begin(isph_ctx *ctx, const isph_particles *P, int antisym, do
 inline int advance_end(isph_ctx *ctx, int count, int dim, double dt, const double *dp, const double *vnp1, double *p,
                        double *x, double *v, int on_device) {
   ISPH_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
-  DevBuf<double> sdp, svn;
+  DevTmp<double> sdp, svn;
   InOut ip, ix, iv;
   const double *ddp = nullptr, *dvn = nullptr;
   int rc = stage(ctx, dp, (size_t)count, on_device, sdp, &ddp);
@@ -486,8 +486,8 @@ inline int shift_apply(isph_ctx *ctx, const isph_particles *P, int antisym, cons
   OpStage st;
   int rc = op_stage(ctx, P, antisym, on_device, st);
   const int n = P->nlocal, n1 = n > 0 ? n : 1;
-  DevBuf<double> sdr, xn, vn, pn, scal;
-  DevBuf<int> sfix;
+  DevTmp<double> sdr, xn, vn, pn, scal;
+  DevTmp<int> sfix;
   InOut ix, iv, ip;
   const double *ddr = nullptr;
   const int *dfix = nullptr;

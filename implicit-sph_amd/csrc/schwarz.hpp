@@ -11,16 +11,20 @@
 // Division of labour.  The integer work that is sequential by definition -- the level-of-fill pattern of
 // Ifpack_IlukGraph (row i merges the FINAL patterns of the rows it eliminates with) and the dependency levels of
 // the two triangular solves -- runs on the host, once per create(), over the matrix pattern (threads over
-// subdomains).  The floating-point work runs on the device:
-//   k_gilu_factor   IKJ numeric factorisation, one launch per dependency level, one wave per row; the row image
-//                   (columns + values) lives in LDS, the pivot rows' upper parts are read coalesced
-//   k_gilu_lower / k_gilu_upper   level-scheduled triangular solves, 16 lanes per row
+// subdomains).  The floating-point work runs on the device, as ONE persistent launch per phase whose rows wait for
+// the very words they depend on (round 3; the round-2 form, one launch per dependency level, is kept behind
+// isph_schwarz_params::level_launches as the bit-for-bit cross-check):
+//   k_gilu_factor_sf   IKJ numeric factorisation, one wave per row, rows dequeued in level order; the row image
+//                      (columns + values) lives in LDS; a finished row is published write-through and flagged
+//   k_gilu_solve_sf    the triangular sweeps, 16 lanes per row, four rows per wave; a result is its own ready flag
 //   k_gilu_gather / k_gilu_combine   import on the extended rows / export with the combine mode (fixed
-//                   summation order: bitwise reproducible)
-// A launch per level makes this path latency-bound: a whole-matrix factor of the 100^3 bench system has
-// thousands of levels.  It exists for fidelity with the reference's configuration and for
-// the small systems the reference itself runs on one rank (BASELINE configs[0]); the production path for large
-// systems stays the block stream of ilu.hpp.
+//                      summation order: bitwise reproducible)
+// What bounds it: the dependency chain.  A whole-matrix factor of the periodic 100^3 bench system has 67 084 levels
+// per direction; a hand-off through global memory costs 1.23 us per level in the sweeps and 2.6 us in the
+// factorisation (measured): 165 ms per application, 10.3 s per 49-iteration solve -- 41 s with a
+// launch per level.  It exists for fidelity with the reference's configuration and for the systems the reference
+// itself runs on one rank (BASELINE configs[0]); the production path for large systems stays the block stream of
+// ilu.hpp, whose blocks break the chain.
 #pragma once
 #include <algorithm>
 #include <queue>
@@ -44,6 +48,15 @@ struct isph_schwarz {
   std::vector<int> lptr, uptr;    // host: first entry of every level in lord / uord
   std::vector<int> loc_ptr;       // host: [nsub+1]
   isph::DevBuf<int> err;
+  // synchronisation-free path (one persistent launch per sweep, see k_gilu_solve_sf): the level orders padded so that
+  // every level starts at a multiple of 4 positions (-1 = padding), the two result vectors that double as ready flags,
+  // the per-row "factored" flags and the work counters [0] L sweep, [1] U sweep, [2] factorisation, [3] spin time-out
+  isph::DevBuf<int> lord4, uord4, rowflag, ctr;
+  isph::DevBuf<unsigned long long> ybits, zbits;
+  int n4l = 0, n4u = 0;
+  bool syncfree = true;
+  int *h_tmo = nullptr;   // pinned: the time-out word of the previous application (checked at the next one)
+  int sweep_blocks = 0;   // persistent workgroups (256 threads) of a sweep
 };
 
 namespace isph {
@@ -153,10 +166,205 @@ __global__ __launch_bounds__(256) void k_gilu_upper(int count, const int *__rest
   if (live && sub == 0) w[i] = (w[i] - s) / d;
 }
 
+// ---- synchronisation-free sweeps ----------------------------------------------------------------------------------
+// One launch per triangular sweep instead of one per dependency level (the whole-matrix factor of the 100^3 system has
+// 67 084 L levels: 134 168 launches per application before).  Persistent waves take four consecutive positions of the
+// level order at a time from one device-wide counter (a position's dependencies sit at earlier positions, and a
+// position is only ever held by a running wave, so the sweep cannot deadlock whatever the residency of the grid), 16
+// lanes per row as before.  A result IS its own ready flag: the output vector starts as a signalling-NaN pattern no
+// arithmetic produces, every result is ONE 8-byte write-through (sc1) store, and a consumer polls the very word it
+// needs with sc1 loads -- no flag, no fence (MI355X_MICROARCH.md, hand-off price list, "granule").  Every access to the
+// shared words is an agent-scope atomic on a global-address-space pointer; nothing else touches them in the launch.
+// The arithmetic (lane t, t+16, ... of a row, xor-shuffle sum) is that of k_gilu_lower / k_gilu_upper: same bits.
+// A spin that sees no progress for kSpinLimit polls sets ctr[3] and stores 0 -- every wave drains, the host fails the
+// application loudly.
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) int gi32_t;
+constexpr unsigned long long kGiluSentinel = 0xFFF4A5A5DEADBEEFull;  // signalling NaN, payload of our own
+constexpr int kSpinLimit = 1 << 20;  // polls of one word (~0.2 us each) before a wait gives up
+
+__device__ __forceinline__ unsigned long long sf_load(const unsigned long long *p) {
+  return __hip_atomic_load((const gu64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sf_store(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store((gu64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int sf_flag(const int *p) {
+  return __hip_atomic_load((const gi32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_gilu_fill_bits(int n, unsigned long long *__restrict__ a, unsigned long long *__restrict__ b) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    a[i] = kGiluSentinel;
+    b[i] = kGiluSentinel;
+  }
+}
+
+// A lane's share of a row is handled in chunks of kSfChunk entries: the chunk's factor values and columns are loaded
+// first, then ALL its dependencies are requested together and only the ones still missing are asked for again -- a
+// round of polling costs one memory round trip whatever the number of outstanding words, and nothing but that round
+// trip, the 16-lane sum and the one store sits between a row's last dependency and its own result (the first version
+// walked the entries one after the other: factor loads, then a poll, per entry -- 2.1 us per level against 1.x now;
+// both numbers in DESIGN section 7).
+constexpr int kSfChunk = 6;  // 16 lanes x 6 = 96 entries per round: a whole ILU(0) row of the SPH operators
+
+template <bool UPPER>
+__global__ __launch_bounds__(256) void k_gilu_solve_sf(int npos, const int *__restrict__ order4,
+                                                       const long long *__restrict__ rp, const int *__restrict__ ci,
+                                                       const int *__restrict__ dg, const double *__restrict__ val,
+                                                       const double *__restrict__ rhs, unsigned long long *out,
+                                                       int *ctr) {
+  __shared__ int s_base[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 15, grp = lane >> 4;
+  int *head = ctr + (UPPER ? 1 : 0), *tmo = ctr + 3;
+  for (;;) {
+    // the dequeued position goes through LDS: `if (lane == 0) base = add(); base = readfirstlane(base)` was compiled into
+    // a loop nest in which lane 0 had left the active set at the readfirstlane, which then returned another lane's 0
+    if (lane == 0) s_base[wave] = __hip_atomic_fetch_add((gi32_t *)head, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int base = s_base[wave];
+    if (base >= npos) break;
+    const int pos = base + grp;
+    const int i = pos < npos ? order4[pos] : -1;  // -1: padding at the end of a level
+    double s = 0.0, d = 1.0, ri = 0.0;
+    bool timed_out = sf_flag(tmo) != 0;  // the launch has given up: drain without waiting
+    if (i >= 0) {
+      const long long b = rp[i];
+      const int kd = dg[i];
+      // this lane's entries: first, first + 16, ... below last
+      const long long first = UPPER ? b + kd + 1 + sub : b + sub;
+      const long long last = UPPER ? rp[i + 1] : b + kd;
+      ri = rhs[i];
+      if (UPPER) d = val[b + kd];
+      for (long long q0 = first; q0 < last; q0 += 16 * kSfChunk) {
+        double v[kSfChunk];
+        int c[kSfChunk];
+        unsigned long long x[kSfChunk];
+#pragma unroll
+        for (int k = 0; k < kSfChunk; ++k) {
+          const long long q = q0 + 16 * k;
+          const bool ok = q < last;
+          v[k] = ok ? val[q] : 0.0;
+          c[k] = ok ? ci[q] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < kSfChunk; ++k) x[k] = c[k] >= 0 ? sf_load(out + c[k]) : 0ull;
+        int spins = 0;
+        for (;;) {
+          bool pending = false;
+#pragma unroll
+          for (int k = 0; k < kSfChunk; ++k) pending = pending || x[k] == kGiluSentinel;
+          if (!pending || timed_out) break;
+          __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int k = 0; k < kSfChunk; ++k)
+            if (x[k] == kGiluSentinel) x[k] = sf_load(out + c[k]);
+          if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) timed_out = true;
+        }
+#pragma unroll
+        for (int k = 0; k < kSfChunk; ++k)
+          if (c[k] >= 0) s += v[k] * (x[k] == kGiluSentinel ? 0.0 : __longlong_as_double((long long)x[k]));
+      }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if (__ballot(timed_out) != 0ull) {
+      if (lane == 0) __hip_atomic_store((gi32_t *)tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s = 0.0;
+    }
+    if (i >= 0 && sub == 0) {
+      const double r = UPPER ? (ri - s) / d : ri - s;
+      unsigned long long bits = (unsigned long long)__double_as_longlong(r);
+      if (bits == kGiluSentinel) bits ^= 1ull;  // cannot come out of arithmetic; never leave a dependant waiting
+      sf_store(out + i, bits);
+    }
+  }
+}
+
+// numeric factorisation, one wave per row, rows taken in level order from ctr[2].  A finished row is published by
+// write-through stores of its values, the wave's own s_waitcnt vmcnt(0), then its flag; a consumer polls the flag of the
+// pivot row and reads the pivot row's upper part with sc1 loads.  EVERY access to `val` in this launch is an sc1 atomic
+// (rows share cache lines with their neighbours: one plain load would park a line in L1/L2 that a later sc1 load of the
+// neighbour's finished values could hit).  Same operations in the same order as k_gilu_factor: same bits.
+__global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__restrict__ order,
+                                                       const long long *__restrict__ rp, const int *__restrict__ ci,
+                                                       const int *__restrict__ dg, double *val, int *rowflag, int *ctr,
+                                                       int *__restrict__ err) {
+  extern __shared__ double gilu_lds[];
+  __shared__ int s_pos, s_dead;
+  unsigned long long *vbits = reinterpret_cast<unsigned long long *>(val);
+  const int lane = threadIdx.x;
+  int *tmo = ctr + 3;
+  for (;;) {
+    __syncthreads();  // the previous row's image and position are no longer read
+    if (lane == 0) s_pos = __hip_atomic_fetch_add((gi32_t *)(ctr + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // through LDS, not readfirstlane: see k_gilu_solve_sf
+    const int pos = s_pos;
+    if (pos >= nloc) break;
+    const int i = order[pos];
+    const long long b = rp[i];
+    const int len = (int)(rp[i + 1] - b), nlow = dg[i];
+    double *w = gilu_lds;
+    int *cols = reinterpret_cast<int *>(gilu_lds + len);
+    for (int t = lane; t < len; t += 64) {
+      w[t] = __longlong_as_double((long long)sf_load(vbits + b + t));
+      cols[t] = ci[b + t];
+    }
+    __syncthreads();
+    bool dead = sf_flag(tmo) != 0;  // the launch has given up: drain without waiting
+    for (int t = 0; t < nlow && !dead; ++t) {
+      const int k = cols[t];
+      if (lane == 0) {  // wait until row k is final
+        int spins = 0, gave_up = 0;
+        while (sf_flag(rowflag + k) == 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) {
+            gave_up = 1;
+            break;
+          }
+        }
+        s_dead = gave_up;
+      }
+      __syncthreads();
+      dead = s_dead != 0;
+      if (dead) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: the loads below stay behind the poll
+      const long long kb = rp[k], ke = rp[k + 1];
+      const int kd = dg[k];
+      const double lik = w[t] / __longlong_as_double((long long)sf_load(vbits + kb + kd));
+      __syncthreads();
+      if (lane == 0) w[t] = lik;
+      for (long long q = kb + kd + 1 + lane; q < ke; q += 64) {
+        const int j = ci[q];
+        // binary search for column j among this row's columns right of position t
+        int lo = t + 1, hi = len - 1, p = -1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const int c = cols[mid];
+          if (c == j) { p = mid; break; }
+          if (c < j) lo = mid + 1; else hi = mid - 1;
+        }
+        if (p >= 0) w[p] -= lik * __longlong_as_double((long long)sf_load(vbits + q));
+      }
+      __syncthreads();
+    }
+    if (dead && lane == 0) __hip_atomic_store((gi32_t *)tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (len > nlow && !(fabs(w[nlow]) > 0.0) && lane == 0) atomicOr(err, 2);  // zero pivot (every row, level 0 included)
+    for (int t = lane; t < len; t += 64) sf_store(vbits + b + t, (unsigned long long)__double_as_longlong(w[t]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left before its flag does
+    if (lane == 0) __hip_atomic_store((gi32_t *)(rowflag + i), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 inline void schwarz_destroy(isph_schwarz *S) {
   if (!S) return;
   S->rp.release(); S->ci.release(); S->dg.release(); S->val.release(); S->w.release(); S->rows.release();
   S->lord.release(); S->uord.release(); S->rev_ptr.release(); S->rev_idx.release(); S->err.release();
+  S->lord4.release(); S->uord4.release(); S->rowflag.release(); S->ctr.release(); S->ybits.release(); S->zbits.release();
+  if (S->h_tmo) (void)hipHostFree(S->h_tmo);
   delete S;
 }
 
@@ -172,9 +380,9 @@ inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long l
   rp.assign((size_t)n + 1, 0);
   for (int i = 0; i < n; ++i) rp[(size_t)i + 1] = rp[(size_t)i] + len[(size_t)i];
   const long long nnz = rp[(size_t)n];
-  DevBuf<long long> drp;
-  DevBuf<int> dci;
-  DevBuf<double> dv;
+  DevTmp<long long> drp;
+  DevTmp<int> dci;
+  DevTmp<double> dv;
   ISPH_CHECK(drp.reserve((size_t)n + 1));
   ISPH_CHECK(dci.reserve((size_t)(nnz > 0 ? nnz : 1)));
   ISPH_CHECK(dv.reserve((size_t)(nnz > 0 ? nnz : 1)));
@@ -247,7 +455,7 @@ inline void gilu_symbolic_sub(int m, const long long *lrp, const int *lci, int b
 }
 
 inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_size, int overlap, int combine,
-                          isph_schwarz **out) {
+                          isph_schwarz **out, bool syncfree = true) {
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && overlap >= 0 && (combine == 0 || combine == 1), "bad Schwarz parameters");
   const int n = A->S.nrow;
   std::vector<long long> rp;
@@ -255,7 +463,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   std::vector<double> av;
   ISPH_CHECK(schwarz_host_csr(ctx, A, rp, ci, av));
   isph_schwarz *S = new isph_schwarz();
-  S->n = n; S->fill = fill; S->overlap = overlap; S->combine = combine;
+  S->n = n; S->fill = fill; S->overlap = overlap; S->combine = combine; S->syncfree = syncfree;
   // ---- subdomains: consecutive owned ranges, extended by `overlap` layers (ascending global row per layer)
   const int B = block_size > 0 ? block_size : (n > 0 ? n : 1);
   const int nsub = n > 0 ? (n + B - 1) / B : 0;
@@ -441,6 +649,20 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   std::vector<int> lord, uord;
   bucket(llev, nl, S->lptr, lord);
   bucket(ulev, nu, S->uptr, uord);
+  // the same orders with every level padded to a multiple of four positions: a wave of the synchronisation-free sweeps
+  // takes four consecutive positions, and rows of one wave must not wait for each other
+  auto pad4 = [&](const std::vector<int> &ptr, const std::vector<int> &ord, std::vector<int> &out4) {
+    out4.clear();
+    out4.reserve(ord.size() + 4 * (ptr.size() > 0 ? ptr.size() - 1 : 0));
+    for (size_t l = 0; l + 1 < ptr.size(); ++l) {
+      for (int q = ptr[l]; q < ptr[l + 1]; ++q) out4.push_back(ord[(size_t)q]);
+      while (out4.size() % 4) out4.push_back(-1);
+    }
+  };
+  std::vector<int> lord4, uord4;
+  pad4(S->lptr, lord, lord4);
+  pad4(S->uptr, uord, uord4);
+  S->n4l = (int)lord4.size(); S->n4u = (int)uord4.size();
   // ---- combine lists: global row -> local rows (Add: every copy, Zero: the owned copy), subdomain order
   std::vector<long long> rev_ptr((size_t)n + 1, 0);
   std::vector<int> rev_idx;
@@ -478,21 +700,54 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (rc == ISPH_SUCCESS) rc = up(S->rev_idx, rev_idx);
   if (rc == ISPH_SUCCESS) rc = S->w.reserve((size_t)(nloc > 0 ? nloc : 1));
   if (rc == ISPH_SUCCESS) rc = S->err.reserve(1);
+  if (rc == ISPH_SUCCESS && syncfree) {
+    rc = up(S->lord4, lord4);
+    if (rc == ISPH_SUCCESS) rc = up(S->uord4, uord4);
+    if (rc == ISPH_SUCCESS) rc = S->rowflag.reserve((size_t)(nloc > 0 ? nloc : 1));
+    if (rc == ISPH_SUCCESS) rc = S->ctr.reserve(4);
+    if (rc == ISPH_SUCCESS) rc = S->ybits.reserve((size_t)(nloc > 0 ? nloc : 1));
+    if (rc == ISPH_SUCCESS) rc = S->zbits.reserve((size_t)(nloc > 0 ? nloc : 1));
+    if (rc == ISPH_SUCCESS && hipHostMalloc((void **)&S->h_tmo, sizeof(int), hipHostMallocDefault) != hipSuccess)
+      rc = fail("pinned allocation failed", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) *S->h_tmo = 0;
+  }
   if (rc != ISPH_SUCCESS) { schwarz_destroy(S); return rc; }
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  // persistent workgroups of a sweep (4 waves x 4 rows each).  The sweeps are bound by the hand-off latency of the
+  // dependency chain, not by the rows in flight: 4 ... 256 workgroups gave 11.2 ... 10.1 ms on a 2384-level factor
+  // (profiles/r03_schwarz_syncfree.txt); a quarter of the CUs keeps the pollers off most of the chip
+  S->sweep_blocks = std::max(16, ncu / 4);
   hipError_t e = hipMemsetAsync(S->err.p, 0, sizeof(int), ctx->stream);
-  // ---- numeric factorisation, level by level (level 0 rows have no lower part: nothing to eliminate)
+  // ---- numeric factorisation
   const size_t lds = (size_t)maxrow * 12 + 16;
-  for (int l = 1; l < nl && e == hipSuccess; ++l) {
-    const int cnt = S->lptr[(size_t)l + 1] - S->lptr[(size_t)l];
-    if (cnt == 0) continue;
-    hipLaunchKernelGGL(k_gilu_factor, dim3(cnt), dim3(64), lds, ctx->stream, cnt, S->lord.p + S->lptr[(size_t)l], S->rp.p,
-                       S->ci.p, S->dg.p, S->val.p, S->err.p);
+  int htmo = 0;
+  if (syncfree && nloc > 0) {
+    // one persistent launch: rows in level order, a row waits for the rows it eliminates with (k_gilu_factor_sf)
+    if (e == hipSuccess) e = hipMemsetAsync(S->rowflag.p, 0, sizeof(int) * (size_t)nloc, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(S->ctr.p, 0, 4 * sizeof(int), ctx->stream);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gilu_factor_sf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+      const int waves = std::min(nloc, ncu * 16);
+      hipLaunchKernelGGL(k_gilu_factor_sf, dim3(waves), dim3(64), lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p,
+                         S->val.p, S->rowflag.p, S->ctr.p, S->err.p);
+      e = hipMemcpyAsync(&htmo, S->ctr.p + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    }
+  } else {
+    // level by level (level 0 rows have no lower part; their pivots are checked by the launch of level 0 all the same)
+    for (int l = 0; l < nl && e == hipSuccess; ++l) {
+      const int cnt = S->lptr[(size_t)l + 1] - S->lptr[(size_t)l];
+      if (cnt == 0) continue;
+      hipLaunchKernelGGL(k_gilu_factor, dim3(cnt), dim3(64), lds, ctx->stream, cnt, S->lord.p + S->lptr[(size_t)l], S->rp.p,
+                         S->ci.p, S->dg.p, S->val.p, S->err.p);
+    }
   }
   int herr = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&herr, S->err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host vectors above are read by the async copies
   if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) { schwarz_destroy(S); return fail(hipGetErrorString(e), __FILE__, __LINE__); }
+  if (htmo) { schwarz_destroy(S); return fail("Schwarz ILU factorisation: a row waited for its pivot row beyond the spin limit", __FILE__, __LINE__); }
   if (herr) { schwarz_destroy(S); return fail("zero pivot in the Schwarz ILU factorisation", __FILE__, __LINE__); }
   *out = S;
   return ISPH_SUCCESS;
@@ -502,6 +757,23 @@ inline int schwarz_apply(isph_ctx *ctx, const isph_schwarz *S, const double *r, 
   if (S->n == 0) return ISPH_SUCCESS;
   const int nloc = S->nloc;
   hipLaunchKernelGGL(k_gilu_gather, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nloc, S->rows.p, r, S->w.p);
+  if (S->syncfree) {
+    // two persistent launches: L sweep (rhs = gathered r, results -> ybits), U sweep (rhs = y, results -> zbits)
+    ISPH_REQUIRE(*S->h_tmo == 0, "Schwarz ILU sweep: a row waited for a dependency beyond the spin limit (previous application)");
+    hipLaunchKernelGGL(k_gilu_fill_bits, dim3(stream_grid(nloc)), dim3(kBlock), 0, ctx->stream, nloc, S->ybits.p, S->zbits.p);
+    ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p, 0, 2 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL((k_gilu_solve_sf<false>), dim3(S->sweep_blocks), dim3(256), 0, ctx->stream, S->n4l, (const int *)S->lord4.p,
+                       (const long long *)S->rp.p, (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p,
+                       (const double *)S->w.p, S->ybits.p, S->ctr.p);
+    hipLaunchKernelGGL((k_gilu_solve_sf<true>), dim3(S->sweep_blocks), dim3(256), 0, ctx->stream, S->n4u, (const int *)S->uord4.p,
+                       (const long long *)S->rp.p, (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p,
+                       reinterpret_cast<const double *>(S->ybits.p), S->zbits.p, S->ctr.p);
+    ISPH_CHECK_HIP(hipMemcpyAsync(S->h_tmo, S->ctr.p + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_gilu_combine, dim3((S->n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S->n, S->rev_ptr.p,
+                       S->rev_idx.p, reinterpret_cast<const double *>(S->zbits.p), z);
+    ISPH_CHECK_HIP(hipGetLastError());
+    return ISPH_SUCCESS;
+  }
   for (int l = 1; l < S->nlev_l; ++l) {
     const int cnt = S->lptr[(size_t)l + 1] - S->lptr[(size_t)l];
     if (cnt == 0) continue;

@@ -105,7 +105,7 @@ inline bool sell_cols16(isph_ctx *ctx, const Sell &S) {
   if (S.c16_state != 0) return S.c16_state > 0;
   S.c16_state = -1;
   if (S.nslices == 0 || S.stored == 0) return false;
-  DevBuf<int> flag;
+  DevTmp<int> flag;
   if (flag.reserve(1) != ISPH_SUCCESS || S.col16.reserve((size_t)S.stored) != ISPH_SUCCESS ||
       S.wtab.reserve((size_t)S.nslices * 64) != ISPH_SUCCESS) { flag.release(); return false; }
   int h = 0;

@@ -17,7 +17,7 @@ NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
 KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
-    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
@@ -106,6 +106,7 @@ def lib():
         L.isph_halo_destroy.restype = None
         L.isph_prec_create_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.isph_pool_set_cap.argtypes = [C.c_longlong]
         L.isph_pool_cached_bytes.argtypes = []
         L.isph_pool_cached_bytes.restype = C.c_longlong
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
@@ -219,6 +220,14 @@ def _f64(a):
 def pool_trim():
     """Return the device buffers the library keeps for the next set-up to the driver (isph_pool_trim)."""
     _check(lib().isph_pool_trim())
+
+
+def pool_set_cap(nbytes):
+    """Limit the library's cache of freed device blocks (isph_pool_set_cap; <= 0 restores the default of 80 % of the
+    memory that was free at the first release).  torch's caching allocator does not see this cache: a process that
+    lets torch allocate large tensors next to the library either caps it here or calls pool_trim() when
+    torch.cuda.OutOfMemoryError is raised and retries."""
+    _check(lib().isph_pool_set_cap(int(nbytes)))
 
 
 def pool_cached_bytes():
@@ -438,16 +447,18 @@ class Precond:
 
 
 class SchwarzParams(C.Structure):
-    _fields_ = [("level_of_fill", C.c_int), ("overlap", C.c_int), ("combine", C.c_int), ("block_size", C.c_int)]
+    _fields_ = [("level_of_fill", C.c_int), ("overlap", C.c_int), ("combine", C.c_int), ("block_size", C.c_int),
+                ("level_launches", C.c_int)]
 
 
 class PrecondSchwarz(Precond):
     """isph_prec_create_schwarz: Ifpack_AdditiveSchwarz<ILU(k)> (precond_ifpack.h:28-75).  block_size 0 = one
     subdomain = the whole local matrix (the reference on one rank); combine "add" (reference) | "zero"."""
 
-    def __init__(self, ctx, A, level_of_fill=1, overlap=1, combine="add", block_size=0):
+    def __init__(self, ctx, A, level_of_fill=1, overlap=1, combine="add", block_size=0, level_launches=False):
         self.ctx, self.h, self.n = ctx, C.c_void_p(), A.info()["nrow"]
-        prm = SchwarzParams(int(level_of_fill), int(overlap), {"add": 0, "zero": 1}[combine], int(block_size))
+        prm = SchwarzParams(int(level_of_fill), int(overlap), {"add": 0, "zero": 1}[combine], int(block_size),
+                            int(bool(level_launches)))
         _check(lib().isph_prec_create_schwarz(ctx.h, A.h, C.byref(prm), C.byref(self.h)))
 
     def schwarz_info(self):

@@ -29,7 +29,11 @@ inline int halo_lists_from_import(const Epetra_CrsMatrix &E, HaloLists &H) {
   const int *exp = imp->ExportLIDs();
 #else
   const Epetra_Import *imp = E.Importer();
-  if (!imp) return ISPH_FAILURE;
+  if (!imp) {  // a rank without ghost columns has no importer: empty lists (it still takes part in the collectives)
+    H.peers.clear(); H.send_idx.clear();
+    H.send_ptr.assign(1, 0); H.recv_ptr.assign(1, 0);
+    return E.NumMyCols() == E.NumMyRows() ? ISPH_SUCCESS : ISPH_FAILURE;
+  }
   const int nto = imp->NumSends(), nfrom = imp->NumReceives();
   const int *pto = imp->ProcsTo(), *lto = imp->LengthsTo(), *pfrom = imp->ProcsFrom(), *lfrom = imp->LengthsFrom();
   const int *exp = imp->ExportLIDs();

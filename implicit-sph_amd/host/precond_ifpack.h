@@ -72,12 +72,19 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     // of the neighbouring RANKS (Ifpack ignores it on one rank): level 1 = the rows of the matrix' ghost columns,
     // fetched with the matrix' importer (halo_lists.h) and factored with the rank's own (isph_prec_create_overlap);
     // levels above 1 are factored as level 1 and the notice below says so.
-    if (block == 0 && overlap >= 1 && _A.get() != NULL && _A->NumMyCols() > _A->NumMyRows()) {
+    // The choice is made from rank-uniform information (the parameters and "does ANY rank have ghost columns"): the row
+    // import below is collective, so a rank without ghost columns -- an isolated subdomain -- must enter it as well,
+    // with empty lists, and a failure on one rank must fail all of them.
+    const int any_ghosts = _A.get() != NULL ? _comm.MaxAll(_A->NumMyCols() > _A->NumMyRows() ? 1 : 0) : 0;
+    if (block == 0 && overlap >= 1 && any_ghosts) {
       HaloLists H;
       std::vector<int> rp, ci;
       std::vector<double> v;
-      if (halo_lists_from_import(*_A, H) != ISPH_SUCCESS || extend_rows_one_layer(*_A, _comm, H, rp, ci, v) != ISPH_SUCCESS) {
-        std::fprintf(stderr, ">> PrecondWrapper_Ifpack(HIP): cannot import the rows of the ghost columns (Overlap Level %d)\n", overlap);
+      int bad = halo_lists_from_import(*_A, H) != ISPH_SUCCESS ? 1 : 0;
+      if (_comm.MaxAll(bad) == 0) bad = extend_rows_one_layer(*_A, _comm, H, rp, ci, v) != ISPH_SUCCESS ? 1 : 0;
+      if (_comm.MaxAll(bad)) {
+        if (_comm.MyPID() == 0)
+          std::fprintf(stderr, ">> PrecondWrapper_Ifpack(HIP): cannot import the rows of the ghost columns (Overlap Level %d)\n", overlap);
         return ISPH_FAILURE;
       }
       if (overlap > 1 && _comm.MyPID() == 0 && !_warned) {

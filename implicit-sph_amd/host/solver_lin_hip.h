@@ -215,13 +215,21 @@ class SolverLin_HIP : public SolverLin {
   int ensureContext() {
     if (_ctx) return ISPH_SUCCESS;
     if (!needComm()) return isph_ctx_create(_device, nullptr, &_ctx);
-    char uid[ISPH_UID_BYTES];
-    std::memset(uid, 0, sizeof(uid));
-    if (_comm.MyPID() == 0 && isph_comm_unique_id(uid) != ISPH_SUCCESS) return ISPH_FAILURE;
+    // rank 0 draws the RCCL id; its status travels with the id so that every rank fails together instead of waiting in
+    // a broadcast (or in ncclCommInitRank) for a rank that has already returned
+    struct { int status; char uid[ISPH_UID_BYTES]; } msg;
+    std::memset(&msg, 0, sizeof(msg));
+    if (_comm.MyPID() == 0) msg.status = isph_comm_unique_id(msg.uid);
 #ifdef ISPH_HAVE_MPI
-    MPI_Bcast(uid, ISPH_UID_BYTES, MPI_BYTE, 0, _comm.Comm());
+    MPI_Bcast(&msg, (int)sizeof(msg), MPI_BYTE, 0, _comm.Comm());
+#else
+    if (_comm.NumProc() > 1) {  // cannot happen with the stand-in communicator (one rank); kept for a real Epetra_MpiComm
+      std::fprintf(stderr, ">> SolverLin_HIP: %d ranks need a build with -DISPH_HAVE_MPI (the RCCL id is broadcast over MPI)\n", _comm.NumProc());
+      return ISPH_FAILURE;
+    }
 #endif
-    return isph_ctx_create_dist(_device, nullptr, _comm.MyPID(), _comm.NumProc(), uid, &_ctx);
+    if (msg.status != ISPH_SUCCESS) return ISPH_FAILURE;
+    return isph_ctx_create_dist(_device, nullptr, _comm.MyPID(), _comm.NumProc(), msg.uid, &_ctx);
   }
   // Epetra_Import of the matrix -> isph_mat_set_halo: peers = ProcsTo U ProcsFrom (ascending), per peer the owned rows
   // to send (ExportLIDs, grouped by destination) and the number of ghost values to receive (ghost columns are stored

@@ -52,6 +52,11 @@ void isph_ctx_destroy(isph_ctx *ctx);
  * device and returns them to the driver; isph_pool_cached_bytes() reports how much is held.  No reference counterpart
  * (the reference has no device memory). */
 int isph_pool_trim(void);
+/* Upper limit of the cache in bytes (default: 80 % of the device memory that was free when the
+ * library first gave a block back; bytes <= 0 restores the default).  A process that shares the
+ * device with another allocator (torch, a second library) sets this to what it can spare, or calls
+ * isph_pool_trim() before the other allocator needs the memory. */
+int isph_pool_set_cap(long long bytes);
 long long isph_pool_cached_bytes(void);
 const char *isph_last_error(void);
 
@@ -145,6 +150,9 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
  * export: rows[nloc] (global row of every local row), loc_ptr[nsub+1], factor CSR in local numbering. */
 typedef struct {
   int level_of_fill, overlap, combine, block_size;
+  int level_launches; /* 0 (default): the factorisation and every triangular sweep are ONE persistent launch whose rows
+                         wait for the rows they depend on; 1: one launch per dependency level (the older form, kept as
+                         the cross-check of the first -- both give the same bits) */
 } isph_schwarz_params;
 void isph_schwarz_params_default(isph_schwarz_params *p);
 int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwarz_params *prm, isph_prec **M);

@@ -15,6 +15,12 @@
 
 using namespace LAMMPS_NS;
 
+#ifdef ISPH_HAVE_MPI
+static const MPI_Comm kWorld = MPI_COMM_WORLD;  // built with -DISPH_HAVE_MPI: the real communicator (one rank under mpiexec -n 1 or singleton init)
+#else
+static const MPI_Comm kWorld = 0;
+#endif
+
 // "block": in.bin = n, nnz, H (rp, ci, val) | dim | for each block (i,j) row-major: flag [, nnz, rp, ci, val] |
 // b [dim][n].  Drives createBlockMatrix / setBlock / solveBlockProblem exactly like pair_isph.cpp:944-972, with
 // PrecondWrapper_ML built from H (prec->setMatrix(A.crs), pair_isph.cpp:926).
@@ -45,7 +51,7 @@ static int run_block(const char *fin, const char *fout) {
   if (std::fread(b.data(), 8, b.size(), f) != b.size()) return 2;
   std::fclose(f);
   for (int i = 0; i < n; ++i) gid[(size_t)i] = i + 1;
-  MPI_Comm world = 0;
+  MPI_Comm world = kWorld;
   Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
   Epetra_CrsMatrix H(n, n, rp.data(), ci.data(), val.data());
   PrecondWrapper_ML prec(world);
@@ -95,7 +101,7 @@ static int run_selfhalo(const char *fin, const char *fout, bool overlap, bool ex
   if (std::fread(send_idx.data(), 4, send_idx.size(), f) != send_idx.size()) return 2;
   std::fclose(f);
   for (int i = 0; i < n; ++i) gid[(size_t)i] = i + 1;
-  MPI_Comm world = 0;
+  MPI_Comm world = kWorld;
   Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
   const int me = 0, nrecv = ncol - n;
   Epetra_Import importer(1, &me, &nsend, send_idx.data(), 1, &me, &nrecv);
@@ -140,7 +146,19 @@ static int run_selfhalo(const char *fin, const char *fout, bool overlap, bool ex
   return info.converged ? 0 : 3;
 }
 
+static int run(int argc, char **argv);
 int main(int argc, char **argv) {
+#ifdef ISPH_HAVE_MPI
+  MPI_Init(&argc, &argv);
+  const int rc = run(argc, argv);
+  MPI_Finalize();
+  return rc;
+#else
+  return run(argc, argv);
+#endif
+}
+
+static int run(int argc, char **argv) {
   if (argc > 4 && std::string(argv[4]) == "block") return run_block(argv[1], argv[2]);
   if (argc > 4 && std::string(argv[4]) == "selfhalo") return run_selfhalo(argv[1], argv[2], false);
   if (argc > 4 && std::string(argv[4]) == "selfhalo-overlap") return run_selfhalo(argv[1], argv[2], true);
@@ -158,7 +176,7 @@ int main(int argc, char **argv) {
   for (int i = 0; i < n; ++i) gid[(size_t)i] = i + 1;
   const bool singular = std::atoi(argv[3]) != 0;
 
-  MPI_Comm world = 0;
+  MPI_Comm world = kWorld;
   Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
   Epetra_CrsMatrix AA(n, n, rp.data(), ci.data(), val.data());
 

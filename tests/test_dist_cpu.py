@@ -284,3 +284,125 @@ def test_cpp_adapter_row_import_equals_the_python_plumbing(tmp_path):
     Ac = sps.csr_matrix((vc, cic, rpc), shape=(nxt, nxt))
     Ap = sps.csr_matrix((ve, cie, rpe), shape=(nxt, nxt))
     assert abs(Ac - Ap).max() == 0.0
+
+
+# ------------------------------------------------------------------ the C++ mirror under real MPI, two CPU ranks
+def _worker_rows(rank, world, port, pgrid, dim, n, out):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["ISPH_ORACLE_THREADS"] = "1"
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import isph_amd  # noqa: F401
+        from isph_amd import dist, workload
+        import oracle as orc
+        ncell = tuple(n * g for g in pgrid[:dim])
+        spec = workload.TGVSpec(dim=dim, ncell=ncell, pgrid=pgrid[:dim], rank=rank, brick=(4,) * dim,
+                                origin=(0.5,) * dim if dim == 2 else (0.0,) * 3, mode=workload.JITTER)
+        parts = workload.make_tgv(spec)
+        plan = dist.make_plan(parts, td)
+        nl = parts["nlocal"]
+        P = orc.Particles(parts, plan.colmap, kernel=spec.kernel)
+        orc.lib().orc_compute_volumes(P.ref())
+        P.vfrac[:] = dist.forward_scalar(plan, P.vfrac[:nl].copy(), td).numpy()
+        rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True, rank0=(rank == 0))
+        rpe, cie, ve = dist.extend_rows(plan, rp, ci, val, td)
+        out.put((rank, nl, plan.ncol, rp, ci, val, np.asarray(plan.peers), np.asarray(plan.send_ptr), np.asarray(plan.send_idx),
+                 np.asarray(plan.recv_ptr), (rpe, cie, ve), parts["x"][:nl].copy()))
+    finally:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def test_cpp_mirror_under_mpi_two_ranks(tmp_path):
+    """The -DISPH_HAVE_MPI build of the C++ mirror on two CPU ranks (`mpiexec -n 2`, no device): the importer-driven
+    row import of "Overlap Level" 1 (host/halo_lists.h: MPI_Allgather + MPI_Sendrecv of (length, global ids, values)
+    per peer; ref: precond_ifpack.h:43,60-74) gives the extended subdomains dist.extend_rows builds over gloo on the
+    2-brick box, entry for entry; and SolverLin::createNullVector normalises a masked null vector of UNEQUAL local
+    counts with the global norm (solver_lin.cpp:72-74: Norm2 is an all-reduce), so the pieces form one unit vector."""
+    import subprocess
+    import scipy.sparse as sps
+    from isph_amd import build
+    exes = build.build_cpp_mpi()
+    if exes is None:
+        pytest.skip("no MPI installation (mpi.h / mpiexec) on this machine")
+    world, pgrid, dim, n = 2, (2, 1, 1), 3, 6
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, pgrid, dim, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    masks = []
+    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, ext, x in res:
+        # the fluid mask of a wall-bounded case: different counts on the two ranks
+        mask = (x[:, 0] < (2.0 if rank == 0 else 2.0 * np.pi + 3.5)).astype(np.int32)
+        masks.append(mask)
+        nsend = np.diff(send_ptr); nrecv = np.diff(recv_ptr)
+        to = [k for k in range(len(peers)) if nsend[k] > 0]
+        frm = [k for k in range(len(peers)) if nrecv[k] > 0]
+        with open(tmp_path / ("rank%d.bin" % rank), "wb") as f:
+            np.array([nl, ncol, len(val)], np.int32).tofile(f)
+            rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f); val.tofile(f)
+            np.array([len(to)], np.int32).tofile(f)
+            peers[to].astype(np.int32).tofile(f); nsend[to].astype(np.int32).tofile(f)
+            np.array([int(send_ptr[-1])], np.int32).tofile(f)
+            send_idx.astype(np.int32).tofile(f)
+            np.array([len(frm)], np.int32).tofile(f)
+            peers[frm].astype(np.int32).tofile(f); nrecv[frm].astype(np.int32).tofile(f)
+            mask.tofile(f)
+    assert masks[0].sum() != masks[1].sum() and masks[0].sum() > 0 and masks[1].sum() > 0
+    r = subprocess.run([build.MPIEXEC, "-n", "2", exes[1], str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 of 2" in r.stdout and "rank 1 of 2" in r.stdout
+    total = float(sum(m.sum() for m in masks))
+    pieces = []
+    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, (rpe, cie, ve), x in res:
+        with open(tmp_path / ("ext%d.bin" % rank), "rb") as f:
+            nxt, nnz = np.fromfile(f, np.int32, 2)
+            rpc = np.fromfile(f, np.int32, nxt + 1); cic = np.fromfile(f, np.int32, nnz); vc = np.fromfile(f, np.float64, nnz)
+        assert nxt == ncol and np.array_equal(rpc, rpe)
+        Ac = sps.csr_matrix((vc, cic, rpc), shape=(nxt, nxt))
+        Ap = sps.csr_matrix((ve, cie, rpe), shape=(nxt, nxt))
+        assert abs(Ac - Ap).max() == 0.0
+        nv = np.fromfile(tmp_path / ("nv%d.bin" % rank))
+        assert np.allclose(nv, masks[rank] / np.sqrt(total), rtol=0, atol=1e-15)
+        pieces.append(nv)
+    assert abs(sum(float(p @ p) for p in pieces) - 1.0) < 1e-14          # one unit vector over both ranks
+
+
+def test_cpp_mirror_mpi_build_runs_single_rank(tmp_path):
+    """The -DISPH_HAVE_MPI build of the main C++ driver (real Epetra_MpiComm over MPI_COMM_WORLD, MPI_Bcast of the RCCL
+    id in SolverLin_HIP) is built by build_cpp_mpi; here its device-free mode runs under `mpiexec -n 1` and must agree
+    with the plain build."""
+    import subprocess
+    from isph_amd import build, dist, workload
+    import oracle as orc
+    exes = build.build_cpp_mpi()
+    if exes is None:
+        pytest.skip("no MPI installation (mpi.h / mpiexec) on this machine")
+    spec = workload.TGVSpec(dim=3, ncell=(8, 8, 8), brick=(4, 4, 4), mode=workload.JITTER)
+    parts = workload.make_tgv(spec)
+    plan = dist.make_self_halo_plan(parts)
+    P = orc.Particles(parts, plan.colmap).precompute(corrections=False)
+    rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True)
+    n = parts["nlocal"]
+    fin = tmp_path / "sys.bin"
+    with open(fin, "wb") as f:
+        np.array([n, plan.ncol, len(val)], np.int32).tofile(f)
+        rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f); val.tofile(f); b.tofile(f)
+        np.array([len(plan.send_idx)], np.int32).tofile(f)
+        plan.send_idx.astype(np.int32).tofile(f)
+    outs = []
+    for cmd, name in (([build.MPIEXEC, "-n", "1", exes[0]], "mpi.bin"), ([build.build_cpp_test()], "plain.bin")):
+        r = subprocess.run(cmd + [str(fin), str(tmp_path / name), "1", "selfhalo-extend"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(open(tmp_path / name, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000

@@ -141,3 +141,35 @@ def test_overlap_level_one_across_ranks_through_the_self_peer_plan(fill, combine
         assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n,fill,block,overlap", [(16, 0, 0, 0), (16, 1, 0, 0), (32, 0, 0, 0), (24, 1, 0, 0), (24, 0, 2048, 1)])
+def test_synchronisation_free_sweeps_equal_the_level_launches(gpu_ctx, n, fill, block, overlap):
+    """The persistent form of the factorisation and of the two triangular sweeps (one launch each; a row waits for the
+    very words it depends on, csrc/schwarz.hpp k_gilu_factor_sf / k_gilu_solve_sf) against one launch per dependency
+    level: the same factor and the same application BIT FOR BIT (same operations in the same order), on whole-matrix
+    ILU(0)/ILU(1) with thousands of levels and on overlapping subdomains.  Repeated applications reuse the flag words."""
+    sp = tgv_spec(dim=3, n=n, mode=workload.JITTER)
+    p = workload.make_tgv(sp)
+    colmap = workload.single_rank_colmap(p)
+    vf = hip.compute_volumes(gpu_ctx, p, colmap)
+    A, b = hip.assemble_poisson(gpu_ctx, p, colmap, sp.dt, p["rho"], np.ascontiguousarray(p["v"]),
+                                vfrac=np.ascontiguousarray(vf[p["owner_index"]]))
+    N = p["nlocal"]
+    Ms = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=fill, overlap=overlap, block_size=block)
+    Ml = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=fill, overlap=overlap, block_size=block, level_launches=True)
+    info = Ms.schwarz_info()
+    assert info == Ml.schwarz_info() and info["levels_l"] > (100 if block == 0 else 10)
+    for a, c in zip(Ms.export(), Ml.export()):
+        assert np.array_equal(a, c)
+    rng = np.random.default_rng(n)
+    for rep in range(3):
+        r = rng.standard_normal(N)
+        zs, zl = Ms.apply(r), Ml.apply(r)
+        assert np.all(np.isfinite(zs)) and np.array_equal(zs, zl)
+    xs, xl = np.zeros(N), np.zeros(N)
+    i1 = hip.solve(gpu_ctx, A, b.copy(), xs, prec=Ms, singular=True)
+    i2 = hip.solve(gpu_ctx, A, b.copy(), xl, prec=Ml, singular=True)
+    assert i1.converged == 1 and i1.iters == i2.iters and np.array_equal(xs, xl)
+    for o in (Ms, Ml, A):
+        o.close()
