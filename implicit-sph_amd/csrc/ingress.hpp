@@ -4,8 +4,10 @@
 // everything here is inside what the reference times as "ISPH: solvePoisson", so the 12 B per stored entry have to
 // cross PCIe at the link's rate and nothing else may be on the critical path.
 //
-//   worker threads : pageable -> pinned ring slot (memcpy; the column range check rides along in the same pass)
-//   main thread    : slot -> device CSR image (hipMemcpyAsync on a copy stream), event per slot;
+//   worker threads : pageable -> pinned ring slot: values by memcpy, columns as 16-bit differences to the previous
+//                    column of the row where the rows allow it (10 instead of 12 bytes per entry on the link; the
+//                    range check rides along in the same pass), the first column of every row in a table behind them
+//   main thread    : slot -> device image, ONE hipMemcpyAsync per chunk on a copy stream, event per slot;
 //                    compute stream waits on the event and converts the slices whose rows have fully arrived
 //                    (k_csr_to_sell over a slice range), so only the last chunk's conversion is exposed;
 //   hooks          : work that only needs the rows that are already there is queued behind the conversion --
@@ -30,20 +32,21 @@
 namespace isph {
 
 struct HostStager {
-  static constexpr size_t kChunk = (size_t)4 << 20;  // entries per ring slot: 16 MiB of columns + 32 MiB of values
+  static constexpr size_t kChunk = (size_t)4 << 20;  // entries per ring slot; a slot is 12 bytes per entry = 48 MiB
   int nslots = 0, nthreads = 0;
-  int *pcol = nullptr;      // pinned [nslots][kChunk]
-  double *pval = nullptr;   // pinned [nslots][kChunk]
+  char *pslot = nullptr;    // pinned [nslots][12 * kChunk]: one chunk as it crosses the link (layout: sell.hpp CsrChunks)
   hipStream_t copy_stream = nullptr;
   static constexpr int kAux = 2;
   hipStream_t aux[kAux] = {nullptr, nullptr};  // set-up batches of the fused path, round robin
   hipEvent_t ev_conv = nullptr, ev_aux[kAux] = {nullptr, nullptr};
-  std::vector<hipEvent_t> ev;  // per slot: its last H2D pair has completed
+  std::vector<hipEvent_t> ev;  // per slot: its last copy has completed
   DevBuf<int> flag;            // [0] some row was not column-sorted, [1] a slice has more than 64 column windows
   // wall-clock milestones of the last ingress in ms since its start (isph_ingress_info): [0] workers started and device
   // buffers reserved, [1] all chunks queued on the copy stream, [2] copy stream drained, [3] compute stream drained
-  // (conversion + hooks), [4] end (incl. row sort), [5] of which the main thread waited for staged chunks, [6] chunks, [7] threads
+  // (conversion + hooks), [4] end (incl. row sort), [5] of which the main thread waited for staged chunks, [6] bytes that
+  // crossed the link, [7] threads
   double stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long bytes_sent = 0;    // over the link in the last ingress
   ~HostStager() {
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     for (int k = 0; k < kAux; ++k) {
@@ -52,8 +55,7 @@ struct HostStager {
     }
     if (ev_conv) (void)hipEventDestroy(ev_conv);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    if (pcol) (void)hipHostFree(pcol);
-    if (pval) (void)hipHostFree(pval);
+    if (pslot) (void)hipHostFree(pslot);
     flag.release();
   }
 };
@@ -62,10 +64,11 @@ inline int stager_get(isph_ctx *ctx, HostStager **out) {
   if (!ctx->stager) {
     HostStager *S = new HostStager();
     const unsigned hc = std::thread::hardware_concurrency();
-    S->nthreads = (int)std::min(4u, std::max(1u, hc / 2));  // 4 x 34 GB/s against a 57.6 GB/s link
+    // a staging thread packs and copies ~10 GB/s of entries (0.5 ns for the 16-bit column pass + 0.5 ns for the value copy
+    // per entry); eight of them stay ahead of the 57.6 GB/s link (profiles/r03_dropin.txt)
+    S->nthreads = (int)std::min(8u, std::max(1u, hc / 2));
     S->nslots = S->nthreads + 2;
-    bool ok = hipHostMalloc((void **)&S->pcol, sizeof(int) * HostStager::kChunk * (size_t)S->nslots, hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void **)&S->pval, sizeof(double) * HostStager::kChunk * (size_t)S->nslots, hipHostMallocDefault) == hipSuccess &&
+    bool ok = hipHostMalloc((void **)&S->pslot, 12 * HostStager::kChunk * (size_t)S->nslots, hipHostMallocDefault) == hipSuccess &&
               hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int s = 0; ok && s < S->nslots; ++s) {
       hipEvent_t e = nullptr;
@@ -100,6 +103,11 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
   ISPH_REQUIRE(!is_device_pointer(rowptr) && !is_device_pointer(colidx) && !is_device_pointer(val),
                "device pointer passed with on_device = 0");
   ISPH_REQUIRE(rowptr[0] >= 0 && rowptr[nrow] >= rowptr[0], "rowptr not monotone");
+  {  // the staging threads walk the rows: the row pointers are checked before they start (0.3 ms at 10^6 rows)
+    int bad = 0;
+    for (int i = 0; i < nrow; ++i) bad |= rowptr[i + 1] < rowptr[i];
+    ISPH_REQUIRE(!bad, "rowptr not monotone");
+  }
   const long long nnz = rowptr[nrow];
   HostStager *H = nullptr;
   ISPH_CHECK(stager_get(ctx, &H));
@@ -107,15 +115,20 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   double wait_fill = 0.0;
 
-  // ---- the workers start on the caller's arrays at once; everything below overlaps with their first chunks
   // chunk sizes ramp up (1/8, 1/4, 1/2 of a slot, then whole slots): the link starts after 0.2 ms of staging instead of 1.4
   std::vector<long long> cstart(1, 0);
   for (long long sz = (long long)HostStager::kChunk / 8; cstart.back() < nnz; sz = std::min<long long>(2 * sz, (long long)HostStager::kChunk))
     cstart.push_back(std::min(nnz, cstart.back() + sz));
   const long long nchunks = (long long)cstart.size() - 1;
+  const bool packing = nchunks <= 64 * kModeWords;  // the mode bits travel as a kernel argument
+  std::vector<int> crow((size_t)nchunks + 1, nrow);  // first row that starts at or behind the chunk's first entry
+  for (long long c = 0; c <= nchunks; ++c)
+    crow[(size_t)c] = (int)(std::lower_bound(rowptr, rowptr + nrow + 1, (int)cstart[(size_t)c]) - rowptr);
+
+  // ---- the workers start on the caller's arrays at once; everything below overlaps with their first chunks
   std::mutex mu;
   std::condition_variable cv;
-  std::vector<char> filled((size_t)nchunks, 0), recorded((size_t)nchunks, 0);
+  std::vector<char> filled((size_t)nchunks, 0), recorded((size_t)nchunks, 0);  // filled: 1 = 32-bit columns, 2 = 16-bit differences
   std::atomic<long long> next(0);
   std::atomic<int> bad_col(0), hip_err(0);
   auto worker = [&]() {
@@ -133,21 +146,62 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
         }
         if (state == 1 && hipEventSynchronize(H->ev[(size_t)slot]) != hipSuccess) hip_err.store(1);
       }
-      const long long p0 = cstart[(size_t)c];
-      const size_t cnt = (size_t)(cstart[(size_t)c + 1] - p0);
-      int *dc = H->pcol + (size_t)slot * HostStager::kChunk;
-      const int *sc = colidx + p0;
+      const long long p0 = cstart[(size_t)c], p1 = cstart[(size_t)c + 1];
+      const size_t cnt = (size_t)(p1 - p0);
+      char *base = H->pslot + (size_t)slot * 12 * HostStager::kChunk;
+      memcpy(base, val + p0, sizeof(double) * cnt);
       unsigned over = 0;
-      for (size_t k = 0; k < cnt; ++k) {  // copy + range check in one pass
-        const int cc = sc[k];
-        over |= (unsigned)((unsigned)cc >= (unsigned)ncol);
-        dc[k] = cc;
+      // columns.  One flat pass (it vectorises and runs at copy speed): range check and the 16-bit difference to the
+      // previous entry, row starts included; then one pass over the rows that start here: their first column goes to the
+      // table behind the differences, and a start the flat pass counted as "too wide" (the previous row ended further
+      // right) is taken back.  A real difference outside [0, 65535] -- unsorted rows, or neighbours in a row more than
+      // 65535 columns apart --, or a table that does not fit the chunk's 12 bytes per entry (rows of fewer than two
+      // entries on average), sends the chunk as plain 32-bit columns.
+      const int r0 = crow[(size_t)c], r1 = crow[(size_t)c + 1];
+      const size_t off_rf = (10 * cnt + 3) & ~(size_t)3;
+      bool pack16 = packing && off_rf + 4 * (size_t)(r1 - r0) <= 12 * cnt;
+      if (pack16) {
+        unsigned short *d16 = reinterpret_cast<unsigned short *>(base + 8 * cnt);
+        int *rowfirst = reinterpret_cast<int *>(base + off_rf);
+        const long long q0 = p0 > 0 ? p0 : 1;  // entry 0 has no predecessor (it is a row start)
+        if (p0 == 0) { d16[0] = 0; over |= (unsigned)((unsigned)colidx[0] >= (unsigned)ncol); }
+        const int *src = colidx + q0;
+        unsigned short *dst = d16 + (q0 - p0);
+        const size_t m = (size_t)(p1 - q0);
+        unsigned nw = 0, ov = 0;
+        for (size_t k = 0; k < m; ++k) {
+          const int cc = src[k];
+          const unsigned diff = (unsigned)(cc - src[(ptrdiff_t)k - 1]);
+          nw += diff > 65535u;
+          ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
+          dst[k] = (unsigned short)diff;
+        }
+        over |= ov;
+        long long nwide = nw;
+        for (int r = r0; r < r1; ++r) {
+          const long long rs = rowptr[r];
+          rowfirst[r - r0] = rs < nnz ? colidx[rs] : 0;  // (rows without entries: never read)
+          if (rowptr[r + 1] == rs) continue;
+          d16[rs - p0] = 0;
+          if (rs > 0 && (unsigned)(colidx[rs] - colidx[rs - 1]) > 65535u) --nwide;
+        }
+        if (nwide > 0) pack16 = false;
+      }
+      if (!pack16) {
+        int *dc = reinterpret_cast<int *>(base + 8 * cnt);
+        const int *sc = colidx + p0;
+        unsigned ov = 0;
+        for (size_t k = 0; k < cnt; ++k) {  // plain copy + range check in one pass
+          const int cc = sc[k];
+          ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
+          dc[k] = cc;
+        }
+        over |= ov;
       }
       if (over) bad_col.store(1);
-      memcpy(H->pval + (size_t)slot * HostStager::kChunk, val + p0, sizeof(double) * cnt);
       {
         std::lock_guard<std::mutex> lk(mu);
-        filled[(size_t)c] = 1;
+        filled[(size_t)c] = pack16 ? 2 : 1;
       }
       cv.notify_all();
     }
@@ -169,14 +223,15 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
   const int nthreads = (int)std::min<long long>(H->nthreads, nchunks);
   for (int t = 0; t < nthreads; ++t) pool.th.emplace_back(worker);
 
-  struct Guard {  // every early return gives the matrix and the device CSR image back
+  struct Guard {  // every early return gives the matrix and the device image back
     isph_mat *A = nullptr;
-    DevBuf<int> drp, dci;
-    DevBuf<double> dv;
+    DevBuf<int> drp, dcrow;
+    DevBuf<long long> dcstart;
+    DevBuf<char> stage;
     hipStream_t copy_stream = nullptr;
     ~Guard() {
       (void)hipStreamSynchronize(copy_stream);  // no copy may still read the ring when the next call refills it
-      drp.release(); dci.release(); dv.release();
+      drp.release(); dcrow.release(); dcstart.release(); stage.release();
       if (A) isph_mat_destroy(A);
     }
   } g;
@@ -186,22 +241,17 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
   S.nrow = nrow; S.ncol = ncol; S.nnz = nnz;
   S.nslices = (nrow + kSlice - 1) / kSlice;
 
-  // slice offsets and the widest slice from the host row pointers (and their monotonicity on the way)
+  // slice offsets and the widest slice from the host row pointers
   std::vector<long long> so((size_t)S.nslices + 1, 0);
-  int wmax = 0, wmin = 0;
+  int wmax = 0;
   for (int s = 0; s < S.nslices; ++s) {
     int w = 0;
     const int r1 = std::min(nrow, (s + 1) * kSlice);
-    for (int r = s * kSlice; r < r1; ++r) {
-      const int len = rowptr[r + 1] - rowptr[r];
-      w = std::max(w, len);
-      wmin = std::min(wmin, len);
-    }
+    for (int r = s * kSlice; r < r1; ++r) w = std::max(w, rowptr[r + 1] - rowptr[r]);
     w = (w + 1) & ~1;
     wmax = std::max(wmax, w);
     so[(size_t)s + 1] = so[(size_t)s] + (long long)w * kSlice;
   }
-  ISPH_REQUIRE(wmin >= 0, "rowptr not monotone");
   S.stored = so[(size_t)S.nslices];
   S.wmax = wmax;
   ISPH_CHECK(S.slice_off.reserve((size_t)S.nslices + 1));
@@ -209,19 +259,25 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
   ISPH_CHECK(S.col.reserve((size_t)(S.stored > 0 ? S.stored : 1)));
   ISPH_CHECK(S.val.reserve((size_t)(S.stored > 0 ? S.stored : 1)));
   ISPH_CHECK(g.drp.reserve((size_t)nrow + 1));
-  ISPH_CHECK(g.dci.reserve((size_t)(nnz > 0 ? nnz : 1)));
-  ISPH_CHECK(g.dv.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  ISPH_CHECK(g.stage.reserve((size_t)(nnz > 0 ? 12 * nnz : 16)));
+  ISPH_CHECK(g.dcstart.reserve((size_t)nchunks + 1));
+  ISPH_CHECK(g.dcrow.reserve((size_t)nchunks + 1));
   // small operands (synchronous copies of pageable memory: 4 MB + 125 kB at 1 M rows)
   ISPH_CHECK_HIP(hipMemcpyAsync(g.drp.p, rowptr, sizeof(int) * ((size_t)nrow + 1), hipMemcpyHostToDevice, ctx->stream));
   ISPH_CHECK_HIP(hipMemcpyAsync(S.slice_off.p, so.data(), sizeof(long long) * so.size(), hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(g.dcstart.p, cstart.data(), sizeof(long long) * cstart.size(), hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(g.dcrow.p, crow.data(), sizeof(int) * crow.size(), hipMemcpyHostToDevice, ctx->stream));
   ISPH_CHECK_HIP(hipMemsetAsync(H->flag.p, 0, 2 * sizeof(int), ctx->stream));
   if (nrow > 0)
     hipLaunchKernelGGL(k_csr_rowlen, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, (const int *)g.drp.p, S.rowlen.p);
   if (hooks && hooks->begin) ISPH_CHECK(hooks->begin(g.A));
   H->stats[0] = since();
 
+  CsrChunks ck{};
+  ck.stage = g.stage.p; ck.cstart = g.dcstart.p; ck.crow = g.dcrow.p; ck.nchunks = (int)nchunks;
   int rc = ISPH_SUCCESS;
   int slices_done = 0;
+  long long sent = 0;
   auto convert_upto = [&](long long entries_arrived) {
     // slices whose 64 rows end at or before the last uploaded entry
     int lo = slices_done, hi = S.nslices;
@@ -232,18 +288,20 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
     if (lo > slices_done) {
       const int cnt = lo - slices_done;
       hipLaunchKernelGGL(k_csr_to_sell<int>, dim3((cnt + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, (const int *)g.drp.p,
-                         (const int *)g.dci.p, (const double *)g.dv.p, (const long long *)S.slice_off.p, S.col.p, S.val.p,
-                         slices_done, lo, H->flag.p);
+                         (const int *)nullptr, (const double *)nullptr, (const long long *)S.slice_off.p, S.col.p, S.val.p,
+                         slices_done, lo, H->flag.p, ck);
       const int s0 = slices_done;
       slices_done = lo;
       if (hooks && hooks->slices && rc == ISPH_SUCCESS) rc = hooks->slices(g.A, s0, lo);
     }
   };
   for (long long c = 0; c < nchunks; ++c) {
+    char how = 0;
     {
       const double w0 = since();
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&] { return filled[(size_t)c] != 0; });
+      how = filled[(size_t)c];
       wait_fill += since() - w0;
     }
     const int slot = (int)(c % H->nslots);
@@ -251,13 +309,16 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
     const size_t cnt = (size_t)(cstart[(size_t)c + 1] - p0);
     char state = 1;  // 1: event recorded, 2: nothing to wait for (a HIP call failed; workers must not block on the event)
     if (rc == ISPH_SUCCESS) {
-      if (hipMemcpyAsync(g.dci.p + p0, H->pcol + (size_t)slot * HostStager::kChunk, sizeof(int) * cnt, hipMemcpyHostToDevice, H->copy_stream) != hipSuccess ||
-          hipMemcpyAsync(g.dv.p + p0, H->pval + (size_t)slot * HostStager::kChunk, sizeof(double) * cnt, hipMemcpyHostToDevice, H->copy_stream) != hipSuccess ||
+      // ONE copy per chunk: values, columns and (16-bit mode) the first columns of the rows that start in it
+      const size_t bytes = how == 2 ? ((10 * cnt + 3) & ~(size_t)3) + 4 * (size_t)(crow[(size_t)c + 1] - crow[(size_t)c]) : 12 * cnt;
+      if (how == 2) ck.mode16[c >> 6] |= 1ull << (c & 63);
+      if (hipMemcpyAsync(g.stage.p + 12 * p0, H->pslot + (size_t)slot * 12 * HostStager::kChunk, bytes, hipMemcpyHostToDevice, H->copy_stream) != hipSuccess ||
           hipEventRecord(H->ev[(size_t)slot], H->copy_stream) != hipSuccess ||
           hipStreamWaitEvent(ctx->stream, H->ev[(size_t)slot], 0) != hipSuccess)
         rc = fail("upload of a CSR chunk failed", __FILE__, __LINE__);
       else
         convert_upto(p0 + (long long)cnt);
+      sent += (long long)bytes;
     }
     if (rc != ISPH_SUCCESS) state = 2;
     {
@@ -291,7 +352,8 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
     if (S.c16_state != 1) { S.col16.release(); S.wtab.release(); }
   }
   ISPH_CHECK_HIP(hipGetLastError());
-  H->stats[4] = since(); H->stats[5] = wait_fill; H->stats[6] = (double)nchunks; H->stats[7] = (double)nthreads;
+  H->bytes_sent = sent + 4 * ((long long)nrow + 1);
+  H->stats[4] = since(); H->stats[5] = wait_fill; H->stats[6] = (double)H->bytes_sent; H->stats[7] = (double)nthreads;
   *Aout = g.A;
   g.A = nullptr;
   return ISPH_SUCCESS;

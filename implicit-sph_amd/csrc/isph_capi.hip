@@ -321,7 +321,7 @@ static int mat_from_device_csr_t(isph_ctx *ctx, int nrow, int ncol, const OFF *d
     rc = sell_finalize_offsets(ctx, S);
     if (rc == ISPH_SUCCESS) {
       hipLaunchKernelGGL(k_csr_to_sell<OFF>, dim3((S.nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, drp, dci, dv,
-                         (const long long *)S.slice_off.p, S.col.p, S.val.p, 0, S.nslices, (int *)nullptr);
+                         (const long long *)S.slice_off.p, S.col.p, S.val.p, 0, S.nslices, (int *)nullptr, CsrChunks{});
       rc = rows_sorted ? sell_set_wmax(ctx, S) : sell_sort_rows(ctx, S);
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         rc = fail("CSR->SELL conversion failed", __FILE__, __LINE__);

@@ -96,12 +96,49 @@ __global__ void k_csr_rowlen(int nrow, const int *__restrict__ rowptr, int *__re
   if (row < nrow) rowlen[row] = rowptr[row + 1] - rowptr[row];
 }
 
-// slices [slice_begin, slice_end); unsorted (optional) is raised when a row's columns are not ascending
+// slices [slice_begin, slice_end); unsorted (optional) is raised when a row's columns are not ascending.
+// Chunked image (host ingress, ingress.hpp; ck.stage != nullptr, colidx / cval unused): the entry range is cut into
+// chunks [cstart[c], cstart[c+1]), and chunk c -- cnt entries -- lives at stage + 12 cstart[c] as it crossed the link in
+// ONE copy:   [ cnt fp64 values | columns | first columns of the rows that start in the chunk ]
+// with the columns either cnt 32-bit indices (mode bit 0; no first-column table) or cnt 16-bit differences to the
+// previous column of the same row (mode bit 1: 10 instead of 12 bytes per entry on the link), the table then at the
+// next 4-byte boundary, indexed by row - crow[c].  A lane walks its row front to back anyway, so the running sum of the
+// differences costs nothing.
+constexpr int kModeWords = 8;  // 512 chunks
+struct CsrChunks {
+  const char *stage;
+  const long long *cstart;
+  const int *crow;
+  unsigned long long mode16[kModeWords];
+  int nchunks;
+};
+struct ChunkView {
+  const double *vals;
+  const unsigned short *d16;
+  const int *c32, *rowfirst;
+  long long cbase, cend;
+  int row0;
+  bool m16;
+};
+__device__ __forceinline__ ChunkView chunk_view(const CsrChunks &ck, int ch) {
+  ChunkView v;
+  v.cbase = ck.cstart[ch];
+  v.cend = ck.cstart[ch + 1];
+  const long long cnt = v.cend - v.cbase;
+  const char *base = ck.stage + 12 * v.cbase;
+  v.vals = reinterpret_cast<const double *>(base);
+  v.m16 = (ck.mode16[ch >> 6] >> (ch & 63)) & 1ull;
+  v.d16 = reinterpret_cast<const unsigned short *>(base + 8 * cnt);
+  v.c32 = reinterpret_cast<const int *>(base + 8 * cnt);
+  v.rowfirst = reinterpret_cast<const int *>(base + ((10 * cnt + 3) & ~3ll));
+  v.row0 = ck.crow[ch];
+  return v;
+}
 template <class OFF>
 __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const int *__restrict__ colidx,
                               const double *__restrict__ cval, const long long *__restrict__ slice_off,
                               int *__restrict__ scol, double *__restrict__ sval, int slice_begin, int slice_end,
-                              int *__restrict__ unsorted) {
+                              int *__restrict__ unsorted, CsrChunks ck) {
   const int slice = slice_begin + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int row = slice * kSlice + lane;
@@ -114,18 +151,47 @@ __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const in
     beg = rowptr[row];
     len = (int)(rowptr[row + 1] - beg);
   }
-  // padding repeats a column the row already reads (always in range, also for rectangular operators)
-  const int padcol = len > 0 ? colidx[beg] : 0;
+  const bool chunked = ck.stage != nullptr;
+  int ch = 0;
+  ChunkView cv{};
+  int padcol = 0;  // padding repeats a column the row already reads (always in range, also for rectangular operators)
+  if (len > 0) {
+    if (chunked) {  // chunk of the row's first entry
+      int lo = 0, hi = ck.nchunks - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ck.cstart[mid] <= (long long)beg) lo = mid; else hi = mid - 1;
+      }
+      ch = lo;
+      cv = chunk_view(ck, ch);
+      padcol = cv.m16 ? cv.rowfirst[row - cv.row0] : cv.c32[(long long)beg - cv.cbase];
+    } else {
+      padcol = colidx[beg];
+    }
+  }
   int prev = -1;
   bool desc = false;
   for (int k = 0; k < w; ++k) {
     const long long p = sell_pos(off, lane, k);
     if (k < len) {
-      const int c = colidx[beg + k];
+      const long long q = (long long)beg + k;
+      int c;
+      double v;
+      if (!chunked) {
+        c = colidx[q];
+        v = cval[q];
+      } else {
+        if (q >= cv.cend) cv = chunk_view(ck, ++ch);
+        const long long e = q - cv.cbase;
+        v = cv.vals[e];
+        if (!cv.m16) c = cv.c32[e];
+        else if (k == 0) c = padcol;
+        else c = prev + (int)cv.d16[e];
+      }
       desc = desc || c < prev;
       prev = c;
       scol[p] = c;
-      sval[p] = cval[beg + k];
+      sval[p] = v;
     } else {
       scol[p] = padcol;
       sval[p] = 0.0;

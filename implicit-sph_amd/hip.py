@@ -107,6 +107,7 @@ def lib():
         L.isph_prec_create_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.isph_pool_set_cap.argtypes = [C.c_longlong]
+        L.isph_ingress_info.argtypes = [C.c_void_p, C.c_void_p]
         L.isph_pool_cached_bytes.argtypes = []
         L.isph_pool_cached_bytes.restype = C.c_longlong
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
@@ -220,6 +221,14 @@ def _f64(a):
 def pool_trim():
     """Return the device buffers the library keeps for the next set-up to the driver (isph_pool_trim)."""
     _check(lib().isph_pool_trim())
+
+
+def ingress_info(ctx):
+    """isph_ingress_info: milestones of the context's last host-side matrix ingress (ms), bytes that crossed the link."""
+    a = (C.c_double * 8)()
+    _check(lib().isph_ingress_info(ctx.h, a))
+    return dict(staged_ms=a[0], queued_ms=a[1], copied_ms=a[2], device_done_ms=a[3], end_ms=a[4], waited_for_staging_ms=a[5],
+                link_bytes=int(a[6]), threads=int(a[7]))
 
 
 def pool_set_cap(nbytes):

@@ -84,7 +84,8 @@ int isph_mat_create_csr_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *ro
 /* Diagnostics of the last host-side ingress on this context (milliseconds since its start):
  * [0] staging threads started, device buffers reserved  [1] all chunks queued on the copy stream
  * [2] copy stream drained  [3] compute stream drained (conversion + fused set-up)  [4] end
- * [5] time the queueing thread waited for staged chunks  [6] chunks  [7] staging threads.
+ * [5] time the queueing thread waited for staged chunks  [6] bytes that crossed the link (16-bit
+ * column differences where the rows allow them: 10 instead of 12 per entry)  [7] staging threads.
  * No reference counterpart. */
 int isph_ingress_info(const isph_ctx *ctx, double info[8]);
 /* Halo plan = what Epetra builds inside FillComplete (column map + Import,

@@ -261,8 +261,8 @@ static int run(int argc, char **argv) {
     double gi[8];
     if (li_solver.lastIngressInfo(gi) == ISPH_SUCCESS)
       std::printf("{\"ingress_last_call\": {\"staged_ms\": %.3f, \"queued_ms\": %.3f, \"copied_ms\": %.3f, \"device_done_ms\": %.3f, "
-                  "\"end_ms\": %.3f, \"waited_for_staging_ms\": %.3f, \"chunks\": %.0f, \"threads\": %.0f}}\n",
-                  gi[0], gi[1], gi[2], gi[3], gi[4], gi[5], gi[6], gi[7]);
+                  "\"end_ms\": %.3f, \"waited_for_staging_ms\": %.3f, \"link_bytes\": %.0f, \"link_GBps_while_copying\": %.2f, \"threads\": %.0f}}\n",
+                  gi[0], gi[1], gi[2], gi[3], gi[4], gi[5], gi[6], gi[6] / gi[2] * 1e-6, gi[7]);
   }
   const int rc = timed ? LAMMPS_SUCCESS : li_solver.solveProblem(&prec, "test_solver_lin");
   if (rc != LAMMPS_SUCCESS) return 1;

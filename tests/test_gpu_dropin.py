@@ -52,6 +52,40 @@ def test_host_csr_ingress_round_trip(gpu_ctx, n, maxlen, sort):
     A.close()
 
 
+@pytest.mark.parametrize("n,band,sort", [(3000, 20000, True), (200000, 30000, True), (200000, 30000, False), (50000, 400000, True)])
+def test_host_csr_ingress_packs_columns_where_the_rows_allow_it(gpu_ctx, n, band, sort):
+    """Rows whose sorted neighbours lie less than 65536 columns apart cross the link as 16-bit differences (10 bytes
+    per entry instead of 12, the first column of every row in a table): the matrix must come out the same, and the
+    ingress must report the smaller transfer.  Unsorted rows and rows with wider gaps go as 32-bit columns."""
+    rng = np.random.default_rng(band)
+    ncol = n + band
+    lens = rng.integers(1, 40, size=n)
+    rp = np.zeros(n + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = np.empty(rp[-1], np.int32)
+    for i in range(n):
+        c = i + rng.choice(band, size=lens[i], replace=False)
+        ci[rp[i]:rp[i + 1]] = np.sort(c) if sort else c
+    val = rng.standard_normal(rp[-1])
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val, ncol=ncol)
+    info = hip.ingress_info(gpu_ctx)
+    nnz = int(rp[-1])
+    packed = sort and band <= 65536
+    if packed:
+        assert info["link_bytes"] < 10.5 * nnz + 8 * n + 64, info
+    else:
+        assert info["link_bytes"] >= 12 * nnz, info
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp)
+    if sort:
+        assert np.array_equal(ci2, ci) and np.array_equal(v2, val)
+    else:
+        for i in range(0, n, 997):
+            o = np.argsort(ci[rp[i]:rp[i + 1]], kind="stable")
+            assert np.array_equal(ci2[rp[i]:rp[i + 1]], ci[rp[i]:rp[i + 1]][o]) and np.array_equal(v2[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]][o])
+    A.close()
+
+
 def test_host_csr_ingress_refuses_bad_operands(gpu_ctx):
     rp = np.array([0, 2, 4], np.int32)
     ci = np.array([0, 1, 0, 5], np.int32)          # column 5 of a 2-column matrix, found by the copy pass
@@ -112,13 +146,15 @@ def test_dropin_solver_lin_at_config1_size(gpu_ctx, tmp_path):
     print("dropin:", rec)
 
 
-@pytest.mark.parametrize("n,block,shuffle", [(16, 512, False), (40, 512, False), (40, 256, False), (24, 512, True)])
-def test_fused_ingress_equals_separate_calls(gpu_ctx, n, block, shuffle):
+@pytest.mark.parametrize("n,block,shuffle,brick", [(16, 512, False, 8), (40, 512, False, 8), (40, 256, False, 8), (24, 512, True, 8),
+                                                   (40, 512, False, 1)])
+def test_fused_ingress_equals_separate_calls(gpu_ctx, n, block, shuffle, brick):
     """isph_mat_create_csr_bjacobi (ILU(0) set-up queued range by range behind the arriving rows) against
     isph_mat_create_csr + isph_prec_create: the same matrix, the same factor and the same application, bit for bit.
     40^3 = 64 000 rows x 104 entries is more than one 4 Mi-entry chunk and several set-up batches; `shuffle` hands over
-    rows that are not column-sorted (the fused set-up is then redone on the sorted image)."""
-    sp = tgv_spec(dim=3, n=n, mode=workload.JITTER)
+    rows that are not column-sorted (the fused set-up is then redone on the sorted image); brick 1 = lexicographic
+    particle order, whose rows cross the link as 16-bit column differences."""
+    sp = tgv_spec(dim=3, n=n, mode=workload.JITTER, brick=brick)
     p = workload.make_tgv(sp)
     colmap = workload.single_rank_colmap(p)
     vf = hip.compute_volumes(gpu_ctx, p, colmap)
