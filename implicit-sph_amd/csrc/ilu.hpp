@@ -42,6 +42,12 @@ struct isph_ilu {
   isph::DevBuf<int> llev;         // [n] L-level of every row (level-synchronous factorisation)
   isph::DevBuf<double> dinv;      // [n] 1/d_i
   isph::DevBuf<long long> boff;   // [nblocks+1] first factor entry of every block (multiples of 64)
+  // exact stream sizing (large streams: a counting pass of the schedule, then the fill): 64 x the running chunk count of
+  // the blocks, used in place of boff -- with capacity factor 1 and no slack -- wherever the stream is addressed
+  isph::DevBuf<long long> sboff;
+  bool exact = false;
+  long long stream_entries = 0;  // exact mode: 64 x the chunks the schedule counted
+  const long long *stream_off() const { return exact ? sboff.p : boff.p; }
   isph::DevBuf<unsigned char> flev;  // level of fill of every factor entry (ILU(k) symbolic phase only)
   long long stream_chunks = 0;
   long long total = 0;      // entries reserved for the factor (ILU(0): A's sliced-ELL size; ILU(k): sum of the blocks)
@@ -372,6 +378,27 @@ __global__ void k_ilu_boff0(int nblocks, int B, int nslices, const long long *__
   if (b <= nblocks) boff[b] = slice_off[min((long long)b * (B / 64), (long long)nslices)];
 }
 
+// exact stream offsets from the counting pass: sboff[b] = 64 x (chunks of the blocks before b), sboff[nblocks] = 64 x total
+__global__ __launch_bounds__(1024) void k_ilu_exact_offsets(int nblocks, const int *__restrict__ blkinfo, long long *__restrict__ sboff) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const int per = (nblocks + 1023) / 1024;
+  const int b0 = min(t * per, nblocks), b1 = min(b0 + per, nblocks);
+  long long sum = 0;
+  for (int b = b0; b < b1; ++b) sum += (long long)blkinfo[4 * b] + blkinfo[4 * b + 1];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const long long v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  long long run = t > 0 ? part[t - 1] : 0;
+  for (int b = b0; b < b1; ++b) { sboff[b] = run * 64; run += (long long)blkinfo[4 * b] + blkinfo[4 * b + 1]; }
+  if (t == 1023) sboff[nblocks] = part[1023] * 64;
+}
+
 __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long long *__restrict__ boff,
                                                        const long long *__restrict__ frp,
                                                        const int *__restrict__ fcol, const int *__restrict__ flen,
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
                                                        int capf, int slack, int *__restrict__ err,
                                                        const double *__restrict__ sgs_fval,
-                                                       const double *__restrict__ sgs_dinv, int b0) {
+                                                       const double *__restrict__ sgs_dinv, int b0, int count_only) {
   extern __shared__ int lds_i[];
   int *levL = lds_i;             // [B] level of every row in the L solve
   int *levU = levL + B;          // [B] ... in the U solve
@@ -406,16 +433,18 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   const int t = threadIdx.x;
   const bool active = t < m;
   const int i = blo + t;
-  const long long region = boff[b + 1] - boff[b];
-  const long long cap = capf * (region >> 6) + slack;
-  const long long base = ilu_base_chunk(boff, b, capf, slack);
+  // count_only: the pass that sizes the stream exactly -- levels, ranks and steps as below, the chunk counts go to
+  // blkinfo, nothing is written to the stream (which does not exist yet), nothing can overflow
+  const long long region = count_only ? 0 : boff[b + 1] - boff[b];
+  const long long cap = count_only ? 0x7fffffffffffffffLL : capf * (region >> 6) + slack;
+  const long long base = count_only ? 0 : ilu_base_chunk(boff, b, capf, slack);
   long long rp = 0;
   int len = 0, dg = 0;
   if (active) {
     rp = frp[i];
     len = flen[i];
     dg = fdiag[i];
-    fdst[rp + dg] = -1;
+    if (!count_only) fdst[rp + dg] = -1;
     srp[t] = rp; slen[t] = len; sdg[t] = dg;
   }
   __syncthreads();
@@ -553,6 +582,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
     }
     __syncthreads();
     if ((long long)used + s_nch > cap) return;  // uniform exit; host reports the error
+    if (count_only) { used += s_nch; __syncthreads(); continue; }
     // ---- emission.  A wave writes the rows of its own 64 threads one after the other, lanes over the row's stream
     // entries: entry x of a row sits at factor slot rp + d0 + x (consecutive lanes read consecutive slots) and goes to
     // chunk x / g, lane ls + x % g (runs of g consecutive stream words).  (One thread per row made every access of a
@@ -902,7 +932,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
 inline void ilu_destroy(isph_ilu *F) {
   if (!F) return;
   F->frp.release(); F->fcol.release(); F->flen.release(); F->fdiag.release(); F->err.release(); F->fval.release();
-  F->boff.release(); F->flev.release();
+  F->boff.release(); F->sboff.release(); F->flev.release();
   F->sv.release(); F->sc.release(); F->si.release(); F->sperm.release(); F->fdst.release(); F->blkinfo.release(); F->dinv.release(); F->llev.release();
   delete F;
 }
@@ -996,8 +1026,19 @@ inline int ilu_symbolic(isph_ctx *ctx, isph_ilu *F, int K) {
 // ---- set-up in pieces: allocations that only need the matrix' SHAPE (ilu_begin), then extract / schedule / factor over
 // ranges of blocks.  ilu_create runs them over all blocks with the host check between schedule and factorisation; the
 // host CSR ingress (ingress.hpp) queues them range by range behind the rows that have arrived over PCIe.
+// above this size (10 bytes per stream entry at the capacity rule's factor 2) the stream is sized exactly by a counting
+// pass of the schedule: the 4 M x 749 operator of BASELINE configs[4] would reserve 110 GB for a 55 GB Gauss-Seidel stream
+inline long long &ilu_exact_stream_bytes() {
+  static long long v = 4LL << 30;  // isph_set_exact_stream_threshold
+  return v;
+}
+inline bool ilu_wants_exact_stream(const isph_ilu *F) {
+  const long long rule_chunks = kCapFactor * (F->total >> 6) + (long long)(kPadChunks + 2 * F->B) * (F->nblocks + 1) + kPadChunks;
+  return rule_chunks * 64 * 10 > ilu_exact_stream_bytes();
+}
 inline int ilu_size_stream(isph_ilu *F) {
-  F->stream_chunks = F->capf * (F->total >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
+  const long long entries = F->exact ? F->stream_entries : F->total;
+  F->stream_chunks = F->capf * (entries >> 6) + (long long)(kPadChunks + F->slack) * (F->nblocks + 1) + kPadChunks;
   int r = F->sv.reserve((size_t)F->stream_chunks * 64);
   if (r == ISPH_SUCCESS) r = F->sc.reserve((size_t)F->stream_chunks * 64);
   if (r == ISPH_SUCCESS) r = F->si.reserve((size_t)F->stream_chunks + 64);
@@ -1043,12 +1084,12 @@ inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int
 }
 
 // ILU(0) only: block regions = the sliced-ELL regions of the blocks' rows, the stream sized from them
-inline int ilu_begin_fill0(isph_ctx *ctx, isph_ilu *F, const Sell &S) {
+inline int ilu_begin_fill0(isph_ctx *ctx, isph_ilu *F, const Sell &S, bool size_stream = true) {
   if (S.nrow == 0) return ISPH_SUCCESS;
   hipLaunchKernelGGL(k_ilu_boff0, dim3((F->nblocks + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, F->nblocks,
                      F->B, S.nslices, (const long long *)S.slice_off.p, F->boff.p);
   ISPH_CHECK(F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1)));
-  return ilu_size_stream(F);
+  return size_stream ? ilu_size_stream(F) : ISPH_SUCCESS;
 }
 
 // st: the stream of a ranged launch (ingress.hpp runs consecutive ranges on alternating streams); default ctx->stream
@@ -1059,13 +1100,14 @@ inline void ilu_launch_extract(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0
                      F->fval.p, F->flen.p, F->fdiag.p, F->err.p, b0);
 }
 
-inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, bool sgs, hipStream_t st = nullptr) {
+inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, bool sgs, hipStream_t st = nullptr,
+                                bool count_only = false) {
   const size_t Bz = (size_t)F->B;
   const size_t lds_s = sizeof(int) * (14 * Bz + 10) + sizeof(long long) * Bz;
-  hipLaunchKernelGGL(k_ilu_schedule, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->boff.p, F->frp.p, F->fcol.p,
+  hipLaunchKernelGGL(k_ilu_schedule, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->stream_off(), F->frp.p, F->fcol.p,
                      F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p, F->blkinfo.p, F->llev.p, F->capf,
                      F->slack, F->err.p, sgs ? (const double *)F->fval.p : (const double *)nullptr,
-                     sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0);
+                     sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0, count_only ? 1 : 0);
 }
 
 // err_dev != nullptr: the kernel itself skips its blocks when the set-up so far has raised an error (ranged launches)
@@ -1081,11 +1123,11 @@ inline int ilu_launch_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, 
   ISPH_CHECK_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
   if (wide)
     hipLaunchKernelGGL((k_ilu_factor<kIluWaves, true>), dim3(nb), dim3(kIluWaves * 64), lds_f, st, S.nrow, F->B, W,
-                       F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->boff.p,
+                       F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->stream_off(),
                        F->capf, F->slack, b0, err_dev);
   else
     hipLaunchKernelGGL((k_ilu_factor<kIluWaves, false>), dim3(nb), dim3(kIluWaves * 64), lds_f, st, S.nrow, F->B, W,
-                       F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->boff.p,
+                       F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->stream_off(),
                        F->capf, F->slack, b0, err_dev);
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
@@ -1098,12 +1140,27 @@ inline int ilu_schedule_and_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, bo
   if (sgs)  // pivots first: the schedule writes the Gauss-Seidel stream values itself
     hipLaunchKernelGGL(k_sgs_pivots, dim3((S.nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S.nrow, F->frp.p,
                        F->fval.p, F->fdiag.p, F->dinv.p);
+  if (F->exact) {  // counting pass: chunk counts per block -> exact offsets -> a stream of exactly that size
+    rc = F->sboff.reserve((size_t)F->nblocks + 1);
+    if (rc == ISPH_SUCCESS) {
+      ilu_launch_schedule(ctx, F, S, 0, F->nblocks, sgs, nullptr, /*count_only=*/true);
+      hipLaunchKernelGGL(k_ilu_exact_offsets, dim3(1), dim3(1024), 0, ctx->stream, F->nblocks, (const int *)F->blkinfo.p, F->sboff.p);
+      long long total = 0;
+      if (hipMemcpyAsync(&total, F->sboff.p + F->nblocks, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = fail("copy failed", __FILE__, __LINE__);
+      if (rc == ISPH_SUCCESS) rc = ilu_check_err(ctx, F, "ILU extract/schedule (counting pass) failed");
+      F->stream_entries = total;
+      F->capf = 1; F->slack = 0;
+      if (rc == ISPH_SUCCESS) rc = ilu_size_stream(F);
+    }
+  }
   for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS; ++attempt) {
     ilu_launch_schedule(ctx, F, S, 0, F->nblocks, sgs);
     // the factor kernel must not run on a partial schedule: check now (one sync per build)
     bool overflow = false;
     rc = ilu_check_err(ctx, F, "ILU extract/schedule kernel failed", attempt == 0 ? &overflow : nullptr);
     if (!overflow) break;
+    if (F->exact) { rc = fail("ILU stream: the fill pass needed more chunks than the counting pass found", __FILE__, __LINE__); break; }
     F->capf = kCapFactorSafe; F->slack = 2 * F->B;  // proven bound, see kCapFactorSafe
     rc = ilu_size_stream(F);
     if (rc == ISPH_SUCCESS && hipMemsetAsync(F->err.p, 0, sizeof(int), ctx->stream) != hipSuccess)
@@ -1129,9 +1186,11 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
     if (fill > 0) {
       rc = ilu_symbolic(ctx, F, fill);
       if (rc == ISPH_SUCCESS) rc = F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1));
-      if (rc == ISPH_SUCCESS) rc = ilu_size_stream(F);
+      F->exact = ilu_wants_exact_stream(F);
+      if (rc == ISPH_SUCCESS && !F->exact) rc = ilu_size_stream(F);
     } else {
-      rc = ilu_begin_fill0(ctx, F, S);
+      F->exact = ilu_wants_exact_stream(F);
+      rc = ilu_begin_fill0(ctx, F, S, /*size_stream=*/!F->exact);
     }
     if (rc == ISPH_SUCCESS) rc = ilu_schedule_and_factor(ctx, F, S, sgs);
   }
@@ -1301,7 +1360,7 @@ inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double
     ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_solve_stream_multi<WV, kPrefetch, NV>),         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
     hipLaunchKernelGGL((k_ilu_solve_stream_multi<WV, kPrefetch, NV>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, \
-                       ctx->stream, F->n, F->B, F->nblocks, F->boff.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p,               \
+                       ctx->stream, F->n, F->B, F->nblocks, F->stream_off(), F->sv.p, F->sc.p, F->si.p, F->sperm.p,               \
                        F->blkinfo.p, F->dinv.p, X, F->capf, F->slack);                                                      \
   } while (0)
   if (K == 2) ISPH_ILU_LAUNCH_MULTI(2);
@@ -1324,7 +1383,7 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
       ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_solve_stream<WV, PF>),                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
     hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, \
-                       F->n, F->B, F->nblocks, F->boff.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->blkinfo.p,          \
+                       F->n, F->B, F->nblocks, F->stream_off(), F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->blkinfo.p,          \
                        F->dinv.p, r, z, F->capf, F->slack);                                                             \
   } while (0)
   if (pf == 12) ISPH_ILU_LAUNCH(12);

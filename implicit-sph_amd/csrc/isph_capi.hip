@@ -262,6 +262,11 @@ int isph_pool_trim(void) {
   return ISPH_SUCCESS;
 }
 
+int isph_set_exact_stream_threshold(long long bytes) {
+  ilu_exact_stream_bytes() = bytes >= 0 ? bytes : (4LL << 30);
+  return ISPH_SUCCESS;
+}
+
 int isph_pool_set_cap(long long bytes) {
   DevPool &p = DevPool::get();
   {
@@ -517,6 +522,36 @@ int isph_mat_info(const isph_mat *A, long long info[6]) {
   ISPH_REQUIRE(A && info, "NULL argument");
   info[0] = A->S.nrow; info[1] = A->S.ncol; info[2] = A->S.nnz; info[3] = A->S.nslices;
   info[4] = A->S.stored; info[5] = A->S.stored * 12 + ((long long)A->S.nslices + 1) * 8;
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_export_rows(isph_ctx *ctx, const isph_mat *A, int row_begin, int nrows, long long *rowptr, int *colidx,
+                         double *val, long long capacity) {
+  ISPH_REQUIRE(ctx && A && rowptr && colidx && val, "NULL argument");
+  const Sell &S = A->S;
+  ISPH_REQUIRE(row_begin >= 0 && nrows >= 0 && (long long)row_begin + nrows <= S.nrow, "row range outside the matrix");
+  std::vector<int> len((size_t)(nrows > 0 ? nrows : 1));
+  if (nrows > 0) ISPH_CHECK_HIP(hipMemcpyAsync(len.data(), S.rowlen.p + row_begin, sizeof(int) * (size_t)nrows, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  rowptr[0] = 0;
+  for (int i = 0; i < nrows; ++i) rowptr[i + 1] = rowptr[i] + len[(size_t)i];
+  const long long nnz = rowptr[nrows];
+  ISPH_REQUIRE(nnz <= capacity, "isph_mat_export_rows: colidx / val too small for the requested rows");
+  if (nnz == 0) return ISPH_SUCCESS;
+  DevTmp<long long> drp;
+  DevTmp<int> dci;
+  DevTmp<double> dv;
+  ISPH_CHECK(drp.reserve((size_t)nrows + 1));
+  ISPH_CHECK(dci.reserve((size_t)nnz));
+  ISPH_CHECK(dv.reserve((size_t)nnz));
+  ISPH_CHECK_HIP(hipMemcpyAsync(drp.p, rowptr, sizeof(long long) * ((size_t)nrows + 1), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_sell_rows_to_csr, dim3((nrows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_begin, nrows,
+                     (const int *)S.rowlen.p, (const long long *)S.slice_off.p, (const int *)S.col.p, (const double *)S.val.p,
+                     (const long long *)drp.p, dci.p, dv.p);
+  ISPH_CHECK_HIP(hipMemcpyAsync(colidx, dci.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(val, dv.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
 

@@ -274,6 +274,25 @@ __global__ void k_sell_to_csr(int nrow, const int *__restrict__ rowlen, const lo
   }
 }
 
+// rows [row0, row0 + n) only, row pointers relative to the range (ranged export for host-side checks at sizes where
+// the whole matrix does not fit a 32-bit CSR)
+__global__ void k_sell_rows_to_csr(int row0, int n, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
+                                   const int *__restrict__ scol, const double *__restrict__ sval,
+                                   const long long *__restrict__ rowptr, int *__restrict__ colidx,
+                                   double *__restrict__ cval) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int row = row0 + t;
+  const long long off = slice_off[row >> 6];
+  const int lane = row & 63;
+  const long long beg = rowptr[t];
+  for (int k = 0; k < rowlen[row]; ++k) {
+    const long long p = sell_pos(off, lane, k);
+    colidx[beg + k] = scol[p];
+    cval[beg + k] = sval[p];
+  }
+}
+
 // ---- SpMV ----------------------------------------------------------------
 // One wavefront per slice, lane == row.  UNROLL pair-columns are issued
 // back-to-back so each lane keeps UNROLL 16-B value loads, UNROLL 8-B index

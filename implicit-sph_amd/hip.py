@@ -17,8 +17,8 @@ NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
 KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
-    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
-    "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr",
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
+    "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
@@ -107,6 +107,7 @@ def lib():
         L.isph_prec_create_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.isph_pool_set_cap.argtypes = [C.c_longlong]
+        L.isph_set_exact_stream_threshold.argtypes = [C.c_longlong]
         L.isph_ingress_info.argtypes = [C.c_void_p, C.c_void_p]
         L.isph_pool_cached_bytes.argtypes = []
         L.isph_pool_cached_bytes.restype = C.c_longlong
@@ -119,6 +120,7 @@ def lib():
                                         C.c_void_p]
         L.isph_mat_info.argtypes = [C.c_void_p, C.c_void_p]
         L.isph_mat_export_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_mat_export_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         L.isph_mat_destroy.argtypes = [C.c_void_p]
         L.isph_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_spmv_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -237,6 +239,12 @@ def pool_set_cap(nbytes):
     lets torch allocate large tensors next to the library either caps it here or calls pool_trim() when
     torch.cuda.OutOfMemoryError is raised and retries."""
     _check(lib().isph_pool_set_cap(int(nbytes)))
+
+
+def set_exact_stream_threshold(nbytes):
+    """isph_set_exact_stream_threshold: ILU / Gauss-Seidel streams whose capacity-rule reservation exceeds nbytes are sized
+    by a counting pass instead (default 4 GiB; 0 = always exact; < 0 = default)."""
+    _check(lib().isph_set_exact_stream_threshold(int(nbytes)))
 
 
 def pool_cached_bytes():
@@ -376,6 +384,33 @@ class Matrix:
         v = np.zeros(i["nnz"])
         _check(lib().isph_mat_export_csr(self.ctx.h, self.h, _ptr(rp), _ptr(ci), _ptr(v)))
         return rp, ci, v
+
+    def export_rows(self, row_begin, nrows, capacity=None):
+        """isph_mat_export_rows: rows [row_begin, row_begin + nrows) as (rowptr int64 relative, colidx, val)."""
+        cap = int(capacity if capacity is not None else nrows * 4096)
+        rp = np.zeros(nrows + 1, dtype=np.int64)
+        ci = np.zeros(cap, dtype=np.int32)
+        v = np.zeros(cap)
+        _check(lib().isph_mat_export_rows(self.ctx.h, self.h, int(row_begin), int(nrows), _ptr(rp), _ptr(ci), _ptr(v), cap))
+        return rp, ci[:rp[-1]], v[:rp[-1]]
+
+    def sampled_product(self, x, nsamples=64, rows_per_sample=64, seed=0):
+        """(A x) on `nsamples` runs of `rows_per_sample` consecutive rows, computed ON THE HOST from exported rows: an
+        operator application that shares nothing with the SpMV kernels.  Returns (row indices, values)."""
+        n = self.info()["nrow"]
+        xh = x.detach().cpu().numpy() if _is_torch(x) else np.asarray(x)
+        rng = np.random.default_rng(seed)
+        starts = np.unique(np.minimum(rng.integers(0, max(n - rows_per_sample, 0) + 1, size=nsamples), max(n - rows_per_sample, 0)))
+        rows, vals, mags = [], [], []
+        for s0 in starts:
+            m = min(rows_per_sample, n - int(s0))
+            rp, ci, v = self.export_rows(int(s0), m)
+            prod = v * xh[ci]
+            vals.append(np.add.reduceat(prod, rp[:-1]) * (np.diff(rp) > 0) if len(prod) else np.zeros(m))
+            mags.append(np.add.reduceat(np.abs(prod), rp[:-1]) * (np.diff(rp) > 0) if len(prod) else np.zeros(m))
+            rows.append(np.arange(int(s0), int(s0) + m))
+        self.last_sample_magnitude = np.concatenate(mags)     # sum_j |a_ij x_j| per sampled row: the scale of its round-off
+        return np.concatenate(rows), np.concatenate(vals)
 
     def spmv(self, x, y=None):
         x = _f64(x)

@@ -57,6 +57,12 @@ int isph_pool_trim(void);
  * device with another allocator (torch, a second library) sets this to what it can spare, or calls
  * isph_pool_trim() before the other allocator needs the memory. */
 int isph_pool_set_cap(long long bytes);
+/* The triangular-solve stream of the block ILU / Gauss-Seidel set-up is reserved at twice a proven bound of its size
+ * (one pass, no counting) unless that reservation exceeds this many bytes; above it the schedule first counts the
+ * chunks of every block and the stream is allocated exactly (one more pass over the factor pattern, half the memory:
+ * the smoother of the 4 M x 749 operator of BASELINE configs[4] takes 55 GB instead of 110).  Default 4 GiB;
+ * bytes < 0 restores it, 0 sizes every stream exactly.  Process-wide.  No reference counterpart. */
+int isph_set_exact_stream_threshold(long long bytes);
 long long isph_pool_cached_bytes(void);
 const char *isph_last_error(void);
 
@@ -110,6 +116,12 @@ void isph_halo_destroy(isph_halo_plan *plan);
 int isph_mat_info(const isph_mat *A, long long info[6]);
 /* Export as CSR with sorted columns (device->host); caller sizes from info. */
 int isph_mat_export_csr(isph_ctx *ctx, const isph_mat *A, int *rowptr, int *colidx, double *val);
+/* Rows [row_begin, row_begin + nrows) as CSR, row pointers relative to the range (64-bit), columns ascending; fails
+ * when the rows hold more than `capacity` entries.  For host-side checks of matrices beyond a 32-bit CSR (the
+ * 3*10^9-entry operator of BASELINE configs[4]): a test exports a few thousand sampled rows and multiplies them itself.
+ * No reference counterpart (Epetra_CrsMatrix::ExtractMyRowView is the closest). */
+int isph_mat_export_rows(isph_ctx *ctx, const isph_mat *A, int row_begin, int nrows, long long *rowptr, int *colidx,
+                         double *val, long long capacity);
 void isph_mat_destroy(isph_mat *A);
 
 /* y = A x  (Epetra_CrsMatrix::Apply incl. the ghost Import; ref: solver_lin.h:133).

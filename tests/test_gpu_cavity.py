@@ -9,6 +9,8 @@ import scipy.sparse as sps
 from isph_amd import hip, workload
 import oracle as orc
 
+from sampled_check import assert_spmv_matches_host_on_sampled_rows
+
 pytestmark = pytest.mark.gpu
 
 THETA, BETA = 1.0, 0.1          # lid-driven-cavity.xml: theta 1.0, beta 0.1
@@ -136,7 +138,9 @@ def test_wall_bounded_poisson_every_singular_mode_and_preconditioner(gpu_ctx, si
     bw = b.copy()
     info = hip.solve(gpu_ctx, A, bw, x, prec=M, singular=null, null_mask=mask)
     assert info.converged == 1 and np.all(np.isfinite(x)), (singular, morris, prec, info.iters)
-    r = bw - A.spmv(x)
+    ax = A.spmv(x)
+    assert_spmv_matches_host_on_sampled_rows(A, x, ax, nsamples=16)   # the product the residual rests on, re-done on the host
+    r = bw - ax
     if null:                                             # solved in the complement of the masked null vector
         nvv = mask / np.sqrt(float(mask.sum()))
         r -= (r @ nvv) * nvv
@@ -182,7 +186,10 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
     for i in range(3):
         r = b[i * n:(i + 1) * n].clone()
         for j in range(3):
-            y = blocks[i][j].spmv(x[j * n:(j + 1) * n].contiguous())
+            xj = x[j * n:(j + 1) * n].contiguous()
+            y = blocks[i][j].spmv(xj)
+            if i == j or (i, j) == (0, 1):   # independent host product on sampled rows of the diagonal blocks and one coupling block
+                assert_spmv_matches_host_on_sampled_rows(blocks[i][j], xj, y, nsamples=32)
             r -= y
         res2 += float((r * r).sum())
         bn2 += float((b[i * n:(i + 1) * n] ** 2).sum())
@@ -210,7 +217,9 @@ def test_cavity_config3_full_size_properties(gpu_ctx):
     # (solver_lin_belos.h:215-219), returns x - (x.n) n.  With wall Neumann rows n = mask/|mask| is not an exact null
     # vector of A (those rows couple to fluid columns), so the returned x differs from the Krylov solution by a
     # multiple of n and its projected residual lies along q = P A n: remove that one direction, the rest is <= 2e-8.
-    r = bpw - A.spmv(xp)
+    axp = A.spmv(xp)
+    assert_spmv_matches_host_on_sampled_rows(A, xp, axp)
+    r = bpw - axp
     r -= (r @ nvec) * nvec
     an = A.spmv(nvec)
     an -= (an @ nvec) * nvec

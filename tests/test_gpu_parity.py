@@ -1290,3 +1290,43 @@ def test_repeated_setups_do_not_grow_device_memory(gpu_ctx):
         used.append(tot - fr)
     assert max(used[3:]) - min(used[3:]) <= 8 << 20, used          # after both kinds ran once: flat to within 8 MB
     assert hip.pool_cached_bytes() > 0
+
+
+@pytest.mark.parametrize("kind", ["bjacobi-ilu0", "bjacobi-ilu1", "sa-amg"])
+def test_exactly_sized_stream_gives_the_same_preconditioner(gpu_ctx, kind):
+    """The triangular-solve stream sized by a counting pass of the schedule (what streams beyond 4 GiB get: the
+    Gauss-Seidel smoother of BASELINE configs[4]) against the one-pass capacity rule: the same factor, the same stream
+    length, the same application bit for bit -- only the reservation differs."""
+    pr = Problem(tgv_spec(dim=3, n=20, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    nv = np.ones(n) / np.sqrt(n)
+    r = np.random.default_rng(9).standard_normal(n)
+
+    def make():
+        if kind == "sa-amg":
+            return hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(block=256, coarse_max=64))
+        return hip.Precond(gpu_ctx, A, kind, 256)
+    M0 = make()
+    z0 = M0.apply(r)
+    i0 = M0.info() if kind != "sa-amg" else None
+    try:
+        hip.set_exact_stream_threshold(0)
+        M1 = make()
+        z1 = M1.apply(r)
+        if kind != "sa-amg":
+            i1 = M1.info()
+            assert i1["stream_chunks"] == i0["stream_chunks"] and i1["factor_nnz"] == i0["factor_nnz"]
+            assert i1["stream_capacity"] < i0["stream_capacity"]              # exact: used chunks + the per-block pads
+            assert i1["stream_capacity"] <= i1["stream_chunks"] + 33 * (i1["nblocks"] + 1) + 32
+            for a, c in zip(M0.export_ilu(), M1.export_ilu()):
+                assert np.array_equal(a, c)
+        if kind == "sa-amg":   # two AMG set-ups differ in the last bits (the Galerkin products accumulate with LDS atomics)
+            assert np.linalg.norm(z0 - z1) <= 1e-11 * np.linalg.norm(z0)
+        else:
+            assert np.array_equal(z0, z1)
+        M1.close()
+    finally:
+        hip.set_exact_stream_threshold(-1)
+    M0.close(); A.close()

@@ -10,6 +10,8 @@ import scipy.sparse as sps
 from isph_amd import hip, workload
 import oracle as orc
 
+from sampled_check import assert_spmv_matches_host_on_sampled_rows
+
 pytestmark = pytest.mark.gpu
 
 
@@ -109,8 +111,14 @@ def test_porous_config4_properties_at_size(gpu_ctx, nc, reference_beads):
     bw = b.clone()
     info = hip.solve(gpu_ctx, A, bw, xs, prec=M, singular=False)
     assert info.converged == 1
-    r = b - A.spmv(xs)
+    ax = A.spmv(xs)
+    r = b - ax
     assert float(r.norm() / b.norm()) < 2e-8
+    # the residual above trusts the kernel under test: 4 096 rows of the operator are exported and multiplied on the
+    # host (nothing shared with the SpMV kernels) -- they must give the device's product, and a small residual
+    rows, axh = assert_spmv_matches_host_on_sampled_rows(A, xs, ax)
+    bh = b.cpu().numpy()
+    assert np.linalg.norm(bh[rows] - axh) <= 2e-8 * float(b.norm()) * np.sqrt(len(rows) / n) * 20
     assert float(xs[solid].abs().max()) <= 1e-12 * float(xs.abs().max())
     del M, A
     torch.cuda.empty_cache()
