@@ -71,6 +71,7 @@ struct DevPool {
   std::multimap<size_t, void *> free_blocks;   // ready: no kernel can still touch them
   std::vector<std::pair<size_t, void *>> pending;  // released since the last device synchronisation
   size_t cached = 0;
+  size_t live = 0, peak_live = 0;  // bytes handed out and not yet given back; its high-water mark (isph_pool_info)
   std::mutex mu;
   static DevPool &get() {
     static DevPool p;
@@ -87,17 +88,21 @@ struct DevPool {
     }
     return nullptr;
   }
+  void note_live(size_t got) {
+    live += got;
+    if (live > peak_live) peak_live = live;
+  }
   void *alloc(size_t bytes, size_t *got) {
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (void *p = take_ready(bytes, got)) return p;
+      if (void *p = take_ready(bytes, got)) { note_live(*got); return p; }
       bool fits = false;
       for (auto &kv : pending) fits = fits || (kv.first >= bytes && kv.first <= bytes + bytes / 4 + 4096);
       if (fits) {
         (void)hipDeviceSynchronize();
         for (auto &kv : pending) free_blocks.emplace(kv.first, kv.second);
         pending.clear();
-        if (void *p = take_ready(bytes, got)) return p;
+        if (void *p = take_ready(bytes, got)) { note_live(*got); return p; }
       }
     }
     void *p = nullptr;
@@ -106,11 +111,16 @@ struct DevPool {
       if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
     }
     *got = bytes;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      note_live(bytes);
+    }
     return p;
   }
   void release(void *p, size_t bytes) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(mu);
+    live -= bytes <= live ? bytes : live;
     if (bytes >= 4096 && cached + bytes <= cap()) {
       pending.emplace_back(bytes, p);
       cached += bytes;

@@ -47,6 +47,7 @@ struct isph_ilu {
   isph::DevBuf<long long> sboff;
   bool exact = false;
   long long stream_entries = 0;  // exact mode: 64 x the chunks the schedule counted
+  bool compact = false;          // exact mode, ILU(0) / Gauss-Seidel: the factor regions hold the in-block entries only
   const long long *stream_off() const { return exact ? sboff.p : boff.p; }
   isph::DevBuf<unsigned char> flev;  // level of fill of every factor entry (ILU(k) symbolic phase only)
   long long stream_chunks = 0;
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
                                                       const int *__restrict__ scol, const double *__restrict__ sval,
                                                       long long *__restrict__ frp, int *__restrict__ fcol,
                                                       double *__restrict__ fval, int *__restrict__ flen,
-                                                      int *__restrict__ fdiag, int *__restrict__ err, int b0) {
+                                                      int *__restrict__ fdiag, int *__restrict__ err, int b0,
+                                                      const long long *__restrict__ base_off) {
   __shared__ int wsum[16];
   extern __shared__ double ext_lds[];
   const int nwv = blockDim.x >> 6;
@@ -81,7 +83,9 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
   const int b = blockIdx.x + b0, blo = b * B, bhi = min(blo + B, n);  // b0: first block of a ranged launch
   const int t = threadIdx.x, i = blo + t;
   const bool active = i < bhi;
-  const long long base = slice_off[(long long)b * (B / 64)];
+  // the block's rows go back to back into its region: A's own sliced-ELL region of these rows, or -- compact mode, large
+  // operators -- a region of exactly the block's in-block entries (k_ilu_count_inblock)
+  const long long base = base_off ? base_off[b] : slice_off[(long long)b * (B / 64)];
   long long off = 0;
   int lane = 0, len = 0, cnt = 0, dg = -1;
   if (active) {
@@ -156,6 +160,31 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
     sstart[ln] += got;  // read again only behind the next flush's barrier
     got = 0;
   }
+}
+
+// in-block entries of every block, rounded up to a multiple of 64 (compact factor regions of large operators: a row of
+// the 4 M x 749 operator of BASELINE configs[4] keeps ~15 % of its entries inside its 512-row block)
+__global__ __launch_bounds__(1024) void k_ilu_count_inblock(int n, int B, const int *__restrict__ rowlen,
+                                                            const long long *__restrict__ slice_off,
+                                                            const int *__restrict__ scol, int *__restrict__ blktot) {
+  __shared__ int s_sum;
+  const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n);
+  const int i = blo + threadIdx.x;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  int cnt = 0;
+  if (i < bhi) {
+    const long long off = slice_off[i >> 6];
+    const int lane = i & 63, len = rowlen[i];
+    for (int k = 0; k < len; ++k) {
+      const int c = scol[sell_pos(off, lane, k)];
+      cnt += c >= blo && c < bhi;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_sum, cnt);
+  __syncthreads();
+  if (threadIdx.x == 0) blktot[b] = (s_sum + 63) & ~63;
 }
 
 // ---------------------------------------------------------------------------
@@ -1046,7 +1075,7 @@ inline int ilu_size_stream(isph_ilu *F) {
 }
 
 // needs S.nrow, S.stored, S.wmax, S.nslices and S.slice_off on the device (stream-ordered); not S.col / S.val
-inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int fill, isph_ilu **out) {
+inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int fill, isph_ilu **out, bool defer_factor_arrays = false) {
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
                "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && !(sgs && fill), "level of fill must be in [0,8]");
@@ -1056,8 +1085,8 @@ inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int
   F->total = S.stored;
   const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
   F->capf = kCapFactor; F->slack = 2 * block_size;
-  int rc = F->fcol.reserve(stored);
-  if (rc == ISPH_SUCCESS) rc = F->fval.reserve(stored);
+  int rc = defer_factor_arrays ? ISPH_SUCCESS : F->fcol.reserve(stored);
+  if (rc == ISPH_SUCCESS && !defer_factor_arrays) rc = F->fval.reserve(stored);
   if (rc == ISPH_SUCCESS) rc = F->frp.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->flen.reserve(n1);
   if (rc == ISPH_SUCCESS) rc = F->fdiag.reserve(n1);
@@ -1097,7 +1126,7 @@ inline void ilu_launch_extract(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0
   const size_t lds_e = (size_t)(F->B / 64) * 64 * ((kExtChunk + 1) * 8 + (kExtChunk + 1) * 4);
   hipLaunchKernelGGL(k_ilu_extract, dim3(nb), dim3(F->B), lds_e, st ? st : ctx->stream, S.nrow, F->B, (const int *)S.rowlen.p,
                      (const long long *)S.slice_off.p, (const int *)S.col.p, (const double *)S.val.p, F->frp.p, F->fcol.p,
-                     F->fval.p, F->flen.p, F->fdiag.p, F->err.p, b0);
+                     F->fval.p, F->flen.p, F->fdiag.p, F->err.p, b0, F->compact ? (const long long *)F->boff.p : (const long long *)nullptr);
 }
 
 inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, bool sgs, hipStream_t st = nullptr,
@@ -1179,9 +1208,40 @@ inline int ilu_schedule_and_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, bo
 inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false, int fill = 0) {
   const Sell &S = A->S;
   isph_ilu *F = nullptr;
-  ISPH_CHECK(ilu_begin(ctx, S, block_size, sgs, fill, &F));
+  // large operators (see ilu_wants_exact_stream): the factor regions are sized from a count of the in-block entries
+  // instead of A's sliced-ELL regions, and the stream from a counting pass of the schedule
+  bool big = false;
+  {
+    isph_ilu probe;
+    probe.total = S.stored; probe.B = block_size; probe.nblocks = (S.nrow + block_size - 1) / block_size;
+    big = fill == 0 && S.nrow > 0 && ilu_wants_exact_stream(&probe);
+  }
+  ISPH_CHECK(ilu_begin(ctx, S, block_size, sgs, fill, &F, /*defer_factor_arrays=*/big));
   int rc = ISPH_SUCCESS;
-  if (S.nrow > 0) {
+  if (big) {
+    DevTmp<int> blktot;
+    rc = blktot.reserve((size_t)F->nblocks);
+    long long total = 0;
+    if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL(k_ilu_count_inblock, dim3(F->nblocks), dim3(block_size), 0, ctx->stream, S.nrow, block_size,
+                         (const int *)S.rowlen.p, (const long long *)S.slice_off.p, (const int *)S.col.p, blktot.p);
+      hipLaunchKernelGGL(k_iluk_block_offsets, dim3(1), dim3(1024), 0, ctx->stream, F->nblocks, (const int *)blktot.p, F->boff.p);
+      if (hipMemcpyAsync(&total, F->boff.p + F->nblocks, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = fail("count of the in-block entries failed", __FILE__, __LINE__);
+    }
+    F->total = total;
+    F->compact = true;
+    F->exact = true;
+    const size_t tot1 = (size_t)(total > 0 ? total : 1);
+    if (rc == ISPH_SUCCESS) rc = F->fcol.reserve(tot1);
+    if (rc == ISPH_SUCCESS) rc = F->fval.reserve(tot1);
+    if (rc == ISPH_SUCCESS) rc = F->fdst.reserve(tot1);
+    if (rc == ISPH_SUCCESS) {
+      ilu_launch_extract(ctx, F, S, 0, F->nblocks);
+      rc = ilu_schedule_and_factor(ctx, F, S, sgs);
+    }
+  } else if (S.nrow > 0) {
     ilu_launch_extract(ctx, F, S, 0, F->nblocks);
     if (fill > 0) {
       rc = ilu_symbolic(ctx, F, fill);

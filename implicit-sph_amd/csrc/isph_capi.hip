@@ -277,6 +277,15 @@ int isph_pool_set_cap(long long bytes) {
   return ISPH_SUCCESS;
 }
 
+int isph_pool_info(long long info[4], int reset_peak) {
+  ISPH_REQUIRE(info, "NULL argument");
+  DevPool &p = DevPool::get();
+  std::lock_guard<std::mutex> lk(p.mu);
+  info[0] = (long long)p.cached; info[1] = (long long)p.live; info[2] = (long long)p.peak_live; info[3] = (long long)p.cap_bytes;
+  if (reset_peak) p.peak_live = p.live;
+  return ISPH_SUCCESS;
+}
+
 long long isph_pool_cached_bytes(void) {
   DevPool &p = DevPool::get();
   std::lock_guard<std::mutex> lk(p.mu);

@@ -17,7 +17,7 @@ NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
 KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
-    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_pool_info", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
@@ -109,6 +109,7 @@ def lib():
         L.isph_pool_set_cap.argtypes = [C.c_longlong]
         L.isph_set_exact_stream_threshold.argtypes = [C.c_longlong]
         L.isph_ingress_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.isph_pool_info.argtypes = [C.c_void_p, C.c_int]
         L.isph_pool_cached_bytes.argtypes = []
         L.isph_pool_cached_bytes.restype = C.c_longlong
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
@@ -245,6 +246,13 @@ def set_exact_stream_threshold(nbytes):
     """isph_set_exact_stream_threshold: ILU / Gauss-Seidel streams whose capacity-rule reservation exceeds nbytes are sized
     by a counting pass instead (default 4 GiB; 0 = always exact; < 0 = default)."""
     _check(lib().isph_set_exact_stream_threshold(int(nbytes)))
+
+
+def pool_info(reset_peak=False):
+    """isph_pool_info: dict(cached, live, peak_live, cap) in bytes."""
+    a = (C.c_longlong * 4)()
+    _check(lib().isph_pool_info(a, int(reset_peak)))
+    return dict(cached=a[0], live=a[1], peak_live=a[2], cap=a[3])
 
 
 def pool_cached_bytes():

@@ -64,6 +64,9 @@ int isph_pool_set_cap(long long bytes);
  * bytes < 0 restores it, 0 sizes every stream exactly.  Process-wide.  No reference counterpart. */
 int isph_set_exact_stream_threshold(long long bytes);
 long long isph_pool_cached_bytes(void);
+/* [0] bytes cached, [1] bytes handed out to live objects, [2] high-water mark of [1] (reset to [1] when reset_peak != 0),
+ * [3] the cache limit in force (0: not yet determined). */
+int isph_pool_info(long long info[4], int reset_peak);
 const char *isph_last_error(void);
 
 /* ---- matrix ----------------------------------------------------------- */

@@ -22,7 +22,10 @@ T0 = time.time()
 def stage(msg):
     torch.cuda.synchronize()
     ctx.sync()
-    print("[%7.1fs] %s | device memory in use %.1f GB" % (time.time() - T0, msg, (torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9), flush=True)
+    used = (torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9
+    pi = hip.pool_info(reset_peak=True)
+    print("[%7.1fs] %s | device memory in use %.1f GB; library: live %.1f GB, peak live since the last line %.1f GB, cached %.1f GB" %
+          (time.time() - T0, msg, used, pi["live"] / 1e9, pi["peak_live"] / 1e9, pi["cached"] / 1e9), flush=True)
 
 
 if os.environ.get("ISPH_REFERENCE_BEADS"):   # the script's own bead pack and aspect ratio (tests/golden/...npz)
