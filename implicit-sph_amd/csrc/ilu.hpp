@@ -1409,7 +1409,14 @@ inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double
   if (F->n == 0) return ISPH_SUCCESS;
   constexpr int WV = 4;
   const size_t lds = sizeof(double) * (size_t)(K + 1) * (size_t)F->B * WV;
-  if (K < 2 || K > 4 || lds > 160 * 1024) {
+  // K sweeps when one sweep for all vectors does not fit the LDS this device gives a workgroup (asked, not assumed)
+  static const size_t lds_max = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+      return (size_t)64 * 1024;
+    return (size_t)v;
+  }();
+  if (K < 2 || K > 4 || lds > lds_max) {
     for (int k = 0; k < K; ++k) ISPH_CHECK(ilu_apply(ctx, F, rs[k], zs[k]));
     return ISPH_SUCCESS;
   }
