@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 C=$1; T=$2; K=$3; shift 3
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_k_$T -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc_k_$T.log 2>&1 || { tail -5 $OUT/pmc_k_$T.log; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_k_$T -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dropin "$@" > $OUT/pmc_k_$T.log 2>&1 || { tail -5 $OUT/pmc_k_$T.log; exit 1; }
 F=$(ls -t $OUT/pmc_k_$T/*/*counter_collection.csv | head -1)
 python3 - "$F" "$K" <<'PY'
 import csv, sys, collections, re
