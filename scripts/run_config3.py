@@ -55,6 +55,10 @@ for step in range(3):
     vstar[:n] = vs
     vstar = vstar[own].contiguous()
     A, bp = hip.assemble_poisson(ctx, dp, colmap, p["dt"], rho, vstar, vfrac=vfrac, Gc=Gc, kinds=p["kinds"], normal=nrm)
+    if step == 0:
+        im = A.info()
+        print("Poisson operator: %d rows, %d entries (%.2f per row), SpMV algorithmic bytes %.4f GB" %
+              (im["nrow"], im["nnz"], im["nnz"] / im["nrow"], (12 * im["nnz"] + 16 * im["nrow"] + 4 * (im["nrow"] + 1)) / 1e9), flush=True)
     t4 = sync()
     xp = torch.zeros(n, dtype=torch.float64, device=dev)
     if prec == "sa-amg":
