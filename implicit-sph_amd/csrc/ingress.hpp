@@ -22,14 +22,71 @@
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <cstdint>
 #include <condition_variable>
 #include <functional>
 #include <thread>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "core.hpp"
 #include "ilu.hpp"
 
 namespace isph {
+
+// Staging copies with non-temporal stores: the pinned ring is written by the staging threads and read by the DMA engine
+// only.  With ordinary stores the freshly written lines sit dirty in the cores' caches and every DMA read has to be served
+// from there: the more staging threads, the slower the link ran (copies of the 100^3 matrix done after 24.4 ms with 4
+// threads, 26.5 with 8, 34 with 12).  Streaming stores put the data in memory behind the write-combining buffers.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void stage_copy_avx2(void *dst, const void *src, size_t bytes) {
+  char *d = static_cast<char *>(dst);
+  const char *s = static_cast<const char *>(src);
+  size_t k = 0;
+  while (k < bytes && (reinterpret_cast<uintptr_t>(d + k) & 31)) { d[k] = s[k]; ++k; }
+  for (; k + 128 <= bytes; k += 128) {
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k + 32));
+    const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k + 64));
+    const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k + 96));
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(d + k), a);
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(d + k + 32), b);
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(d + k + 64), c);
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(d + k + 96), e);
+  }
+  for (; k < bytes; ++k) d[k] = s[k];
+  _mm_sfence();
+}
+// copy of n column indices with the range check [0, ncol) riding along; returns nonzero when one is outside
+__attribute__((target("avx2"))) inline unsigned stage_cols_avx2(int *dst, const int *src, size_t n, unsigned ncol) {
+  unsigned over = 0;
+  size_t k = 0;
+  while (k < n && (reinterpret_cast<uintptr_t>(dst + k) & 31)) { dst[k] = src[k]; over |= (unsigned)((unsigned)src[k] >= ncol); ++k; }
+  const __m256i sign = _mm256_set1_epi32((int)0x80000000u);
+  const __m256i lim = _mm256_set1_epi32((int)((ncol - 1u) ^ 0x80000000u));  // unsigned x > ncol - 1  <=>  (x ^ sign) >s (ncol - 1) ^ sign
+  __m256i bad = _mm256_setzero_si256();
+  for (; k + 16 <= n; k += 16) {
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + k + 8));
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k), a);
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(dst + k + 8), b);
+    bad = _mm256_or_si256(bad, _mm256_or_si256(_mm256_cmpgt_epi32(_mm256_xor_si256(a, sign), lim), _mm256_cmpgt_epi32(_mm256_xor_si256(b, sign), lim)));
+  }
+  if (!_mm256_testz_si256(bad, bad)) over = 1;
+  for (; k < n; ++k) { dst[k] = src[k]; over |= (unsigned)((unsigned)src[k] >= ncol); }
+  _mm_sfence();
+  return over;
+}
+inline bool stage_have_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+#else
+inline bool stage_have_avx2() { return false; }
+inline void stage_copy_avx2(void *, const void *, size_t) {}
+inline unsigned stage_cols_avx2(int *, const int *, size_t, unsigned) { return 0; }
+#endif
+inline void stage_copy(void *dst, const void *src, size_t bytes) {
+  if (stage_have_avx2()) stage_copy_avx2(dst, src, bytes); else memcpy(dst, src, bytes);
+}
 
 struct HostStager {
   static constexpr size_t kChunk = (size_t)4 << 20;  // entries per ring slot; a slot is 12 bytes per entry = 48 MiB
@@ -64,9 +121,9 @@ inline int stager_get(isph_ctx *ctx, HostStager **out) {
   if (!ctx->stager) {
     HostStager *S = new HostStager();
     const unsigned hc = std::thread::hardware_concurrency();
-    // a staging thread packs and copies ~10 GB/s of entries (0.5 ns for the 16-bit column pass + 0.5 ns for the value copy
-    // per entry); eight of them stay ahead of the 57.6 GB/s link (profiles/r03_dropin.txt)
-    S->nthreads = (int)std::min(8u, std::max(1u, hc / 2));
+    // a staging thread moves ~10-15 GB/s of entries into the ring (streaming stores); four to eight of them all end the
+    // copies of the 100^3 matrix after 24.3-25.0 ms, twelve and more lose 1-2 ms (profiles/r03_dropin.txt)
+    S->nthreads = (int)std::min(6u, std::max(1u, hc / 2));
     S->nslots = S->nthreads + 2;
     bool ok = hipHostMalloc((void **)&S->pslot, 12 * HostStager::kChunk * (size_t)S->nslots, hipHostMallocDefault) == hipSuccess &&
               hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking) == hipSuccess;
@@ -149,7 +206,7 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
       const long long p0 = cstart[(size_t)c], p1 = cstart[(size_t)c + 1];
       const size_t cnt = (size_t)(p1 - p0);
       char *base = H->pslot + (size_t)slot * 12 * HostStager::kChunk;
-      memcpy(base, val + p0, sizeof(double) * cnt);
+      stage_copy(base, val + p0, sizeof(double) * cnt);
       unsigned over = 0;
       // columns.  One flat pass (it vectorises and runs at copy speed): range check and the 16-bit difference to the
       // previous entry, row starts included; then one pass over the rows that start here: their first column goes to the
@@ -191,10 +248,14 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
         int *dc = reinterpret_cast<int *>(base + 8 * cnt);
         const int *sc = colidx + p0;
         unsigned ov = 0;
-        for (size_t k = 0; k < cnt; ++k) {  // plain copy + range check in one pass
-          const int cc = sc[k];
-          ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
-          dc[k] = cc;
+        if (stage_have_avx2() && ncol > 0) {
+          ov = stage_cols_avx2(dc, sc, cnt, (unsigned)ncol);
+        } else {
+          for (size_t k = 0; k < cnt; ++k) {  // plain copy + range check in one pass
+            const int cc = sc[k];
+            ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
+            dc[k] = cc;
+          }
         }
         over |= ov;
       }

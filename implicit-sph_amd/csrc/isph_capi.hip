@@ -971,11 +971,23 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
   // a [lda x nvec] column-major view owns lda (nvec - 1) + n elements (Epetra_MultiVector(View, map, ptr, lda, nvec)): the
   // tail lda - n of the last column is not the caller's to give
   const size_t tot = (size_t)lda * (size_t)(nvec - 1) + (size_t)n;
+  // Host operands: a context that has made a host-side matrix ingress owns a pinned ring (ingress.hpp); b, x and the null
+  // mask then travel through it -- a streaming copy into a slot, an asynchronous DMA from there, the next operand staged
+  // while the previous one is on the link -- instead of as synchronous copies of pageable memory (17 GB/s on this box).
+  HostStager *ring = !on_device && ctx->stager && ctx->stager->nslots >= 3 && sizeof(double) * tot <= 12 * HostStager::kChunk ? ctx->stager : nullptr;
+  auto ring_slot = [&](int k) { return ring->pslot + (size_t)k * 12 * HostStager::kChunk; };
   if (!on_device) {
     ISPH_CHECK(ctx->bdev.reserve(tot));
     ISPH_CHECK(ctx->xdev.reserve(tot));
-    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->bdev.p, b, sizeof(double) * tot, hipMemcpyHostToDevice, st));
-    ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p, x, sizeof(double) * tot, hipMemcpyHostToDevice, st));
+    if (ring) {
+      stage_copy(ring_slot(0), b, sizeof(double) * tot);
+      ISPH_CHECK_HIP(hipMemcpyAsync(ctx->bdev.p, ring_slot(0), sizeof(double) * tot, hipMemcpyHostToDevice, st));
+      stage_copy(ring_slot(1), x, sizeof(double) * tot);
+      ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p, ring_slot(1), sizeof(double) * tot, hipMemcpyHostToDevice, st));
+    } else {
+      ISPH_CHECK_HIP(hipMemcpyAsync(ctx->bdev.p, b, sizeof(double) * tot, hipMemcpyHostToDevice, st));
+      ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p, x, sizeof(double) * tot, hipMemcpyHostToDevice, st));
+    }
     db = ctx->bdev.p;
     dx = ctx->xdev.p;
   }
@@ -986,7 +998,12 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
     ISPH_CHECK(ctx->nvec.reserve((size_t)(n > 0 ? n : 1)));
     if (null_mask) {
       ISPH_CHECK(ctx->imask.reserve((size_t)(n > 0 ? n : 1)));
-      ISPH_CHECK_HIP(hipMemcpyAsync(ctx->imask.p, null_mask, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+      if (ring) {
+        stage_copy(ring_slot(2), null_mask, sizeof(int) * (size_t)n);
+        ISPH_CHECK_HIP(hipMemcpyAsync(ctx->imask.p, ring_slot(2), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+      } else {
+        ISPH_CHECK_HIP(hipMemcpyAsync(ctx->imask.p, null_mask, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+      }
       hipLaunchKernelGGL(k_mask_to_double, dim3(sg), dim3(kBlock), 0, st, n, ctx->imask.p, ctx->nvec.p);
     } else {
       hipLaunchKernelGGL(k_fill, dim3(sg), dim3(kBlock), 0, st, n, ctx->nvec.p, 1.0);
@@ -1040,7 +1057,15 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
       else printf(">> isph::Status - Failed to converge! ||r|| / ||b|| = %6.4e\n", ci.rel_res_explicit);
     }
   }
-  if (!on_device) {
+  if (!on_device && ring) {  // x first (the caller's result), b's copy-out overlaps nothing but is half the pageable time
+    ISPH_CHECK_HIP(hipMemcpyAsync(ring_slot(0), dx, sizeof(double) * tot, hipMemcpyDeviceToHost, st));
+    ISPH_CHECK_HIP(hipEventRecord(ring->ev[0], st));
+    ISPH_CHECK_HIP(hipMemcpyAsync(ring_slot(1), db, sizeof(double) * tot, hipMemcpyDeviceToHost, st));
+    ISPH_CHECK_HIP(hipEventSynchronize(ring->ev[0]));
+    memcpy(x, ring_slot(0), sizeof(double) * tot);  // while b is on the link
+    ISPH_CHECK_HIP(hipStreamSynchronize(st));
+    memcpy(b, ring_slot(1), sizeof(double) * tot);
+  } else if (!on_device) {
     ISPH_CHECK_HIP(hipMemcpyAsync(b, db, sizeof(double) * tot, hipMemcpyDeviceToHost, st));
     ISPH_CHECK_HIP(hipMemcpyAsync(x, dx, sizeof(double) * tot, hipMemcpyDeviceToHost, st));
   }

@@ -39,6 +39,10 @@ class PrecondWrapper {
   virtual void setBlockMatrix(Thyra::PhysicallyBlockedLinearOpBase<double> *) { return; }
   virtual Teuchos::ParameterList *setParameters(Teuchos::ParameterList *param = NULL) { return _param.get(); }
   virtual void setNullVector(double *) { return; }  // base no-op, ref: precond.h:40
+  // true when setNullVector() is more than the base no-op: SolverLin_HIP then forms the host copy of the null vector
+  // before create() like the reference (solver_lin_belos.h:149-151); for the others the 8 n bytes are not touched per
+  // solve (the device forms its own null vector from the mask) and getNullVector() builds the host copy on demand
+  virtual bool usesNullVector() const { return false; }
   // The reference builds the Ifpack/ML object here; the device object needs the
   // device matrix, which SolverLin_HIP owns, so create() only records the request
   // and the build happens inside solveProblem (same place in the timeline:

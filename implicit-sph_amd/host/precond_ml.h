@@ -41,6 +41,7 @@ class PrecondWrapper_ML : public PrecondWrapper {
 
   // ref: precond_ml.h:97-127 -- one pre-computed null-space vector; the smoother becomes the coarse solver
   virtual void setNullVector(double *n) { _null = n; }
+  virtual bool usesNullVector() const { return true; }
 
  protected:
   virtual int createOnDevice(isph_ctx *ctx, const isph_mat *A) {

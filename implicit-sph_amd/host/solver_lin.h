@@ -58,6 +58,7 @@ class SolverLin {
     const double inv = 1.0 / std::sqrt(sum);
     for (int i = 0; i < m; ++i) v[i] = (mask ? (double)mask[i] : 1.0) * inv;
     for (int i = m; i < len; ++i) v[i] = 0.0;
+    _n_stale = false;
     return LAMMPS_SUCCESS;
   }
   int createBlockMatrix(const int dim, const char *) { _dim = dim; return LAMMPS_SUCCESS; }
@@ -101,7 +102,10 @@ class SolverLin {
   Teuchos::RCP<Epetra_Map> getNodalMap() const { return _map; }
   Teuchos::RCP<Epetra_MultiVector> getLoadMultiVector() { return _b; }
   Teuchos::RCP<Epetra_MultiVector> getSolutionMultiVector() { return _x; }
-  Teuchos::RCP<Epetra_Vector> getNullVector() { return _n; }
+  Teuchos::RCP<Epetra_Vector> getNullVector() {
+    if (_n_stale) { createNullVector(); }
+    return _n;
+  }
 
   virtual void setParameters(Teuchos::ParameterList *param = NULL) {}
   virtual int solveProblem(PrecondWrapper *prec = NULL, const char *name = NULL) { return 0; }
@@ -119,6 +123,7 @@ class SolverLin {
   Teuchos::RCP<Epetra_Vector> _n;
   Teuchos::RCP<Epetra_IntSerialDenseVector> _null_mask;
   bool _is_singular;
+  bool _n_stale = false;  // a singular solve ran without needing the host copy of the null vector
 };
 
 }  // namespace LAMMPS_NS

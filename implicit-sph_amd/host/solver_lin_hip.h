@@ -90,7 +90,8 @@ class SolverLin_HIP : public SolverLin {
 
     int rc = ISPH_SUCCESS;
     if (prec != NULL) {
-      if (_is_singular) { createNullVector(); prec->setNullVector(_n->Values()); }  // :149-151
+      if (_is_singular && prec->usesNullVector()) { createNullVector(); prec->setNullVector(_n->Values()); }  // :149-151
+      else if (_is_singular) _n_stale = true;  // getNullVector() forms it when somebody asks
       prec->create();
       if (fused > 0) prec->adoptDevice(Mfused);
       else rc = prec->createOnDevice(_ctx, A);  // Ifpack Initialize+Compute happen here (:153)
@@ -105,7 +106,7 @@ class SolverLin_HIP : public SolverLin {
                       _is_singular ? 1 : 0, _null_mask ? _null_mask->Values() : nullptr, &p, &info, 0);
     const std::chrono::steady_clock::time_point t3 = std::chrono::steady_clock::now();
     if (prec != NULL) {
-      if (_is_singular) prec->setNullVector(NULL);
+      if (_is_singular && prec->usesNullVector()) prec->setNullVector(NULL);
       prec->free();  // :186-191
     }
     isph_mat_destroy(A);

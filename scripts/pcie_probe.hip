@@ -1,6 +1,7 @@
 // pcie_probe.hip -- what the host->device link of this box delivers, to judge the host CSR ingress against
 // (csrc/ingress.hpp): pinned H2D on 1/2/4 streams, chunk sizes, and pageable->pinned memcpy with T threads.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -50,6 +51,30 @@ int main() {
       const double t = now() - t0;
       if (rep) printf("pageable -> pinned memcpy, %2d threads : %6.2f ms  %6.2f GB/s\n", T, t * 1e3, total / t * 1e-9);
     }
+  }
+  // the link while staging threads copy pageable -> pinned next to it (what the ingress pipeline does)
+  for (int T : {0, 4, 8}) {
+    std::vector<char> page2(total, 3);
+    char *pin2 = nullptr;
+    CK(hipHostMalloc((void **)&pin2, total, hipHostMallocDefault));
+    std::atomic<int> stop(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        const size_t lo = total / T * t, hi = t == T - 1 ? total : total / T * (t + 1);
+        while (!stop.load()) memcpy(pin2 + lo, page2.data() + lo, hi - lo);
+      });
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipDeviceSynchronize());
+      const double t0 = now();
+      for (size_t o = 0; o < total; o += (size_t)48 << 20) CK(hipMemcpyAsync(dev + o, pin + o, std::min((size_t)48 << 20, total - o), hipMemcpyHostToDevice, st[0]));
+      CK(hipDeviceSynchronize());
+      const double t = now() - t0;
+      if (rep) printf("pinned H2D 48 MiB copies beside %d memcpy threads: %6.2f ms  %6.2f GB/s\n", T, t * 1e3, total / t * 1e-9);
+    }
+    stop.store(1);
+    for (auto &x : th) x.join();
+    CK(hipHostFree(pin2));
   }
   printf("hardware_concurrency %u\n", std::thread::hardware_concurrency());
   return 0;

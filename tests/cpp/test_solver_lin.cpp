@@ -236,6 +236,7 @@ static int run(int argc, char **argv) {
     li_solver.setTiming(true);
     std::vector<double> t[5];
     int iters = 0, conv = 1;
+    double gpu_solve_ms = 0.0;
     for (int k = 0; k < repeat + 1; ++k) {
       b = b0;
       li_solver.setMatrix(&AA);
@@ -249,15 +250,16 @@ static int run(int argc, char **argv) {
       for (int q = 0; q < 4; ++q) t[q].push_back(ms[q]);
       t[4].push_back(wall);
       iters = li_solver.lastSolveInfo().iters;
+      gpu_solve_ms = li_solver.lastSolveInfo().solve_ms;
       conv = conv && li_solver.lastSolveInfo().converged;
     }
     for (int q = 0; q < 5; ++q) std::sort(t[q].begin(), t[q].end());
     const size_t mid = t[4].size() / 2;
     std::printf("{\"dropin\": {\"rows\": %d, \"entries\": %d, \"repeat\": %d, \"iterations\": %d, \"converged\": %d, "
                 "\"ms_per_solve\": %.3f, \"ingress_ms\": %.3f, \"setup_ms\": %.3f, \"krylov_ms\": %.3f, \"release_ms\": %.3f, "
-                "\"ingress_GBps\": %.2f}}\n",
+                "\"ingress_GBps\": %.2f, \"krylov_gpu_event_ms_last_call\": %.3f}}\n",
                 n, nnz, repeat, iters, conv, t[4][mid], t[0][mid], t[1][mid], t[2][mid], t[3][mid],
-                (12.0 * nnz + 4.0 * (n + 1)) / t[0][mid] * 1e-6);
+                (12.0 * nnz + 4.0 * (n + 1)) / t[0][mid] * 1e-6, gpu_solve_ms);
     double gi[8];
     if (li_solver.lastIngressInfo(gi) == ISPH_SUCCESS)
       std::printf("{\"ingress_last_call\": {\"staged_ms\": %.3f, \"queued_ms\": %.3f, \"copied_ms\": %.3f, \"device_done_ms\": %.3f, "
