@@ -124,7 +124,7 @@ inline int stager_get(isph_ctx *ctx, HostStager **out) {
     // a staging thread moves ~10-15 GB/s of entries into the ring (streaming stores); four to eight of them all end the
     // copies of the 100^3 matrix after 24.3-25.0 ms, twelve and more lose 1-2 ms (profiles/r03_dropin.txt)
     S->nthreads = (int)std::min(6u, std::max(1u, hc / 2));
-    S->nslots = S->nthreads + 2;
+    S->nslots = 4;  // all threads stage one chunk together: one on the link, one queued, one being staged, one spare
     bool ok = hipHostMalloc((void **)&S->pslot, 12 * HostStager::kChunk * (size_t)S->nslots, hipHostMallocDefault) == hipSuccess &&
               hipStreamCreateWithFlags(&S->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int s = 0; ok && s < S->nslots; ++s) {
@@ -172,10 +172,14 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
   auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
   double wait_fill = 0.0;
 
-  // chunk sizes ramp up (1/8, 1/4, 1/2 of a slot, then whole slots): the link starts after 0.2 ms of staging instead of 1.4
+  // Chunks: a small first one (the link starts after ~0.1 ms of staging, and its rows decide whether this matrix travels
+  // with 16-bit column differences), then whole slots.  EVERY chunk is staged by ALL staging threads together, each
+  // taking a part of it: a 48 MiB chunk is in the ring after 0.7 ms and goes over the link in one copy at the link's best
+  // rate, while the threads stage the next one.  (One thread per chunk -- the first version -- kept six chunks in flight
+  // but delivered the first whole slot after 4 ms: the link idled for 3 of the first 4.5 ms.)
   std::vector<long long> cstart(1, 0);
-  for (long long sz = (long long)HostStager::kChunk / 8; cstart.back() < nnz; sz = std::min<long long>(2 * sz, (long long)HostStager::kChunk))
-    cstart.push_back(std::min(nnz, cstart.back() + sz));
+  if (nnz > 0) cstart.push_back(std::min(nnz, (long long)HostStager::kChunk / 8));
+  while (cstart.back() < nnz) cstart.push_back(std::min(nnz, cstart.back() + (long long)HostStager::kChunk));
   const long long nchunks = (long long)cstart.size() - 1;
   const bool packing = nchunks <= 64 * kModeWords;  // the mode bits travel as a kernel argument
   std::vector<int> crow((size_t)nchunks + 1, nrow);  // first row that starts at or behind the chunk's first entry
@@ -183,15 +187,23 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
     crow[(size_t)c] = (int)(std::lower_bound(rowptr, rowptr + nrow + 1, (int)cstart[(size_t)c]) - rowptr);
 
   // ---- the workers start on the caller's arrays at once; everything below overlaps with their first chunks
+  const int P = (int)std::max<long long>(1, std::min<long long>(H->nthreads, nnz / 65536));  // parts per chunk = staging threads
   std::mutex mu;
   std::condition_variable cv;
   std::vector<char> filled((size_t)nchunks, 0), recorded((size_t)nchunks, 0);  // filled: 1 = 32-bit columns, 2 = 16-bit differences
+  std::vector<std::atomic<int>> parts_done((size_t)(nchunks > 0 ? nchunks : 1));
+  std::vector<std::atomic<long long>> nwide_sum((size_t)(nchunks > 0 ? nchunks : 1));
+  for (auto &a : parts_done) a.store(0);
+  for (auto &a : nwide_sum) a.store(0);
   std::atomic<long long> next(0);
   std::atomic<int> bad_col(0), hip_err(0);
+  std::atomic<int> verdict(0);  // 16-bit differences for this matrix?  0: chunk 0 not staged yet, 1: yes, 2: no
   auto worker = [&]() {
     (void)hipSetDevice(ctx->device);
     for (;;) {
-      const long long c = next.fetch_add(1);
+      const long long id = next.fetch_add(1);
+      const long long c = id / P;
+      const int part = (int)(id % P);
       if (c >= nchunks) break;
       const int slot = (int)(c % H->nslots);
       if (c >= H->nslots) {  // the slot's previous chunk must have left it
@@ -206,35 +218,69 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
       const long long p0 = cstart[(size_t)c], p1 = cstart[(size_t)c + 1];
       const size_t cnt = (size_t)(p1 - p0);
       char *base = H->pslot + (size_t)slot * 12 * HostStager::kChunk;
-      stage_copy(base, val + p0, sizeof(double) * cnt);
-      unsigned over = 0;
-      // columns.  One flat pass (it vectorises and runs at copy speed): range check and the 16-bit difference to the
-      // previous entry, row starts included; then one pass over the rows that start here: their first column goes to the
-      // table behind the differences, and a start the flat pass counted as "too wide" (the previous row ended further
-      // right) is taken back.  A real difference outside [0, 65535] -- unsorted rows, or neighbours in a row more than
-      // 65535 columns apart --, or a table that does not fit the chunk's 12 bytes per entry (rows of fewer than two
-      // entries on average), sends the chunk as plain 32-bit columns.
       const int r0 = crow[(size_t)c], r1 = crow[(size_t)c + 1];
       const size_t off_rf = (10 * cnt + 3) & ~(size_t)3;
-      bool pack16 = packing && off_rf + 4 * (size_t)(r1 - r0) <= 12 * cnt;
-      if (pack16) {
+      const bool fits16 = packing && off_rf + 4 * (size_t)(r1 - r0) <= 12 * cnt;
+      // columns as 16-bit differences?  chunk 0 tries (when they fit), the others follow its verdict
+      bool try16 = fits16;
+      if (c > 0) {
+        int v = verdict.load();
+        if (v == 0) {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return verdict.load() != 0; });
+          v = verdict.load();
+        }
+        try16 = fits16 && v == 1;
+      }
+      // this thread's part of the chunk, boundaries on multiples of 32 entries (aligned streaming stores)
+      auto cut = [&](int k) { return k >= P ? p1 : std::min(p1, p0 + (((long long)cnt * k / P) & ~31LL)); };
+      const long long q_lo = cut(part), q_hi = cut(part + 1);
+      unsigned over = 0;
+      if (q_hi > q_lo) {
+        stage_copy(base + 8 * (size_t)(q_lo - p0), val + q_lo, sizeof(double) * (size_t)(q_hi - q_lo));
+        if (try16) {
+          // flat pass (vectorises, runs at copy speed): range check and the 16-bit difference to the previous entry, row
+          // starts included; the chunk's finisher takes the row starts back
+          unsigned short *d16 = reinterpret_cast<unsigned short *>(base + 8 * cnt);
+          const long long qa = q_lo > 0 ? q_lo : 1;  // entry 0 has no predecessor (it is a row start)
+          if (q_lo == 0) { d16[0] = 0; over |= (unsigned)((unsigned)colidx[0] >= (unsigned)ncol); }
+          const int *src = colidx + qa;
+          unsigned short *dst = d16 + (qa - p0);
+          const size_t m = (size_t)(q_hi - qa);
+          unsigned nw = 0, ov = 0;
+          for (size_t k = 0; k < m; ++k) {
+            const int cc = src[k];
+            const unsigned diff = (unsigned)(cc - src[(ptrdiff_t)k - 1]);
+            nw += diff > 65535u;
+            ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
+            dst[k] = (unsigned short)diff;
+          }
+          over |= ov;
+          nwide_sum[(size_t)c].fetch_add((long long)nw);
+        } else {
+          int *dc = reinterpret_cast<int *>(base + 8 * cnt) + (q_lo - p0);
+          const int *sc = colidx + q_lo;
+          const size_t m = (size_t)(q_hi - q_lo);
+          if (stage_have_avx2() && ncol > 0) {
+            over |= stage_cols_avx2(dc, sc, m, (unsigned)ncol);
+          } else {
+            unsigned ov = 0;
+            for (size_t k = 0; k < m; ++k) { const int cc = sc[k]; ov |= (unsigned)((unsigned)cc >= (unsigned)ncol); dc[k] = cc; }
+            over |= ov;
+          }
+        }
+      }
+      if (over) bad_col.store(1);
+      if (parts_done[(size_t)c].fetch_add(1) + 1 < P) continue;
+      // ---- the thread that finishes the chunk's last part closes it
+      bool pack16 = try16;
+      if (try16) {
+        // rows that start in this chunk: first column to the table behind the differences; a start the flat pass counted
+        // as "too wide" (the previous row ended further right) is taken back.  A real difference outside [0, 65535] --
+        // unsorted rows, or neighbours in a row more than 65535 columns apart -- sends the chunk as 32-bit columns.
         unsigned short *d16 = reinterpret_cast<unsigned short *>(base + 8 * cnt);
         int *rowfirst = reinterpret_cast<int *>(base + off_rf);
-        const long long q0 = p0 > 0 ? p0 : 1;  // entry 0 has no predecessor (it is a row start)
-        if (p0 == 0) { d16[0] = 0; over |= (unsigned)((unsigned)colidx[0] >= (unsigned)ncol); }
-        const int *src = colidx + q0;
-        unsigned short *dst = d16 + (q0 - p0);
-        const size_t m = (size_t)(p1 - q0);
-        unsigned nw = 0, ov = 0;
-        for (size_t k = 0; k < m; ++k) {
-          const int cc = src[k];
-          const unsigned diff = (unsigned)(cc - src[(ptrdiff_t)k - 1]);
-          nw += diff > 65535u;
-          ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
-          dst[k] = (unsigned short)diff;
-        }
-        over |= ov;
-        long long nwide = nw;
+        long long nwide = nwide_sum[(size_t)c].load();
         for (int r = r0; r < r1; ++r) {
           const long long rs = rowptr[r];
           rowfirst[r - r0] = rs < nnz ? colidx[rs] : 0;  // (rows without entries: never read)
@@ -242,26 +288,16 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
           d16[rs - p0] = 0;
           if (rs > 0 && (unsigned)(colidx[rs] - colidx[rs - 1]) > 65535u) --nwide;
         }
-        if (nwide > 0) pack16 = false;
-      }
-      if (!pack16) {
-        int *dc = reinterpret_cast<int *>(base + 8 * cnt);
-        const int *sc = colidx + p0;
-        unsigned ov = 0;
-        if (stage_have_avx2() && ncol > 0) {
-          ov = stage_cols_avx2(dc, sc, cnt, (unsigned)ncol);
-        } else {
-          for (size_t k = 0; k < cnt; ++k) {  // plain copy + range check in one pass
-            const int cc = sc[k];
-            ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
-            dc[k] = cc;
-          }
+        if (nwide > 0) {  // not this chunk: its columns once more, plain (this thread alone; rare after chunk 0)
+          pack16 = false;
+          int *dc = reinterpret_cast<int *>(base + 8 * cnt);
+          if (stage_have_avx2() && ncol > 0) (void)stage_cols_avx2(dc, colidx + p0, cnt, (unsigned)ncol);
+          else for (size_t k = 0; k < cnt; ++k) dc[k] = colidx[p0 + (long long)k];
         }
-        over |= ov;
       }
-      if (over) bad_col.store(1);
       {
         std::lock_guard<std::mutex> lk(mu);
+        if (c == 0) verdict.store(pack16 ? 1 : 2);
         filled[(size_t)c] = pack16 ? 2 : 1;
       }
       cv.notify_all();
@@ -272,16 +308,18 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
     std::mutex &mu;
     std::condition_variable &cv;
     std::vector<char> &recorded;
+    std::atomic<int> &verdict;
     ~Pool() {
       {
         std::lock_guard<std::mutex> lk(mu);
         for (char &r : recorded) if (r == 0) r = 2;  // nothing will be recorded any more: do not wait for it
+        if (verdict.load() == 0) verdict.store(2);
       }
       cv.notify_all();
       for (std::thread &t : th) t.join();
     }
-  } pool{{}, mu, cv, recorded};
-  const int nthreads = (int)std::min<long long>(H->nthreads, nchunks);
+  } pool{{}, mu, cv, recorded, verdict};
+  const int nthreads = nchunks > 0 ? P : 0;
   for (int t = 0; t < nthreads; ++t) pool.th.emplace_back(worker);
 
   struct Guard {  // every early return gives the matrix and the device image back
@@ -449,16 +487,17 @@ inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int
   };
   hooks.slices = [&](isph_mat *A, int s0, int s1) -> int {
     const Sell &S = A->S;
-    hipLaunchKernelGGL(k_sell_compress_cols, dim3((s1 - s0 + 3) / 4), dim3(kBlock), 0, ctx->stream, s0, s1,
-                       (const long long *)S.slice_off.p, (const int *)S.col.p, S.col16.p, S.wtab.p, H->flag.p + 1);
     const int ready = s1 == S.nslices ? F->nblocks : s1 / spb;
     const int batch = std::max(1, F->nblocks / kBatchDiv);
-    if (ready > blocks_done && (ready - blocks_done >= batch || s1 == S.nslices)) {
+    const bool fire = ready > blocks_done && (ready - blocks_done >= batch || s1 == S.nslices);
+    if (fire) ISPH_CHECK_HIP(hipEventRecord(H->ev_conv, ctx->stream));  // behind the conversion, in front of the column windows
+    hipLaunchKernelGGL(k_sell_compress_cols, dim3((s1 - s0 + 3) / 4), dim3(kBlock), 0, ctx->stream, s0, s1,
+                       (const long long *)S.slice_off.p, (const int *)S.col.p, S.col16.p, S.wtab.p, H->flag.p + 1);
+    if (fire) {
       // consecutive batches run on alternating side streams behind the conversion of their rows, so their
       // dependency-chain latencies overlap each other and the link
       const int nb = ready - blocks_done;
       hipStream_t st = H->aux[nbatch % HostStager::kAux];
-      ISPH_CHECK_HIP(hipEventRecord(H->ev_conv, ctx->stream));
       ISPH_CHECK_HIP(hipStreamWaitEvent(st, H->ev_conv, 0));
       ilu_launch_extract(ctx, F, S, blocks_done, nb, st);
       ilu_launch_schedule(ctx, F, S, blocks_done, nb, false, st);

@@ -13,6 +13,7 @@ from isph_amd import build, hip, workload  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rep = sys.argv[2] if len(sys.argv) > 2 else "7"
+keep = len(sys.argv) > 3 and sys.argv[3] == "keep"   # leave the system file under /dev/shm for a profiler run
 exe = build.build_cpp_test()
 ctx = hip.Context(0)
 sp = workload.TGVSpec(dim=3, ncell=(n, n, n), brick=(8, 8, 8), mode=workload.ADVECT)
@@ -32,5 +33,5 @@ try:
     print("\n".join(l for l in r.stdout.splitlines() if l.startswith("{")), r.stderr[-500:])
 finally:
     for f_ in (fin, fout):
-        if os.path.exists(f_):
+        if os.path.exists(f_) and not keep:
             os.remove(f_)
