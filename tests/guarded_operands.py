@@ -96,6 +96,11 @@ def main():
         assert hip.solve(ctx, A, b1, x1, prec=Ms, singular=True, null_mask=G(np.ones(n, np.int32))).converged == 1
         rp, ci, val = A.export_csr()
         hip.Matrix.from_csr(ctx, G(rp), G(ci), G(val)).spmv(G(np.ones(n)))
+        # the fused host ingress (matrix + block ILU(0) in one call) and the ranged row export
+        Af, Mf = hip.Matrix.from_host_csr_with_bjacobi(ctx, G(rp), G(ci), G(val), 256)
+        Mf.apply(G(np.ones(n)))
+        rpr, cir, vr = Af.export_rows(n - 70, 70)
+        assert rpr[-1] == rp[n] - rp[n - 70] and np.array_equal(cir, ci[rp[n - 70]:rp[n]])
         # the streaming operators either side of the solve (in place on their [nall] operands)
         vs, pp = G(np.ascontiguousarray(p["v"])), G(np.asarray(pres).copy())
         hip.correct_velocity_pressure(ctx, p, colmap, 0.01, rho, pres, vs, pp, vfrac, antisym=antisym, Gc=kw["Gc"])
