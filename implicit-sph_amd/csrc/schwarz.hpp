@@ -27,6 +27,7 @@
 // ilu.hpp, whose blocks break the chain.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <queue>
 #include <thread>
 #include <type_traits>
@@ -551,7 +552,13 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   std::vector<long long> lrp((size_t)nloc + 1, 0);
   std::vector<int> lci;
   std::vector<double> lv;
-  {
+  if (nsub == 1 && nloc == n && A->S.ncol == n) {
+    // one subdomain = the whole matrix and no ghost columns to filter (the reference on one rank; the extended matrix of
+    // isph_prec_create_overlap): the local matrix is the host CSR itself, rows already column-sorted
+    lrp.swap(rp);
+    lci.swap(ci);
+    lv.swap(av);
+  } else {
     const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     // pass 1: counts
     auto count = [&](int t) {
@@ -608,9 +615,9 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   std::vector<double> fv;
   bool missing_diag = false;
   if (fill == 0) {
-    frp = lrp;
-    fci = lci;
-    fv = lv;
+    frp.swap(lrp);  // the local matrix IS the factor pattern: no second copy of 1.2 GB at 10^6 rows
+    fci.swap(lci);
+    fv.swap(lv);
     for (int q = 0; q < nloc; ++q) {
       const auto b = fci.begin() + frp[(size_t)q], e = fci.begin() + frp[(size_t)q + 1];
       const auto it = std::lower_bound(b, e, q);
