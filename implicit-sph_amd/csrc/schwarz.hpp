@@ -21,7 +21,7 @@
 //                      summation order: bitwise reproducible)
 // What bounds it: the dependency chain.  A whole-matrix factor of the periodic 100^3 bench system has 67 084 levels
 // per direction; a hand-off through global memory costs 1.23 us per level in the sweeps and 2.6 us in the
-// factorisation (measured): 165 ms per application, 10.3 s per 49-iteration solve -- 41 s with a
+// factorisation (measured): 165 ms per application, 9.7 s per 49-iteration solve -- 41 s with a
 // launch per level.  It exists for fidelity with the reference's configuration and for the systems the reference
 // itself runs on one rank (BASELINE configs[0]); the production path for large systems stays the block stream of
 // ilu.hpp, whose blocks break the chain.
