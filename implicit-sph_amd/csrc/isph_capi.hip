@@ -643,7 +643,7 @@ int isph_spmv(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, int 
   return ISPH_SUCCESS;
 }
 
-int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double *y_dev, int reps, double *avg_ms) {
+int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double *y_dev, int reps, int variant, double *avg_ms) {
   ISPH_REQUIRE(ctx && A && x_dev && y_dev && avg_ms && reps > 0, "bad argument");
   const Sell &S = A->S;
   ISPH_REQUIRE(S.ncol == S.nrow || A->halo.npeers > 0, "ghost columns without halo plan");
@@ -660,9 +660,7 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
   const double *xuse = x_dev;
   int nbp = 0;
   const int grid = spmv_grid(S.nslices, &nbp);
-  // kernel-tuning aid: ISPH_SPMV_VARIANT selects an experimental instantiation for this timing call only
-  const char *vs = getenv("ISPH_SPMV_VARIANT");
-  const int variant = vs ? atoi(vs) : 0;
+  // kernel-tuning aid: `variant` selects an experimental instantiation for this timing call only (0: production)
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
 #define ISPH_SPMV_LAUNCH(U, NTF)                                                                                      \
   hipLaunchKernelGGL((k_sell_spmv<U, false, NTF>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp, \

@@ -124,7 +124,7 @@ def lib():
         L.isph_mat_export_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
         L.isph_mat_destroy.argtypes = [C.c_void_p]
         L.isph_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.isph_spmv_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.isph_spmv_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.isph_prec_create.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
         L.isph_prec_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_prec_export_ilu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -436,9 +436,9 @@ class Matrix:
         _check(lib().isph_spmv(self.ctx.h, self.h, _ptr(x), _ptr(y), _on_device(x, y)))
         return y
 
-    def spmv_time(self, x, y, reps=20):
+    def spmv_time(self, x, y, reps=20, variant=0):
         ms = C.c_double()
-        _check(lib().isph_spmv_time(self.ctx.h, self.h, _ptr(x), _ptr(y), reps, C.byref(ms)))
+        _check(lib().isph_spmv_time(self.ctx.h, self.h, _ptr(x), _ptr(y), reps, int(variant), C.byref(ms)))
         return ms.value
 
     def close(self):

@@ -133,9 +133,10 @@ void isph_mat_destroy(isph_mat *A);
 int isph_spmv(isph_ctx *ctx, const isph_mat *A, const double *x /*[h|d]*/,
               double *y /*[h|d]*/, int on_device);
 /* Time `reps` back-to-back SpMV launches with HIP events on the library
- * stream; returns the average kernel time in milliseconds. */
+ * stream; returns the average kernel time in milliseconds.  variant 0 = the production kernel; 1..5 = experimental
+ * instantiations of the 32-bit-column kernel (unroll / cache policy), for scripts/spmv_variants.py only. */
 int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double *y_dev,
-                   int reps, double *avg_ms);
+                   int reps, int variant, double *avg_ms);
 
 /* ---- preconditioner --------------------------------------------------- */
 

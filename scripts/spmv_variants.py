@@ -24,9 +24,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     info = A.info()
     alg = 12 * info["nnz"] + 16 * info["nrow"] + 4 * (info["nrow"] + 1)
     for v in (0, 1, 2, 3, 4, 5, 0):
-        os.environ["ISPH_SPMV_VARIANT"] = str(v)
-        A.spmv_time(x, y, reps=10)
-        ms = min(A.spmv_time(x, y, reps=50) for _ in range(3))
+        A.spmv_time(x, y, reps=10, variant=v)
+        ms = min(A.spmv_time(x, y, reps=50, variant=v) for _ in range(3))
         print("variant %d: %.4f ms  %.0f GB/s  %.3f of 8 TB/s" % (v, ms, alg / ms / 1e6, alg / ms / 1e6 / 8000), flush=True)
 else:
     subprocess.run([sys.executable, os.path.abspath(__file__), "child"], check=True)
