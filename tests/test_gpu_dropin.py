@@ -187,3 +187,28 @@ def test_fused_ingress_equals_separate_calls(gpu_ctx, n, block, shuffle, brick):
     assert i1.iters == i2.iters and np.array_equal(x1, x2)
     for o in (M1, M2, A1, A2):
         o.close()
+
+
+def test_host_csr_ingress_degenerate_shapes(gpu_ctx):
+    """No entries at all, rows without entries at both ends, one dense row: the pipeline's chunk / slice book-keeping at
+    its edges (no chunk, a first chunk that is also the last, slices that complete without a copy)."""
+    n = 130
+    A = hip.Matrix.from_csr(gpu_ctx, np.zeros(n + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    assert A.info()["nnz"] == 0 and np.array_equal(A.spmv(np.ones(n)), np.zeros(n))
+    A.close()
+    rp = np.zeros(n + 1, np.int32)
+    rp[70:] = n                                          # row 69 is dense, everything else is empty
+    ci = np.arange(n, dtype=np.int32)
+    v = np.arange(1.0, n + 1.0)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, v)
+    y = A.spmv(np.ones(n))
+    assert y[69] == v.sum() and np.count_nonzero(y) == 1
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2, v)
+    A.close()
+    # the fused entry on an identity matrix: every block factors trivially, M^-1 = I
+    m = 1000
+    Af, Mf = hip.Matrix.from_host_csr_with_bjacobi(gpu_ctx, np.arange(m + 1, dtype=np.int32), np.arange(m, dtype=np.int32), np.full(m, 2.0), 64)
+    r = np.linspace(-1.0, 1.0, m)
+    assert np.array_equal(Mf.apply(r), r / 2.0) and np.array_equal(Af.spmv(r), 2.0 * r)
+    Mf.close(); Af.close()
