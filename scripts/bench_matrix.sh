@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 : > $OUT/bench_matrix.txt
 run() {
-  timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > $OUT/bench_matrix_one.log 2>&1
+  timeout -k 10 300 python bench.py --no-cpu-baseline --no-dropin "$@" > $OUT/bench_matrix_one.log 2>&1
   grep '^{"metric' $OUT/bench_matrix_one.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print('$*', '| rows', c['rows_per_gpu'], 'its', c['iterations'], 'ms', round(d['ms_per_step'],1), 'spmv frac', round(d['roofline']['frac'],3), 'levels', [l['rows'] for l in c.get('amg',{}).get('levels',[])])" >> $OUT/bench_matrix.txt 2>&1 || echo "$* FAILED" >> $OUT/bench_matrix.txt
 }
 run --prec bjacobi-ilu0
@@ -25,4 +25,5 @@ run --ncell 100 --kernel quintic --prec sa-amg
 run --mode jitter --prec bjacobi-ilu0
 run --mode jitter --prec jacobi
 run --mode jitter --prec sa-amg
+run --prec ilu0 --steps 1 --warmup 0
 cat $OUT/bench_matrix.txt
