@@ -1,4 +1,4 @@
-"""Soak: many consecutive set-up + solve rounds of the headline configuration (ILU and SA-AMG alternating); device memory
+"""Soak: many consecutive set-up + solve rounds of the headline configuration (ILU, SA-AMG and the host-CSR drop-in in turn); device memory
 in use and the time per round must stay flat (the pool hands the same buffers back every round).
 usage on the GPU box: python scripts/soak.py [rounds]"""
 import os
@@ -30,14 +30,22 @@ rho = torch.from_numpy(parts["rho"]).to(dev)
 v = torch.from_numpy(np.ascontiguousarray(parts["v"])).to(dev)
 nullvec = torch.full((n,), 1.0 / np.sqrt(n), dtype=torch.float64, device=dev)
 times, mem = [], []
+host = None   # the system as a host CSR: every third round goes through the drop-in's ingress (pinned ring, fused set-up)
 for r in range(rounds):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    vf = hip.compute_volumes(ctx, dp, colmap)
-    A, b = hip.assemble_poisson(ctx, dp, colmap, spec.dt, rho, v, vfrac=vf[own].contiguous())
-    M = hip.PrecondAMG(ctx, A, nullvec=nullvec) if r % 2 else hip.Precond(ctx, A, "bjacobi-ilu0", 512)
-    x = torch.zeros(n, dtype=torch.float64, device=dev)
-    info = hip.solve(ctx, A, b, x, prec=M, singular=True)
+    if r % 3 == 2 and host is not None:
+        A, M = hip.Matrix.from_host_csr_with_bjacobi(ctx, host[0], host[1], host[2], 512)
+        bh, xh = host[3].copy(), np.zeros(n)
+        info = hip.solve(ctx, A, bh, xh, prec=M, singular=True)
+    else:
+        vf = hip.compute_volumes(ctx, dp, colmap)
+        A, b = hip.assemble_poisson(ctx, dp, colmap, spec.dt, rho, v, vfrac=vf[own].contiguous())
+        if host is None:
+            host = A.export_csr() + (b.cpu().numpy(),)
+        M = hip.PrecondAMG(ctx, A, nullvec=nullvec) if r % 2 else hip.Precond(ctx, A, "bjacobi-ilu0", 512)
+        x = torch.zeros(n, dtype=torch.float64, device=dev)
+        info = hip.solve(ctx, A, b, x, prec=M, singular=True)
     M.close()
     A.close()
     torch.cuda.synchronize()
@@ -46,7 +54,7 @@ for r in range(rounds):
     mem.append((tot - fr) / 1e9)
     assert info.converged == 1
     if r % 50 == 49 or r == rounds - 1:
-        print("round %d: last 20 rounds %.1f ms avg (ILU and AMG alternating), device memory in use %.2f GB, library pool %.2f GB"
+        print("round %d: last 20 rounds %.1f ms avg (ILU, AMG and the host-ingress drop-in in turn), device memory in use %.2f GB, library pool %.2f GB"
               % (r + 1, float(np.mean(times[-20:])), mem[-1], hip.pool_cached_bytes() / 1e9), flush=True)
 print("memory in use: round 10 %.2f GB, last %.2f GB; time per round: rounds 10-30 %.1f ms, last 20 %.1f ms"
       % (mem[9], mem[-1], float(np.mean(times[10:30])), float(np.mean(times[-20:]))))
