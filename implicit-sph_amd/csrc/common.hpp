@@ -258,6 +258,32 @@ __device__ __forceinline__ double group8_sum(double v) {
   return v;
 }
 
+// sum within aligned groups of 16 lanes (a DPP row), result in every lane: the butterfly v += v(lane ^ 1), ^ 2, ^ 4,
+// ^ 8 with the exchanges done by DPP moves instead of ds_bpermute, which queues behind other LDS traffic (the polling
+// reads of the triangular sweeps).  quad_perm gives the partners of the first two steps; after them a quad holds one
+// value, so the mirror of 8 lanes and the mirror of 16 deliver exactly the operands of the ^ 4 and ^ 8 steps --
+// the same bits as the __shfl_xor butterfly.
+__device__ __forceinline__ double group16_sum(double v) {
+  v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);   // row_half_mirror
+  v += dpp_move<0x140>(v);   // row_mirror
+  return v;
+}
+
+// max within aligned groups of 16 lanes, result in every lane (same exchanges as group16_sum)
+template <int CTRL>
+__device__ __forceinline__ int dpp_move_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int group16_max_i32(int v) {
+  int t = dpp_move_i32<0xB1>(v); v = t > v ? t : v;
+  t = dpp_move_i32<0x4E>(v); v = t > v ? t : v;
+  t = dpp_move_i32<0x141>(v); v = t > v ? t : v;
+  t = dpp_move_i32<0x140>(v); v = t > v ? t : v;
+  return v;
+}
+
 // XCD-aware block remap: the dispatcher deals blocks round-robin over the 8
 // XCDs, so blockIdx b lands on XCD b%8.  Give each XCD one contiguous range of
 // work items so its private L2 only sees that range's slice of x.

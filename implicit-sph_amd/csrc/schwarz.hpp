@@ -16,18 +16,19 @@
 // isph_schwarz_params::level_launches as the bit-for-bit cross-check):
 //   k_gilu_factor_sf   IKJ numeric factorisation, one wave per row, rows dequeued in level order; the row image
 //                      (columns + values) lives in LDS; a finished row is published write-through and flagged
-//   k_gilu_solve_sf    the triangular sweeps, 16 lanes per row, four rows per wave; a result is its own ready flag
+//   k_gilu_solve_run   the triangular sweeps, 16 lanes per row, runs of 64 positions per workgroup; a result is its
+//                      own ready flag, handed on through LDS inside a run and through global memory between runs
 //   k_gilu_gather / k_gilu_combine   import on the extended rows / export with the combine mode (fixed
 //                      summation order: bitwise reproducible)
 // What bounds it: the dependency chain.  A whole-matrix factor of the periodic 100^3 bench system has 67 084 levels
-// per direction; a hand-off through global memory costs 1.23 us per level in the sweeps and 2.6 us in the
-// factorisation (measured): 165 ms per application, 9.7 s per 49-iteration solve -- 41 s with a
-// launch per level.  It exists for fidelity with the reference's configuration and for the systems the reference
+// per direction; measured per level: 1.35 us for a hand-off between workgroups through global
+// memory, 0.40 us inside a workgroup through LDS, 0.67 us on average over a sweep; 2.6 us in the factorisation.  It exists for fidelity with the reference's configuration and for the systems the reference
 // itself runs on one rank (BASELINE configs[0]); the production path for large systems stays the block stream of
 // ilu.hpp, whose blocks break the chain.
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <queue>
 #include <thread>
 #include <type_traits>
@@ -49,15 +50,18 @@ struct isph_schwarz {
   std::vector<int> lptr, uptr;    // host: first entry of every level in lord / uord
   std::vector<int> loc_ptr;       // host: [nsub+1]
   isph::DevBuf<int> err;
-  // synchronisation-free path (one persistent launch per sweep, see k_gilu_solve_sf): the level orders padded so that
+  // synchronisation-free path (one persistent launch per sweep, see k_gilu_solve_run): the level orders padded so that
   // every level starts at a multiple of 4 positions (-1 = padding), the two result vectors that double as ready flags,
   // the per-row "factored" flags and the work counters [0] L sweep, [1] U sweep, [2] factorisation, [3] spin time-out
   isph::DevBuf<int> lord4, uord4, rowflag, ctr;
+  isph::DevBuf<int> lpos4, upos4;  // [nloc] position of every local row in lord4 / uord4
+  isph::DevBuf<int> lrun, urun;    // first position of every run of the LDS hand-off sweeps (+ end)
+  int nrun_l = 0, nrun_u = 0;
   isph::DevBuf<unsigned long long> ybits, zbits;
   int n4l = 0, n4u = 0;
   bool syncfree = true;
   int *h_tmo = nullptr;   // pinned: the time-out word of the previous application (checked at the next one)
-  int sweep_blocks = 0;   // persistent workgroups (256 threads) of a sweep
+  int sweep_blocks = 0;   // persistent workgroups (1024 threads) of a sweep
 };
 
 namespace isph {
@@ -138,10 +142,7 @@ __global__ __launch_bounds__(256) void k_gilu_lower(int count, const int *__rest
     const int nlow = dg[i];
     for (int t = sub; t < nlow; t += 16) s += val[b + t] * w[ci[b + t]];
   }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  s += __shfl_xor(s, 8, 64);
+  s = group16_sum(s);
   if (live && sub == 0) w[i] -= s;
 }
 
@@ -160,23 +161,19 @@ __global__ __launch_bounds__(256) void k_gilu_upper(int count, const int *__rest
     d = val[b + kd];
     for (long long q = b + kd + 1 + sub; q < e; q += 16) s += val[q] * w[ci[q]];
   }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  s += __shfl_xor(s, 8, 64);
+  s = group16_sum(s);
   if (live && sub == 0) w[i] = (w[i] - s) / d;
 }
 
 // ---- synchronisation-free sweeps ----------------------------------------------------------------------------------
 // One launch per triangular sweep instead of one per dependency level (the whole-matrix factor of the 100^3 system has
-// 67 084 L levels: 134 168 launches per application before).  Persistent waves take four consecutive positions of the
-// level order at a time from one device-wide counter (a position's dependencies sit at earlier positions, and a
-// position is only ever held by a running wave, so the sweep cannot deadlock whatever the residency of the grid), 16
-// lanes per row as before.  A result IS its own ready flag: the output vector starts as a signalling-NaN pattern no
-// arithmetic produces, every result is ONE 8-byte write-through (sc1) store, and a consumer polls the very word it
-// needs with sc1 loads -- no flag, no fence (MI355X_MICROARCH.md, hand-off price list, "granule").  Every access to the
-// shared words is an agent-scope atomic on a global-address-space pointer; nothing else touches them in the launch.
-// The arithmetic (lane t, t+16, ... of a row, xor-shuffle sum) is that of k_gilu_lower / k_gilu_upper: same bits.
+// 67 084 L levels: 134 168 launches per application before).  Persistent workgroups take RUNS of the level order from
+// one device-wide counter (a position's dependencies sit at earlier positions, and a position is only ever held by a
+// running workgroup, so the sweep cannot deadlock whatever the residency of the grid), 16 lanes per row as before.  A
+// result IS its own ready flag: the output vector starts as a signalling-NaN pattern no arithmetic produces, every
+// result is ONE 8-byte write-through (sc1) store, and a consumer polls the very word it needs with sc1 loads -- no
+// flag, no fence (MI355X_MICROARCH.md, hand-off price list, "granule").  Every access to the shared words is an
+// agent-scope atomic on a global-address-space pointer; nothing else touches them in the launch.
 // A spin that sees no progress for kSpinLimit polls sets ctr[3] and stores 0 -- every wave drains, the host fails the
 // application loudly.
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
@@ -193,85 +190,142 @@ __device__ __forceinline__ void sf_store(unsigned long long *p, unsigned long lo
 __device__ __forceinline__ int sf_flag(const int *p) {
   return __hip_atomic_load((const gi32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// [n] of both: a word that is always there (0.0), see k_gilu_solve_run
 __global__ void k_gilu_fill_bits(int n, unsigned long long *__restrict__ a, unsigned long long *__restrict__ b) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    a[i] = kGiluSentinel;
-    b[i] = kGiluSentinel;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+    a[i] = i < n ? kGiluSentinel : 0ull;
+    b[i] = i < n ? kGiluSentinel : 0ull;
   }
 }
 
-// A lane's share of a row is handled in chunks of kSfChunk entries: the chunk's factor values and columns are loaded
-// first, then ALL its dependencies are requested together and only the ones still missing are asked for again -- a
-// round of polling costs one memory round trip whatever the number of outstanding words, and nothing but that round
-// trip, the 16-lane sum and the one store sits between a row's last dependency and its own result (the first version
-// walked the entries one after the other: factor loads, then a poll, per entry -- 2.1 us per level against 1.x now;
-// both numbers in DESIGN section 7).
-constexpr int kSfChunk = 6;  // 16 lanes x 6 = 96 entries per round: a whole ILU(0) row of the SPH operators
-
+// A lane's share of a row is handled in chunks of kSfChunk entries (16 lanes x 6 = 96 entries: a whole ILU(0) row of
+// the SPH operators).  A workgroup of 16 waves takes a RUN of up to 64 consecutive positions of the padded level order,
+// whole levels (three or four of the SPH factors), four positions = rows of one level per wave; a dependency
+// whose position lies inside the run is read from the run's LDS image of the results, the others from global memory
+// with sc1 loads.  Only the first level of a run waits for a global hand-off (0.5 us for the bare exchange between two
+// workgroups, scripts/lds_handoff_probe.hip); inside the run a hand-off is an LDS write and read (0.08 us).
+// At those latencies the instructions between "last dependency seen" and "result stored" are what is left, so the row
+// does everything it can before it waits: the products with the dependencies outside the run are summed as soon as
+// those are there (they belong to earlier levels), the ones inside the run are kept as a list of two (value, slot)
+// pairs per lane -- a lane rarely has more; the rest go through a slower loop -- and what remains after the last word
+// arrives is two multiply-adds, the 16-lane sum and the store.  Summation order per lane: outside-the-run terms by
+// entry, then inside-the-run terms by entry; fixed by the factor's pattern and the run table, so the result is
+// reproducible bit for bit from application to application, and differs from the level-launch kernels' by rounding.
+// Deadlock-free for the same reason as above: runs are dequeued in order, a row waits for earlier positions only,
+// and all waves of a workgroup are resident together.
+constexpr int kSfChunk = 6;
+constexpr int kRun = 64;
+constexpr int kRunsNear = 2;   // a run polls for its words once all but this many of the runs before it are complete
 template <bool UPPER>
-__global__ __launch_bounds__(256) void k_gilu_solve_sf(int npos, const int *__restrict__ order4,
-                                                       const long long *__restrict__ rp, const int *__restrict__ ci,
-                                                       const int *__restrict__ dg, const double *__restrict__ val,
-                                                       const double *__restrict__ rhs, unsigned long long *out,
-                                                       int *ctr) {
-  __shared__ int s_base[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 15, grp = lane >> 4;
-  int *head = ctr + (UPPER ? 1 : 0), *tmo = ctr + 3;
-  for (;;) {
-    // the dequeued position goes through LDS: `if (lane == 0) base = add(); base = readfirstlane(base)` was compiled into
-    // a loop nest in which lane 0 had left the active set at the readfirstlane, which then returned another lane's 0
-    if (lane == 0) s_base[wave] = __hip_atomic_fetch_add((gi32_t *)head, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int base = s_base[wave];
-    if (base >= npos) break;
-    const int pos = base + grp;
-    const int i = pos < npos ? order4[pos] : -1;  // -1: padding at the end of a level
+__global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *__restrict__ runstart,
+                                                         const int *__restrict__ order4,
+                                                         const int *__restrict__ rowpos4,
+                                                         const long long *__restrict__ rp, const int *__restrict__ ci,
+                                                         const int *__restrict__ dg, const double *__restrict__ val,
+                                                         const double *__restrict__ rhs, unsigned long long *out,
+                                                         int ready, int *ctr, int knear) {
+  // [kRun] of an image is a word that is always there (0.0): the target of a lane's unused list entries
+  __shared__ unsigned long long s_out[2][kRun + 1];
+  __shared__ int s_base[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15, grp = lane >> 4;
+  int *head = ctr + (UPPER ? 1 : 0), *tmo = ctr + 3, *done = ctr + (UPPER ? 5 : 4);
+  bool had_run = false;
+  for (int par = 0;; par ^= 1) {
+    __builtin_amdgcn_s_setprio(0);
+    if (had_run) {
+      __syncthreads();   // every row of the previous run is stored
+      if (tid == 0) __hip_atomic_fetch_add((gi32_t *)done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) s_base[par] = __hip_atomic_fetch_add((gi32_t *)head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid <= kRun) s_out[par][tid] = tid < kRun ? kGiluSentinel : 0ull;
+    __syncthreads();   // the other image is free again once every wave has passed this barrier
+    const int run = s_base[par];
+    if (run >= nruns) break;
+    had_run = true;
+    const int base = runstart[run], len = runstart[run + 1] - base;
+    const int pos = base + 4 * wave + grp;
+    const int i = pos - base < len ? order4[pos] : -1;
     double s = 0.0, d = 1.0, ri = 0.0;
-    bool timed_out = sf_flag(tmo) != 0;  // the launch has given up: drain without waiting
+    bool timed_out = sf_flag(tmo) != 0;
     if (i >= 0) {
       const long long b = rp[i];
       const int kd = dg[i];
-      // this lane's entries: first, first + 16, ... below last
-      const long long first = UPPER ? b + kd + 1 + sub : b + sub;
+      const long long first = UPPER ? b + kd + 1 : b;   // the chunk loop is uniform over the row's 16 lanes
       const long long last = UPPER ? rp[i + 1] : b + kd;
       ri = rhs[i];
       if (UPPER) d = val[b + kd];
       for (long long q0 = first; q0 < last; q0 += 16 * kSfChunk) {
-        double v[kSfChunk];
-        int c[kSfChunk];
+        double vf[kSfChunk], w0 = 0.0, w1 = 0.0;
+        int c[kSfChunk], slot[kSfChunk], n0 = kRun, n1 = kRun, nn = 0;
         unsigned long long x[kSfChunk];
 #pragma unroll
         for (int k = 0; k < kSfChunk; ++k) {
-          const long long q = q0 + 16 * k;
+          const long long q = q0 + sub + 16 * k;
           const bool ok = q < last;
-          v[k] = ok ? val[q] : 0.0;
+          vf[k] = ok ? val[q] : 0.0;
           c[k] = ok ? ci[q] : -1;
         }
 #pragma unroll
-        for (int k = 0; k < kSfChunk; ++k) x[k] = c[k] >= 0 ? sf_load(out + c[k]) : 0ull;
+        for (int k = 0; k < kSfChunk; ++k) {
+          slot[k] = c[k] >= 0 ? rowpos4[c[k]] - base : -1;   // >= 0: inside this run
+          if (slot[k] >= 0) {
+            if (nn == 0) { n0 = slot[k]; w0 = vf[k]; }
+            if (nn == 1) { n1 = slot[k]; w1 = vf[k]; }
+            if (nn < 2) { vf[k] = 0.0; slot[k] = -1; }   // on the list; what keeps slot >= 0 goes the slow way
+            ++nn;
+            c[k] = ready;
+          }
+          if (c[k] < 0) c[k] = ready;   // no entry: the word that is always there, times 0
+        }
+        // phase 0: far from the front of the sweep nothing this run waits for can be there; sleep until all but a few
+        // of the runs before it are complete instead of asking for every missing word again and again
+        if (knear > 0 && q0 == first) {
+          int sp = 0;
+          while (sf_flag(done) < run - knear && !timed_out) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++sp >= kSpinLimit || sf_flag(tmo)) timed_out = true;
+          }
+        }
+        // phase 1: the dependencies outside the run, from global memory, all six words of the lane per round
         int spins = 0;
         for (;;) {
           bool pending = false;
 #pragma unroll
+          for (int k = 0; k < kSfChunk; ++k) x[k] = sf_load(out + c[k]);
+#pragma unroll
           for (int k = 0; k < kSfChunk; ++k) pending = pending || x[k] == kGiluSentinel;
           if (!pending || timed_out) break;
           __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-          for (int k = 0; k < kSfChunk; ++k)
-            if (x[k] == kGiluSentinel) x[k] = sf_load(out + c[k]);
           if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) timed_out = true;
         }
 #pragma unroll
-        for (int k = 0; k < kSfChunk; ++k)
-          if (c[k] >= 0) s += v[k] * (x[k] == kGiluSentinel ? 0.0 : __longlong_as_double((long long)x[k]));
+        for (int k = 0; k < kSfChunk; ++k) s += vf[k] * (timed_out ? 0.0 : __longlong_as_double((long long)x[k]));
+        // phase 2: the dependencies inside the run, from its LDS image
+        unsigned long long y0, y1;
+        spins = 0;
+        for (;;) {
+          y0 = __hip_atomic_load(&s_out[par][n0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          y1 = __hip_atomic_load(&s_out[par][n1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((y0 != kGiluSentinel && y1 != kGiluSentinel) || timed_out) break;
+          if ((++spins & 4095) == 0 && (sf_flag(tmo) || spins >= 64 * kSpinLimit)) timed_out = true;
+        }
+        s += w0 * (timed_out ? 0.0 : __longlong_as_double((long long)y0));
+        s += w1 * (timed_out ? 0.0 : __longlong_as_double((long long)y1));
+        if (nn > 2) {   // third and further dependencies of this lane inside the run: one after the other
+#pragma unroll
+          for (int k = 0; k < kSfChunk; ++k) {
+            if (slot[k] < 0) continue;
+            unsigned long long y;
+            spins = 0;
+            while ((y = __hip_atomic_load(&s_out[par][slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kGiluSentinel && !timed_out)
+              if ((++spins & 4095) == 0 && (sf_flag(tmo) || spins >= 64 * kSpinLimit)) timed_out = true;
+            s += vf[k] * (timed_out ? 0.0 : __longlong_as_double((long long)y));
+          }
+        }
       }
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
+    __builtin_amdgcn_s_setprio(3);   // the wave that holds the chain goes first on its SIMD
+    s = group16_sum(s);
     if (__ballot(timed_out) != 0ull) {
       if (lane == 0) __hip_atomic_store((gi32_t *)tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s = 0.0;
@@ -279,7 +333,8 @@ __global__ __launch_bounds__(256) void k_gilu_solve_sf(int npos, const int *__re
     if (i >= 0 && sub == 0) {
       const double r = UPPER ? (ri - s) / d : ri - s;
       unsigned long long bits = (unsigned long long)__double_as_longlong(r);
-      if (bits == kGiluSentinel) bits ^= 1ull;  // cannot come out of arithmetic; never leave a dependant waiting
+      if (bits == kGiluSentinel) bits ^= 1ull;
+      __hip_atomic_store(&s_out[par][pos - base], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       sf_store(out + i, bits);
     }
   }
@@ -302,7 +357,9 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
   for (;;) {
     __syncthreads();  // the previous row's image and position are no longer read
     if (lane == 0) s_pos = __hip_atomic_fetch_add((gi32_t *)(ctr + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();  // through LDS, not readfirstlane: see k_gilu_solve_sf
+    // through LDS: `if (lane == 0) p = add(); p = readfirstlane(p)` was compiled into a loop nest in which lane 0 had
+    // left the active set at the readfirstlane, which then returned another lane's 0
+    __syncthreads();
     const int pos = s_pos;
     if (pos >= nloc) break;
     const int i = order[pos];
@@ -364,7 +421,7 @@ inline void schwarz_destroy(isph_schwarz *S) {
   if (!S) return;
   S->rp.release(); S->ci.release(); S->dg.release(); S->val.release(); S->w.release(); S->rows.release();
   S->lord.release(); S->uord.release(); S->rev_ptr.release(); S->rev_idx.release(); S->err.release();
-  S->lord4.release(); S->uord4.release(); S->rowflag.release(); S->ctr.release(); S->ybits.release(); S->zbits.release();
+  S->lord4.release(); S->uord4.release(); S->lpos4.release(); S->upos4.release(); S->lrun.release(); S->urun.release(); S->rowflag.release(); S->ctr.release(); S->ybits.release(); S->zbits.release();
   if (S->h_tmo) (void)hipHostFree(S->h_tmo);
   delete S;
 }
@@ -724,6 +781,28 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   pad4(S->lptr, lord, lord4);
   pad4(S->uptr, uord, uord4);
   S->n4l = (int)lord4.size(); S->n4u = (int)uord4.size();
+  // runs of the LDS hand-off sweeps: whole levels, at most kRun positions (a level longer than that is cut)
+  auto runs_of = [&](const std::vector<int> &ptr, std::vector<int> &rs) {
+    rs.assign(1, 0);
+    int pos = 0, cur = 0;   // cur: positions in the open run
+    for (size_t l = 0; l + 1 < ptr.size(); ++l) {
+      int sz = (ptr[l + 1] - ptr[l] + 3) / 4 * 4;
+      if (cur > 0 && cur + sz > kRun) { rs.push_back(pos); cur = 0; }
+      while (sz > 0) {
+        const int take = std::min(sz, kRun - cur);
+        pos += take; cur += take; sz -= take;
+        if (cur == kRun) { rs.push_back(pos); cur = 0; }
+      }
+    }
+    if (cur > 0) rs.push_back(pos);
+  };
+  std::vector<int> lrun, urun;
+  runs_of(S->lptr, lrun);
+  runs_of(S->uptr, urun);
+  S->nrun_l = (int)lrun.size() - 1; S->nrun_u = (int)urun.size() - 1;
+  std::vector<int> lpos4((size_t)nloc, 0), upos4((size_t)nloc, 0);
+  for (size_t q = 0; q < lord4.size(); ++q) if (lord4[q] >= 0) lpos4[(size_t)lord4[q]] = (int)q;
+  for (size_t q = 0; q < uord4.size(); ++q) if (uord4[q] >= 0) upos4[(size_t)uord4[q]] = (int)q;
   // ---- combine lists: global row -> local rows (Add: every copy, Zero: the owned copy), subdomain order
   std::vector<long long> rev_ptr((size_t)n + 1, 0);
   std::vector<int> rev_idx;
@@ -764,10 +843,14 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (rc == ISPH_SUCCESS && syncfree) {
     rc = up(S->lord4, lord4);
     if (rc == ISPH_SUCCESS) rc = up(S->uord4, uord4);
+    if (rc == ISPH_SUCCESS) rc = up(S->lpos4, lpos4);
+    if (rc == ISPH_SUCCESS) rc = up(S->upos4, upos4);
+    if (rc == ISPH_SUCCESS) rc = up(S->lrun, lrun);
+    if (rc == ISPH_SUCCESS) rc = up(S->urun, urun);
     if (rc == ISPH_SUCCESS) rc = S->rowflag.reserve((size_t)(nloc > 0 ? nloc : 1));
-    if (rc == ISPH_SUCCESS) rc = S->ctr.reserve(4);
-    if (rc == ISPH_SUCCESS) rc = S->ybits.reserve((size_t)(nloc > 0 ? nloc : 1));
-    if (rc == ISPH_SUCCESS) rc = S->zbits.reserve((size_t)(nloc > 0 ? nloc : 1));
+    if (rc == ISPH_SUCCESS) rc = S->ctr.reserve(8);
+    if (rc == ISPH_SUCCESS) rc = S->ybits.reserve((size_t)nloc + 1);
+    if (rc == ISPH_SUCCESS) rc = S->zbits.reserve((size_t)nloc + 1);
     if (rc == ISPH_SUCCESS && hipHostMalloc((void **)&S->h_tmo, sizeof(int), hipHostMallocDefault) != hipSuccess)
       rc = fail("pinned allocation failed", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) *S->h_tmo = 0;
@@ -775,10 +858,11 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (rc != ISPH_SUCCESS) { schwarz_destroy(S); return rc; }
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  // persistent workgroups of a sweep (4 waves x 4 rows each).  The sweeps are bound by the hand-off latency of the
-  // dependency chain, not by the rows in flight: 4 ... 256 workgroups gave 11.2 ... 10.1 ms on a 2384-level factor
-  // (profiles/r03_schwarz_syncfree.txt); a quarter of the CUs keeps the pollers off most of the chip
-  S->sweep_blocks = std::max(16, ncu / 4);
+  // persistent workgroups of a sweep (16 waves x 4 rows each: one run).  The sweeps are bound by the hand-off latency
+  // of the dependency chain, not by the rows in flight -- the workgroups ahead of the front only have to have their
+  // operands loaded by the time it reaches them (about 3 us per run): 16, 32, 64 workgroups gave 9.99, 10.09, 10.18 ms
+  // on a 7503-level factor (profiles/r03_schwarz_syncfree.txt)
+  S->sweep_blocks = std::max(16, ncu / 8);
   hipError_t e = hipMemsetAsync(S->err.p, 0, sizeof(int), ctx->stream);
   // ---- numeric factorisation
   const size_t lds = (size_t)maxrow * 12 + 16;
@@ -823,12 +907,15 @@ inline int schwarz_apply(isph_ctx *ctx, const isph_schwarz *S, const double *r, 
     ISPH_REQUIRE(*S->h_tmo == 0, "Schwarz ILU sweep: a row waited for a dependency beyond the spin limit (previous application)");
     hipLaunchKernelGGL(k_gilu_fill_bits, dim3(stream_grid(nloc)), dim3(kBlock), 0, ctx->stream, nloc, S->ybits.p, S->zbits.p);
     ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p, 0, 2 * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL((k_gilu_solve_sf<false>), dim3(S->sweep_blocks), dim3(256), 0, ctx->stream, S->n4l, (const int *)S->lord4.p,
-                       (const long long *)S->rp.p, (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p,
-                       (const double *)S->w.p, S->ybits.p, S->ctr.p);
-    hipLaunchKernelGGL((k_gilu_solve_sf<true>), dim3(S->sweep_blocks), dim3(256), 0, ctx->stream, S->n4u, (const int *)S->uord4.p,
-                       (const long long *)S->rp.p, (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p,
-                       reinterpret_cast<const double *>(S->ybits.p), S->zbits.p, S->ctr.p);
+    ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p + 4, 0, 2 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL((k_gilu_solve_run<false>), dim3(S->sweep_blocks), dim3(16 * kRun), 0, ctx->stream, S->nrun_l,
+                       (const int *)S->lrun.p, (const int *)S->lord4.p, (const int *)S->lpos4.p, (const long long *)S->rp.p,
+                       (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p, (const double *)S->w.p, S->ybits.p,
+                       nloc, S->ctr.p, kRunsNear);
+    hipLaunchKernelGGL((k_gilu_solve_run<true>), dim3(S->sweep_blocks), dim3(16 * kRun), 0, ctx->stream, S->nrun_u,
+                       (const int *)S->urun.p, (const int *)S->uord4.p, (const int *)S->upos4.p, (const long long *)S->rp.p,
+                       (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p,
+                       reinterpret_cast<const double *>(S->ybits.p), S->zbits.p, nloc, S->ctr.p, kRunsNear);
     ISPH_CHECK_HIP(hipMemcpyAsync(S->h_tmo, S->ctr.p + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_gilu_combine, dim3((S->n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S->n, S->rev_ptr.p,
                        S->rev_idx.p, reinterpret_cast<const double *>(S->zbits.p), z);

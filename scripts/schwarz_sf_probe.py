@@ -44,7 +44,7 @@ for n in ns:
         torch.cuda.synchronize(); t0 = time.perf_counter()
         Ml.apply(r, z2)
         torch.cuda.synchronize()
-        P("  apply level launches %.2f ms" % ((time.perf_counter() - t0) * 1e3), "equal bits:", bool(torch.equal(z, z2)),
+        P("  apply level launches %.2f ms" % ((time.perf_counter() - t0) * 1e3), "equal bits:", bool(torch.equal(z, z2)), "max rel diff %.2e" % float((z - z2).abs().max() / z2.abs().max()),
           "factor equal:", all(np.array_equal(a, c) for a, c in zip(Ms.export(), Ml.export())))
         Ml.close()
     x = np.zeros(N)

@@ -146,9 +146,12 @@ def test_overlap_level_one_across_ranks_through_the_self_peer_plan(fill, combine
 @pytest.mark.parametrize("n,fill,block,overlap", [(16, 0, 0, 0), (16, 1, 0, 0), (32, 0, 0, 0), (24, 1, 0, 0), (24, 0, 2048, 1)])
 def test_synchronisation_free_sweeps_equal_the_level_launches(gpu_ctx, n, fill, block, overlap):
     """The persistent form of the factorisation and of the two triangular sweeps (one launch each; a row waits for the
-    very words it depends on, csrc/schwarz.hpp k_gilu_factor_sf / k_gilu_solve_sf) against one launch per dependency
-    level: the same factor and the same application BIT FOR BIT (same operations in the same order), on whole-matrix
-    ILU(0)/ILU(1) with thousands of levels and on overlapping subdomains.  Repeated applications reuse the flag words."""
+    very words it depends on, csrc/schwarz.hpp k_gilu_factor_sf / k_gilu_solve_run) against one launch per dependency
+    level, on whole-matrix ILU(0)/ILU(1) with thousands of levels and on overlapping subdomains.  The factor: BIT FOR
+    BIT (same operations in the same order).  The application: the sweeps sum a row's products in another order (terms
+    from outside the workgroup's run of rows first, then the ones handed on through LDS), so equal to a few units of
+    rounding -- and bit for bit from one application to the next, whatever the order the rows happened to finish in.
+    Repeated applications reuse the flag words."""
     sp = tgv_spec(dim=3, n=n, mode=workload.JITTER)
     p = workload.make_tgv(sp)
     colmap = workload.single_rank_colmap(p)
@@ -166,10 +169,14 @@ def test_synchronisation_free_sweeps_equal_the_level_launches(gpu_ctx, n, fill, 
     for rep in range(3):
         r = rng.standard_normal(N)
         zs, zl = Ms.apply(r), Ml.apply(r)
-        assert np.all(np.isfinite(zs)) and np.array_equal(zs, zl)
+        assert np.all(np.isfinite(zs)) and np.max(np.abs(zs - zl)) <= 1e-13 * np.abs(zl).max()
+        assert np.array_equal(zs, Ms.apply(r))                  # reproducible
     xs, xl = np.zeros(N), np.zeros(N)
     i1 = hip.solve(gpu_ctx, A, b.copy(), xs, prec=Ms, singular=True)
     i2 = hip.solve(gpu_ctx, A, b.copy(), xl, prec=Ml, singular=True)
-    assert i1.converged == 1 and i1.iters == i2.iters and np.array_equal(xs, xl)
+    assert i1.converged == 1 and abs(i1.iters - i2.iters) <= 1 and np.linalg.norm(xs - xl) <= 1e-7 * np.linalg.norm(xl)
+    xr = np.zeros(N)
+    i3 = hip.solve(gpu_ctx, A, b.copy(), xr, prec=Ms, singular=True)
+    assert i3.iters == i1.iters and np.array_equal(xs, xr)     # the whole solve is reproducible
     for o in (Ms, Ml, A):
         o.close()
