@@ -206,15 +206,20 @@ __global__ void k_gilu_fill_bits(int n, unsigned long long *__restrict__ a, unsi
 // workgroups, scripts/lds_handoff_probe.hip); inside the run a hand-off is an LDS write and read (0.08 us).
 // At those latencies the instructions between "last dependency seen" and "result stored" are what is left, so the row
 // does everything it can before it waits: the products with the dependencies outside the run are summed as soon as
-// those are there (they belong to earlier levels), the ones inside the run are kept as a list of two (value, slot)
-// pairs per lane -- a lane rarely has more; the rest go through a slower loop -- and what remains after the last word
-// arrives is two multiply-adds, the 16-lane sum and the store.  Summation order per lane: outside-the-run terms by
+// those are there (they belong to earlier levels), over all chunks of the row; the ones inside the run are kept as a
+// list of kNearCap (value, slot) pairs per lane -- a run holds 63 earlier positions, a lane a sixteenth of the row:
+// more is rare, and goes through a slower loop -- and what remains after the last word arrives is kNearCap
+// multiply-adds, the 16-lane sum and the store.  (With the wait for the outside words inside the chunk loop, as first
+// written, every chunk of a long row put a round trip to memory on the chain: 3.07 us per level on the ILU(1) factor
+// of the 100^3 system, whose rows have four chunks.)  Summation order per lane: outside-the-run terms by
 // entry, then inside-the-run terms by entry; fixed by the factor's pattern and the run table, so the result is
-// reproducible bit for bit from application to application, and differs from the level-launch kernels' by rounding.
+// reproducible bit for bit from application to application, and differs from the level-launch kernels' by rounding
+// (theirs divide by the pivot, the U sweep here multiplies with its reciprocal, taken before the row waits).
 // Deadlock-free for the same reason as above: runs are dequeued in order, a row waits for earlier positions only,
 // and all waves of a workgroup are resident together.
 constexpr int kSfChunk = 6;
 constexpr int kRun = 64;
+constexpr int kNearCap = 6;   // (value, slot) pairs a lane keeps for the dependencies inside the run
 constexpr int kRunsNear = 2;   // a run polls for its words once all but this many of the runs before it are complete
 template <bool UPPER>
 __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *__restrict__ runstart,
@@ -253,10 +258,25 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
       const long long first = UPPER ? b + kd + 1 : b;   // the chunk loop is uniform over the row's 16 lanes
       const long long last = UPPER ? rp[i + 1] : b + kd;
       ri = rhs[i];
-      if (UPPER) d = val[b + kd];
+      if (UPPER) d = 1.0 / val[b + kd];   // the division happens before the row waits, not after
+      // phase 0: far from the front of the sweep nothing this run waits for can be there; sleep until all but a few
+      // of the runs before it are complete instead of asking for every missing word again and again
+      if (knear > 0) {
+        int sp = 0;
+        while (sf_flag(done) < run - knear && !timed_out) {
+          __builtin_amdgcn_s_sleep(32);
+          if (++sp >= kSpinLimit || sf_flag(tmo)) timed_out = true;
+        }
+      }
+      // phase 1, over all chunks of the row (one for ILU(0), up to ~six for ILU(2)): the products with the dependencies
+      // outside the run are summed; the ones inside the run go on the lane's list of (value, slot) pairs
+      double nw[kNearCap];
+      int nslot[kNearCap], nn = 0;
+#pragma unroll
+      for (int j = 0; j < kNearCap; ++j) { nw[j] = 0.0; nslot[j] = kRun; }
       for (long long q0 = first; q0 < last; q0 += 16 * kSfChunk) {
-        double vf[kSfChunk], w0 = 0.0, w1 = 0.0;
-        int c[kSfChunk], slot[kSfChunk], n0 = kRun, n1 = kRun, nn = 0;
+        double vf[kSfChunk];
+        int c[kSfChunk];
         unsigned long long x[kSfChunk];
 #pragma unroll
         for (int k = 0; k < kSfChunk; ++k) {
@@ -267,28 +287,17 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
         }
 #pragma unroll
         for (int k = 0; k < kSfChunk; ++k) {
-          slot[k] = c[k] >= 0 ? rowpos4[c[k]] - base : -1;   // >= 0: inside this run
-          if (slot[k] >= 0) {
-            if (nn == 0) { n0 = slot[k]; w0 = vf[k]; }
-            if (nn == 1) { n1 = slot[k]; w1 = vf[k]; }
-            if (nn < 2) { vf[k] = 0.0; slot[k] = -1; }   // on the list; what keeps slot >= 0 goes the slow way
-            ++nn;
-            c[k] = ready;
+          const int sl = c[k] >= 0 ? rowpos4[c[k]] - base : -1;   // >= 0: inside this run
+          if (sl >= 0) {
+#pragma unroll
+            for (int j = 0; j < kNearCap; ++j)
+              if (nn == j) { nslot[j] = sl; nw[j] = vf[k]; }
+            ++nn;   // past kNearCap: phase 2 walks the row again for it
           }
-          if (c[k] < 0) c[k] = ready;   // no entry: the word that is always there, times 0
+          if (sl >= 0 || c[k] < 0) { c[k] = ready; vf[k] = 0.0; }   // listed / no entry: the word that is always there, times 0
         }
-        // phase 0: far from the front of the sweep nothing this run waits for can be there; sleep until all but a few
-        // of the runs before it are complete instead of asking for every missing word again and again
-        if (knear > 0 && q0 == first) {
-          int sp = 0;
-          while (sf_flag(done) < run - knear && !timed_out) {
-            __builtin_amdgcn_s_sleep(32);
-            if (++sp >= kSpinLimit || sf_flag(tmo)) timed_out = true;
-          }
-        }
-        // phase 1: the dependencies outside the run, from global memory, all six words of the lane per round
         int spins = 0;
-        for (;;) {
+        for (;;) {   // all six words of the lane per round
           bool pending = false;
 #pragma unroll
           for (int k = 0; k < kSfChunk; ++k) x[k] = sf_load(out + c[k]);
@@ -300,27 +309,45 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
         }
 #pragma unroll
         for (int k = 0; k < kSfChunk; ++k) s += vf[k] * (timed_out ? 0.0 : __longlong_as_double((long long)x[k]));
-        // phase 2: the dependencies inside the run, from its LDS image
-        unsigned long long y0, y1;
-        spins = 0;
+      }
+      // phase 2: the dependencies inside the run, from its LDS image: the first two of the list (all there is, for most
+      // lanes of an ILU(0) row), then the rest of it
+      {
+        unsigned long long y[kNearCap];
+        int spins = 0;
         for (;;) {
-          y0 = __hip_atomic_load(&s_out[par][n0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          y1 = __hip_atomic_load(&s_out[par][n1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if ((y0 != kGiluSentinel && y1 != kGiluSentinel) || timed_out) break;
+          y[0] = __hip_atomic_load(&s_out[par][nslot[0]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          y[1] = __hip_atomic_load(&s_out[par][nslot[1]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((y[0] != kGiluSentinel && y[1] != kGiluSentinel) || timed_out) break;
           if ((++spins & 4095) == 0 && (sf_flag(tmo) || spins >= 64 * kSpinLimit)) timed_out = true;
         }
-        s += w0 * (timed_out ? 0.0 : __longlong_as_double((long long)y0));
-        s += w1 * (timed_out ? 0.0 : __longlong_as_double((long long)y1));
-        if (nn > 2) {   // third and further dependencies of this lane inside the run: one after the other
+        s += nw[0] * (timed_out ? 0.0 : __longlong_as_double((long long)y[0]));
+        s += nw[1] * (timed_out ? 0.0 : __longlong_as_double((long long)y[1]));
+        if (nn > 2) {
+          spins = 0;
+          for (;;) {
+            bool pending = false;
 #pragma unroll
-          for (int k = 0; k < kSfChunk; ++k) {
-            if (slot[k] < 0) continue;
-            unsigned long long y;
-            spins = 0;
-            while ((y = __hip_atomic_load(&s_out[par][slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kGiluSentinel && !timed_out)
-              if ((++spins & 4095) == 0 && (sf_flag(tmo) || spins >= 64 * kSpinLimit)) timed_out = true;
-            s += vf[k] * (timed_out ? 0.0 : __longlong_as_double((long long)y));
+            for (int j = 2; j < kNearCap; ++j) y[j] = __hip_atomic_load(&s_out[par][nslot[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int j = 2; j < kNearCap; ++j) pending = pending || y[j] == kGiluSentinel;
+            if (!pending || timed_out) break;
+            if ((++spins & 4095) == 0 && (sf_flag(tmo) || spins >= 64 * kSpinLimit)) timed_out = true;
           }
+#pragma unroll
+          for (int j = 2; j < kNearCap; ++j) s += nw[j] * (timed_out ? 0.0 : __longlong_as_double((long long)y[j]));
+        }
+      }
+      if (nn > kNearCap) {   // more dependencies of this lane inside the run than its list holds: one after the other
+        int seen = 0;
+        for (long long q = first + sub; q < last; q += 16) {
+          const int sl = rowpos4[ci[q]] - base;
+          if (sl < 0 || seen++ < kNearCap) continue;
+          unsigned long long y;
+          int spins = 0;
+          while ((y = __hip_atomic_load(&s_out[par][sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kGiluSentinel && !timed_out)
+            if ((++spins & 4095) == 0 && (sf_flag(tmo) || spins >= 64 * kSpinLimit)) timed_out = true;
+          s += val[q] * (timed_out ? 0.0 : __longlong_as_double((long long)y));
         }
       }
     }
@@ -331,7 +358,7 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
       s = 0.0;
     }
     if (i >= 0 && sub == 0) {
-      const double r = UPPER ? (ri - s) / d : ri - s;
+      const double r = UPPER ? (ri - s) * d : ri - s;
       unsigned long long bits = (unsigned long long)__double_as_longlong(r);
       if (bits == kGiluSentinel) bits ^= 1ull;
       __hip_atomic_store(&s_out[par][pos - base], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
