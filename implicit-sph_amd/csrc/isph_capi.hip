@@ -798,6 +798,12 @@ int isph_prec_schwarz_info(const isph_prec *M, long long info[6]) {
   return ISPH_SUCCESS;
 }
 
+int isph_prec_schwarz_timing(const isph_prec *M, double ms[6]) {
+  ISPH_REQUIRE(M && M->type == 4 && M->schwarz && ms, "not a Schwarz preconditioner");
+  for (int k = 0; k < 6; ++k) ms[k] = M->schwarz->t_ms[k];
+  return ISPH_SUCCESS;
+}
+
 int isph_prec_schwarz_export(isph_ctx *ctx, const isph_prec *M, int *rows, int *loc_ptr, long long *rowptr, int *colidx,
                              double *val) {
   ISPH_REQUIRE(ctx && M && M->type == 4 && M->schwarz && rows && loc_ptr && rowptr && colidx && val, "bad argument");

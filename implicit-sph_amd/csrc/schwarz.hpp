@@ -62,6 +62,9 @@ struct isph_schwarz {
   bool syncfree = true;
   int *h_tmo = nullptr;   // pinned: the time-out word of the previous application (checked at the next one)
   int sweep_blocks = 0;   // persistent workgroups (1024 threads) of a sweep
+  // wall time of create(), ms: [0] matrix to the host [1] subdomains + local matrices [2] level-of-fill pattern
+  // [3] dependency levels, orders, runs, combine lists [4] upload [5] numeric factorisation (to the final synchronise)
+  double t_ms[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace isph {
@@ -455,8 +458,10 @@ inline void schwarz_destroy(isph_schwarz *S) {
 
 // host copy of A as CSR with ascending columns; columns >= nrow (ghosts owned by other ranks) are dropped: they
 // are outside every local subdomain (Ifpack_LocalFilter)
+// keep != nullptr: the CSR image is written into keep's factor arrays and stays there; only the pattern comes to the
+// host (the one-subdomain ILU(0) case, where the matrix IS the factor pattern: no 0.8 GB of values down and up again)
 inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long long> &rp, std::vector<int> &ci,
-                            std::vector<double> &v) {
+                            std::vector<double> &v, isph_schwarz *keep = nullptr) {
   const Sell &S = A->S;
   const int n = S.nrow;
   std::vector<int> len((size_t)n);
@@ -465,6 +470,20 @@ inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long l
   rp.assign((size_t)n + 1, 0);
   for (int i = 0; i < n; ++i) rp[(size_t)i + 1] = rp[(size_t)i] + len[(size_t)i];
   const long long nnz = rp[(size_t)n];
+  if (keep) {
+    ISPH_CHECK(keep->rp.reserve((size_t)n + 1));
+    ISPH_CHECK(keep->ci.reserve((size_t)(nnz > 0 ? nnz : 1)));
+    ISPH_CHECK(keep->val.reserve((size_t)(nnz > 0 ? nnz : 1)));
+    ISPH_CHECK_HIP(hipMemcpyAsync(keep->rp.p, rp.data(), sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (n > 0)
+      hipLaunchKernelGGL(k_sell_to_csr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, S.rowlen.p,
+                         S.slice_off.p, S.col.p, S.val.p, keep->rp.p, keep->ci.p, keep->val.p);
+    ci.resize((size_t)nnz);
+    v.clear();
+    ISPH_CHECK_HIP(hipMemcpyAsync(ci.data(), keep->ci.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return ISPH_SUCCESS;
+  }
   DevTmp<long long> drp;
   DevTmp<int> dci;
   DevTmp<double> dv;
@@ -586,8 +605,17 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   std::vector<long long> rp;
   std::vector<int> ci;
   std::vector<double> av;
-  ISPH_CHECK(schwarz_host_csr(ctx, A, rp, ci, av));
+  auto clk = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(clk() - t0).count(); };
+  auto t0 = clk();
   isph_schwarz *S = new isph_schwarz();
+  // one subdomain = the whole matrix, no ghost columns to filter, no fill: the device image of the matrix is the factor
+  const bool resident = fill == 0 && (block_size <= 0 || block_size >= n) && n > 0 && A->S.ncol == n;
+  {
+    const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, resident ? S : nullptr);
+    if (rc0 != ISPH_SUCCESS) { schwarz_destroy(S); return rc0; }
+  }
+  S->t_ms[0] = ms_since(t0); t0 = clk();
   S->n = n; S->fill = fill; S->overlap = overlap; S->combine = combine; S->syncfree = syncfree;
   // ---- subdomains: consecutive owned ranges, extended by `overlap` layers (ascending global row per layer)
   const int B = block_size > 0 ? block_size : (n > 0 ? n : 1);
@@ -693,6 +721,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     for (int t = 0; t < nth; ++t) th.emplace_back(fillm, t);
     for (auto &x : th) x.join();
   }
+  S->t_ms[1] = ms_since(t0); t0 = clk();
   // ---- level-of-fill pattern (k > 0) and the factor arrays
   std::vector<long long> frp((size_t)nloc + 1, 0);
   std::vector<int> fci, fdg((size_t)nloc, -1);
@@ -765,21 +794,27 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   for (int q = 0; q < nloc; ++q) maxrow = std::max(maxrow, (int)(frp[(size_t)q + 1] - frp[(size_t)q]));
   S->maxrow = maxrow;
   if (maxrow > kGiluMaxRow) { schwarz_destroy(S); return fail("ILU(k) row exceeds the LDS row image (lower the level of fill)", __FILE__, __LINE__); }
+  S->t_ms[2] = ms_since(t0); t0 = clk();
   // ---- dependency levels of the two solves (the factorisation follows the L levels)
   std::vector<int> llev((size_t)nloc, 0), ulev((size_t)nloc, 0);
   int nl = 0, nu = 0;
-  for (int q = 0; q < nloc; ++q) {
-    int l = 0;
-    const long long b = frp[(size_t)q];
-    for (int t = 0; t < fdg[(size_t)q]; ++t) l = std::max(l, llev[(size_t)fci[(size_t)(b + t)]] + 1);
-    llev[(size_t)q] = l;
-    nl = std::max(nl, l + 1);
-  }
-  for (int q = nloc - 1; q >= 0; --q) {
-    int l = 0;
-    for (long long p = frp[(size_t)q] + fdg[(size_t)q] + 1; p < frp[(size_t)q + 1]; ++p) l = std::max(l, ulev[(size_t)fci[(size_t)p]] + 1);
-    ulev[(size_t)q] = l;
-    nu = std::max(nu, l + 1);
+  {   // the two recurrences are sequential in themselves and independent of each other: one thread each
+    std::thread tl([&] {
+      for (int q = 0; q < nloc; ++q) {
+        int l = 0;
+        const long long b = frp[(size_t)q];
+        for (int t = 0; t < fdg[(size_t)q]; ++t) l = std::max(l, llev[(size_t)fci[(size_t)(b + t)]] + 1);
+        llev[(size_t)q] = l;
+        nl = std::max(nl, l + 1);
+      }
+    });
+    for (int q = nloc - 1; q >= 0; --q) {
+      int l = 0;
+      for (long long p = frp[(size_t)q] + fdg[(size_t)q] + 1; p < frp[(size_t)q + 1]; ++p) l = std::max(l, ulev[(size_t)fci[(size_t)p]] + 1);
+      ulev[(size_t)q] = l;
+      nu = std::max(nu, l + 1);
+    }
+    tl.join();
   }
   if (nloc == 0) nl = nu = 0;
   S->nlev_l = nl; S->nlev_u = nu;
@@ -848,6 +883,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
       for (int q = 0; q < cnt; ++q) rev_idx[(size_t)cur[(size_t)hrows[(size_t)base + q]]++] = base + q;
     }
   }
+  S->t_ms[3] = ms_since(t0); t0 = clk();
   // ---- upload
   auto up = [&](auto &buf, const auto &vec) -> int {
     using T = typename std::remove_reference<decltype(vec)>::type::value_type;
@@ -856,10 +892,13 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
       ISPH_CHECK_HIP(hipMemcpyAsync(buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, ctx->stream));
     return ISPH_SUCCESS;
   };
-  int rc = up(S->rp, frp);
-  if (rc == ISPH_SUCCESS) rc = up(S->ci, fci);
+  int rc = ISPH_SUCCESS;
+  if (!resident) {
+    rc = up(S->rp, frp);
+    if (rc == ISPH_SUCCESS) rc = up(S->ci, fci);
+    if (rc == ISPH_SUCCESS) rc = up(S->val, fv);
+  }
   if (rc == ISPH_SUCCESS) rc = up(S->dg, fdg);
-  if (rc == ISPH_SUCCESS) rc = up(S->val, fv);
   if (rc == ISPH_SUCCESS) rc = up(S->rows, hrows);
   if (rc == ISPH_SUCCESS) rc = up(S->lord, lord);
   if (rc == ISPH_SUCCESS) rc = up(S->uord, uord);
@@ -891,6 +930,8 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   // on a 7503-level factor (profiles/r03_schwarz_syncfree.txt)
   S->sweep_blocks = std::max(16, ncu / 8);
   hipError_t e = hipMemsetAsync(S->err.p, 0, sizeof(int), ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the uploads are done: the stage times below are what they say
+  S->t_ms[4] = ms_since(t0); t0 = clk();
   // ---- numeric factorisation
   const size_t lds = (size_t)maxrow * 12 + 16;
   int htmo = 0;
@@ -921,6 +962,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (e != hipSuccess) { schwarz_destroy(S); return fail(hipGetErrorString(e), __FILE__, __LINE__); }
   if (htmo) { schwarz_destroy(S); return fail("Schwarz ILU factorisation: a row waited for its pivot row beyond the spin limit", __FILE__, __LINE__); }
   if (herr) { schwarz_destroy(S); return fail("zero pivot in the Schwarz ILU factorisation", __FILE__, __LINE__); }
+  S->t_ms[5] = ms_since(t0);
   *out = S;
   return ISPH_SUCCESS;
 }

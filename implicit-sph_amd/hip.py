@@ -25,7 +25,7 @@ EXPORTS = [
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
-    "isph_schwarz_params_default", "isph_prec_create_schwarz", "isph_prec_schwarz_info", "isph_prec_schwarz_export",
+    "isph_schwarz_params_default", "isph_prec_create_schwarz", "isph_prec_schwarz_info", "isph_prec_schwarz_timing", "isph_prec_schwarz_export",
 ]
 
 
@@ -155,6 +155,7 @@ def lib():
         L.isph_prec_create_schwarz.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_prec_schwarz_info.argtypes = [C.c_void_p, C.c_void_p]
         L.isph_prec_schwarz_export.argtypes = [C.c_void_p] * 7
+        L.isph_prec_schwarz_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.isph_amg_params_default.argtypes = [C.c_void_p]
         L.isph_prec_create_amg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.isph_prec_amg_levels.argtypes = [C.c_void_p]
@@ -517,6 +518,12 @@ class PrecondSchwarz(Precond):
         a = (C.c_longlong * 6)()
         _check(lib().isph_prec_schwarz_info(self.h, a))
         return dict(nloc=a[0], nnz=a[1], nsub=a[2], levels_l=a[3], levels_u=a[4], maxrow=a[5])
+
+    def create_timing(self):
+        """ms of the create call by stage (isph_prec_schwarz_timing)."""
+        a = (C.c_double * 6)()
+        _check(lib().isph_prec_schwarz_timing(self.h, a))
+        return dict(to_host=a[0], local_matrices=a[1], pattern=a[2], levels=a[3], upload=a[4], factor=a[5])
 
     def export(self):
         i = self.schwarz_info()

@@ -174,6 +174,9 @@ typedef struct {
 void isph_schwarz_params_default(isph_schwarz_params *p);
 int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwarz_params *prm, isph_prec **M);
 int isph_prec_schwarz_info(const isph_prec *M, long long info[6]);
+/* wall time of the create call, ms: [0] matrix to the host [1] subdomains + local matrices [2] level-of-fill pattern
+ * [3] dependency levels, orders, combine lists [4] upload [5] numeric factorisation */
+int isph_prec_schwarz_timing(const isph_prec *M, double ms[6]);
 int isph_prec_schwarz_export(isph_ctx *ctx, const isph_prec *M, int *rows, int *loc_ptr, long long *rowptr,
                              int *colidx, double *val);
 /* Ifpack_AdditiveSchwarz<ILU(k)> with "Overlap Level" 1 across ranks (ref: precond_ifpack.h:43,60-74; Ifpack builds an

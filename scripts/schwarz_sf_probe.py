@@ -28,6 +28,7 @@ for n in ns:
     Ms = hip.PrecondSchwarz(ctx, A, level_of_fill=fill, overlap=0, block_size=0)
     torch.cuda.synchronize()
     P("  create sync-free %.1f ms" % ((time.perf_counter() - t0) * 1e3), Ms.schwarz_info())
+    P("  create stages, ms:", {k: round(v, 1) for k, v in Ms.create_timing().items()})
     r = torch.from_numpy(np.random.default_rng(0).standard_normal(N)).cuda()
     z = torch.empty_like(r)
     for rep in range(3):
