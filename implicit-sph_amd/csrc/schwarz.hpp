@@ -214,7 +214,7 @@ __global__ void k_gilu_fill_bits(int n, unsigned long long *__restrict__ a, unsi
 // more is rare, and goes through a slower loop -- and what remains after the last word arrives is kNearCap
 // multiply-adds, the 16-lane sum and the store.  (With the wait for the outside words inside the chunk loop, as first
 // written, every chunk of a long row put a round trip to memory on the chain: 3.07 us per level on the ILU(1) factor
-// of the 100^3 system, whose rows have four chunks.)  Summation order per lane: outside-the-run terms by
+// of the 100^3 system, whose rows have two to four chunks; 0.73 us now.)  Summation order per lane: outside-the-run terms by
 // entry, then inside-the-run terms by entry; fixed by the factor's pattern and the run table, so the result is
 // reproducible bit for bit from application to application, and differs from the level-launch kernels' by rounding
 // (theirs divide by the pivot, the U sweep here multiplies with its reciprocal, taken before the row waits).
