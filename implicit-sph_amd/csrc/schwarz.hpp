@@ -22,7 +22,7 @@
 //                      summation order: bitwise reproducible)
 // What bounds it: the dependency chain.  A whole-matrix factor of the periodic 100^3 bench system has 67 084 levels
 // per direction; measured per level: 1.35 us for a hand-off between workgroups through global
-// memory, 0.40 us inside a workgroup through LDS, 0.67 us on average over a sweep; 2.6 us in the factorisation.  It exists for fidelity with the reference's configuration and for the systems the reference
+// memory, 0.40 us inside a workgroup through LDS, 0.61 us on average over a sweep; 6.6 us in the factorisation.  It exists for fidelity with the reference's configuration and for the systems the reference
 // itself runs on one rank (BASELINE configs[0]); the production path for large systems stays the block stream of
 // ilu.hpp, whose blocks break the chain.
 #pragma once
