@@ -413,37 +413,53 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
     if (lane == 0) s_dead = sf_flag(tmo);  // the launch has given up: drain without waiting
     __syncthreads();
     bool dead = s_dead != 0;
-    // pointers of the first pivot row; those of the next one are requested a step ahead
-    long long kb = 0, ke = 0;
-    int kd = 0;
+    // A pivot step needs, in this order: the pivot row's pointers, then its columns and values (their addresses do
+    // not depend on each other), then the slot look-up in LDS.  All of it lies beyond the L2 (0.4 + 0.8 GB of factor
+    // per 10^6 rows against 4 MB per XCD), and a row has its pivots arrive one level apart -- so the time of ONE step
+    // on values that are already there is what a level costs, and the steps are software-pipelined: pointers two steps
+    // ahead, columns + values + pivot one step ahead (a value that is not there yet is asked for again when its step
+    // comes).  Without the pipeline: 6.6 us per level; the hand-off itself is about 2.
+    long long kb = 0, ke = 0, kb_n = 0, ke_n = 0;
+    int kd = 0, kd_n = 0, jc = -1;
+    unsigned long long xd = 0ull, xu = 0ull;
     if (nlow > 0) { const int k = cols[0]; kb = rp[k]; ke = rp[k + 1]; kd = dg[k]; }
+    if (nlow > 1) { const int k = cols[1]; kb_n = rp[k]; ke_n = rp[k + 1]; kd_n = dg[k]; }
+    if (nlow > 0) {
+      const long long q = kb + kd + 1 + lane;
+      if (q < ke) { jc = ci[q]; xu = sf_load(fout + q); }
+      xd = sf_load(fout + kb + kd);
+    }
     for (int t = 0; t < nlow && !dead; ++t) {
-      long long kb_n = 0, ke_n = 0;
-      int kd_n = 0;
-      if (t + 1 < nlow) { const int k = cols[t + 1]; kb_n = rp[k]; ke_n = rp[k + 1]; kd_n = dg[k]; }
+      // requests for the steps to come
+      long long kb_nn = 0, ke_nn = 0;
+      int kd_nn = 0, jn = -1;
+      unsigned long long xd_n = 0ull, xu_n = 0ull;
+      if (t + 2 < nlow) { const int k = cols[t + 2]; kb_nn = rp[k]; ke_nn = rp[k + 1]; kd_nn = dg[k]; }
+      if (t + 1 < nlow) {
+        const long long qn = kb_n + kd_n + 1 + lane;
+        if (qn < ke_n) { jn = ci[qn]; xu_n = sf_load(fout + qn); }
+        xd_n = sf_load(fout + kb_n + kd_n);
+      }
+      // this step
       const long long ub = kb + kd + 1;   // the pivot row's upper part
-      // pattern work of this lane's first entry of the upper part, before any value is asked for
       long long q = ub + lane;
       int p = -1;
-      if (q < ke) {
-        const int j = ci[q];
+      if (jc >= 0) {
         int lo = t + 1, hi = len - 1;
-        while (lo <= hi) {   // binary search for column j among this row's columns right of position t
+        while (lo <= hi) {   // binary search for column jc among this row's columns right of position t
           const int mid = (lo + hi) >> 1;
           const int c = cols[mid];
-          if (c == j) { p = mid; break; }
-          if (c < j) lo = mid + 1; else hi = mid - 1;
+          if (c == jc) { p = mid; break; }
+          if (c < jc) lo = mid + 1; else hi = mid - 1;
         }
       }
-      // the pivot and this lane's entry, polled together
-      unsigned long long xd, xu = 0ull;
+      if (p < 0) xu = 0ull;
       int spins = 0;
       bool gave_up = false;
-      for (;;) {
+      while ((xd == kGiluSentinel || xu == kGiluSentinel) && !gave_up) {   // the pivot and this lane's entry
+        __builtin_amdgcn_s_sleep(1);
         xd = sf_load(fout + kb + kd);
         if (p >= 0) xu = sf_load(fout + q);
-        if ((xd != kGiluSentinel && xu != kGiluSentinel) || gave_up) break;
-        __builtin_amdgcn_s_sleep(1);
         if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) gave_up = true;
       }
       const double lik = w[t] / __longlong_as_double((long long)xd);
@@ -472,7 +488,8 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
       if (__ballot(gave_up) != 0ull && lane == 0) s_dead = 1;
       __syncthreads();
       dead = s_dead != 0;
-      kb = kb_n; ke = ke_n; kd = kd_n;
+      kb = kb_n; ke = ke_n; kd = kd_n; kb_n = kb_nn; ke_n = ke_nn; kd_n = kd_nn;
+      jc = jn; xd = xd_n; xu = xu_n;
     }
     if (dead && lane == 0) __hip_atomic_store((gi32_t *)tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (len > nlow && !(fabs(w[nlow]) > 0.0) && lane == 0) atomicOr(err, 2);  // zero pivot (every row, level 0 included)
@@ -807,24 +824,36 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     }
     for (int q = 0; q < nloc; ++q) frp[(size_t)q + 1] += frp[(size_t)q];
     fci.resize((size_t)frp[(size_t)nloc]);
-    fv.assign((size_t)frp[(size_t)nloc], 0.0);
-    for (int s = 0; s < nsub; ++s) {
-      const int base = S->loc_ptr[(size_t)s];
-      for (size_t r = 0; r < pat[(size_t)s].size(); ++r) {
-        const GiluRow &row = pat[(size_t)s][r];
-        long long w = frp[(size_t)base + r];
-        long long p = lrp[(size_t)base + r];
-        const long long pe = lrp[(size_t)base + r + 1];
-        fdg[(size_t)base + r] = row.diag;
-        for (size_t q = 0; q < row.col.size(); ++q, ++w) {
-          const int c = base + row.col[q];
-          fci[(size_t)w] = c;
-          while (p < pe && lci[(size_t)p] < c) ++p;
-          if (p < pe && lci[(size_t)p] == c) fv[(size_t)w] = lv[(size_t)p];
+    fv.resize((size_t)frp[(size_t)nloc]);
+    // the factor arrays: pattern columns, A's values scattered into them (fill entries 0); threads over row ranges
+    // (370 M entries for the ILU(1) pattern of the 100^3 system: 1.6 s on one thread)
+    auto scatter = [&](int t) {
+      for (int s = 0; s < nsub; ++s) {
+        const int base = S->loc_ptr[(size_t)s], m = (int)pat[(size_t)s].size();
+        const int r0 = (int)((long long)m * t / nth), r1 = (int)((long long)m * (t + 1) / nth);
+        for (int r = r0; r < r1; ++r) {
+          const GiluRow &row = pat[(size_t)s][(size_t)r];
+          long long w = frp[(size_t)base + r];
+          long long p = lrp[(size_t)base + r];
+          const long long pe = lrp[(size_t)base + r + 1];
+          fdg[(size_t)base + r] = row.diag;
+          for (size_t q = 0; q < row.col.size(); ++q, ++w) {
+            const int c = base + row.col[q];
+            fci[(size_t)w] = c;
+            while (p < pe && lci[(size_t)p] < c) ++p;
+            fv[(size_t)w] = p < pe && lci[(size_t)p] == c ? lv[(size_t)p] : 0.0;
+          }
+          std::vector<int>().swap(pat[(size_t)s][(size_t)r].col);
+          std::vector<unsigned char>().swap(pat[(size_t)s][(size_t)r].lev);
         }
       }
-      std::vector<GiluRow>().swap(pat[(size_t)s]);
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nth; ++t) th.emplace_back(scatter, t);
+      for (auto &x : th) x.join();
     }
+    for (int s = 0; s < nsub; ++s) std::vector<GiluRow>().swap(pat[(size_t)s]);
   }
   S->nnz = frp[(size_t)nloc];
   int maxrow = 0;
