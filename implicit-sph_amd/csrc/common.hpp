@@ -271,19 +271,6 @@ __device__ __forceinline__ double group16_sum(double v) {
   return v;
 }
 
-// max within aligned groups of 16 lanes, result in every lane (same exchanges as group16_sum)
-template <int CTRL>
-__device__ __forceinline__ int dpp_move_i32(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-__device__ __forceinline__ int group16_max_i32(int v) {
-  int t = dpp_move_i32<0xB1>(v); v = t > v ? t : v;
-  t = dpp_move_i32<0x4E>(v); v = t > v ? t : v;
-  t = dpp_move_i32<0x141>(v); v = t > v ? t : v;
-  t = dpp_move_i32<0x140>(v); v = t > v ? t : v;
-  return v;
-}
-
 // XCD-aware block remap: the dispatcher deals blocks round-robin over the 8
 // XCDs, so blockIdx b lands on XCD b%8.  Give each XCD one contiguous range of
 // work items so its private L2 only sees that range's slice of x.
