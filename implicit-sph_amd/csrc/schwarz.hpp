@@ -413,53 +413,63 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
     if (lane == 0) s_dead = sf_flag(tmo);  // the launch has given up: drain without waiting
     __syncthreads();
     bool dead = s_dead != 0;
-    // A pivot step needs, in this order: the pivot row's pointers, then its columns and values (their addresses do
-    // not depend on each other), then the slot look-up in LDS.  All of it lies beyond the L2 (0.4 + 0.8 GB of factor
-    // per 10^6 rows against 4 MB per XCD), and a row has its pivots arrive one level apart -- so the time of ONE step
-    // on values that are already there is what a level costs, and the steps are software-pipelined: pointers two steps
-    // ahead, columns + values + pivot one step ahead (a value that is not there yet is asked for again when its step
-    // comes).  Without the pipeline: 6.6 us per level; the hand-off itself is about 2.
-    long long kb = 0, ke = 0, kb_n = 0, ke_n = 0;
-    int kd = 0, kd_n = 0, jc = -1;
+    // A pivot step needs: the pivot row's pointers, then its columns and its values (their addresses do not depend on
+    // each other), then the slot look-up in LDS for the column (seven dependent LDS reads, 0.6 us), then the update.
+    // All the loads go beyond the L2 (0.4 + 0.8 GB of factor per 10^6 rows against 4 MB per XCD).  A row's pivots lie
+    // on consecutive levels (34 distinct levels for the 51 pivots of an ILU(0) row), so they arrive one level apart and
+    // the row is never ahead of them: the time of ONE step is what a level costs.  Per-row time stamps (32^3 factor)
+    // gave 0.7 us to see a value that is there + 1.2 us to get from there to the next step's wait, most of it the
+    // look-up.  So the steps are software-pipelined: pointers three steps ahead, columns two, values and pivot one, and
+    // the look-up of step t + 1 runs while step t's values are being asked for again.
+    auto slot_of = [&](int j, int t) {   // position of column j among this row's columns right of position t, or -1
+      int lo = t + 1, hi = len - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = cols[mid];
+        if (c == j) return mid;
+        if (c < j) lo = mid + 1; else hi = mid - 1;
+      }
+      return -1;
+    };
+    long long kb = 0, ke = 0, kb1 = 0, ke1 = 0, kb2 = 0, ke2 = 0;
+    int kd = 0, kd1 = 0, kd2 = 0, j1 = -1, p = -1;
     unsigned long long xd = 0ull, xu = 0ull;
     if (nlow > 0) { const int k = cols[0]; kb = rp[k]; ke = rp[k + 1]; kd = dg[k]; }
-    if (nlow > 1) { const int k = cols[1]; kb_n = rp[k]; ke_n = rp[k + 1]; kd_n = dg[k]; }
+    if (nlow > 1) { const int k = cols[1]; kb1 = rp[k]; ke1 = rp[k + 1]; kd1 = dg[k]; }
+    if (nlow > 2) { const int k = cols[2]; kb2 = rp[k]; ke2 = rp[k + 1]; kd2 = dg[k]; }
     if (nlow > 0) {
       const long long q = kb + kd + 1 + lane;
-      if (q < ke) { jc = ci[q]; xu = sf_load(fout + q); }
+      int j0 = -1;
+      if (q < ke) { j0 = ci[q]; xu = sf_load(fout + q); }
       xd = sf_load(fout + kb + kd);
+      if (nlow > 1) { const long long q1 = kb1 + kd1 + 1 + lane; if (q1 < ke1) j1 = ci[q1]; }
+      if (j0 >= 0) p = slot_of(j0, 0);
+      if (p < 0) xu = 0ull;
     }
     for (int t = 0; t < nlow && !dead; ++t) {
       // requests for the steps to come
-      long long kb_nn = 0, ke_nn = 0;
-      int kd_nn = 0, jn = -1;
-      unsigned long long xd_n = 0ull, xu_n = 0ull;
-      if (t + 2 < nlow) { const int k = cols[t + 2]; kb_nn = rp[k]; ke_nn = rp[k + 1]; kd_nn = dg[k]; }
+      long long kb3 = 0, ke3 = 0;
+      int kd3 = 0, j2 = -1, p1 = -1;
+      unsigned long long xd1 = 0ull, xu1 = 0ull;
+      if (t + 3 < nlow) { const int k = cols[t + 3]; kb3 = rp[k]; ke3 = rp[k + 1]; kd3 = dg[k]; }
+      if (t + 2 < nlow) { const long long q2 = kb2 + kd2 + 1 + lane; if (q2 < ke2) j2 = ci[q2]; }
+      const long long q1 = kb1 + kd1 + 1 + lane;
       if (t + 1 < nlow) {
-        const long long qn = kb_n + kd_n + 1 + lane;
-        if (qn < ke_n) { jn = ci[qn]; xu_n = sf_load(fout + qn); }
-        xd_n = sf_load(fout + kb_n + kd_n);
+        if (q1 < ke1) xu1 = sf_load(fout + q1);
+        xd1 = sf_load(fout + kb1 + kd1);
       }
-      // this step
+      // this step: ask again for what was not there a step ago, and look the next step's column up meanwhile
       const long long ub = kb + kd + 1;   // the pivot row's upper part
       long long q = ub + lane;
-      int p = -1;
-      if (jc >= 0) {
-        int lo = t + 1, hi = len - 1;
-        while (lo <= hi) {   // binary search for column jc among this row's columns right of position t
-          const int mid = (lo + hi) >> 1;
-          const int c = cols[mid];
-          if (c == jc) { p = mid; break; }
-          if (c < jc) lo = mid + 1; else hi = mid - 1;
-        }
-      }
-      if (p < 0) xu = 0ull;
+      if (xd == kGiluSentinel) xd = sf_load(fout + kb + kd);
+      if (xu == kGiluSentinel) xu = sf_load(fout + q);
+      if (j1 >= 0) p1 = slot_of(j1, t + 1);
       int spins = 0;
       bool gave_up = false;
       while ((xd == kGiluSentinel || xu == kGiluSentinel) && !gave_up) {   // the pivot and this lane's entry
         __builtin_amdgcn_s_sleep(1);
-        xd = sf_load(fout + kb + kd);
-        if (p >= 0) xu = sf_load(fout + q);
+        if (xd == kGiluSentinel) xd = sf_load(fout + kb + kd);
+        if (xu == kGiluSentinel) xu = sf_load(fout + q);
         if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) gave_up = true;
       }
       const double lik = w[t] / __longlong_as_double((long long)xd);
@@ -468,28 +478,21 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
       if (lane == 0) w[t] = lik;
       if (p >= 0) w[p] -= lik * __longlong_as_double((long long)xu);
       for (q += 64; q < ke && !gave_up; q += 64) {   // upper parts longer than a wave (ILU(k > 0))
-        const int j = ci[q];
-        int lo = t + 1, hi = len - 1;
-        p = -1;
-        while (lo <= hi) {
-          const int mid = (lo + hi) >> 1;
-          const int c = cols[mid];
-          if (c == j) { p = mid; break; }
-          if (c < j) lo = mid + 1; else hi = mid - 1;
-        }
-        if (p < 0) continue;
+        const int pl = slot_of(ci[q], t);
+        if (pl < 0) continue;
+        unsigned long long x1;
         spins = 0;
-        while ((xu = sf_load(fout + q)) == kGiluSentinel) {
+        while ((x1 = sf_load(fout + q)) == kGiluSentinel) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) { gave_up = true; break; }
         }
-        if (!gave_up) w[p] -= lik * __longlong_as_double((long long)xu);
+        if (!gave_up) w[pl] -= lik * __longlong_as_double((long long)x1);
       }
       if (__ballot(gave_up) != 0ull && lane == 0) s_dead = 1;
       __syncthreads();
       dead = s_dead != 0;
-      kb = kb_n; ke = ke_n; kd = kd_n; kb_n = kb_nn; ke_n = ke_nn; kd_n = kd_nn;
-      jc = jn; xd = xd_n; xu = xu_n;
+      kb = kb1; ke = ke1; kd = kd1; kb1 = kb2; ke1 = ke2; kd1 = kd2; kb2 = kb3; ke2 = ke3; kd2 = kd3;
+      p = p1; j1 = j2; xd = xd1; xu = p1 >= 0 ? xu1 : 0ull;
     }
     if (dead && lane == 0) __hip_atomic_store((gi32_t *)tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (len > nlow && !(fabs(w[nlow]) > 0.0) && lane == 0) atomicOr(err, 2);  // zero pivot (every row, level 0 included)
