@@ -655,6 +655,28 @@ inline void gilu_symbolic1_rows(int m, const long long *lrp, const int *lci, int
   }
 }
 
+// host array that is either a std::vector taken over from the caller or a block whose elements are NOT value-initialised:
+// the 4.4 GB of factor arrays of a 10^6-row ILU(1) pattern are written once, by 16 threads -- a std::vector::resize would
+// first zero them on one
+template <class T>
+struct HostArr {
+  using value_type = T;
+  std::vector<T> v;
+  T *raw = nullptr;
+  size_t n = 0;
+  HostArr() = default;
+  HostArr(const HostArr &) = delete;
+  HostArr &operator=(const HostArr &) = delete;
+  ~HostArr() { free(raw); }
+  bool alloc(size_t k) { free(raw); raw = static_cast<T *>(malloc((k > 0 ? k : 1) * sizeof(T))); n = k; return raw != nullptr; }
+  T *data() { return raw ? raw : v.data(); }
+  const T *data() const { return raw ? raw : v.data(); }
+  size_t size() const { return raw ? n : v.size(); }
+  bool empty() const { return size() == 0; }
+  T &operator[](size_t i) { return data()[i]; }
+  const T &operator[](size_t i) const { return data()[i]; }
+};
+
 inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_size, int overlap, int combine,
                           isph_schwarz **out, bool syncfree = true) {
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && overlap >= 0 && (combine == 0 || combine == 1), "bad Schwarz parameters");
@@ -781,15 +803,16 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   S->t_ms[1] = ms_since(t0); t0 = clk();
   // ---- level-of-fill pattern (k > 0) and the factor arrays
   std::vector<long long> frp((size_t)nloc + 1, 0);
-  std::vector<int> fci, fdg((size_t)nloc, -1);
-  std::vector<double> fv;
+  HostArr<int> fci;
+  HostArr<double> fv;
+  std::vector<int> fdg((size_t)nloc, -1);
   bool missing_diag = false;
   if (fill == 0) {
     frp.swap(lrp);  // the local matrix IS the factor pattern: no second copy of 1.2 GB at 10^6 rows
-    fci.swap(lci);
-    fv.swap(lv);
+    fci.v.swap(lci);
+    fv.v.swap(lv);
     for (int q = 0; q < nloc; ++q) {
-      const auto b = fci.begin() + frp[(size_t)q], e = fci.begin() + frp[(size_t)q + 1];
+      const int *b = fci.data() + frp[(size_t)q], *e = fci.data() + frp[(size_t)q + 1];
       const auto it = std::lower_bound(b, e, q);
       if (it == e || *it != q) missing_diag = true; else fdg[(size_t)q] = (int)(it - b);
     }
@@ -826,8 +849,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
       for (size_t r = 0; r < pat[(size_t)s].size(); ++r) frp[(size_t)base + r + 1] = (long long)pat[(size_t)s][r].col.size();
     }
     for (int q = 0; q < nloc; ++q) frp[(size_t)q + 1] += frp[(size_t)q];
-    fci.resize((size_t)frp[(size_t)nloc]);
-    fv.resize((size_t)frp[(size_t)nloc]);
+    if (!fci.alloc((size_t)frp[(size_t)nloc]) || !fv.alloc((size_t)frp[(size_t)nloc])) { schwarz_destroy(S); return fail("host allocation failed", __FILE__, __LINE__); }
     // the factor arrays: pattern columns, A's values scattered into them (fill entries 0); threads over row ranges
     // (370 M entries for the ILU(1) pattern of the 100^3 system: 1.6 s on one thread)
     auto scatter = [&](int t) {
