@@ -380,17 +380,22 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
 // "this row stored" stand one division, one multiply-subtract per lane and two barriers.  (The first version of this
 // launch polled a flag per row, then loaded the pivot row's pointers, its pivot, its columns and values one after the
 // other and waited for its own stores before raising its flag: five round trips to memory per level, 7.2 us measured
-// on the 100^3 factor.)  Same operations in the same order as k_gilu_factor: same bits.
+// on the 100^3 factor.)  WAVES = 4 for factors whose pivot rows have more than 64 entries right of the
+// diagonal on average (ILU(k > 0)): a thread per entry, so that a step stays one round of requests (ILU(1) of the 100^3
+// system: 12.8 -> 5.5 us per level).  Same operations in the same
+// order as k_gilu_factor: same bits.
 __global__ void k_gilu_fill_sentinel(long long n, unsigned long long *__restrict__ a) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) a[i] = kGiluSentinel;
 }
 
-__global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__restrict__ order,
-                                                       const long long *__restrict__ rp, const int *__restrict__ ci,
-                                                       const int *__restrict__ dg, const double *__restrict__ ain,
-                                                       unsigned long long *fout, int *ctr, int *__restrict__ err) {
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gilu_factor_sf(int nloc, const int *__restrict__ order,
+                                                               const long long *__restrict__ rp, const int *__restrict__ ci,
+                                                               const int *__restrict__ dg, const double *__restrict__ ain,
+                                                               unsigned long long *fout, int *ctr, int *__restrict__ err) {
   extern __shared__ double gilu_lds[];
   __shared__ int s_pos, s_dead;
+  constexpr int T = 64 * WAVES;   // threads per row: one per entry of a pivot row's upper part and round
   const int lane = threadIdx.x;
   int *tmo = ctr + 3;
   for (;;) {
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
     const int len = (int)(rp[i + 1] - b), nlow = dg[i];
     double *w = gilu_lds;
     int *cols = reinterpret_cast<int *>(gilu_lds + len);
-    for (int t = lane; t < len; t += 64) {
+    for (int t = lane; t < len; t += T) {
       w[t] = ain[b + t];
       cols[t] = ci[b + t];
     }
@@ -473,11 +478,11 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
         if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) gave_up = true;
       }
       const double lik = w[t] / __longlong_as_double((long long)xd);
-      if (__ballot(gave_up) != 0ull && lane == 0) s_dead = 1;
+      if (gave_up) s_dead = 1;
       __syncthreads();
       if (lane == 0) w[t] = lik;
       if (p >= 0) w[p] -= lik * __longlong_as_double((long long)xu);
-      for (q += 64; q < ke && !gave_up; q += 64) {   // upper parts longer than a wave (ILU(k > 0))
+      for (q += T; q < ke && !gave_up; q += T) {   // upper parts longer than the workgroup
         const int pl = slot_of(ci[q], t);
         if (pl < 0) continue;
         unsigned long long x1;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
         }
         if (!gave_up) w[pl] -= lik * __longlong_as_double((long long)x1);
       }
-      if (__ballot(gave_up) != 0ull && lane == 0) s_dead = 1;
+      if (gave_up) s_dead = 1;
       __syncthreads();
       dead = s_dead != 0;
       kb = kb1; ke = ke1; kd = kd1; kb1 = kb2; ke1 = ke2; kd1 = kd2; kb2 = kb3; ke2 = ke3; kd2 = kd3;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(64) void k_gilu_factor_sf(int nloc, const int *__re
     }
     if (dead && lane == 0) __hip_atomic_store((gi32_t *)tmo, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (len > nlow && !(fabs(w[nlow]) > 0.0) && lane == 0) atomicOr(err, 2);  // zero pivot (every row, level 0 included)
-    for (int t = lane; t < len; t += 64) {
+    for (int t = lane; t < len; t += T) {
       unsigned long long bits = dead ? 0ull : (unsigned long long)__double_as_longlong(w[t]);
       if (bits == kGiluSentinel) bits ^= 1ull;  // cannot come out of arithmetic; never leave a dependant waiting
       sf_store(fout + b + t, bits);
@@ -1034,11 +1039,20 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     hipLaunchKernelGGL(k_gilu_fill_sentinel, dim3(stream_grid((int)std::min<long long>(S->nnz, 1 << 30))), dim3(kBlock), 0, ctx->stream,
                        S->nnz, reinterpret_cast<unsigned long long *>(fout.p));
     if (e == hipSuccess) e = hipMemsetAsync(S->ctr.p, 0, 4 * sizeof(int), ctx->stream);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gilu_factor_sf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // threads per row: one per entry of an average pivot row's upper part, up to 256 (512 measured no better on ILU(2))
+    const long long upper = nloc > 0 ? (S->nnz - nloc) / 2 / nloc : 0;
+    const int fw = upper > 64 ? 4 : 1;
+    const void *fk = fw == 4 ? reinterpret_cast<const void *>(k_gilu_factor_sf<4>) : reinterpret_cast<const void *>(k_gilu_factor_sf<1>);
+    if (e == hipSuccess) e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) {
       const int waves = std::min(nloc, ncu * 16);
-      hipLaunchKernelGGL(k_gilu_factor_sf, dim3(waves), dim3(64), lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p,
-                         (const double *)S->val.p, reinterpret_cast<unsigned long long *>(fout.p), S->ctr.p, S->err.p);
+      const dim3 grid((waves + fw - 1) / fw), block(64 * fw);
+      unsigned long long *fo = reinterpret_cast<unsigned long long *>(fout.p);
+      const double *ain = S->val.p;
+      if (fw == 4)
+        hipLaunchKernelGGL(k_gilu_factor_sf<4>, grid, block, lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p, ain, fo, S->ctr.p, S->err.p);
+      else
+        hipLaunchKernelGGL(k_gilu_factor_sf<1>, grid, block, lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p, ain, fo, S->ctr.p, S->err.p);
       e = hipMemcpyAsync(&htmo, S->ctr.p + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     }
     std::swap(S->val, fout);   // the stream is synchronised below before anything reads the factor
