@@ -61,7 +61,9 @@ struct isph_schwarz {
   int n4l = 0, n4u = 0;
   bool syncfree = true;
   int *h_tmo = nullptr;   // pinned: the time-out word of the previous application (checked at the next one)
-  int sweep_blocks = 0;   // persistent workgroups (1024 threads) of a sweep
+  // persistent workgroups (1024 threads) of the L / U sweep, and how many earlier runs may still be open when a run
+  // starts polling (k_gilu_solve_run): both follow the width of the levels
+  int sweep_blocks[2] = {0, 0}, runs_near[2] = {2, 2};
   // wall time of create(), ms: [0] matrix to the host [1] subdomains + local matrices [2] level-of-fill pattern
   // [3] dependency levels, orders, runs, combine lists [4] upload [5] numeric factorisation (to the final synchronise)
   double t_ms[6] = {0, 0, 0, 0, 0, 0};
@@ -69,6 +71,7 @@ struct isph_schwarz {
 
 namespace isph {
 
+constexpr int kGiluWideLevel = 4096;  // rows per dependency level from which one launch per level is the faster form
 constexpr int kGiluMaxRow = 5000;  // row image in LDS: 12 B per entry, below the 64 KiB default dynamic-LDS limit
 
 // rl = r[rows]
@@ -223,7 +226,6 @@ __global__ void k_gilu_fill_bits(int n, unsigned long long *__restrict__ a, unsi
 constexpr int kSfChunk = 6;
 constexpr int kRun = 64;
 constexpr int kNearCap = 6;   // (value, slot) pairs a lane keeps for the dependencies inside the run
-constexpr int kRunsNear = 2;   // a run polls for its words once all but this many of the runs before it are complete
 template <bool UPPER>
 __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *__restrict__ runstart,
                                                          const int *__restrict__ order4,
@@ -914,6 +916,12 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   }
   if (nloc == 0) nl = nu = 0;
   S->nlev_l = nl; S->nlev_u = nu;
+  // Which form runs: the persistent launches win where the dependency chain is long and narrow (whole-matrix factors:
+  // 15 rows per level, 0.6 us per level against 6.6 us for a launch); with thousands of rows per level a launch per
+  // level is amortised and streams the rows at full width -- 512-row blocks + one overlap layer at 10^6 rows (294
+  // levels of 15 000 rows): application 5.2 ms with level launches, 11.6 ms persistent; factorisation 106 / 234 ms.
+  if (syncfree && nloc > 0 && nloc / std::max(1, std::min(nl, nu)) >= kGiluWideLevel) syncfree = false;
+  S->syncfree = syncfree;
   auto bucket = [&](const std::vector<int> &lev, int nlev, std::vector<int> &ptr, std::vector<int> &ord) {
     ptr.assign((size_t)nlev + 1, 0);
     for (int q = 0; q < nloc; ++q) ++ptr[(size_t)lev[(size_t)q] + 1];
@@ -1019,11 +1027,20 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (rc != ISPH_SUCCESS) { schwarz_destroy(S); return rc; }
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  // persistent workgroups of a sweep (16 waves x 4 rows each: one run).  The sweeps are bound by the hand-off latency
-  // of the dependency chain, not by the rows in flight -- the workgroups ahead of the front only have to have their
-  // operands loaded by the time it reaches them (about 3 us per run): 16, 32, 64 workgroups gave 9.99, 10.09, 10.18 ms
-  // on a 7503-level factor (profiles/r03_schwarz_syncfree.txt)
-  S->sweep_blocks = std::max(16, ncu / 8);
+  // persistent workgroups of a sweep (16 waves x 4 rows each: one run) and the throttle window.  Narrow levels (the
+  // whole-matrix factors: 15 rows per level): the sweep is bound by the hand-off latency of the dependency chain, not by
+  // the rows in flight -- the workgroups ahead of the front only have to have their operands loaded by the time it
+  // reaches them (about 3 us per run): 16, 32, 64 workgroups gave 9.99, 10.09, 10.18 ms on a 7503-level factor, and a
+  // run that starts polling before all but two of the earlier ones are complete only adds traffic
+  // (profiles/r03_schwarz_syncfree.txt).  Wide levels (many subdomains: 15 000 rows per level for 512-row blocks + one
+  // overlap layer at 10^6 rows): a level is hundreds of runs that do not wait for each other -- all of them, and the
+  // next level's, must be open at once, on as many workgroups as the chip holds (one of 1024 threads and 80 registers per CU).
+  for (int d = 0; d < 2; ++d) {
+    const int nlev = d == 0 ? nl : nu, nrun = d == 0 ? S->nrun_l : S->nrun_u;
+    const int per_level = nlev > 0 ? (nrun + nlev - 1) / nlev : 1;   // runs per level
+    S->runs_near[d] = std::max(2, 2 * per_level);
+    S->sweep_blocks[d] = std::min(ncu, std::max(std::max(16, ncu / 8), S->runs_near[d] + 16));
+  }
   hipError_t e = hipMemsetAsync(S->err.p, 0, sizeof(int), ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the uploads are done: the stage times below are what they say
   S->t_ms[4] = ms_since(t0); t0 = clk();
@@ -1089,14 +1106,14 @@ inline int schwarz_apply(isph_ctx *ctx, const isph_schwarz *S, const double *r, 
     hipLaunchKernelGGL(k_gilu_fill_bits, dim3(stream_grid(nloc)), dim3(kBlock), 0, ctx->stream, nloc, S->ybits.p, S->zbits.p);
     ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p, 0, 2 * sizeof(int), ctx->stream));
     ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p + 4, 0, 2 * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL((k_gilu_solve_run<false>), dim3(S->sweep_blocks), dim3(16 * kRun), 0, ctx->stream, S->nrun_l,
+    hipLaunchKernelGGL((k_gilu_solve_run<false>), dim3(S->sweep_blocks[0]), dim3(16 * kRun), 0, ctx->stream, S->nrun_l,
                        (const int *)S->lrun.p, (const int *)S->lord4.p, (const int *)S->lpos4.p, (const long long *)S->rp.p,
                        (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p, (const double *)S->w.p, S->ybits.p,
-                       nloc, S->ctr.p, kRunsNear);
-    hipLaunchKernelGGL((k_gilu_solve_run<true>), dim3(S->sweep_blocks), dim3(16 * kRun), 0, ctx->stream, S->nrun_u,
+                       nloc, S->ctr.p, S->runs_near[0]);
+    hipLaunchKernelGGL((k_gilu_solve_run<true>), dim3(S->sweep_blocks[1]), dim3(16 * kRun), 0, ctx->stream, S->nrun_u,
                        (const int *)S->urun.p, (const int *)S->uord4.p, (const int *)S->upos4.p, (const long long *)S->rp.p,
                        (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p,
-                       reinterpret_cast<const double *>(S->ybits.p), S->zbits.p, nloc, S->ctr.p, kRunsNear);
+                       reinterpret_cast<const double *>(S->ybits.p), S->zbits.p, nloc, S->ctr.p, S->runs_near[1]);
     ISPH_CHECK_HIP(hipMemcpyAsync(S->h_tmo, S->ctr.p + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_gilu_combine, dim3((S->n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S->n, S->rev_ptr.p,
                        S->rev_idx.p, reinterpret_cast<const double *>(S->zbits.p), z);
