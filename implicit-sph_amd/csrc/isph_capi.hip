@@ -791,10 +791,10 @@ int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwar
   return ISPH_SUCCESS;
 }
 
-int isph_prec_schwarz_info(const isph_prec *M, long long info[6]) {
+int isph_prec_schwarz_info(const isph_prec *M, long long info[7]) {
   ISPH_REQUIRE(M && M->type == 4 && M->schwarz && info, "not a Schwarz preconditioner");
   const isph_schwarz *S = M->schwarz;
-  info[0] = S->nloc; info[1] = S->nnz; info[2] = S->nsub; info[3] = S->nlev_l; info[4] = S->nlev_u; info[5] = S->maxrow;
+  info[0] = S->nloc; info[1] = S->nnz; info[2] = S->nsub; info[3] = S->nlev_l; info[4] = S->nlev_u; info[5] = S->maxrow; info[6] = S->syncfree ? 1 : 0;
   return ISPH_SUCCESS;
 }
 

@@ -515,9 +515,9 @@ class PrecondSchwarz(Precond):
         _check(lib().isph_prec_create_schwarz(ctx.h, A.h, C.byref(prm), C.byref(self.h)))
 
     def schwarz_info(self):
-        a = (C.c_longlong * 6)()
+        a = (C.c_longlong * 7)()
         _check(lib().isph_prec_schwarz_info(self.h, a))
-        return dict(nloc=a[0], nnz=a[1], nsub=a[2], levels_l=a[3], levels_u=a[4], maxrow=a[5])
+        return dict(nloc=a[0], nnz=a[1], nsub=a[2], levels_l=a[3], levels_u=a[4], maxrow=a[5], persistent=a[6])
 
     def create_timing(self):
         """ms of the create call by stage (isph_prec_schwarz_timing)."""

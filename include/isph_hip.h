@@ -161,19 +161,22 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
  * 1 = "Zero", restricted additive Schwarz).  block_size = 0: one subdomain = the whole local matrix, which is what
  * the reference factors on one MPI rank (Ifpack ignores the overlap there); block_size = B > 0: consecutive
  * subdomains of B rows (any B), each extended by `overlap` layers of the rows its columns reference, like the ranks
- * of a parallel run.  isph_prec_create(type = "ilu<k>") is the block_size = 0 case.  Level-scheduled on the device
- * (one launch per dependency level): the fidelity path; "bjacobi-ilu<k>" is the throughput path.
- * info: [0] extended rows [1] factor entries [2] subdomains [3] L levels [4] U levels [5] longest factor row.
+ * of a parallel run.  isph_prec_create(type = "ilu<k>") is the block_size = 0 case.  Level-scheduled on the device:
+ * the fidelity path; "bjacobi-ilu<k>" is the throughput path.
+ * info: [0] extended rows [1] factor entries [2] subdomains [3] L levels [4] U levels [5] longest factor row
+ * [6] 1 = persistent launches, 0 = one launch per dependency level (see level_launches).
  * export: rows[nloc] (global row of every local row), loc_ptr[nsub+1], factor CSR in local numbering. */
 typedef struct {
   int level_of_fill, overlap, combine, block_size;
-  int level_launches; /* 0 (default): the factorisation and every triangular sweep are ONE persistent launch whose rows
-                         wait for the rows they depend on; 1: one launch per dependency level (the older form, kept as
-                         the cross-check of the first -- both give the same bits) */
+  int level_launches; /* 0 (default): the form is picked by the width of the dependency levels -- narrow levels (whole-
+                         matrix factors): the factorisation and every triangular sweep are ONE persistent launch whose
+                         rows wait for the rows they depend on; >= 4096 rows per level (many subdomains): one launch
+                         per level.  1: always one launch per level (the cross-check of the persistent form: same
+                         factor bit for bit, application equal to rounding) */
 } isph_schwarz_params;
 void isph_schwarz_params_default(isph_schwarz_params *p);
 int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwarz_params *prm, isph_prec **M);
-int isph_prec_schwarz_info(const isph_prec *M, long long info[6]);
+int isph_prec_schwarz_info(const isph_prec *M, long long info[7]);
 /* wall time of the create call, ms: [0] matrix to the host [1] subdomains + local matrices [2] level-of-fill pattern
  * [3] dependency levels, orders, combine lists [4] upload [5] numeric factorisation */
 int isph_prec_schwarz_timing(const isph_prec *M, double ms[6]);

@@ -161,8 +161,9 @@ def test_synchronisation_free_sweeps_equal_the_level_launches(gpu_ctx, n, fill, 
     N = p["nlocal"]
     Ms = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=fill, overlap=overlap, block_size=block)
     Ml = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=fill, overlap=overlap, block_size=block, level_launches=True)
-    info = Ms.schwarz_info()
-    assert info == Ml.schwarz_info() and info["levels_l"] > (100 if block == 0 else 10)
+    info, infol = Ms.schwarz_info(), Ml.schwarz_info()
+    assert info.pop("persistent") == 1 and infol.pop("persistent") == 0     # the two forms really are compared
+    assert info == infol and info["levels_l"] > (100 if block == 0 else 10)
     for a, c in zip(Ms.export(), Ml.export()):
         assert np.array_equal(a, c)
     rng = np.random.default_rng(n)
@@ -179,4 +180,30 @@ def test_synchronisation_free_sweeps_equal_the_level_launches(gpu_ctx, n, fill, 
     i3 = hip.solve(gpu_ctx, A, b.copy(), xr, prec=Ms, singular=True)
     assert i3.iters == i1.iters and np.array_equal(xs, xr)     # the whole solve is reproducible
     for o in (Ms, Ml, A):
+        o.close()
+
+
+def test_form_of_the_sweeps_follows_the_width_of_the_levels(gpu_ctx):
+    """create() picks the persistent launches for long, narrow dependency chains (one subdomain = the whole matrix) and
+    one launch per level where a level holds thousands of rows (many small subdomains: csrc/schwarz.hpp kGiluWideLevel,
+    measured in profiles/r03_schwarz_syncfree.txt); both give the oracle's preconditioner."""
+    sp = tgv_spec(dim=3, n=64, mode=workload.JITTER)
+    p = workload.make_tgv(sp)
+    colmap = workload.single_rank_colmap(p)
+    vf = hip.compute_volumes(gpu_ctx, p, colmap)
+    A, b = hip.assemble_poisson(gpu_ctx, p, colmap, sp.dt, p["rho"], np.ascontiguousarray(p["v"]),
+                                vfrac=np.ascontiguousarray(vf[p["owner_index"]]))
+    N = p["nlocal"]
+    whole = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=0, overlap=0, block_size=0)
+    small = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=0, overlap=0, block_size=64)
+    iw, ism = whole.schwarz_info(), small.schwarz_info()
+    assert iw["persistent"] == 1 and iw["nloc"] // iw["levels_l"] < 4096
+    assert ism["persistent"] == 0 and ism["nloc"] // min(ism["levels_l"], ism["levels_u"]) >= 4096
+    forced = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=0, overlap=0, block_size=64, level_launches=True)
+    r = np.random.default_rng(5).standard_normal(N)
+    assert np.array_equal(small.apply(r), forced.apply(r))
+    x = np.zeros(N)
+    info = hip.solve(gpu_ctx, A, b.copy(), x, prec=small, singular=True)
+    assert info.converged == 1
+    for o in (whole, small, forced, A):
         o.close()
