@@ -522,10 +522,33 @@ inline void schwarz_destroy(isph_schwarz *S) {
 
 // host copy of A as CSR with ascending columns; columns >= nrow (ghosts owned by other ranks) are dropped: they
 // are outside every local subdomain (Ifpack_LocalFilter)
+// host array that is either a std::vector taken over from the caller or a block whose elements are NOT value-initialised:
+// the 4.4 GB of factor arrays of a 10^6-row ILU(1) pattern are written once, by 16 threads -- a std::vector::resize would
+// first zero them on one
+template <class T>
+struct HostArr {
+  using value_type = T;
+  std::vector<T> v;
+  T *raw = nullptr;
+  size_t n = 0;
+  HostArr() = default;
+  HostArr(const HostArr &) = delete;
+  HostArr &operator=(const HostArr &) = delete;
+  ~HostArr() { free(raw); }
+  bool alloc(size_t k) { free(raw); raw = static_cast<T *>(malloc((k > 0 ? k : 1) * sizeof(T))); n = k; return raw != nullptr; }
+  T *data() { return raw ? raw : v.data(); }
+  const T *data() const { return raw ? raw : v.data(); }
+  size_t size() const { return raw ? n : v.size(); }
+  bool empty() const { return size() == 0; }
+  T &operator[](size_t i) { return data()[i]; }
+  const T &operator[](size_t i) const { return data()[i]; }
+  void swap(HostArr &o) { v.swap(o.v); std::swap(raw, o.raw); std::swap(n, o.n); }
+};
+
 // keep != nullptr: the CSR image is written into keep's factor arrays and stays there; only the pattern comes to the
 // host (the one-subdomain ILU(0) case, where the matrix IS the factor pattern: no 0.8 GB of values down and up again)
-inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long long> &rp, std::vector<int> &ci,
-                            std::vector<double> &v, isph_schwarz *keep = nullptr) {
+inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long long> &rp, HostArr<int> &ci,
+                            HostArr<double> &v, isph_schwarz *keep = nullptr) {
   const Sell &S = A->S;
   const int n = S.nrow;
   std::vector<int> len((size_t)n);
@@ -542,8 +565,7 @@ inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long l
     if (n > 0)
       hipLaunchKernelGGL(k_sell_to_csr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, S.rowlen.p,
                          S.slice_off.p, S.col.p, S.val.p, keep->rp.p, keep->ci.p, keep->val.p);
-    ci.resize((size_t)nnz);
-    v.clear();
+    if (!ci.alloc((size_t)nnz)) return fail("host allocation failed", __FILE__, __LINE__);
     ISPH_CHECK_HIP(hipMemcpyAsync(ci.data(), keep->ci.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
     ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return ISPH_SUCCESS;
@@ -558,8 +580,7 @@ inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long l
   if (n > 0)
     hipLaunchKernelGGL(k_sell_to_csr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, S.rowlen.p,
                        S.slice_off.p, S.col.p, S.val.p, drp.p, dci.p, dv.p);
-  ci.resize((size_t)nnz);
-  v.resize((size_t)nnz);
+  if (!ci.alloc((size_t)nnz) || !v.alloc((size_t)nnz)) return fail("host allocation failed", __FILE__, __LINE__);
   ISPH_CHECK_HIP(hipMemcpyAsync(ci.data(), dci.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipMemcpyAsync(v.data(), dv.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -662,35 +683,13 @@ inline void gilu_symbolic1_rows(int m, const long long *lrp, const int *lci, int
   }
 }
 
-// host array that is either a std::vector taken over from the caller or a block whose elements are NOT value-initialised:
-// the 4.4 GB of factor arrays of a 10^6-row ILU(1) pattern are written once, by 16 threads -- a std::vector::resize would
-// first zero them on one
-template <class T>
-struct HostArr {
-  using value_type = T;
-  std::vector<T> v;
-  T *raw = nullptr;
-  size_t n = 0;
-  HostArr() = default;
-  HostArr(const HostArr &) = delete;
-  HostArr &operator=(const HostArr &) = delete;
-  ~HostArr() { free(raw); }
-  bool alloc(size_t k) { free(raw); raw = static_cast<T *>(malloc((k > 0 ? k : 1) * sizeof(T))); n = k; return raw != nullptr; }
-  T *data() { return raw ? raw : v.data(); }
-  const T *data() const { return raw ? raw : v.data(); }
-  size_t size() const { return raw ? n : v.size(); }
-  bool empty() const { return size() == 0; }
-  T &operator[](size_t i) { return data()[i]; }
-  const T &operator[](size_t i) const { return data()[i]; }
-};
-
 inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_size, int overlap, int combine,
                           isph_schwarz **out, bool syncfree = true) {
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && overlap >= 0 && (combine == 0 || combine == 1), "bad Schwarz parameters");
   const int n = A->S.nrow;
   std::vector<long long> rp;
-  std::vector<int> ci;
-  std::vector<double> av;
+  HostArr<int> ci;
+  HostArr<double> av;
   auto clk = [] { return std::chrono::steady_clock::now(); };
   auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(clk() - t0).count(); };
   auto t0 = clk();
@@ -748,8 +747,8 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     std::copy(srows[(size_t)s].begin(), srows[(size_t)s].end(), hrows.begin() + S->loc_ptr[(size_t)s]);
   // ---- local block-diagonal matrix (Ifpack_LocalFilter), columns in local numbering, ascending
   std::vector<long long> lrp((size_t)nloc + 1, 0);
-  std::vector<int> lci;
-  std::vector<double> lv;
+  HostArr<int> lci;
+  HostArr<double> lv;
   if (nsub == 1 && nloc == n && A->S.ncol == n) {
     // one subdomain = the whole matrix and no ghost columns to filter (the reference on one rank; the extended matrix of
     // isph_prec_create_overlap): the local matrix is the host CSR itself, rows already column-sorted
@@ -780,8 +779,8 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
       for (auto &x : th) x.join();
     }
     for (int q = 0; q < nloc; ++q) lrp[(size_t)q + 1] += lrp[(size_t)q];
-    lci.resize((size_t)lrp[(size_t)nloc]);
-    lv.resize((size_t)lrp[(size_t)nloc]);
+    // written once by the threads below: no value-initialisation of 4 GB on one thread first
+    if (!lci.alloc((size_t)lrp[(size_t)nloc]) || !lv.alloc((size_t)lrp[(size_t)nloc])) { schwarz_destroy(S); return fail("host allocation failed", __FILE__, __LINE__); }
     auto fillm = [&](int t) {
       std::vector<int> loc((size_t)n, -1);
       std::vector<std::pair<int, double>> tmp;
@@ -789,15 +788,24 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
         const std::vector<int> &rows = srows[(size_t)s];
         const int base = S->loc_ptr[(size_t)s];
         for (size_t q = 0; q < rows.size(); ++q) loc[(size_t)rows[q]] = (int)q;
+        // local columns ascending: a row's global columns are ascending, the owned rows of the subdomain are a
+        // contiguous ascending range and sit in front of the overlap rows, and every overlap layer is ascending -- so
+        // the owned columns come out in order, and the others after them are in order too unless they mix layers
+        const int nown_s = nown[(size_t)s];
         for (size_t q = 0; q < rows.size(); ++q) {
           const int i = rows[q];
           tmp.clear();
+          long long wq = lrp[(size_t)base + q];
           for (long long p = rp[(size_t)i]; p < rp[(size_t)i + 1]; ++p) {
             const int c = ci[(size_t)p];
-            if (c < n && loc[(size_t)c] >= 0) tmp.emplace_back(base + loc[(size_t)c], av[(size_t)p]);
+            if (c >= n) continue;
+            const int l = loc[(size_t)c];
+            if (l < 0) continue;
+            if (l < nown_s) { lci[(size_t)wq] = base + l; lv[(size_t)wq] = av[(size_t)p]; ++wq; }
+            else tmp.emplace_back(base + l, av[(size_t)p]);
           }
-          std::sort(tmp.begin(), tmp.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
-          long long wq = lrp[(size_t)base + q];
+          auto less = [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; };
+          if (!std::is_sorted(tmp.begin(), tmp.end(), less)) std::sort(tmp.begin(), tmp.end(), less);
           for (auto &e : tmp) { lci[(size_t)wq] = e.first; lv[(size_t)wq] = e.second; ++wq; }
         }
         for (size_t q = 0; q < rows.size(); ++q) loc[(size_t)rows[q]] = -1;
@@ -816,8 +824,8 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   bool missing_diag = false;
   if (fill == 0) {
     frp.swap(lrp);  // the local matrix IS the factor pattern: no second copy of 1.2 GB at 10^6 rows
-    fci.v.swap(lci);
-    fv.v.swap(lv);
+    fci.swap(lci);
+    fv.swap(lv);
     for (int q = 0; q < nloc; ++q) {
       const int *b = fci.data() + frp[(size_t)q], *e = fci.data() + frp[(size_t)q + 1];
       const auto it = std::lower_bound(b, e, q);
