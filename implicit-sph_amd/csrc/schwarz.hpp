@@ -59,6 +59,7 @@ struct isph_schwarz {
   int nrun_l = 0, nrun_u = 0;
   isph::DevBuf<unsigned long long> ybits, zbits;
   int n4l = 0, n4u = 0;
+  bool long_rows = false;   // many rows have more entries on one side of the diagonal than a chunk of the sweeps holds
   bool syncfree = true;
   int *h_tmo = nullptr;   // pinned: the time-out word of the previous application (checked at the next one)
   // persistent workgroups (1024 threads) of the L / U sweep, and how many earlier runs may still be open when a run
@@ -226,7 +227,9 @@ __global__ void k_gilu_fill_bits(int n, unsigned long long *__restrict__ a, unsi
 constexpr int kSfChunk = 6;
 constexpr int kRun = 64;
 constexpr int kNearCap = 6;   // (value, slot) pairs a lane keeps for the dependencies inside the run
-template <bool UPPER>
+constexpr int kFarCap = 6;    // (value, row) pairs a lane keeps for the recent dependencies outside it
+constexpr int kRecent = 2 * kRun;   // positions before the run that count as recent: the two runs before it at most
+template <bool UPPER, bool SPLIT>
 __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *__restrict__ runstart,
                                                          const int *__restrict__ order4,
                                                          const int *__restrict__ rowpos4,
@@ -273,12 +276,23 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
           if (++sp >= kSpinLimit || sf_flag(tmo)) timed_out = true;
         }
       }
-      // phase 1, over all chunks of the row (one for ILU(0), up to ~six for ILU(2)): the products with the dependencies
-      // outside the run are summed; the ones inside the run go on the lane's list of (value, slot) pairs
-      double nw[kNearCap];
-      int nslot[kNearCap], nn = 0;
+      // phase 1, over all chunks of the row (one for ILU(0), up to ~six for ILU(2)).  Three kinds of dependency:
+      //  - inside the run: on the lane's list of (value, slot) pairs, waited for in LDS (phase 2);
+      //  - outside the run but within the last kRecent positions before it (the two runs before this one, which the
+      //    throttle above lets be open): on a second list of (value, row) pairs, waited for in global memory AFTER the
+      //    chunk loop -- a long row has several chunks, and with the wait inside the loop every chunk after the one that
+      //    held the late word put its loads (three dependent round trips) between that word and the row's store: 4.1 us
+      //    per hand-off between runs on the ILU(1) factor against 1.4 us for ILU(0)'s one-chunk rows;
+      //  - older: there when the throttle opens (checked all the same), summed inside the loop.
+      double nw[kNearCap], rw[kFarCap];
+      int nslot[kNearCap], rc[kFarCap], nn = 0, nr = 0;
+      // (SPLIT = false, factors whose rows all fit one chunk: nothing stands behind a row's one wait, its recent words
+      // stay in the chunk's round of requests and the second list is not used)
+      constexpr int lo_recent = SPLIT ? -kRecent : 0;
 #pragma unroll
       for (int j = 0; j < kNearCap; ++j) { nw[j] = 0.0; nslot[j] = kRun; }
+#pragma unroll
+      for (int j = 0; j < kFarCap; ++j) { rw[j] = 0.0; rc[j] = ready; }
       for (long long q0 = first; q0 < last; q0 += 16 * kSfChunk) {
         double vf[kSfChunk];
         int c[kSfChunk];
@@ -292,14 +306,19 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
         }
 #pragma unroll
         for (int k = 0; k < kSfChunk; ++k) {
-          const int sl = c[k] >= 0 ? rowpos4[c[k]] - base : -1;   // >= 0: inside this run
+          const int sl = c[k] >= 0 ? rowpos4[c[k]] - base : INT_MIN;   // >= 0: inside this run
           if (sl >= 0) {
 #pragma unroll
             for (int j = 0; j < kNearCap; ++j)
               if (nn == j) { nslot[j] = sl; nw[j] = vf[k]; }
             ++nn;   // past kNearCap: phase 2 walks the row again for it
+          } else if (sl >= lo_recent) {
+#pragma unroll
+            for (int j = 0; j < kFarCap; ++j)
+              if (nr == j) { rc[j] = c[k]; rw[j] = vf[k]; }
+            ++nr;   // past kFarCap: walked again below
           }
-          if (sl >= 0 || c[k] < 0) { c[k] = ready; vf[k] = 0.0; }   // listed / no entry: the word that is always there, times 0
+          if (sl >= lo_recent || c[k] < 0) { c[k] = ready; vf[k] = 0.0; }   // listed / no entry: the word that is always there, times 0
         }
         int spins = 0;
         for (;;) {   // all six words of the lane per round
@@ -314,6 +333,37 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
         }
 #pragma unroll
         for (int k = 0; k < kSfChunk; ++k) s += vf[k] * (timed_out ? 0.0 : __longlong_as_double((long long)x[k]));
+      }
+      if (SPLIT) {   // the recent words outside the run: all of the lane's list per round
+        unsigned long long y[kFarCap];
+        int spins = 0;
+        for (;;) {
+          bool pending = false;
+#pragma unroll
+          for (int j = 0; j < kFarCap; ++j) y[j] = sf_load(out + rc[j]);
+#pragma unroll
+          for (int j = 0; j < kFarCap; ++j) pending = pending || y[j] == kGiluSentinel;
+          if (!pending || timed_out) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) timed_out = true;
+        }
+#pragma unroll
+        for (int j = 0; j < kFarCap; ++j) s += rw[j] * (timed_out ? 0.0 : __longlong_as_double((long long)y[j]));
+      }
+      if (SPLIT && nr > kFarCap) {   // more recent words than the list holds: one after the other
+        int seen = 0;
+        for (long long q = first + sub; q < last; q += 16) {
+          const int cq = ci[q];
+          const int sl = rowpos4[cq] - base;
+          if (sl >= 0 || sl < lo_recent || seen++ < kFarCap) continue;
+          unsigned long long y;
+          int spins = 0;
+          while ((y = sf_load(out + cq)) == kGiluSentinel && !timed_out) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins >= kSpinLimit || ((spins & 255) == 0 && sf_flag(tmo))) timed_out = true;
+          }
+          s += val[q] * (timed_out ? 0.0 : __longlong_as_double((long long)y));
+        }
       }
       // phase 2: the dependencies inside the run, from its LDS image: the first two of the list (all there is, for most
       // lanes of an ILU(0) row), then the rest of it
@@ -899,6 +949,12 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   int maxrow = 0;
   for (int q = 0; q < nloc; ++q) maxrow = std::max(maxrow, (int)(frp[(size_t)q + 1] - frp[(size_t)q]));
   S->maxrow = maxrow;
+  {   // (more than one row in twenty: the periodic SPH ILU(0) factors have a few rows with all 104 neighbours on one side)
+    long long nlong = 0;
+    for (int q = 0; q < nloc; ++q)
+      nlong += fdg[(size_t)q] > 16 * kSfChunk || frp[(size_t)q + 1] - frp[(size_t)q] - fdg[(size_t)q] - 1 > 16 * kSfChunk;
+    S->long_rows = nlong * 20 > nloc;
+  }
   if (maxrow > kGiluMaxRow) { schwarz_destroy(S); return fail("ILU(k) row exceeds the LDS row image (lower the level of fill)", __FILE__, __LINE__); }
   S->t_ms[2] = ms_since(t0); t0 = clk();
   // ---- dependency levels of the two solves (the factorisation follows the L levels)
@@ -1114,14 +1170,18 @@ inline int schwarz_apply(isph_ctx *ctx, const isph_schwarz *S, const double *r, 
     hipLaunchKernelGGL(k_gilu_fill_bits, dim3(stream_grid(nloc)), dim3(kBlock), 0, ctx->stream, nloc, S->ybits.p, S->zbits.p);
     ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p, 0, 2 * sizeof(int), ctx->stream));
     ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p + 4, 0, 2 * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL((k_gilu_solve_run<false>), dim3(S->sweep_blocks[0]), dim3(16 * kRun), 0, ctx->stream, S->nrun_l,
-                       (const int *)S->lrun.p, (const int *)S->lord4.p, (const int *)S->lpos4.p, (const long long *)S->rp.p,
-                       (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p, (const double *)S->w.p, S->ybits.p,
-                       nloc, S->ctr.p, S->runs_near[0]);
-    hipLaunchKernelGGL((k_gilu_solve_run<true>), dim3(S->sweep_blocks[1]), dim3(16 * kRun), 0, ctx->stream, S->nrun_u,
-                       (const int *)S->urun.p, (const int *)S->uord4.p, (const int *)S->upos4.p, (const long long *)S->rp.p,
-                       (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p,
-                       reinterpret_cast<const double *>(S->ybits.p), S->zbits.p, nloc, S->ctr.p, S->runs_near[1]);
+    auto sweep = [&](auto kernel, int d, int nrun, const int *run, const int *ord, const int *pos, const double *rhs, unsigned long long *res) {
+      hipLaunchKernelGGL(kernel, dim3(S->sweep_blocks[d]), dim3(16 * kRun), 0, ctx->stream, nrun, run, ord, pos, (const long long *)S->rp.p,
+                         (const int *)S->ci.p, (const int *)S->dg.p, (const double *)S->val.p, rhs, res, nloc, S->ctr.p, S->runs_near[d]);
+    };
+    const double *yv = reinterpret_cast<const double *>(S->ybits.p);
+    if (S->long_rows) {
+      sweep(k_gilu_solve_run<false, true>, 0, S->nrun_l, S->lrun.p, S->lord4.p, S->lpos4.p, S->w.p, S->ybits.p);
+      sweep(k_gilu_solve_run<true, true>, 1, S->nrun_u, S->urun.p, S->uord4.p, S->upos4.p, yv, S->zbits.p);
+    } else {
+      sweep(k_gilu_solve_run<false, false>, 0, S->nrun_l, S->lrun.p, S->lord4.p, S->lpos4.p, S->w.p, S->ybits.p);
+      sweep(k_gilu_solve_run<true, false>, 1, S->nrun_u, S->urun.p, S->uord4.p, S->upos4.p, yv, S->zbits.p);
+    }
     ISPH_CHECK_HIP(hipMemcpyAsync(S->h_tmo, S->ctr.p + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_gilu_combine, dim3((S->n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S->n, S->rev_ptr.p,
                        S->rev_idx.p, reinterpret_cast<const double *>(S->zbits.p), z);
