@@ -957,6 +957,25 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   }
   if (maxrow > kGiluMaxRow) { schwarz_destroy(S); return fail("ILU(k) row exceeds the LDS row image (lower the level of fill)", __FILE__, __LINE__); }
   S->t_ms[2] = ms_since(t0); t0 = clk();
+  // the factor arrays start on their way to the device now, on a helper thread (copies from pageable memory keep the
+  // calling thread busy): the level analysis below needs the pattern on the host only -- 4.4 GB and 0.3 s for the ILU(1)
+  // pattern of the 100^3 system, next to 0.45 s of level recurrences
+  int rc_up = ISPH_SUCCESS;
+  std::thread uploader;
+  if (!resident) {
+    rc_up = S->rp.reserve((size_t)nloc + 1);
+    if (rc_up == ISPH_SUCCESS) rc_up = S->ci.reserve((size_t)(S->nnz > 0 ? S->nnz : 1));
+    if (rc_up == ISPH_SUCCESS) rc_up = S->val.reserve((size_t)(S->nnz > 0 ? S->nnz : 1));
+    if (rc_up != ISPH_SUCCESS) { schwarz_destroy(S); return rc_up; }
+    uploader = std::thread([&, dev = ctx->device, st = ctx->stream] {
+      hipError_t e = hipSetDevice(dev);
+      if (e == hipSuccess) e = hipMemcpyAsync(S->rp.p, frp.data(), sizeof(long long) * ((size_t)nloc + 1), hipMemcpyHostToDevice, st);
+      if (e == hipSuccess && S->nnz > 0) e = hipMemcpyAsync(S->ci.p, fci.data(), sizeof(int) * (size_t)S->nnz, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess && S->nnz > 0) e = hipMemcpyAsync(S->val.p, fv.data(), sizeof(double) * (size_t)S->nnz, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) rc_up = fail(hipGetErrorString(e), __FILE__, __LINE__);
+    });
+  }
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};   // on every way out
   // ---- dependency levels of the two solves (the factorisation follows the L levels)
   std::vector<int> llev((size_t)nloc, 0), ulev((size_t)nloc, 0);
   int nl = 0, nu = 0;
@@ -1060,12 +1079,8 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
       ISPH_CHECK_HIP(hipMemcpyAsync(buf.p, vec.data(), sizeof(T) * vec.size(), hipMemcpyHostToDevice, ctx->stream));
     return ISPH_SUCCESS;
   };
-  int rc = ISPH_SUCCESS;
-  if (!resident) {
-    rc = up(S->rp, frp);
-    if (rc == ISPH_SUCCESS) rc = up(S->ci, fci);
-    if (rc == ISPH_SUCCESS) rc = up(S->val, fv);
-  }
+  if (uploader.joinable()) uploader.join();
+  int rc = rc_up;
   if (rc == ISPH_SUCCESS) rc = up(S->dg, fdg);
   if (rc == ISPH_SUCCESS) rc = up(S->rows, hrows);
   if (rc == ISPH_SUCCESS) rc = up(S->lord, lord);
