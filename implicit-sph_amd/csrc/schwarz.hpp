@@ -444,7 +444,7 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_gilu_factor_sf(int nloc, const int *__restrict__ order,
                                                                const long long *__restrict__ rp, const int *__restrict__ ci,
                                                                const int *__restrict__ dg, const double *__restrict__ ain,
-                                                               unsigned long long *fout, int *ctr, int *__restrict__ err) {
+                                                               unsigned long long *fout, int *ctr, int *__restrict__ err, int hbits) {
   extern __shared__ double gilu_lds[];
   __shared__ int s_pos, s_dead;
   constexpr int T = 64 * WAVES;   // threads per row: one per entry of a pivot row's upper part and round
@@ -463,12 +463,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_gilu_factor_sf(int nloc, const i
     const int len = (int)(rp[i + 1] - b), nlow = dg[i];
     double *w = gilu_lds;
     int *cols = reinterpret_cast<int *>(gilu_lds + len);
+    // column -> position table of this row (open addressing, at most half full): a look-up is one or two LDS reads
+    // instead of the seven dependent ones of a binary search.  hbits = 0: the table does not fit, binary search.
+    int *hkey = cols + len + (len & 1);
+    unsigned short *hpos = reinterpret_cast<unsigned short *>(hkey + (hbits ? (1 << hbits) : 0));
+    const int hmask = (1 << hbits) - 1;
     for (int t = lane; t < len; t += T) {
       w[t] = ain[b + t];
       cols[t] = ci[b + t];
     }
+    if (hbits)
+      for (int t = lane; t <= hmask; t += T) hkey[t] = -1;
     if (lane == 0) s_dead = sf_flag(tmo);  // the launch has given up: drain without waiting
     __syncthreads();
+    if (hbits) {
+      for (int t = lane; t < len; t += T) {
+        const int key = cols[t];
+        int h = (int)(((unsigned)key * 2654435761u) >> (32 - hbits));
+        while (atomicCAS(&hkey[h], -1, key) != -1) h = (h + 1) & hmask;
+        hpos[h] = (unsigned short)t;
+      }
+      __syncthreads();
+    }
     bool dead = s_dead != 0;
     // A pivot step needs: the pivot row's pointers, then its columns and its values (their addresses do not depend on
     // each other), then the slot look-up in LDS for the column (seven dependent LDS reads, 0.6 us), then the update.
@@ -479,6 +495,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_gilu_factor_sf(int nloc, const i
     // look-up.  So the steps are software-pipelined: pointers three steps ahead, columns two, values and pivot one, and
     // the look-up of step t + 1 runs while step t's values are being asked for again.
     auto slot_of = [&](int j, int t) {   // position of column j among this row's columns right of position t, or -1
+      if (hbits) {   // (a column of a pivot row's upper part that this row has lies right of the pivot's position)
+        int h = (int)(((unsigned)j * 2654435761u) >> (32 - hbits));
+        for (;;) {
+          const int key = hkey[h];
+          if (key == j) return (int)hpos[h];
+          if (key == -1) return -1;
+          h = (h + 1) & hmask;
+        }
+      }
       int lo = t + 1, hi = len - 1;
       while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
@@ -1124,7 +1149,13 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the uploads are done: the stage times below are what they say
   S->t_ms[4] = ms_since(t0); t0 = clk();
   // ---- numeric factorisation
-  const size_t lds = (size_t)maxrow * 12 + 16;
+  // LDS of a factorisation workgroup: the row image (values + columns) and, when it fits the 64 KiB every launch may
+  // ask for, the column -> position table of k_gilu_factor_sf (a power of two >= twice the longest row, 6 B per slot)
+  int hbits = 0;
+  while ((1 << hbits) < 2 * std::max(maxrow, 1)) ++hbits;
+  const size_t lds_row = (size_t)maxrow * 12 + 16, lds_tab = ((size_t)6 << hbits) + 8;
+  if (!syncfree || maxrow >= 65535 || lds_row + lds_tab > 64 * 1024) hbits = 0;
+  const size_t lds = lds_row + (hbits ? lds_tab : 0);
   int htmo = 0;
   if (syncfree && nloc > 0) {
     // one persistent launch: rows in level order, a row waits for the values of the rows it eliminates with
@@ -1146,9 +1177,9 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
       unsigned long long *fo = reinterpret_cast<unsigned long long *>(fout.p);
       const double *ain = S->val.p;
       if (fw == 4)
-        hipLaunchKernelGGL(k_gilu_factor_sf<4>, grid, block, lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p, ain, fo, S->ctr.p, S->err.p);
+        hipLaunchKernelGGL(k_gilu_factor_sf<4>, grid, block, lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p, ain, fo, S->ctr.p, S->err.p, hbits);
       else
-        hipLaunchKernelGGL(k_gilu_factor_sf<1>, grid, block, lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p, ain, fo, S->ctr.p, S->err.p);
+        hipLaunchKernelGGL(k_gilu_factor_sf<1>, grid, block, lds, ctx->stream, nloc, S->lord.p, S->rp.p, S->ci.p, S->dg.p, ain, fo, S->ctr.p, S->err.p, hbits);
       e = hipMemcpyAsync(&htmo, S->ctr.p + 3, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     }
     std::swap(S->val, fout);   // the stream is synchronised below before anything reads the factor
