@@ -11,7 +11,8 @@
 // Division of labour.  The integer work that is sequential by definition -- the level-of-fill pattern of
 // Ifpack_IlukGraph (row i merges the FINAL patterns of the rows it eliminates with) and the dependency levels of
 // the two triangular solves -- runs on the host, once per create(), over the matrix pattern (threads over
-// subdomains).  The floating-point work runs on the device, as ONE persistent launch per phase whose rows wait for
+// subdomains); the level-1 pattern depends on A's pattern only, and for a whole-matrix factor it is built on the device
+// (k_gilu_symbolic1).  The floating-point work runs on the device, as ONE persistent launch per phase whose rows wait for
 // the very words they depend on (round 3; the round-2 form, one launch per dependency level, is kept behind
 // isph_schwarz_params::level_launches as the bit-for-bit cross-check):
 //   k_gilu_factor_sf   IKJ numeric factorisation, one wave per row, rows dequeued in level order; the row image
