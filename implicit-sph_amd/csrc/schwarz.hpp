@@ -806,6 +806,10 @@ __global__ __launch_bounds__(128) void k_gilu_symbolic1(int n, const long long *
       }
     };
     const long long b = rp[i], e = rp[i + 1];
+    if (e - b >= kSymCap / 2) {   // A's own row does not fit the table: the host builds the pattern
+      if (lane == 0) { atomicOr(err, 4); if (!FILL) rowlen[i] = 0; }
+      continue;
+    }
     bool has_diag = false;
     for (long long p = b + lane; p < e; p += 64) { const int c = ci[p]; insert(c, (int)(p - b)); has_diag = has_diag || c == i; }
     if (__ballot(has_diag) == 0ull && lane == 0) insert(i, -2);   // structurally missing diagonal: Ifpack inserts it (value 0)

@@ -21,6 +21,8 @@ def _factor_close(gv, fv):
     (dict(dim=3, n=12, mode=workload.JITTER, brick=4), 1),
     (dict(dim=3, n=16, mode=workload.ADVECT, brick=8), 0),
     (dict(dim=3, n=12, mode=workload.ADVECT, brick=4), 2),
+    # Quintic cut 3h: 400+ entries per row, level-1 rows beyond the device pattern kernel's table: the host builds it
+    (dict(dim=3, n=12, mode=workload.ADVECT, brick=4, kernel="quintic", cut_over_h=3.0), 1),
 ])
 def test_whole_matrix_iluk_matches_oracle(gpu_ctx, case, fill):
     """"ilu<k>": pattern exact, factor 1e-10, apply 1e-11, GMRES iterations +-1 and x 1e-6 against the oracle's
