@@ -229,7 +229,10 @@ constexpr int kSfChunk = 6;
 constexpr int kRun = 64;
 constexpr int kNearCap = 6;   // (value, slot) pairs a lane keeps for the dependencies inside the run
 constexpr int kFarCap = 6;    // (value, row) pairs a lane keeps for the recent dependencies outside it
-constexpr int kRecent = 2 * kRun;   // positions before the run that count as recent: the two runs before it at most
+constexpr int kLongWindow = 4;       // throttle window of the factors with long rows: their rows need longer to get ready
+constexpr int kRecent = 2 * kRun;    // positions before the run that count as recent (the two runs before it; what the wider
+                                     // window lets be open beyond that is so far back that it is there when asked for:
+                                     // 256 positions and a list of 10 measured slower)
 template <bool UPPER, bool SPLIT>
 __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *__restrict__ runstart,
                                                          const int *__restrict__ order4,
@@ -1303,7 +1306,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   for (int d = 0; d < 2; ++d) {
     const int nlev = d == 0 ? nl : nu, nrun = d == 0 ? S->nrun_l : S->nrun_u;
     const int per_level = nlev > 0 ? (nrun + nlev - 1) / nlev : 1;   // runs per level
-    S->runs_near[d] = std::max(2, 2 * per_level);
+    S->runs_near[d] = std::max(S->long_rows ? kLongWindow : 2, 2 * per_level);
     S->sweep_blocks[d] = std::min(ncu, std::max(std::max(16, ncu / 8), S->runs_near[d] + 16));
   }
   hipError_t e = hipMemsetAsync(S->err.p, 0, sizeof(int), ctx->stream);
