@@ -370,8 +370,8 @@ __global__ __launch_bounds__(1024) void k_gilu_solve_run(int nruns, const int *_
         }
       }
       // phase 2: the dependencies inside the run, from its LDS image: the first two of the list (all there is, for most
-      // lanes of an ILU(0) row), then the rest of it
-      {
+      // lanes of an ILU(0) row), then the rest of it.  A wave of the run's first level has no such word at all.
+      if (__ballot(nn > 0) != 0ull) {
         unsigned long long y[kNearCap];
         int spins = 0;
         for (;;) {
