@@ -76,6 +76,18 @@ def build_cpp_test(force=False):
     return CPP_TEST
 
 
+RANK_THREADS = os.path.join(ROOT, "tests", "cpp", "librank_threads.so")
+
+
+def build_rank_threads(force=False):
+    """TEST transport (tests/cpp/rank_threads.cpp): N ranks as threads of one process for isph_ctx_create_hostcomm;
+    plain g++, no device code."""
+    src = os.path.join(ROOT, "tests", "cpp", "rank_threads.cpp")
+    if force or _stale(RANK_THREADS, [src, os.path.join(INC, "isph_hip.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INC, "-o", RANK_THREADS, src])
+    return RANK_THREADS
+
+
 MPI_INC, MPI_LIB = "/opt/conda/include", "/opt/conda/lib"
 MPIEXEC = "/opt/conda/bin/mpiexec"
 CPP_TEST_MPI = os.path.join(ROOT, "tests", "cpp", "test_solver_lin_mpi")
@@ -84,7 +96,8 @@ CPP_MPI_HOST = os.path.join(ROOT, "tests", "cpp", "test_mpi_host")
 
 def have_mpi():
     """The image ships MPICH under /opt/conda (its `mpicxx` wrapper is broken, plain g++ with -I/-L works)."""
-    return os.path.exists(os.path.join(MPI_INC, "mpi.h")) and os.path.exists(MPIEXEC)
+    return (os.path.exists(os.path.join(MPI_INC, "mpi.h")) and os.path.exists(MPIEXEC)
+            and os.path.exists(os.path.join(MPI_LIB, "libmpi.so")) and os.path.exists(os.path.join(MPI_LIB, "libmpi.so.12")))
 
 
 def build_cpp_mpi(force=False):
@@ -116,4 +129,4 @@ def build_cpp_mpi(force=False):
 
 
 def build_all(force=False):
-    return build_host(force), build_hip(force), build_cpp_test(force), build_cpp_mpi(force)
+    return build_host(force), build_hip(force), build_cpp_test(force), build_cpp_mpi(force), build_rank_threads(force)

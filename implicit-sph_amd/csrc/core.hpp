@@ -11,6 +11,10 @@ struct isph_ctx {
   bool own_stream = false;
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  // host-staged transport (isph_ctx_create_hostcomm; comm.hpp): callbacks of the caller + pinned staging buffers
+  isph_host_transport host_tr = {nullptr, nullptr, nullptr};
+  double *hsend = nullptr, *hrecv = nullptr;
+  size_t hsend_cap = 0, hrecv_cap = 0;
   bool profile = false;
   // reduction scratch + small scalar mailboxes
   isph::DevBuf<double> partial;   // per-block partials

@@ -50,18 +50,7 @@ inline void overlap_destroy(isph_overlap *O) {
 
 inline int overlap_exchange(isph_ctx *ctx, const isph_halo &H, const double *send, double *recv, bool reverse) {
   // forward: send[send range p] -> peer p, recv[recv range p] <- peer p; reverse: the two roles swapped
-  if (H.npeers == 0) return ISPH_SUCCESS;
-  ISPH_REQUIRE(ctx->comm, "no communicator");
-  ncclResult_t nr = ncclGroupStart();
-  for (int p = 0; p < H.npeers && nr == ncclSuccess; ++p) {
-    const int s0 = reverse ? H.recv_ptr[(size_t)p] : H.send_ptr[(size_t)p], s1 = reverse ? H.recv_ptr[(size_t)p + 1] : H.send_ptr[(size_t)p + 1];
-    const int r0 = reverse ? H.send_ptr[(size_t)p] : H.recv_ptr[(size_t)p], r1 = reverse ? H.send_ptr[(size_t)p + 1] : H.recv_ptr[(size_t)p + 1];
-    if (s1 > s0) nr = ncclSend(send + s0, (size_t)(s1 - s0), ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
-    if (nr == ncclSuccess && r1 > r0) nr = ncclRecv(recv + r0, (size_t)(r1 - r0), ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
-  }
-  const ncclResult_t ne = ncclGroupEnd();
-  if (nr != ncclSuccess || ne != ncclSuccess) return fail("RCCL exchange of the overlap rows failed", __FILE__, __LINE__);
-  return ISPH_SUCCESS;
+  return comm_exchange(ctx, H, send, recv, 1, reverse, ctx->stream);
 }
 
 inline int overlap_apply(isph_ctx *ctx, const isph_overlap *O, const double *r, double *z) {
@@ -244,6 +233,19 @@ int isph_ctx_create_dist(int device, void *stream, int rank, int nranks, const c
   return ISPH_SUCCESS;
 }
 
+int isph_ctx_create_hostcomm(int device, void *stream, int rank, int nranks, const isph_host_transport *t, isph_ctx **ctx) {
+  ISPH_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank/nranks");
+  ISPH_REQUIRE(t && t->exchange && t->allreduce, "host transport without its two callbacks");
+  ISPH_CHECK(ctx_create_common(device, stream, ctx));
+  isph_ctx *c = *ctx;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->host_tr = *t;
+  // the same second stream as the RCCL contexts: the staged halo exchange is ordered exactly like the grouped send/recv
+  ISPH_CHECK_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  return ISPH_SUCCESS;
+}
+
 int isph_ctx_sync(isph_ctx *ctx) {
   ISPH_REQUIRE(ctx, "ctx is NULL");
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -300,6 +302,8 @@ void isph_ctx_destroy(isph_ctx *c) {
   if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   c->xghost.release();
   if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->hsend) (void)hipHostFree(c->hsend);
+  if (c->hrecv) (void)hipHostFree(c->hrecv);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
@@ -410,7 +414,7 @@ int isph_halo_create(isph_ctx *ctx, int nlocal, int npeers, const int *peer_rank
                      const int *send_idx, const int *recv_ptr, isph_halo_plan **plan) {
   ISPH_REQUIRE(ctx && plan && nlocal >= 0 && npeers >= 0, "NULL or negative argument");
   ISPH_REQUIRE(npeers == 0 || (peer_rank && send_ptr && recv_ptr), "NULL halo lists");
-  ISPH_REQUIRE(npeers == 0 || ctx->comm, "a halo plan with peers needs a context made by isph_ctx_create_dist");
+  ISPH_REQUIRE(npeers == 0 || comm_active(ctx), "a halo plan with peers needs a context made by isph_ctx_create_dist or isph_ctx_create_hostcomm");
   isph_halo_plan *P = new isph_halo_plan();
   P->nlocal = nlocal;
   isph_halo &H = P->H;
@@ -454,7 +458,7 @@ int isph_halo_forward(isph_ctx *ctx, const isph_halo_plan *P, const double *x, d
   const isph_halo &H = P->H;
   if (H.nrecv == 0 && H.nsend == 0) return ISPH_SUCCESS;
   ISPH_REQUIRE(x && ghosts, "NULL field");
-  ISPH_REQUIRE(ctx->comm, "no communicator");
+  ISPH_REQUIRE(comm_active(ctx), "no communicator");
   DevTmp<double> tx, tg;
   const double *dx = nullptr;
   int rc = stage_in(ctx, x, (size_t)P->nlocal * ncomp, on_device, tx, &dx);
@@ -466,16 +470,7 @@ int isph_halo_forward(isph_ctx *ctx, const isph_halo_plan *P, const double *x, d
     if (H.nsend > 0)
       hipLaunchKernelGGL(k_gather_atoms, dim3(stream_grid((long long)H.nsend * ncomp)), dim3(kBlock), 0, ctx->stream, H.nsend,
                          ncomp, (const int *)H.send_idx.p, dx, ctx->sendbuf.p);
-    ncclResult_t nr = ncclGroupStart();
-    for (int p = 0; p < H.npeers && nr == ncclSuccess; ++p) {
-      const size_t ns = (size_t)(H.send_ptr[(size_t)p + 1] - H.send_ptr[(size_t)p]) * ncomp;
-      const size_t nrv = (size_t)(H.recv_ptr[(size_t)p + 1] - H.recv_ptr[(size_t)p]) * ncomp;
-      if (ns > 0) nr = ncclSend(ctx->sendbuf.p + (size_t)H.send_ptr[(size_t)p] * ncomp, ns, ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
-      if (nr == ncclSuccess && nrv > 0)
-        nr = ncclRecv(dg + (size_t)H.recv_ptr[(size_t)p] * ncomp, nrv, ncclDouble, H.peer[(size_t)p], ctx->comm, ctx->stream);
-    }
-    const ncclResult_t ne = ncclGroupEnd();
-    if (nr != ncclSuccess || ne != ncclSuccess) rc = fail("RCCL halo exchange failed", __FILE__, __LINE__);
+    rc = comm_exchange(ctx, H, ctx->sendbuf.p, dg, ncomp, false, ctx->stream);
   }
   if (rc == ISPH_SUCCESS && !on_device && H.nrecv > 0 &&
       hipMemcpyAsync(ghosts, dg, sizeof(double) * (size_t)H.nrecv * ncomp, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
@@ -815,7 +810,7 @@ int isph_prec_create_overlap(isph_ctx *ctx, const isph_mat *Aext, int nlocal, in
                              isph_prec **Mout) {
   ISPH_REQUIRE(ctx && Aext && Mout && nlocal >= 0 && npeers >= 0 && (combine == 0 || combine == 1), "bad argument");
   ISPH_REQUIRE(npeers == 0 || (peer_rank && send_ptr && send_idx && recv_ptr), "NULL halo lists");
-  ISPH_REQUIRE(npeers == 0 || ctx->comm, "overlap across ranks needs a context made by isph_ctx_create_dist");
+  ISPH_REQUIRE(npeers == 0 || comm_active(ctx), "overlap across ranks needs a context made by isph_ctx_create_dist or isph_ctx_create_hostcomm");
   const int nrecv = npeers > 0 ? recv_ptr[npeers] : 0, nsend = npeers > 0 ? send_ptr[npeers] : 0;
   ISPH_REQUIRE(Aext->S.nrow == nlocal + nrecv && Aext->S.ncol == Aext->S.nrow,
                "the extended matrix must be square with nlocal + (number of ghost columns) rows");
@@ -870,7 +865,7 @@ int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params
   int rc = nullvec ? stage_in(ctx, nullvec, (size_t)M->n, on_device, tn, &dn) : ISPH_SUCCESS;
   if (rc == ISPH_SUCCESS) rc = amg_create(ctx, A, prm, dn, &M->amg);
   tn.release();
-  if (ctx->comm && ctx->nranks > 1) {
+  if (comm_active(ctx) && ctx->nranks > 1) {
     // The hierarchy is built per rank (Uncoupled); only the fine level exchanges halos inside the cycle, and how often
     // depends on whether a rank coarsened at all and on its coarse solver.  Ranks that disagree would wait for each
     // other forever: agree here, once per set-up, and fail on every rank together instead.

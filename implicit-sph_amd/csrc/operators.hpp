@@ -15,6 +15,7 @@
 // (assemble.hpp), MirrorNothing coefficients.
 #pragma once
 #include "assemble.hpp"
+#include "comm.hpp"
 
 namespace isph {
 
@@ -511,9 +512,8 @@ inline int shift_apply(isph_ctx *ctx, const isph_particles *P, int antisym, cons
       if (n > 0)
         hipLaunchKernelGGL(k_max_fluid_speed, dim3(grid), dim3(kBlock), 0, ctx->stream, n, P->dim, st.a.type, st.T.kind,
                            (const double *)iv.dev, reinterpret_cast<unsigned long long *>(scal.p));
-      if (ctx->comm && ncclAllReduce(scal.p, scal.p, 1, ncclDouble, ncclMax, ctx->comm, ctx->stream) != ncclSuccess)
-        rc = fail("ncclAllReduce(max) failed", __FILE__, __LINE__);
-      if (n > 0)
+      rc = comm_allreduce(ctx, scal.p, 1, /*max*/ 1, ctx->stream);
+      if (rc == ISPH_SUCCESS && n > 0)
         hipLaunchKernelGGL(k_compute_shift, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, st.T, st.a, shift * dt,
                            (const double *)scal.p, shiftcut * shiftcut, nonfluidweight, sdr.p);
       ddr = sdr.p;

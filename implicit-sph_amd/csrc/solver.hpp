@@ -8,6 +8,7 @@
 #pragma once
 #include <cmath>
 
+#include "comm.hpp"
 #include "core.hpp"
 #include "krylov.hpp"
 
@@ -17,8 +18,7 @@ int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z
 int prec_apply_multi_dev(isph_ctx *ctx, const isph_prec *M, int K, const double *const *rs, double *const *zs);  // isph_capi.hip
 
 inline int allreduce_inplace(isph_ctx *ctx, double *d, int count) {
-  if (ctx->comm) ISPH_CHECK_NCCL(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
-  return ISPH_SUCCESS;
+  return comm_allreduce(ctx, d, count, /*sum*/ 0, ctx->stream);
 }
 
 // device scalar mailbox layout
@@ -51,13 +51,15 @@ __global__ void k_gather(int n, const int *__restrict__ idx, const double *__res
 }
 
 // Starts the halo exchange of x for a matrix with ghost columns: the boundary values are packed on the compute stream,
-// the grouped ncclSend/ncclRecv runs on ctx->comm_stream and lands in ctx->xghost; ctx->ev_halo marks its end.  The
+// the point-to-point exchange (comm.hpp: grouped ncclSend/ncclRecv, or the host-staged transport) runs on
+// ctx->comm_stream and lands in ctx->xghost; ctx->ev_halo marks its end.  The
 // caller launches the interior slices on the compute stream meanwhile and makes the compute stream wait on ev_halo
 // before the boundary slices.  The communicator is only ever used by one operation at a time: the exchange starts
 // after everything queued before it (ev_pack) and every later collective is queued behind the boundary kernel, which
 // itself waits for ev_halo.  (Ifpack/Epetra do this Import inside Epetra_CrsMatrix::Apply, solver_lin.h:133.)
 inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x) {
-  ISPH_REQUIRE(ctx->comm && ctx->comm_stream, "a matrix with a halo needs a context made by isph_ctx_create_dist");
+  ISPH_REQUIRE(comm_active(ctx) && ctx->comm_stream,
+               "a matrix with a halo needs a context made by isph_ctx_create_dist or isph_ctx_create_hostcomm");
   const Sell &S = A->S;
   const isph_halo &H = A->halo;
   ISPH_REQUIRE(H.nrecv == S.ncol - S.nrow, "matrix has ghost columns but no matching halo plan");
@@ -69,13 +71,7 @@ inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x) {
                        ctx->sendbuf.p);
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev_pack, ctx->stream));
   ISPH_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_pack, 0));
-  ISPH_CHECK_NCCL(ncclGroupStart());
-  for (int p = 0; p < H.npeers; ++p) {
-    const int ns = H.send_ptr[p + 1] - H.send_ptr[p], nr = H.recv_ptr[p + 1] - H.recv_ptr[p];
-    if (ns > 0) ISPH_CHECK_NCCL(ncclSend(ctx->sendbuf.p + H.send_ptr[p], (size_t)ns, ncclDouble, H.peer[p], ctx->comm, ctx->comm_stream));
-    if (nr > 0) ISPH_CHECK_NCCL(ncclRecv(ctx->xghost.p + H.recv_ptr[p], (size_t)nr, ncclDouble, H.peer[p], ctx->comm, ctx->comm_stream));
-  }
-  ISPH_CHECK_NCCL(ncclGroupEnd());
+  ISPH_CHECK(comm_exchange(ctx, H, ctx->sendbuf.p, ctx->xghost.p, 1, false, ctx->comm_stream));
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev_halo, ctx->comm_stream));
   return ISPH_SUCCESS;
 }

@@ -17,7 +17,7 @@ NOT_SINGULAR, NULLSPACE, PINZERO, DOUBLEDIAG = 0, 1, 2, 3
 KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
-    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_pool_info", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
+    "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_create_hostcomm", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_pool_info", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
@@ -97,6 +97,7 @@ def lib():
         L.isph_prec_nnz.argtypes = [C.c_void_p]
         L.isph_ctx_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.isph_ctx_create_dist.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p]
+        L.isph_ctx_create_hostcomm.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.isph_ctx_sync.argtypes = [C.c_void_p]
         L.isph_ctx_destroy.argtypes = [C.c_void_p]
         L.isph_pool_trim.argtypes = []
@@ -260,10 +261,16 @@ def pool_cached_bytes():
     return int(lib().isph_pool_cached_bytes())
 
 
-class Context:
-    """isph_ctx: device + stream (+ RCCL communicator when nranks > 1)."""
+class HostTransport(C.Structure):
+    """isph_host_transport: the two callbacks of a host-staged communicator (isph_ctx_create_hostcomm)."""
+    _fields_ = [("user", C.c_void_p), ("exchange", C.c_void_p), ("allreduce", C.c_void_p)]
 
-    def __init__(self, device=0, stream=None, rank=0, nranks=1, uid=None):
+
+class Context:
+    """isph_ctx: device + stream (+ RCCL communicator when nranks > 1, or the host-staged transport `transport`, a
+    HostTransport whose callbacks outlive the context, for ranks that share a device)."""
+
+    def __init__(self, device=0, stream=None, rank=0, nranks=1, uid=None, transport=None):
         self.h = C.c_void_p()
         self.rank, self.nranks = rank, nranks
         if stream is None and "torch" in sys.modules:
@@ -275,7 +282,9 @@ class Context:
         # handle 0 is the legacy null stream: the library then creates its own stream with hipStreamDefault,
         # i.e. one that is implicitly ordered against null-stream work (isph_capi.hip ctx_create_common)
         sp = C.c_void_p(stream) if stream else None
-        if nranks > 1 or uid is not None:
+        if transport is not None:
+            _check(lib().isph_ctx_create_hostcomm(device, sp, rank, nranks, C.byref(transport), C.byref(self.h)))
+        elif nranks > 1 or uid is not None:
             _check(lib().isph_ctx_create_dist(device, sp, rank, nranks, uid, C.byref(self.h)))
         else:
             _check(lib().isph_ctx_create(device, sp, C.byref(self.h)))

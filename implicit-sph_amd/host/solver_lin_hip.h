@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
@@ -14,6 +15,7 @@
 
 #include "halo_lists.h"
 #include "isph_hip.h"
+#include "mpi_transport.h"
 #include "solver_lin.h"
 
 namespace LAMMPS_NS {
@@ -216,6 +218,17 @@ class SolverLin_HIP : public SolverLin {
   int ensureContext() {
     if (_ctx) return ISPH_SUCCESS;
     if (!needComm()) return isph_ctx_create(_device, nullptr, &_ctx);
+#ifdef ISPH_HAVE_MPI
+    // Which transport: RCCL needs one device per rank.  Ranks that share a device (several MPI ranks of a LAMMPS run
+    // per GPU) exchange through the caller's MPI communicator instead, staged through pinned memory (csrc/comm.hpp).
+    // "auto": every rank gathers the device indices of the ranks on its node; one shared device anywhere => MPI
+    // everywhere (the choice must be the same on all ranks).  ISPH_TRANSPORT=rccl|mpi overrides.
+    if (useMpiTransport()) {
+      _mpi.comm = _comm.Comm();
+      const isph_host_transport t = _mpi.table();
+      return isph_ctx_create_hostcomm(_device, nullptr, _comm.MyPID(), _comm.NumProc(), &t, &_ctx);
+    }
+#endif
     // rank 0 draws the RCCL id; its status travels with the id so that every rank fails together instead of waiting in
     // a broadcast (or in ncclCommInitRank) for a rank that has already returned
     struct { int status; char uid[ISPH_UID_BYTES]; } msg;
@@ -232,6 +245,32 @@ class SolverLin_HIP : public SolverLin {
     if (msg.status != ISPH_SUCCESS) return ISPH_FAILURE;
     return isph_ctx_create_dist(_device, nullptr, _comm.MyPID(), _comm.NumProc(), msg.uid, &_ctx);
   }
+#ifdef ISPH_HAVE_MPI
+  bool useMpiTransport() {
+    const char *e = std::getenv("ISPH_TRANSPORT");
+    int choice = -1;  // -1 auto, 0 rccl, 1 mpi
+    if (e && std::string(e) == "mpi") choice = 1;
+    else if (e && std::string(e) == "rccl") choice = 0;
+    if (choice < 0) {
+      MPI_Comm node;
+      int shared = 0;
+      if (MPI_Comm_split_type(_comm.Comm(), MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, &node) == MPI_SUCCESS) {
+        int nn = 1, me = 0;
+        MPI_Comm_size(node, &nn);
+        MPI_Comm_rank(node, &me);
+        std::vector<int> dev((size_t)nn, 0);
+        MPI_Allgather(&_device, 1, MPI_INT, dev.data(), 1, MPI_INT, node);
+        for (int r = 0; r < nn; ++r) shared = shared || (r != me && dev[(size_t)r] == _device);
+        MPI_Comm_free(&node);
+      }
+      choice = _comm.MaxAll(shared);
+      if (choice && _comm.MyPID() == 0)
+        std::printf(">> SolverLin_HIP: ranks share a device -- halo exchange and dot products go through MPI (host-staged), not RCCL\n");
+    }
+    return choice == 1;
+  }
+  MpiTransport _mpi;
+#endif
   // Epetra_Import of the matrix -> isph_mat_set_halo: peers = ProcsTo U ProcsFrom (ascending), per peer the owned rows
   // to send (ExportLIDs, grouped by destination) and the number of ghost values to receive (ghost columns are stored
   // grouped by source rank, Epetra's column-map order).

@@ -45,6 +45,23 @@ int isph_ctx_create(int device, void *stream, isph_ctx **ctx);
 int isph_comm_unique_id(char *uid);
 int isph_ctx_create_dist(int device, void *stream, int rank, int nranks,
                          const char *uid, isph_ctx **ctx);
+/* Multi-rank WITHOUT RCCL: ranks that share a device (several MPI ranks of a LAMMPS run on one GPU -- RCCL refuses two
+ * ranks of a communicator on one device), or a launcher that wants its own MPI communicator to carry the traffic as
+ * the reference does (Epetra_MpiComm, ref: solver_lin.cpp:30-31).  The library stages the device buffers through pinned
+ * host memory and calls back; kernels, streams and their order are those of the RCCL path, only the host waits.
+ *   exchange : for p in [0,npeers): send[send_off[p] .. send_off[p+1]) -> rank peer[p], recv[recv_off[p] .. recv_off[p+1])
+ *              <- rank peer[p]; all messages posted together (MPI_Irecv/MPI_Isend/MPI_Waitall); a peer may be the rank
+ *              itself.  Every rank calls it in the same order; a rank without peers does not call it.
+ *   allreduce: in place over all ranks, op 0 = sum, 1 = max; called by every rank.
+ * Both return 0 on success.  host/mpi_transport.h is the MPI implementation the C++ mirror uses. */
+typedef struct {
+  void *user;
+  int (*exchange)(void *user, int npeers, const int *peer, const double *send, const long long *send_off,
+                  double *recv, const long long *recv_off);
+  int (*allreduce)(void *user, double *buf, int count, int op);
+} isph_host_transport;
+int isph_ctx_create_hostcomm(int device, void *stream, int rank, int nranks, const isph_host_transport *transport,
+                             isph_ctx **ctx);
 int isph_ctx_sync(isph_ctx *ctx);
 void isph_ctx_destroy(isph_ctx *ctx);
 /* Device buffers released by the library are kept for the next set-up (the reference rebuilds matrix and preconditioner

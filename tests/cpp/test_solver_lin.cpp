@@ -146,6 +146,89 @@ static int run_selfhalo(const char *fin, const char *fout, bool overlap, bool ex
   return info.converged ? 0 : 3;
 }
 
+#ifdef ISPH_HAVE_MPI
+// "ranks": mpiexec -n N <exe> <dir> <unused> <singular> ranks <bjacobi|overlap|ml>.  Rank r reads <dir>/rank<r>.bin =
+// nl, ncol, nnz, rp, ci (ghost columns >= nl), val, b[nl] | nto, procs_to, lengths_to | nexp, export_lids | nfrom,
+// procs_from, lengths_from -- the local matrix of one rank of a decomposed run with the lists of its Epetra_Import --
+// and drives SolverLin(MPI_Comm&) exactly like PairISPH does on every rank (pair_isph.cpp:988-1011).  All ranks of the
+// test share device 0, so SolverLin_HIP picks the MPI transport (host/mpi_transport.h).  Writes <dir>/x<r>.bin.
+static int run_ranks(const char *dir, bool singular, const std::string &mode) {
+  int me = 0, np = 1;
+  MPI_Comm_rank(MPI_COMM_WORLD, &me);
+  MPI_Comm_size(MPI_COMM_WORLD, &np);
+  const std::string fin = std::string(dir) + "/rank" + std::to_string(me) + ".bin";
+  FILE *f = std::fopen(fin.c_str(), "rb");
+  if (!f) return 2;
+  int nl = 0, ncol = 0, nnz = 0;
+  if (std::fread(&nl, 4, 1, f) != 1 || std::fread(&ncol, 4, 1, f) != 1 || std::fread(&nnz, 4, 1, f) != 1) return 2;
+  std::vector<int> rp((size_t)nl + 1), ci((size_t)nnz), gid((size_t)nl);
+  std::vector<double> val((size_t)nnz), b((size_t)nl), x((size_t)nl, 0.0);
+  if (std::fread(rp.data(), 4, rp.size(), f) != rp.size() || std::fread(ci.data(), 4, ci.size(), f) != ci.size() ||
+      std::fread(val.data(), 8, val.size(), f) != val.size() || std::fread(b.data(), 8, b.size(), f) != b.size()) return 2;
+  auto read_list = [&](std::vector<int> &v) {
+    int n = 0;
+    if (std::fread(&n, 4, 1, f) != 1) return false;
+    v.resize((size_t)n);
+    return n == 0 || std::fread(v.data(), 4, v.size(), f) == v.size();
+  };
+  std::vector<int> pto, lto, exp, pfrom, lfrom;
+  int nto = 0, nfrom = 0;
+  if (std::fread(&nto, 4, 1, f) != 1) return 2;
+  pto.resize((size_t)nto); lto.resize((size_t)nto);
+  if (nto && (std::fread(pto.data(), 4, pto.size(), f) != pto.size() || std::fread(lto.data(), 4, lto.size(), f) != lto.size())) return 2;
+  if (!read_list(exp)) return 2;
+  if (std::fread(&nfrom, 4, 1, f) != 1) return 2;
+  pfrom.resize((size_t)nfrom); lfrom.resize((size_t)nfrom);
+  if (nfrom && (std::fread(pfrom.data(), 4, pfrom.size(), f) != pfrom.size() || std::fread(lfrom.data(), 4, lfrom.size(), f) != lfrom.size())) return 2;
+  std::fclose(f);
+  int off = 0;
+  MPI_Exscan(&nl, &off, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
+  if (me == 0) off = 0;
+  for (int i = 0; i < nl; ++i) gid[(size_t)i] = off + i + 1;
+  MPI_Comm world = MPI_COMM_WORLD;
+  Epetra_Map nodalmap(-1, nl, gid.data(), 1, Epetra_MpiComm(world));
+  Epetra_Import importer(nto, pto.data(), lto.data(), exp.data(), nfrom, pfrom.data(), lfrom.data());
+  Epetra_CrsMatrix AA(nl, ncol, rp.data(), ci.data(), val.data(), ncol > nl ? &importer : nullptr);
+  PrecondWrapper_Ifpack prec_ifpack(world);
+  PrecondWrapper_ML prec_ml(world);
+  PrecondWrapper &prec = mode == "ml" ? static_cast<PrecondWrapper &>(prec_ml) : static_cast<PrecondWrapper &>(prec_ifpack);
+  Teuchos::ParameterList *pp = prec.setParameters();
+  if (mode == "ml") {
+    pp->set("coarse: max size", 64);
+    pp->set("aggregation: threshold", 0.02);
+    pp->set("isph: block rows", 256);
+  } else {
+    pp->set("fact: level-of-fill", 0);
+    pp->set("Overlap Level", mode == "overlap" ? 1 : 0);
+    pp->set("isph: block rows", mode == "overlap" ? 0 : 256);
+  }
+  SolverLin_Belos li_solver(world);
+  li_solver.setParameters();
+  li_solver.setNodalMap(&nodalmap);
+  li_solver.setMatrix(&AA);
+  prec.setMatrix(&AA);
+  li_solver.createSolutionMultiVector(x.data(), nl, 1);
+  li_solver.createLoadMultiVector(b.data(), nl, 1);
+  Epetra_IntSerialDenseVector null_mask(nl);
+  if (singular) {
+    for (int i = 0; i < nl; ++i) null_mask[i] = 1;
+    li_solver.setNullVectorMask(&null_mask);
+    li_solver.setMatrixIsSingular(true);
+  }
+  li_solver.setInitialSolution(SolverLin::Zero);
+  if (li_solver.solveProblem(&prec, "ranks") != LAMMPS_SUCCESS) return 1;
+  const isph_solve_info &info = li_solver.lastSolveInfo();
+  std::printf("rank %d of %d: converged=%d iters=%d rel=%.3e\n", me, np, info.converged, info.iters, info.rel_res_implicit);
+  const std::string fout = std::string(dir) + "/x" + std::to_string(me) + ".bin";
+  f = std::fopen(fout.c_str(), "wb");
+  const int hdr[2] = {info.converged, info.iters};
+  std::fwrite(hdr, 4, 2, f);
+  std::fwrite(x.data(), 8, x.size(), f);
+  std::fclose(f);
+  return info.converged ? 0 : 3;
+}
+#endif
+
 static int run(int argc, char **argv);
 int main(int argc, char **argv) {
 #ifdef ISPH_HAVE_MPI
@@ -159,6 +242,9 @@ int main(int argc, char **argv) {
 }
 
 static int run(int argc, char **argv) {
+#ifdef ISPH_HAVE_MPI
+  if (argc > 5 && std::string(argv[4]) == "ranks") return run_ranks(argv[1], std::atoi(argv[3]) != 0, argv[5]);
+#endif
   if (argc > 4 && std::string(argv[4]) == "block") return run_block(argv[1], argv[2]);
   if (argc > 4 && std::string(argv[4]) == "selfhalo") return run_selfhalo(argv[1], argv[2], false);
   if (argc > 4 && std::string(argv[4]) == "selfhalo-overlap") return run_selfhalo(argv[1], argv[2], true);

@@ -1,0 +1,331 @@
+"""-m gpu: the multi-rank path with DIFFERENT peers per rank, on one GPU.
+
+Every rank is a thread with its own context over the host-staged transport (tests/ranks.py, tests/cpp/rank_threads.cpp;
+include/isph_hip.h isph_ctx_create_hostcomm) -- the code that runs is the library's multi-rank code: forward comm of the
+volumes (isph_halo_forward), row-local assembly with ghost columns and the rank-0-only singular modes, the halo exchange
+on the second stream overlapped with the interior slices, boundary slices, all-reduced dots, block-Jacobi ILU per rank,
+"Overlap Level" 1 with the Add return to a different owner, rank-local SA-AMG.  Partitioning = the reference's: rows =
+the rank's particles, columns = owned + ghost tags (pair_isph.cpp:1258-1259; Epetra_Import inside
+Epetra_CrsMatrix::Apply, solver_lin.h:133; Norm2/Dot all-reduces, solver_lin.cpp:72-74).
+
+The checker is the SINGLE-RANK oracle on the whole lattice, permuted to the rank-concatenated row order: assembled
+rows entry by entry, iteration counts +-1 (the dots are reduced in another order), pressure <= 1e-6."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from isph_amd import dist, hip, workload
+import oracle as orc
+from ranks import RankGroup, empty_parts
+
+pytestmark = pytest.mark.gpu
+
+BLOCK = 256
+
+
+def _spec(dim, pgrid, n, rank=None):
+    ncell = tuple(n * g for g in pgrid[:dim])
+    kw = dict(dim=dim, ncell=ncell, brick=(4,) * dim, origin=(0.5,) * dim if dim == 2 else (0.0,) * 3, mode=workload.JITTER)
+    if rank is not None:
+        kw.update(pgrid=pgrid[:dim], rank=rank)
+    return workload.TGVSpec(**kw)
+
+
+def _rank_setup(rank, G, dim, pgrid, n, singular):
+    """particles, plan, context, volumes with forward comm, assembled Poisson system of one rank"""
+    nreal = int(np.prod(pgrid[:dim]))
+    if rank < nreal:
+        spec = _spec(dim, pgrid, n, rank)
+        parts = workload.make_tgv(spec)
+    else:                                               # an extra rank without particles
+        spec = _spec(dim, pgrid, n, 0)
+        parts = empty_parts(spec, rank)
+    plan = dist.make_plan(parts, G.td(rank))
+    ctx = G.context(rank)
+    nl = int(parts["nlocal"])
+    fwd = hip.HaloForward(ctx, nl, plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+    vf = hip.compute_volumes(ctx, parts, plan.colmap)
+    vfrac = np.ascontiguousarray(dist.forward_scalar_rccl(fwd, plan, vf))          # [nall], ghosts from their owners
+    fwd.close()
+    A, b = hip.assemble_poisson(ctx, parts, plan.colmap, spec.dt, parts["rho"], np.ascontiguousarray(parts["v"]), vfrac=vfrac,
+                                ncol=plan.ncol, singular=singular, rank0=(rank == 0))
+    if plan.ncol > nl:
+        A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
+    rp, ci, v = A.export_csr()
+    col_tag = np.zeros(plan.ncol, dtype=np.int64)
+    col_tag[plan.colmap] = parts["tag"]
+    return dict(spec=spec, parts=parts, plan=plan, ctx=ctx, A=A, b=b, csr=(rp, ci, v), col_tag=col_tag, nl=nl,
+                rtag=parts["tag"][:nl].astype(np.int64))
+
+
+class GlobalOracle:
+    """the single-rank oracle system of the whole lattice and its permutation to rank-concatenated order"""
+
+    def __init__(self, dim, pgrid, n, singular, rtags):
+        spec = _spec(dim, pgrid, n)
+        parts = workload.make_tgv(spec)
+        P = orc.Particles(parts, workload.single_rank_colmap(parts)).precompute(corrections=False)
+        rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True, singular=singular)
+        self.N = N = parts["nlocal"]
+        self.A = sps.csr_matrix((val, ci, rp), shape=(N, N))
+        self.b = b
+        self.scale = np.abs(val).max()
+        self.pos = np.zeros(N + 1, dtype=np.int64)
+        self.pos[parts["tag"][:N].astype(np.int64)] = np.arange(N)
+        self.perm = np.concatenate([self.pos[t] for t in rtags])            # concatenated row -> oracle row
+        assert len(np.unique(self.perm)) == N
+        self.off = np.concatenate([[0], np.cumsum([len(t) for t in rtags])]).astype(np.int64)
+        Ap = self.A[self.perm][:, self.perm].tocsr()
+        Ap.sort_indices()
+        self.Ap = Ap
+        self.bp = b[self.perm]
+
+    def check_rows(self, results):
+        """every rank's device-assembled rows and right-hand side against the oracle's, keyed by global tags"""
+        for r, res in enumerate(results):
+            rp, ci, v = res["csr"]
+            nl = res["nl"]
+            if nl == 0:
+                continue
+            rows = np.repeat(self.pos[res["rtag"]], np.diff(rp))
+            D = sps.csr_matrix((v, (rows, self.pos[res["col_tag"][ci]])), shape=(self.N, self.N))
+            sel = self.pos[res["rtag"]]
+            assert abs(D[sel] - self.A[sel]).max() <= 1e-12 * self.scale, "rank %d: assembled rows differ" % r
+            assert np.max(np.abs(res["b"] - self.b[sel])) <= 1e-12 * np.abs(self.b).max(), "rank %d: rhs differs" % r
+
+    def block_ptr(self, block):
+        bp = [0]
+        for r in range(len(self.off) - 1):
+            lo, hi = int(self.off[r]), int(self.off[r + 1])
+            bp += list(range(lo + block, hi, block)) + ([hi] if hi > lo else [])
+        return np.asarray(bp, dtype=np.int32)
+
+
+def _solve_bjacobi(rank, G, dim, pgrid, n, singular):
+    st = _rank_setup(rank, G, dim, pgrid, n, singular)
+    ctx, A = st["ctx"], st["A"]
+    try:
+        M = hip.Precond(ctx, A, "bjacobi-ilu0", BLOCK)
+        x, bb = np.zeros(st["nl"]), st["b"].copy()
+        info = hip.solve(ctx, A, bb, x, prec=M, singular=(singular == orc.NULLSPACE))
+        # one more product through the halo path, for the explicit residual of the global system
+        y = A.spmv(x)
+        M.close()
+        return dict(st, x=x, y=y, bproj=bb, info=(info.converged, info.iters, info.rel_res_explicit), ctx=None, A=None, parts=None)
+    finally:
+        A.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("dim,pgrid,n", [(3, (2, 1, 1), 8), (3, (2, 2, 1), 8), (3, (2, 2, 2), 8), (2, (2, 2, 1), 16),
+                                         (3, (1, 2, 2), 8)])
+def test_distributed_fgmres_bjacobi_ilu0_matches_the_single_rank_oracle(dim, pgrid, n):
+    """2x1x1, 2x2x1 and 2x2x2 bricks (the 2-, 4- and 8-GPU grids of bench.py; 2x2x2 is the decomposition of BASELINE
+    configs[2]): FGMRES(50) + block-Jacobi ILU(0) with the NullSpace projection over all ranks."""
+    world = int(np.prod(pgrid[:dim]))
+    G = RankGroup(world)
+    try:
+        res = G.run(_solve_bjacobi, dim, pgrid, n, orc.NULLSPACE)
+        cnt = G.counts()
+    finally:
+        G.close()
+    O = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [r["rtag"] for r in res])
+    O.check_rows(res)
+    # every rank has peers that are not itself, and not all ranks have the same peers
+    peers = [tuple(int(p) for p in r["plan"].peers) for r in res]
+    assert all(len(p) > 0 and q not in p for q, p in enumerate(peers)), peers
+    if world > 2:
+        assert len(set(peers)) > 1
+    ilu = orc.ILU(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, O.block_ptr(BLOCK))
+    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="ilu", ilu=ilu)
+    infos = {r["info"][:2] for r in res}
+    assert len(infos) == 1, "ranks disagree on convergence / iteration count: %s" % infos
+    conv, iters = infos.pop()
+    assert conv == 1 and io.converged == 1 and abs(iters - io.iters) <= 1, (iters, io.iters)
+    x = np.concatenate([r["x"] for r in res])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    # explicit residual of the GLOBAL system from the distributed product, projected like the operator
+    y = np.concatenate([r["y"] for r in res])
+    bb = np.concatenate([r["bproj"] for r in res])
+    rres = bb - (y - y.mean())
+    assert np.linalg.norm(rres) / np.linalg.norm(bb) < 2e-8
+    assert np.max(np.abs(y - O.Ap @ x)) <= 1e-11 * O.scale * np.abs(x).max()     # halo SpMV == global operator
+    assert abs(x.mean()) <= 1e-12 * np.abs(x).max()
+    assert cnt["exchanges"] > world * iters and cnt["allreduces"] > world * iters
+    print("ranks %d grid %s: iterations %d (oracle %d), %d exchanges, %d all-reduces" % (world, pgrid, iters, io.iters,
+                                                                                         cnt["exchanges"], cnt["allreduces"]))
+
+
+@pytest.mark.parametrize("mode", [orc.PINZERO, orc.DOUBLEDIAG])
+def test_rank0_only_singular_modes_across_ranks(mode):
+    """PinZero / DoubleDiag modify ONE row, on rank 0 only (modifySingularMatrix, pair_isph.cpp:493-520, called once on
+    rank 0 by functor_incomp_navier_stokes_poisson.h:150-170): the other ranks must assemble plain rows, and the solve
+    (no projection) must land on the oracle's solution of the same modified system."""
+    dim, pgrid, n = 3, (2, 2, 1), 8
+    G = RankGroup(4)
+    try:
+        res = G.run(_solve_bjacobi, dim, pgrid, n, mode)
+    finally:
+        G.close()
+    O = GlobalOracle(dim, pgrid, n, mode, [r["rtag"] for r in res])
+    O.check_rows(res)
+    Oplain = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [r["rtag"] for r in res])
+    changed = np.unique((abs(O.Ap - Oplain.Ap)).tocoo().row)
+    assert len(changed) == 1 and changed[0] < O.off[1], "exactly one row, owned by rank 0, differs from the plain operator"
+    ilu = orc.ILU(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, O.block_ptr(BLOCK))
+    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=False, prec="ilu", ilu=ilu)
+    infos = {r["info"][:2] for r in res}
+    assert len(infos) == 1
+    conv, iters = infos.pop()
+    assert conv == 1 and io.converged == 1 and abs(iters - io.iters) <= 1, (iters, io.iters)
+    x = np.concatenate([r["x"] for r in res])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+def test_a_rank_without_particles_takes_part_in_the_collectives():
+    """LAMMPS allows empty subdomains: the rank owns no rows, has no peers, and still enters every all-reduce of the
+    Krylov loop (a rank that skipped them would hang the others).  3 ranks: 2x1x1 bricks + one empty rank."""
+    dim, pgrid, n = 3, (2, 1, 1), 8
+    G = RankGroup(3)
+    try:
+        res = G.run(_solve_bjacobi, dim, pgrid, n, orc.NULLSPACE)
+    finally:
+        G.close()
+    assert res[2]["nl"] == 0 and len(res[2]["plan"].peers) == 0
+    O = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [r["rtag"] for r in res])
+    O.check_rows(res)
+    ilu = orc.ILU(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, O.block_ptr(BLOCK))
+    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="ilu", ilu=ilu)
+    infos = {r["info"][:2] for r in res}
+    assert len(infos) == 1
+    conv, iters = infos.pop()
+    assert conv == 1 and abs(iters - io.iters) <= 1
+    x = np.concatenate([r["x"] for r in res])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+# ------------------------------------------------------------------ "Overlap Level" 1 across ranks
+def _solve_overlap(rank, G, dim, pgrid, n, fill, combine):
+    st = _rank_setup(rank, G, dim, pgrid, n, orc.NULLSPACE)
+    ctx, A, plan = st["ctx"], st["A"], st["plan"]
+    try:
+        rp, ci, v = st["csr"]
+        rpe, cie, ve = dist.extend_rows(plan, rp, ci, v, G.td(rank))
+        Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
+        M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=fill, combine=combine)
+        Aext.close()
+        r = np.cos(0.37 * st["rtag"].astype(np.float64))
+        z = M.apply(r)
+        x, bb = np.zeros(st["nl"]), st["b"].copy()
+        info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
+        M.close()
+        return dict(st, x=x, r=r, z=z, info=(info.converged, info.iters), ctx=None, A=None, parts=None)
+    finally:
+        A.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("pgrid,fill,combine", [((2, 1, 1), 0, "add"), ((2, 2, 1), 1, "add"), ((2, 2, 1), 0, "zero"),
+                                                ((2, 2, 2), 0, "add")])
+def test_overlap_one_schwarz_across_different_owners(pgrid, fill, combine):
+    """Ifpack_AdditiveSchwarz<ILU(k)> with "Overlap Level" 1 on several ranks (the reference's default decomposition,
+    precond_ifpack.h:35-43,60-74): gather of the ghost part of r from its OWNERS, ILU(k) of the extended subdomain,
+    and with combine Add the return of the ghost part of z to a different rank, which adds it.  One application and
+    the whole solve against oracle/isph_schwarz_oracle.c on the global matrix with one subdomain per rank."""
+    dim, n = 3, 8
+    world = int(np.prod(pgrid))
+    G = RankGroup(world)
+    try:
+        res = G.run(_solve_overlap, dim, pgrid, n, fill, combine)
+    finally:
+        G.close()
+    O = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [r["rtag"] for r in res])
+    O.check_rows(res)
+    S = orc.Schwarz(O.Ap.indptr, O.Ap.indices, O.Ap.data, fill, own_ptr=O.off.astype(np.int32), overlap=1, combine=combine)
+    r = np.concatenate([q["r"] for q in res])
+    z = np.concatenate([q["z"] for q in res])
+    zo = S.apply(r)
+    assert np.max(np.abs(z - zo)) <= 1e-10 * np.abs(zo).max()
+    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="schwarz", schwarz=S)
+    infos = {q["info"] for q in res}
+    assert len(infos) == 1
+    conv, iters = infos.pop()
+    assert conv == 1 and io.converged == 1 and abs(iters - io.iters) <= 1, (iters, io.iters)
+    x = np.concatenate([q["x"] for q in res])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    print("overlap-1 ILU(%d) %s on %d ranks: iterations %d (oracle %d)" % (fill, combine, world, iters, io.iters))
+
+
+# ------------------------------------------------------------------ the C++ mirror on several MPI ranks sharing the GPU
+def _export_rank(rank, G, dim, pgrid, n):
+    st = _rank_setup(rank, G, dim, pgrid, n, orc.NULLSPACE)
+    st["A"].close()
+    st["ctx"].close()
+    return dict(st, ctx=None, A=None, parts=None)
+
+
+@pytest.mark.parametrize("pgrid,mode", [((2, 1, 1), "bjacobi"), ((2, 2, 1), "bjacobi"), ((2, 2, 1), "overlap"), ((2, 1, 1), "ml")])
+def test_cpp_mirror_on_mpi_ranks_sharing_one_gpu(tmp_path, pgrid, mode):
+    """SolverLin(MPI_Comm&) on 2 and 4 real MPI ranks (`mpiexec -n N`, fresh processes), all on device 0: the mirror
+    sees that the ranks share a device and takes the MPI transport (host/mpi_transport.h: MPI_Isend/Irecv/Waitall for
+    the Import, MPI_Allreduce for the dots) in place of RCCL; matrix ingress with the lists of each rank's
+    Epetra_Import (host/halo_lists.h), PrecondWrapper_Ifpack on 256-row blocks / with "Overlap Level" 1 (row import
+    over MPI_Sendrecv), PrecondWrapper_ML with the null vector.  Against the single-rank oracle of the whole system."""
+    import subprocess
+    from isph_amd import build
+    exes = build.build_cpp_mpi()
+    if exes is None:
+        pytest.skip("no MPI installation (mpi.h / mpiexec / libmpi) on this machine")
+    dim, n = 3, 8
+    world = int(np.prod(pgrid))
+    G = RankGroup(world)
+    try:
+        res = G.run(_export_rank, dim, pgrid, n)
+    finally:
+        G.close()
+    O = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [r["rtag"] for r in res])
+    O.check_rows(res)
+    for rank, r in enumerate(res):
+        plan = r["plan"]
+        rp, ci, v = r["csr"]
+        nsend, nrecv = np.diff(plan.send_ptr), np.diff(plan.recv_ptr)
+        to = [k for k in range(plan.npeers) if nsend[k] > 0]
+        frm = [k for k in range(plan.npeers) if nrecv[k] > 0]
+        with open(tmp_path / ("rank%d.bin" % rank), "wb") as f:
+            np.array([r["nl"], plan.ncol, len(v)], np.int32).tofile(f)
+            rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f); v.tofile(f); r["b"].tofile(f)
+            np.array([len(to)], np.int32).tofile(f)
+            plan.peers[to].astype(np.int32).tofile(f); nsend[to].astype(np.int32).tofile(f)
+            np.array([int(plan.send_ptr[-1])], np.int32).tofile(f)
+            plan.send_idx.astype(np.int32).tofile(f)
+            np.array([len(frm)], np.int32).tofile(f)
+            plan.peers[frm].astype(np.int32).tofile(f); nrecv[frm].astype(np.int32).tofile(f)
+    run = subprocess.run([build.MPIEXEC, "-n", str(world), exes[0], str(tmp_path), "-", "1", "ranks", mode],
+                         capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "ranks share a device" in run.stdout
+    xs, its = [], set()
+    for rank in range(world):
+        with open(tmp_path / ("x%d.bin" % rank), "rb") as f:
+            conv, iters = np.fromfile(f, np.int32, 2)
+            xs.append(np.fromfile(f, np.float64))
+        assert conv == 1
+        its.add(int(iters))
+    assert len(its) == 1
+    iters = its.pop()
+    x = np.concatenate(xs)
+    if mode == "bjacobi":
+        ilu = orc.ILU(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, O.block_ptr(BLOCK))
+        xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="ilu", ilu=ilu)
+    elif mode == "overlap":
+        S = orc.Schwarz(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, own_ptr=O.off.astype(np.int32), overlap=1, combine="add")
+        xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="schwarz", schwarz=S)
+    else:
+        xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="jacobi")
+    assert io.converged == 1
+    if mode != "ml":
+        assert abs(iters - io.iters) <= 1, (iters, io.iters)
+    else:
+        assert iters < io.iters, (iters, io.iters)      # the rank-local hierarchies must beat point Jacobi on the same system
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    print("mpiexec -n %d %s: iterations %d (oracle %s %d)" % (world, mode, iters, "jacobi" if mode == "ml" else mode, io.iters))
