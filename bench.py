@@ -243,6 +243,8 @@ def main():
     spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=(8, 8, 8),
                             mode=mode, kernel=args.kernel, cut_over_h=2.0 if args.kernel == "wendland" else 3.0)
     parts = workload.make_tgv(spec)
+    if world > 1:
+        parts = dist.prune_ghosts(parts)                  # ghost columns = the referenced tags only (Epetra's column map)
     if args.force_rccl and world == 1:
         plan = dist.make_self_halo_plan(parts)
     else:

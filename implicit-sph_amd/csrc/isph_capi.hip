@@ -63,7 +63,7 @@ inline int overlap_apply(isph_ctx *ctx, const isph_overlap *O, const double *r, 
   ISPH_CHECK(overlap_exchange(ctx, H, O->sbuf.p, O->rext.p + n, false));
   ISPH_CHECK(schwarz_apply(ctx, O->inner, O->rext.p, O->zext.p));
   ISPH_CHECK_HIP(hipMemcpyAsync(z, O->zext.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
-  if (O->combine == 0 && H.nrecv > 0) {  // Add: the neighbours' corrections of my rows come home
+  if (O->combine == 0 && H.npeers > 0) {  // Add: the neighbours' corrections of my rows come home (a rank may only send or only receive)
     ISPH_CHECK(overlap_exchange(ctx, H, O->zext.p + n, O->rbuf.p, true));
     for (int p = 0; p < H.npeers; ++p) {  // one launch per peer: a row can be in several peers' lists, never twice in one
       const int s0 = H.send_ptr[(size_t)p], cnt = H.send_ptr[(size_t)p + 1] - s0;

@@ -54,6 +54,29 @@ def make_self_halo_plan(parts):
     return plan
 
 
+def prune_ghosts(parts):
+    """Drops the ghost particles no owned particle lists as a neighbour.  The generator (like LAMMPS) creates every
+    ghost inside the box of the rank's brick grown by the cut-off; the corners of that box lie outside every
+    neighbourhood sphere.  Epetra's column map only holds columns that were inserted (FunctorOuterGraph inserts tag[j]
+    for r^2 < cutsq, functor_graph.h:62-80; FillComplete builds the map and the Import from them), so those ghosts are
+    neither matrix columns nor halo traffic in the reference -- and not rows of Ifpack's overlapped subdomain
+    (precond_ifpack.h:43).  Returns a new dict with nall reduced and neigh_idx renumbered; owned particles are kept."""
+    nl, na = int(parts["nlocal"]), int(parts["nall"])
+    keep = np.zeros(na, dtype=bool)
+    keep[:nl] = True
+    keep[parts["neigh_idx"]] = True
+    if keep.all():
+        return parts
+    newidx = np.cumsum(keep, dtype=np.int64) - 1
+    out = dict(parts)
+    for k, v in parts.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == na and k not in ("neigh_idx", "neigh_ptr"):
+            out[k] = np.ascontiguousarray(v[keep])
+    out["neigh_idx"] = newidx[parts["neigh_idx"]].astype(parts["neigh_idx"].dtype)
+    out["nall"] = int(keep.sum())
+    return out
+
+
 def make_plan(parts, td=None):
     """parts: output of workload.make_tgv for this rank.  td: torch.distributed
     (initialised) or None for a single rank."""
