@@ -454,10 +454,13 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   int *sdg = slen + B;           // [B]
   int *spos = sdg + B;           // [B] position of a row in the current direction's solve order
   long long *srp = reinterpret_cast<long long *>(spos + B + (B & 1));  // [B]
-  __shared__ int s_nlev, s_nsched, s_nch;
+  __shared__ int s_nlev, s_nsched, s_nch, s_err;
   // rows without a diagonal or with duplicate / unsorted columns (flagged by k_ilu_extract) would send the level
-  // walk through uninitialised levels: leave the block alone, the host reports the error
-  if (*err & (1 | 32)) return;
+  // walk through uninitialised levels: leave the block alone, the host reports the error.  The word is read ONCE per
+  // workgroup (kernels of the next ingress batch may be raising bits of it meanwhile): the exit is uniform
+  if (threadIdx.x == 0) s_err = *err;
+  __syncthreads();
+  if (s_err & (1 | 32)) return;
   const int b = blockIdx.x + b0, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
   const int t = threadIdx.x;
   const bool active = t < m;
@@ -702,10 +705,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
   int *levs = lcnt + B + 1;                               // [B] L-level of every row
   unsigned short *order = reinterpret_cast<unsigned short *>(levs + B);  // [B] rows sorted by (level,row)
   unsigned short *pos = order + B;                        // [WAVES][B] slot+1 of a column in the current row
-  __shared__ int s_nlev;
+  __shared__ int s_nlev, s_err;
   // a ranged launch (host CSR ingress, ingress.hpp) queues this kernel before the host has seen the schedule's error
-  // word: a failed extraction or an overflowed stream leaves the blocks alone and the host redoes the set-up
-  if (err != nullptr && (*err & (1 | 16 | 32))) return;
+  // word: a failed extraction or an overflowed stream leaves the blocks alone and the host redoes the set-up.  One
+  // read per workgroup, then a uniform exit (the next batch's kernels may be raising bits concurrently)
+  if (threadIdx.x == 0) s_err = err != nullptr ? *err : 0;
+  __syncthreads();
+  if (s_err & (1 | 16 | 32)) return;
   const int bid = blockIdx.x + b0;
   const int blo = bid * B, bhi = min(blo + B, n), m = bhi - blo;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -159,7 +159,7 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
                             isph_mat **Aout, const IngressHooks *hooks = nullptr, bool *was_unsorted = nullptr) {
   ISPH_REQUIRE(!is_device_pointer(rowptr) && !is_device_pointer(colidx) && !is_device_pointer(val),
                "device pointer passed with on_device = 0");
-  ISPH_REQUIRE(rowptr[0] >= 0 && rowptr[nrow] >= rowptr[0], "rowptr not monotone");
+  ISPH_REQUIRE(rowptr[0] == 0 && rowptr[nrow] >= 0, "rowptr must start at 0 (Epetra's ExtractCrsDataPointers does) and be monotone");
   {  // the staging threads walk the rows: the row pointers are checked before they start (0.3 ms at 10^6 rows)
     int bad = 0;
     for (int i = 0; i < nrow; ++i) bad |= rowptr[i + 1] < rowptr[i];
@@ -485,6 +485,9 @@ inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int
     ISPH_CHECK(ilu_begin(ctx, S, block_size, false, 0, &F));
     return ilu_begin_fill0(ctx, F, S);
   };
+  // The hook kernels run BEFORE the host has reported an out-of-range column (bad_col is checked when the ingress ends):
+  // none of them indexes memory by a column -- k_sell_compress_cols takes differences, the ILU extract / schedule /
+  // factor kernels compare a column against the block's row range and only use it as an index inside that range.
   hooks.slices = [&](isph_mat *A, int s0, int s1) -> int {
     const Sell &S = A->S;
     const int ready = s1 == S.nslices ? F->nblocks : s1 / spb;
@@ -527,6 +530,10 @@ inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int
     rc = ilu_create(ctx, A, block_size, &F, false, 0);
   }
   if (rc != ISPH_SUCCESS) {
+    // a failure may have skipped the hook call that joins the side streams (it only runs while rc is good): batches
+    // queued on them still read F and A -- drain them before the objects go back to the pool
+    for (int k = 0; k < HostStager::kAux; ++k) (void)hipStreamSynchronize(H->aux[k]);
+    (void)hipStreamSynchronize(ctx->stream);
     if (F) ilu_destroy(F);
     if (A) isph_mat_destroy(A);
     return rc;

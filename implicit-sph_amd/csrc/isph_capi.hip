@@ -76,6 +76,34 @@ inline int overlap_apply(isph_ctx *ctx, const isph_overlap *O, const double *r, 
   return ISPH_SUCCESS;
 }
 
+// The persistent triangular sweeps of the Schwarz path (schwarz.hpp k_gilu_solve_run) give up after a spin limit, store
+// zeros and raise a word that the application copies to S->h_tmo.  Called with the stream DRAINED at the end of every
+// solve / host-side application: a raised word fails the call -- on every rank together (one small max-reduction per
+// solve; a rank that returned alone would leave the others waiting in their next collective) -- and is cleared, so one
+// spurious time-out (a shared device, a debugger) does not poison the object.  A silently zeroed M^-1 r is never
+// reported as a converged solve.
+int prec_health(isph_ctx *ctx, const isph_prec *M) {
+  if (!M || (M->type != 4 && M->type != 5)) return ISPH_SUCCESS;
+  const isph_schwarz *S = M->type == 4 ? M->schwarz : (M->ovl ? M->ovl->inner : nullptr);
+  double bad = 0.0;
+  if (S && S->syncfree && S->h_tmo && *S->h_tmo != 0) {
+    bad = 1.0;
+    *S->h_tmo = 0;
+    ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p + 3, 0, sizeof(int), ctx->stream));
+  }
+  if (comm_active(ctx) && ctx->nranks > 1) {
+    ISPH_CHECK(ensure_scalars(ctx));
+    double *d = ctx->dscal.p + SC_MISC + 30;
+    ISPH_CHECK_HIP(hipMemcpyAsync(d, &bad, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ISPH_CHECK(comm_allreduce(ctx, d, 1, /*max*/ 1, ctx->stream));
+    ISPH_CHECK_HIP(hipMemcpyAsync(&bad, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (bad != 0.0)
+    return fail("Schwarz ILU sweep: a row waited for a dependency beyond the spin limit; the result of this call is not valid", __FILE__, __LINE__);
+  return ISPH_SUCCESS;
+}
+
 int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z) {
   ISPH_REQUIRE(M != nullptr, "preconditioner is NULL");
   const int n = M->n;
@@ -733,7 +761,7 @@ int isph_prec_apply(isph_ctx *ctx, const isph_prec *M, const double *r, double *
   ISPH_CHECK_HIP(hipMemcpyAsync(z, ctx->bdev.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   ISPH_CHECK_HIP(hipGetLastError());
-  return ISPH_SUCCESS;
+  return prec_health(ctx, M);
 }
 
 int isph_prec_export_ilu(isph_ctx *ctx, const isph_prec *M, int *rowptr, int *colidx, double *val) {
@@ -1086,7 +1114,7 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
     info->spmv_calls = (int)(ctx->ev_used / 2);
   }
   ISPH_CHECK_HIP(hipGetLastError());
-  return ISPH_SUCCESS;
+  return prec_health(ctx, M);  // the stream is drained (ev1): every application of this solve has reported
 }
 
 // SolverLin_Belos::solveBlockProblem (ref: solver_lin_belos.h:53-128): GMRES / CG over the product vector
@@ -1155,7 +1183,7 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
     else printf(">> isph::Status - Failed to converge! ||r|| / ||b|| = %6.4e\n", ci.rel_res_explicit);
   }
   ISPH_CHECK_HIP(hipGetLastError());
-  return ISPH_SUCCESS;
+  return prec_health(ctx, M);
 }
 
 /* ---- assembly --------------------------------------------------------- */

@@ -62,7 +62,7 @@ struct isph_schwarz {
   int n4l = 0, n4u = 0;
   bool long_rows = false;   // many rows have more entries on one side of the diagonal than a chunk of the sweeps holds
   bool syncfree = true;
-  int *h_tmo = nullptr;   // pinned: the time-out word of the previous application (checked at the next one)
+  int *h_tmo = nullptr;   // pinned: the time-out word of the last application (read by prec_health with the stream drained)
   // persistent workgroups (1024 threads) of the L / U sweep, and how many earlier runs may still be open when a run
   // starts polling (k_gilu_solve_run): both follow the width of the levels
   int sweep_blocks[2] = {0, 0}, runs_near[2] = {2, 2};
@@ -1376,7 +1376,8 @@ inline int schwarz_apply(isph_ctx *ctx, const isph_schwarz *S, const double *r, 
   hipLaunchKernelGGL(k_gilu_gather, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nloc, S->rows.p, r, S->w.p);
   if (S->syncfree) {
     // two persistent launches: L sweep (rhs = gathered r, results -> ybits), U sweep (rhs = y, results -> zbits)
-    ISPH_REQUIRE(*S->h_tmo == 0, "Schwarz ILU sweep: a row waited for a dependency beyond the spin limit (previous application)");
+    // a time-out of an earlier application is reported by prec_health() at the end of the solve, behind a stream
+    // synchronisation and on all ranks together; here the host has not waited for the copy of the word
     hipLaunchKernelGGL(k_gilu_fill_bits, dim3(stream_grid(nloc)), dim3(kBlock), 0, ctx->stream, nloc, S->ybits.p, S->zbits.p);
     ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p, 0, 2 * sizeof(int), ctx->stream));
     ISPH_CHECK_HIP(hipMemsetAsync(S->ctr.p + 4, 0, 2 * sizeof(int), ctx->stream));

@@ -47,15 +47,26 @@ class SolverLin {
   // scale the pieces differently and the result would not be in the null space.  The vector is kept between solves
   // (8 MB of first-touch page faults per solve at 10^6 rows otherwise).
   int createNullVector() {
+    _n_sumsq = globalMaskSumSq();
+    return fillNullVector();
+  }
+  // the collective half of createNullVector: sum of squares of the mask over ALL ranks (8 bytes all-reduced)
+  double globalMaskSumSq() {
+    const int len = _map->NumMyElements();
+    const int m = _null_mask ? std::min(_null_mask->Length(), len) : len;
+    const int *mask = _null_mask ? _null_mask->Values() : NULL;
+    double sum = 0.0;
+    for (int i = 0; i < m; ++i) { const double a = mask ? (double)mask[i] : 1.0; sum += a * a; }
+    return _comm.SumAll(sum);
+  }
+  // the local half: n = mask / sqrt(_n_sumsq); no communication (getNullVector() may be called by one rank alone)
+  int fillNullVector() {
     if (!_n || _n->MyLength() != _map->NumMyElements()) _n = Teuchos::rcp(new Epetra_Vector(*_map, true));
     double *v = _n->Values();
     const int len = _n->MyLength();
     const int m = _null_mask ? std::min(_null_mask->Length(), len) : len;
     const int *mask = _null_mask ? _null_mask->Values() : NULL;
-    double sum = 0.0;
-    for (int i = 0; i < m; ++i) { const double a = mask ? (double)mask[i] : 1.0; sum += a * a; }
-    sum = _comm.SumAll(sum);
-    const double inv = 1.0 / std::sqrt(sum);
+    const double inv = 1.0 / std::sqrt(_n_sumsq);
     for (int i = 0; i < m; ++i) v[i] = (mask ? (double)mask[i] : 1.0) * inv;
     for (int i = m; i < len; ++i) v[i] = 0.0;
     _n_stale = false;
@@ -103,7 +114,7 @@ class SolverLin {
   Teuchos::RCP<Epetra_MultiVector> getLoadMultiVector() { return _b; }
   Teuchos::RCP<Epetra_MultiVector> getSolutionMultiVector() { return _x; }
   Teuchos::RCP<Epetra_Vector> getNullVector() {
-    if (_n_stale) { createNullVector(); }
+    if (_n_stale) { fillNullVector(); }  // local: the norm was all-reduced inside solveProblem, where every rank is
     return _n;
   }
 
@@ -124,6 +135,7 @@ class SolverLin {
   Teuchos::RCP<Epetra_IntSerialDenseVector> _null_mask;
   bool _is_singular;
   bool _n_stale = false;  // a singular solve ran without needing the host copy of the null vector
+  double _n_sumsq = 1.0;  // global sum of squares of the mask, all-reduced by the last singular solve
 };
 
 }  // namespace LAMMPS_NS

@@ -91,9 +91,11 @@ class SolverLin_HIP : public SolverLin {
     const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();  // the ingress returns synchronised
 
     int rc = ISPH_SUCCESS;
+    // the norm of the null vector is all-reduced here, where every rank is (8 bytes); getNullVector() then fills the
+    // host copy locally when somebody asks -- a getter that only rank 0 calls must not be a collective
+    if (_is_singular && !(prec != NULL && prec->usesNullVector())) { _n_sumsq = globalMaskSumSq(); _n_stale = true; }
     if (prec != NULL) {
       if (_is_singular && prec->usesNullVector()) { createNullVector(); prec->setNullVector(_n->Values()); }  // :149-151
-      else if (_is_singular) _n_stale = true;  // getNullVector() forms it when somebody asks
       prec->create();
       if (fused > 0) prec->adoptDevice(Mfused);
       else rc = prec->createOnDevice(_ctx, A);  // Ifpack Initialize+Compute happen here (:153)
