@@ -34,6 +34,73 @@ def spmv_algorithmic_bytes(nrow, nnz):
     return 12 * nnz + 16 * nrow + 4 * (nrow + 1)
 
 
+def solve_roofline(mat, pinfo, inf, prm, nprof, prof, sec_per_solve, prec):
+    """SURVEY.md 8(d) summed over the whole solve, and the kernels of the hot loop one by one.
+
+    Algorithmic bytes (N rows, nnz matrix entries, nnz_f factor entries; FGMRES(m) with the null vector deflated inside
+    the Gram-Schmidt step, so a step at column j of a cycle projects against nk = j + 2 vectors):
+      SpMV                     12 nnz + 16 N + 4 (N + 1)
+      preconditioner apply     12 nnz_f + 16 N                    (block ILU(0): two triangular sweeps over the factor)
+      Gram-Schmidt step        dots (nk + 1) 8N, update (nk + 1) 8N + 8N, norm 8N, flexible store of z_j 8N; dots and
+                               update once more when the DGKS test asks for the second pass (counted from the run)
+      per cycle                r = b - A x: SpMV + 3 vectors; x += Z y: (j + 2) 8N
+      set-up                   read A (12 nnz + 4 (N + 1)), write the factor (12 nnz_f + 8 N)
+    The kernels: algorithmic bytes of what one launch has to touch / its average duration from HIP events on the
+    library's stream (profile passes outside the timed region; isph_ctx_profile_read)."""
+    N, nnz = mat["nrow"], mat["nnz"]
+    nnzf = int(pinfo.get("factor_nnz", 0)) if prec.startswith("bjacobi-ilu") else 0
+    v8 = 8.0 * N
+    spmv_b = 12.0 * nnz + 16.0 * N + 4.0 * (N + 1)
+    prec_b = (12.0 * nnzf + 16.0 * N) if nnzf else (24.0 * N if prec == "jacobi" else 0.0)
+    m = prm.num_blocks
+    iters, cycles = int(inf.iters), int(inf.restarts) + 1
+    gs = dot_b = axd_b = axn_b = 0.0
+    per_cycle = 0.0
+    left = iters
+    for _ in range(cycles):
+        jn = min(m, left)
+        left -= jn
+        for j in range(jn):
+            nk = j + 2
+            gs += (nk + 1) * v8 + (nk + 1) * v8 + v8 + v8 + v8
+            dot_b += (nk + 1) * v8                     # k_multi_dot: V[0..nk) and w
+            axd_b += (nk + 2) * v8                     # k_multi_axpy_dot: V, w in, w out (the second projection rides along)
+            axn_b += 2 * v8                            # k_multi_axpy_norm without the second pass: w in, v_next out
+        per_cycle += spmv_b + 3 * v8 + (jn + 2) * v8
+    reorth = int(getattr(inf, "reorth", 0))
+    avg_nk = (iters / cycles) / 2.0 + 2.0
+    gs += reorth * 2 * (avg_nk + 1) * v8
+    axn_b += reorth * (avg_nk + 1) * v8
+    setup_b = (12.0 * nnz + 4.0 * (N + 1)) + (12.0 * nnzf + 8.0 * N) if nnzf else 0.0
+    total = iters * (spmv_b + prec_b) + gs + per_cycle + setup_b
+    kern = {}
+
+    def add(name, cls, bytes_per_solve):
+        ms, calls = prof.get(cls, (0.0, 0))
+        if calls:
+            per_launch = bytes_per_solve * nprof / calls
+            kern[name] = {"avg_us": ms / calls * 1e3, "launches_per_solve": calls / nprof, "algorithmic_bytes": per_launch,
+                          "GBps": per_launch / (ms / calls * 1e-3) / 1e9, "frac": per_launch / (ms / calls * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    add("k_sell_spmv16", "spmv", (iters + cycles + 1) * spmv_b)           # + r = b - A x per cycle + the explicit residual
+    if nnzf:
+        add("k_ilu_solve_stream", "prec_apply", iters * prec_b)
+        add("k_ilu_extract", "ilu_extract", 12.0 * nnz + 12.0 * nnzf)
+        add("k_ilu_schedule", "ilu_schedule", 4.0 * nnzf + 10.0 * nnzf)     # pattern in, stream words + destinations out
+        add("k_ilu_factor", "ilu_factor", 12.0 * nnzf + 10.0 * nnzf + 8.0 * N)
+    add("k_multi_dot", "multi_dot", dot_b)
+    add("k_multi_axpy_dot", "multi_axpy_dot", axd_b)
+    add("k_multi_axpy_norm", "multi_axpy_norm", axn_b)
+    in_kernels_ms = sum(ms for ms, _ in prof.values()) / nprof
+    return {"solve": {"algorithmic_bytes": total, "ms": sec_per_solve * 1e3, "GBps": total / sec_per_solve / 1e9,
+                      "frac": total / sec_per_solve / 1e9 / HBM_PEAK_GBS, "iterations": iters, "cycles": cycles,
+                      "second_gram_schmidt_passes": reorth,
+                      "bytes": {"spmv": iters * spmv_b, "prec_apply": iters * prec_b, "gram_schmidt": gs, "per_cycle": per_cycle,
+                                "setup": setup_b},
+                      "ms_inside_bracketed_kernels": in_kernels_ms},
+            "kernels": kern}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,6 +119,7 @@ def parse():
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the SolverLin drop-in leg (host CSR through the C++ mirror)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the jacobi / sa-amg lines measured beside the headline")
     ap.add_argument("--cpu-ifpack-1rank", action="store_true",
                     help="also time the reference's 1-rank configuration (whole-matrix ILU(1), one thread): minutes")
     ap.add_argument("--spmv-reps", type=int, default=50)
@@ -294,36 +362,37 @@ def main():
     pinfo = {}
     nullvec = torch.full((nlocal,), 1.0 / np.sqrt(float(nlocal * world)), dtype=torch.float64, device=dev)
 
-    def step():
+    def step(prec=None):
+        prec = prec or args.prec
         bwork.copy_(b)
         x.zero_()
-        if args.prec == "sa-amg":
+        if prec == "sa-amg":
             M = hip.PrecondAMG(ctx, A, nullvec=nullvec, params=hip.AmgParams(block=args.block, theta=args.amg_theta))
             if not pinfo:
                 pinfo.update(levels=[M.level_info(l) for l in range(M.levels)])
-        elif args.prec.startswith("schwarz-ilu"):
-            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(args.prec[-1]), overlap=args.overlap, combine=args.combine,
+        elif prec.startswith("schwarz-ilu"):
+            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(prec[-1]), overlap=args.overlap, combine=args.combine,
                                    block_size=args.block)
             if not pinfo:
                 pinfo.update(M.schwarz_info())
-        elif args.prec in ("ilu0", "ilu1"):
-            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(args.prec[-1]), overlap=0, block_size=0)
+        elif prec in ("ilu0", "ilu1"):
+            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(prec[-1]), overlap=0, block_size=0)
             if not pinfo:
                 pinfo.update(M.schwarz_info())
-        elif args.prec.startswith("overlap-ilu"):
+        elif prec.startswith("overlap-ilu"):
             # Ifpack on N ranks with "Overlap Level" 1: this rank's rows + the rows of its ghost columns, one ILU(k) block
             assert plan.npeers, "overlap-ilu<k> needs ghost columns (--gpus > 1 or --force-rccl)"
             rpl, cil, vall = A.export_csr()
             rpe, cie, ve = dist.extend_rows(plan, rpl, cil, vall, td)
             Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
-            M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=int(args.prec[-1]), combine=args.combine)
+            M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=int(prec[-1]), combine=args.combine)
             Aext.close()
             if not pinfo:
                 pinfo.update(extended_rows=len(rpe) - 1, extended_nnz=int(rpe[-1]))
         else:
-            M = hip.Precond(ctx, A, args.prec, args.block)
-        if not pinfo and args.prec.startswith("bjacobi-ilu"):
-            pinfo.update(M.info())
+            M = hip.Precond(ctx, A, prec, args.block)
+        if not pinfo and prec == args.prec and prec.startswith("bjacobi-ilu"):
+            pinfo.update(M.info(), factor_nnz_exact=int(M.info()["factor_nnz"]))
         inf = hip.solve(ctx, A, bwork, x, prec=M, singular=True, params=prm)
         M.close()
         return inf
@@ -345,11 +414,13 @@ def main():
     # separate, untimed passes so that the event records do not sit inside the timed steps
     ctx.set_profile(True)
     spmv_ms, spmv_calls = 0.0, 0
-    for _ in range(2):
+    nprof = 2
+    for _ in range(nprof):
         infp = step()
         spmv_ms += infp.spmv_ms
         spmv_calls += infp.spmv_calls
     barrier()
+    prof = ctx.profile_read()          # {class: (ms, launches)} over the nprof untimed passes (set-up + solve)
     if td is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -405,6 +476,22 @@ def main():
                          "traffic_source": (tsrc + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)") if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches": spmv_calls},
         }
+        out["roofline"].update(solve_roofline(info_m, pinfo, inf, prm, nprof, prof, elapsed / args.steps, args.prec))
+        if world == 1 and not args.no_alt and args.prec == "bjacobi-ilu0":
+            # the two other preconditioners of the C ABI on the SAME resident system, measured in this run (same step(): the
+            # preconditioner is rebuilt every solve): point Jacobi and SA-AMG (PrecondWrapper_ML's stand-in)
+            alt = {}
+            for name in ("jacobi", "sa-amg"):
+                for _ in range(2):
+                    ia = step(name)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    ia = step(name)
+                torch.cuda.synchronize()
+                alt[name] = {"ms_per_solve": (time.perf_counter() - t0) / 3 * 1e3, "iterations": ia.iters, "converged": ia.converged,
+                             "rel_res": ia.rel_res_implicit}
+            out["alt"] = alt
         if world == 1 and not args.no_dropin and not args.force_rccl and args.prec == "bjacobi-ilu0" and args.block == 512:
             # the unchanged SolverLin drop-in (host CSR in, host x out) beside the device-resident figure above
             d = dropin_leg(A, b)

@@ -16,6 +16,7 @@ struct isph_ctx {
   double *hsend = nullptr, *hrecv = nullptr;
   size_t hsend_cap = 0, hrecv_cap = 0;
   bool profile = false;
+  int stat_reorth = 0;  // Gram-Schmidt steps of the current solve whose second (DGKS) pass was applied
   // reduction scratch + small scalar mailboxes
   isph::DevBuf<double> partial;   // per-block partials
   isph::DevBuf<double> dscal;     // device scalars (dot results, Hessenberg column, ...)
@@ -25,7 +26,8 @@ struct isph_ctx {
   isph::DevBuf<double> V, Z, wv, tv, rv, pv, nvec, xext, sendbuf, bdev, xdev;
   isph::DevBuf<int> imask;
   // profiling events
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> ev;     // pairs (begin, end) of profile mode
+  std::vector<int> ev_class;      // class of every pair (isph::ProfClass)
   size_t ev_used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_fetch = nullptr;  // marks the scalar mailbox copy of a Krylov iteration (host waits on it only)
@@ -37,6 +39,35 @@ struct isph_ctx {
   isph::DevBuf<double> xghost;
   isph::HostStager *stager = nullptr;  // created by the first host-side isph_mat_create_csr
 };
+
+namespace isph {
+// profile mode (isph_ctx_set_profile): HIP events on the library's stream around the launches of one class of kernels;
+// isph_ctx_profile_read sums them per class.  Recorded on ctx->stream only (side-stream launches are not bracketed).
+enum ProfClass { PROF_SPMV = 0, PROF_PREC_APPLY, PROF_MULTI_DOT, PROF_MULTI_AXPY_DOT, PROF_MULTI_AXPY_NORM, PROF_ILU_EXTRACT,
+                 PROF_ILU_SCHEDULE, PROF_ILU_FACTOR, PROF_NCLASS };
+struct ProfScope {
+  isph_ctx *c;
+  size_t slot = (size_t)-1;
+  ProfScope(isph_ctx *ctx, int cls, hipStream_t st = nullptr) : c(ctx) {
+    if (!c || !c->profile || (st && st != c->stream)) return;
+    if (c->ev_used + 2 > c->ev.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->ev.push_back(a); c->ev.push_back(b);
+      c->ev_class.push_back(cls);
+    }
+    slot = c->ev_used;
+    c->ev_class[slot / 2] = cls;
+    c->ev_used += 2;
+    (void)hipEventRecord(c->ev[slot], c->stream);
+  }
+  ~ProfScope() { end(); }
+  void end() {
+    if (slot != (size_t)-1) (void)hipEventRecord(c->ev[slot + 1], c->stream);
+    slot = (size_t)-1;
+  }
+};
+}  // namespace isph
 
 struct isph_halo {
   int npeers = 0;

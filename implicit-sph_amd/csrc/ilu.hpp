@@ -1130,6 +1130,7 @@ inline int ilu_begin_fill0(isph_ctx *ctx, isph_ilu *F, const Sell &S, bool size_
 // st: the stream of a ranged launch (ingress.hpp runs consecutive ranges on alternating streams); default ctx->stream
 inline void ilu_launch_extract(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, hipStream_t st = nullptr) {
   const size_t lds_e = (size_t)(F->B / 64) * 64 * ((kExtChunk + 1) * 8 + (kExtChunk + 1) * 4);
+  ProfScope prof(ctx, PROF_ILU_EXTRACT, st);
   hipLaunchKernelGGL(k_ilu_extract, dim3(nb), dim3(F->B), lds_e, st ? st : ctx->stream, S.nrow, F->B, (const int *)S.rowlen.p,
                      (const long long *)S.slice_off.p, (const int *)S.col.p, (const double *)S.val.p, F->frp.p, F->fcol.p,
                      F->fval.p, F->flen.p, F->fdiag.p, F->err.p, b0, F->compact ? (const long long *)F->boff.p : (const long long *)nullptr);
@@ -1139,6 +1140,7 @@ inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b
                                 bool count_only = false) {
   const size_t Bz = (size_t)F->B;
   const size_t lds_s = sizeof(int) * (14 * Bz + 10) + sizeof(long long) * Bz;
+  ProfScope prof(ctx, PROF_ILU_SCHEDULE, st);
   hipLaunchKernelGGL(k_ilu_schedule, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->stream_off(), F->frp.p, F->fcol.p,
                      F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p, F->blkinfo.p, F->llev.p, F->capf,
                      F->slack, F->err.p, sgs ? (const double *)F->fval.p : (const double *)nullptr,
@@ -1156,6 +1158,7 @@ inline int ilu_launch_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, 
   const void *fk = wide ? reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, true>)
                         : reinterpret_cast<const void *>(k_ilu_factor<kIluWaves, false>);
   ISPH_CHECK_HIP(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+  ProfScope prof(ctx, PROF_ILU_FACTOR, st_in);
   if (wide)
     hipLaunchKernelGGL((k_ilu_factor<kIluWaves, true>), dim3(nb), dim3(kIluWaves * 64), lds_f, st, S.nrow, F->B, W,
                        F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->stream_off(),

@@ -107,6 +107,7 @@ int prec_health(isph_ctx *ctx, const isph_prec *M) {
 int prec_apply_dev(isph_ctx *ctx, const isph_prec *M, const double *r, double *z) {
   ISPH_REQUIRE(M != nullptr, "preconditioner is NULL");
   const int n = M->n;
+  ProfScope prof(ctx, PROF_PREC_APPLY);
   if (M->type == 0) {
     // identity: callers pass distinct buffers
     if (r != z) ISPH_CHECK_HIP(hipMemcpyAsync(z, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -283,6 +284,21 @@ int isph_ctx_sync(isph_ctx *ctx) {
 int isph_ctx_set_profile(isph_ctx *ctx, int on) {
   ISPH_REQUIRE(ctx, "ctx is NULL");
   ctx->profile = on != 0;
+  ctx->ev_used = 0;  // switching the mode starts a new collection
+  return ISPH_SUCCESS;
+}
+
+int isph_ctx_profile_read(isph_ctx *ctx, double ms[8], int calls[8]) {
+  ISPH_REQUIRE(ctx && ms && calls, "NULL argument");
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 8; ++k) { ms[k] = 0.0; calls[k] = 0; }
+  for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+    float t = 0.f;
+    ISPH_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev[k], ctx->ev[k + 1]));
+    const int c = ctx->ev_class[k / 2];
+    if (c >= 0 && c < 8) { ms[c] += t; calls[c] += 1; }
+  }
+  ctx->ev_used = 0;
   return ISPH_SUCCESS;
 }
 
@@ -991,7 +1007,11 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
   memset(info, 0, sizeof(*info));
   ISPH_CHECK(ensure_scalars(ctx));
   hipStream_t st = ctx->stream;
-  ctx->ev_used = 0;
+  // profile mode: events accumulate over set-up and solve until isph_ctx_profile_read collects them; this solve's own
+  // SpMV figures (info->spmv_ms) are summed from ev_start on
+  if (ctx->ev_used > (1u << 16)) ctx->ev_used = 0;
+  const size_t ev_start = ctx->ev_used;
+  ctx->stat_reorth = 0;
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, st));
 
   double *db = b, *dx = x;
@@ -1103,15 +1123,19 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
   info->converged = conv; info->iters = iters; info->restarts = restarts;
   info->rel_res_implicit = worst_imp; info->rel_res_explicit = worst_exp;
   info->solve_ms = ms;
+  info->reorth = ctx->stat_reorth;
   if (ctx->profile) {
     double tot_ms = 0.0;
-    for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+    int calls = 0;
+    for (size_t k = ev_start; k + 1 < ctx->ev_used; k += 2) {
+      if (ctx->ev_class[k / 2] != PROF_SPMV) continue;
       float t = 0.f;
       ISPH_CHECK_HIP(hipEventElapsedTime(&t, ctx->ev[k], ctx->ev[k + 1]));
       tot_ms += t;
+      ++calls;
     }
     info->spmv_ms = tot_ms;
-    info->spmv_calls = (int)(ctx->ev_used / 2);
+    info->spmv_calls = calls;
   }
   ISPH_CHECK_HIP(hipGetLastError());
   return prec_health(ctx, M);  // the stream is drained (ev1): every application of this solve has reported
@@ -1138,7 +1162,7 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
   memset(info, 0, sizeof(*info));
   ISPH_CHECK(ensure_scalars(ctx));
   hipStream_t st = ctx->stream;
-  ctx->ev_used = 0;
+  if (ctx->ev_used > (1u << 16)) ctx->ev_used = 0;
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev0, st));
   // product vectors are contiguous [dim][n] on the device
   const size_t nt = (size_t)dim * (size_t)n;

@@ -76,26 +76,6 @@ inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x) {
   return ISPH_SUCCESS;
 }
 
-inline int profile_begin(isph_ctx *ctx, size_t *slot) {
-  *slot = (size_t)-1;
-  if (!ctx->profile) return ISPH_SUCCESS;
-  if (ctx->ev_used + 2 > ctx->ev.size()) {
-    for (int k = 0; k < 2; ++k) {
-      hipEvent_t e;
-      ISPH_CHECK_HIP(hipEventCreate(&e));
-      ctx->ev.push_back(e);
-    }
-  }
-  *slot = ctx->ev_used;
-  ctx->ev_used += 2;
-  ISPH_CHECK_HIP(hipEventRecord(ctx->ev[*slot], ctx->stream));
-  return ISPH_SUCCESS;
-}
-inline int profile_end(isph_ctx *ctx, size_t slot) {
-  if (slot != (size_t)-1) ISPH_CHECK_HIP(hipEventRecord(ctx->ev[slot + 1], ctx->stream));
-  return ISPH_SUCCESS;
-}
-
 // builds the 16-bit column copy of a matrix on first use (see k_sell_compress_cols); returns whether it is usable
 inline bool sell_cols16(isph_ctx *ctx, const Sell &S) {
   if (S.c16_state != 0) return S.c16_state > 0;
@@ -138,8 +118,7 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
   const bool halo = !(S.ncol == S.nrow || A->local);
   // AMG transfer / coarse operators are small or have very long rows: the window tables do not pay there
   const bool c16 = !A->local && sell_cols16(ctx, S);
-  size_t slot = (size_t)-1;
-  if (!A->local) ISPH_CHECK(profile_begin(ctx, &slot));  // the SpMV statistics are those of the caller's operator only
+  ProfScope prof(A->local ? nullptr : ctx, PROF_SPMV);  // the SpMV statistics are those of the caller's operator only
   if (nvec)
     ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
   if (!halo) {
@@ -155,7 +134,7 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
     if (nvec) spmv_launch<true, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);
     else spmv_launch<false, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);
   }
-  ISPH_CHECK(profile_end(ctx, slot));
+  prof.end();
   if (nvec) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, 1, S.nslices, ctx->partial.p,
                        ctx->dscal.p + SC_MISC);
@@ -174,8 +153,7 @@ inline int spmm_dev(isph_ctx *ctx, const isph_mat *A, int K, const double *const
     for (int k = 0; k < K; ++k) ISPH_CHECK(spmv_dev(ctx, A, xs[k], ys[k], nullptr));
     return ISPH_SUCCESS;
   }
-  size_t slot = (size_t)-1;
-  ISPH_CHECK(profile_begin(ctx, &slot));
+  ProfScope prof(ctx, PROF_SPMV);
   SpmmVecs V;
   for (int k = 0; k < 4; ++k) { V.x[k] = xs[k < K ? k : 0]; V.y[k] = ys[k < K ? k : 0]; }
   int nbp = 0;
@@ -191,7 +169,7 @@ inline int spmm_dev(isph_ctx *ctx, const isph_mat *A, int K, const double *const
       hipLaunchKernelGGL((k_sell_spmm16<4>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp, S.slice_off.p,
                          S.col16.p, S.wtab.p, S.val.p, V);
   }
-  ISPH_CHECK(profile_end(ctx, slot));
+  prof.end();
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
@@ -305,33 +283,43 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
   double *dh1 = ctx->dscal.p + mb + SC_DOT, *dh2 = ctx->dscal.p + mb + SC_Y, *dor = ctx->dscal.p + mb + SC_ORTHO;  // mb: mailbox of this right-hand side
   constexpr int dot_grid = 512;
   if (g > dot_grid) g = dot_grid;
-  hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+  {
+    ProfScope prof(ctx, PROF_MULTI_DOT);
+    hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+  }
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh1,
                      (const double *)nullptr);
   ISPH_CHECK(allreduce_inplace(ctx, dh1, nk + 1));
-  if (nk <= 16)
-    hipLaunchKernelGGL((k_multi_axpy_dot<16>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
-  else if (nk <= 32)
-    hipLaunchKernelGGL((k_multi_axpy_dot<32>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
-  else
-    hipLaunchKernelGGL((k_multi_axpy_dot<64>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+  {
+    ProfScope prof(ctx, PROF_MULTI_AXPY_DOT);
+    if (nk <= 16)
+      hipLaunchKernelGGL((k_multi_axpy_dot<16>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+    else if (nk <= 32)
+      hipLaunchKernelGGL((k_multi_axpy_dot<32>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+    else
+      hipLaunchKernelGGL((k_multi_axpy_dot<64>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+  }
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh2,
                      (const double *)nullptr);
   ISPH_CHECK(allreduce_inplace(ctx, dh2, nk + 1));
   const int g2 = stream_grid(n);
   // the DGKS decision (taken by the kernel itself from the reduced scalars), the second update and the normalised next
   // basis vector (vnext = w / |w|) leave in one sweep
-  hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, (const double *)dh2, w, ctx->partial.p,
-                     (const double *)(dh1 + nk), deflate ? (const double *)dh1 : (const double *)nullptr, ortho == 1 ? 1 : 0,
-                     dor, vnext);
+  {
+    ProfScope prof(ctx, PROF_MULTI_AXPY_NORM);
+    hipLaunchKernelGGL(k_multi_axpy_norm, dim3(g2), dim3(kBlock), 0, st, n, nk, V, ld, (const double *)dh2, w, ctx->partial.p,
+                       (const double *)(dh1 + nk), deflate ? (const double *)dh1 : (const double *)nullptr, ortho == 1 ? 1 : 0,
+                       dor, vnext);
+  }
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
 
 // host side of ortho_enqueue, once the mailbox is in hscal
-inline void ortho_collect(const isph_ctx *ctx, int nk, double *h, double *wnorm, int mb = 0) {
+inline void ortho_collect(isph_ctx *ctx, int nk, double *h, double *wnorm, int mb = 0) {
   const double *hs = ctx->hscal + mb;
   const bool second = hs[SC_ORTHO] != 0.0;
+  if (second) ++ctx->stat_reorth;
   for (int k = 0; k < nk; ++k) h[k] = hs[SC_DOT + k] + (second ? hs[SC_Y + k] : 0.0);
   *wnorm = std::sqrt(hs[SC_ORTHO + 1]);
 }

@@ -250,6 +250,8 @@ typedef struct {
   double solve_ms;          /* HIP-event time of the whole call on the stream */
   double spmv_ms;           /* sum of SpMV kernel times (profile mode only) */
   int spmv_calls;
+  int reorth;               /* Gram-Schmidt steps whose second pass was applied (DGKS: when the norm dropped below
+                               1/sqrt(2) of its value before the first pass; ICGS: every step) */
 } isph_solve_info;
 
 /* Replaces SolverLin_Belos::solveProblem (ref: solver_lin_belos.h:130-222):
@@ -264,8 +266,16 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M,
                double *b /*[h|d]*/, double *x /*[h|d]*/, int nvec, int lda,
                int is_singular, const int *null_mask /*[h] or NULL*/,
                const isph_solver_params *prm, isph_solve_info *info, int on_device);
-/* profile mode: record HIP events around every SpMV launch inside isph_solve */
+/* profile mode: HIP events on the library's stream around the launches of the hot kernels, by class:
+ *   [0] SpMV (k_sell_spmv16 incl. the halo exchange when there is one)   [1] preconditioner application (block ILU:
+ *   k_ilu_solve_stream)   [2] k_multi_dot   [3] k_multi_axpy_dot   [4] k_multi_axpy_norm (the three sweeps of one
+ *   DGKS step)   [5] k_ilu_extract   [6] k_ilu_schedule   [7] k_ilu_factor (set-up of the block ILU).
+ * isph_ctx_set_profile switches the mode and starts a new collection; isph_ctx_profile_read synchronises the stream,
+ * returns milliseconds and launch counts per class since the collection started, and starts the next one.
+ * isph_solve_info::spmv_ms / spmv_calls are class 0 of that one solve.  No reference counterpart (the reference's
+ * Teuchos timers stop at "ISPH: solvePoisson", utils.cpp:37-38). */
 int isph_ctx_set_profile(isph_ctx *ctx, int on);
+int isph_ctx_profile_read(isph_ctx *ctx, double ms[8], int calls[8]);
 
 /* ---- assembly --------------------------------------------------------- */
 
