@@ -116,6 +116,11 @@ def parse():
     ap.add_argument("--combine", default="add", choices=["add", "zero"], help='schwarz-ilu<k>: "schwarz: combine mode"')
     ap.add_argument("--amg-theta", type=float, default=0.0, help='"aggregation: threshold" of the sa-amg variant (ML default 0)')
     ap.add_argument("--block", type=int, default=512)
+    ap.add_argument("--brick", default="10,10,5",
+                    help="particle numbering: bricks of this many lattice cells, brick by brick (x fastest inside).  When the "
+                         "bricks tile the lattice and hold <= 1024 particles they are the block-Jacobi subdomains "
+                         "(isph_prec_create_blocks), like the bricks of LAMMPS' decomposition are Ifpack's; otherwise "
+                         "subdomains are --block consecutive rows")
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the SolverLin drop-in leg (host CSR through the C++ mirror)")
@@ -143,7 +148,7 @@ def pgrid_for(n):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
 
 
-def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False):
+def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False, bptr=None):
     """Oracle (CPU restatement of Belos FGMRES + Ifpack ILU(k) / ML SA-AMG) timed on the host cores, every variant run
     to convergence (preconditioner set-up + the whole solve, nothing extrapolated):
       same_blocks     the GPU's own subdomains (`block` rows each), all threads
@@ -174,7 +179,9 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False)
                     converged=int(info.converged), cores=orc.num_threads(), config=label, measured=True)
 
     lof = int(prec[-1]) if prec.startswith("bjacobi-ilu") else 0
-    same = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
+    same = bptr if bptr is not None else np.arange(0, n + block, block).clip(0, n).astype(np.int32)
+    if bptr is not None:
+        block = int(np.diff(bptr).max())
     percore = np.linspace(0, n, threads + 1).astype(np.int32)
     variants = {"same_blocks": run(lof, same, "%s, %d-row blocks (the GPU's subdomains)" % (prec, block))}
     if prec.startswith("bjacobi-ilu"):
@@ -308,7 +315,8 @@ def main():
     pg = pgrid_for(world)
     n = args.ncell
     mode = {"advect": workload.ADVECT, "jitter": workload.JITTER, "lattice": workload.LATTICE}[args.mode]
-    spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=(8, 8, 8),
+    brick = tuple(int(t) for t in args.brick.split(","))
+    spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=brick,
                             mode=mode, kernel=args.kernel, cut_over_h=2.0 if args.kernel == "wendland" else 3.0)
     parts = workload.make_tgv(spec)
     if world > 1:
@@ -318,6 +326,11 @@ def main():
     else:
         plan = dist.make_plan(parts, td)                  # column map + halo lists (trivial on 1 rank)
     nlocal = parts["nlocal"]
+    # block-Jacobi subdomains = the bricks of the numbering when they tile this rank's lattice
+    brows = brick[0] * brick[1] * brick[2]
+    bptr = None
+    if all(n % k == 0 for k in brick) and brows <= 1024 and args.prec == "bjacobi-ilu0":
+        bptr = np.arange(0, nlocal + brows, brows).clip(0, nlocal).astype(np.int32)
 
     # device-resident particle arrays
     dparts = dict(parts)
@@ -389,6 +402,8 @@ def main():
             Aext.close()
             if not pinfo:
                 pinfo.update(extended_rows=len(rpe) - 1, extended_nnz=int(rpe[-1]))
+        elif prec == "bjacobi-ilu0" and bptr is not None:
+            M = hip.Precond(ctx, A, prec, block_ptr=bptr)
         else:
             M = hip.Precond(ctx, A, prec, args.block)
         if not pinfo and prec == args.prec and prec.startswith("bjacobi-ilu"):
@@ -463,7 +478,10 @@ def main():
                                    "state after one Lagrangian step (mode=%s)" % (n, "" if world == 1 else "/[2] brick", args.mode),
                        "rows_per_gpu": nlocal, "global_rows": nlocal * world, "nnz_per_gpu": info_m["nnz"],
                        "nnz_per_row": info_m["nnz"] / max(nlocal, 1), "sell_padding": info_m["stored"] / max(info_m["nnz"], 1),
-                       "solver": "FGMRES(50) DGKS tol 1e-8, right prec", "precond": args.prec, "block_rows": args.block,
+                       "solver": "FGMRES(50) DGKS tol 1e-8, right prec", "precond": args.prec,
+                       "block_rows": brows if bptr is not None else args.block,
+                       "subdomains": ("%dx%dx%d-cell bricks of the particle numbering (%d rows each)" % (brick + (brows,))) if bptr is not None
+                                     else "%d consecutive rows" % args.block,
                        "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms, "assemble_first_call_ms": assemble_first_ms,
@@ -492,7 +510,7 @@ def main():
                 alt[name] = {"ms_per_solve": (time.perf_counter() - t0) / 3 * 1e3, "iterations": ia.iters, "converged": ia.converged,
                              "rel_res": ia.rel_res_implicit}
             out["alt"] = alt
-        if world == 1 and not args.no_dropin and not args.force_rccl and args.prec == "bjacobi-ilu0" and args.block == 512:
+        if world == 1 and not args.no_dropin and not args.force_rccl and args.prec == "bjacobi-ilu0" and args.block == 512 and bptr is None:
             # the unchanged SolverLin drop-in (host CSR in, host x out) beside the device-resident figure above
             d = dropin_leg(A, b)
             if isinstance(d, tuple):
@@ -506,7 +524,7 @@ def main():
                 out["dropin"] = d
         if world == 1 and not args.no_cpu_baseline and args.prec in ("none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg"):
             rp, ci, val = A.export_csr()
-            cb = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, args.prec, args.amg_theta, args.cpu_ifpack_1rank)
+            cb = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, args.prec, args.amg_theta, args.cpu_ifpack_1rank, bptr)
             out["cpu_baseline"] = cb
             out["config"]["speedup_vs_cpu"] = out["value"] / cb["value"]            # against the FASTEST CPU variant
             for k in ("same_blocks", "block_per_core", "block_per_core_ilu1", "single_thread", "ifpack_1rank"):

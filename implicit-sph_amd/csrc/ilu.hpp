@@ -54,9 +54,19 @@ struct isph_ilu {
   long long total = 0;      // entries reserved for the factor (ILU(0): A's sliced-ELL size; ILU(k): sum of the blocks)
   int fill = 0;             // level of fill
   int capf = 0, slack = 0;  // stream capacity rule in force (see kCapFactorSafe)
+  // caller-defined subdomains (isph_prec_create_blocks): block b = rows bptr[b] .. bptr[b+1], at most B of them (B is then
+  // the CAPACITY of a block: LDS sizes, threads per workgroup, stride of the per-block tables); NULL = B rows each
+  isph::DevBuf<int> bptr;
+  const int *blocks() const { return bptr.p; }
 };
 
 namespace isph {
+
+// rows of block b: consecutive ranges of B rows, or the caller's table
+__device__ __forceinline__ void ilu_block_rows(const int *__restrict__ bptr, int b, int B, int n, int &blo, int &bhi) {
+  if (bptr) { blo = bptr[b]; bhi = bptr[b + 1]; }
+  else { blo = b * B; bhi = min(blo + B, n); }
+}
 
 // ---------------------------------------------------------------------------
 // extract: one workgroup (B threads) per block.  Thread t counts the in-block
@@ -71,7 +81,8 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
                                                       long long *__restrict__ frp, int *__restrict__ fcol,
                                                       double *__restrict__ fval, int *__restrict__ flen,
                                                       int *__restrict__ fdiag, int *__restrict__ err, int b0,
-                                                      const long long *__restrict__ base_off) {
+                                                      const long long *__restrict__ base_off,
+                                                      const int *__restrict__ bptr) {
   __shared__ int wsum[16];
   extern __shared__ double ext_lds[];
   const int nwv = blockDim.x >> 6;
@@ -80,7 +91,9 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
   int (*stage_col)[64][kExtChunk] = reinterpret_cast<int (*)[64][kExtChunk]>(ext_lds + (size_t)nwv * 64 * (kExtChunk + 1));
   int (*stage_cnt)[64] = reinterpret_cast<int (*)[64]>(reinterpret_cast<int *>(ext_lds + (size_t)nwv * 64 * (kExtChunk + 1)) +
                                                        (size_t)nwv * 64 * kExtChunk);
-  const int b = blockIdx.x + b0, blo = b * B, bhi = min(blo + B, n);  // b0: first block of a ranged launch
+  const int b = blockIdx.x + b0;  // b0: first block of a ranged launch
+  int blo, bhi;
+  ilu_block_rows(bptr, b, B, n, blo, bhi);
   const int t = threadIdx.x, i = blo + t;
   const bool active = i < bhi;
   // the block's rows go back to back into its region: A's own sliced-ELL region of these rows, or -- compact mode, large
@@ -166,9 +179,12 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
 // the 4 M x 749 operator of BASELINE configs[4] keeps ~15 % of its entries inside its 512-row block)
 __global__ __launch_bounds__(1024) void k_ilu_count_inblock(int n, int B, const int *__restrict__ rowlen,
                                                             const long long *__restrict__ slice_off,
-                                                            const int *__restrict__ scol, int *__restrict__ blktot) {
+                                                            const int *__restrict__ scol, int *__restrict__ blktot,
+                                                            const int *__restrict__ bptr) {
   __shared__ int s_sum;
-  const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n);
+  const int b = blockIdx.x;
+  int blo, bhi;
+  ilu_block_rows(bptr, b, B, n, blo, bhi);
   const int i = blo + threadIdx.x;
   if (threadIdx.x == 0) s_sum = 0;
   __syncthreads();
@@ -437,7 +453,8 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
                                                        int *__restrict__ blkinfo, int *__restrict__ llev,
                                                        int capf, int slack, int *__restrict__ err,
                                                        const double *__restrict__ sgs_fval,
-                                                       const double *__restrict__ sgs_dinv, int b0, int count_only) {
+                                                       const double *__restrict__ sgs_dinv, int b0, int count_only,
+                                                       const int *__restrict__ bptr) {
   extern __shared__ int lds_i[];
   int *levL = lds_i;             // [B] level of every row in the L solve
   int *levU = levL + B;          // [B] ... in the U solve
@@ -461,7 +478,10 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   if (threadIdx.x == 0) s_err = *err;
   __syncthreads();
   if (s_err & (1 | 32)) return;
-  const int b = blockIdx.x + b0, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
+  const int b = blockIdx.x + b0;
+  int blo, bhi;
+  ilu_block_rows(bptr, b, B, n, blo, bhi);
+  const int m = bhi - blo;
   const int t = threadIdx.x;
   const bool active = t < m;
   const int i = blo + t;
@@ -692,7 +712,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
                                                            const int *__restrict__ fdiag, const int *__restrict__ fdst,
                                                            const int *__restrict__ llev, double *__restrict__ sv,
                                                            double *__restrict__ dinv, const long long *__restrict__ boff,
-                                                           int capf, int slack, int b0, const int *__restrict__ err) {
+                                                           int capf, int slack, int b0, const int *__restrict__ err,
+                                                           const int *__restrict__ bptr) {
   extern __shared__ double lds_f[];
   double *diag = lds_f;                                   // [B] 1/d_k of the finished rows
   double *wval = diag + B;                                // [WAVES][W]
@@ -713,7 +734,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
   __syncthreads();
   if (s_err & (1 | 16 | 32)) return;
   const int bid = blockIdx.x + b0;
-  const int blo = bid * B, bhi = min(blo + B, n), m = bhi - blo;
+  int blo, bhi;
+  ilu_block_rows(bptr, bid, B, n, blo, bhi);
+  const int m = bhi - blo;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *svb = sv + ilu_base_chunk(boff, bid, capf, slack) * 64;  // this block's part of the solve stream
   if (threadIdx.x == 0) s_nlev = 0;
@@ -862,7 +885,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
                                                                  const int *__restrict__ blkinfo,
                                                                  const double *__restrict__ dinv,
                                                                  const double *__restrict__ r, double *__restrict__ z,
-                                                                 int capf, int slack) {
+                                                                 int capf, int slack, const int *__restrict__ bptr) {
   extern __shared__ double lds_y[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);  // wave-uniform: keep what follows scalar
@@ -872,7 +895,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
   double *yl = lds_y + (size_t)wave * 3 * B;
   double *yu = yl + B;
   double *dv = yu + B;
-  const int blo = b * B, m = min(blo + B, n) - blo;
+  int blo, bhi;
+  ilu_block_rows(bptr, b, B, n, blo, bhi);
+  const int m = bhi - blo;
   const unsigned short *__restrict__ posl = sperm + (size_t)b * 2 * B;  // row -> position in the L / U order
   const unsigned short *__restrict__ posu = posl + B;
   for (int t = lane; t < m; t += 64) {
@@ -967,6 +992,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
 inline void ilu_destroy(isph_ilu *F) {
   if (!F) return;
   F->frp.release(); F->fcol.release(); F->flen.release(); F->fdiag.release(); F->err.release(); F->fval.release();
+  F->bptr.release();
   F->boff.release(); F->sboff.release(); F->flev.release();
   F->sv.release(); F->sc.release(); F->si.release(); F->sperm.release(); F->fdst.release(); F->blkinfo.release(); F->dinv.release(); F->llev.release();
   delete F;
@@ -1081,13 +1107,25 @@ inline int ilu_size_stream(isph_ilu *F) {
 }
 
 // needs S.nrow, S.stored, S.wmax, S.nslices and S.slice_off on the device (stream-ordered); not S.col / S.val
-inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int fill, isph_ilu **out, bool defer_factor_arrays = false) {
+// nblocks_tab > 0: the caller's subdomains, host_bptr[0 .. nblocks_tab] (ascending from 0 to nrow, every block at most
+// block_size rows -- block_size is then the capacity); ILU(0) / Gauss-Seidel only
+inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int fill, isph_ilu **out, bool defer_factor_arrays = false,
+                     int nblocks_tab = 0, const int *host_bptr = nullptr) {
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
                "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && !(sgs && fill), "level of fill must be in [0,8]");
+  ISPH_REQUIRE(nblocks_tab == 0 || (host_bptr && fill == 0), "a table of subdomains needs level of fill 0");
   isph_ilu *F = new isph_ilu();
   F->n = S.nrow; F->B = block_size; F->wmax = S.wmax; F->fill = fill;
-  F->nblocks = (S.nrow + block_size - 1) / block_size;
+  F->nblocks = nblocks_tab > 0 ? nblocks_tab : (S.nrow + block_size - 1) / block_size;
+  if (nblocks_tab > 0) {
+    if (F->bptr.reserve((size_t)nblocks_tab + 1) != ISPH_SUCCESS ||
+        hipMemcpyAsync(F->bptr.p, host_bptr, sizeof(int) * ((size_t)nblocks_tab + 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {  // the caller's array need not outlive the call
+      ilu_destroy(F);
+      return fail("copy of the subdomain table failed", __FILE__, __LINE__);
+    }
+  }
   F->total = S.stored;
   const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
   F->capf = kCapFactor; F->slack = 2 * block_size;
@@ -1133,7 +1171,8 @@ inline void ilu_launch_extract(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0
   ProfScope prof(ctx, PROF_ILU_EXTRACT, st);
   hipLaunchKernelGGL(k_ilu_extract, dim3(nb), dim3(F->B), lds_e, st ? st : ctx->stream, S.nrow, F->B, (const int *)S.rowlen.p,
                      (const long long *)S.slice_off.p, (const int *)S.col.p, (const double *)S.val.p, F->frp.p, F->fcol.p,
-                     F->fval.p, F->flen.p, F->fdiag.p, F->err.p, b0, F->compact ? (const long long *)F->boff.p : (const long long *)nullptr);
+                     F->fval.p, F->flen.p, F->fdiag.p, F->err.p, b0, F->compact ? (const long long *)F->boff.p : (const long long *)nullptr,
+                     F->blocks());
 }
 
 inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, int nb, bool sgs, hipStream_t st = nullptr,
@@ -1144,7 +1183,7 @@ inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b
   hipLaunchKernelGGL(k_ilu_schedule, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->stream_off(), F->frp.p, F->fcol.p,
                      F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p, F->blkinfo.p, F->llev.p, F->capf,
                      F->slack, F->err.p, sgs ? (const double *)F->fval.p : (const double *)nullptr,
-                     sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0, count_only ? 1 : 0);
+                     sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0, count_only ? 1 : 0, F->blocks());
 }
 
 // err_dev != nullptr: the kernel itself skips its blocks when the set-up so far has raised an error (ranged launches)
@@ -1162,11 +1201,11 @@ inline int ilu_launch_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b0, 
   if (wide)
     hipLaunchKernelGGL((k_ilu_factor<kIluWaves, true>), dim3(nb), dim3(kIluWaves * 64), lds_f, st, S.nrow, F->B, W,
                        F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->stream_off(),
-                       F->capf, F->slack, b0, err_dev);
+                       F->capf, F->slack, b0, err_dev, F->blocks());
   else
     hipLaunchKernelGGL((k_ilu_factor<kIluWaves, false>), dim3(nb), dim3(kIluWaves * 64), lds_f, st, S.nrow, F->B, W,
                        F->frp.p, F->fcol.p, F->fval.p, F->flen.p, F->fdiag.p, F->fdst.p, F->llev.p, F->sv.p, F->dinv.p, F->stream_off(),
-                       F->capf, F->slack, b0, err_dev);
+                       F->capf, F->slack, b0, err_dev, F->blocks());
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
 }
@@ -1214,26 +1253,53 @@ inline int ilu_schedule_and_factor(isph_ctx *ctx, isph_ilu *F, const Sell &S, bo
   return rc;
 }
 
-inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false, int fill = 0) {
+inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu **out, bool sgs = false, int fill = 0,
+                      int nblocks_tab = 0, const int *host_bptr = nullptr) {
   const Sell &S = A->S;
   isph_ilu *F = nullptr;
+  const bool var = nblocks_tab > 0;
+  if (var) {
+    ISPH_REQUIRE(host_bptr && host_bptr[0] == 0 && host_bptr[nblocks_tab] == S.nrow, "subdomain table must run from 0 to the number of rows");
+    for (int b = 0; b < nblocks_tab; ++b)
+      ISPH_REQUIRE(host_bptr[b + 1] > host_bptr[b] && host_bptr[b + 1] - host_bptr[b] <= block_size,
+                   "every subdomain needs between 1 and `capacity` rows");
+  }
   // large operators (see ilu_wants_exact_stream): the factor regions are sized from a count of the in-block entries
   // instead of A's sliced-ELL regions, and the stream from a counting pass of the schedule
   bool big = false;
   {
     isph_ilu probe;
-    probe.total = S.stored; probe.B = block_size; probe.nblocks = (S.nrow + block_size - 1) / block_size;
+    probe.total = S.stored; probe.B = block_size; probe.nblocks = var ? nblocks_tab : (S.nrow + block_size - 1) / block_size;
     big = fill == 0 && S.nrow > 0 && ilu_wants_exact_stream(&probe);
   }
-  ISPH_CHECK(ilu_begin(ctx, S, block_size, sgs, fill, &F, /*defer_factor_arrays=*/big));
+  ISPH_CHECK(ilu_begin(ctx, S, block_size, sgs, fill, &F, /*defer_factor_arrays=*/big, nblocks_tab, host_bptr));
   int rc = ISPH_SUCCESS;
-  if (big) {
+  if (var && !big && S.nrow > 0) {
+    // caller-defined subdomains: their rows are not whole 64-row slices of A, so a block's factor region cannot be A's
+    // own sliced-ELL region -- the regions are the in-block entry counts (64-aligned), formed on the device without a
+    // host round trip; the arrays keep the upper bound (all of A's entries) ilu_begin reserved
+    DevTmp<int> blktot;
+    rc = blktot.reserve((size_t)F->nblocks);
+    if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL(k_ilu_count_inblock, dim3(F->nblocks), dim3(block_size), 0, ctx->stream, S.nrow, block_size,
+                         (const int *)S.rowlen.p, (const long long *)S.slice_off.p, (const int *)S.col.p, blktot.p, F->blocks());
+      hipLaunchKernelGGL(k_iluk_block_offsets, dim3(1), dim3(1024), 0, ctx->stream, F->nblocks, (const int *)blktot.p, F->boff.p);
+      F->compact = true;
+      rc = F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1));
+    }
+    if (rc == ISPH_SUCCESS) rc = ilu_size_stream(F);
+    if (rc == ISPH_SUCCESS) {
+      ilu_launch_extract(ctx, F, S, 0, F->nblocks);
+      rc = ilu_schedule_and_factor(ctx, F, S, sgs);
+    }
+    blktot.release();
+  } else if (big) {
     DevTmp<int> blktot;
     rc = blktot.reserve((size_t)F->nblocks);
     long long total = 0;
     if (rc == ISPH_SUCCESS) {
       hipLaunchKernelGGL(k_ilu_count_inblock, dim3(F->nblocks), dim3(block_size), 0, ctx->stream, S.nrow, block_size,
-                         (const int *)S.rowlen.p, (const long long *)S.slice_off.p, (const int *)S.col.p, blktot.p);
+                         (const int *)S.rowlen.p, (const long long *)S.slice_off.p, (const int *)S.col.p, blktot.p, F->blocks());
       hipLaunchKernelGGL(k_iluk_block_offsets, dim3(1), dim3(1024), 0, ctx->stream, F->nblocks, (const int *)blktot.p, F->boff.p);
       if (hipMemcpyAsync(&total, F->boff.p + F->nblocks, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -1285,14 +1351,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream_multi(int n, in
                                                                        const unsigned short *__restrict__ sperm,
                                                                        const int *__restrict__ blkinfo,
                                                                        const double *__restrict__ dinv, IluVecs X,
-                                                                       int capf, int slack) {
+                                                                       int capf, int slack, const int *__restrict__ bptr) {
   extern __shared__ double lds_y[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);
   if (b >= nblocks) return;
   double *yb = lds_y + (size_t)wave * (NV + 1) * B;  // y[k] = yb + k * B
   double *dv = yb + (size_t)NV * B;
-  const int blo = b * B, m = min(blo + B, n) - blo;
+  int blo, bhi;
+  ilu_block_rows(bptr, b, B, n, blo, bhi);
+  const int m = bhi - blo;
   const unsigned short *__restrict__ posl = sperm + (size_t)b * 2 * B;
   const unsigned short *__restrict__ posu = posl + B;
   for (int t = lane; t < m; t += 64) {
@@ -1437,7 +1505,7 @@ inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
     hipLaunchKernelGGL((k_ilu_solve_stream_multi<WV, kPrefetch, NV>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, \
                        ctx->stream, F->n, F->B, F->nblocks, F->stream_off(), F->sv.p, F->sc.p, F->si.p, F->sperm.p,               \
-                       F->blkinfo.p, F->dinv.p, X, F->capf, F->slack);                                                      \
+                       F->blkinfo.p, F->dinv.p, X, F->capf, F->slack, F->blocks());                                         \
   } while (0)
   if (K == 2) ISPH_ILU_LAUNCH_MULTI(2);
   else if (K == 3) ISPH_ILU_LAUNCH_MULTI(3);
@@ -1460,7 +1528,7 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
     hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, \
                        F->n, F->B, F->nblocks, F->stream_off(), F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->blkinfo.p,          \
-                       F->dinv.p, r, z, F->capf, F->slack);                                                             \
+                       F->dinv.p, r, z, F->capf, F->slack, F->blocks());                                                \
   } while (0)
   if (pf == 12) ISPH_ILU_LAUNCH(12);
   else if (pf == 16) ISPH_ILU_LAUNCH(16);

@@ -727,6 +727,22 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
 
 /* ---- preconditioner --------------------------------------------------- */
 
+int isph_prec_create_blocks(isph_ctx *ctx, const isph_mat *A, int nblocks, const int *block_ptr, isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && A && Mout && nblocks > 0 && block_ptr, "NULL argument or no subdomains");
+  ISPH_REQUIRE(!is_device_pointer(block_ptr), "block_ptr must be a host array");
+  int cap = 64;
+  for (int b = 0; b < nblocks; ++b) cap = std::max(cap, block_ptr[b + 1] - block_ptr[b]);
+  cap = (cap + 63) / 64 * 64;
+  ISPH_REQUIRE(cap <= 1024, "a subdomain of the block stream holds at most 1024 rows (isph_prec_create_schwarz takes larger ones)");
+  isph_prec *M = new isph_prec();
+  M->n = A->S.nrow;
+  M->type = 2;
+  const int rc = ilu_create(ctx, A, cap, &M->ilu, /*sgs=*/false, /*fill=*/0, nblocks, block_ptr);
+  if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
+  *Mout = M;
+  return ISPH_SUCCESS;
+}
+
 int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int block_size, isph_prec **Mout) {
   ISPH_REQUIRE(ctx && A && type && Mout, "NULL argument");
   isph_prec *M = new isph_prec();

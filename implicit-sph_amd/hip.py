@@ -19,7 +19,7 @@ KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 EXPORTS = [
     "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_create_hostcomm", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_pool_info", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
-    "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_apply",
+    "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_ctx_profile_read", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
@@ -128,6 +128,7 @@ def lib():
         L.isph_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_spmv_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.isph_prec_create.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+        L.isph_prec_create_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.isph_prec_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_prec_export_ilu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_prec_destroy.argtypes = [C.c_void_p]
@@ -476,10 +477,17 @@ class Matrix:
 class Precond:
     """isph_prec == PrecondWrapper_Ifpack::create() result."""
 
-    def __init__(self, ctx, A, kind="bjacobi-ilu0", block_size=512):
+    def __init__(self, ctx, A, kind="bjacobi-ilu0", block_size=512, block_ptr=None):
+        """block_ptr: the caller's subdomains (isph_prec_create_blocks; kind must be "bjacobi-ilu0"): ascending row
+        offsets from 0 to nrow, at most 1024 rows per subdomain"""
         self.ctx, self.n = ctx, A.info()["nrow"]
         self.h = C.c_void_p()
-        _check(lib().isph_prec_create(ctx.h, A.h, kind.encode(), block_size, C.byref(self.h)))
+        if block_ptr is not None:
+            assert kind == "bjacobi-ilu0"
+            bp = np.ascontiguousarray(block_ptr, dtype=np.int32)
+            _check(lib().isph_prec_create_blocks(ctx.h, A.h, len(bp) - 1, _ptr(bp), C.byref(self.h)))
+        else:
+            _check(lib().isph_prec_create(ctx.h, A.h, kind.encode(), block_size, C.byref(self.h)))
 
     def apply(self, r, z=None):
         r = _f64(r)

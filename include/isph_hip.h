@@ -173,6 +173,14 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
  * Rebuilt every solve in the reference (solver_lin_belos.h:153,190). */
 int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int block_size,
                      isph_prec **M);
+/* "bjacobi-ilu0" on the CALLER'S subdomains: block b = rows block_ptr[b] .. block_ptr[b+1] (host array of nblocks + 1
+ * ascending offsets from 0 to nrow, at most 1024 rows each; the rows of a subdomain are consecutive in the matrix).  The
+ * reference's subdomains are the bricks of LAMMPS' spatial decomposition (one per MPI rank, ref: precond_ifpack.h:60-74
+ * with pair_isph.cpp:1258-1259); a caller that numbers its particles brick by brick hands the brick boundaries over
+ * here instead of accepting a cut every block_size rows -- a thin remainder brick at the edge of the box is then a
+ * subdomain of its own shape and not the two halves of its neighbours.  Same kernels and data layout as
+ * isph_prec_create("bjacobi-ilu0"). */
+int isph_prec_create_blocks(isph_ctx *ctx, const isph_mat *A, int nblocks, const int *block_ptr, isph_prec **M);
 /* Ifpack_AdditiveSchwarz<Ifpack_ILU> with the parameters PrecondWrapper_Ifpack sets (ref: precond_ifpack.h:30-45,
  * 60-74): "fact: level-of-fill" (default 1), "Overlap Level" (default 1), "schwarz: combine mode" (default "Add" = 0;
  * 1 = "Zero", restricted additive Schwarz).  block_size = 0: one subdomain = the whole local matrix, which is what
