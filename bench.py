@@ -121,6 +121,8 @@ def parse():
                          "bricks tile the lattice and hold <= 1024 particles they are the block-Jacobi subdomains "
                          "(isph_prec_create_blocks), like the bricks of LAMMPS' decomposition are Ifpack's; otherwise "
                          "subdomains are --block consecutive rows")
+    ap.add_argument("--colour", type=int, default=0,
+                    help="numbering inside a brick: 0 lexicographic, c > 1 multi-colour with period c (isph_workload.h)")
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the SolverLin drop-in leg (host CSR through the C++ mirror)")
@@ -316,7 +318,7 @@ def main():
     n = args.ncell
     mode = {"advect": workload.ADVECT, "jitter": workload.JITTER, "lattice": workload.LATTICE}[args.mode]
     brick = tuple(int(t) for t in args.brick.split(","))
-    spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=brick,
+    spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=brick, colour_period=args.colour,
                             mode=mode, kernel=args.kernel, cut_over_h=2.0 if args.kernel == "wendland" else 3.0)
     parts = workload.make_tgv(spec)
     if world > 1:

@@ -29,7 +29,23 @@ inline void split(int N, int P, int r, int &lo, int &hi) {
 
 // local index of owned cell c (coordinates relative to the rank's lo) in a
 // rank whose owned extent is n, ordered in bricks of bs (x fastest everywhere)
-inline int brick_index(const int n[3], const int bs[3], const int c[3]) {
+// rank of cell (i0,i1,i2) of a brick of bd cells in the multi-colour numbering of period cp (isph_workload.h):
+// cells before it = all cells of smaller colours + cells of its colour that precede it lexicographically
+inline long long colour_rank(const int bd[3], const int i[3], int cp) {
+  auto cnt = [&](int extent, int colour) { return colour < extent ? (extent - 1 - colour) / cp + 1 : 0; };  // cells with coordinate = colour mod cp
+  const int col[3] = {i[0] % cp, i[1] % cp, i[2] % cp};
+  long long before = 0;
+  for (int c2 = 0; c2 < cp; ++c2)
+    for (int c1 = 0; c1 < cp; ++c1)
+      for (int c0 = 0; c0 < cp; ++c0) {
+        const bool smaller = c2 < col[2] || (c2 == col[2] && (c1 < col[1] || (c1 == col[1] && c0 < col[0])));
+        if (smaller) before += (long long)cnt(bd[0], c0) * cnt(bd[1], c1) * cnt(bd[2], c2);
+      }
+  const long long n0 = cnt(bd[0], col[0]), n1 = cnt(bd[1], col[1]);
+  return before + ((long long)(i[2] / cp) * n1 + i[1] / cp) * n0 + i[0] / cp;
+}
+
+inline int brick_index(const int n[3], const int bs[3], const int c[3], int cp = 0) {
   int b[3], i[3], bd[3];
   for (int a = 0; a < 3; ++a) {
     const int s = bs[a] > 0 ? bs[a] : n[a];
@@ -42,7 +58,7 @@ inline int brick_index(const int n[3], const int bs[3], const int c[3]) {
   long long off = (long long)b[2] * s2 * n[0] * n[1];
   off += (long long)b[1] * s1 * n[0] * bd[2];
   off += (long long)b[0] * s0 * bd[1] * bd[2];
-  off += ((long long)i[2] * bd[1] + i[1]) * bd[0] + i[0];
+  off += cp > 1 ? colour_rank(bd, i, cp) : ((long long)i[2] * bd[1] + i[1]) * bd[0] + i[0];
   return (int)off;
 }
 
@@ -167,7 +183,7 @@ long long tgv_fill_t(const isph_tgv_spec *s, double *x, double *v, int *tag, int
         const long long ec = ((long long)ez * L.ext[1] + ey) * L.ext[0] + ex;
         int p, orank_p, oidx_p;
         if (own) {
-          p = brick_index(L.n, L.bs, c) * nb;
+          p = brick_index(L.n, L.bs, c, s->colour_period) * nb;
           orank_p = s->rank;
           oidx_p = p;
         } else {
@@ -185,7 +201,7 @@ long long tgv_fill_t(const isph_tgv_spec *s, double *x, double *v, int *tag, int
             oc[a] = gw[a] - olo[a];
           }
           orank_p = (orc[2] * L.P[1] + orc[1]) * L.P[0] + orc[0];
-          oidx_p = brick_index(on, L.bs, oc) * nb;
+          oidx_p = brick_index(on, L.bs, oc, s->colour_period) * nb;
         }
         pidx[(size_t)ec] = p;
         for (int b = 0; b < nb; ++b) {

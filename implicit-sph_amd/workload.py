@@ -17,7 +17,7 @@ class _Spec(C.Structure):
                 ("brick", C.c_int * 3), ("origin", C.c_double * 3), ("h_over_dx", C.c_double),
                 ("cut_over_h", C.c_double), ("skin", C.c_double), ("mode", C.c_int),
                 ("jitter_amp", C.c_double), ("seed", C.c_ulonglong), ("umax", C.c_double),
-                ("advect_dt", C.c_double), ("basis", C.c_int)]
+                ("advect_dt", C.c_double), ("basis", C.c_int), ("colour_period", C.c_int)]
 
 
 _lib = None
@@ -53,6 +53,7 @@ class TGVSpec:
     rho: float = 1.0
     nu: float = 0.1
     basis: int = 1          # 2 = bcc (second particle at the cell centre)
+    colour_period: int = 0  # > 1: multi-colour numbering inside a brick (isph_workload.h)
     extra: dict = field(default_factory=dict)
 
     @property
@@ -91,6 +92,7 @@ class TGVSpec:
         s.mode, s.jitter_amp, s.seed, s.umax = self.mode, self.jitter_amp, self.seed, self.umax
         s.advect_dt = self.advect_dt if self.advect_dt >= 0 else self.dt
         s.basis = self.basis
+        s.colour_period = self.colour_period
         return s
 
 

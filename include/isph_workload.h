@@ -39,6 +39,12 @@ typedef struct {
   int basis;             /* particles per cell: 0/1 simple cubic (`lattice sc`), 2 body-centred cubic
                             (`lattice bcc ${dx}`, sph-script/pore-scale-flow-3d.lmp): second site at the
                             cell centre; the cell's particles are numbered consecutively */
+  int colour_period;     /* numbering INSIDE a brick: 0/1 lexicographic (x fastest); c > 1: multi-colour -- the cells of
+                            a brick are numbered colour by colour, colour = (ix mod c, iy mod c, iz mod c) (x fastest), and
+                            lexicographically inside a colour.  With c = 3 cells of one colour are 3 spacings apart, i.e.
+                            beyond the Wendland cut of the undisturbed lattice: the rows of one colour of a block-Jacobi
+                            ILU(0) subdomain do not depend on each other and the triangular sweeps have ~c^3 levels
+                            instead of one per lattice diagonal */
 } isph_tgv_spec;
 
 /* Sizes needed to allocate the arrays of isph_tgv_fill. */
