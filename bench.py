@@ -207,7 +207,7 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False,
     return out
 
 
-def dropin_leg(A, b, repeat=5):
+def dropin_leg(A, b, repeat=5, sub_rows=0):
     """The path `north_star` names, unchanged: the matrix as a HOST Epetra CSR handed to SolverLin_Belos::solveProblem
     (pair_isph.cpp:924-926,988-1011 -> host/solver_lin_hip.h) with PrecondWrapper_Ifpack (fill 0, overlap 0, 512-row
     subdomains = the headline preconditioner).  The C++ driver of the mirror classes (tests/cpp/test_solver_lin.cpp, mode
@@ -227,7 +227,7 @@ def dropin_leg(A, b, repeat=5):
             np.array([n, len(val)], np.int32).tofile(f)
             rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
             val.tofile(f); bh.tofile(f)
-        r = subprocess.run([exe, fin, fout, "1", "timed", str(repeat)], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([exe, fin, fout, "1", "timed", str(repeat), str(int(sub_rows))], capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             return {"error": (r.stdout + r.stderr)[-400:]}
         rec = None
@@ -512,9 +512,9 @@ def main():
                 alt[name] = {"ms_per_solve": (time.perf_counter() - t0) / 3 * 1e3, "iterations": ia.iters, "converged": ia.converged,
                              "rel_res": ia.rel_res_implicit}
             out["alt"] = alt
-        if world == 1 and not args.no_dropin and not args.force_rccl and args.prec == "bjacobi-ilu0" and args.block == 512 and bptr is None:
+        if world == 1 and not args.no_dropin and not args.force_rccl and args.prec == "bjacobi-ilu0" and (args.block == 512 or bptr is not None):
             # the unchanged SolverLin drop-in (host CSR in, host x out) beside the device-resident figure above
-            d = dropin_leg(A, b)
+            d = dropin_leg(A, b, sub_rows=brows if bptr is not None else 0)
             if isinstance(d, tuple):
                 rec, xd = d
                 xr = x.cpu().numpy()

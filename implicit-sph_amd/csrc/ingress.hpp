@@ -467,10 +467,20 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
 // with more side streams than hardware queues (HIP maps its streams onto 4) the copy stream ends up sharing a queue with
 // a 2 ms factorisation kernel and the link idles: 32-38 ms.
 constexpr int kBatchDiv = 12;
+// nblocks_tab > 0: the caller's subdomains (host table bptr[0 .. nblocks_tab], isph_mat_create_csr_blocks); block_size is then
+// the capacity of a block.  Their factor regions are the entry ranges of their rows in the host CSR, 64-aligned -- known
+// from the row pointers before the first entry has crossed the link.
 inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
-                                    int block_size, isph_mat **Aout, isph_ilu **Fout) {
+                                    int block_size, isph_mat **Aout, isph_ilu **Fout, int nblocks_tab = 0,
+                                    const int *bptr = nullptr) {
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
                "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
+  const bool var = nblocks_tab > 0;
+  if (var) {
+    ISPH_REQUIRE(bptr && bptr[0] == 0 && bptr[nblocks_tab] == nrow, "subdomain table must run from 0 to the number of rows");
+    for (int b = 0; b < nblocks_tab; ++b)
+      ISPH_REQUIRE(bptr[b + 1] > bptr[b] && bptr[b + 1] - bptr[b] <= block_size, "every subdomain needs between 1 and `capacity` rows");
+  }
   HostStager *H = nullptr;
   ISPH_CHECK(stager_get(ctx, &H));
   isph_ilu *F = nullptr;
@@ -482,15 +492,39 @@ inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int
     if (S.nrow == 0) return ISPH_SUCCESS;
     ISPH_CHECK(S.col16.reserve((size_t)(S.stored > 0 ? S.stored : 1)));
     ISPH_CHECK(S.wtab.reserve((size_t)S.nslices * 64));
-    ISPH_CHECK(ilu_begin(ctx, S, block_size, false, 0, &F));
-    return ilu_begin_fill0(ctx, F, S);
+    if (!var) {
+      ISPH_CHECK(ilu_begin(ctx, S, block_size, false, 0, &F));
+      return ilu_begin_fill0(ctx, F, S);
+    }
+    ISPH_CHECK(ilu_begin(ctx, S, block_size, false, 0, &F, /*defer_factor_arrays=*/true, nblocks_tab, bptr));
+    std::vector<long long> hb((size_t)nblocks_tab + 1, 0);
+    for (int b = 0; b < nblocks_tab; ++b)
+      hb[(size_t)b + 1] = hb[(size_t)b] + (((long long)rowptr[bptr[b + 1]] - rowptr[bptr[b]] + 63) & ~63LL);
+    F->total = hb[(size_t)nblocks_tab];
+    F->compact = true;
+    const size_t tot1 = (size_t)(F->total > 0 ? F->total : 1);
+    ISPH_CHECK(F->fcol.reserve(tot1));
+    ISPH_CHECK(F->fval.reserve(tot1));
+    ISPH_CHECK(F->fdst.reserve(tot1));
+    ISPH_CHECK_HIP(hipMemcpyAsync(F->boff.p, hb.data(), sizeof(long long) * hb.size(), hipMemcpyHostToDevice, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // hb leaves scope
+    return ilu_size_stream(F);
+  };
+  // blocks whose last row lies in a converted slice
+  auto blocks_ready = [&](int s1, int nslices) {
+    if (s1 == nslices) return F->nblocks;
+    if (!var) return s1 / spb;
+    const int rows = s1 * 64;
+    int lo = 0, hi = nblocks_tab;
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (bptr[mid] <= rows) lo = mid; else hi = mid - 1; }
+    return lo;
   };
   // The hook kernels run BEFORE the host has reported an out-of-range column (bad_col is checked when the ingress ends):
   // none of them indexes memory by a column -- k_sell_compress_cols takes differences, the ILU extract / schedule /
   // factor kernels compare a column against the block's row range and only use it as an index inside that range.
   hooks.slices = [&](isph_mat *A, int s0, int s1) -> int {
     const Sell &S = A->S;
-    const int ready = s1 == S.nslices ? F->nblocks : s1 / spb;
+    const int ready = blocks_ready(s1, S.nslices);
     const int batch = std::max(1, F->nblocks / kBatchDiv);
     const bool fire = ready > blocks_done && (ready - blocks_done >= batch || s1 == S.nslices);
     if (fire) ISPH_CHECK_HIP(hipEventRecord(H->ev_conv, ctx->stream));  // behind the conversion, in front of the column windows
@@ -527,7 +561,7 @@ inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int
   if (rc == ISPH_SUCCESS && (redo || !F)) {  // sorted now / stream at its proven capacity: the plain set-up
     if (F) ilu_destroy(F);
     F = nullptr;
-    rc = ilu_create(ctx, A, block_size, &F, false, 0);
+    rc = ilu_create(ctx, A, block_size, &F, false, 0, nblocks_tab, bptr);
   }
   if (rc != ISPH_SUCCESS) {
     // a failure may have skipped the hook call that joins the side streams (it only runs while rc is good): batches

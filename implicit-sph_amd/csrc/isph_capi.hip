@@ -418,6 +418,26 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, co
   return ISPH_SUCCESS;
 }
 
+int isph_mat_create_csr_blocks(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
+                               int nblocks, const int *block_ptr, isph_mat **Aout, isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && Aout && Mout && rowptr && colidx && val && nblocks > 0 && block_ptr, "NULL argument or no subdomains");
+  ISPH_REQUIRE(nrow >= 0 && ncol >= nrow, "need 0 <= nrow <= ncol");
+  int cap = 64;
+  for (int b = 0; b < nblocks; ++b) cap = std::max(cap, block_ptr[b + 1] - block_ptr[b]);
+  cap = (cap + 63) / 64 * 64;
+  ISPH_REQUIRE(cap <= 1024, "a subdomain of the block stream holds at most 1024 rows");
+  isph_mat *A = nullptr;
+  isph_ilu *F = nullptr;
+  ISPH_CHECK(csr_ingress_host_bjacobi(ctx, nrow, ncol, rowptr, colidx, val, cap, &A, &F, nblocks, block_ptr));
+  isph_prec *M = new isph_prec();
+  M->n = nrow;
+  M->type = 2;
+  M->ilu = F;
+  *Aout = A;
+  *Mout = M;
+  return ISPH_SUCCESS;
+}
+
 int isph_mat_create_csr_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
                                 int block_size, isph_mat **Aout, isph_prec **Mout) {
   ISPH_REQUIRE(ctx && Aout && Mout && rowptr && colidx && val, "NULL argument");

@@ -18,7 +18,7 @@ KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
     "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_create_hostcomm", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_pool_info", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
-    "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
+    "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_ctx_profile_read", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
@@ -119,6 +119,8 @@ def lib():
                                           C.c_int, C.c_void_p]
         L.isph_mat_create_csr_bjacobi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_int, C.c_void_p, C.c_void_p]
+        L.isph_mat_create_csr_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
         L.isph_mat_info.argtypes = [C.c_void_p, C.c_void_p]
@@ -380,9 +382,10 @@ class Matrix:
         return m
 
     @classmethod
-    def from_host_csr_with_bjacobi(cls, ctx, rowptr, colidx, val, block_size=512, ncol=None):
+    def from_host_csr_with_bjacobi(cls, ctx, rowptr, colidx, val, block_size=512, ncol=None, block_ptr=None):
         """isph_mat_create_csr_bjacobi: host CSR ingress fused with the block-Jacobi ILU(0) set-up (the drop-in path of
-        SolverLin_Belos::solveProblem with PrecondWrapper_Ifpack).  Returns (Matrix, Precond)."""
+        SolverLin_Belos::solveProblem with PrecondWrapper_Ifpack).  block_ptr: the caller's subdomains
+        (isph_mat_create_csr_blocks).  Returns (Matrix, Precond)."""
         rowptr, colidx, val = _i32(rowptr), _i32(colidx), _f64(val)
         if _is_torch(rowptr) or _is_torch(colidx) or _is_torch(val):
             raise IsphError("isph_mat_create_csr_bjacobi takes host arrays")
@@ -390,6 +393,11 @@ class Matrix:
         m = cls(ctx)
         M = Precond.__new__(Precond)
         M.ctx, M.n, M.h = ctx, nrow, C.c_void_p()
+        if block_ptr is not None:
+            bp = np.ascontiguousarray(block_ptr, dtype=np.int32)
+            _check(lib().isph_mat_create_csr_blocks(ctx.h, nrow, nrow if ncol is None else ncol, _ptr(rowptr), _ptr(colidx),
+                                                    _ptr(val), len(bp) - 1, _ptr(bp), C.byref(m.h), C.byref(M.h)))
+            return m, M
         _check(lib().isph_mat_create_csr_bjacobi(ctx.h, nrow, nrow if ncol is None else ncol, _ptr(rowptr), _ptr(colidx),
                                                  _ptr(val), block_size, C.byref(m.h), C.byref(M.h)))
         return m, M

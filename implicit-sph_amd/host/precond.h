@@ -25,6 +25,8 @@ class PrecondWrapper {
   // ingress can set up while the matrix is still crossing PCIe (isph_mat_create_csr_bjacobi); SolverLin_HIP then hands
   // the finished object over with adoptDevice() instead of calling createOnDevice()
   virtual int fusedIngressBlockRows() { return 0; }
+  // the wrapper's own table of subdomains for that fused set-up (isph_mat_create_csr_blocks), if it has one
+  virtual bool fusedIngressSubdomains(int &, const int *&) { return false; }
   void adoptDevice(isph_prec *M) { free(); _M = M; }
 
  public:

@@ -1,6 +1,7 @@
 // precond_ifpack.h -- PrecondWrapper_Ifpack over the HIP block-Jacobi ILU(k)
 // (ref: precond_ifpack.h:28-85: same parameter keys and defaults).
 #pragma once
+#include <algorithm>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -33,15 +34,37 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     return _param.get();
   }
 
+  // Device-side extension (not a reference method): the additive-Schwarz subdomains INSIDE this rank as consecutive row
+  // ranges, block b = rows block_ptr[b] .. block_ptr[b+1] (at most 1024 rows each).  The reference has one subdomain per
+  // rank, a brick of LAMMPS' decomposition; an adapter that numbers the rank's particles brick by brick passes the brick
+  // boundaries here and gets compact subdomains instead of a cut every "isph: block rows" rows.  Level of fill 0,
+  // overlap 0 (isph_prec_create_blocks).  nblocks = 0 clears the table.
+  void setSubdomains(int nblocks, const int *block_ptr) {
+    _bptr.clear();
+    if (nblocks > 0 && block_ptr != NULL) _bptr.assign(block_ptr, block_ptr + nblocks + 1);
+  }
+
  protected:
   // the throughput path (block-Jacobi ILU(0), overlap 0 inside the rank) can be built during the matrix ingress
   virtual int fusedIngressBlockRows() {
     setParameters(_param.get());
     const int block = _param->get("isph: block rows", 512);
     if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0) return 0;
+    if (!_bptr.empty()) {
+      int cap = 64;
+      for (size_t b = 0; b + 1 < _bptr.size(); ++b) cap = std::max(cap, _bptr[b + 1] - _bptr[b]);
+      noticeOnce(0, cap, _param->get("Overlap Level", 1));
+      return cap <= 1024 ? (cap + 63) / 64 * 64 : 0;
+    }
     if (block < 64 || block > 1024 || block % 64 != 0) return 0;
     noticeOnce(0, block, _param->get("Overlap Level", 1));
     return block;
+  }
+  virtual bool fusedIngressSubdomains(int &nblocks, const int *&bptr) {
+    if (_bptr.empty()) return false;
+    nblocks = (int)_bptr.size() - 1;
+    bptr = _bptr.data();
+    return true;
   }
   void noticeOnce(int fill, int block, int overlap) {
     if (_comm.MyPID() == 0 && !_warned) {
@@ -100,6 +123,10 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
       isph_mat_destroy(Aext);
       return ierr;
     }
+    if (!_bptr.empty() && fill == 0) {  // the caller's subdomains (setSubdomains)
+      noticeOnce(fill, 0, overlap);
+      return isph_prec_create_blocks(ctx, A, (int)_bptr.size() - 1, _bptr.data(), &_M);
+    }
     if (block == 0 || block > 1024) {
       isph_schwarz_params sp;
       isph_schwarz_params_default(&sp);
@@ -117,6 +144,7 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     return isph_prec_create(ctx, A, kind.c_str(), block, &_M);
   }
   bool _warned = false;
+  std::vector<int> _bptr;  // setSubdomains
 };
 
 }  // namespace LAMMPS_NS

@@ -84,8 +84,12 @@ class SolverLin_HIP : public SolverLin {
     // a preconditioner that is local to 512-row subdomains is set up while the matrix is still on the link
     const int fused = prec != NULL ? prec->fusedIngressBlockRows() : 0;
     isph_prec *Mfused = nullptr;
-    if ((fused > 0 ? isph_mat_create_csr_bjacobi(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, fused, &A, &Mfused)
-                   : isph_mat_create_csr(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, 0, &A)) != ISPH_SUCCESS)
+    int nsub = 0;
+    const int *subptr = nullptr;
+    const bool table = fused > 0 && prec->fusedIngressSubdomains(nsub, subptr);
+    if ((table ? isph_mat_create_csr_blocks(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, nsub, subptr, &A, &Mfused)
+         : fused > 0 ? isph_mat_create_csr_bjacobi(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, fused, &A, &Mfused)
+                     : isph_mat_create_csr(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, 0, &A)) != ISPH_SUCCESS)
       return report_failure();
     if (attachHalo(A, *_A) != ISPH_SUCCESS) { isph_mat_destroy(A); isph_prec_destroy(Mfused); return report_failure(); }
     const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();  // the ingress returns synchronised

@@ -107,6 +107,11 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[
 int isph_mat_create_csr_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h]*/,
                                 const int *colidx /*[h]*/, const double *val /*[h]*/, int block_size,
                                 isph_mat **A, isph_prec **M);
+/* The same with the caller's subdomains (see isph_prec_create_blocks): the result of isph_mat_create_csr(on_device = 0)
+ * followed by isph_prec_create_blocks(A, nblocks, block_ptr), bit for bit. */
+int isph_mat_create_csr_blocks(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h]*/, const int *colidx /*[h]*/,
+                               const double *val /*[h]*/, int nblocks, const int *block_ptr /*[h]*/, isph_mat **A,
+                               isph_prec **M);
 /* Diagnostics of the last host-side ingress on this context (milliseconds since its start):
  * [0] staging threads started, device buffers reserved  [1] all chunks queued on the copy stream
  * [2] copy stream drained  [3] compute stream drained (conversion + fused set-up)  [4] end

@@ -284,6 +284,15 @@ static int run(int argc, char **argv) {
     pp->set("Overlap Level", 0);
   }
   pp->set("isph: block rows", ifpack_reference ? 0 : timed ? 512 : 256);
+  // argv[6] = rows per subdomain of a caller-defined table (PrecondWrapper_Ifpack::setSubdomains): consecutive ranges of
+  // that many rows, e.g. the 500-row bricks of bench.py's particle numbering
+  std::vector<int> subptr;
+  if (argc > 6 && std::atoi(argv[6]) > 0 && !use_ml) {
+    const int sub = std::atoi(argv[6]);
+    for (int at = 0; at < n; at += sub) subptr.push_back(at);
+    subptr.push_back(n);
+    prec_ifpack.setSubdomains((int)subptr.size() - 1, subptr.data());
+  }
 
   SolverLin_Belos li_solver(world);
   li_solver.setParameters();

@@ -66,3 +66,47 @@ def test_caller_subdomains_are_validated(gpu_ctx):
         with pytest.raises(hip.IsphError):
             hip.Precond(gpu_ctx, A, "bjacobi-ilu0", block_ptr=np.asarray(bad, dtype=np.int32))
     A.close()
+
+
+def test_fused_host_ingress_with_caller_subdomains_is_the_two_step_result(gpu_ctx):
+    """isph_mat_create_csr_blocks (host CSR crossing PCIe with the set-up of the caller's subdomains running behind the
+    rows that have arrived) == isph_mat_create_csr + isph_prec_create_blocks, bit for bit."""
+    spec = workload.TGVSpec(dim=3, ncell=(30, 30, 30), brick=(10, 10, 5), mode=workload.JITTER)
+    pr = Problem(spec)
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    for kind in ("bricks500", "ragged"):
+        bp = _tables(n, kind)
+        A1 = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+        M1 = hip.Precond(gpu_ctx, A1, "bjacobi-ilu0", block_ptr=bp)
+        A2, M2 = hip.Matrix.from_host_csr_with_bjacobi(gpu_ctx, rp, ci, val, block_ptr=bp)
+        r = np.random.default_rng(3).standard_normal(n)
+        assert np.array_equal(M1.apply(r), M2.apply(r))
+        f1, f2 = M1.export_ilu(), M2.export_ilu()
+        assert all(np.array_equal(a, c) for a, c in zip(f1, f2))
+        assert np.array_equal(A1.spmv(r), A2.spmv(r))
+        for o in (M1, M2, A1, A2):
+            o.close()
+
+
+def test_cpp_mirror_with_subdomain_table(gpu_ctx, tmp_path):
+    """PrecondWrapper_Ifpack::setSubdomains through SolverLin_Belos::solveProblem (fused ingress with the table)."""
+    import subprocess
+    from isph_amd import build
+    spec = workload.TGVSpec(dim=3, ncell=(20, 20, 20), brick=(10, 10, 5), mode=workload.JITTER)
+    pr = Problem(spec)
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    exe = build.build_cpp_test()
+    fin, fout = tmp_path / "sys.bin", tmp_path / "x.bin"
+    with open(fin, "wb") as f:
+        np.array([n, len(val)], np.int32).tofile(f)
+        rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f); val.tofile(f); b.tofile(f)
+    r = subprocess.run([exe, str(fin), str(fout), "1", "timed", "2", "500"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    x = np.fromfile(fout)[:n]
+    bp = _tables(n, "bricks500")
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=orc.ILU(rp, ci, val, 0, bp))
+    its = [int(t.split(":")[1].split(",")[0]) for t in r.stdout.split('"iterations"')[1:2]]
+    assert abs(its[0] - io.iters) <= 1, (its, io.iters)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
