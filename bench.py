@@ -130,6 +130,13 @@ def parse():
     ap.add_argument("--cpu-ifpack-1rank", action="store_true",
                     help="also time the reference's 1-rank configuration (whole-matrix ILU(1), one thread): minutes")
     ap.add_argument("--spmv-reps", type=int, default=50)
+    ap.add_argument("--workload", default="solve", choices=["solve", "step"],
+                    help="solve (default): the headline, one pressure-Poisson solve per step on a resident system.  step: the "
+                         "reference's own benchmark protocol (bench-script/hopper/tgv/1728: tgv.xml + tgv-3d-p24.lmp) -- "
+                         "consecutive ISPH time steps, everything rebuilt every step; see step_workload()")
+    ap.add_argument("--theta", type=float, default=0.5, help="step workload: time discretisation of the Helmholtz step (tgv.xml:13)")
+    ap.add_argument("--singular", default="doublediag", choices=["nullspace", "pinzero", "doublediag"],
+                    help="step workload: \"Singular Poisson\" (tgv.xml:11 DoubleDiag; the sph-script uses NullSpace)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the --gpus ranks as child processes from this one (automatic when --gpus > 1 and no "
                          "torch.distributed.run environment is present)")
@@ -241,6 +248,154 @@ def dropin_leg(A, b, repeat=5, sub_rows=0):
     return rec, xd
 
 
+def step_workload(args, json_fd):
+    """The reference's benchmark protocol as a measured record: `run 20` of
+    bench-script/hopper/tgv/1728/tgv-3d-p24.lmp with tgv.xml -- 3-D TGV on a simple-cubic lattice, Quintic kernel cut 3h
+    (--kernel quintic; wendland = the sph-script), theta 0.5, "Singular Poisson" DoubleDiag, dt = h/8 (.lmp:130), fixes
+    isph + isph/shift 0.05 -- on ONE GPU.  Every step runs PairISPH::compute as the reference does (pair_isph.cpp:1241-1380,
+    SURVEY 3.1): computePre (volumes, G_i, L_i) -> Helmholtz assembly + 3-component solve -> Poisson assembly -> solve
+    -> zero-mean pressure -> velocity / pressure correction, then advanceTime (fix isph) and the particle shift (fix
+    isph/shift).  Matrices and preconditioners are rebuilt every step.  Between steps the host plays LAMMPS: wrap, ghost
+    atoms, neighbour list (workload.make_cloud) -- timed and reported, not part of the path.
+    value = steps / (sum of the device stages), the scope of the reference's `ISPH:` timers (utils.cpp:37-38)."""
+    import torch
+    import isph_amd  # noqa: F401
+    from isph_amd import hip, workload
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", 0)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    ctx = hip.Context(0, stream=tstream.cuda_stream)
+    n = args.ncell
+    brick = tuple(int(t) for t in args.brick.split(","))
+    coh = 2.0 if args.kernel == "wendland" else 3.0
+    spec = workload.TGVSpec(dim=3, ncell=(n, n, n), brick=brick, mode=workload.LATTICE, kernel=args.kernel, cut_over_h=coh)
+    parts0 = workload.make_tgv(spec)
+    N = parts0["nlocal"]
+    L = 2.0 * np.pi
+    dt = 0.125 * spec.h                                   # timestep of the bench script (tgv-3d-p24.lmp:130 = h/8)
+    brows = brick[0] * brick[1] * brick[2]
+    bptr = np.arange(0, N + brows, brows).clip(0, N).astype(np.int32) if all(n % k == 0 for k in brick) and brows <= 1024 else None
+    smode = {"nullspace": hip.NULLSPACE, "pinzero": hip.PINZERO, "doublediag": hip.DOUBLEDIAG}[args.singular]
+    x = torch.from_numpy(np.ascontiguousarray(parts0["x"][:N])).to(dev)
+    v = torch.from_numpy(np.ascontiguousarray(parts0["v"][:N])).to(dev)
+    pr = torch.zeros(N, dtype=torch.float64, device=dev)
+    g = np.zeros(3)
+    stages = ("neighbour_host", "upload", "computePre", "helmholtz_assemble", "helmholtz_solve", "poisson_assemble", "poisson_solve",
+              "correct_advance", "shift")
+    acc = {k: 0.0 for k in stages}
+    its = {"helmholtz": [], "poisson": []}
+
+    def sync():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def make_prec(A, singular):
+        if args.prec == "sa-amg":                            # ml.xml: max levels 10, Gauss-Seidel 4 sweeps pre and post
+            nv = torch.full((N,), 1.0 / np.sqrt(float(N)), dtype=torch.float64, device=dev) if singular else None
+            return hip.PrecondAMG(ctx, A, nullvec=nv, params=hip.AmgParams(max_levels=10, sweeps=4, block=args.block, theta=args.amg_theta))
+        if args.prec == "bjacobi-ilu0" and bptr is not None:
+            return hip.Precond(ctx, A, args.prec, block_ptr=bptr)
+        return hip.Precond(ctx, A, args.prec, args.block)
+
+    total = args.warmup + args.steps
+    for step in range(total):
+        timed = step >= args.warmup
+        t0 = time.perf_counter()
+        cloud = workload.make_cloud(x.cpu().numpy(), (L, L, L), spec.h, spec.cut, like=parts0)
+        t1 = time.perf_counter()
+        own = torch.from_numpy(cloud["owner_index"].astype(np.int64)).to(dev)
+        dp = dict(cloud)
+        for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+            dp[k] = torch.from_numpy(np.ascontiguousarray(cloud[k])).to(dev)
+        colmap = own.to(torch.int32).contiguous()
+        rho = torch.from_numpy(cloud["rho"]).to(dev)
+        nu = torch.from_numpy(cloud["nu"]).to(dev)
+        vall = v[own].contiguous()
+        pall = pr[own].contiguous()
+        zeros3 = torch.zeros_like(vall)
+        t2 = sync()
+        # ---- computePre (pair_isph_corrected.cpp:302-313): V_i, then G_i and L_i (always formed, whatever the family)
+        vf = hip.compute_volumes(ctx, dp, colmap, kernel=args.kernel)
+        vfrac = vf[own].contiguous()
+        Gc, Lc = hip.compute_corrections(ctx, dp, colmap, vfrac, kernel=args.kernel)
+        t3 = sync()
+        # ---- Helmholtz (pair_isph.cpp:932-982)
+        if args.theta < 1e-24:
+            H, bh = hip.assemble_helmholtz(ctx, dp, colmap, dt, 0.0, nu, rho, pall, zeros3, g, vall, vfrac=vfrac, kernel=args.kernel, rhs_only=True)
+            t4 = t5 = sync()
+            xh = bh
+        else:
+            H, bh = hip.assemble_helmholtz(ctx, dp, colmap, dt, args.theta, nu, rho, pall, zeros3, g, vall, vfrac=vfrac, kernel=args.kernel)
+            t4 = sync()
+            MH = make_prec(H, False)
+            xh = torch.cat([v[:, 0], v[:, 1], v[:, 2]]).contiguous()       # x = View(vstar): the current velocity
+            ih = hip.solve(ctx, H, bh, xh, prec=MH, singular=False, nvec=3, lda=N)
+            MH.close(); H.close()
+            its["helmholtz"].append(int(ih.iters))
+            t5 = sync()
+        vstar = torch.stack([xh[:N], xh[N:2 * N], xh[2 * N:3 * N]], dim=1).contiguous()
+        vstar_all = vstar[own].contiguous()
+        # ---- Poisson (pair_isph.cpp:988-1023)
+        A, b = hip.assemble_poisson(ctx, dp, colmap, dt, rho, vstar_all, vfrac=vfrac, kernel=args.kernel, singular=smode)
+        t6 = sync()
+        M = make_prec(A, smode == hip.NULLSPACE)
+        dpv = torch.zeros(N, dtype=torch.float64, device=dev)
+        ip = hip.solve(ctx, A, b, dpv, prec=M, singular=(smode == hip.NULLSPACE))
+        M.close(); A.close()
+        its["poisson"].append(int(ip.iters))
+        dpv -= dpv.mean()                                                  # computeZeroMeanPressure
+        t7 = sync()
+        # ---- correction + advanceTime (pair_isph.cpp:1030-1031, pair_isph_corrected.cpp:1172-1199)
+        dp_all = dpv[own].contiguous()
+        hip.correct_velocity_pressure(ctx, dp, colmap, dt, rho, dp_all, vstar_all, pall, vfrac, kernel=args.kernel)
+        dpa = hip.advance_begin(ctx, dp, colmap, dt, pall, vall, vstar_all, vfrac, kernel=args.kernel)
+        xall = dp["x"]
+        hip.advance_end(ctx, N, 3, dt, dpa, vstar_all, pall, xall, vall)
+        t8 = sync()
+        # ---- fix isph/shift 0.05 (fix_isph_shift.cpp:146-163): computePre on the moved particles, then shiftParticles
+        vall2 = vall[:N][own].contiguous()
+        pall2 = pall[:N][own].contiguous()
+        dp["x"] = (xall[:N][own] + (xall - xall[own])).contiguous()        # ghosts follow their owners
+        vf2 = hip.compute_volumes(ctx, dp, colmap, kernel=args.kernel)
+        vfrac2 = vf2[own].contiguous()
+        hip.shift_particles(ctx, dp, colmap, 0.05, spec.cut, 0.1, dt, dp["x"], vall2, pall2, vfrac2, kernel=args.kernel)
+        t9 = sync()
+        x, v, pr = dp["x"][:N].clone(), vall2[:N].clone(), pall2[:N].clone()
+        if timed:
+            for k, d in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6, t8 - t7, t9 - t8)):
+                acc[k] += d
+        sys.stderr.write("step %d: pre %.1f  helm asm %.1f solve %.1f [%s its]  poisson asm %.1f solve %.1f [%d its]  corr+adv %.1f  shift %.1f  | host neighbours %.0f ms\n"
+                         % (step, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, its["helmholtz"][-1] if its["helmholtz"] else "-",
+                            (t6 - t5) * 1e3, (t7 - t6) * 1e3, ip.iters, (t8 - t7) * 1e3, (t9 - t8) * 1e3, (t1 - t0) * 1e3))
+    K = args.steps
+    dev_s = sum(acc[k] for k in stages[2:])
+    # sanity of the physics: the kinetic energy of the decaying vortex only goes down, the velocity stays finite
+    ke = float((v * v).sum().item()) * 0.5
+    out = {
+        "metric": "ISPH time steps/sec (3D TGV, %d^3 particles, %s cut %gh, theta %g, %s, GMRES(50)+%s; PairISPH::compute + fix isph + fix isph/shift per step)"
+                  % (n, args.kernel, coh, args.theta, args.singular, args.prec),
+        "value": K / dev_s, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
+        "ms_per_step": dev_s / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "reference benchmark protocol bench-script/hopper/tgv/1728 (tgv.xml, tgv-3d-p24.lmp: run 20), one GPU",
+                   "rows": N, "kernel": args.kernel, "cut_over_h": coh, "theta": args.theta, "singular": args.singular, "precond": args.prec,
+                   "dt": dt, "subdomains": ("%dx%dx%d bricks" % brick) if bptr is not None else "%d rows" % args.block,
+                   "iterations_poisson": its["poisson"][args.warmup:], "iterations_helmholtz_3rhs_total": its["helmholtz"][args.warmup:],
+                   "kinetic_energy_sum_end": ke},
+        "stages_ms_per_step": {k: acc[k] / K * 1e3 for k in stages},
+        "split": {"ISPH: computePre": acc["computePre"] / K * 1e3,
+                  "ISPH: computeHelmholtz": acc["helmholtz_assemble"] / K * 1e3, "ISPH: solveHelmholtz": acc["helmholtz_solve"] / K * 1e3,
+                  "ISPH: computePoisson": acc["poisson_assemble"] / K * 1e3, "ISPH: solvePoisson": acc["poisson_solve"] / K * 1e3,
+                  "assembly_ms": (acc["computePre"] + acc["helmholtz_assemble"] + acc["poisson_assemble"]) / K * 1e3,
+                  "solve_ms": (acc["helmholtz_solve"] + acc["poisson_solve"]) / K * 1e3},
+        "host_lammps_side_ms_per_step": {"neighbour_list_and_ghosts": acc["neighbour_host"] / K * 1e3, "upload": acc["upload"] / K * 1e3,
+                                         "note": "what LAMMPS does between compute() calls; not in `value`"},
+    }
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    ctx.close()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without torch.distributed.run: this process never touches the GPU; it starts one
     fresh child per rank (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* like torchrun), waits, and exits non-zero if a rank failed.
@@ -282,6 +437,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.workload == "step":
+        assert args.gpus == 1, "--workload step runs on one GPU"
+        return step_workload(args, json_fd)
     import torch
     import isph_amd  # noqa: F401
     from isph_amd import hip, workload, dist

@@ -6,6 +6,7 @@
 // for the lattices of sph-script/taylor-green-vortex-{2d,3d}.lmp.
 #include "isph_workload.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -268,4 +269,129 @@ extern "C" long long isph_tgv_fill(const isph_tgv_spec *s, double *x, double *v,
 extern "C" long long isph_tgv_fill64(const isph_tgv_spec *s, double *x, double *v, int *tag, int *owner_rank,
                                      int *owner_index, long long *neigh_ptr, int *neigh_idx) {
   return tgv_fill_t<long long>(s, x, v, tag, owner_rank, owner_index, neigh_ptr, neigh_idx);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// General particle cloud in a periodic box: what LAMMPS does between two calls of PairISPH::compute when the particles
+// have moved -- wrap into the box, create the ghost atoms (periodic images within the cut of a face) and rebuild the full
+// neighbour list with cells of the cut's size (Neighbor::build; `neighbor ${skin} bin`, `neigh_modify every 1`,
+// bench-script/hopper/tgv/1728/tgv-3d-p24.lmp:95-96).  One rank, periodic in every direction.  Host only; not part of the
+// path (the reference gets these arrays from LAMMPS), used by bench.py --workload step to run consecutive time steps.
+namespace {
+struct Cloud {
+  int dim, nlocal;
+  double L[3], cut;
+  std::vector<double> gx;        // ghost positions [nghost][3]
+  std::vector<int> gowner;       // ghost -> owner
+};
+
+inline void cloud_ghosts(int dim, int nlocal, const double *x, const double *L, double cut, Cloud &C) {
+  C.dim = dim; C.nlocal = nlocal; C.cut = cut;
+  for (int a = 0; a < 3; ++a) C.L[a] = L[a];
+  const int s2 = dim == 3 ? 1 : 0;
+  for (int i = 0; i < nlocal; ++i) {
+    const double *p = &x[3 * (size_t)i];
+    int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // image shifts that can land within the cut of the box
+    for (int a = 0; a < dim; ++a) {
+      if (p[a] < cut) hi[a] = 1;            // image at p + L lies within cut beyond the upper face
+      if (p[a] >= L[a] - cut) lo[a] = -1;   // image at p - L lies within cut below the lower face
+    }
+    for (int sz = (s2 ? lo[2] : 0); sz <= (s2 ? hi[2] : 0); ++sz)
+      for (int sy = lo[1]; sy <= hi[1]; ++sy)
+        for (int sx = lo[0]; sx <= hi[0]; ++sx) {
+          if (!sx && !sy && !sz) continue;
+          C.gx.push_back(p[0] + sx * L[0]);
+          C.gx.push_back(p[1] + sy * L[1]);
+          C.gx.push_back(dim == 3 ? p[2] + sz * L[2] : 0.0);
+          C.gowner.push_back(i);
+        }
+  }
+}
+}  // namespace
+
+// Pass 1 (x_all == NULL): returns the number of ghosts for the wrapped owned positions x[nlocal][3].
+// Pass 2: fills x_all[nall][3] (owned first, then ghosts), owner_index[nall], neigh_ptr[nlocal+1] (64-bit) and, when
+// neigh_idx != NULL, the lists; returns the number of list entries.  Call with neigh_idx == NULL to size it.
+extern "C" long long isph_cloud_build(int dim, int nlocal, const double *x, const double *L, double cut, double *x_all,
+                                      int *owner_index, long long *neigh_ptr, int *neigh_idx) {
+  if ((dim != 2 && dim != 3) || nlocal < 0 || cut <= 0.0) return -1;
+  for (int a = 0; a < dim; ++a)
+    if (L[a] < 2.0 * cut) return -1;  // a particle would see two images of a neighbour
+  Cloud C;
+  cloud_ghosts(dim, nlocal, x, L, cut, C);
+  const int nghost = (int)C.gowner.size(), nall = nlocal + nghost;
+  if (!x_all) return nghost;
+  for (size_t k = 0; k < (size_t)nlocal * 3; ++k) x_all[k] = x[k];
+  for (size_t k = 0; k < C.gx.size(); ++k) x_all[(size_t)nlocal * 3 + k] = C.gx[k];
+  for (int i = 0; i < nlocal; ++i) owner_index[i] = i;
+  for (int g = 0; g < nghost; ++g) owner_index[nlocal + g] = C.gowner[(size_t)g];
+  // cells of at least the cut's size over [-cut, L + cut)
+  int nc[3] = {1, 1, 1};
+  double cs[3] = {1, 1, 1}, org[3] = {0, 0, 0};
+  for (int a = 0; a < dim; ++a) {
+    nc[a] = std::max(1, (int)std::floor((L[a] + 2.0 * cut) / cut));
+    cs[a] = (L[a] + 2.0 * cut) / nc[a];
+    org[a] = -cut;
+  }
+  const long long ncell = (long long)nc[0] * nc[1] * nc[2];
+  auto cell_of = [&](const double *p, int c[3]) {
+    for (int a = 0; a < 3; ++a) {
+      c[a] = a < dim ? (int)std::floor((p[a] - org[a]) / cs[a]) : 0;
+      if (c[a] < 0) c[a] = 0;
+      if (c[a] >= nc[a]) c[a] = nc[a] - 1;
+    }
+  };
+  std::vector<int> cstart((size_t)ncell + 1, 0), order((size_t)nall), cid((size_t)nall);
+  for (int j = 0; j < nall; ++j) {
+    int c[3];
+    cell_of(&x_all[3 * (size_t)j], c);
+    cid[(size_t)j] = (c[2] * nc[1] + c[1]) * nc[0] + c[0];
+    ++cstart[(size_t)cid[(size_t)j] + 1];
+  }
+  for (long long c = 0; c < ncell; ++c) cstart[(size_t)c + 1] += cstart[(size_t)c];
+  {
+    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
+    for (int j = 0; j < nall; ++j) order[(size_t)fill[(size_t)cid[(size_t)j]]++] = j;  // ascending particle index inside a cell
+  }
+  const double cutsq = cut * cut;
+  std::vector<int> cnt((size_t)nlocal, 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      neigh_ptr[0] = 0;
+      for (int i = 0; i < nlocal; ++i) neigh_ptr[i + 1] = neigh_ptr[i] + cnt[(size_t)i];
+      if (!neigh_idx) break;
+    }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int i = 0; i < nlocal; ++i) {
+      const double *xi = &x_all[3 * (size_t)i];
+      int c[3];
+      cell_of(xi, c);
+      int n = 0;
+      int *out = pass == 1 ? &neigh_idx[neigh_ptr[i]] : nullptr;
+      for (int oz = (dim == 3 ? -1 : 0); oz <= (dim == 3 ? 1 : 0); ++oz) {
+        const int cz = c[2] + oz;
+        if (cz < 0 || cz >= nc[2]) continue;
+        for (int oy = -1; oy <= 1; ++oy) {
+          const int cy = c[1] + oy;
+          if (cy < 0 || cy >= nc[1]) continue;
+          for (int ox = -1; ox <= 1; ++ox) {
+            const int cx = c[0] + ox;
+            if (cx < 0 || cx >= nc[0]) continue;
+            const long long cc = ((long long)cz * nc[1] + cy) * nc[0] + cx;
+            for (int q = cstart[(size_t)cc]; q < cstart[(size_t)cc + 1]; ++q) {
+              const int j = order[(size_t)q];
+              if (j == i) continue;
+              const double *xj = &x_all[3 * (size_t)j];
+              double rsq = 0.0;
+              for (int a = 0; a < dim; ++a) { const double d = xi[a] - xj[a]; rsq += d * d; }
+              if (rsq < cutsq) { if (out) out[n] = j; ++n; }
+            }
+          }
+        }
+      }
+      if (pass == 0) cnt[(size_t)i] = n;
+      else if (out) std::sort(out, out + n);  // ascending particle index: a fixed summation order whatever the cell walk
+    }
+  }
+  return neigh_ptr[nlocal];
 }

@@ -129,6 +129,45 @@ def make_tgv(spec: TGVSpec):
                 h=spec.h, cut=spec.cut, dt=spec.dt)
 
 
+def make_cloud(x_owned, box, h, cut, dim=3, like=None):
+    """Ghost atoms + full neighbour list of a general particle cloud in a periodic box (isph_cloud_build): the dict
+    make_tgv returns, for owned positions x_owned [nlocal, 3] (wrapped into the box here).  `like`: a make_tgv dict whose
+    spec / per-particle constants (rho, nu, type of the owned particles) are carried over; tags are 1 + the owned index."""
+    lib = _host()
+    lib.isph_cloud_build.restype = C.c_longlong
+    lib.isph_cloud_build.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L = np.ascontiguousarray(list(box) + [1.0] * (3 - len(box)), dtype=np.float64)
+    x = np.ascontiguousarray(x_owned, dtype=np.float64).copy()
+    for a in range(dim):
+        x[:, a] = np.mod(x[:, a], L[a])
+        x[x[:, a] >= L[a], a] = 0.0                  # mod can return L for tiny negatives
+    nl = x.shape[0]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    ng = lib.isph_cloud_build(dim, nl, p(x), p(L), float(cut), None, None, None, None)
+    if ng < 0:
+        raise ValueError("isph_cloud_build: bad arguments (box shorter than two cuts?)")
+    nall = nl + int(ng)
+    xa = np.zeros((nall, 3))
+    own = np.zeros(nall, dtype=np.int32)
+    nptr = np.zeros(nl + 1, dtype=np.int64)
+    nn = lib.isph_cloud_build(dim, nl, p(x), p(L), float(cut), p(xa), p(own), p(nptr), None)
+    nidx = np.zeros(max(int(nn), 1), dtype=np.int32)
+    nn = lib.isph_cloud_build(dim, nl, p(x), p(L), float(cut), p(xa), p(own), p(nptr), p(nidx))
+    nidx = nidx[:nn]
+    if nn < 2 ** 31 - 1:
+        nptr = nptr.astype(np.int32)
+    spec = like["spec"] if like is not None else None
+    out = dict(spec=spec, dim=dim, nlocal=nl, nall=nall, x=xa, v=np.zeros((nall, 3)), tag=(own + 1).astype(np.int32),
+               type=np.ones(nall, dtype=np.int32), owner_rank=np.zeros(nall, dtype=np.int32), owner_index=own,
+               neigh_ptr=nptr, neigh_idx=nidx, h=float(h), cut=float(cut))
+    if like is not None:
+        for k in ("rho", "nu"):
+            out[k] = np.ascontiguousarray(like[k][:nl][own])
+        out["type"] = np.ascontiguousarray(like["type"][:nl][own])
+        out["dt"] = like.get("dt")
+    return out
+
+
 def single_rank_colmap(parts):
     """Matrix column of every particle on one rank: ghosts are periodic images,
     their column is the owner's local id (Epetra LID of the shared tag)."""

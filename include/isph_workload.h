@@ -63,6 +63,15 @@ long long isph_tgv_fill64(const isph_tgv_spec *s, double *x, double *v, int *tag
                           int *owner_rank, int *owner_index,
                           long long *neigh_ptr, int *neigh_idx);
 
+/* A general particle cloud in a periodic box (one rank): wrap-around ghost atoms + full neighbour list for owned
+ * positions x[nlocal][3] already wrapped into [0, L) -- what LAMMPS rebuilds between two PairISPH::compute calls once the
+ * particles have moved (Neighbor::build with `neighbor ${skin} bin`, bench-script/hopper/tgv/1728/tgv-3d-p24.lmp:95-96).
+ * x_all == NULL: returns the number of ghosts.  Otherwise fills x_all[nall][3] (owned first), owner_index[nall],
+ * neigh_ptr[nlocal+1] and -- when neigh_idx != NULL -- the lists (ascending particle index per row); returns the
+ * number of list entries (call once with neigh_idx == NULL to size it).  < 0: bad arguments (L < 2 cut). */
+long long isph_cloud_build(int dim, int nlocal, const double *x, const double *L, double cut, double *x_all,
+                           int *owner_index, long long *neigh_ptr, int *neigh_idx);
+
 #ifdef __cplusplus
 }
 #endif

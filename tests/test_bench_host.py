@@ -47,3 +47,34 @@ def test_self_launch_propagates_a_failing_rank():
     assert r.returncode != 0
     assert "bench.py needs a GPU" in r.stderr
     assert r.stdout.strip() == ""                                     # no JSON line from a failed run
+
+
+def test_cloud_builder_reproduces_the_generators_neighbourhoods():
+    """workload.make_cloud (ghost images + cell-list neighbour search of ARBITRARY positions in a periodic box: the LAMMPS
+    side of bench.py --workload step) against workload.make_tgv on the advected lattice: same neighbour geometry per row
+    (pairs exactly on the cut radius, where W = 0, round either way and are left out of the comparison)."""
+    import numpy as np
+    import isph_amd  # noqa: F401
+    from isph_amd import workload
+    for dim, n in ((3, 16), (2, 24)):
+        spec = workload.TGVSpec(dim=dim, ncell=(n,) * dim, brick=(8,) * dim, origin=(0.5,) * dim if dim == 2 else (0.0,) * 3,
+                                mode=workload.ADVECT)
+        p = workload.make_tgv(spec)
+        nl = p["nlocal"]
+        c = workload.make_cloud(p["x"][:nl], (2 * np.pi,) * dim, spec.h, spec.cut, dim=dim, like=p)
+        assert c["nlocal"] == nl and np.array_equal(c["owner_index"][:nl], np.arange(nl))
+        assert np.all(c["tag"] == c["owner_index"] + 1)
+
+        def rows(q):
+            out = []
+            for i in range(0, nl, 17):
+                j = q["neigh_idx"][q["neigh_ptr"][i]:q["neigh_ptr"][i + 1]]
+                d = q["x"][j] - q["x"][i]
+                d = d[np.abs(np.linalg.norm(d, axis=1) - spec.cut) > 1e-9]
+                out.append(sorted(map(tuple, np.round(d, 8))))
+            return out
+        assert rows(c) == rows(p)
+        # ghosts are exact periodic images of their owners
+        L = 2 * np.pi
+        dxo = c["x"][nl:] - c["x"][c["owner_index"][nl:]]
+        assert np.allclose(dxo / L, np.round(dxo / L), atol=1e-12) and np.all(np.abs(dxo).max(axis=1) > 1.0)

@@ -122,3 +122,29 @@ def test_device_chain_reproduces_reference_tgv_table(gpu_ctx, kernel, N):
     tol_p = 6e-3 if (kernel, N) == ("quintic", 16) else 2.5e-3
     assert abs(h["p_err"] / ref["p_err"] - 1) < tol_p, (h["p_err"], ref["p_err"])
     assert abs(h["u_err"] / ref["u_err"] - 1) < 2.5e-3, (h["u_err"], ref["u_err"])
+
+
+def test_bench_step_workload_runs_consecutive_steps(tmp_path):
+    """bench.py --workload step (the reference's benchmark protocol, bench-script/hopper/tgv/1728): consecutive time steps
+    with the neighbour lists rebuilt from the MOVED particles; the record carries the assembly / solve split and the
+    vortex loses kinetic energy monotonically at the rate of the viscous decay (d/dt KE = -4 nu KE for the 2-D TGV mode)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kes = []
+    for steps in (1, 4):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "step", "--ncell", "20", "--kernel", "wendland",
+                            "--steps", str(steps), "--warmup", "0", "--brick", "10,10,5", "--singular", "nullspace"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        assert rec["unit"] == "steps/s" and rec["value"] > 0 and len(rec["config"]["iterations_poisson"]) == steps
+        assert abs(rec["split"]["assembly_ms"] + rec["split"]["solve_ms"] - rec["ms_per_step"]) < rec["ms_per_step"]
+        kes.append((rec["config"]["kinetic_energy_sum_end"], rec["config"]["dt"]))
+    ke0 = 0.5 * 20 ** 3 * 0.1 ** 2 * 0.5                           # sum over the lattice of |v|^2 / 2, Umax = 0.1
+    (ke1, dt), (ke4, _) = kes
+    assert ke4 < ke1 < ke0
+    rate = -np.log(ke4 / ke1) / (3 * dt)                              # three more steps
+    assert 0.5 * 4 * 0.1 < rate < 2.0 * 4 * 0.1, rate                 # 4 nu = 0.4 within a factor 2 (coarse 20^3 lattice)
