@@ -135,8 +135,9 @@ def parse():
                          "reference's own benchmark protocol (bench-script/hopper/tgv/1728: tgv.xml + tgv-3d-p24.lmp) -- "
                          "consecutive ISPH time steps, everything rebuilt every step; see step_workload()")
     ap.add_argument("--theta", type=float, default=0.5, help="step workload: time discretisation of the Helmholtz step (tgv.xml:13)")
-    ap.add_argument("--singular", default="doublediag", choices=["nullspace", "pinzero", "doublediag"],
-                    help="step workload: \"Singular Poisson\" (tgv.xml:11 DoubleDiag; the sph-script uses NullSpace)")
+    ap.add_argument("--singular", default="nullspace", choices=["nullspace", "pinzero", "doublediag"],
+                    help="step workload: \"Singular Poisson\" (sph-script/taylor-green-vortex.xml NullSpace; tgv.xml:11 of the "
+                         "hopper bench asks for DoubleDiag, which it pairs with ML)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the --gpus ranks as child processes from this one (automatic when --gpus > 1 and no "
                          "torch.distributed.run environment is present)")
@@ -293,7 +294,7 @@ def step_workload(args, json_fd):
     def make_prec(A, singular):
         if args.prec == "sa-amg":                            # ml.xml: max levels 10, Gauss-Seidel 4 sweeps pre and post
             nv = torch.full((N,), 1.0 / np.sqrt(float(N)), dtype=torch.float64, device=dev) if singular else None
-            return hip.PrecondAMG(ctx, A, nullvec=nv, params=hip.AmgParams(max_levels=10, sweeps=4, block=args.block, theta=args.amg_theta))
+            return hip.PrecondAMG(ctx, A, nullvec=nv, params=hip.AmgParams(max_levels=8, sweeps=4, block=args.block, theta=args.amg_theta))  # ml.xml asks for 10; the library's hierarchy holds 8 (4 are reached at 10^6 rows)
         if args.prec == "bjacobi-ilu0" and bptr is not None:
             return hip.Precond(ctx, A, args.prec, block_ptr=bptr)
         return hip.Precond(ctx, A, args.prec, args.block)
