@@ -248,3 +248,103 @@ def extend_rows(plan, rowptr, colidx, val, td=None):
     v_ext = np.concatenate([val[:rowptr[n]]] + gv) if gv else val[:rowptr[n]]
     assert rp_ext[-1] < 2 ** 31
     return rp_ext.astype(np.int32), ci_ext.astype(np.int32), v_ext
+
+
+def extend_rows_levels(plan, rowptr, colidx, val, td, levels=1):
+    """"Overlap Level" L across ranks (precond_ifpack.h:43; Ifpack_OverlappingRowMatrix with OverlapLevel = L): the rank's
+    rows, then L layers of imported rows -- layer 1 = the rows of the matrix' ghost columns, layer l + 1 = the rows of
+    the columns the layer-l rows reference outside everything gathered so far -- each layer in ascending global row
+    number (rank-concatenated numbering: rows of rank r are off[r] .. off[r] + n_r), entries that leave the extended set
+    dropped (Ifpack_LocalFilter).  Rows may come from ranks that are not neighbours of the matrix' own halo.
+
+    Returns (rowptr, colidx, val, xplan): the CSR of the square extended matrix and the halo lists of its imported rows in
+    the form isph_prec_create_overlap takes -- one (peer, send range, receive range) triple per layer and owner, so a rank
+    can appear once per layer; receive ranges follow the extended row order.  xplan.nlocal / xplan.ncol = owned /
+    extended rows.  td: torch.distributed-like (get_world_size, all_gather_object)."""
+    n = int(plan.nlocal)
+    me, world = int(plan.rank), td.get_world_size()
+    rowptr, colidx, val = np.asarray(rowptr, dtype=np.int64), np.asarray(colidx, dtype=np.int64), np.asarray(val, dtype=np.float64)
+    sizes = [None] * world
+    td.all_gather_object(sizes, n)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    # global id of every local column of my own rows
+    gcol = np.empty(int(plan.ncol), dtype=np.int64)
+    gcol[:n] = off[me] + np.arange(n)
+    for k, p in enumerate(plan.peers):
+        r0, r1 = int(plan.recv_ptr[k]), int(plan.recv_ptr[k + 1])
+        gcol[n + r0:n + r1] = off[int(p)] + plan.recv_idx[r0:r1].astype(np.int64)
+    have = set(range(int(off[me]), int(off[me]) + n))            # global ids of the extended rows gathered so far
+    ext_gids = []                                                   # imported rows, in extended order
+    ext_rows = []                                                   # (global column ids, values) of every imported row
+    peers, send_ptr, send_idx, recv_ptr = [], [0], [], [0]
+    frontier = np.unique(gcol[colidx[:rowptr[n]]])                  # columns referenced by the rows of the previous layer
+    for _ in range(int(levels)):
+        want = np.asarray(sorted(g for g in frontier.tolist() if g not in have), dtype=np.int64)
+        owner = np.searchsorted(off, want, side="right") - 1
+        mine = {int(r): (want[owner == r] - off[r]).astype(np.int64) for r in np.unique(owner)}
+        allwant = [None] * world
+        td.all_gather_object(allwant, mine)
+        # rows the others want from me, with global column ids
+        out = {}
+        for p in range(world):
+            idx = allwant[p].get(me) if p != me else None
+            if idx is None or len(idx) == 0:
+                continue
+            lens = rowptr[idx + 1] - rowptr[idx]
+            take = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in idx])
+            out[p] = (lens, gcol[colidx[take]], val[take])
+        allout = [None] * world
+        td.all_gather_object(allout, out)
+        nxt = []
+        for r in sorted(set(mine) | set(out)):                      # one triple per owner / requester of this layer
+            idx_r = mine.get(r, np.zeros(0, np.int64))
+            snd = np.asarray(allwant[r].get(me, np.zeros(0, np.int64)), dtype=np.int64) if r != me else np.zeros(0, np.int64)
+            peers.append(int(r))
+            send_idx.append(snd.astype(np.int32))
+            send_ptr.append(send_ptr[-1] + len(snd))
+            recv_ptr.append(recv_ptr[-1] + len(idx_r))
+            if len(idx_r):
+                lens, gids, vals = allout[r][me]
+                assert len(lens) == len(idx_r)
+                start = 0
+                for k, ln in enumerate(lens):
+                    g = int(off[r] + idx_r[k])
+                    ext_gids.append(g)
+                    have.add(g)
+                    ext_rows.append((np.asarray(gids[start:start + ln], dtype=np.int64), np.asarray(vals[start:start + ln])))
+                    nxt.append(ext_rows[-1][0])
+                    start += int(ln)
+        frontier = np.unique(np.concatenate(nxt)) if nxt else np.zeros(0, np.int64)
+    # local index of every global id of the extended set
+    ext_gids = np.asarray(ext_gids, dtype=np.int64)
+    order = np.argsort(ext_gids, kind="stable")
+    gs = ext_gids[order]
+
+    def ext_index(g):
+        e = np.full(len(g), -1, dtype=np.int64)
+        own = (g >= off[me]) & (g < off[me] + n)
+        e[own] = g[own] - off[me]
+        if len(gs):
+            pos = np.clip(np.searchsorted(gs, g), 0, len(gs) - 1)
+            hit = (gs[pos] == g) & ~own
+            e[hit] = n + order[pos[hit]]
+        return e
+
+    rp_out, ci_out, v_out = [0], [], []
+    eo = ext_index(gcol[colidx[:rowptr[n]]])
+    for i in range(n):
+        a, b = int(rowptr[i]), int(rowptr[i + 1])
+        e, vv = eo[a:b], val[a:b]
+        keep = e >= 0
+        o = np.argsort(e[keep], kind="stable")
+        ci_out.append(e[keep][o]); v_out.append(vv[keep][o]); rp_out.append(rp_out[-1] + int(keep.sum()))
+    for gids, vals in ext_rows:
+        e = ext_index(gids)
+        keep = e >= 0
+        o = np.argsort(e[keep], kind="stable")
+        ci_out.append(e[keep][o]); v_out.append(vals[keep][o]); rp_out.append(rp_out[-1] + int(keep.sum()))
+    xplan = HaloPlan(me, world, n, n + len(ext_gids), plan.colmap, np.asarray(peers, np.int32), np.asarray(send_ptr, np.int32),
+                     np.concatenate(send_idx).astype(np.int32) if send_idx else np.zeros(0, np.int32), np.asarray(recv_ptr, np.int32))
+    xplan.ext_gids = ext_gids
+    return (np.asarray(rp_out, dtype=np.int32), np.concatenate(ci_out).astype(np.int32) if ci_out else np.zeros(0, np.int32),
+            np.concatenate(v_out) if v_out else np.zeros(0), xplan)

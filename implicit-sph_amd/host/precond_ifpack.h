@@ -94,32 +94,43 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     // ILU(fill) level-scheduled on the device (isph_prec_create_schwarz).  "Overlap Level" extends a subdomain by rows
     // of the neighbouring RANKS (Ifpack ignores it on one rank): level 1 = the rows of the matrix' ghost columns,
     // fetched with the matrix' importer (halo_lists.h) and factored with the rank's own (isph_prec_create_overlap);
-    // levels above 1 are factored as level 1 and the notice below says so.
+    // level L > 1 = L such layers, each gathered by one all-to-all round (rows of non-neighbour ranks included).
     // The choice is made from rank-uniform information (the parameters and "does ANY rank have ghost columns"): the row
     // import below is collective, so a rank without ghost columns -- an isolated subdomain -- must enter it as well,
     // with empty lists, and a failure on one rank must fail all of them.
     const int any_ghosts = _A.get() != NULL ? _comm.MaxAll(_A->NumMyCols() > _A->NumMyRows() ? 1 : 0) : 0;
     if (block == 0 && overlap >= 1 && any_ghosts) {
-      HaloLists H;
+      HaloLists H, XH;
       std::vector<int> rp, ci;
       std::vector<double> v;
       int bad = halo_lists_from_import(*_A, H) != ISPH_SUCCESS ? 1 : 0;
-      if (_comm.MaxAll(bad) == 0) bad = extend_rows_one_layer(*_A, _comm, H, rp, ci, v) != ISPH_SUCCESS ? 1 : 0;
+      bool layered = false;
+#ifdef ISPH_HAVE_MPI
+      // more than one rank: L layers of imported rows, each its own all-to-all round (halo_lists.h extend_rows_levels)
+      if (_comm.NumProc() > 1) {
+        layered = true;
+        if (_comm.MaxAll(bad) == 0) bad = extend_rows_levels(*_A, _comm, H, overlap, rp, ci, v, XH) != ISPH_SUCCESS ? 1 : 0;
+      }
+#endif
+      if (!layered) {
+        if (_comm.MaxAll(bad) == 0) bad = extend_rows_one_layer(*_A, _comm, H, rp, ci, v) != ISPH_SUCCESS ? 1 : 0;
+        XH = H;
+        if (overlap > 1 && _comm.MyPID() == 0 && !_warned) {  // the self-peer importer of a one-rank run: one layer
+          std::printf(">> PrecondWrapper_Ifpack(HIP): Overlap Level %d on one rank with a self importer is factored as Overlap Level 1\n", overlap);
+          _warned = true;
+        }
+      }
       if (_comm.MaxAll(bad)) {
         if (_comm.MyPID() == 0)
           std::fprintf(stderr, ">> PrecondWrapper_Ifpack(HIP): cannot import the rows of the ghost columns (Overlap Level %d)\n", overlap);
         return ISPH_FAILURE;
       }
-      if (overlap > 1 && _comm.MyPID() == 0 && !_warned) {
-        std::printf(">> PrecondWrapper_Ifpack(HIP): Overlap Level %d across ranks is factored as Overlap Level 1\n", overlap);
-        _warned = true;
-      }
       const int next = (int)rp.size() - 1;
       isph_mat *Aext = NULL;
       int ierr = isph_mat_create_csr(ctx, next, next, rp.data(), ci.data(), v.data(), 0, &Aext);
       if (ierr != ISPH_SUCCESS) return ierr;
-      ierr = isph_prec_create_overlap(ctx, Aext, _A->NumMyRows(), fill, (mode == "Zero") ? 1 : 0, H.npeers(), H.peers.data(),
-                                      H.send_ptr.data(), H.send_idx.data(), H.recv_ptr.data(), &_M);
+      ierr = isph_prec_create_overlap(ctx, Aext, _A->NumMyRows(), fill, (mode == "Zero") ? 1 : 0, XH.npeers(), XH.peers.data(),
+                                      XH.send_ptr.data(), XH.send_idx.data(), XH.recv_ptr.data(), &_M);
       isph_mat_destroy(Aext);
       return ierr;
     }

@@ -5,6 +5,7 @@
 // Rank r reads <dir>/rank<r>.bin = n, ncol, nnz | rp, ci, val | nto, procs_to, lengths_to | nexp, export_lids |
 // nfrom, procs_from, lengths_from | mask[n]   and writes <dir>/ext<r>.bin (next, nnz, rp, ci, val) and <dir>/nv<r>.bin.
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,25 @@ int main(int argc, char **argv) {
       std::fwrite(&next, 4, 1, f); std::fwrite(&ennz, 4, 1, f);
       std::fwrite(erp.data(), 4, erp.size(), f); std::fwrite(eci.data(), 4, eci.size(), f); std::fwrite(ev.data(), 8, ev.size(), f);
       std::fclose(f);
+    }
+    // argv[2] = L: "Overlap Level" L through the all-to-all rounds of extend_rows_levels -> <dir>/extL<r>.bin =
+    // next, nnz, rp, ci, val | ntriples, peers, send_ptr, nsend, send_idx, recv_ptr
+    const int levels = argc > 2 ? std::atoi(argv[2]) : 0;
+    if (levels > 0 && !rc) {
+      HaloLists XH;
+      std::vector<int> lrp, lci;
+      std::vector<double> lv;
+      int badl = extend_rows_levels(A, comm, H, levels, lrp, lci, lv, XH) != ISPH_SUCCESS ? 1 : 0;
+      if (comm.MaxAll(badl)) rc = 1;
+      if (!rc) {
+        const int next = (int)lrp.size() - 1, ennz = (int)lci.size(), nt = XH.npeers(), ns = (int)XH.send_idx.size();
+        f = std::fopen((dir + "/extL" + std::to_string(comm.MyPID()) + ".bin").c_str(), "wb");
+        std::fwrite(&next, 4, 1, f); std::fwrite(&ennz, 4, 1, f);
+        std::fwrite(lrp.data(), 4, lrp.size(), f); std::fwrite(lci.data(), 4, lci.size(), f); std::fwrite(lv.data(), 8, lv.size(), f);
+        std::fwrite(&nt, 4, 1, f); std::fwrite(XH.peers.data(), 4, (size_t)nt, f); std::fwrite(XH.send_ptr.data(), 4, (size_t)nt + 1, f);
+        std::fwrite(&ns, 4, 1, f); std::fwrite(XH.send_idx.data(), 4, (size_t)ns, f); std::fwrite(XH.recv_ptr.data(), 4, (size_t)nt + 1, f);
+        std::fclose(f);
+      }
     }
     // SolverLin::createNullVector over the communicator, with a mask of unequal local counts
     gid.resize((size_t)n);

@@ -199,8 +199,9 @@ static int run_ranks(const char *dir, bool singular, const std::string &mode) {
     pp->set("isph: block rows", 256);
   } else {
     pp->set("fact: level-of-fill", 0);
-    pp->set("Overlap Level", mode == "overlap" ? 1 : 0);
-    pp->set("isph: block rows", mode == "overlap" ? 0 : 256);
+    const bool ov = mode.rfind("overlap", 0) == 0;      // "overlap" = level 1, "overlap2" / "overlap3" = more layers
+    pp->set("Overlap Level", ov ? (mode.size() > 7 ? std::atoi(mode.c_str() + 7) : 1) : 0);
+    pp->set("isph: block rows", ov ? 0 : 256);
   }
   SolverLin_Belos li_solver(world);
   li_solver.setParameters();

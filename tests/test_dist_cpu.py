@@ -287,7 +287,7 @@ def test_cpp_adapter_row_import_equals_the_python_plumbing(tmp_path):
 
 
 # ------------------------------------------------------------------ the C++ mirror under real MPI, two CPU ranks
-def _worker_rows(rank, world, port, pgrid, dim, n, out):
+def _worker_rows(rank, world, port, pgrid, dim, n, out, levels=0):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -303,6 +303,8 @@ def _worker_rows(rank, world, port, pgrid, dim, n, out):
         spec = workload.TGVSpec(dim=dim, ncell=ncell, pgrid=pgrid[:dim], rank=rank, brick=(4,) * dim,
                                 origin=(0.5,) * dim if dim == 2 else (0.0,) * 3, mode=workload.JITTER)
         parts = workload.make_tgv(spec)
+        if levels:
+            parts = dist.prune_ghosts(parts)           # column map = the referenced tags, like Epetra's (layers follow references)
         plan = dist.make_plan(parts, td)
         nl = parts["nlocal"]
         P = orc.Particles(parts, plan.colmap, kernel=spec.kernel)
@@ -310,8 +312,11 @@ def _worker_rows(rank, world, port, pgrid, dim, n, out):
         P.vfrac[:] = dist.forward_scalar(plan, P.vfrac[:nl].copy(), td).numpy()
         rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True, rank0=(rank == 0))
         rpe, cie, ve = dist.extend_rows(plan, rp, ci, val, td)
+        lv = dist.extend_rows_levels(plan, rp, ci, val, td, levels=levels) if levels else None
+        if lv is not None:
+            lv = lv[:3] + (np.asarray(lv[3].peers), np.asarray(lv[3].send_ptr), np.asarray(lv[3].send_idx), np.asarray(lv[3].recv_ptr))
         out.put((rank, nl, plan.ncol, rp, ci, val, np.asarray(plan.peers), np.asarray(plan.send_ptr), np.asarray(plan.send_idx),
-                 np.asarray(plan.recv_ptr), (rpe, cie, ve), parts["x"][:nl].copy()))
+                 np.asarray(plan.recv_ptr), (rpe, cie, ve), parts["x"][:nl].copy(), lv))
     finally:
         td.barrier()
         td.destroy_process_group()
@@ -341,7 +346,7 @@ def test_cpp_mirror_under_mpi_two_ranks(tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     masks = []
-    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, ext, x in res:
+    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, ext, x, _lv in res:
         # the fluid mask of a wall-bounded case: different counts on the two ranks
         mask = (x[:, 0] < (2.0 if rank == 0 else 2.0 * np.pi + 3.5)).astype(np.int32)
         masks.append(mask)
@@ -364,7 +369,7 @@ def test_cpp_mirror_under_mpi_two_ranks(tmp_path):
     assert "rank 0 of 2" in r.stdout and "rank 1 of 2" in r.stdout
     total = float(sum(m.sum() for m in masks))
     pieces = []
-    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, (rpe, cie, ve), x in res:
+    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, (rpe, cie, ve), x, _lv in res:
         with open(tmp_path / ("ext%d.bin" % rank), "rb") as f:
             nxt, nnz = np.fromfile(f, np.int32, 2)
             rpc = np.fromfile(f, np.int32, nxt + 1); cic = np.fromfile(f, np.int32, nnz); vc = np.fromfile(f, np.float64, nnz)
@@ -406,3 +411,59 @@ def test_cpp_mirror_mpi_build_runs_single_rank(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(open(tmp_path / name, "rb").read())
     assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+@pytest.mark.parametrize("levels", [2, 3])
+def test_cpp_overlap_levels_under_mpi_four_ranks(tmp_path, levels):
+    """"Overlap Level" L > 1 across ranks (precond_ifpack.h:43): host/halo_lists.h extend_rows_levels (one MPI_Alltoallv
+    round per layer; rows of NON-neighbour ranks included: four slabs of 8 cells, three layers reach across a whole slab)
+    under `mpiexec -n 4` against dist.extend_rows_levels over gloo -- extended matrix and the halo triples of the
+    imported rows, entry for entry.  The Python side is pinned to oracle/isph_schwarz_oracle.c on the device
+    (tests/test_gpu_ranks.py)."""
+    import subprocess
+    from isph_amd import build
+    exes = build.build_cpp_mpi()
+    if exes is None:
+        pytest.skip("no MPI installation (mpi.h / mpiexec / libmpi) on this machine")
+    world, pgrid, dim, n = 4, (4, 1, 1), 3, 8
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rows, args=(r, world, port, pgrid, dim, n, out, levels)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, ext, x, lv in res:
+        nsend, nrecv = np.diff(send_ptr), np.diff(recv_ptr)
+        to = [k for k in range(len(peers)) if nsend[k] > 0]
+        frm = [k for k in range(len(peers)) if nrecv[k] > 0]
+        with open(tmp_path / ("rank%d.bin" % rank), "wb") as f:
+            np.array([nl, ncol, len(val)], np.int32).tofile(f)
+            rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f); val.tofile(f)
+            np.array([len(to)], np.int32).tofile(f)
+            peers[to].astype(np.int32).tofile(f); nsend[to].astype(np.int32).tofile(f)
+            np.array([int(send_ptr[-1])], np.int32).tofile(f)
+            send_idx.astype(np.int32).tofile(f)
+            np.array([len(frm)], np.int32).tofile(f)
+            peers[frm].astype(np.int32).tofile(f); nrecv[frm].astype(np.int32).tofile(f)
+            np.ones(nl, np.int32).tofile(f)
+    r = subprocess.run([build.MPIEXEC, "-n", "4", exes[1], str(tmp_path), str(levels)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    far = 0
+    for rank, nl, ncol, rp, ci, val, peers, send_ptr, send_idx, recv_ptr, ext, x, lv in res:
+        rpe, cie, ve, xpeers, xsp, xsi, xrp = lv
+        with open(tmp_path / ("extL%d.bin" % rank), "rb") as f:
+            nxt, nnz = np.fromfile(f, np.int32, 2)
+            rpc = np.fromfile(f, np.int32, nxt + 1); cic = np.fromfile(f, np.int32, nnz); vc = np.fromfile(f, np.float64, nnz)
+            nt = int(np.fromfile(f, np.int32, 1)[0])
+            cpeers = np.fromfile(f, np.int32, nt); csp = np.fromfile(f, np.int32, nt + 1)
+            ns = int(np.fromfile(f, np.int32, 1)[0])
+            csi = np.fromfile(f, np.int32, ns); crp = np.fromfile(f, np.int32, nt + 1)
+        assert nxt == len(rpe) - 1 and np.array_equal(rpc, rpe) and np.array_equal(cic, cie) and np.array_equal(vc, ve)
+        assert np.array_equal(cpeers, xpeers) and np.array_equal(csp, xsp) and np.array_equal(csi, xsi) and np.array_equal(crp, xrp)
+        assert nxt > ncol                                           # more rows than one layer gives
+        far += int(any(int(p) not in set(int(q) for q in peers) for p in cpeers))
+    assert levels < 3 or far > 0, "three layers must reach a rank the matrix' own halo does not talk to"

@@ -205,24 +205,63 @@ def test_a_rank_without_particles_takes_part_in_the_collectives():
 
 
 # ------------------------------------------------------------------ "Overlap Level" 1 across ranks
-def _solve_overlap(rank, G, dim, pgrid, n, fill, combine):
+def _solve_overlap(rank, G, dim, pgrid, n, fill, combine, levels=1):
     st = _rank_setup(rank, G, dim, pgrid, n, orc.NULLSPACE)
     ctx, A, plan = st["ctx"], st["A"], st["plan"]
     try:
         rp, ci, v = st["csr"]
-        rpe, cie, ve = dist.extend_rows(plan, rp, ci, v, G.td(rank))
+        if levels == 1:
+            rpe, cie, ve = dist.extend_rows(plan, rp, ci, v, G.td(rank))
+            xplan = plan
+        else:                               # L layers: halo triples per layer and owner, non-neighbour ranks included
+            rpe, cie, ve, xplan = dist.extend_rows_levels(plan, rp, ci, v, G.td(rank), levels=levels)
         Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
-        M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=fill, combine=combine)
+        M = hip.PrecondOverlap(ctx, Aext, xplan, level_of_fill=fill, combine=combine)
         Aext.close()
         r = np.cos(0.37 * st["rtag"].astype(np.float64))
         z = M.apply(r)
         x, bb = np.zeros(st["nl"]), st["b"].copy()
         info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
         M.close()
-        return dict(st, x=x, r=r, z=z, info=(info.converged, info.iters), ctx=None, A=None, parts=None)
+        return dict(st, x=x, r=r, z=z, info=(info.converged, info.iters), ctx=None, A=None, parts=None, xpeers=[int(p) for p in xplan.peers],
+                    next=len(rpe) - 1)
     finally:
         A.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("levels,fill,combine", [(2, 0, "add"), (3, 0, "add"), (2, 1, "zero")])
+def test_overlap_levels_above_one_across_ranks(levels, fill, combine):
+    """"Overlap Level" L > 1 on several ranks (precond_ifpack.h:43): four slabs of 8 cells, so the third layer reaches a
+    rank the matrix' own halo never talks to.  Layers gathered by dist.extend_rows_levels, factored and applied by
+    isph_prec_create_overlap with one (peer, send, receive) triple per layer and owner; against
+    oracle/isph_schwarz_oracle.c with overlap = L on the global matrix (application 1e-10, iterations +-1, x 1e-6)."""
+    dim, pgrid, n = 3, (4, 1, 1), 8
+    G = RankGroup(4)
+    try:
+        res = G.run(_solve_overlap, dim, pgrid, n, fill, combine, levels)
+    finally:
+        G.close()
+    O = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [r["rtag"] for r in res])
+    O.check_rows(res)
+    S = orc.Schwarz(O.Ap.indptr, O.Ap.indices, O.Ap.data, fill, own_ptr=O.off.astype(np.int32), overlap=levels, combine=combine)
+    rows, lp, _, _, _ = S.export()
+    assert [q["next"] for q in res] == [int(lp[k + 1] - lp[k]) for k in range(4)]          # the same extended subdomains
+    if levels >= 3:
+        assert any(len(set(q["xpeers"])) == 3 for q in res), "a third layer must import rows of the non-neighbour slab"
+    r = np.concatenate([q["r"] for q in res])
+    z = np.concatenate([q["z"] for q in res])
+    zo = S.apply(r)
+    assert np.max(np.abs(z - zo)) <= 1e-10 * np.abs(zo).max()
+    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="schwarz", schwarz=S)
+    infos = {q["info"] for q in res}
+    assert len(infos) == 1
+    conv, iters = infos.pop()
+    assert conv == 1 and io.converged == 1 and abs(iters - io.iters) <= 1, (iters, io.iters)
+    x = np.concatenate([q["x"] for q in res])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    print("overlap-%d ILU(%d) %s on 4 slabs: iterations %d (oracle %d), extended rows %s" % (levels, fill, combine, iters, io.iters,
+                                                                                            [q["next"] for q in res]))
 
 
 @pytest.mark.parametrize("pgrid,fill,combine", [((2, 1, 1), 0, "add"), ((2, 2, 1), 1, "add"), ((2, 2, 1), 0, "zero"),
@@ -264,7 +303,8 @@ def _export_rank(rank, G, dim, pgrid, n):
     return dict(st, ctx=None, A=None, parts=None)
 
 
-@pytest.mark.parametrize("pgrid,mode", [((2, 1, 1), "bjacobi"), ((2, 2, 1), "bjacobi"), ((2, 2, 1), "overlap"), ((2, 1, 1), "ml")])
+@pytest.mark.parametrize("pgrid,mode", [((2, 1, 1), "bjacobi"), ((2, 2, 1), "bjacobi"), ((2, 2, 1), "overlap"), ((2, 1, 1), "ml"),
+                                        ((4, 1, 1), "overlap2")])
 def test_cpp_mirror_on_mpi_ranks_sharing_one_gpu(tmp_path, pgrid, mode):
     """SolverLin(MPI_Comm&) on 2 and 4 real MPI ranks (`mpiexec -n N`, fresh processes), all on device 0: the mirror
     sees that the ranks share a device and takes the MPI transport (host/mpi_transport.h: MPI_Isend/Irecv/Waitall for
@@ -317,8 +357,8 @@ def test_cpp_mirror_on_mpi_ranks_sharing_one_gpu(tmp_path, pgrid, mode):
     if mode == "bjacobi":
         ilu = orc.ILU(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, O.block_ptr(BLOCK))
         xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="ilu", ilu=ilu)
-    elif mode == "overlap":
-        S = orc.Schwarz(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, own_ptr=O.off.astype(np.int32), overlap=1, combine="add")
+    elif mode.startswith("overlap"):
+        S = orc.Schwarz(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, own_ptr=O.off.astype(np.int32), overlap=int(mode[7:] or 1), combine="add")
         xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="schwarz", schwarz=S)
     else:
         xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="jacobi")
