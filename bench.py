@@ -549,6 +549,7 @@ def main():
                                    block_size=args.block)
             if not pinfo:
                 pinfo.update(M.schwarz_info())
+            pinfo["create_ms"] = M.create_timing()          # of the last create
         elif prec in ("ilu0", "ilu1"):
             M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(prec[-1]), overlap=0, block_size=0)
             if not pinfo:

@@ -1076,15 +1076,21 @@ inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *
   hipLaunchKernelGGL(k_numneigh<OFF>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, dnptr, E.len.p);
   hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, E.len.p, E.off.p);
   hipLaunchKernelGGL(k_exclusive_scan_ll, dim3(1), dim3(1024), 0, ctx->stream, nslices, E.off.p, E.off.p);
+  // ONE host round trip for the sizes: the slice offsets (their last entry is the total) when the lists will be ordered
+  // by column -- the widest slice decides whether the sort's LDS buffer fits --, the total alone otherwise
   long long total = 0;
-  ISPH_CHECK_HIP(hipMemcpyAsync(&total, E.off.p + nslices, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<long long> so;
+  if (dcolmap) {
+    so.resize((size_t)nslices + 1);
+    ISPH_CHECK_HIP(hipMemcpyAsync(so.data(), E.off.p, sizeof(long long) * so.size(), hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    ISPH_CHECK_HIP(hipMemcpyAsync(&total, E.off.p + nslices, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  }
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (dcolmap) total = so[(size_t)nslices];
   ISPH_CHECK(E.idx.reserve((size_t)(total > 0 ? total : 1)));
   T.sorted = 0;
   if (dcolmap) {  // order the lists by matrix column when every row fits the sort's LDS buffer
-    std::vector<long long> so((size_t)nslices + 1);
-    ISPH_CHECK_HIP(hipMemcpyAsync(so.data(), E.off.p, sizeof(long long) * so.size(), hipMemcpyDeviceToHost, ctx->stream));
-    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     long long wmax = 0;
     for (int s = 0; s < nslices; ++s) wmax = std::max(wmax, (so[(size_t)s + 1] - so[(size_t)s]) >> 6);
     if (wmax <= kNeighSortCap) {
