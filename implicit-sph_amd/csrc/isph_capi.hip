@@ -305,6 +305,7 @@ int isph_ctx_profile_read(isph_ctx *ctx, double ms[8], int calls[8]) {
 int isph_pool_trim(void) {
   if (hipDeviceSynchronize() != hipSuccess) return fail("device synchronisation failed", __FILE__, __LINE__);
   DevPool::get().trim();
+  HostPool::get().trim();  // the host work arrays of the Schwarz set-up (schwarz.hpp)
   return ISPH_SUCCESS;
 }
 
@@ -869,7 +870,7 @@ int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwar
 int isph_prec_schwarz_info(const isph_prec *M, long long info[7]) {
   ISPH_REQUIRE(M && M->type == 4 && M->schwarz && info, "not a Schwarz preconditioner");
   const isph_schwarz *S = M->schwarz;
-  info[0] = S->nloc; info[1] = S->nnz; info[2] = S->nsub; info[3] = S->nlev_l; info[4] = S->nlev_u; info[5] = S->maxrow; info[6] = S->syncfree ? 1 : 0;
+  info[0] = S->nloc; info[1] = S->nnz; info[2] = S->nsub; info[3] = S->nlev_l; info[4] = S->nlev_u; info[5] = S->maxrow; info[6] = S->subsweep ? 2 : S->syncfree ? 1 : 0;
   return ISPH_SUCCESS;
 }
 

@@ -62,6 +62,16 @@ struct isph_schwarz {
   int n4l = 0, n4u = 0;
   bool long_rows = false;   // many rows have more entries on one side of the diagonal than a chunk of the sweeps holds
   bool syncfree = true;
+  // many small subdomains (k_gilu_solve_sub): ONE launch per application, one workgroup per subdomain with its part of
+  // the vector in LDS and a barrier per dependency level.  Per subdomain ONE list of levels -- the L levels with work
+  // (1 ..), then the U levels (0 ..) -- with a 16-byte descriptor per row in that order (sub_desc: first entry on the
+  // sweep's side of the diagonal, their number, the local row), level starts sub_lptr, per-subdomain offsets into both
+  // and the number of L levels in the list
+  bool subsweep = false, syncfree_requested = true;
+  int sub_maxrows = 0;
+  isph::DevBuf<long long> sub_desc;              // [2 x 8 bytes per listed row]: start | n, i
+  isph::DevBuf<int> sub_lptr, sub_lofs, sub_nl, loc_ptr_dev;
+  isph::DevBuf<long long> sub_dofs;
   int *h_tmo = nullptr;   // pinned: the time-out word of the last application (read by prec_health with the stream drained)
   // persistent workgroups (1024 threads) of the L / U sweep, and how many earlier runs may still be open when a run
   // starts polling (k_gilu_solve_run): both follow the width of the levels
@@ -171,6 +181,111 @@ __global__ __launch_bounds__(256) void k_gilu_upper(int count, const int *__rest
   }
   s = group16_sum(s);
   if (live && sub == 0) w[i] = (w[i] - s) / d;
+}
+
+// ---- many small subdomains: both sweeps of one subdomain in one workgroup ----------------------------------------------
+// Additive Schwarz on hundreds of subdomains of a few thousand rows (512-row blocks + one overlap layer at 10^6 rows: 1954
+// subdomains of ~2200 rows, 294 levels each): a launch per global level is 588 launches of 15 000 short rows per
+// application, the persistent form pays a hand-off through memory per level.  Here a workgroup owns a subdomain: its part
+// of the vector lives in LDS (the gather of r is fused in), a level's rows take 16 lanes each, one barrier per level, L
+// sweep then U sweep, result to w for k_gilu_combine.  Rows of a subdomain only depend on rows of the same subdomain.
+constexpr int kSubSweepMaxRows = 4096;   // 32 KB of LDS per workgroup
+constexpr int kSubSweepMinSubs = 32;     // fewer subdomains do not fill the chip this way
+// one row of a level as a group of 16 lanes holds it: up to kSubK entries per lane in registers (rows of up to 16 kSubK
+// entries on the side in question; longer ones finish from memory).  Nothing of it depends on the vector, so it is fetched
+// ahead: a level is ~8 rows and ~0.3 us of work, a load from HBM ~2 us, so the entries of the group's row travel FOUR levels
+// ahead (four row images in registers, the loop unrolled by four so that they keep their registers) and its 16-byte
+// descriptor five -- the dependent chain descriptor -> entries never sits between two barriers.
+constexpr int kSubK = 4;
+struct SubDesc { long long start; int n, i; };   // i < 0: the group has no row in the level
+struct SubRow {
+  SubDesc d;
+  double piv;
+  double v[kSubK];
+  int c[kSubK];
+};
+__device__ __forceinline__ SubDesc sub_desc_at(const long long *__restrict__ D, long long q) {
+  SubDesc d;
+  d.start = D[2 * q];
+  const long long w = D[2 * q + 1];
+  d.n = (int)(w & 0xffffffffLL);
+  d.i = (int)(w >> 32);
+  return d;
+}
+__device__ __forceinline__ SubDesc sub_desc_get(const long long *__restrict__ D, const int *__restrict__ lp, int l, int nlev, int grp) {
+  SubDesc d{0, 0, -1};
+  if (l < nlev) {
+    const int q = lp[l] + grp;
+    if (q < lp[l + 1]) d = sub_desc_at(D, q);
+  }
+  return d;
+}
+__device__ __forceinline__ void sub_row_load(SubRow &R, const SubDesc &d, bool upper, int base, int sub,
+                                             const int *__restrict__ ci, const double *__restrict__ val) {
+  R.d = d;
+  R.piv = (upper && d.i >= 0) ? val[d.start - 1] : 1.0;   // the pivot sits in front of the upper part
+#pragma unroll
+  for (int k = 0; k < kSubK; ++k) {
+    const int t = sub + 16 * k;
+    const bool in = t < d.n;
+    R.v[k] = in ? val[d.start + t] : 0.0;
+    R.c[k] = in ? ci[d.start + t] - base : 0;
+  }
+}
+__device__ __forceinline__ void sub_row_apply(const SubRow &R, bool upper, int base, int sub, const int *__restrict__ ci,
+                                              const double *__restrict__ val, double *sub_y) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kSubK; ++k) acc = fma(R.v[k], sub_y[R.c[k]], acc);   // absent entries: 0 * y[0]
+  for (int t = sub + 16 * kSubK; t < R.d.n; t += 16) acc = fma(val[R.d.start + t], sub_y[ci[R.d.start + t] - base], acc);
+  acc = group16_sum(acc);
+  if (R.d.i >= 0 && sub == 0) sub_y[R.d.i - base] = upper ? (sub_y[R.d.i - base] - acc) / R.piv : sub_y[R.d.i - base] - acc;
+}
+
+__global__ __launch_bounds__(256) void k_gilu_solve_sub(const int *__restrict__ loc_ptr, const int *__restrict__ rows,
+                                                        const long long *__restrict__ desc, const long long *__restrict__ dofs,
+                                                        const int *__restrict__ lptr, const int *__restrict__ lofs,
+                                                        const int *__restrict__ nlow_levels, const int *__restrict__ ci,
+                                                        const double *__restrict__ val, const double *__restrict__ r,
+                                                        double *__restrict__ w) {
+  extern __shared__ double sub_y[];
+  const int s = blockIdx.x, base = loc_ptr[s], m = loc_ptr[s + 1] - base;
+  const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15, ngrp = blockDim.x >> 4;
+  const long long *D = desc + 2 * dofs[s];
+  const int *lp = lptr + lofs[s];
+  const int nlev = lofs[s + 1] - lofs[s] - 1, nL = nlow_levels[s];
+  SubRow r0, r1, r2, r3;
+  sub_row_load(r0, sub_desc_get(D, lp, 0, nlev, grp), 0 >= nL, base, sub, ci, val);
+  sub_row_load(r1, sub_desc_get(D, lp, 1, nlev, grp), 1 >= nL, base, sub, ci, val);
+  sub_row_load(r2, sub_desc_get(D, lp, 2, nlev, grp), 2 >= nL, base, sub, ci, val);
+  sub_row_load(r3, sub_desc_get(D, lp, 3, nlev, grp), 3 >= nL, base, sub, ci, val);
+  SubDesc dpend = sub_desc_get(D, lp, 4, nlev, grp);   // descriptor of the row four levels ahead of the level at hand
+  for (int t = tid; t < m; t += blockDim.x) sub_y[t] = r[rows[base + t]];
+  __syncthreads();
+  // level `lvl` with the row image R, then R is refilled for level lvl + 4 (its descriptor arrived a level ago)
+#define ISPH_SUB_STEP(R, lvl)                                                                                   \
+  {                                                                                                             \
+    const int l_ = (lvl);                                                                                       \
+    const bool upper_ = l_ >= nL;                                                                               \
+    const SubDesc dn_ = sub_desc_get(D, lp, l_ + 5, nlev, grp);                                                 \
+    sub_row_apply(R, upper_, base, sub, ci, val, sub_y);                                                        \
+    for (int q = lp[l_] + grp + ngrp; q < lp[l_ + 1]; q += ngrp) { /* more rows than groups: the rest from memory */ \
+      SubRow extra_;                                                                                            \
+      sub_row_load(extra_, sub_desc_at(D, q), upper_, base, sub, ci, val);                                      \
+      sub_row_apply(extra_, upper_, base, sub, ci, val, sub_y);                                                 \
+    }                                                                                                           \
+    sub_row_load(R, dpend, l_ + 4 >= nL, base, sub, ci, val);                                                   \
+    dpend = dn_;                                                                                                \
+    __syncthreads();                                                                                            \
+  }
+  for (int l = 0; l < nlev; l += 4) {   // the conditions are uniform over the workgroup
+    ISPH_SUB_STEP(r0, l)
+    if (l + 1 < nlev) ISPH_SUB_STEP(r1, l + 1)
+    if (l + 2 < nlev) ISPH_SUB_STEP(r2, l + 2)
+    if (l + 3 < nlev) ISPH_SUB_STEP(r3, l + 3)
+  }
+#undef ISPH_SUB_STEP
+  for (int t = tid; t < m; t += blockDim.x) w[base + t] = sub_y[t];
 }
 
 // ---- synchronisation-free sweeps ----------------------------------------------------------------------------------
@@ -594,6 +709,7 @@ inline void schwarz_destroy(isph_schwarz *S) {
   if (!S) return;
   S->rp.release(); S->ci.release(); S->dg.release(); S->val.release(); S->w.release(); S->rows.release();
   S->lord.release(); S->uord.release(); S->rev_ptr.release(); S->rev_idx.release(); S->err.release();
+  S->sub_desc.release(); S->sub_lptr.release(); S->sub_lofs.release(); S->sub_nl.release(); S->sub_dofs.release(); S->loc_ptr_dev.release();
   S->lord4.release(); S->uord4.release(); S->lpos4.release(); S->upos4.release(); S->lrun.release(); S->urun.release(); S->ctr.release(); S->ybits.release(); S->zbits.release();
   if (S->h_tmo) (void)hipHostFree(S->h_tmo);
   delete S;
@@ -604,24 +720,68 @@ inline void schwarz_destroy(isph_schwarz *S) {
 // host array that is either a std::vector taken over from the caller or a block whose elements are NOT value-initialised:
 // the 4.4 GB of factor arrays of a 10^6-row ILU(1) pattern are written once, by 16 threads -- a std::vector::resize would
 // first zero them on one
+// Process-wide cache of the large HOST work arrays of schwarz_create.  The preconditioner is rebuilt every solve
+// (solver_lin_belos.h:153,190); at 10^6 rows its set-up touches 4-6 GB of host arrays, and with malloc / free per call the
+// first-touch page faults and the munmap of those pages cost more than the work done on them (0.6 s of a 1.5 s create).
+// Blocks are reused when the request fits within 50 % slack; at most kCapBytes stay cached; isph_pool_trim() frees them.
+struct HostPool {
+  static constexpr size_t kCapBytes = (size_t)24 << 30;
+  std::multimap<size_t, void *> blocks;
+  size_t cached = 0;
+  std::mutex mu;
+  static HostPool &get() { static HostPool p; return p; }
+  void *alloc(size_t bytes, size_t *got) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = blocks.lower_bound(bytes);
+      if (it != blocks.end() && it->first <= bytes + bytes / 2 + 4096) {
+        void *p = it->second;
+        *got = it->first;
+        cached -= it->first;
+        blocks.erase(it);
+        return p;
+      }
+    }
+    *got = bytes;
+    return malloc(bytes > 0 ? bytes : 1);
+  }
+  void release(void *p, size_t bytes) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes >= ((size_t)1 << 20) && cached + bytes <= kCapBytes) { blocks.emplace(bytes, p); cached += bytes; }
+    else free(p);
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &kv : blocks) free(kv.second);
+    blocks.clear();
+    cached = 0;
+  }
+};
+
 template <class T>
 struct HostArr {
   using value_type = T;
   std::vector<T> v;
   T *raw = nullptr;
-  size_t n = 0;
+  size_t n = 0, bytes = 0;
   HostArr() = default;
   HostArr(const HostArr &) = delete;
   HostArr &operator=(const HostArr &) = delete;
-  ~HostArr() { free(raw); }
-  bool alloc(size_t k) { free(raw); raw = static_cast<T *>(malloc((k > 0 ? k : 1) * sizeof(T))); n = k; return raw != nullptr; }
+  ~HostArr() { HostPool::get().release(raw, bytes); }
+  bool alloc(size_t k) {
+    HostPool::get().release(raw, bytes);
+    raw = static_cast<T *>(HostPool::get().alloc((k > 0 ? k : 1) * sizeof(T), &bytes));
+    n = k;
+    return raw != nullptr;
+  }
   T *data() { return raw ? raw : v.data(); }
   const T *data() const { return raw ? raw : v.data(); }
   size_t size() const { return raw ? n : v.size(); }
   bool empty() const { return size() == 0; }
   T &operator[](size_t i) { return data()[i]; }
   const T &operator[](size_t i) const { return data()[i]; }
-  void swap(HostArr &o) { v.swap(o.v); std::swap(raw, o.raw); std::swap(n, o.n); }
+  void swap(HostArr &o) { v.swap(o.v); std::swap(raw, o.raw); std::swap(n, o.n); std::swap(bytes, o.bytes); }
 };
 
 // keep != nullptr: the CSR image is written into keep's factor arrays and stays there; only the pattern comes to the
@@ -886,6 +1046,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   }
   S->t_ms[0] = ms_since(t0); t0 = clk();
   S->n = n; S->fill = fill; S->overlap = overlap; S->combine = combine; S->syncfree = syncfree;
+  S->syncfree_requested = syncfree;
   // ---- subdomains: consecutive owned ranges, extended by `overlap` layers (ascending global row per layer)
   const int B = block_size > 0 ? block_size : (n > 0 ? n : 1);
   const int nsub = n > 0 ? (n + B - 1) / B : 0;
@@ -1065,10 +1226,21 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     frp.swap(lrp);  // the local matrix IS the factor pattern: no second copy of 1.2 GB at 10^6 rows
     fci.swap(lci);
     fv.swap(lv);
-    for (int q = 0; q < nloc; ++q) {
-      const int *b = fci.data() + frp[(size_t)q], *e = fci.data() + frp[(size_t)q + 1];
-      const auto it = std::lower_bound(b, e, q);
-      if (it == e || *it != q) missing_diag = true; else fdg[(size_t)q] = (int)(it - b);
+    {
+      const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      std::vector<char> miss((size_t)nth, 0);
+      auto find_diag = [&](int t) {
+        const int q0 = (int)((long long)nloc * t / nth), q1 = (int)((long long)nloc * (t + 1) / nth);
+        for (int q = q0; q < q1; ++q) {
+          const int *b = fci.data() + frp[(size_t)q], *e = fci.data() + frp[(size_t)q + 1];
+          const auto it = std::lower_bound(b, e, q);
+          if (it == e || *it != q) miss[(size_t)t] = 1; else fdg[(size_t)q] = (int)(it - b);
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 0; t < nth; ++t) th.emplace_back(find_diag, t);
+      for (auto &x : th) x.join();
+      for (char c : miss) missing_diag = missing_diag || c;
     }
     if (missing_diag) { schwarz_destroy(S); return fail("structurally missing diagonal in a Schwarz subdomain", __FILE__, __LINE__); }
   } else {
@@ -1168,7 +1340,33 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   // ---- dependency levels of the two solves (the factorisation follows the L levels)
   std::vector<int> llev((size_t)nloc, 0), ulev((size_t)nloc, 0);
   int nl = 0, nu = 0;
-  {   // the two recurrences are sequential in themselves and independent of each other: one thread each
+  if (nsub >= 4) {
+    // a row only depends on rows of its own subdomain: the recurrences of different subdomains run on different threads
+    const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<int> tnl((size_t)nth, 0), tnu((size_t)nth, 0);
+    auto rec = [&](int t) {
+      for (int sd = t; sd < nsub; sd += nth) {
+        const int q0 = S->loc_ptr[(size_t)sd], q1 = S->loc_ptr[(size_t)sd + 1];
+        for (int q = q0; q < q1; ++q) {
+          int l = 0;
+          const long long b = frp[(size_t)q];
+          for (int k = 0; k < fdg[(size_t)q]; ++k) l = std::max(l, llev[(size_t)fci[(size_t)(b + k)]] + 1);
+          llev[(size_t)q] = l;
+          tnl[(size_t)t] = std::max(tnl[(size_t)t], l + 1);
+        }
+        for (int q = q1 - 1; q >= q0; --q) {
+          int l = 0;
+          for (long long p = frp[(size_t)q] + fdg[(size_t)q] + 1; p < frp[(size_t)q + 1]; ++p) l = std::max(l, ulev[(size_t)fci[(size_t)p]] + 1);
+          ulev[(size_t)q] = l;
+          tnu[(size_t)t] = std::max(tnu[(size_t)t], l + 1);
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t) th.emplace_back(rec, t);
+    for (auto &x : th) x.join();
+    for (int t = 0; t < nth; ++t) { nl = std::max(nl, tnl[(size_t)t]); nu = std::max(nu, tnu[(size_t)t]); }
+  } else {   // the two recurrences are sequential in themselves and independent of each other: one thread each
     std::thread tl([&] {
       for (int q = 0; q < nloc; ++q) {
         int l = 0;
@@ -1193,7 +1391,70 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   // level is amortised and streams the rows at full width -- 512-row blocks + one overlap layer at 10^6 rows (294
   // levels of 15 000 rows): application 5.2 ms with level launches, 11.6 ms persistent; factorisation 106 / 234 ms.
   if (syncfree && nloc > 0 && nloc / std::max(1, std::min(nl, nu)) >= kGiluWideLevel) syncfree = false;
+  // many small subdomains: one workgroup per subdomain does both sweeps (k_gilu_solve_sub); `syncfree == false` on entry
+  // (isph_schwarz_params::level_launches) keeps the launch per level as the cross-check
+  int maxsub = 0;
+  for (int sd = 0; sd < nsub; ++sd) maxsub = std::max(maxsub, S->loc_ptr[(size_t)sd + 1] - S->loc_ptr[(size_t)sd]);
+  S->sub_maxrows = maxsub;
+  S->subsweep = S->syncfree_requested && nsub >= kSubSweepMinSubs && maxsub <= kSubSweepMaxRows;
+  if (S->subsweep) syncfree = false;
   S->syncfree = syncfree;
+  std::vector<long long> sub_desc, sub_dofs;
+  std::vector<int> sub_lptr, sub_lofs, sub_nl;
+  if (S->subsweep) {
+    sub_dofs.assign((size_t)nsub + 1, 0);
+    sub_lofs.assign((size_t)nsub + 1, 0);
+    sub_nl.assign((size_t)nsub, 0);
+    std::vector<int> snl((size_t)nsub, 0), snu((size_t)nsub, 0);
+    for (int sd = 0; sd < nsub; ++sd) {
+      int a = 0, b = 0, lev0 = 0;
+      for (int q = S->loc_ptr[(size_t)sd]; q < S->loc_ptr[(size_t)sd + 1]; ++q) {
+        a = std::max(a, llev[(size_t)q] + 1); b = std::max(b, ulev[(size_t)q] + 1);
+        lev0 += llev[(size_t)q] == 0;
+      }
+      snl[(size_t)sd] = a; snu[(size_t)sd] = b;
+      const int m = S->loc_ptr[(size_t)sd + 1] - S->loc_ptr[(size_t)sd];
+      sub_nl[(size_t)sd] = a > 0 ? a - 1 : 0;                                         // L level 0 has nothing to subtract
+      sub_lofs[(size_t)sd + 1] = sub_lofs[(size_t)sd] + sub_nl[(size_t)sd] + b + 1;
+      sub_dofs[(size_t)sd + 1] = sub_dofs[(size_t)sd] + (m - lev0) + m;
+    }
+    sub_lptr.assign((size_t)sub_lofs[(size_t)nsub], 0);
+    sub_desc.resize((size_t)(2 * sub_dofs[(size_t)nsub]));
+    const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto orders = [&](int t) {
+      std::vector<int> cnt, ord;
+      for (int sd = t; sd < nsub; sd += nth) {
+        const int q0 = S->loc_ptr[(size_t)sd], m = S->loc_ptr[(size_t)sd + 1] - q0;
+        int *lp = sub_lptr.data() + sub_lofs[(size_t)sd];
+        long long *D = sub_desc.data() + 2 * sub_dofs[(size_t)sd];
+        int pos = 0, lv = 0;
+        ord.resize((size_t)m);
+        for (int dir = 0; dir < 2; ++dir) {
+          const std::vector<int> &lev = dir == 0 ? llev : ulev;
+          const int nlv = dir == 0 ? snl[(size_t)sd] : snu[(size_t)sd];
+          cnt.assign((size_t)nlv + 1, 0);
+          for (int q = 0; q < m; ++q) ++cnt[(size_t)lev[(size_t)(q0 + q)] + 1];
+          for (int l = 0; l < nlv; ++l) cnt[(size_t)l + 1] += cnt[(size_t)l];
+          std::vector<int> cur(cnt.begin(), cnt.end() - 1);
+          for (int q = 0; q < m; ++q) ord[(size_t)cur[(size_t)lev[(size_t)(q0 + q)]]++] = q0 + q;   // ascending row inside a level
+          for (int l = dir == 0 ? 1 : 0; l < nlv; ++l) {
+            lp[lv++] = pos;
+            for (int k = cnt[(size_t)l]; k < cnt[(size_t)l + 1]; ++k, ++pos) {
+              const int i = ord[(size_t)k];
+              const long long start = dir == 0 ? frp[(size_t)i] : frp[(size_t)i] + fdg[(size_t)i] + 1;
+              const int nn = dir == 0 ? fdg[(size_t)i] : (int)(frp[(size_t)i + 1] - start);
+              D[2 * (size_t)pos] = start;
+              D[2 * (size_t)pos + 1] = ((long long)i << 32) | (unsigned int)nn;
+            }
+          }
+        }
+        lp[lv] = pos;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t) th.emplace_back(orders, t);
+    for (auto &x : th) x.join();
+  }
   auto bucket = [&](const std::vector<int> &lev, int nlev, std::vector<int> &ptr, std::vector<int> &ord) {
     ptr.assign((size_t)nlev + 1, 0);
     for (int q = 0; q < nloc; ++q) ++ptr[(size_t)lev[(size_t)q] + 1];
@@ -1216,8 +1477,10 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     }
   };
   std::vector<int> lord4, uord4;
-  pad4(S->lptr, lord, lord4);
-  pad4(S->uptr, uord, uord4);
+  if (syncfree) {   // only the persistent sweeps read these
+    pad4(S->lptr, lord, lord4);
+    pad4(S->uptr, uord, uord4);
+  }
   S->n4l = (int)lord4.size(); S->n4u = (int)uord4.size();
   // runs of the LDS hand-off sweeps: whole levels, at most kRun positions (a level longer than that is cut)
   auto runs_of = [&](const std::vector<int> &ptr, std::vector<int> &rs) {
@@ -1234,13 +1497,15 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     }
     if (cur > 0) rs.push_back(pos);
   };
-  std::vector<int> lrun, urun;
-  runs_of(S->lptr, lrun);
-  runs_of(S->uptr, urun);
-  S->nrun_l = (int)lrun.size() - 1; S->nrun_u = (int)urun.size() - 1;
-  std::vector<int> lpos4((size_t)nloc, 0), upos4((size_t)nloc, 0);
-  for (size_t q = 0; q < lord4.size(); ++q) if (lord4[q] >= 0) lpos4[(size_t)lord4[q]] = (int)q;
-  for (size_t q = 0; q < uord4.size(); ++q) if (uord4[q] >= 0) upos4[(size_t)uord4[q]] = (int)q;
+  std::vector<int> lrun, urun, lpos4, upos4;
+  if (syncfree) {
+    runs_of(S->lptr, lrun);
+    runs_of(S->uptr, urun);
+    S->nrun_l = (int)lrun.size() - 1; S->nrun_u = (int)urun.size() - 1;
+    lpos4.assign((size_t)nloc, 0); upos4.assign((size_t)nloc, 0);
+    for (size_t q = 0; q < lord4.size(); ++q) if (lord4[q] >= 0) lpos4[(size_t)lord4[q]] = (int)q;
+    for (size_t q = 0; q < uord4.size(); ++q) if (uord4[q] >= 0) upos4[(size_t)uord4[q]] = (int)q;
+  }
   // ---- combine lists: global row -> local rows (Add: every copy, Zero: the owned copy), subdomain order
   std::vector<long long> rev_ptr((size_t)n + 1, 0);
   std::vector<int> rev_idx;
@@ -1278,6 +1543,14 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (rc == ISPH_SUCCESS) rc = up(S->rev_idx, rev_idx);
   if (rc == ISPH_SUCCESS) rc = S->w.reserve((size_t)(nloc > 0 ? nloc : 1));
   if (rc == ISPH_SUCCESS) rc = S->err.reserve(1);
+  if (rc == ISPH_SUCCESS && S->subsweep) {
+    rc = up(S->sub_desc, sub_desc);
+    if (rc == ISPH_SUCCESS) rc = up(S->sub_dofs, sub_dofs);
+    if (rc == ISPH_SUCCESS) rc = up(S->sub_lptr, sub_lptr);
+    if (rc == ISPH_SUCCESS) rc = up(S->sub_lofs, sub_lofs);
+    if (rc == ISPH_SUCCESS) rc = up(S->sub_nl, sub_nl);
+    if (rc == ISPH_SUCCESS) rc = up(S->loc_ptr_dev, S->loc_ptr);
+  }
   if (rc == ISPH_SUCCESS && syncfree) {
     rc = up(S->lord4, lord4);
     if (rc == ISPH_SUCCESS) rc = up(S->uord4, uord4);
@@ -1373,6 +1646,16 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
 inline int schwarz_apply(isph_ctx *ctx, const isph_schwarz *S, const double *r, double *z) {
   if (S->n == 0) return ISPH_SUCCESS;
   const int nloc = S->nloc;
+  if (S->subsweep) {
+    const size_t lds = sizeof(double) * (size_t)S->sub_maxrows;
+    hipLaunchKernelGGL(k_gilu_solve_sub, dim3(S->nsub), dim3(256), lds, ctx->stream, (const int *)S->loc_ptr_dev.p, (const int *)S->rows.p,
+                       (const long long *)S->sub_desc.p, (const long long *)S->sub_dofs.p, (const int *)S->sub_lptr.p,
+                       (const int *)S->sub_lofs.p, (const int *)S->sub_nl.p, (const int *)S->ci.p, (const double *)S->val.p, r, S->w.p);
+    hipLaunchKernelGGL(k_gilu_combine, dim3((S->n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S->n, S->rev_ptr.p,
+                       S->rev_idx.p, (const double *)S->w.p, z);
+    ISPH_CHECK_HIP(hipGetLastError());
+    return ISPH_SUCCESS;
+  }
   hipLaunchKernelGGL(k_gilu_gather, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nloc, S->rows.p, r, S->w.p);
   if (S->syncfree) {
     // two persistent launches: L sweep (rhs = gathered r, results -> ybits), U sweep (rhs = y, results -> zbits)

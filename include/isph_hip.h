@@ -194,15 +194,17 @@ int isph_prec_create_blocks(isph_ctx *ctx, const isph_mat *A, int nblocks, const
  * of a parallel run.  isph_prec_create(type = "ilu<k>") is the block_size = 0 case.  Level-scheduled on the device:
  * the fidelity path; "bjacobi-ilu<k>" is the throughput path.
  * info: [0] extended rows [1] factor entries [2] subdomains [3] L levels [4] U levels [5] longest factor row
- * [6] 1 = persistent launches, 0 = one launch per dependency level (see level_launches).
+ * [6] 2 = one workgroup per subdomain does both sweeps (many small subdomains), 1 = persistent launches, 0 = one launch
+ * per dependency level (see level_launches).
  * export: rows[nloc] (global row of every local row), loc_ptr[nsub+1], factor CSR in local numbering. */
 typedef struct {
   int level_of_fill, overlap, combine, block_size;
-  int level_launches; /* 0 (default): the form is picked by the width of the dependency levels -- narrow levels (whole-
-                         matrix factors): the factorisation and every triangular sweep are ONE persistent launch whose
-                         rows wait for the rows they depend on; >= 4096 rows per level (many subdomains): one launch
-                         per level.  1: always one launch per level (the cross-check of the persistent form: same
-                         factor bit for bit, application equal to rounding) */
+  int level_launches; /* 0 (default): the form is picked by the shape of the problem -- >= 32 subdomains of <= 4096 rows:
+                         ONE launch per application, a workgroup per subdomain with its part of the vector in LDS and a
+                         barrier per level; narrow levels (whole-matrix factors): the factorisation and every triangular
+                         sweep are ONE persistent launch whose rows wait for the rows they depend on; otherwise one launch
+                         per level.  1: always one launch per level (the cross-check of the other forms: same factor bit
+                         for bit, application equal to rounding) */
 } isph_schwarz_params;
 void isph_schwarz_params_default(isph_schwarz_params *p);
 int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwarz_params *prm, isph_prec **M);

@@ -186,9 +186,10 @@ def test_synchronisation_free_sweeps_equal_the_level_launches(gpu_ctx, n, fill, 
 
 
 def test_form_of_the_sweeps_follows_the_width_of_the_levels(gpu_ctx):
-    """create() picks the persistent launches for long, narrow dependency chains (one subdomain = the whole matrix) and
-    one launch per level where a level holds thousands of rows (many small subdomains: csrc/schwarz.hpp kGiluWideLevel,
-    measured in profiles/r03_schwarz_syncfree.txt); both give the oracle's preconditioner."""
+    """create() picks the persistent launches for long, narrow dependency chains (one subdomain = the whole matrix), and for
+    many small subdomains -- where a level holds thousands of short rows (csrc/schwarz.hpp kGiluWideLevel, measured in
+    profiles/r03_schwarz_syncfree.txt) -- one workgroup per subdomain (round 4, k_gilu_solve_sub; the launch per level it
+    replaces stays selectable and must agree to rounding); all give the oracle's preconditioner."""
     sp = tgv_spec(dim=3, n=64, mode=workload.JITTER)
     p = workload.make_tgv(sp)
     colmap = workload.single_rank_colmap(p)
@@ -200,12 +201,49 @@ def test_form_of_the_sweeps_follows_the_width_of_the_levels(gpu_ctx):
     small = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=0, overlap=0, block_size=64)
     iw, ism = whole.schwarz_info(), small.schwarz_info()
     assert iw["persistent"] == 1 and iw["nloc"] // iw["levels_l"] < 4096
-    assert ism["persistent"] == 0 and ism["nloc"] // min(ism["levels_l"], ism["levels_u"]) >= 4096
+    assert ism["persistent"] == 2 and ism["nloc"] // min(ism["levels_l"], ism["levels_u"]) >= 4096
     forced = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=0, overlap=0, block_size=64, level_launches=True)
+    assert forced.schwarz_info()["persistent"] == 0
     r = np.random.default_rng(5).standard_normal(N)
-    assert np.array_equal(small.apply(r), forced.apply(r))
+    zs, zf = small.apply(r), forced.apply(r)
+    assert np.linalg.norm(zs - zf) <= 1e-13 * np.linalg.norm(zf)
     x = np.zeros(N)
     info = hip.solve(gpu_ctx, A, b.copy(), x, prec=small, singular=True)
     assert info.converged == 1
     for o in (whole, small, forced, A):
         o.close()
+
+
+@pytest.mark.parametrize("block,fill,overlap,combine", [(256, 0, 1, "add"), (256, 0, 1, "zero"), (192, 1, 1, "add"), (256, 1, 1, "zero"),
+                                                       (256, 0, 0, "add")])
+def test_many_small_subdomains_one_workgroup_per_subdomain(gpu_ctx, block, fill, overlap, combine):
+    """>= 32 subdomains of <= 4096 extended rows take the form with ONE launch per application (k_gilu_solve_sub: a
+    workgroup per subdomain, its part of the vector in LDS, a barrier per level).  Against the oracle like every other form
+    (row lists / pattern exact, factor 1e-10, application 1e-11, iterations +-1, x 1e-6) and against the launch per level on
+    the same factor (same bits in the factor, application equal to rounding)."""
+    pr = Problem(tgv_spec(dim=3, n=24, mode=workload.ADVECT))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    own = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
+    ref = orc.Schwarz(rp, ci, val, fill, own, overlap, combine)
+    orow, olp, orp, oci, ov = ref.export()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=fill, overlap=overlap, combine=combine, block_size=block)
+    assert M.schwarz_info()["persistent"] == 2 and M.schwarz_info()["nsub"] >= 32
+    Ml = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=fill, overlap=overlap, combine=combine, block_size=block, level_launches=True)
+    assert Ml.schwarz_info()["persistent"] == 0
+    rows, lp, grp, gci, gv = M.export()
+    assert np.array_equal(rows, orow) and np.array_equal(lp, olp)
+    assert np.array_equal(grp, orp) and np.array_equal(gci, oci)
+    assert _factor_close(gv, ov)
+    assert np.array_equal(gv, Ml.export()[4])
+    r = np.random.default_rng(7).standard_normal(n)
+    z, zl, zo = M.apply(r), Ml.apply(r), ref.apply(r)
+    assert np.linalg.norm(z - zo) / np.linalg.norm(zo) < 1e-11
+    assert np.linalg.norm(z - zl) / np.linalg.norm(zl) < 1e-13
+    assert np.array_equal(M.apply(r), z)                                  # the same bits from one application to the next
+    x = np.zeros(n)
+    info = hip.solve(gpu_ctx, A, b.copy(), x, prec=M, singular=True)
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=True, prec="schwarz", schwarz=ref)
+    assert info.converged == 1 and io.converged == 1 and abs(info.iters - io.iters) <= 1
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-6
