@@ -472,10 +472,9 @@ def test_rank_local_amg_across_ranks():
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] at its own size, on one GPU
-def _config2_rank(rank, G, n):
+def _config2_rank(rank, G, n, pgrid=(2, 2, 2)):
     import time
-    pgrid = (2, 2, 2)
-    spec = workload.TGVSpec(dim=3, ncell=(2 * n,) * 3, pgrid=pgrid, rank=rank, brick=(10, 10, 5), mode=workload.ADVECT)
+    spec = workload.TGVSpec(dim=3, ncell=tuple(n * g for g in pgrid), pgrid=pgrid, rank=rank, brick=(10, 10, 5), mode=workload.ADVECT)
     parts = dist.prune_ghosts(workload.make_tgv(spec))
     plan = dist.make_plan(parts, G.td(rank))
     ctx = G.context(rank)
