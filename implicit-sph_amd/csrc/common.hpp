@@ -242,12 +242,21 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// max over the 64 lanes, in every lane's return value.  DPP moves like wave_sum (a lane without a source keeps its own
+// value: max(v, v)); the __shfl_xor butterfly this replaces is six dependent ds_bpermute round trips, ~100 cycles each, and
+// sat in the sequential level walk of k_ilu_schedule once per row.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_keep_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ int wave_max_i32(int v) {
-  for (int o = 32; o > 0; o >>= 1) {
-    int t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
+  v = max(v, dpp_keep_i32<0x111>(v));        // row_shr:1
+  v = max(v, dpp_keep_i32<0x112>(v));        // row_shr:2
+  v = max(v, dpp_keep_i32<0x114>(v));        // row_shr:4
+  v = max(v, dpp_keep_i32<0x118>(v));        // row_shr:8   -> lane 15 of each row holds the row's max
+  v = max(v, dpp_keep_i32<0x142, 0xa>(v));   // row_bcast:15 into rows 1 and 3
+  v = max(v, dpp_keep_i32<0x143, 0xc>(v));   // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // sum within aligned groups of 8 lanes (result in every lane of the group)

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
   // next kLevAhead rows already requested.  (A relaxation over all rows needed one sweep per level, ~175 of them:
   // half of this kernel's time, and its LDS column cache kept the kernel at one workgroup per CU.)
   {
-    constexpr int kLevAhead = 4;
+    constexpr int kLevAhead = 16;  // a row is ~0.2 us of work and a column load ~2 us away: 4 rows ahead left the walk waiting (1.85 -> ms measured below)
     const int wave = t >> 6, lane = t & 63;
     const int nwalk = blockDim.x >= 128 ? 2 : 1;  // 64-row blocks have a single wave: it walks both directions
     for (int wdir = wave; wdir < 2; wdir += nwalk) {

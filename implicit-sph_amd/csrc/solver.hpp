@@ -296,6 +296,8 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
       hipLaunchKernelGGL((k_multi_axpy_dot<16>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
     else if (nk <= 32)
       hipLaunchKernelGGL((k_multi_axpy_dot<32>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
+    else if (nk <= 48)  // between the two: 96 + 96 registers keep two waves per SIMD where the 64-wide instance has one
+      hipLaunchKernelGGL((k_multi_axpy_dot<48>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
     else
       hipLaunchKernelGGL((k_multi_axpy_dot<64>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, dh1, w, ctx->partial.p);
   }
