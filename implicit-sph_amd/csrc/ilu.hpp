@@ -649,11 +649,16 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
       }
       const int lane = t & 63;
       for (int src = 0; src < 64; ++src) {
-        const int rT = __shfl(eT, src, 64);
+        // src is wave-uniform: v_readlane instead of a ds_bpermute round trip per value
+        auto from = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
+        auto from64 = [&](long long v) {
+          return (long long)(((unsigned long long)(unsigned)from((int)(v >> 32)) << 32) | (unsigned)from((int)v));
+        };
+        const int rT = from(eT);
         if (rT == 0) continue;  // row without work in this direction (wave-uniform)
-        const int rls = __shfl(els, src, 64), rinfo = __shfl(einfo, src, 64), rg = __shfl(eg, src, 64);
-        const int rnd = __shfl(ndep, src, 64), rd0 = __shfl(d0, src, 64);
-        const long long rrp = __shfl(rp, src, 64), rch0 = __shfl(ech0, src, 64);
+        const int rls = from(els), rinfo = from(einfo), rg = from(eg);
+        const int rnd = from(ndep), rd0 = from(d0);
+        const long long rrp = from64(rp), rch0 = from64(ech0);
         const int tot = rT * rg;
         for (int x = lane; x < tot; x += 64) {
           const int c = x / rg, q = x - c * rg, ln = rls + q;
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long 
 // kFacPrefetch steps ahead (no flags, no waiting inside a row).  LDS: diag[B],
 // frp/flen/fdiag[B], level order + offsets, per wave a row image (values,
 // columns) and a column->slot map.
-constexpr int kFacPrefetch = 4;
+constexpr int kFacPrefetch = 4;  // r4, with the readlane requests: 4 -> 3.62 ms, 6 -> 6.27, 8 -> 5.48 (the queue registers cost a wave per SIMD)
 constexpr int kFacPrefetchWide = 8;
 constexpr int kIluWaves = 8;
 
@@ -794,29 +799,56 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
       int pcq[kPF], pcq2[kPF];      // column of the prefetched U-row entries (-1: none for this lane)
       double pvq[kPF], pvq2[kPF];   // their values
       double pdq[kPF];   // 1/d_k of that step
-      auto request = [&](int s, int &pc, double &pvv, int &pc2, double &pvv2, double &pdv) {
+      int pnq[kPF];      // entries of that pivot row's upper part
+      // What a step needs to know about its pivot row -- where its upper part starts, how long it is, the reciprocal pivot --
+      // is looked up ONCE per row, one pivot per lane, and handed to the step by v_readlane (the step index is wave-uniform):
+      // the four dependent LDS reads this replaces sat on every step's path between its fence and its loads.  (All pivot
+      // rows belong to earlier levels: their tables are final.)  Pivots beyond the 64th of a row take the tables.
+      long long pbase = 0;
+      int pcnt = 0;
+      double pdk = 0.0;
+      if (lane < dg) {
+        const int k = mc[lane];
+        pbase = rpL[k] + dgL[k] + 1;
+        pcnt = lenL[k] - dgL[k] - 1;
+        pdk = diag[k];
+      }
+      auto request = [&](int s, int &pc, double &pvv, int &pc2, double &pvv2, double &pdv, int &pn) {
         pc = -1;
         pc2 = -1;
         pvv = 0.0;
         pvv2 = 0.0;
         pdv = 0.0;
+        pn = 0;
         if (s < dg) {
-          const int k = mc[s];
-          pdv = diag[k];
-          const int t = dgL[k] + 1 + lane;
-          const long long p = rpL[k] + t;
-          if (t < lenL[k]) {
+          long long p0;
+          int cnt;
+          if (s < 64) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)pbase, s);
+            const int hi = __builtin_amdgcn_readlane((int)(pbase >> 32), s);
+            p0 = (long long)(((unsigned long long)(unsigned)hi << 32) | lo);
+            cnt = __builtin_amdgcn_readlane(pcnt, s);
+            pdv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pdk), s), __builtin_amdgcn_readlane(__double2loint(pdk), s));
+          } else {
+            const int k = mc[s];
+            p0 = rpL[k] + dgL[k] + 1;
+            cnt = lenL[k] - dgL[k] - 1;
+            pdv = diag[k];
+          }
+          pn = cnt;
+          const long long p = p0 + lane;
+          if (lane < cnt) {
             pc = fcol[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
             pvv = fval[p];
           }
-          if (WIDE && t + 64 < lenL[k]) {
+          if (WIDE && lane + 64 < cnt) {
             pc2 = fcol[p + 64];
             pvv2 = fval[p + 64];
           }
         }
       };
 #pragma unroll
-      for (int u = 0; u < kPF; ++u) request(u, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
+      for (int u = 0; u < kPF; ++u) request(u, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u], pnq[u]);
       for (int s0 = 0; s0 < dg; s0 += kPF) {
 #pragma unroll
         for (int u = 0; u < kPF; ++u) {
@@ -829,16 +861,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
             if (lane == 0) mv[s] = lik;
             if (ps) mv[ps - 1] -= lik * pvq[u];
             if (WIDE && ps2) mv[ps2 - 1] -= lik * pvq2[u];
-            const int k = mc[s];
-            // U-rows wider than the prefetched part
-            for (int t = dgL[k] + 1 + (WIDE ? 128 : 64) + lane; t < lenL[k]; t += 64) {
-              const long long p = rpL[k] + t;
-              const int ps3 = mp[fcol[p] - blo];
-              if (ps3) mv[ps3 - 1] -= lik * fval[p];
+            if (pnq[u] > (WIDE ? 128 : 64)) {  // U-rows wider than the prefetched part (wave-uniform)
+              const int k = mc[s];
+              for (int t = dgL[k] + 1 + (WIDE ? 128 : 64) + lane; t < lenL[k]; t += 64) {
+                const long long p = rpL[k] + t;
+                const int ps3 = mp[fcol[p] - blo];
+                if (ps3) mv[ps3 - 1] -= lik * fval[p];
+              }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            request(s + kPF, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u]);
+            request(s + kPF, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u], pnq[u]);
           }
         }
       }
