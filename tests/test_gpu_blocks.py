@@ -110,3 +110,34 @@ def test_cpp_mirror_with_subdomain_table(gpu_ctx, tmp_path):
     its = [int(t.split(":")[1].split(",")[0]) for t in r.stdout.split('"iterations"')[1:2]]
     assert abs(its[0] - io.iters) <= 1, (its, io.iters)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+
+
+def test_profile_mode_counts_the_launches_of_every_kernel_class(gpu_ctx):
+    """isph_ctx_profile_read: HIP events around the hot kernels by class.  One set-up + one FGMRES solve with the block
+    ILU(0): one extract / schedule / factor launch, one preconditioner application and one Gram-Schmidt step (three
+    sweeps) per iteration, SpMVs = iterations + one residual per cycle + the explicit residual; the solve's own
+    spmv_calls agrees; times are positive and add up to less than the wall time of the bracket."""
+    import time
+    pr = Problem(tgv_spec(dim=3, n=24, mode=workload.JITTER))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    gpu_ctx.sync()
+    gpu_ctx.set_profile(True)
+    try:
+        t0 = time.perf_counter()
+        M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 512)
+        x, bb = np.zeros(n), b.copy()
+        info = hip.solve(gpu_ctx, A, bb, x, prec=M, singular=True)
+        prof = gpu_ctx.profile_read()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+    finally:
+        gpu_ctx.set_profile(False)
+    cycles = info.restarts + 1
+    assert prof["ilu_extract"][1] == prof["ilu_schedule"][1] == prof["ilu_factor"][1] == 1
+    assert prof["prec_apply"][1] in (info.iters, info.iters + 1)          # + 1: a speculative application behind the last column
+    assert prof["multi_dot"][1] == prof["multi_axpy_dot"][1] == prof["multi_axpy_norm"][1] == info.iters
+    assert prof["spmv"][1] in (info.iters + cycles + 1, info.iters + cycles + 2) and info.spmv_calls == prof["spmv"][1]
+    assert all(ms > 0.0 for ms, calls in prof.values() if calls) and sum(ms for ms, _ in prof.values()) < wall_ms
+    assert gpu_ctx.profile_read()["spmv"] == (0.0, 0)                     # reading starts a new collection
+    M.close(); A.close()
