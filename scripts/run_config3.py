@@ -1,6 +1,8 @@
 """BASELINE configs[3]-shaped step (closed lid-driven cavity, 114^3 fluid + 6 wall layers = 2.0 M particles): stage times
 of computePre, the 3x3 block Helmholtz system (Navier-slip walls) and the pressure Poisson system with wall Neumann rows.
-usage: python scripts/run_config3.py [fluid cells per side] [bjacobi-ilu0 | sa-amg]
+usage: python scripts/run_config3.py [fluid cells per side] [bjacobi-ilu0 | sa-amg] [brick, e.g. 9,9,6]
+A brick that tiles the lattice (fluid + 2 x 6 wall cells per side) and holds <= 1024 particles makes the bricks the
+block-Jacobi subdomains (isph_prec_create_blocks) instead of 512 consecutive rows of the 8x8x8 numbering.
 (lid-driven-cavity.xml:30-32 selects ML: sa-amg is the reference's setting for this case)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,8 +17,11 @@ THETA, BETA = 0.5, 0.0
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
 ctx = hip.Context(0, stream=st.cuda_stream)
-p = workload.make_cavity(nf, wall=6)
+brick = tuple(int(t) for t in sys.argv[3].split(",")) if len(sys.argv) > 3 else (8, 8, 8)
+p = workload.make_cavity(nf, wall=6, brick=brick)
 n, nall = p["nlocal"], p["nall"]
+brows = brick[0] * brick[1] * brick[2]
+bptr = np.arange(0, n + brows, brows).clip(0, n).astype(np.int32) if all((nf + 12) % k == 0 for k in brick) and brows <= 1024 else None
 colmap_h = workload.single_rank_colmap(p)
 dp = dict(p)
 for k in ("x", "type", "neigh_ptr", "neigh_idx"):
@@ -35,7 +40,7 @@ def sync():
     return time.perf_counter()
 
 
-print("particles %d, preconditioner %s" % (n, prec), flush=True)
+print("particles %d, preconditioner %s, subdomains %s" % (n, prec, ("%dx%dx%d bricks" % brick) if bptr is not None else "512 consecutive rows"), flush=True)
 for step in range(3):
     t0 = sync()
     vf = hip.compute_volumes(ctx, dp, colmap)
@@ -47,7 +52,7 @@ for step in range(3):
                                              vel, normal=nrm, vfrac=vfrac, Gc=Gc, kinds=p["kinds"])
     t2 = sync()
     x = vel[:n].t().contiguous().reshape(-1).clone()
-    M = hip.PrecondAMG(ctx, blocks[0][0], params=hip.AmgParams(block=512)) if prec == "sa-amg" else hip.Precond(ctx, blocks[0][0], prec, 512)
+    M = hip.PrecondAMG(ctx, blocks[0][0], params=hip.AmgParams(block=512)) if prec == "sa-amg" else (hip.Precond(ctx, blocks[0][0], prec, block_ptr=bptr) if bptr is not None and prec == "bjacobi-ilu0" else hip.Precond(ctx, blocks[0][0], prec, 512))
     info = hip.solve_block(ctx, blocks, b.clone(), x, prec=M)
     t3 = sync()
     vs = x.reshape(3, n).t().contiguous()
@@ -65,7 +70,7 @@ for step in range(3):
         nvh = mask.astype(np.float64) / np.sqrt(float(mask.sum()))
         MP = hip.PrecondAMG(ctx, A, nullvec=torch.from_numpy(nvh).to(dev), params=hip.AmgParams(block=512))
     else:
-        MP = hip.Precond(ctx, A, prec, 512)
+        MP = hip.Precond(ctx, A, prec, block_ptr=bptr) if bptr is not None and prec == "bjacobi-ilu0" else hip.Precond(ctx, A, prec, 512)
     ip = hip.solve(ctx, A, bp.clone(), xp, prec=MP, singular=True, null_mask=mask)
     t5 = sync()
     print("step %d: computePre %.1f  block-Helmholtz assembly %.1f  block solve(+ILU) %.1f [%d its, conv %d]  Poisson assembly %.1f  "
