@@ -69,9 +69,8 @@ struct isph_schwarz {
   // and the number of L levels in the list
   bool subsweep = false, syncfree_requested = true;
   int sub_maxrows = 0;
-  isph::DevBuf<long long> sub_desc;              // [2 x 8 bytes per listed row]: start | n, i
-  isph::DevBuf<int> sub_lptr, sub_lofs, sub_nl, loc_ptr_dev;
-  isph::DevBuf<long long> sub_dofs;
+  isph::DevBuf<long long> sub_desc;              // [2 x 8 bytes per listed row]: start | n, i  (layout: k_gilu_sub_levels)
+  isph::DevBuf<int> sub_lptr, sub_nlist, loc_ptr_dev;
   int *h_tmo = nullptr;   // pinned: the time-out word of the last application (read by prec_health with the stream drained)
   // persistent workgroups (1024 threads) of the L / U sweep, and how many earlier runs may still be open when a run
   // starts polling (k_gilu_solve_run): both follow the width of the levels
@@ -191,6 +190,8 @@ __global__ __launch_bounds__(256) void k_gilu_upper(int count, const int *__rest
 // sweep then U sweep, result to w for k_gilu_combine.  Rows of a subdomain only depend on rows of the same subdomain.
 constexpr int kSubSweepMaxRows = 4096;   // 32 KB of LDS per workgroup
 constexpr int kSubSweepMinSubs = 32;     // fewer subdomains do not fill the chip this way
+constexpr int kSubFactorMaxRow = 1024;   // longest factor row of the per-subdomain factorisation (row image: 12 B per entry and wave;
+                                         // eight waves per subdomain up to 512 entries, four beyond: 48 KB of LDS either way)
 // one row of a level as a group of 16 lanes holds it: up to kSubK entries per lane in registers (rows of up to 16 kSubK
 // entries on the side in question; longer ones finish from memory).  Nothing of it depends on the vector, so it is fetched
 // ahead: a level is ~8 rows and ~0.3 us of work, a load from HBM ~2 us, so the entries of the group's row travel FOUR levels
@@ -243,17 +244,16 @@ __device__ __forceinline__ void sub_row_apply(const SubRow &R, bool upper, int b
 }
 
 __global__ __launch_bounds__(256) void k_gilu_solve_sub(const int *__restrict__ loc_ptr, const int *__restrict__ rows,
-                                                        const long long *__restrict__ desc, const long long *__restrict__ dofs,
-                                                        const int *__restrict__ lptr, const int *__restrict__ lofs,
-                                                        const int *__restrict__ nlow_levels, const int *__restrict__ ci,
+                                                        const long long *__restrict__ desc, const int *__restrict__ lptr,
+                                                        const int *__restrict__ nlist, const int *__restrict__ ci,
                                                         const double *__restrict__ val, const double *__restrict__ r,
                                                         double *__restrict__ w) {
   extern __shared__ double sub_y[];
   const int s = blockIdx.x, base = loc_ptr[s], m = loc_ptr[s + 1] - base;
   const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15, ngrp = blockDim.x >> 4;
-  const long long *D = desc + 2 * dofs[s];
-  const int *lp = lptr + lofs[s];
-  const int nlev = lofs[s + 1] - lofs[s] - 1, nL = nlow_levels[s];
+  const long long *D = desc + 2 * (2 * (long long)base);   // the layout of k_gilu_sub_levels
+  const int *lp = lptr + 2 * base + 2 * s;
+  const int nL = nlist[2 * s], nlev = nlist[2 * s + 1];
   SubRow r0, r1, r2, r3;
   sub_row_load(r0, sub_desc_get(D, lp, 0, nlev, grp), 0 >= nL, base, sub, ci, val);
   sub_row_load(r1, sub_desc_get(D, lp, 1, nlev, grp), 1 >= nL, base, sub, ci, val);
@@ -286,6 +286,215 @@ __global__ __launch_bounds__(256) void k_gilu_solve_sub(const int *__restrict__ 
   }
 #undef ISPH_SUB_STEP
   for (int t = tid; t < m; t += blockDim.x) w[base + t] = sub_y[t];
+}
+
+// ---- many small subdomains: level analysis and numeric factorisation on the device ------------------------------------
+// k_gilu_sub_levels: one workgroup (two waves) per subdomain.  Wave 0 walks the rows upwards for the L levels, wave 1
+// downwards for the U levels (lev = 1 + max over the dependencies, which all lie in the same subdomain), lanes over a
+// row's dependencies, the columns of the next eight rows already requested; then both directions are sorted by level
+// (ascending row inside a level) straight into the descriptor list of k_gilu_solve_sub: L levels 1 .., then U levels 0 ..
+// Replaces the host recurrences + orders of schwarz_create for this form.
+// Layout (upper bounds, no prefix sums): subdomain s with m rows at base owns descriptor slots 2 base .. 2 base + 2 m and
+// level starts 2 base + 2 s .. + 2 m + 2; nlist[2 s] = listed L levels, nlist[2 s + 1] = all listed levels;
+// maxlev[0 / 1] = deepest L / U level count over all subdomains.
+__global__ __launch_bounds__(128) void k_gilu_sub_levels(const int *__restrict__ loc_ptr, const long long *__restrict__ rp,
+                                                         const int *__restrict__ ci, const int *__restrict__ dg,
+                                                         long long *__restrict__ desc, int *__restrict__ lptr,
+                                                         int *__restrict__ nlist, int *__restrict__ maxlev) {
+  extern __shared__ int sub_lds[];
+  const int s = blockIdx.x, base = loc_ptr[s], m = loc_ptr[s + 1] - base;
+  int *levL = sub_lds, *levU = levL + m, *cnt = levU + m;   // cnt: [m + 2]
+  __shared__ int s_n[2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid < 2) s_n[tid] = 0;
+  {
+    constexpr int kAhead = 8;
+    int *lv = wave == 0 ? levL : levU;
+    const int step = wave == 0 ? 1 : -1, r0 = wave == 0 ? 0 : m - 1;
+    int cq[kAhead], nq[kAhead];
+    long long dq[kAhead];
+    auto request = [&](int k, int &c, int &nd, long long &d0) {
+      c = -1; nd = 0; d0 = 0;
+      if (k < m) {
+        const int q = base + r0 + k * step;
+        const long long b = rp[q];
+        const int kd = dg[q];
+        d0 = wave == 0 ? b : b + kd + 1;
+        nd = wave == 0 ? kd : (int)(rp[q + 1] - d0);
+        if (lane < nd) c = ci[d0 + lane];
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) request(u, cq[u], nq[u], dq[u]);
+    int deepest = 0;
+    for (int k0 = 0; k0 < m; k0 += kAhead) {
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int k = k0 + u;
+        if (k < m) {
+          int nl = cq[u] >= 0 ? lv[cq[u] - base] + 1 : 0;
+          for (int e = lane + 64; e < nq[u]; e += 64) nl = max(nl, lv[ci[dq[u] + e] - base] + 1);
+          nl = wave_max_i32(nl);
+          if (lane == 0) lv[r0 + k * step] = nl;
+          deepest = max(deepest, nl + 1);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          request(k + kAhead, cq[u], nq[u], dq[u]);
+        }
+      }
+    }
+    if (lane == 0) s_n[wave] = deepest;
+  }
+  __syncthreads();
+  const int nl = s_n[0], nu = s_n[1];
+  if (tid == 0) { atomicMax(&maxlev[0], nl); atomicMax(&maxlev[1], nu); }
+  long long *D = desc + 2 * (2 * (long long)base);
+  int *lp = lptr + 2 * base + 2 * s;
+  int pos_base = 0, lev_base = 0;
+  for (int dir = 0; dir < 2; ++dir) {
+    const int *lev = dir == 0 ? levL : levU;
+    const int nlv = dir == 0 ? nl : nu, first = dir == 0 ? 1 : 0;   // L level 0 has nothing to subtract: not listed
+    for (int t = tid; t <= nlv + 1; t += blockDim.x) cnt[t] = 0;
+    __syncthreads();
+    for (int t = tid; t < m; t += blockDim.x) atomicAdd(&cnt[lev[t] + 1], 1);
+    __syncthreads();
+    if (tid == 0)
+      for (int l = 0; l < nlv; ++l) cnt[l + 1] += cnt[l];   // cnt[l] = rows of levels < l
+    __syncthreads();
+    const int skip = first ? cnt[1] : 0;   // rows of L level 0
+    for (int l = first + tid; l < nlv; l += blockDim.x) {
+      int pos = pos_base + cnt[l] - skip;
+      lp[lev_base + l - first] = pos;
+      for (int r = 0; r < m; ++r)
+        if (lev[r] == l) {
+          const int i = base + r;
+          const long long b = rp[i];
+          const int kd = dg[i];
+          const long long start = dir == 0 ? b : b + kd + 1;
+          const int nn = dir == 0 ? kd : (int)(rp[i + 1] - start);
+          D[2 * (long long)pos] = start;
+          D[2 * (long long)pos + 1] = ((long long)i << 32) | (unsigned int)nn;
+          ++pos;
+        }
+    }
+    __syncthreads();
+    pos_base += m - skip;
+    lev_base += nlv - first > 0 ? nlv - first : 0;
+    if (dir == 0 && tid == 0) nlist[2 * s] = lev_base;
+    __syncthreads();
+  }
+  if (tid == 0) { lp[lev_base] = pos_base; nlist[2 * s + 1] = lev_base; }
+}
+
+// k_gilu_sub_factor: IKJ ILU(k) numeric factorisation of one subdomain per workgroup, level by level over the L list of
+// k_gilu_sub_levels (level 0 rows have no lower part), a row per wave, one barrier per level.  Arithmetic of a row = that
+// of k_gilu_factor, operation for operation (same bits); what differs is how the operands arrive: the column -> slot
+// look-up is a table in LDS (the subdomain has at most 4096 columns) instead of a binary search, what a step needs to know
+// about its pivot row is looked up once per row, one pivot per lane, and handed over by v_readlane, and the pivot rows'
+// upper parts are requested four steps ahead (cf. k_ilu_factor, ilu.hpp).
+// LDS per wave: row image (values + columns, 12 B per entry) + the table (2 B per row of the subdomain).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gilu_sub_factor(const int *__restrict__ loc_ptr, const long long *__restrict__ desc,
+                                                                const int *__restrict__ lptr, const int *__restrict__ nlist,
+                                                                const long long *__restrict__ rp, const int *__restrict__ ci,
+                                                                const int *__restrict__ dg, double *__restrict__ val,
+                                                                int maxrow, int msub, int *__restrict__ err) {
+  extern __shared__ double subf_lds[];
+  const int s = blockIdx.x, base = loc_ptr[s], m = loc_ptr[s + 1] - base;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *w = subf_lds + (size_t)wave * maxrow;
+  int *cols = reinterpret_cast<int *>(subf_lds + (size_t)WAVES * maxrow) + (size_t)wave * maxrow;
+  unsigned short *mp = reinterpret_cast<unsigned short *>(reinterpret_cast<int *>(subf_lds + (size_t)WAVES * maxrow) + (size_t)WAVES * maxrow) +
+                       (size_t)wave * msub;   // slot + 1 of a column of the subdomain in the row at hand (0: not in its pattern)
+  for (int t = lane; t < msub; t += 64) mp[t] = 0;
+  const long long *D = desc + 2 * (2 * (long long)base);
+  const int *lp = lptr + 2 * base + 2 * s;
+  const int nL = nlist[2 * s];
+  __syncthreads();
+  constexpr int kPF = 4;
+  for (int l = 0; l < nL; ++l) {
+    for (int q = lp[l] + wave; q < lp[l + 1]; q += WAVES) {
+      const int i = (int)(D[2 * (long long)q + 1] >> 32);
+      const long long b = rp[i];
+      const int len = (int)(rp[i + 1] - b), nlow = dg[i];
+      for (int t = lane; t < len; t += 64) {
+        const int c = ci[b + t];
+        w[t] = val[b + t];
+        cols[t] = c;
+        mp[c - base] = (unsigned short)(t + 1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // per pivot (one per lane, the first 64 of the row): start and length of the pivot row's upper part, its pivot
+      long long pstart = 0;
+      int pcount = 0;
+      double ppiv = 1.0;
+      if (lane < nlow) {
+        const int k = cols[lane];
+        const long long kb = rp[k];
+        const int kd = dg[k];
+        pstart = kb + kd + 1;
+        pcount = (int)(rp[k + 1] - pstart);
+        ppiv = val[kb + kd];
+      }
+      int pcq[kPF], pnq[kPF];
+      double pvq[kPF], pdq[kPF];
+      long long psq[kPF];
+      auto request = [&](int t, int &pc, double &pv, double &pd, int &pn, long long &ps0) {
+        pc = -1; pv = 0.0; pd = 1.0; pn = 0; ps0 = 0;
+        if (t < nlow) {
+          if (t < 64) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)pstart, t);
+            const int hi = __builtin_amdgcn_readlane((int)(pstart >> 32), t);
+            ps0 = (long long)(((unsigned long long)(unsigned)hi << 32) | lo);
+            pn = __builtin_amdgcn_readlane(pcount, t);
+            pd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ppiv), t), __builtin_amdgcn_readlane(__double2loint(ppiv), t));
+          } else {
+            const int k = cols[t];
+            const long long kb = rp[k];
+            const int kd = dg[k];
+            ps0 = kb + kd + 1;
+            pn = (int)(rp[k + 1] - ps0);
+            pd = val[kb + kd];
+          }
+          if (lane < pn) { pc = ci[ps0 + lane]; pv = val[ps0 + lane]; }
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < kPF; ++u) request(u, pcq[u], pvq[u], pdq[u], pnq[u], psq[u]);
+      for (int t0 = 0; t0 < nlow; t0 += kPF) {
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+          const int t = t0 + u;
+          if (t < nlow) {
+            const int ps = pcq[u] >= 0 ? mp[pcq[u] - base] : 0;
+            const double lik = w[t] / pdq[u];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) w[t] = lik;
+            if (ps) w[ps - 1] -= lik * pvq[u];
+            for (int e = lane + 64; e < pnq[u]; e += 64) {   // pivot rows with more than 64 upper entries
+              const int p2 = mp[ci[psq[u] + e] - base];
+              if (p2) w[p2 - 1] -= lik * val[psq[u] + e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            request(t + kPF, pcq[u], pvq[u], pdq[u], pnq[u], psq[u]);
+          }
+        }
+      }
+      for (int t = lane; t < len; t += 64) {
+        val[b + t] = w[t];
+        mp[cols[t] - base] = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();   // level l is in memory before level l + 1 reads its rows
+  }
+  for (int t = threadIdx.x; t < m; t += blockDim.x) {   // zero pivots, level 0 rows included
+    const int q = base + t;
+    if (!(fabs(val[rp[q] + dg[q]]) > 0.0)) atomicOr(err, 2);
+  }
 }
 
 // ---- synchronisation-free sweeps ----------------------------------------------------------------------------------
@@ -709,7 +918,7 @@ inline void schwarz_destroy(isph_schwarz *S) {
   if (!S) return;
   S->rp.release(); S->ci.release(); S->dg.release(); S->val.release(); S->w.release(); S->rows.release();
   S->lord.release(); S->uord.release(); S->rev_ptr.release(); S->rev_idx.release(); S->err.release();
-  S->sub_desc.release(); S->sub_lptr.release(); S->sub_lofs.release(); S->sub_nl.release(); S->sub_dofs.release(); S->loc_ptr_dev.release();
+  S->sub_desc.release(); S->sub_lptr.release(); S->sub_nlist.release(); S->loc_ptr_dev.release();
   S->lord4.release(); S->uord4.release(); S->lpos4.release(); S->upos4.release(); S->lrun.release(); S->urun.release(); S->ctr.release(); S->ybits.release(); S->zbits.release();
   if (S->h_tmo) (void)hipHostFree(S->h_tmo);
   delete S;
@@ -1337,10 +1546,20 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     });
   }
   struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};   // on every way out
+  // many small subdomains: one workgroup per subdomain does the level analysis, the factorisation and both sweeps on the
+  // device (k_gilu_sub_levels, k_gilu_sub_factor, k_gilu_solve_sub); `syncfree == false` on entry
+  // (isph_schwarz_params::level_launches) keeps the host analysis and the launch per level as the cross-check
+  int maxsub = 0;
+  for (int sd = 0; sd < nsub; ++sd) maxsub = std::max(maxsub, S->loc_ptr[(size_t)sd + 1] - S->loc_ptr[(size_t)sd]);
+  S->sub_maxrows = maxsub;
+  S->subsweep = S->syncfree_requested && nsub >= kSubSweepMinSubs && maxsub <= kSubSweepMaxRows && maxrow <= kSubFactorMaxRow;
   // ---- dependency levels of the two solves (the factorisation follows the L levels)
-  std::vector<int> llev((size_t)nloc, 0), ulev((size_t)nloc, 0);
+  std::vector<int> llev, ulev;
+  if (!S->subsweep) { llev.assign((size_t)nloc, 0); ulev.assign((size_t)nloc, 0); }
   int nl = 0, nu = 0;
-  if (nsub >= 4) {
+  if (S->subsweep) {
+    // on the device, below
+  } else if (nsub >= 4) {
     // a row only depends on rows of its own subdomain: the recurrences of different subdomains run on different threads
     const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<int> tnl((size_t)nth, 0), tnu((size_t)nth, 0);
@@ -1391,70 +1610,8 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   // level is amortised and streams the rows at full width -- 512-row blocks + one overlap layer at 10^6 rows (294
   // levels of 15 000 rows): application 5.2 ms with level launches, 11.6 ms persistent; factorisation 106 / 234 ms.
   if (syncfree && nloc > 0 && nloc / std::max(1, std::min(nl, nu)) >= kGiluWideLevel) syncfree = false;
-  // many small subdomains: one workgroup per subdomain does both sweeps (k_gilu_solve_sub); `syncfree == false` on entry
-  // (isph_schwarz_params::level_launches) keeps the launch per level as the cross-check
-  int maxsub = 0;
-  for (int sd = 0; sd < nsub; ++sd) maxsub = std::max(maxsub, S->loc_ptr[(size_t)sd + 1] - S->loc_ptr[(size_t)sd]);
-  S->sub_maxrows = maxsub;
-  S->subsweep = S->syncfree_requested && nsub >= kSubSweepMinSubs && maxsub <= kSubSweepMaxRows;
   if (S->subsweep) syncfree = false;
   S->syncfree = syncfree;
-  std::vector<long long> sub_desc, sub_dofs;
-  std::vector<int> sub_lptr, sub_lofs, sub_nl;
-  if (S->subsweep) {
-    sub_dofs.assign((size_t)nsub + 1, 0);
-    sub_lofs.assign((size_t)nsub + 1, 0);
-    sub_nl.assign((size_t)nsub, 0);
-    std::vector<int> snl((size_t)nsub, 0), snu((size_t)nsub, 0);
-    for (int sd = 0; sd < nsub; ++sd) {
-      int a = 0, b = 0, lev0 = 0;
-      for (int q = S->loc_ptr[(size_t)sd]; q < S->loc_ptr[(size_t)sd + 1]; ++q) {
-        a = std::max(a, llev[(size_t)q] + 1); b = std::max(b, ulev[(size_t)q] + 1);
-        lev0 += llev[(size_t)q] == 0;
-      }
-      snl[(size_t)sd] = a; snu[(size_t)sd] = b;
-      const int m = S->loc_ptr[(size_t)sd + 1] - S->loc_ptr[(size_t)sd];
-      sub_nl[(size_t)sd] = a > 0 ? a - 1 : 0;                                         // L level 0 has nothing to subtract
-      sub_lofs[(size_t)sd + 1] = sub_lofs[(size_t)sd] + sub_nl[(size_t)sd] + b + 1;
-      sub_dofs[(size_t)sd + 1] = sub_dofs[(size_t)sd] + (m - lev0) + m;
-    }
-    sub_lptr.assign((size_t)sub_lofs[(size_t)nsub], 0);
-    sub_desc.resize((size_t)(2 * sub_dofs[(size_t)nsub]));
-    const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    auto orders = [&](int t) {
-      std::vector<int> cnt, ord;
-      for (int sd = t; sd < nsub; sd += nth) {
-        const int q0 = S->loc_ptr[(size_t)sd], m = S->loc_ptr[(size_t)sd + 1] - q0;
-        int *lp = sub_lptr.data() + sub_lofs[(size_t)sd];
-        long long *D = sub_desc.data() + 2 * sub_dofs[(size_t)sd];
-        int pos = 0, lv = 0;
-        ord.resize((size_t)m);
-        for (int dir = 0; dir < 2; ++dir) {
-          const std::vector<int> &lev = dir == 0 ? llev : ulev;
-          const int nlv = dir == 0 ? snl[(size_t)sd] : snu[(size_t)sd];
-          cnt.assign((size_t)nlv + 1, 0);
-          for (int q = 0; q < m; ++q) ++cnt[(size_t)lev[(size_t)(q0 + q)] + 1];
-          for (int l = 0; l < nlv; ++l) cnt[(size_t)l + 1] += cnt[(size_t)l];
-          std::vector<int> cur(cnt.begin(), cnt.end() - 1);
-          for (int q = 0; q < m; ++q) ord[(size_t)cur[(size_t)lev[(size_t)(q0 + q)]]++] = q0 + q;   // ascending row inside a level
-          for (int l = dir == 0 ? 1 : 0; l < nlv; ++l) {
-            lp[lv++] = pos;
-            for (int k = cnt[(size_t)l]; k < cnt[(size_t)l + 1]; ++k, ++pos) {
-              const int i = ord[(size_t)k];
-              const long long start = dir == 0 ? frp[(size_t)i] : frp[(size_t)i] + fdg[(size_t)i] + 1;
-              const int nn = dir == 0 ? fdg[(size_t)i] : (int)(frp[(size_t)i + 1] - start);
-              D[2 * (size_t)pos] = start;
-              D[2 * (size_t)pos + 1] = ((long long)i << 32) | (unsigned int)nn;
-            }
-          }
-        }
-        lp[lv] = pos;
-      }
-    };
-    std::vector<std::thread> th;
-    for (int t = 0; t < nth; ++t) th.emplace_back(orders, t);
-    for (auto &x : th) x.join();
-  }
   auto bucket = [&](const std::vector<int> &lev, int nlev, std::vector<int> &ptr, std::vector<int> &ord) {
     ptr.assign((size_t)nlev + 1, 0);
     for (int q = 0; q < nloc; ++q) ++ptr[(size_t)lev[(size_t)q] + 1];
@@ -1464,8 +1621,10 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     for (int q = 0; q < nloc; ++q) ord[(size_t)cur[(size_t)lev[(size_t)q]]++] = q;
   };
   std::vector<int> lord, uord;
-  bucket(llev, nl, S->lptr, lord);
-  bucket(ulev, nu, S->uptr, uord);
+  if (!S->subsweep) {
+    bucket(llev, nl, S->lptr, lord);
+    bucket(ulev, nu, S->uptr, uord);
+  }
   // the same orders with every level padded to a multiple of four positions: a wave of the synchronisation-free sweeps
   // takes four consecutive positions, and rows of one wave must not wait for each other
   auto pad4 = [&](const std::vector<int> &ptr, const std::vector<int> &ord, std::vector<int> &out4) {
@@ -1543,13 +1702,14 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (rc == ISPH_SUCCESS) rc = up(S->rev_idx, rev_idx);
   if (rc == ISPH_SUCCESS) rc = S->w.reserve((size_t)(nloc > 0 ? nloc : 1));
   if (rc == ISPH_SUCCESS) rc = S->err.reserve(1);
+  DevTmp<int> maxlev;
   if (rc == ISPH_SUCCESS && S->subsweep) {
-    rc = up(S->sub_desc, sub_desc);
-    if (rc == ISPH_SUCCESS) rc = up(S->sub_dofs, sub_dofs);
-    if (rc == ISPH_SUCCESS) rc = up(S->sub_lptr, sub_lptr);
-    if (rc == ISPH_SUCCESS) rc = up(S->sub_lofs, sub_lofs);
-    if (rc == ISPH_SUCCESS) rc = up(S->sub_nl, sub_nl);
+    rc = S->sub_desc.reserve((size_t)4 * (size_t)(nloc > 0 ? nloc : 1));
+    if (rc == ISPH_SUCCESS) rc = S->sub_lptr.reserve((size_t)2 * nloc + (size_t)2 * nsub + 2);
+    if (rc == ISPH_SUCCESS) rc = S->sub_nlist.reserve((size_t)2 * nsub);
     if (rc == ISPH_SUCCESS) rc = up(S->loc_ptr_dev, S->loc_ptr);
+    if (rc == ISPH_SUCCESS) rc = maxlev.reserve(2);
+    if (rc == ISPH_SUCCESS && hipMemsetAsync(maxlev.p, 0, 2 * sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
   }
   if (rc == ISPH_SUCCESS && syncfree) {
     rc = up(S->lord4, lord4);
@@ -1594,7 +1754,22 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (!syncfree || maxrow >= 65535 || lds_row + lds_tab > 64 * 1024) hbits = 0;
   const size_t lds = lds_row + (hbits ? lds_tab : 0);
   int htmo = 0;
-  if (syncfree && nloc > 0) {
+  int hmax[2] = {0, 0};
+  if (S->subsweep && nloc > 0) {
+    // level analysis (descriptor list of the sweeps) and factorisation, one workgroup per subdomain each
+    const size_t lds_lv = sizeof(int) * ((size_t)3 * maxsub + 2);
+    hipLaunchKernelGGL(k_gilu_sub_levels, dim3(nsub), dim3(128), lds_lv, ctx->stream, (const int *)S->loc_ptr_dev.p,
+                       (const long long *)S->rp.p, (const int *)S->ci.p, (const int *)S->dg.p, S->sub_desc.p, S->sub_lptr.p,
+                       S->sub_nlist.p, maxlev.p);
+    const int mr = std::max(maxrow, 1), ms = (maxsub + 63) / 64 * 64;
+    const size_t lds_f = (size_t)4 * ((size_t)mr * 12 + (size_t)ms * 2);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gilu_sub_factor<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+    hipLaunchKernelGGL((k_gilu_sub_factor<4>), dim3(nsub), dim3(64 * 4), lds_f, ctx->stream, (const int *)S->loc_ptr_dev.p,
+                       (const long long *)S->sub_desc.p, (const int *)S->sub_lptr.p, (const int *)S->sub_nlist.p, (const long long *)S->rp.p,
+                       (const int *)S->ci.p, (const int *)S->dg.p, S->val.p, mr, ms, S->err.p);
+    if (e == hipSuccess) e = hipMemcpyAsync(hmax, maxlev.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  } else if (syncfree && nloc > 0) {
     // one persistent launch: rows in level order, a row waits for the values of the rows it eliminates with
     // (k_gilu_factor_sf); the factor goes to a second array that starts as the "not there yet" pattern and takes the
     // place of the input afterwards
@@ -1638,6 +1813,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (e != hipSuccess) { schwarz_destroy(S); return fail(hipGetErrorString(e), __FILE__, __LINE__); }
   if (htmo) { schwarz_destroy(S); return fail("Schwarz ILU factorisation: a row waited for its pivot row beyond the spin limit", __FILE__, __LINE__); }
   if (herr) { schwarz_destroy(S); return fail("zero pivot in the Schwarz ILU factorisation", __FILE__, __LINE__); }
+  if (S->subsweep) { S->nlev_l = hmax[0]; S->nlev_u = hmax[1]; }
   S->t_ms[5] = ms_since(t0);
   *out = S;
   return ISPH_SUCCESS;
@@ -1649,8 +1825,8 @@ inline int schwarz_apply(isph_ctx *ctx, const isph_schwarz *S, const double *r, 
   if (S->subsweep) {
     const size_t lds = sizeof(double) * (size_t)S->sub_maxrows;
     hipLaunchKernelGGL(k_gilu_solve_sub, dim3(S->nsub), dim3(256), lds, ctx->stream, (const int *)S->loc_ptr_dev.p, (const int *)S->rows.p,
-                       (const long long *)S->sub_desc.p, (const long long *)S->sub_dofs.p, (const int *)S->sub_lptr.p,
-                       (const int *)S->sub_lofs.p, (const int *)S->sub_nl.p, (const int *)S->ci.p, (const double *)S->val.p, r, S->w.p);
+                       (const long long *)S->sub_desc.p, (const int *)S->sub_lptr.p, (const int *)S->sub_nlist.p, (const int *)S->ci.p,
+                       (const double *)S->val.p, r, S->w.p);
     hipLaunchKernelGGL(k_gilu_combine, dim3((S->n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, S->n, S->rev_ptr.p,
                        S->rev_idx.p, (const double *)S->w.p, z);
     ISPH_CHECK_HIP(hipGetLastError());
