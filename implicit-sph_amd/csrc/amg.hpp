@@ -78,20 +78,27 @@ __device__ __forceinline__ unsigned amg_hash32(unsigned x) {
 __device__ __forceinline__ unsigned long long amg_key(int state, int i) {
   return ((unsigned long long)state << 62) | ((unsigned long long)amg_hash32((unsigned)i) << 30) | (unsigned long long)i;
 }
+// wave-wide max / min, result in every lane: DPP moves (a lane without a source keeps its own value) + v_readlane, not the
+// six (twelve for 64 bits) dependent ds_bpermute round trips of a __shfl_xor butterfly -- these sit once per matrix row in the
+// MIS sweeps
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned long long dpp_keep_u64(unsigned long long v) {
+  const int lo = dpp_keep_i32<CTRL, ROW_MASK>((int)(unsigned)v), hi = dpp_keep_i32<CTRL, ROW_MASK>((int)(unsigned)(v >> 32));
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
+  unsigned long long t;
+  t = dpp_keep_u64<0x111>(v); v = t > v ? t : v;
+  t = dpp_keep_u64<0x112>(v); v = t > v ? t : v;
+  t = dpp_keep_u64<0x114>(v); v = t > v ? t : v;
+  t = dpp_keep_u64<0x118>(v); v = t > v ? t : v;
+  t = dpp_keep_u64<0x142, 0xa>(v); v = t > v ? t : v;
+  t = dpp_keep_u64<0x143, 0xc>(v); v = t > v ? t : v;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
-__device__ __forceinline__ int wave_min_i32(int v) {
-  for (int o = 32; o > 0; o >>= 1) {
-    const int t = __shfl_xor(v, o, 64);
-    v = t < v ? t : v;
-  }
-  return v;
-}
+__device__ __forceinline__ int wave_min_i32(int v) { return -wave_max_i32(-v); }   // callers pass row lengths / indices >= 0
 __device__ __forceinline__ double wave_max_f64(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
   return v;
