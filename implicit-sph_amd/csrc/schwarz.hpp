@@ -288,6 +288,68 @@ __global__ __launch_bounds__(256) void k_gilu_solve_sub(const int *__restrict__ 
   for (int t = tid; t < m; t += blockDim.x) w[base + t] = sub_y[t];
 }
 
+// ---- many small subdomains: the local matrices on the device (level of fill 0, at most one overlap layer) ------------------
+// Ifpack_LocalFilter per subdomain: local row q = global row rows[q]; its entries whose column is a row of the same
+// subdomain are kept and renumbered -- owned columns (a consecutive global range) first, then the columns of the overlap
+// layer (ascending global row, found by bisection in the subdomain's row list), both in their original order, which is the
+// ascending local order.  One wave per local row; pass 1 counts (kept entries, owned among them), pass 2 writes columns,
+// values and the position of the diagonal.  Replaces 0.14 s of host threads + 0.07 s of upload at 10^6 rows.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_gilu_sub_local(int nloc, int nsub, int n, const int *__restrict__ loc_ptr,
+                                                        const int *__restrict__ nown, const int *__restrict__ rows,
+                                                        const long long *__restrict__ arp, const int *__restrict__ aci,
+                                                        const double *__restrict__ aval, int *__restrict__ cnt,
+                                                        int *__restrict__ cown, const long long *__restrict__ lrp,
+                                                        int *__restrict__ lci, double *__restrict__ lval, int *__restrict__ dg,
+                                                        int *__restrict__ meta /* [0] longest row, [1] bit 0: missing diagonal */) {
+  const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (q >= nloc) return;
+  int lo = 0, hi = nsub;   // subdomain of local row q: last s with loc_ptr[s] <= q
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (loc_ptr[mid] <= q) lo = mid; else hi = mid; }
+  const int s = lo, base = loc_ptr[s], m = loc_ptr[s + 1] - base, no = nown[s];
+  const int g = rows[q], g0 = rows[base];           // owned rows are the consecutive global range g0 .. g0 + no
+  const int *ext = rows + base + no;                // overlap layer, ascending
+  const int next = m - no;
+  const long long b = arp[g], e = arp[g + 1];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int nown_seen = 0, next_seen = 0, dpos = -1;
+  const int own_total = FILL ? cown[q] : 0;
+  const long long out0 = FILL ? lrp[q] : 0;
+  for (long long p0 = b; p0 < e; p0 += 64) {
+    const long long p = p0 + lane;
+    int li = -1;       // local column, -1: dropped
+    bool owned = false;
+    if (p < e) {
+      const int c = aci[p];
+      if (c >= g0 && c < g0 + no) { li = base + (c - g0); owned = true; }
+      else if (c < n && next > 0) {
+        int l2 = 0, h2 = next - 1;
+        while (l2 <= h2) {
+          const int mid = (l2 + h2) >> 1;
+          const int r = ext[mid];
+          if (r == c) { li = base + no + mid; break; }
+          if (r < c) l2 = mid + 1; else h2 = mid - 1;
+        }
+      }
+    }
+    const unsigned long long mo = __ballot(li >= 0 && owned), me = __ballot(li >= 0 && !owned);
+    if (FILL && li >= 0) {
+      const int pos = owned ? nown_seen + __popcll(mo & below) : own_total + next_seen + __popcll(me & below);
+      lci[out0 + pos] = li;
+      lval[out0 + pos] = aval[p];
+      if (li == q) dpos = pos;
+    }
+    nown_seen += __popcll(mo);
+    next_seen += __popcll(me);
+  }
+  if (!FILL) {
+    if (lane == 0) { cnt[q] = nown_seen + next_seen; cown[q] = nown_seen; atomicMax(&meta[0], nown_seen + next_seen); }
+  } else {
+    dpos = wave_max_i32(dpos);
+    if (lane == 0) { dg[q] = dpos; if (dpos < 0) atomicOr(&meta[1], 1); }
+  }
+}
+
 // ---- many small subdomains: level analysis and numeric factorisation on the device ------------------------------------
 // k_gilu_sub_levels: one workgroup (two waves) per subdomain.  Wave 0 walks the rows upwards for the L levels, wave 1
 // downwards for the U levels (lev = 1 + max over the dependencies, which all lie in the same subdomain), lanes over a
@@ -1243,6 +1305,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   // the same with fill 1: the level-1 pattern is built on the device from the device image of the matrix
   // (k_gilu_symbolic1), the factor arrays never exist on the host; `Adev` holds the matrix image meanwhile
   bool resident1 = fill == 1 && (block_size <= 0 || block_size >= n) && n > 0 && A->S.ncol == n;
+  bool devlocal = false;
   isph_schwarz Adev;
   struct AdevGuard {
     isph_schwarz &a;
@@ -1250,7 +1313,11 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     ~AdevGuard() { drop(); }
   } adev_guard{Adev};
   {
-    const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, resident ? S : resident1 ? &Adev : nullptr);
+    // many small subdomains with no fill and at most one overlap layer: the local matrices are built on the device from the
+    // matrix image (k_gilu_sub_local); only the pattern comes to the host, for the subdomain row lists
+    devlocal = syncfree && fill == 0 && overlap <= 1 && !resident && n > 0 && block_size > 0 && A->S.wmax <= kSubFactorMaxRow &&
+               (n + block_size - 1) / block_size >= kSubSweepMinSubs;
+    const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, resident ? S : (resident1 || devlocal) ? &Adev : nullptr);
     if (rc0 != ISPH_SUCCESS) { schwarz_destroy(S); return rc0; }
   }
   S->t_ms[0] = ms_since(t0); t0 = clk();
@@ -1303,7 +1370,72 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   std::vector<long long> lrp((size_t)nloc + 1, 0);
   HostArr<int> lci;
   HostArr<double> lv;
-  if (nsub == 1 && nloc == n && A->S.ncol == n) {
+  int dev_maxrow = 0;
+  if (devlocal) {
+    int maxsub0 = 0;
+    for (int sd = 0; sd < nsub; ++sd) maxsub0 = std::max(maxsub0, S->loc_ptr[(size_t)sd + 1] - S->loc_ptr[(size_t)sd]);
+    if (maxsub0 > kSubSweepMaxRows) {   // the subdomains came out too large for the one-workgroup form: the host path after all
+      devlocal = false;
+      adev_guard.drop();
+      const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, nullptr);
+      if (rc0 != ISPH_SUCCESS) { schwarz_destroy(S); return rc0; }
+    }
+  }
+  if (devlocal) {
+    DevTmp<int> dnown, dcnt, dcown, dmeta;
+    DevBuf<char> scan_tmp;
+    int rcd = S->rows.reserve((size_t)nloc);
+    if (rcd == ISPH_SUCCESS) rcd = S->loc_ptr_dev.reserve((size_t)nsub + 1);
+    if (rcd == ISPH_SUCCESS) rcd = dnown.reserve((size_t)nsub);
+    if (rcd == ISPH_SUCCESS) rcd = dcnt.reserve((size_t)nloc + 1);
+    if (rcd == ISPH_SUCCESS) rcd = dcown.reserve((size_t)nloc);
+    if (rcd == ISPH_SUCCESS) rcd = dmeta.reserve(2);
+    if (rcd == ISPH_SUCCESS) rcd = S->rp.reserve((size_t)nloc + 1);
+    if (rcd == ISPH_SUCCESS) rcd = S->dg.reserve((size_t)nloc);
+    hipError_t ed = hipSuccess;
+    if (rcd == ISPH_SUCCESS) {
+      ed = hipMemcpyAsync(S->rows.p, hrows.data(), sizeof(int) * (size_t)nloc, hipMemcpyHostToDevice, ctx->stream);
+      if (ed == hipSuccess) ed = hipMemcpyAsync(S->loc_ptr_dev.p, S->loc_ptr.data(), sizeof(int) * ((size_t)nsub + 1), hipMemcpyHostToDevice, ctx->stream);
+      if (ed == hipSuccess) ed = hipMemcpyAsync(dnown.p, nown.data(), sizeof(int) * (size_t)nsub, hipMemcpyHostToDevice, ctx->stream);
+      if (ed == hipSuccess) ed = hipMemsetAsync(dmeta.p, 0, 2 * sizeof(int), ctx->stream);
+      if (ed == hipSuccess) ed = hipMemsetAsync(dcnt.p + nloc, 0, sizeof(int), ctx->stream);
+    }
+    const int wgrid = (int)(((long long)nloc * 64 + 255) / 256);
+    if (rcd == ISPH_SUCCESS && ed == hipSuccess) {
+      hipLaunchKernelGGL((k_gilu_sub_local<false>), dim3(wgrid), dim3(256), 0, ctx->stream, nloc, nsub, n, (const int *)S->loc_ptr_dev.p,
+                         (const int *)dnown.p, (const int *)S->rows.p, (const long long *)Adev.rp.p, (const int *)Adev.ci.p,
+                         (const double *)Adev.val.p, dcnt.p, dcown.p, (const long long *)nullptr, (int *)nullptr, (double *)nullptr,
+                         (int *)nullptr, dmeta.p);
+      rcd = amg_scan(ctx, (const int *)dcnt.p, S->rp.p, nloc + 1, scan_tmp);
+    }
+    long long tot = 0;
+    int hmeta[2] = {0, 0};
+    if (rcd == ISPH_SUCCESS && ed == hipSuccess) {
+      ed = hipMemcpyAsync(&tot, S->rp.p + nloc, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+      if (ed == hipSuccess) ed = hipMemcpyAsync(hmeta, dmeta.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+      if (ed == hipSuccess) ed = hipStreamSynchronize(ctx->stream);
+    }
+    if (rcd == ISPH_SUCCESS && ed == hipSuccess) {
+      S->nnz = tot;
+      dev_maxrow = hmeta[0];
+      rcd = S->ci.reserve((size_t)(tot > 0 ? tot : 1));
+      if (rcd == ISPH_SUCCESS) rcd = S->val.reserve((size_t)(tot > 0 ? tot : 1));
+    }
+    if (rcd == ISPH_SUCCESS && ed == hipSuccess) {
+      hipLaunchKernelGGL((k_gilu_sub_local<true>), dim3(wgrid), dim3(256), 0, ctx->stream, nloc, nsub, n, (const int *)S->loc_ptr_dev.p,
+                         (const int *)dnown.p, (const int *)S->rows.p, (const long long *)Adev.rp.p, (const int *)Adev.ci.p,
+                         (const double *)Adev.val.p, dcnt.p, dcown.p, (const long long *)S->rp.p, S->ci.p, S->val.p, S->dg.p, dmeta.p);
+      ed = hipMemcpyAsync(hmeta, dmeta.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+      if (ed == hipSuccess) ed = hipStreamSynchronize(ctx->stream);
+      if (ed == hipSuccess) ed = hipGetLastError();
+    }
+    scan_tmp.release();
+    adev_guard.drop();   // the matrix image is no longer needed
+    if (rcd != ISPH_SUCCESS) { schwarz_destroy(S); return rcd; }
+    if (ed != hipSuccess) { schwarz_destroy(S); return fail(hipGetErrorString(ed), __FILE__, __LINE__); }
+    if (hmeta[1] & 1) { schwarz_destroy(S); return fail("structurally missing diagonal in a Schwarz subdomain", __FILE__, __LINE__); }
+    resident = true;     // the factor arrays are where they belong: nothing to upload
+  } else if (nsub == 1 && nloc == n && A->S.ncol == n) {
     // one subdomain = the whole matrix and no ghost columns to filter (the reference on one rank; the extended matrix of
     // isph_prec_create_overlap): the local matrix is the host CSR itself, rows already column-sorted
     lrp.swap(rp);
@@ -1429,7 +1561,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
       resident = true;           // the factor arrays are where they belong: nothing to upload
     }
   }
-  if (resident1) {
+  if (resident1 || devlocal) {
     // done above
   } else if (fill == 0) {
     frp.swap(lrp);  // the local matrix IS the factor pattern: no second copy of 1.2 GB at 10^6 rows
@@ -1515,11 +1647,12 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     }
     for (int s = 0; s < nsub; ++s) std::vector<GiluRow>().swap(pat[(size_t)s]);
   }
-  S->nnz = frp[(size_t)nloc];
-  int maxrow = 0;
-  for (int q = 0; q < nloc; ++q) maxrow = std::max(maxrow, (int)(frp[(size_t)q + 1] - frp[(size_t)q]));
+  if (!devlocal) S->nnz = frp[(size_t)nloc];
+  int maxrow = dev_maxrow;
+  if (!devlocal)
+    for (int q = 0; q < nloc; ++q) maxrow = std::max(maxrow, (int)(frp[(size_t)q + 1] - frp[(size_t)q]));
   S->maxrow = maxrow;
-  {   // (more than one row in twenty: the periodic SPH ILU(0) factors have a few rows with all 104 neighbours on one side)
+  if (!devlocal) {   // (more than one row in twenty: the periodic SPH ILU(0) factors have a few rows with all 104 neighbours on one side)
     long long nlong = 0;
     for (int q = 0; q < nloc; ++q)
       nlong += fdg[(size_t)q] > 16 * kSfChunk || frp[(size_t)q + 1] - frp[(size_t)q] - fdg[(size_t)q] - 1 > 16 * kSfChunk;
@@ -1694,8 +1827,8 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   };
   if (uploader.joinable()) uploader.join();
   int rc = rc_up;
-  if (rc == ISPH_SUCCESS) rc = up(S->dg, fdg);
-  if (rc == ISPH_SUCCESS) rc = up(S->rows, hrows);
+  if (rc == ISPH_SUCCESS && !devlocal) rc = up(S->dg, fdg);
+  if (rc == ISPH_SUCCESS && !devlocal) rc = up(S->rows, hrows);
   if (rc == ISPH_SUCCESS) rc = up(S->lord, lord);
   if (rc == ISPH_SUCCESS) rc = up(S->uord, uord);
   if (rc == ISPH_SUCCESS) rc = up(S->rev_ptr, rev_ptr);
