@@ -288,6 +288,115 @@ __global__ __launch_bounds__(256) void k_gilu_solve_sub(const int *__restrict__ 
   for (int t = tid; t < m; t += blockDim.x) w[base + t] = sub_y[t];
 }
 
+// ---- many small subdomains: the row lists and the combine lists on the device -------------------------------------------------
+// Subdomain s owns the consecutive rows s B .. s B + B; one overlap layer adds the columns its rows reference outside that
+// range (Ifpack_OverlappingRowMatrix on a row partition), ascending.  One workgroup per subdomain: the referenced columns
+// go through an LDS hash set (the owned rows are one contiguous piece of the CSR image: a flat, coalesced walk), the set is
+// compacted and sorted in LDS (bitonic) and parked at a fixed stride; after the prefix sum over the sizes
+// k_gilu_sub_rows_fill writes the lists where they belong.  A subdomain that outgrows the one-workgroup form
+// (kSubSweepMaxRows) raises flag bit 0: the caller takes the host path then.
+constexpr int kSubHash = 8192;
+__global__ __launch_bounds__(256) void k_gilu_sub_rows(int nsub, int B, int n, int overlap, const long long *__restrict__ arp,
+                                                       const int *__restrict__ aci, int stride, int *__restrict__ ext,
+                                                       int *__restrict__ msize, int *__restrict__ flag) {
+  __shared__ int tab[kSubHash];
+  __shared__ int lst[kSubSweepMaxRows];
+  __shared__ int s_cnt, s_k, s_bad;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int lo = s * B, hi = min(n, lo + B), no = hi - lo;
+  for (int t = tid; t < kSubHash; t += 256) tab[t] = -1;
+  if (tid == 0) { s_cnt = 0; s_k = 0; s_bad = no > stride ? 1 : 0; }
+  __syncthreads();
+  const int cap = stride - no;   // overlap rows the one-workgroup form has room for
+  if (overlap > 0 && nsub > 1 && no <= stride) {
+    const long long b = arp[lo], e = arp[hi];
+    for (long long p = b + tid; p < e; p += 256) {
+      if (*(volatile int *)&s_bad) break;
+      const int c = aci[p];
+      if (c >= n || (c >= lo && c < hi)) continue;
+      unsigned h = ((unsigned)c * 2654435761u) >> 19;   // 13 bits
+      for (int probe = 0; probe < kSubHash; ++probe) {
+        const int old = atomicCAS(&tab[h], -1, c);
+        if (old == -1) { if (atomicAdd(&s_cnt, 1) >= cap) s_bad = 1; break; }
+        if (old == c) break;
+        h = (h + 1) & (kSubHash - 1);
+      }
+    }
+  }
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (s_bad) {   // uniform
+    if (tid == 0) { atomicOr(flag, 1); msize[s] = 0; }
+    return;
+  }
+  for (int t = tid; t < kSubHash; t += 256) {
+    const int c = tab[t];
+    if (c >= 0) lst[atomicAdd(&s_k, 1)] = c;
+  }
+  int np = 1;
+  while (np < cnt) np <<= 1;
+  __syncthreads();
+  for (int t = cnt + tid; t < np; t += 256) lst[t] = INT_MAX;
+  __syncthreads();
+  for (int k = 2; k <= np; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < np; t += 256) {
+        const int u = t ^ j;
+        if (u > t) {
+          const int a = lst[t], c = lst[u];
+          if ((a > c) == ((t & k) == 0)) { lst[t] = c; lst[u] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int t = tid; t < cnt; t += 256) ext[(long long)s * stride + t] = lst[t];
+  if (tid == 0) msize[s] = no + cnt;
+}
+
+__global__ __launch_bounds__(256) void k_gilu_sub_rows_fill(int nsub, int B, int n, int stride, const long long *__restrict__ lp64,
+                                                            const int *__restrict__ ext, int *__restrict__ loc_ptr,
+                                                            int *__restrict__ rows) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int base = (int)lp64[s], m = (int)lp64[s + 1] - base, lo = s * B, no = min(n, lo + B) - lo;
+  if (tid == 0) {
+    loc_ptr[s] = base;
+    if (s == nsub - 1) loc_ptr[nsub] = (int)lp64[nsub];
+  }
+  for (int q = tid; q < m; q += 256) rows[base + q] = q < no ? lo + q : ext[(long long)s * stride + (q - no)];
+}
+
+// combine lists (global row -> local rows).  Zero: the owned copy only, a closed form.  Add: every copy, in ascending local
+// row (= subdomain order, the host's order: the sum in k_gilu_combine is bitwise the same) -- counted and placed with
+// atomics, then each row's short list sorted.
+__global__ void k_gilu_rev_zero(int n, int B, const int *__restrict__ loc_ptr, long long *__restrict__ rev_ptr, int *__restrict__ rev_idx) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > n) return;
+  rev_ptr[g] = g;
+  if (g < n) rev_idx[g] = loc_ptr[g / B] + g % B;
+}
+__global__ void k_gilu_rev_count(int nloc, const int *__restrict__ rows, int *__restrict__ cnt) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nloc) atomicAdd(&cnt[rows[q]], 1);
+}
+__global__ void k_gilu_rev_fill(int nloc, const int *__restrict__ rows, const long long *__restrict__ rev_ptr, int *__restrict__ cur,
+                                int *__restrict__ rev_idx) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nloc) return;
+  const int g = rows[q];
+  rev_idx[rev_ptr[g] + atomicAdd(&cur[g], 1)] = q;
+}
+__global__ void k_gilu_rev_sort(int n, const long long *__restrict__ rev_ptr, int *__restrict__ rev_idx) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const long long b = rev_ptr[g], e = rev_ptr[g + 1];
+  for (long long p = b + 1; p < e; ++p) {
+    const int v = rev_idx[p];
+    long long t = p;
+    for (; t > b && rev_idx[t - 1] > v; --t) rev_idx[t] = rev_idx[t - 1];
+    rev_idx[t] = v;
+  }
+}
+
 // ---- many small subdomains: the local matrices on the device (level of fill 0, at most one overlap layer) ------------------
 // Ifpack_LocalFilter per subdomain: local row q = global row rows[q]; its entries whose column is a row of the same
 // subdomain are kept and renumbered -- owned columns (a consecutive global range) first, then the columns of the overlap
@@ -1058,7 +1167,7 @@ struct HostArr {
 // keep != nullptr: the CSR image is written into keep's factor arrays and stays there; only the pattern comes to the
 // host (the one-subdomain ILU(0) case, where the matrix IS the factor pattern: no 0.8 GB of values down and up again)
 inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long long> &rp, HostArr<int> &ci,
-                            HostArr<double> &v, isph_schwarz *keep = nullptr) {
+                            HostArr<double> &v, isph_schwarz *keep = nullptr, bool pattern_to_host = true) {
   const Sell &S = A->S;
   const int n = S.nrow;
   std::vector<int> len((size_t)n);
@@ -1075,6 +1184,7 @@ inline int schwarz_host_csr(isph_ctx *ctx, const isph_mat *A, std::vector<long l
     if (n > 0)
       hipLaunchKernelGGL(k_sell_to_csr, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, S.rowlen.p,
                          S.slice_off.p, S.col.p, S.val.p, keep->rp.p, keep->ci.p, keep->val.p);
+    if (!pattern_to_host) return ISPH_SUCCESS;   // the caller works on the device image alone
     if (!ci.alloc((size_t)nnz)) return fail("host allocation failed", __FILE__, __LINE__);
     ISPH_CHECK_HIP(hipMemcpyAsync(ci.data(), keep->ci.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
     ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1317,7 +1427,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     // matrix image (k_gilu_sub_local); only the pattern comes to the host, for the subdomain row lists
     devlocal = syncfree && fill == 0 && overlap <= 1 && !resident && n > 0 && block_size > 0 && A->S.wmax <= kSubFactorMaxRow &&
                (n + block_size - 1) / block_size >= kSubSweepMinSubs;
-    const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, resident ? S : (resident1 || devlocal) ? &Adev : nullptr);
+    const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, resident ? S : (resident1 || devlocal) ? &Adev : nullptr, !devlocal);
     if (rc0 != ISPH_SUCCESS) { schwarz_destroy(S); return rc0; }
   }
   S->t_ms[0] = ms_since(t0); t0 = clk();
@@ -1329,7 +1439,56 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   S->nsub = nsub;
   std::vector<std::vector<int>> srows((size_t)nsub);
   std::vector<int> nown((size_t)nsub, 0);
-  {
+  if (devlocal) {
+    // the row lists on the device: hash set + sort per subdomain, prefix sum, fill (k_gilu_sub_rows / _fill)
+    const int stride = kSubSweepMaxRows;
+    DevTmp<int> ext, msize, dflag;
+    DevTmp<long long> lp64;
+    DevBuf<char> scan_tmp;
+    int rcd = msize.reserve((size_t)nsub + 1);
+    if (rcd == ISPH_SUCCESS) rcd = dflag.reserve(1);
+    if (rcd == ISPH_SUCCESS) rcd = lp64.reserve((size_t)nsub + 1);
+    if (rcd == ISPH_SUCCESS) rcd = ext.reserve(overlap > 0 ? (size_t)nsub * (size_t)stride : 1);
+    if (rcd == ISPH_SUCCESS) rcd = S->loc_ptr_dev.reserve((size_t)nsub + 1);
+    hipError_t ed = hipSuccess;
+    std::vector<long long> hlp((size_t)nsub + 1, 0);
+    int hflag = 0;
+    if (rcd == ISPH_SUCCESS) {
+      ed = hipMemsetAsync(msize.p + nsub, 0, sizeof(int), ctx->stream);
+      if (ed == hipSuccess) ed = hipMemsetAsync(dflag.p, 0, sizeof(int), ctx->stream);
+      hipLaunchKernelGGL(k_gilu_sub_rows, dim3(nsub), dim3(256), 0, ctx->stream, nsub, B, n, overlap, (const long long *)Adev.rp.p,
+                         (const int *)Adev.ci.p, stride, ext.p, msize.p, dflag.p);
+      rcd = amg_scan(ctx, (const int *)msize.p, lp64.p, nsub + 1, scan_tmp);
+    }
+    if (rcd == ISPH_SUCCESS && ed == hipSuccess) {
+      ed = hipMemcpyAsync(hlp.data(), lp64.p, sizeof(long long) * ((size_t)nsub + 1), hipMemcpyDeviceToHost, ctx->stream);
+      if (ed == hipSuccess) ed = hipMemcpyAsync(&hflag, dflag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+      if (ed == hipSuccess) ed = hipStreamSynchronize(ctx->stream);
+      if (ed == hipSuccess) ed = hipGetLastError();
+    }
+    scan_tmp.release();
+    if (rcd != ISPH_SUCCESS) { schwarz_destroy(S); return rcd; }
+    if (ed != hipSuccess) { schwarz_destroy(S); return fail(hipGetErrorString(ed), __FILE__, __LINE__); }
+    if (hflag || hlp[(size_t)nsub] > (long long)INT_MAX) {
+      // a subdomain too large for the one-workgroup form: the host path, which needs the matrix on the host after all
+      devlocal = false;
+      adev_guard.drop();
+      const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, nullptr);
+      if (rc0 != ISPH_SUCCESS) { schwarz_destroy(S); return rc0; }
+    } else {
+      S->loc_ptr.resize((size_t)nsub + 1);
+      for (int sd = 0; sd <= nsub; ++sd) S->loc_ptr[(size_t)sd] = (int)hlp[(size_t)sd];
+      for (int sd = 0; sd < nsub; ++sd) nown[(size_t)sd] = std::min(n, sd * B + B) - sd * B;
+      const int nl0 = S->loc_ptr[(size_t)nsub];
+      rcd = S->rows.reserve((size_t)(nl0 > 0 ? nl0 : 1));
+      if (rcd != ISPH_SUCCESS) { schwarz_destroy(S); return rcd; }
+      hipLaunchKernelGGL(k_gilu_sub_rows_fill, dim3(nsub), dim3(256), 0, ctx->stream, nsub, B, n, stride, (const long long *)lp64.p,
+                         (const int *)ext.p, S->loc_ptr_dev.p, S->rows.p);
+      ed = hipStreamSynchronize(ctx->stream);   // ext, lp64 go back to the pool when this scope ends
+      if (ed != hipSuccess) { schwarz_destroy(S); return fail(hipGetErrorString(ed), __FILE__, __LINE__); }
+    }
+  }
+  if (!devlocal) {
     const int nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     auto work = [&](int t) {
       std::vector<int> mark((size_t)n, -1);
@@ -1359,34 +1518,25 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     for (int t = 0; t < nth; ++t) th.emplace_back(work, t);
     for (auto &x : th) x.join();
   }
-  S->loc_ptr.assign((size_t)nsub + 1, 0);
-  for (int s = 0; s < nsub; ++s) S->loc_ptr[(size_t)s + 1] = S->loc_ptr[(size_t)s] + (int)srows[(size_t)s].size();
+  if (!devlocal) {
+    S->loc_ptr.assign((size_t)nsub + 1, 0);
+    for (int s = 0; s < nsub; ++s) S->loc_ptr[(size_t)s + 1] = S->loc_ptr[(size_t)s] + (int)srows[(size_t)s].size();
+  }
   const int nloc = S->loc_ptr[(size_t)nsub];
   S->nloc = nloc;
-  std::vector<int> hrows((size_t)nloc);
-  for (int s = 0; s < nsub; ++s)
-    std::copy(srows[(size_t)s].begin(), srows[(size_t)s].end(), hrows.begin() + S->loc_ptr[(size_t)s]);
+  std::vector<int> hrows(devlocal ? (size_t)0 : (size_t)nloc);
+  if (!devlocal)
+    for (int s = 0; s < nsub; ++s)
+      std::copy(srows[(size_t)s].begin(), srows[(size_t)s].end(), hrows.begin() + S->loc_ptr[(size_t)s]);
   // ---- local block-diagonal matrix (Ifpack_LocalFilter), columns in local numbering, ascending
-  std::vector<long long> lrp((size_t)nloc + 1, 0);
+  std::vector<long long> lrp(devlocal ? (size_t)1 : (size_t)nloc + 1, 0);
   HostArr<int> lci;
   HostArr<double> lv;
   int dev_maxrow = 0;
   if (devlocal) {
-    int maxsub0 = 0;
-    for (int sd = 0; sd < nsub; ++sd) maxsub0 = std::max(maxsub0, S->loc_ptr[(size_t)sd + 1] - S->loc_ptr[(size_t)sd]);
-    if (maxsub0 > kSubSweepMaxRows) {   // the subdomains came out too large for the one-workgroup form: the host path after all
-      devlocal = false;
-      adev_guard.drop();
-      const int rc0 = schwarz_host_csr(ctx, A, rp, ci, av, nullptr);
-      if (rc0 != ISPH_SUCCESS) { schwarz_destroy(S); return rc0; }
-    }
-  }
-  if (devlocal) {
     DevTmp<int> dnown, dcnt, dcown, dmeta;
     DevBuf<char> scan_tmp;
-    int rcd = S->rows.reserve((size_t)nloc);
-    if (rcd == ISPH_SUCCESS) rcd = S->loc_ptr_dev.reserve((size_t)nsub + 1);
-    if (rcd == ISPH_SUCCESS) rcd = dnown.reserve((size_t)nsub);
+    int rcd = dnown.reserve((size_t)nsub);
     if (rcd == ISPH_SUCCESS) rcd = dcnt.reserve((size_t)nloc + 1);
     if (rcd == ISPH_SUCCESS) rcd = dcown.reserve((size_t)nloc);
     if (rcd == ISPH_SUCCESS) rcd = dmeta.reserve(2);
@@ -1394,9 +1544,7 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     if (rcd == ISPH_SUCCESS) rcd = S->dg.reserve((size_t)nloc);
     hipError_t ed = hipSuccess;
     if (rcd == ISPH_SUCCESS) {
-      ed = hipMemcpyAsync(S->rows.p, hrows.data(), sizeof(int) * (size_t)nloc, hipMemcpyHostToDevice, ctx->stream);
-      if (ed == hipSuccess) ed = hipMemcpyAsync(S->loc_ptr_dev.p, S->loc_ptr.data(), sizeof(int) * ((size_t)nsub + 1), hipMemcpyHostToDevice, ctx->stream);
-      if (ed == hipSuccess) ed = hipMemcpyAsync(dnown.p, nown.data(), sizeof(int) * (size_t)nsub, hipMemcpyHostToDevice, ctx->stream);
+      ed = hipMemcpyAsync(dnown.p, nown.data(), sizeof(int) * (size_t)nsub, hipMemcpyHostToDevice, ctx->stream);
       if (ed == hipSuccess) ed = hipMemsetAsync(dmeta.p, 0, 2 * sizeof(int), ctx->stream);
       if (ed == hipSuccess) ed = hipMemsetAsync(dcnt.p + nloc, 0, sizeof(int), ctx->stream);
     }
@@ -1503,10 +1651,10 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   }
   S->t_ms[1] = ms_since(t0); t0 = clk();
   // ---- level-of-fill pattern (k > 0) and the factor arrays
-  std::vector<long long> frp((size_t)nloc + 1, 0);
+  std::vector<long long> frp(devlocal ? (size_t)1 : (size_t)nloc + 1, 0);
   HostArr<int> fci;
   HostArr<double> fv;
-  std::vector<int> fdg((size_t)nloc, -1);
+  std::vector<int> fdg(devlocal ? (size_t)0 : (size_t)nloc, -1);
   bool missing_diag = false;
   if (resident1) {
     // count, prefix on the host (4 MB down, 8 MB up), fill; then the pattern comes to the host for the level analysis
@@ -1799,9 +1947,9 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
     for (size_t q = 0; q < uord4.size(); ++q) if (uord4[q] >= 0) upos4[(size_t)uord4[q]] = (int)q;
   }
   // ---- combine lists: global row -> local rows (Add: every copy, Zero: the owned copy), subdomain order
-  std::vector<long long> rev_ptr((size_t)n + 1, 0);
+  std::vector<long long> rev_ptr(devlocal ? (size_t)0 : (size_t)n + 1, 0);
   std::vector<int> rev_idx;
-  {
+  if (!devlocal) {
     for (int s = 0; s < nsub; ++s) {
       const int base = S->loc_ptr[(size_t)s];
       const int cnt = combine == 0 ? S->loc_ptr[(size_t)s + 1] - base : nown[(size_t)s];
@@ -1831,8 +1979,34 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
   if (rc == ISPH_SUCCESS && !devlocal) rc = up(S->rows, hrows);
   if (rc == ISPH_SUCCESS) rc = up(S->lord, lord);
   if (rc == ISPH_SUCCESS) rc = up(S->uord, uord);
-  if (rc == ISPH_SUCCESS) rc = up(S->rev_ptr, rev_ptr);
-  if (rc == ISPH_SUCCESS) rc = up(S->rev_idx, rev_idx);
+  if (rc == ISPH_SUCCESS && !devlocal) rc = up(S->rev_ptr, rev_ptr);
+  if (rc == ISPH_SUCCESS && !devlocal) rc = up(S->rev_idx, rev_idx);
+  if (rc == ISPH_SUCCESS && devlocal) {   // the combine lists on the device (k_gilu_rev_*)
+    const bool add = combine == 0;
+    rc = S->rev_ptr.reserve((size_t)n + 1);
+    if (rc == ISPH_SUCCESS) rc = S->rev_idx.reserve((size_t)std::max(add ? nloc : n, 1));
+    if (rc == ISPH_SUCCESS && !add) {
+      hipLaunchKernelGGL(k_gilu_rev_zero, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, B, (const int *)S->loc_ptr_dev.p,
+                         S->rev_ptr.p, S->rev_idx.p);
+    } else if (rc == ISPH_SUCCESS) {
+      DevTmp<int> rcnt;
+      DevBuf<char> scan_tmp;
+      rc = rcnt.reserve((size_t)n + 1);
+      if (rc == ISPH_SUCCESS && hipMemsetAsync(rcnt.p, 0, sizeof(int) * ((size_t)n + 1), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+      if (rc == ISPH_SUCCESS) {
+        hipLaunchKernelGGL(k_gilu_rev_count, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nloc, (const int *)S->rows.p, rcnt.p);
+        rc = amg_scan(ctx, (const int *)rcnt.p, S->rev_ptr.p, n + 1, scan_tmp);
+      }
+      if (rc == ISPH_SUCCESS && hipMemsetAsync(rcnt.p, 0, sizeof(int) * ((size_t)n + 1), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+      if (rc == ISPH_SUCCESS) {
+        hipLaunchKernelGGL(k_gilu_rev_fill, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nloc, (const int *)S->rows.p,
+                           (const long long *)S->rev_ptr.p, rcnt.p, S->rev_idx.p);
+        hipLaunchKernelGGL(k_gilu_rev_sort, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, (const long long *)S->rev_ptr.p, S->rev_idx.p);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("combine lists failed", __FILE__, __LINE__);   // rcnt, scan_tmp leave scope
+      }
+      scan_tmp.release();
+    }
+  }
   if (rc == ISPH_SUCCESS) rc = S->w.reserve((size_t)(nloc > 0 ? nloc : 1));
   if (rc == ISPH_SUCCESS) rc = S->err.reserve(1);
   DevTmp<int> maxlev;

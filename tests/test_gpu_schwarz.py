@@ -215,7 +215,7 @@ def test_form_of_the_sweeps_follows_the_width_of_the_levels(gpu_ctx):
 
 
 @pytest.mark.parametrize("block,fill,overlap,combine", [(256, 0, 1, "add"), (256, 0, 1, "zero"), (192, 1, 1, "add"), (256, 1, 1, "zero"),
-                                                       (256, 0, 0, "add")])
+                                                       (256, 0, 0, "add"), (200, 0, 1, "add"), (200, 0, 1, "zero"), (200, 0, 0, "zero")])
 def test_many_small_subdomains_one_workgroup_per_subdomain(gpu_ctx, block, fill, overlap, combine):
     """>= 32 subdomains of <= 4096 extended rows take the form with ONE launch per application (k_gilu_solve_sub: a
     workgroup per subdomain, its part of the vector in LDS, a barrier per level).  Against the oracle like every other form
