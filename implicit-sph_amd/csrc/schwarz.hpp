@@ -452,7 +452,11 @@ __global__ __launch_bounds__(256) void k_gilu_sub_local(int nloc, int nsub, int 
     next_seen += __popcll(me);
   }
   if (!FILL) {
-    if (lane == 0) { cnt[q] = nown_seen + next_seen; cown[q] = nown_seen; atomicMax(&meta[0], nown_seen + next_seen); }
+    if (lane == 0) {
+      cnt[q] = nown_seen + next_seen; cown[q] = nown_seen;
+      // (an atomic of every wave on the one word took 41 of the pass' 49 ms at 4.3 M rows)
+      if (nown_seen + next_seen > *(volatile int *)&meta[0]) atomicMax(&meta[0], nown_seen + next_seen);
+    }
   } else {
     dpos = wave_max_i32(dpos);
     if (lane == 0) { dg[q] = dpos; if (dpos < 0) atomicOr(&meta[1], 1); }
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gilu_sub_factor(const int *__res
   const int *lp = lptr + 2 * base + 2 * s;
   const int nL = nlist[2 * s];
   __syncthreads();
-  constexpr int kPF = 4;
+  constexpr int kPF = 4;   // 8 measured the same (58.9 / 58.2 ms at 100^3): the launch is bound by L2 misses, see below
   for (int l = 0; l < nL; ++l) {
     for (int q = lp[l] + wave; q < lp[l + 1]; q += WAVES) {
       const int i = (int)(D[2 * (long long)q + 1] >> 32);
@@ -2069,6 +2073,9 @@ inline int schwarz_create(isph_ctx *ctx, const isph_mat *A, int fill, int block_
                        (const long long *)S->rp.p, (const int *)S->ci.p, (const int *)S->dg.p, S->sub_desc.p, S->sub_lptr.p,
                        S->sub_nlist.p, maxlev.p);
     const int mr = std::max(maxrow, 1), ms = (maxsub + 63) / 64 * 64;
+    // (PMC at 100^3, 512 rows + one layer: FETCH_SIZE 76 GB against 8 GB of factor, L2 hit 16 % -- every pivot row's upper
+    //  part is re-read ~40 times and 1500 resident subdomains x 0.4 MB of live rows do not fit the 32 MB of L2; fewer resident
+    //  subdomains (2 per CU instead of 4-6) were slower, 88 against 59 ms: the chain per subdomain bounds it then)
     const size_t lds_f = (size_t)4 * ((size_t)mr * 12 + (size_t)ms * 2);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gilu_sub_factor<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
