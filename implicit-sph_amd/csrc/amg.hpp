@@ -25,6 +25,8 @@ int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const int *drp, const
 int mat_from_device_csr(isph_ctx *ctx, int nrow, int ncol, const long long *drp, const int *dci, const double *dv,
                         long long nnz, isph_mat **Aout, bool rows_sorted = false);
 void isph_mat_destroy(isph_mat *A);
+extern "C" int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_rank, const int *send_ptr,
+                                 const int *send_idx, const int *recv_ptr);
 
 namespace isph {
 
@@ -63,6 +65,10 @@ struct isph_amg {
   std::vector<isph::AmgLevel *> L;
   isph::DevBuf<double> cinv;  // dense inverse of the coarsest operator (non-singular case)
   int nc = 0;
+  // more than one rank (coarse levels across ranks, see amg_extend_prolongator): the coarsest operator of ALL ranks is
+  // inverted on every rank (nc = its global size, rows nc_off .. nc_off + nc_loc are this rank's)
+  int dist = 0, nc_off = 0, nc_loc = 0;
+  isph::DevBuf<double> bglob;
 };
 
 namespace isph {
@@ -809,7 +815,7 @@ inline void amg_level_destroy(AmgLevel *L) {
 inline void amg_destroy(isph_amg *G) {
   if (!G) return;
   for (auto *L : G->L) amg_level_destroy(L);
-  G->cinv.release();
+  G->cinv.release(); G->bglob.release();
   delete G;
 }
 
@@ -968,6 +974,186 @@ inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, int nag
   return rc;
 }
 
+
+// ---- coarse levels across ranks --------------------------------------------------------------------------------------
+// ML's "Uncoupled" aggregation keeps aggregates (and here the smoothed prolongator's columns) on the rank, but its
+// Galerkin operator P^T A P is the product with the WHOLE A (precond_ml.h:49, ML_Gen_MGHierarchy): a coarse row couples
+// to the neighbours' aggregates through A's ghost columns.  What that takes on top of the rank-local set-up:
+//   * the rows of P that belong to A's ghost columns -- every rank sends the P rows of its send-list nodes with the fine
+//     level's own halo plan (a fixed record per node: length, the peer's coarse list size, K column positions, K values;
+//     K = longest such row over all ranks), the columns as positions in the ascending list of coarse unknowns the rank
+//     will send to that peer from now on -- which IS the coarse level's send list;
+//   * P extended by those rows (columns nagg + offset of the peer + position), so that A P and R (A P) come out of the
+//     same SpGEMM kernels with ghost columns in the coarse operator;
+//   * the coarse operator's halo plan (same peers; the send lists above; receive counts as announced by the peers).
+// The cycle's coarse SpMVs then exchange like the fine one does (spmv_dev).
+__global__ void k_amg_send_rowmax(int nsend, const int *__restrict__ send_idx, const rp_t *__restrict__ prp, int *__restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nsend) return;
+  const int i = send_idx[k], len = (int)(prp[i + 1] - prp[i]);
+  if (len > *(volatile int *)out) atomicMax(out, len);
+}
+__global__ void k_amg_mark_cols(int s0, int s1, const int *__restrict__ send_idx, const rp_t *__restrict__ prp,
+                                const int *__restrict__ pci, int *__restrict__ flag) {
+  const int k = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= s1) return;
+  const int i = send_idx[k];
+  for (rp_t p = prp[i]; p < prp[i + 1]; ++p) flag[pci[p]] = 1;
+}
+__global__ void k_amg_compact(int n, const int *__restrict__ flag, const int *__restrict__ pos, int *__restrict__ list) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n && flag[c]) list[pos[c]] = c;
+}
+// record of send slot k: [len, count, pos_0 .. pos_{K-1}, val_0 .. val_{K-1}]
+__global__ void k_amg_pack_rows(int s0, int s1, const int *__restrict__ send_idx, const rp_t *__restrict__ prp,
+                                const int *__restrict__ pci, const double *__restrict__ pv, const int *__restrict__ pos,
+                                int K, int count, double *__restrict__ buf) {
+  const int k = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= s1) return;
+  const int i = send_idx[k];
+  const rp_t b = prp[i];
+  const int len = (int)(prp[i + 1] - b);
+  double *rec = buf + (size_t)k * (2 + 2 * (size_t)K);
+  rec[0] = (double)len; rec[1] = (double)count;
+  for (int t = 0; t < K; ++t) {
+    rec[2 + t] = t < len ? (double)pos[pci[b + t]] : 0.0;
+    rec[2 + K + t] = t < len ? pv[b + t] : 0.0;
+  }
+}
+__global__ void k_amg_ext_len(int n, int nrecv, const rp_t *__restrict__ prp, const double *__restrict__ rbuf, int K, int *__restrict__ len) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) len[q] = (int)(prp[q + 1] - prp[q]);
+  else if (q < n + nrecv) len[q] = (int)rbuf[(size_t)(q - n) * (2 + 2 * (size_t)K)];
+  else if (q == n + nrecv) len[q] = 0;
+}
+__global__ void k_amg_ext_fill(int n, int nrecv, const rp_t *__restrict__ prp, const int *__restrict__ pci, const double *__restrict__ pv,
+                               const double *__restrict__ rbuf, int K, const int *__restrict__ slot_col0, const rp_t *__restrict__ erp,
+                               int *__restrict__ eci, double *__restrict__ ev) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n + nrecv) return;
+  const rp_t w = erp[q];
+  if (q < n) {
+    const rp_t b = prp[q];
+    const int len = (int)(prp[q + 1] - b);
+    for (int t = 0; t < len; ++t) { eci[w + t] = pci[b + t]; ev[w + t] = pv[b + t]; }
+  } else {
+    const double *rec = rbuf + (size_t)(q - n) * (2 + 2 * (size_t)K);
+    const int len = (int)rec[0], c0 = slot_col0[q - n];
+    for (int t = 0; t < len; ++t) { eci[w + t] = c0 + (int)rec[2 + t]; ev[w + t] = rec[2 + K + t]; }
+  }
+}
+
+// in-place all-reduce of a few host numbers (op 0 sum, 1 max); every rank of the communicator calls it
+inline int amg_host_allreduce(isph_ctx *ctx, double *h, int count, int op) {
+  DevTmp<double> d;
+  ISPH_CHECK(d.reserve((size_t)count));
+  ISPH_CHECK_HIP(hipMemcpyAsync(d.p, h, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK(comm_allreduce(ctx, d.p, count, op, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(h, d.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return ISPH_SUCCESS;
+}
+
+// P (n x nagg, this rank's rows) -> Pext ((n + ghosts of A) x (nagg + ghosts of the coarse level)) and the coarse halo
+// lists.  K: longest P row on any send list of any rank (agreed by the caller).
+inline int amg_extend_prolongator(isph_ctx *ctx, const isph_halo &H, const DCsr &P, int K, DCsr &Pext, std::vector<int> &csend_ptr,
+                                  std::vector<int> &csend_idx, std::vector<int> &crecv_ptr, DevBuf<char> &tmp) {
+  const int n = P.n, nagg = P.m, np = H.npeers, nsend = H.nsend, nrecv = H.nrecv;
+  const size_t rec = 2 + 2 * (size_t)K;
+  DevTmp<double> sbuf, rbuf;
+  DevTmp<int> flag, pos, list, slot0, len;
+  ISPH_CHECK(sbuf.reserve(std::max<size_t>((size_t)nsend * rec, 1)));
+  ISPH_CHECK(rbuf.reserve(std::max<size_t>((size_t)nrecv * rec, 1)));
+  ISPH_CHECK(flag.reserve((size_t)nagg + 1));
+  ISPH_CHECK(pos.reserve((size_t)nagg + 1));
+  ISPH_CHECK(list.reserve((size_t)std::max(nagg, 1)));
+  csend_ptr.assign((size_t)np + 1, 0);
+  csend_idx.clear();
+  std::vector<int> hl;
+  for (int p = 0; p < np; ++p) {
+    const int s0 = H.send_ptr[(size_t)p], s1 = H.send_ptr[(size_t)p + 1];
+    int count = 0;
+    if (s1 > s0) {
+      ISPH_CHECK_HIP(hipMemsetAsync(flag.p, 0, sizeof(int) * ((size_t)nagg + 1), ctx->stream));
+      hipLaunchKernelGGL(k_amg_mark_cols, dim3((s1 - s0 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, s0, s1, (const int *)H.send_idx.p,
+                         (const rp_t *)P.rp.p, (const int *)P.ci.p, flag.p);
+      ISPH_CHECK(amg_scan(ctx, (const int *)flag.p, pos.p, nagg + 1, tmp));
+      ISPH_CHECK(amg_read_int(ctx, pos.p + nagg, &count));
+      if (count > 0) {
+        hipLaunchKernelGGL(k_amg_compact, dim3((nagg + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nagg, (const int *)flag.p,
+                           (const int *)pos.p, list.p);
+        hl.resize((size_t)count);
+        ISPH_CHECK_HIP(hipMemcpyAsync(hl.data(), list.p, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+      }
+      hipLaunchKernelGGL(k_amg_pack_rows, dim3((s1 - s0 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, s0, s1, (const int *)H.send_idx.p,
+                         (const rp_t *)P.rp.p, (const int *)P.ci.p, (const double *)P.v.p, (const int *)pos.p, K, count, sbuf.p);
+      ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if (count > 0) csend_idx.insert(csend_idx.end(), hl.begin(), hl.end());
+    }
+    csend_ptr[(size_t)p + 1] = csend_ptr[(size_t)p] + count;
+  }
+  ISPH_CHECK(comm_exchange(ctx, H, sbuf.p, rbuf.p, (int)rec, false, ctx->stream));
+  // what every peer will send from now on: announced in each of its records
+  crecv_ptr.assign((size_t)np + 1, 0);
+  std::vector<double> cnt((size_t)np, 0.0);
+  for (int p = 0; p < np; ++p) {
+    const int r0 = H.recv_ptr[(size_t)p], r1 = H.recv_ptr[(size_t)p + 1];
+    if (r1 > r0) ISPH_CHECK_HIP(hipMemcpyAsync(&cnt[(size_t)p], rbuf.p + (size_t)r0 * rec + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int> hslot((size_t)std::max(nrecv, 1), 0);
+  for (int p = 0; p < np; ++p) {
+    crecv_ptr[(size_t)p + 1] = crecv_ptr[(size_t)p] + (int)cnt[(size_t)p];
+    for (int k = H.recv_ptr[(size_t)p]; k < H.recv_ptr[(size_t)p + 1]; ++k) hslot[(size_t)k] = nagg + crecv_ptr[(size_t)p];
+  }
+  const int ncg = crecv_ptr[(size_t)np];
+  ISPH_CHECK(slot0.reserve((size_t)std::max(nrecv, 1)));
+  if (nrecv > 0) ISPH_CHECK_HIP(hipMemcpyAsync(slot0.p, hslot.data(), sizeof(int) * (size_t)nrecv, hipMemcpyHostToDevice, ctx->stream));
+  const int ne = n + nrecv;
+  ISPH_CHECK(len.reserve((size_t)ne + 1));
+  hipLaunchKernelGGL(k_amg_ext_len, dim3((ne + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, nrecv, (const rp_t *)P.rp.p,
+                     (const double *)rbuf.p, K, len.p);
+  Pext.n = ne; Pext.m = nagg + ncg;
+  ISPH_CHECK(Pext.rp.reserve((size_t)ne + 1));
+  ISPH_CHECK(amg_scan(ctx, (const int *)len.p, Pext.rp.p, ne + 1, tmp));
+  long long nnz = 0;
+  ISPH_CHECK(amg_read_off(ctx, Pext.rp.p + ne, &nnz));
+  Pext.nnz = nnz;
+  ISPH_CHECK(Pext.ci.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  ISPH_CHECK(Pext.v.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  hipLaunchKernelGGL(k_amg_ext_fill, dim3((ne + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, nrecv, (const rp_t *)P.rp.p,
+                     (const int *)P.ci.p, (const double *)P.v.p, (const double *)rbuf.p, K, (const int *)slot0.p, (const rp_t *)Pext.rp.p,
+                     Pext.ci.p, Pext.v.p);
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // hslot and the temporaries go out of scope
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
+// the coarsest operator of all ranks as one dense [A | I] on every rank: own rows written, the rest summed in
+__global__ void k_dense_from_csr_glob(int nc, int N, int off, const rp_t *__restrict__ rp, const int *__restrict__ ci,
+                                      const double *__restrict__ v, const double *__restrict__ ghost_gid, double *__restrict__ aug) {
+  const int i = blockIdx.x;
+  double *row = aug + (size_t)(off + i) * 2 * N;
+  if (threadIdx.x == 0) row[N + off + i] = 1.0;
+  for (rp_t p = rp[i] + threadIdx.x; p < rp[i + 1]; p += blockDim.x) {
+    const int c = ci[p];
+    row[c < nc ? off + c : (int)ghost_gid[c - nc]] = v[p];
+  }
+}
+__global__ void k_amg_gid(int n, int off, const int *__restrict__ idx, double *__restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = (double)(off + idx[k]);
+}
+__global__ __launch_bounds__(256) void k_dense_apply_rows(int nloc, int N, int off, const double *__restrict__ aug,
+                                                          const double *__restrict__ b, double *__restrict__ x) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= nloc) return;
+  double s = 0.0;
+  for (int c = lane; c < N; c += 64) s += aug[(size_t)(off + i) * 2 * N + N + c] * b[c];
+  s = wave_sum(s);
+  if (lane == 0) x[i] = s;
+}
+
 inline int amg_level_buffers(AmgLevel *L) {
   const size_t m = (size_t)(L->A.n > 0 ? L->A.n : 1) + 64;
   ISPH_CHECK(L->x.reserve(m));
@@ -1004,26 +1190,66 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
       hipLaunchKernelGGL(k_fill, dim3(stream_grid(n0)), dim3(kBlock), 0, ctx->stream, n0, L0->nv.p, 1.0);
     }
   }
-  while (rc == ISPH_SUCCESS && G->nlev < prm->max_levels) {
+  // more than one rank: every decision about the depth of the hierarchy is taken by all ranks together (the set-up and
+  // the cycle exchange with the neighbours on every level), a failure on one rank is a failure on all
+  const bool dist = comm_active(ctx) && ctx->nranks > 1;
+  G->dist = dist ? 1 : 0;
+  while ((dist || rc == ISPH_SUCCESS) && G->nlev < prm->max_levels) {
     AmgLevel *L = G->L.back();
     const int n = L->A.n;
-    if (n <= prm->coarse_max) break;
-    rc = dg.reserve((size_t)n);
-    if (rc != ISPH_SUCCESS) break;
-    hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const rp_t *)L->A.rp.p,
-                       (const int *)L->A.ci.p, (const double *)L->A.v.p, dg.p);
+    if (dist) {   // go on while any rank is above coarse_max (and none has failed)
+      double h[2] = {rc == ISPH_SUCCESS && n > prm->coarse_max ? 1.0 : 0.0, rc == ISPH_SUCCESS ? 0.0 : 1.0};
+      if (amg_host_allreduce(ctx, h, 2, 1) != ISPH_SUCCESS) { rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__); break; }
+      if (h[1] != 0.0) { if (rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__); break; }
+      if (h[0] == 0.0) break;
+    } else if (n <= prm->coarse_max) break;
+    rc = dg.reserve((size_t)(n > 0 ? n : 1));
+    if (rc != ISPH_SUCCESS && !dist) break;
     int nagg = 0;
-    rc = amg_aggregate(ctx, L, dg.p, prm->theta, tmp, &nagg);
-    if (rc != ISPH_SUCCESS) break;
+    if (rc == ISPH_SUCCESS && n > 0) {
+      hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const rp_t *)L->A.rp.p,
+                         (const int *)L->A.ci.p, (const double *)L->A.v.p, dg.p);
+      rc = amg_aggregate(ctx, L, dg.p, prm->theta, tmp, &nagg);
+    }
+    if (rc != ISPH_SUCCESS && !dist) break;
     // no coarsening, or a coarse space too small to carry anything but the null vector: stop here
-    if (nagg < 8 || nagg >= n) { L->agg.release(); break; }
+    bool stop = rc != ISPH_SUCCESS || nagg < 8 || nagg >= n;
+    if (dist) {   // ... on every rank if on one
+      double h[2] = {stop ? 1.0 : 0.0, rc == ISPH_SUCCESS ? 0.0 : 1.0};
+      if (amg_host_allreduce(ctx, h, 2, 1) != ISPH_SUCCESS) { rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__); break; }
+      if (h[1] != 0.0 && rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__);
+      stop = h[0] != 0.0;
+    }
+    if (stop) { L->agg.release(); break; }
     AmgLevel *Lc = new AmgLevel();
     rc = amg_prolongator(ctx, L, dg.p, nagg, prm->omega, Lc->nv, tmp, derr.p);
-    DCsr AP;
+    DCsr AP, Pext;
     DCsr &R = L->R;
+    const isph_halo &H = L->Am->halo;
+    std::vector<int> cs_ptr, cs_idx, cr_ptr;
+    bool extended = false;
+    if (dist) {
+      // the P rows behind A's ghost columns (amg_extend_prolongator); K is agreed first, by all ranks
+      DevTmp<int> kmax;
+      int hk = 0;
+      if (rc == ISPH_SUCCESS) rc = kmax.reserve(1);
+      if (rc == ISPH_SUCCESS && hipMemsetAsync(kmax.p, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+      if (rc == ISPH_SUCCESS && H.nsend > 0)
+        hipLaunchKernelGGL(k_amg_send_rowmax, dim3((H.nsend + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, H.nsend,
+                           (const int *)H.send_idx.p, (const rp_t *)L->P.rp.p, kmax.p);
+      if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, kmax.p, &hk);
+      double h[2] = {(double)hk, rc == ISPH_SUCCESS ? 0.0 : 1.0};
+      if (amg_host_allreduce(ctx, h, 2, 1) != ISPH_SUCCESS) { rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__); amg_level_destroy(Lc); break; }
+      if (h[1] != 0.0) { if (rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__); amg_level_destroy(Lc); break; }
+      if (H.npeers > 0) {   // (a rank without ghost columns of its own still owes its neighbours their rows)
+        rc = amg_extend_prolongator(ctx, H, L->P, std::max((int)h[0], 1), Pext, cs_ptr, cs_idx, cr_ptr, tmp);
+        extended = rc == ISPH_SUCCESS;
+      }
+    }
     if (rc == ISPH_SUCCESS) rc = amg_transpose(ctx, L->P, R, tmp);
-    if (rc == ISPH_SUCCESS) rc = amg_spgemm_ap(ctx, L->A, L->P, AP, tmp, derr.p);
+    if (rc == ISPH_SUCCESS) rc = amg_spgemm_ap(ctx, L->A, extended ? Pext : L->P, AP, tmp, derr.p);
     if (rc == ISPH_SUCCESS) rc = amg_spgemm_t<4096, 256>(ctx, R, AP, Lc->A, tmp, derr.p);
+    Pext.release();
     int herr = 0;
     if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, derr.p, &herr);
     if (rc == ISPH_SUCCESS && (herr & 1)) rc = fail("AMG: a row touches more than 512 aggregates", __FILE__, __LINE__);
@@ -1032,13 +1258,19 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc == ISPH_SUCCESS) rc = mat_from_device_csr(ctx, Lc->A.n, Lc->A.m, Lc->A.rp.p, Lc->A.ci.p, Lc->A.v.p, Lc->A.nnz, &Lc->Aown);
     // without ghost columns A (x + P e) = A x + (A P) e: the cycle updates the residual with the product already at hand
     // (a fifth of A's entries) instead of a second sweep over A
-    if (rc == ISPH_SUCCESS && (L->Am->S.ncol == L->Am->S.nrow || L->Am->local)) {
+    // (not on a rank that sends to neighbours: the product it saves is also this rank's part of their exchange)
+    if (rc == ISPH_SUCCESS && ((L->Am->S.ncol == L->Am->S.nrow && L->Am->halo.nsend == 0) || L->Am->local)) {
       rc = mat_from_device_csr(ctx, AP.n, AP.m, AP.rp.p, AP.ci.p, AP.v.p, AP.nnz, &L->APm, /*rows_sorted=*/true);
       if (rc == ISPH_SUCCESS) L->APm->local = true;
     }
     AP.release();
-    if (rc != ISPH_SUCCESS) { amg_level_destroy(Lc); break; }
-    L->Pm->local = Lc->Aown->local = true;
+    if (rc == ISPH_SUCCESS && extended) {   // the coarse operator exchanges with the same peers (lists: amg_extend_prolongator)
+      rc = isph_mat_set_halo(ctx, Lc->Aown, H.npeers, H.peer.data(), cs_ptr.data(), cs_idx.empty() ? nullptr : cs_idx.data(), cr_ptr.data());
+      if (rc == ISPH_SUCCESS) Lc->Aown->aux = true;
+    }
+    if (rc != ISPH_SUCCESS) { amg_level_destroy(Lc); if (dist) continue; break; }   // dist: the next consensus ends the loop on all ranks
+    L->Pm->local = true;
+    if (!extended) Lc->Aown->local = true;
     Lc->Am = Lc->Aown;
     G->L.push_back(Lc);
     ++G->nlev;
@@ -1048,6 +1280,19 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   if (G->nlev > 1) { L0->A.ci.release(); L0->A.v.release(); L0->A.rp.release(); }
   // smoothers, work vectors, coarse solve
   G->coarse_smooth = G->singular || G->L.back()->A.n > kAmgDenseMax;
+  int nc_off = 0, nc_glob = G->L.back()->A.n;
+  if (dist) {
+    // the coarsest operators of all ranks form ONE system (ML gathers it for its direct solver): every rank inverts it
+    std::vector<double> h((size_t)ctx->nranks + 1, 0.0);
+    h[(size_t)ctx->rank] = (double)G->L.back()->A.n;
+    h[(size_t)ctx->nranks] = rc == ISPH_SUCCESS ? 0.0 : 1.0;
+    if (amg_host_allreduce(ctx, h.data(), ctx->nranks + 1, 0) != ISPH_SUCCESS) rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__);
+    else if (h[(size_t)ctx->nranks] != 0.0 && rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__);
+    double tot = 0.0;
+    for (int r = 0; r < ctx->nranks; ++r) { if (r == ctx->rank) nc_off = (int)tot; tot += h[(size_t)r]; }
+    nc_glob = tot > 2.0e9 ? 2000000000 : (int)tot;
+    G->coarse_smooth = G->singular || nc_glob > kAmgDenseMax;
+  }
   for (int l = 0; l < G->nlev && rc == ISPH_SUCCESS; ++l) {
     AmgLevel *L = G->L[(size_t)l];
     rc = amg_level_buffers(L);
@@ -1056,7 +1301,36 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc == ISPH_SUCCESS && (!last || G->coarse_smooth))
       rc = ilu_create(ctx, L->Am, l == 0 ? G->block : kAmgCoarseBlock, &L->sgs, /*sgs=*/true);
   }
-  if (rc == ISPH_SUCCESS && !G->coarse_smooth) {
+  if (rc == ISPH_SUCCESS && !G->coarse_smooth && dist && G->nlev > 1) {
+    AmgLevel *L = G->L.back();
+    const int ncl = L->A.n, N = nc_glob;
+    G->nc = N; G->nc_off = nc_off; G->nc_loc = ncl;
+    const isph_halo &Hc = L->Am->halo;
+    DevTmp<double> gs, gr;
+    rc = G->cinv.reserve((size_t)2 * N * N + (size_t)N + 1);
+    if (rc == ISPH_SUCCESS) rc = G->bglob.reserve((size_t)std::max(N, 1));
+    if (rc == ISPH_SUCCESS) rc = gs.reserve((size_t)std::max(Hc.nsend, 1));
+    if (rc == ISPH_SUCCESS) rc = gr.reserve((size_t)std::max(Hc.nrecv, 1));
+    if (rc == ISPH_SUCCESS && hipMemsetAsync(G->cinv.p, 0, sizeof(double) * (size_t)2 * N * N, ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS && Hc.nsend > 0)
+      hipLaunchKernelGGL(k_amg_gid, dim3((Hc.nsend + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, Hc.nsend, nc_off, (const int *)Hc.send_idx.p, gs.p);
+    if (rc == ISPH_SUCCESS) rc = comm_exchange(ctx, Hc, gs.p, gr.p, 1, false, ctx->stream);   // global numbers of the ghost columns
+    if (rc == ISPH_SUCCESS && ncl > 0)
+      hipLaunchKernelGGL(k_dense_from_csr_glob, dim3(ncl), dim3(kBlock), 0, ctx->stream, ncl, N, nc_off, (const rp_t *)L->A.rp.p,
+                         (const int *)L->A.ci.p, (const double *)L->A.v.p, (const double *)gr.p, G->cinv.p);
+    if (rc == ISPH_SUCCESS) rc = comm_allreduce(ctx, G->cinv.p, 2 * N * N, 0, ctx->stream);
+    if (rc == ISPH_SUCCESS && N > 0) {
+      double *colk = G->cinv.p + (size_t)2 * N * N;
+      for (int k = 0; k < N; ++k) {
+        hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, ctx->stream, N, k, G->cinv.p, colk, derr.p);
+        hipLaunchKernelGGL(k_gj_elim, dim3(N), dim3(256), 0, ctx->stream, N, k, G->cinv.p, (const double *)colk, (const int *)derr.p);
+      }
+      int herr = 0;
+      rc = amg_read_int(ctx, derr.p, &herr);
+      if (rc == ISPH_SUCCESS && (herr & 4)) rc = fail("AMG: coarsest operator is singular (pass the null vector)", __FILE__, __LINE__);
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == ISPH_SUCCESS) rc = fail("AMG setup failed", __FILE__, __LINE__);   // gs, gr leave scope
+  } else if (rc == ISPH_SUCCESS && !G->coarse_smooth) {
     AmgLevel *L = G->L.back();
     const int nc = L->A.n;
     G->nc = nc;
@@ -1103,6 +1377,17 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
     if (G->coarse_smooth) {
       ISPH_CHECK(amg_smooth(ctx, G, l, b, x, true));
       for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
+    } else if (G->dist && G->nlev > 1) {
+      // the right-hand side of all ranks, then this rank's rows of the inverse
+      const int N = G->nc;
+      if (N > 0) {
+        ISPH_CHECK_HIP(hipMemsetAsync(G->bglob.p, 0, sizeof(double) * (size_t)N, ctx->stream));
+        if (n > 0) ISPH_CHECK_HIP(hipMemcpyAsync(G->bglob.p + G->nc_off, b, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        ISPH_CHECK(comm_allreduce(ctx, G->bglob.p, N, 0, ctx->stream));
+        if (n > 0)
+          hipLaunchKernelGGL(k_dense_apply_rows, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, N, G->nc_off, (const double *)G->cinv.p,
+                             (const double *)G->bglob.p, x);
+      }
     } else if (n > 0) {
       hipLaunchKernelGGL(k_dense_apply, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const double *)G->cinv.p, b, x);
     }

@@ -83,6 +83,7 @@ struct isph_mat {
   isph::Sell S;
   isph_halo halo;
   bool local = false;  // rectangular operator on rank-local vectors (AMG transfer operators): no ghost columns
+  bool aux = false;    // a level operator of the AMG hierarchy with its own halo plan: not in the caller's SpMV statistics
 };
 
 struct isph_ilu;  // ilu.hpp

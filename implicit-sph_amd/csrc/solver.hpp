@@ -115,10 +115,11 @@ inline void spmv_launch(isph_ctx *ctx, const Sell &S, bool c16, int nsl, const i
 // y = A x ; if nvec: also SC_MISC+0 = y.nvec (all-reduced)
 inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, const double *nvec) {
   const Sell &S = A->S;
-  const bool halo = !(S.ncol == S.nrow || A->local);
+  // (a rank whose own rows reference no ghost column still sends what its neighbours' rows reference)
+  const bool halo = !A->local && (S.ncol != S.nrow || A->halo.nsend > 0);
   // AMG transfer / coarse operators are small or have very long rows: the window tables do not pay there
-  const bool c16 = !A->local && sell_cols16(ctx, S);
-  ProfScope prof(A->local ? nullptr : ctx, PROF_SPMV);  // the SpMV statistics are those of the caller's operator only
+  const bool c16 = !A->local && !A->aux && sell_cols16(ctx, S);
+  ProfScope prof((A->local || A->aux) ? nullptr : ctx, PROF_SPMV);  // the SpMV statistics are those of the caller's operator only
   if (nvec)
     ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
   if (!halo) {
@@ -148,7 +149,7 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
 // columns exist (k_sell_spmm16), otherwise one product after the other.  Same bits either way.
 inline int spmm_dev(isph_ctx *ctx, const isph_mat *A, int K, const double *const *xs, double *const *ys) {
   const Sell &S = A->S;
-  const bool halo = !(S.ncol == S.nrow || A->local);
+  const bool halo = !A->local && (S.ncol != S.nrow || A->halo.nsend > 0);
   if (K < 2 || K > 4 || halo || A->local || !sell_cols16(ctx, S)) {
     for (int k = 0; k < K; ++k) ISPH_CHECK(spmv_dev(ctx, A, xs[k], ys[k], nullptr));
     return ISPH_SUCCESS;

@@ -375,19 +375,22 @@ def test_cpp_mirror_on_mpi_ranks_sharing_one_gpu(tmp_path, pgrid, mode):
 AMG_KW = dict(theta=0.02, block=256, coarse_max=64)
 
 
-def _solve_amg(rank, G, dim, pgrid, n):
-    st = _rank_setup(rank, G, dim, pgrid, n, orc.NULLSPACE)
+def _solve_amg(rank, G, dim, pgrid, n, mode, sweeps):
+    st = _rank_setup(rank, G, dim, pgrid, n, mode)
     ctx, A = st["ctx"], st["A"]
     try:
-        M = hip.PrecondAMG(ctx, A, params=hip.AmgParams(**AMG_KW))            # every rank enters the set-up consensus
+        nullvec = None
+        if mode == orc.NULLSPACE:                                             # setNullVector: the normalised mask of ALL ranks
+            nullvec = np.full(st["nl"], 1.0 / np.sqrt(float(np.prod(pgrid[:dim])) * n ** dim))
+        M = hip.PrecondAMG(ctx, A, nullvec=nullvec, params=hip.AmgParams(sweeps=sweeps, **AMG_KW))   # collective set-up
         levels = M.levels
         P0 = M.export(0, "P")
         A1 = M.export(1, "A")
         agg = M.aggregates(0)
         r = np.cos(0.37 * st["rtag"].astype(np.float64))
-        z = M.apply(r)                                                      # fine-level residuals go through the halo
+        z = M.apply(r)                                                      # fine AND coarse residuals go through a halo
         x, bb = np.zeros(st["nl"]), st["b"].copy()
-        info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
+        info = hip.solve(ctx, A, bb, x, prec=M, singular=(mode == orc.NULLSPACE))
         M.close()
         return dict(st, levels=levels, P0=P0, A1=A1, agg=agg, r=r, z=z, x=x, info=(info.converged, info.iters), ctx=None, A=None,
                     parts=None)
@@ -411,24 +414,27 @@ def _block_sgs(Ass, block, r):
     return z
 
 
-def test_rank_local_amg_across_ranks():
-    """PrecondWrapper_ML's stand-in on 4 ranks: aggregation, prolongator and Galerkin operator are built per rank from
-    the rank's owned columns (ML's Uncoupled aggregation never crosses the processor boundary; precond_ml.h:49), the
-    fine-level residuals see the neighbours through the halo.  Checked: (i) every rank's aggregates / P / coarse
-    operator equal oracle/isph_amg_oracle.c on the rank's filtered matrix, entry by entry; (ii) ONE application on all
-    ranks equals the two-level cycle written out in numpy on the GLOBAL operator -- pre-smoothing per rank, residual
-    with the neighbours' smoothed values, per-rank coarse correction, post-smoothing; (iii) FGMRES with it lands on the
-    global solution in fewer iterations than with block-Jacobi ILU(0)."""
+@pytest.mark.parametrize("mode,sweeps", [(orc.DOUBLEDIAG, 1), (orc.NULLSPACE, 2)])
+def test_amg_coarse_levels_across_ranks(mode, sweeps):
+    """PrecondWrapper_ML's stand-in on 4 ranks.  Aggregates and the smoothed prolongator stay on the rank (ML's Uncoupled
+    aggregation, precond_ml.h:49); the Galerkin operator is P^T A P with the WHOLE A: coarse rows couple to the neighbours'
+    aggregates and the coarse level exchanges a halo of its own (csrc/amg.hpp, amg_extend_prolongator).  Checked:
+    (i) every rank's aggregates / P equal oracle/isph_amg_oracle.c on the rank's filtered matrix, entry by entry;
+    (ii) every rank's coarse rows equal the rows of Pg^T A Pg (Pg = blockdiag of the ranks' P, A the GLOBAL oracle matrix):
+    the owned block entry by entry, the ghost columns as the sorted values of the row's other entries;
+    (iii) ONE application on all ranks equals the two-level cycle written out in numpy with that global coarse operator --
+    DoubleDiag: the coarse systems of all ranks solved as one (the dense inverse every rank holds); NullSpace with the
+    null vector, 2 sweeps: the coarse level smoothed twice, its residual through the coarse halo;
+    (iv) FGMRES with it lands on the global solution in fewer iterations than with block-Jacobi ILU(0)."""
     dim, pgrid, n = 3, (2, 2, 1), 8
     G = RankGroup(4)
     try:
-        res = G.run(_solve_amg, dim, pgrid, n)
+        res = G.run(_solve_amg, dim, pgrid, n, mode, sweeps)
     finally:
         G.close()
-    O = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [q["rtag"] for q in res])
+    O = GlobalOracle(dim, pgrid, n, mode, [q["rtag"] for q in res])
     O.check_rows(res)
-    N = O.N
-    Pg, A1inv, Ass = [], [], []
+    Pg, Ass, ncs = [], [], []
     for rank, q in enumerate(res):
         assert q["levels"] == 2, "the numpy cycle below is the two-level one"
         rp, ci, v = q["csr"]
@@ -437,38 +443,72 @@ def test_rank_local_amg_across_ranks():
         rpf = np.zeros(nl + 1, np.int32)
         rpf[1:] = np.cumsum(np.add.reduceat(keep.astype(np.int64), rp[:-1]))
         cif, vf = ci[keep], v[keep]
-        Go = orc.AMG(rpf, cif, vf, **AMG_KW)
-        assert Go.levels == 2
+        nv = None if mode != orc.NULLSPACE else np.full(nl, 1.0 / np.sqrt(float(O.N)))
+        Go = orc.AMG(rpf, cif, vf, nullvec=nv, **AMG_KW)
         assert np.array_equal(Go.aggregates(0), q["agg"])
         ro, co, vo = Go.export(0, "P")
         rg, cg, vg = q["P0"]
         assert np.array_equal(ro, rg) and np.array_equal(co, cg) and np.max(np.abs(vo - vg)) <= 1e-12 * np.abs(vo).max()
-        ro, co, vo = Go.export(1, "A")
-        rg, cg, vg = q["A1"]
-        assert np.array_equal(ro, rg) and np.array_equal(co, cg) and np.max(np.abs(vo - vg)) <= 1e-11 * np.abs(vo).max()
-        nc = len(rg) - 1
-        Pg.append(sps.csr_matrix((q["P0"][2], q["P0"][1], q["P0"][0]), shape=(nl, nc)))
-        A1inv.append(np.linalg.inv(sps.csr_matrix((vg, cg, rg), shape=(nc, nc)).toarray()))
+        nc = len(q["A1"][0]) - 1
+        ncs.append(nc)
+        Pg.append(sps.csr_matrix((vg, cg, rg), shape=(nl, nc)))
         Ass.append(sps.csr_matrix((vf, cif, rpf), shape=(nl, nl)))
+    Pglob = sps.block_diag(Pg, format="csr")
+    Ac = (Pglob.T @ O.Ap @ Pglob).tocsr()
+    Ac.sort_indices()
+    coff = np.concatenate([[0], np.cumsum(ncs)]).astype(np.int64)
+    scale = np.abs(Ac.data).max()
+    nghost = 0
+    for rank, q in enumerate(res):
+        rg, cg, vg = q["A1"]
+        nc = ncs[rank]
+        lo = int(coff[rank])
+        D = sps.csr_matrix((vg, cg, rg), shape=(nc, int(cg.max()) + 1 if len(cg) else nc)).tocsr()
+        own = D[:, :nc]
+        assert abs(own - Ac[lo:lo + nc][:, lo:lo + nc]).max() <= 1e-11 * scale, "rank %d: owned block of the coarse operator" % rank
+        ref_rows = Ac[lo:lo + nc].tolil()
+        ref_rows[:, lo:lo + nc] = 0
+        ref_rows = ref_rows.tocsr()
+        ref_rows.eliminate_zeros()
+        gh = D[:, nc:].tocsr()
+        nghost += gh.nnz
+        for i in range(nc):
+            a = np.sort(gh.data[gh.indptr[i]:gh.indptr[i + 1]])
+            b = np.sort(ref_rows.data[ref_rows.indptr[i]:ref_rows.indptr[i + 1]])
+            a, b = a[np.abs(a) > 1e-13 * scale], b[np.abs(b) > 1e-13 * scale]
+            assert len(a) == len(b) and np.max(np.abs(a - b), initial=0.0) <= 1e-11 * scale, "rank %d coarse row %d: couplings to the neighbours" % (rank, i)
+    assert nghost > 0, "the coarse operator has no couplings across ranks"
     r = np.concatenate([q["r"] for q in res])
     sl = [slice(int(O.off[k]), int(O.off[k + 1])) for k in range(4)]
+    csl = [slice(int(coff[k]), int(coff[k + 1])) for k in range(4)]
     blk = AMG_KW["block"]
-    x = np.concatenate([_block_sgs(Ass[k], blk, r[sl[k]]) for k in range(4)])              # pre-smoothing, zero guess
-    rr = r - O.Ap @ x                                                                         # halo: neighbours' x
-    x = x + np.concatenate([Pg[k] @ (A1inv[k] @ (Pg[k].T @ rr[sl[k]])) for k in range(4)])     # coarse correction per rank
-    rr = r - O.Ap @ x
-    x = x + np.concatenate([_block_sgs(Ass[k], blk, rr[sl[k]]) for k in range(4)])          # post-smoothing
+    sgs = lambda rr: np.concatenate([_block_sgs(Ass[k], blk, rr[sl[k]]) for k in range(4)])
+    x = sgs(r)                                                                                # pre-smoothing, zero guess
+    for _ in range(1, sweeps):
+        x = x + sgs(r - O.Ap @ x)
+    bc = Pglob.T @ (r - O.Ap @ x)
+    if mode == orc.NULLSPACE:                                                # the smoother as the coarse solver, 64-row blocks per rank
+        Acc = [Ac[csl[k]][:, csl[k]].tocsr() for k in range(4)]
+        sgc = lambda rr: np.concatenate([_block_sgs(Acc[k], 64, rr[csl[k]]) for k in range(4)])
+        xc = sgc(bc)
+        for _ in range(1, sweeps):
+            xc = xc + sgc(bc - Ac @ xc)
+    else:
+        xc = np.linalg.solve(Ac.toarray(), bc)
+    x = x + Pglob @ xc
+    for _ in range(sweeps):
+        x = x + sgs(r - O.Ap @ x)                                                            # post-smoothing
     z = np.concatenate([q["z"] for q in res])
     assert np.max(np.abs(z - x)) <= 1e-9 * np.abs(x).max()
     infos = {q["info"] for q in res}
     assert len(infos) == 1
     conv, iters = infos.pop()
     ilu = orc.ILU(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, O.block_ptr(BLOCK))
-    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=True, prec="ilu", ilu=ilu)
+    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=(mode == orc.NULLSPACE), prec="ilu", ilu=ilu)
     assert conv == 1 and iters < io.iters, (iters, io.iters)
     xs = np.concatenate([q["x"] for q in res])
     assert np.linalg.norm(xs - xo) / np.linalg.norm(xo) <= 1e-6
-    print("rank-local AMG on 4 ranks: iterations %d (block-Jacobi ILU(0): %d)" % (iters, io.iters))
+    print("AMG with coarse levels across 4 ranks: iterations %d (block-Jacobi ILU(0): %d)" % (iters, io.iters))
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] at its own size, on one GPU
