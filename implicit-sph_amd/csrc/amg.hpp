@@ -1192,7 +1192,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   }
   // more than one rank: every decision about the depth of the hierarchy is taken by all ranks together (the set-up and
   // the cycle exchange with the neighbours on every level), a failure on one rank is a failure on all
-  const bool dist = comm_active(ctx) && ctx->nranks > 1;
+  // (ISPH_AMG_RANK_LOCAL=1: the hierarchy of rounds 1-3, P^T A P with the rank's own columns only -- kept for comparisons)
+  const char *env_local = getenv("ISPH_AMG_RANK_LOCAL");
+  const bool dist = comm_active(ctx) && ctx->nranks > 1 && !(env_local && env_local[0] == '1');
   G->dist = dist ? 1 : 0;
   while ((dist || rc == ISPH_SUCCESS) && G->nlev < prm->max_levels) {
     AmgLevel *L = G->L.back();

@@ -13,11 +13,13 @@ from ranks import RankGroup
 
 hip.lib()
 n = int(os.environ.get("ISPH_NCELL", "100"))
-for pgrid in ((2, 1, 1), (2, 2, 1), (2, 2, 2)):
+prec = os.environ.get("ISPH_PREC", "bjacobi-ilu0")   # or sa-amg
+print("preconditioner", prec, flush=True)
+for pgrid in ((1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2)):
     world = int(np.prod(pgrid))
     G = RankGroup(world, timeout_s=600.0)
     try:
-        res = G.run(T._config2_rank, n, pgrid)
+        res = G.run(T._config2_rank, n, pgrid, prec)
         cnt = G.counts()
     finally:
         G.close()

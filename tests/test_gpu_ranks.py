@@ -512,7 +512,7 @@ def test_amg_coarse_levels_across_ranks(mode, sweeps):
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] at its own size, on one GPU
-def _config2_rank(rank, G, n, pgrid=(2, 2, 2)):
+def _config2_rank(rank, G, n, pgrid=(2, 2, 2), prec="bjacobi-ilu0"):
     import time
     spec = workload.TGVSpec(dim=3, ncell=tuple(n * g for g in pgrid), pgrid=pgrid, rank=rank, brick=(10, 10, 5), mode=workload.ADVECT)
     parts = dist.prune_ghosts(workload.make_tgv(spec))
@@ -530,7 +530,10 @@ def _config2_rank(rank, G, n, pgrid=(2, 2, 2)):
         bp = np.arange(0, nl + 500, 500).clip(0, nl).astype(np.int32)
         x, bb = np.zeros(nl), b.copy()
         t0 = time.perf_counter()
-        M = hip.Precond(ctx, A, "bjacobi-ilu0", block_ptr=bp)
+        if prec == "sa-amg":                                # setNullVector: the normalised mask of all ranks
+            M = hip.PrecondAMG(ctx, A, nullvec=np.full(nl, 1.0 / np.sqrt(float(nl) * float(np.prod(pgrid)))))
+        else:
+            M = hip.Precond(ctx, A, "bjacobi-ilu0", block_ptr=bp)
         info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
         wall = time.perf_counter() - t0
         y = A.spmv(x)                                  # distributed product for the explicit residual of the global system
