@@ -438,7 +438,11 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
  * defaults "coarse: max size" 128, "aggregation: damping factor" 4/3, "aggregation: threshold" 0.  `block` is the
  * row-block the Gauss-Seidel sweeps are local to (ML: the processor).  nullvec != NULL restates
  * PrecondWrapper_ML::setNullVector (precond_ml.h:97-127): one pre-computed null-space vector, smoother as the
- * coarse solver.  The hierarchy is rebuilt on every create, like the reference does on every solve. */
+ * coarse solver.  The hierarchy is rebuilt on every create, like the reference does on every solve.
+ * More than one rank (a context with a communicator, A with its halo plan set): the call is COLLECTIVE.  Aggregates and
+ * prolongator stay on the rank (Uncoupled), the coarse operators are P^T A P with the whole A -- ghost columns and a halo
+ * plan per level, derived from A's -- and the coarsest systems of all ranks are solved as one (a dense inverse on every
+ * rank; the smoother when nullvec is given).  Every rank must call it, with the same parameters. */
 typedef struct {
   int max_levels, coarse_max;
   double omega;
