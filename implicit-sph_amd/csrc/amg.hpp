@@ -1303,6 +1303,11 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc == ISPH_SUCCESS && (!last || G->coarse_smooth))
       rc = ilu_create(ctx, L->Am, l == 0 ? G->block : kAmgCoarseBlock, &L->sgs, /*sgs=*/true);
   }
+  if (dist) {   // the smoothers are built per rank: a failure there must keep every rank out of the collective steps below
+    double h = rc == ISPH_SUCCESS ? 0.0 : 1.0;
+    if (amg_host_allreduce(ctx, &h, 1, 1) != ISPH_SUCCESS) rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__);
+    else if (h != 0.0 && rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__);
+  }
   if (rc == ISPH_SUCCESS && !G->coarse_smooth && dist && G->nlev > 1) {
     AmgLevel *L = G->L.back();
     const int ncl = L->A.n, N = nc_glob;

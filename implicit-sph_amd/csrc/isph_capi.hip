@@ -947,9 +947,9 @@ int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params
   if (rc == ISPH_SUCCESS) rc = amg_create(ctx, A, prm, dn, &M->amg);
   tn.release();
   if (comm_active(ctx) && ctx->nranks > 1) {
-    // The hierarchy is built per rank (Uncoupled); only the fine level exchanges halos inside the cycle, and how often
-    // depends on whether a rank coarsened at all and on its coarse solver.  Ranks that disagree would wait for each
-    // other forever: agree here, once per set-up, and fail on every rank together instead.
+    // Every level exchanges halos inside the cycle, and how often depends on the depth of the hierarchy and on the coarse
+    // solver.  amg_create agrees on both between the ranks while it builds (amg.hpp); this is the last word on the outcome:
+    // ranks that disagree would wait for each other forever -- fail on every rank together instead.
     double h[3] = {rc == ISPH_SUCCESS ? 1.0 : 0.0, (rc == ISPH_SUCCESS && M->amg->nlev > 1) ? 1.0 : 0.0,
                    (rc == ISPH_SUCCESS && M->amg->coarse_smooth) ? 1.0 : 0.0};
     DevTmp<double> d;

@@ -375,18 +375,18 @@ def test_cpp_mirror_on_mpi_ranks_sharing_one_gpu(tmp_path, pgrid, mode):
 AMG_KW = dict(theta=0.02, block=256, coarse_max=64)
 
 
-def _solve_amg(rank, G, dim, pgrid, n, mode, sweeps):
+def _solve_amg(rank, G, dim, pgrid, n, mode, sweeps, kw=None):
     st = _rank_setup(rank, G, dim, pgrid, n, mode)
     ctx, A = st["ctx"], st["A"]
     try:
         nullvec = None
         if mode == orc.NULLSPACE:                                             # setNullVector: the normalised mask of ALL ranks
             nullvec = np.full(st["nl"], 1.0 / np.sqrt(float(np.prod(pgrid[:dim])) * n ** dim))
-        M = hip.PrecondAMG(ctx, A, nullvec=nullvec, params=hip.AmgParams(sweeps=sweeps, **AMG_KW))   # collective set-up
+        M = hip.PrecondAMG(ctx, A, nullvec=nullvec, params=hip.AmgParams(sweeps=sweeps, **(kw or AMG_KW)))   # collective set-up
         levels = M.levels
-        P0 = M.export(0, "P")
-        A1 = M.export(1, "A")
-        agg = M.aggregates(0)
+        P0 = M.export(0, "P") if levels > 1 else None
+        A1 = M.export(1, "A") if levels > 1 else None
+        agg = M.aggregates(0) if levels > 1 else None
         r = np.cos(0.37 * st["rtag"].astype(np.float64))
         z = M.apply(r)                                                      # fine AND coarse residuals go through a halo
         x, bb = np.zeros(st["nl"]), st["b"].copy()
@@ -509,6 +509,36 @@ def test_amg_coarse_levels_across_ranks(mode, sweeps):
     xs = np.concatenate([q["x"] for q in res])
     assert np.linalg.norm(xs - xo) / np.linalg.norm(xo) <= 1e-6
     print("AMG with coarse levels across 4 ranks: iterations %d (block-Jacobi ILU(0): %d)" % (iters, io.iters))
+
+
+@pytest.mark.parametrize("mode", [orc.DOUBLEDIAG, orc.NULLSPACE])
+def test_amg_deeper_hierarchy_across_eight_ranks(mode):
+    """2x2x2 ranks, every rank with seven different peers, coarse_max small enough for three or more levels: every level
+    below the fine one has its own halo plan, derived from the level above.  All ranks report the same depth, iteration
+    count and convergence; the solution is the single-rank oracle's (ILU-preconditioned) to 1e-6."""
+    dim, pgrid, n = 3, (2, 2, 2), 16
+    kw = dict(theta=0.02, block=256, coarse_max=8)
+    G = RankGroup(8)
+    try:
+        res = G.run(_solve_amg, dim, pgrid, n, mode, 1, kw)
+    finally:
+        G.close()
+    O = GlobalOracle(dim, pgrid, n, mode, [q["rtag"] for q in res])
+    assert len({q["levels"] for q in res}) == 1 and res[0]["levels"] >= 3, [q["levels"] for q in res]
+    infos = {q["info"] for q in res}
+    assert len(infos) == 1, infos
+    conv, iters = infos.pop()
+    ilu = orc.ILU(O.Ap.indptr, O.Ap.indices, O.Ap.data, 0, O.block_ptr(BLOCK))
+    xo, io, _ = orc.solve(O.Ap.indptr, O.Ap.indices, O.Ap.data, O.bp, singular=(mode == orc.NULLSPACE), prec="ilu", ilu=ilu)
+    assert conv == 1 and io.converged == 1 and iters < io.iters, (iters, io.iters)
+    xs = np.concatenate([q["x"] for q in res])
+    rr = O.bp - O.Ap @ xs                                                   # explicit residual of the GLOBAL system
+    if mode == orc.NULLSPACE:
+        rr = rr - rr.mean()
+    assert np.linalg.norm(rr) / np.linalg.norm(O.bp) <= 2e-8
+    # (DoubleDiag leaves the system a doubled diagonal entry away from singular: x moves by 1e-5 between two solves at 1e-8)
+    assert np.linalg.norm(xs - xo) / np.linalg.norm(xo) <= (1e-6 if mode == orc.NULLSPACE else 1e-4)
+    print("AMG, %d levels across 8 ranks: iterations %d (block-Jacobi ILU(0): %d)" % (res[0]["levels"], iters, io.iters))
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] at its own size, on one GPU
