@@ -18,6 +18,63 @@ constexpr int kDotBatch = 16;  // basis vectors whose partial sums a thread keep
 // Basis vectors are processed in batches of kDotBatch: every thread keeps one running sum per vector of the
 // batch in registers while it grid-strides over its rows, so the wave/block reduction (DPP + LDS) happens once
 // per batch instead of once per row chunk; w is re-read once per batch (+8N bytes per 16 vectors).
+// The Gram-Schmidt form: two ADJACENT rows per thread and 16-byte load (ld is a multiple of 64 and the vectors come from the
+// pool: 16-byte aligned; the caller checks), one trip in flight -- 43.5 -> 36 us at nk ~ 27 against k_multi_dot<2> (two
+// strided rows, 8-byte loads).  The same change in the two update kernels below measured no gain (39.3 -> 40.1, 36.6 -> 37.6 us).
+__global__ __launch_bounds__(kBlock) void k_multi_dot_v2(int n, int nk, const double *__restrict__ V, long long ld,
+                                                         const double *__restrict__ w, double *__restrict__ partial) {
+  __shared__ double sred[kDotBatch + 1][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long stride = (long long)gridDim.x * kBlock, np = n >> 1;
+  const long long p0 = (long long)blockIdx.x * kBlock + threadIdx.x;
+  const double2 *__restrict__ w2 = reinterpret_cast<const double2 *>(w);
+  for (int k0 = 0; k0 < nk || k0 == 0; k0 += kDotBatch) {
+    const int nb = min(kDotBatch, nk - k0);
+    const bool last = k0 + kDotBatch >= nk;
+    double acc[kDotBatch];
+#pragma unroll
+    for (int u = 0; u < kDotBatch; ++u) acc[u] = 0.0;
+    double ww = 0.0;
+    const double *__restrict__ vb = V + (long long)k0 * ld;
+    for (long long p = p0; p < np; p += stride) {
+      const double2 wi = w2[p];
+      if (last) ww = fma(wi.y, wi.y, fma(wi.x, wi.x, ww));
+      double2 v[kDotBatch];
+#pragma unroll
+      for (int u = 0; u < kDotBatch; ++u)
+        if (u < nb) v[u] = reinterpret_cast<const double2 *>(vb + (long long)u * ld)[p];
+#pragma unroll
+      for (int u = 0; u < kDotBatch; ++u)
+        if (u < nb) acc[u] = fma(v[u].y, wi.y, fma(v[u].x, wi.x, acc[u]));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // the odd last row
+      const double wi = w[n - 1];
+      if (last) ww = fma(wi, wi, ww);
+      for (int u = 0; u < nb; ++u) acc[u] = fma(vb[(long long)u * ld + n - 1], wi, acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kDotBatch; ++u) {
+      if (u < nb) {
+        const double s = wave_sum(acc[u]);
+        if (lane == 0) sred[u][wave] = s;
+      }
+    }
+    if (last) {
+      ww = wave_sum(ww);
+      if (lane == 0) sred[kDotBatch][wave] = ww;
+    }
+    __syncthreads();
+    if (threadIdx.x < nb)
+      partial[(long long)(k0 + threadIdx.x) * gridDim.x + blockIdx.x] =
+          (sred[threadIdx.x][0] + sred[threadIdx.x][1]) + (sred[threadIdx.x][2] + sred[threadIdx.x][3]);
+    if (last && threadIdx.x == 0)
+      partial[(long long)nk * gridDim.x + blockIdx.x] =
+          (sred[kDotBatch][0] + sred[kDotBatch][1]) + (sred[kDotBatch][2] + sred[kDotBatch][3]);
+    __syncthreads();
+    if (last) break;
+  }
+}
+
 template <int ROWS>
 __global__ __launch_bounds__(kBlock) void k_multi_dot(int n, int nk, const double *__restrict__ V, long long ld,
                                                       const double *__restrict__ w,

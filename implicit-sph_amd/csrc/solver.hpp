@@ -282,11 +282,14 @@ inline int ortho_enqueue(isph_ctx *ctx, int n, int nk, const double *V, long lon
   ISPH_CHECK(ctx->partial.reserve((size_t)kMaxRedBlocks * 66));
   hipStream_t st = ctx->stream;
   double *dh1 = ctx->dscal.p + mb + SC_DOT, *dh2 = ctx->dscal.p + mb + SC_Y, *dor = ctx->dscal.p + mb + SC_ORTHO;  // mb: mailbox of this right-hand side
-  constexpr int dot_grid = 512;
+  constexpr int dot_grid = 512;   // (256 ... 1024 workgroups: the same 36 us for the multi-dot, the fused update slower above 512)
   if (g > dot_grid) g = dot_grid;
   {
     ProfScope prof(ctx, PROF_MULTI_DOT);
-    hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+    if ((reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0)
+      hipLaunchKernelGGL(k_multi_dot_v2, dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
+    else
+      hipLaunchKernelGGL((k_multi_dot<2>), dim3(g), dim3(kBlock), 0, st, n, nk, V, ld, w, ctx->partial.p);
   }
   hipLaunchKernelGGL(k_reduce_partials, dim3(nk + 1), dim3(kBlock), 0, st, nk + 1, g, ctx->partial.p, dh1,
                      (const double *)nullptr);
