@@ -1154,6 +1154,30 @@ __global__ __launch_bounds__(256) void k_dense_apply_rows(int nloc, int N, int o
   if (lane == 0) x[i] = s;
 }
 
+// A rank that cannot coarsen any further while others still can (few rows, an empty rank) passes its level on unchanged:
+// every row its own aggregate, P = I -- so that it still takes part in the exchanges of the level and its neighbours'
+// coarse rows find its unknowns.
+__global__ void k_amg_identity_p(int n, int *__restrict__ agg, rp_t *__restrict__ prp, int *__restrict__ pci, double *__restrict__ pv,
+                                 const double *__restrict__ nv, double *__restrict__ nvc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { agg[i] = i; prp[i] = i; pci[i] = i; pv[i] = 1.0; nvc[i] = nv[i]; }
+  if (i == n) prp[n] = n;
+}
+inline int amg_identity_prolongator(isph_ctx *ctx, AmgLevel *L, DevBuf<double> &nvc) {
+  const int n = L->A.n;
+  DCsr &P = L->P;
+  P.n = n; P.m = n; P.nnz = n;
+  ISPH_CHECK(L->agg.reserve((size_t)std::max(n, 1)));
+  ISPH_CHECK(P.rp.reserve((size_t)n + 1));
+  ISPH_CHECK(P.ci.reserve((size_t)std::max(n, 1)));
+  ISPH_CHECK(P.v.reserve((size_t)std::max(n, 1)));
+  ISPH_CHECK(nvc.reserve((size_t)std::max(n, 1)));
+  hipLaunchKernelGGL(k_amg_identity_p, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, L->agg.p, P.rp.p, P.ci.p, P.v.p,
+                     (const double *)L->nv.p, nvc.p);
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
 inline int amg_level_buffers(AmgLevel *L) {
   const size_t m = (size_t)(L->A.n > 0 ? L->A.n : 1) + 64;
   ISPH_CHECK(L->x.reserve(m));
@@ -1216,15 +1240,18 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc != ISPH_SUCCESS && !dist) break;
     // no coarsening, or a coarse space too small to carry anything but the null vector: stop here
     bool stop = rc != ISPH_SUCCESS || nagg < 8 || nagg >= n;
-    if (dist) {   // ... on every rank if on one
-      double h[2] = {stop ? 1.0 : 0.0, rc == ISPH_SUCCESS ? 0.0 : 1.0};
+    bool identity = false;
+    if (dist) {   // ... when no rank can go on; a rank that cannot while others can passes its level on unchanged (P = I)
+      double h[2] = {stop ? 0.0 : 1.0, rc == ISPH_SUCCESS ? 0.0 : 1.0};
       if (amg_host_allreduce(ctx, h, 2, 1) != ISPH_SUCCESS) { rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__); break; }
       if (h[1] != 0.0 && rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__);
-      stop = h[0] != 0.0;
+      identity = stop && h[0] != 0.0 && rc == ISPH_SUCCESS;
+      stop = h[0] == 0.0 || rc != ISPH_SUCCESS;
     }
     if (stop) { L->agg.release(); break; }
     AmgLevel *Lc = new AmgLevel();
-    rc = amg_prolongator(ctx, L, dg.p, nagg, prm->omega, Lc->nv, tmp, derr.p);
+    if (identity) { nagg = n; rc = amg_identity_prolongator(ctx, L, Lc->nv); }
+    else rc = amg_prolongator(ctx, L, dg.p, nagg, prm->omega, Lc->nv, tmp, derr.p);
     DCsr AP, Pext;
     DCsr &R = L->R;
     const isph_halo &H = L->Am->halo;
@@ -1405,8 +1432,9 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
   ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
   hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
-  hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const rp_t *)L->R.rp.p,
-                     (const int *)L->R.ci.p, (const double *)L->R.v.p, (const double *)L->r.p, Lc->b.p);
+  if (L->R.n > 0)   // (a rank without rows still walks the cycle: its neighbours' exchanges and the all-reduces count on it)
+    hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const rp_t *)L->R.rp.p,
+                       (const int *)L->R.ci.p, (const double *)L->R.v.p, (const double *)L->r.p, Lc->b.p);
   ISPH_CHECK(amg_vcycle(ctx, G, l + 1, Lc->b.p, Lc->x.p));
   ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, L->z.p, nullptr));
   hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,

@@ -541,6 +541,26 @@ def test_amg_deeper_hierarchy_across_eight_ranks(mode):
     print("AMG, %d levels across 8 ranks: iterations %d (block-Jacobi ILU(0): %d)" % (res[0]["levels"], iters, io.iters))
 
 
+def test_amg_with_a_rank_that_cannot_coarsen():
+    """Five ranks on a 2x2x1 decomposition: the fifth owns no particles.  It cannot coarsen, the others can: it passes its
+    (empty) level on unchanged and stays in every collective step; the four others build the same hierarchy as without it
+    (same depth, same iteration count as the 4-rank run) and land on the same solution."""
+    dim, pgrid, n = 3, (2, 2, 1), 8
+    runs = []
+    for world in (4, 5):
+        G = RankGroup(world)
+        try:
+            runs.append(G.run(_solve_amg, dim, pgrid, n, orc.NULLSPACE, 1))
+        finally:
+            G.close()
+    four, five = runs
+    assert five[4]["nl"] == 0
+    assert {q["levels"] for q in five} == {four[0]["levels"]} and four[0]["levels"] >= 2
+    assert {q["info"] for q in five} == {q["info"] for q in four} and four[0]["info"][0] == 1
+    for a, b in zip(four, five[:4]):
+        assert np.max(np.abs(a["x"] - b["x"])) <= 1e-12 * np.abs(a["x"]).max()
+
+
 # ------------------------------------------------------------------ BASELINE configs[2] at its own size, on one GPU
 def _config2_rank(rank, G, n, pgrid=(2, 2, 2), prec="bjacobi-ilu0"):
     import time
