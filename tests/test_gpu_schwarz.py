@@ -247,3 +247,27 @@ def test_many_small_subdomains_one_workgroup_per_subdomain(gpu_ctx, block, fill,
     xo, io, _ = orc.solve(rp, ci, val, b, singular=True, prec="schwarz", schwarz=ref)
     assert info.converged == 1 and io.converged == 1 and abs(info.iters - io.iters) <= 1
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-6
+
+
+def test_many_subdomains_too_large_for_one_workgroup_take_the_host_path(gpu_ctx):
+    """>= 32 subdomains whose extended row lists outgrow the one-workgroup form (4096 rows): the device-side row lists raise
+    their flag and the set-up falls back to the host path with a launch per level -- same row lists, pattern and
+    application as the oracle."""
+    pr = Problem(tgv_spec(dim=3, n=40, mode=workload.ADVECT))
+    rp, ci, val, b = pr.poisson()
+    n, block = pr.n, 1600
+    own = np.arange(0, n + block, block).clip(0, n).astype(np.int32)
+    ref = orc.Schwarz(rp, ci, val, 0, own, 1, "zero")
+    orow, olp, orp, oci, ov = ref.export()
+    assert len(own) - 1 >= 32 and np.diff(olp).max() > 4096
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.PrecondSchwarz(gpu_ctx, A, level_of_fill=0, overlap=1, combine="zero", block_size=block)
+    assert M.schwarz_info()["persistent"] != 2
+    rows, lp, grp, gci, gv = M.export()
+    assert np.array_equal(rows, orow) and np.array_equal(lp, olp)
+    assert np.array_equal(grp, orp) and np.array_equal(gci, oci)
+    assert _factor_close(gv, ov)
+    r = np.random.default_rng(11).standard_normal(n)
+    z, zo = M.apply(r), ref.apply(r)
+    assert np.linalg.norm(z - zo) / np.linalg.norm(zo) < 1e-11
+    M.close(); A.close()
