@@ -141,6 +141,10 @@ def parse():
     ap.add_argument("--spawn", action="store_true",
                     help="start the --gpus ranks as child processes from this one (automatic when --gpus > 1 and no "
                          "torch.distributed.run environment is present)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of --gpus N on ONE device: the N process ranks all use device 0 and talk through the "
+                         "host-staged transport over gloo (RCCL forms no communicator between ranks of one device); "
+                         "not a performance figure")
     ap.add_argument("--force-rccl", action="store_true",
                     help="1 GPU only: route the periodic images through the RCCL halo path (send/recv to self)")
     return ap.parse_args()
@@ -451,6 +455,8 @@ def main():
     ngpu = args.gpus
     assert world == ngpu, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (ngpu, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # one non-default stream for torch's own kernels AND the library: every producer/consumer pair is stream-ordered
@@ -459,7 +465,13 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
 
-    if world > 1:
+    transport = None
+    if world > 1 and args.share_gpu:
+        import torch.distributed as td
+        td.init_process_group("gloo")
+        transport = dist.td_host_transport(td)            # kept alive until the context is gone
+        ctx = hip.Context(0, stream=stream, rank=rank, nranks=world, transport=transport)
+    elif world > 1:
         import torch.distributed as td
         td.init_process_group("nccl", device_id=dev)
         uid = [hip.Context.unique_id() if rank == 0 else None]
@@ -600,7 +612,7 @@ def main():
     prof = ctx.profile_read()          # {class: (ms, launches)} over the nprof untimed passes (set-up + solve)
     x_headline = x.clone()             # the headline configuration's solution (the alt runs below reuse x)
     if td is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -645,7 +657,9 @@ def main():
                        "block_rows": brows if bptr is not None else args.block,
                        "subdomains": ("%dx%dx%d-cell bricks of the particle numbering (%d rows each)" % (brick + (brows,))) if bptr is not None
                                      else "%d consecutive rows" % args.block,
-                       "parallelism": "domain bricks %dx%dx%d, RCCL halo + all-reduce" % pg,
+                       "parallelism": ("domain bricks %dx%dx%d, " % pg) +
+                                      ("host-staged halo + all-reduce over gloo, ALL RANKS ON ONE GPU (rehearsal, not a performance figure)"
+                                       if args.share_gpu else "RCCL halo + all-reduce"),
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms, "assemble_first_call_ms": assemble_first_ms,
                        "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo},

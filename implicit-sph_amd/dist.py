@@ -11,6 +11,7 @@ Index lists are exchanged once at plan time with torch.distributed object
 collectives (works on gloo and nccl); the per-SpMV exchange itself runs inside
 libisph_hip on RCCL (csrc/solver.hpp halo_exchange).
 """
+import sys
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -348,3 +349,55 @@ def extend_rows_levels(plan, rowptr, colidx, val, td, levels=1):
     xplan.ext_gids = ext_gids
     return (np.asarray(rp_out, dtype=np.int32), np.concatenate(ci_out).astype(np.int32) if ci_out else np.zeros(0, np.int32),
             np.concatenate(v_out) if v_out else np.zeros(0), xplan)
+
+
+def td_host_transport(td):
+    """hip.HostTransport (isph_host_transport) over a torch.distributed process group with CPU tensors (gloo): the
+    host-staged transport for process ranks that SHARE one device -- RCCL refuses to form a communicator there.  Used by
+    `bench.py --share-gpu` to rehearse the N-rank run (decomposition, plan, halo exchange, all-reduces, timing) on a
+    one-GPU box; the callbacks must outlive the context: keep the returned object."""
+    import ctypes as C
+    import torch
+    from . import hip
+    EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_longlong),
+                     C.POINTER(C.c_double), C.POINTER(C.c_longlong))
+    AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+    me = td.get_rank()
+
+    def exchange(user, npeers, peer, send, so, recv, ro):
+        try:
+            ns_all, nr_all = int(so[npeers]), int(ro[npeers])
+            sbuf = torch.from_numpy(np.ctypeslib.as_array(send, shape=(max(ns_all, 1),)))
+            rbuf = torch.from_numpy(np.ctypeslib.as_array(recv, shape=(max(nr_all, 1),)))
+            reqs = []
+            for p in range(npeers):
+                s0, s1, r0, r1 = int(so[p]), int(so[p + 1]), int(ro[p]), int(ro[p + 1])
+                if int(peer[p]) == me:                    # periodic wrap onto the same rank
+                    assert s1 - s0 == r1 - r0
+                    rbuf[r0:r1] = sbuf[s0:s1]
+                    continue
+                if r1 > r0:
+                    reqs.append(td.irecv(rbuf[r0:r1], src=int(peer[p])))
+                if s1 > s0:
+                    reqs.append(td.isend(sbuf[s0:s1].clone(), dst=int(peer[p])))
+            for q in reqs:
+                q.wait()
+            return 0
+        except Exception as e:                            # never let an exception cross the C boundary
+            sys.stderr.write("td_host_transport.exchange: %r\n" % (e,))
+            return 1
+
+    def allreduce(user, buf, count, op):
+        try:
+            t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(max(int(count), 1),)))[:int(count)]
+            td.all_reduce(t, op=td.ReduceOp.MAX if op == 1 else td.ReduceOp.SUM)
+            return 0
+        except Exception as e:
+            sys.stderr.write("td_host_transport.allreduce: %r\n" % (e,))
+            return 1
+
+    tr = hip.HostTransport()
+    tr._keep = (EX(exchange), AR(allreduce))              # the CFUNCTYPE objects own the thunks
+    tr.exchange = C.cast(tr._keep[0], C.c_void_p)
+    tr.allreduce = C.cast(tr._keep[1], C.c_void_p)
+    return tr
