@@ -444,7 +444,9 @@ __global__ __launch_bounds__(1024) void k_ilu_exact_offsets(int nblocks, const i
   if (t == 1023) sboff[nblocks] = part[1023] * 64;
 }
 
-__global__ __launch_bounds__(1024) void k_ilu_schedule(int n, int B, const long long *__restrict__ boff,
+// (second launch bound: eight waves per SIMD.  The kernel needed 106 SGPRs -- seven waves per SIMD, THREE 512-thread blocks per
+//  CU -- with 17 of them spilled to VGPR lanes it has four like its LDS allows: 1.60 -> 1.34 ms at 100^3)
+__global__ __launch_bounds__(1024, 8) void k_ilu_schedule(int n, int B, const long long *__restrict__ boff,
                                                        const long long *__restrict__ frp,
                                                        const int *__restrict__ fcol, const int *__restrict__ flen,
                                                        const int *__restrict__ fdiag, double *__restrict__ sv,
