@@ -74,6 +74,7 @@ __device__ __forceinline__ void ilu_block_rows(const int *__restrict__ bptr, int
 // coalesced), a block scan places the rows back to back inside the block's
 // region, then every thread copies its entries.
 constexpr int kExtChunk = 8;  // entries of a row staged per round (dynamic LDS: waves x 64 rows x 8 x 12 B)
+constexpr int kExtAhead = 8;  // slots of a row whose loads are issued together
 
 __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *__restrict__ rowlen,
                                                       const long long *__restrict__ slice_off,
@@ -107,13 +108,19 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
     len = rowlen[i];
     int prevc = -1;
     bool disorder = false;
-    for (int k = 0; k < len; ++k) {
-      const int c = scol[sell_pos(off, lane, k)];
-      if (c >= blo && c < bhi) {
-        if (c <= prevc) disorder = true;  // every later stage relies on strictly ascending columns (one diagonal)
-        prevc = c;
-        if (c == i) dg = cnt;
-        ++cnt;
+    for (int k0 = 0; k0 < len; k0 += kExtAhead) {   // the loads of kExtAhead slots first, then the dependent counting
+      int cq[kExtAhead];
+#pragma unroll
+      for (int u = 0; u < kExtAhead; ++u) cq[u] = k0 + u < len ? scol[sell_pos(off, lane, k0 + u)] : -1;
+#pragma unroll
+      for (int u = 0; u < kExtAhead; ++u) {
+        const int c = cq[u];
+        if (k0 + u < len && c >= blo && c < bhi) {
+          if (c <= prevc) disorder = true;  // every later stage relies on strictly ascending columns (one diagonal)
+          prevc = c;
+          if (c == i) dg = cnt;
+          ++cnt;
+        }
       }
     }
     if (disorder) atomicOr(err, 32);
@@ -145,13 +152,28 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
   sstart[ln] = start;
   int got = 0;
   const int lenmax = wave_max_i32(len);
+  int cq[kExtAhead];
+  double vq[kExtAhead];
   for (int k = 0; k < lenmax; ++k) {
+    const int u0 = k % kExtAhead;
+    if (u0 == 0) {   // columns and values of the next kExtAhead slots are requested together (the values of entries outside
+                     // the block travel in vain: 4 of 10 on the bench matrix, against a load per slot that waited for its column)
+#pragma unroll
+      for (int u = 0; u < kExtAhead; ++u) {
+        const bool in = k + u < len;
+        const long long p = sell_pos(off, lane, in ? k + u : 0);
+        cq[u] = in ? scol[p] : -1;
+        vq[u] = in ? sval[p] : 0.0;
+      }
+    }
+    int c = -1;
+    double v = 0.0;
+#pragma unroll
+    for (int u = 0; u < kExtAhead; ++u) if (u == u0) { c = cq[u]; v = vq[u]; }
     if (k < len) {
-      const long long p = sell_pos(off, lane, k);
-      const int c = scol[p];
       if (c >= blo && c < bhi) {
         stage_col[wv][ln][got] = c;
-        stage_val[wv][ln][got] = sval[p];
+        stage_val[wv][ln][got] = v;
         ++got;
       }
     }
