@@ -319,6 +319,9 @@ def step_workload(args, json_fd):
         vall = v[own].contiguous()
         pall = pr[own].contiguous()
         zeros3 = torch.zeros_like(vall)
+        # the functors of one time step all walk the same neighbour list (LAMMPS rebuilds it between steps at most): the
+        # library builds its layout of the list once per step instead of once per operator call
+        ctx.hold_neighbours(True)
         t2 = sync()
         # ---- computePre (pair_isph_corrected.cpp:302-313): V_i, then G_i and L_i (always formed, whatever the family)
         vf = hip.compute_volumes(ctx, dp, colmap, kernel=args.kernel)
@@ -366,6 +369,7 @@ def step_workload(args, json_fd):
         vfrac2 = vf2[own].contiguous()
         hip.shift_particles(ctx, dp, colmap, 0.05, spec.cut, 0.1, dt, dp["x"], vall2, pall2, vfrac2, kernel=args.kernel)
         t9 = sync()
+        ctx.hold_neighbours(False)
         x, v, pr = dp["x"][:N].clone(), vall2[:N].clone(), pall2[:N].clone()
         if timed:
             for k, d in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6, t8 - t7, t9 - t8)):

@@ -1068,6 +1068,13 @@ template <class OFF>
 inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *dnidx, NeighEll &E, AsmTables &T,
                              const int *dcolmap) {
   const int nslices = (n + kSlice - 1) / kSlice;
+  // a held list (isph_ctx_hold_neighbours): the layout of an earlier call with the same arrays is still good
+  isph_neigh_layout *slot = (ctx->neigh_hold && n > 0) ? &ctx->neigh_cache[dcolmap ? 1 : 0] : nullptr;
+  if (slot && slot->n == n && slot->nptr == (const void *)dnptr && slot->nidx == dnidx && slot->colmap == dcolmap) {
+    T.nlen = slot->len.p; T.noff = slot->off.p; T.nt = slot->idx.p; T.sorted = slot->is_sorted;
+    return ISPH_SUCCESS;
+  }
+  const int *const nidx_key = dnidx;
   ISPH_CHECK(E.len.reserve((size_t)(n > 0 ? n : 1)));
   ISPH_CHECK(E.off.reserve((size_t)nslices + 1));
   T.nlen = E.len.p;
@@ -1105,6 +1112,10 @@ inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *
   ISPH_CHECK_HIP(hipGetLastError());
   T.noff = E.off.p;
   T.nt = E.idx.p;
+  if (slot) {   // the buffers move into the context (T keeps pointing at them); E takes the slot's old ones and frees them
+    std::swap(slot->off, E.off); std::swap(slot->idx, E.idx); std::swap(slot->len, E.len); std::swap(slot->sorted, E.sorted);
+    slot->n = n; slot->nptr = (const void *)dnptr; slot->nidx = nidx_key; slot->colmap = dcolmap; slot->is_sorted = T.sorted;
+  }
   return ISPH_SUCCESS;
 }
 inline int build_neigh_ell(isph_ctx *ctx, int n, const NeighPtr &np, const int *dnidx, NeighEll &E, AsmTables &T,

@@ -5,6 +5,17 @@
 
 namespace isph { struct HostStager; }  // ingress.hpp: pinned ring of the host CSR ingress
 
+// The layout of a neighbour list the row kernels read (slice-transposed, optionally ordered by matrix column:
+// assemble.hpp build_neigh_ell), kept between operator calls while the caller holds the list (isph_ctx_hold_neighbours).
+struct isph_neigh_layout {
+  const void *nptr = nullptr;
+  const int *nidx = nullptr, *colmap = nullptr;
+  int n = -1, is_sorted = 0;
+  isph::DevBuf<long long> off;
+  isph::DevBuf<int> idx, len, sorted;
+  void release() { off.release(); idx.release(); len.release(); sorted.release(); nptr = nullptr; nidx = colmap = nullptr; n = -1; is_sorted = 0; }
+};
+
 struct isph_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -38,6 +49,8 @@ struct isph_ctx {
   hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
   isph::DevBuf<double> xghost;
   isph::HostStager *stager = nullptr;  // created by the first host-side isph_mat_create_csr
+  bool neigh_hold = false;             // isph_ctx_hold_neighbours
+  isph_neigh_layout neigh_cache[2];    // [0] list order, [1] ordered by matrix column
 };
 
 namespace isph {

@@ -288,6 +288,13 @@ int isph_ctx_set_profile(isph_ctx *ctx, int on) {
   return ISPH_SUCCESS;
 }
 
+int isph_ctx_hold_neighbours(isph_ctx *ctx, int on) {
+  ISPH_REQUIRE(ctx, "ctx is NULL");
+  for (auto &c : ctx->neigh_cache) c.release();   // either way: what was kept belongs to the list of before
+  ctx->neigh_hold = on != 0;
+  return ISPH_SUCCESS;
+}
+
 int isph_ctx_profile_read(isph_ctx *ctx, double ms[8], int calls[8]) {
   ISPH_REQUIRE(ctx && ms && calls, "NULL argument");
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -346,6 +353,7 @@ void isph_ctx_destroy(isph_ctx *c) {
   if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
   if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   c->xghost.release();
+  for (auto &nc : c->neigh_cache) nc.release();
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->hsend) (void)hipHostFree(c->hsend);
   if (c->hrecv) (void)hipHostFree(c->hrecv);

@@ -21,7 +21,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_ctx_profile_read", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
@@ -114,6 +114,7 @@ def lib():
         L.isph_pool_cached_bytes.argtypes = []
         L.isph_pool_cached_bytes.restype = C.c_longlong
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
+        L.isph_ctx_hold_neighbours.argtypes = [C.c_void_p, C.c_int]
         L.isph_ctx_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_create_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]
@@ -304,6 +305,10 @@ class Context:
 
     def set_profile(self, on):
         _check(lib().isph_ctx_set_profile(self.h, int(on)))
+
+    def hold_neighbours(self, on):
+        """isph_ctx_hold_neighbours: while held, the operator calls share one layout of the (unchanged) neighbour list"""
+        _check(lib().isph_ctx_hold_neighbours(self.h, int(on)))
 
     PROFILE_CLASSES = ("spmv", "prec_apply", "multi_dot", "multi_axpy_dot", "multi_axpy_norm", "ilu_extract", "ilu_schedule",
                        "ilu_factor")

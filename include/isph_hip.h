@@ -290,6 +290,13 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M,
  * isph_solve_info::spmv_ms / spmv_calls are class 0 of that one solve.  No reference counterpart (the reference's
  * Teuchos timers stop at "ISPH: solvePoisson", utils.cpp:37-38). */
 int isph_ctx_set_profile(isph_ctx *ctx, int on);
+/* Between isph_ctx_hold_neighbours(ctx, 1) and isph_ctx_hold_neighbours(ctx, 0) the caller guarantees that the neighbour
+ * list it passes in isph_particles (the same neigh_ptr / neigh_idx arrays, on the device) does not change: the layout the
+ * row kernels read -- slice-transposed, ordered by matrix column for the assemblies -- is then built by the first operator
+ * call and reused by the following ones, instead of once per call.  What LAMMPS' neighbour list is to the reference's
+ * functors between two re-neighbourings (pair_isph.cpp: every functor of a time step walks the same list->firstneigh).
+ * Either call drops what was kept.  Without it every call is self-contained. */
+int isph_ctx_hold_neighbours(isph_ctx *ctx, int on);
 int isph_ctx_profile_read(isph_ctx *ctx, double ms[8], int calls[8]);
 
 /* ---- assembly --------------------------------------------------------- */

@@ -148,3 +148,50 @@ def test_bench_step_workload_runs_consecutive_steps(tmp_path):
     assert ke4 < ke1 < ke0
     rate = -np.log(ke4 / ke1) / (3 * dt)                              # three more steps
     assert 0.5 * 4 * 0.1 < rate < 2.0 * 4 * 0.1, rate                 # 4 nu = 0.4 within a factor 2 (coarse 20^3 lattice)
+
+
+def test_held_neighbour_list_gives_the_same_operators(gpu_ctx):
+    """isph_ctx_hold_neighbours: while the caller holds the list, the operator calls share one layout of it (built by the
+    first call); volumes, corrections, the Poisson matrix and its right-hand side are bit for bit those of self-contained
+    calls, and releasing the hold drops the layout (a different list behind the same arrays is seen afterwards)."""
+    import torch
+    from isph_amd import workload
+    spec = workload.TGVSpec(dim=3, ncell=(12, 12, 12), brick=(4, 4, 4), mode=workload.ADVECT)
+    parts = workload.make_tgv(spec)
+    dev = torch.device("cuda", 0)
+    colmap_h = workload.single_rank_colmap(parts)
+    dp = dict(parts)
+    for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+        dp[k] = torch.from_numpy(np.ascontiguousarray(parts[k])).to(dev)
+    colmap = torch.from_numpy(colmap_h).to(dev)
+    own = torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)
+    rho = torch.from_numpy(parts["rho"]).to(dev)
+    vstar = torch.from_numpy(np.ascontiguousarray(parts["v"])).to(dev)
+
+    def run():
+        vf = hip.compute_volumes(gpu_ctx, dp, colmap)
+        vfrac = vf[own].contiguous()
+        G, L = hip.compute_corrections(gpu_ctx, dp, colmap, vfrac)
+        A, b = hip.assemble_poisson(gpu_ctx, dp, colmap, spec.dt, rho, vstar, vfrac=vfrac)
+        out = (vf.cpu().numpy(), G.cpu().numpy(), L.cpu().numpy(), b.cpu().numpy()) + tuple(A.export_csr())
+        A.close()
+        return out
+
+    ref = run()
+    gpu_ctx.hold_neighbours(True)
+    try:
+        first, second = run(), run()
+    finally:
+        gpu_ctx.hold_neighbours(False)
+    for a, b_, c in zip(ref, first, second):
+        assert np.array_equal(a, b_) and np.array_equal(a, c)
+    # a shorter list behind the same device arrays: only seen because the hold was released
+    nidx = dp["neigh_idx"]
+    keep = nidx.clone()
+    nl = parts["nlocal"]
+    ptr = dp["neigh_ptr"].cpu().numpy()
+    first_row = slice(int(ptr[0]), int(ptr[1]))
+    nidx[first_row] = nidx[first_row.start]            # row 0 now lists one neighbour over and over
+    changed = run()
+    nidx.copy_(keep)
+    assert not np.array_equal(changed[0], ref[0])
