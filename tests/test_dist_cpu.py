@@ -467,3 +467,59 @@ def test_cpp_overlap_levels_under_mpi_four_ranks(tmp_path, levels):
         assert nxt > ncol                                           # more rows than one layer gives
         far += int(any(int(p) not in set(int(q) for q in peers) for p in cpeers))
     assert levels < 3 or far > 0, "three layers must reach a rank the matrix' own halo does not talk to"
+
+
+def _worker_transport(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        import isph_amd  # noqa: F401
+        from isph_amd import dist
+        tr = dist.td_host_transport(td)
+        exchange, allreduce = tr._keep
+        # every rank talks to every other one and to itself (the periodic wrap of a one-rank-wide direction); rank r sends
+        # r + 1 + p numbers to its p-th peer, numbered so that the receiver can tell sender and position
+        peers = [(rank + 1 + k) % world for k in range(world)]                 # the last one is `rank` itself
+        nsend = [rank + 1 + k for k in range(world)]
+        so = np.concatenate([[0], np.cumsum(nsend)]).astype(np.int64)
+        send = np.concatenate([1000.0 * rank + 10.0 * peers[k] + np.arange(nsend[k]) / 16.0 for k in range(world)])
+        # what arrives from peer q: q's block for me; q lists me at index (rank - q - 1) mod world
+        nrecv = [peers[k] + 1 + ((rank - peers[k] - 1) % world) for k in range(world)]
+        ro = np.concatenate([[0], np.cumsum(nrecv)]).astype(np.int64)
+        recv = np.full(int(ro[-1]), -1.0)
+        pa = np.asarray(peers, dtype=np.int32)
+        dp = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        rc = exchange(None, world, dp(pa, C.c_int), dp(send, C.c_double), dp(so, C.c_longlong), dp(recv, C.c_double), dp(ro, C.c_longlong))
+        want = np.concatenate([1000.0 * peers[k] + 10.0 * rank + np.arange(nrecv[k]) / 16.0 for k in range(world)])
+        buf = np.array([float(rank + 1), -float(rank)])
+        rc2 = allreduce(None, dp(buf, C.c_double), 2, 0)
+        mx = np.array([float(rank), 7.0 - rank])
+        rc3 = allreduce(None, dp(mx, C.c_double), 2, 1)
+        out.put((rank, rc, rc2, rc3, bool(np.array_equal(recv, want)), buf.tolist(), mx.tolist()))
+    finally:
+        td.destroy_process_group()
+
+
+def test_gloo_host_transport_callbacks_three_ranks():
+    """dist.td_host_transport -- the host-staged transport `bench.py --share-gpu` hands to isph_ctx_create_hostcomm -- with
+    its two callbacks called directly (no device): an exchange in which every rank sends blocks of different lengths to
+    every other rank AND to itself, and the sum / max all-reduce."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_transport, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rc, rc2, rc3, ok, s, m in res:
+        assert rc == 0 and rc2 == 0 and rc3 == 0 and ok, (rank, rc, rc2, rc3, ok)
+        assert s == [6.0, -3.0] and m == [2.0, 7.0]
