@@ -734,8 +734,9 @@ constexpr int kIluWaves = 8;
 
 // WIDE: two U-row entries per lane are prefetched (U-rows of up to 128 entries: ILU(k > 0), wide kernels); the narrow
 // variant keeps one (the bench matrix has ~30 upper entries per row and the second queue only costs there).
+// (second launch bound of the narrow variant: eight waves per SIMD = four 512-thread blocks per CU, which its LDS allows)
 template <int WAVES, bool WIDE>
-__global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, const long long *__restrict__ frp,
+__global__ __launch_bounds__(WAVES * 64, WIDE ? 1 : 8) void k_ilu_factor(int n, int B, int W, const long long *__restrict__ frp,
                                                            const int *__restrict__ fcol, double *__restrict__ fval,
                                                            const int *__restrict__ flen,
                                                            const int *__restrict__ fdiag, const int *__restrict__ fdst,
@@ -837,13 +838,53 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
         pcnt = lenL[k] - dgL[k] - 1;
         pdk = diag[k];
       }
+      // Rows whose pivots all have at most 64 upper entries and that have at most 64 pivots -- all rows of the narrow variant
+      // on the bench matrices -- take a loop with NOTHING conditional around its loads: every request issues exactly two
+      // loads for every lane (a lane without an entry, or a request behind the last pivot, reads the row's own first entry
+      // again and the step ignores it).  Loads under a branch, or an inner loop with loads of its own, cannot be counted by
+      // the compiler's s_waitcnt pass: it then waits for (nearly) everything in flight at some steps -- vmcnt(1) / vmcnt(0)
+      // in the ISA where vmcnt(2 (kPF - 1)) belongs -- and the queue drains.  The other rows take the plain loop below.
+      const bool narrow_row = !WIDE && dg <= 64 && __ballot(lane < dg && pcnt > 64) == 0;   // wave-uniform
+      if (narrow_row) {
+        auto request1 = [&](int s, int &pc, double &pvv, double &pdv, int &pn) {
+          const int sl = s < dg ? s : 0;   // (dg >= 1 here: the loop below does not run otherwise)
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)pbase, sl);
+          const int hi = __builtin_amdgcn_readlane((int)(pbase >> 32), sl);
+          const long long p0 = (long long)(((unsigned long long)(unsigned)hi << 32) | lo);
+          const int cnt = s < dg ? __builtin_amdgcn_readlane(pcnt, sl) : 0;
+          pdv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pdk), sl), __builtin_amdgcn_readlane(__double2loint(pdk), sl));
+          pn = cnt;
+          const long long p = lane < cnt ? p0 + lane : rp;
+          pc = fcol[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
+          pvv = fval[p];
+        };
+        if (dg > 0) {
+#pragma unroll
+          for (int u = 0; u < kPF; ++u) request1(u, pcq[u], pvq[u], pdq[u], pnq[u]);
+          for (int s0 = 0; s0 < dg; s0 += kPF) {
+#pragma unroll
+            for (int u = 0; u < kPF; ++u) {
+              const int s = s0 + u;
+              if (s < dg) {
+                const int ps = lane < pnq[u] ? mp[pcq[u] - blo] : 0;  // slot+1 in row i (0: not in the pattern)
+                const double lik = mv[s] * pdq[u];   // l_ik = a_ik / d_k (reciprocal stored once per pivot)
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) mv[s] = lik;
+                if (ps) mv[ps - 1] -= lik * pvq[u];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+              }
+              request1(s + kPF, pcq[u], pvq[u], pdq[u], pnq[u]);   // unconditionally: the loads of every slot stay countable
+            }
+          }
+        }
+      } else {
       auto request = [&](int s, int &pc, double &pvv, int &pc2, double &pvv2, double &pdv, int &pn) {
-        pc = -1;
         pc2 = -1;
-        pvv = 0.0;
         pvv2 = 0.0;
         pdv = 0.0;
         pn = 0;
+        long long pbeg = rp;
         if (s < dg) {
           long long p0;
           int cnt;
@@ -860,15 +901,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
             pdv = diag[k];
           }
           pn = cnt;
-          const long long p = p0 + lane;
-          if (lane < cnt) {
-            pc = fcol[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
-            pvv = fval[p];
-          }
-          if (WIDE && lane + 64 < cnt) {
-            pc2 = fcol[p + 64];
-            pvv2 = fval[p + 64];
-          }
+          pbeg = p0;
+        }
+        // EVERY request issues its loads, for every lane (a lane without an entry, or a request behind the last pivot, reads
+        // the row's own first entry again and the step ignores it): loads under a branch cannot be counted by the compiler's
+        // s_waitcnt pass, which then waits for (nearly) everything in flight at each step -- vmcnt(1) / vmcnt(0) in the ISA
+        // instead of vmcnt(2 (kPF - 1)) -- and the queue is a queue of one.
+        const long long p = lane < pn ? pbeg + lane : rp;
+        pc = fcol[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
+        pvv = fval[p];
+        if (WIDE) {
+          const long long p2 = lane + 64 < pn ? pbeg + 64 + lane : rp;
+          pc2 = fcol[p2];
+          pvv2 = fval[p2];
         }
       };
 #pragma unroll
@@ -878,8 +923,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
         for (int u = 0; u < kPF; ++u) {
           const int s = s0 + u;
           if (s < dg) {
-            const int ps = pcq[u] >= 0 ? mp[pcq[u] - blo] : 0;  // slot+1 in row i (0: not in the pattern)
-            const int ps2 = WIDE && pcq2[u] >= 0 ? mp[pcq2[u] - blo] : 0;
+            const int ps = lane < pnq[u] ? mp[pcq[u] - blo] : 0;  // slot+1 in row i (0: not in the pattern)
+            const int ps2 = WIDE && lane + 64 < pnq[u] ? mp[pcq2[u] - blo] : 0;
             const double lik = mv[s] * pdq[u];   // l_ik = a_ik / d_k (reciprocal stored once per pivot)
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) mv[s] = lik;
@@ -898,6 +943,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_factor(int n, int B, int W, 
             request(s + kPF, pcq[u], pvq[u], pcq2[u], pvq2[u], pdq[u], pnq[u]);
           }
         }
+      }
       }
       for (int s = lane; s < len; s += 64) {
         fval[rp + s] = mv[s];
