@@ -672,17 +672,26 @@ __global__ __launch_bounds__(1024, 8) void k_ilu_schedule(int n, int B, const lo
         ech0 = base + used + choff[sstep[sp]];
       }
       const int lane = t & 63;
-      for (int src = 0; src < 64; ++src) {
-        // src is wave-uniform: v_readlane instead of a ds_bpermute round trip per value
-        auto from = [&](int v) { return __builtin_amdgcn_readlane(v, src); };
-        auto from64 = [&](long long v) {
-          return (long long)(((unsigned long long)(unsigned)from((int)(v >> 32)) << 32) | (unsigned)from((int)v));
-        };
-        const int rT = from(eT);
-        if (rT == 0) continue;  // row without work in this direction (wave-uniform)
-        const int rls = from(els), rinfo = from(einfo), rg = from(eg);
-        const int rnd = from(ndep), rd0 = from(d0);
-        const long long rrp = from64(rp), rch0 = from64(ech0);
+      // src is wave-uniform: v_readlane instead of a ds_bpermute round trip per value
+      auto from = [&](int v, int src) { return __builtin_amdgcn_readlane(v, src); };
+      auto from64 = [&](long long v, int src) {
+        return (long long)(((unsigned long long)(unsigned)from((int)(v >> 32), src) << 32) | (unsigned)from((int)v, src));
+      };
+      // the factor column of this lane's first entry of row `src` of the wave (row 64: none) -- requested one row ahead, for
+      // every lane (a lane without an entry reads the wave's first slot), so that a row does not start with a load it waits for
+      const long long rp_safe = from64(rp, 0);
+      auto colreq = [&](int src) -> int {
+        const int sl = src < 64 ? src : 63;
+        const int nd = src < 64 ? from(ndep, sl) : 0;
+        const long long slot = lane < nd ? from64(rp, sl) + from(d0, sl) + lane : rp_safe;
+        return fcol[slot];
+      };
+      auto emit = [&](int src, int cj_first) {
+        const int rT = from(eT, src);
+        if (rT == 0) return;  // row without work in this direction (wave-uniform)
+        const int rls = from(els, src), rinfo = from(einfo, src), rg = from(eg, src);
+        const int rnd = from(ndep, src), rd0 = from(d0, src);
+        const long long rrp = from64(rp, src), rch0 = from64(ech0, src);
         const int tot = rT * rg;
         for (int x = lane; x < tot; x += 64) {
           const int c = x / rg, q = x - c * rg, ln = rls + q;
@@ -692,7 +701,7 @@ __global__ __launch_bounds__(1024, 8) void k_ilu_schedule(int n, int B, const lo
                                  (q == rg - 1 ? (1u << kTail16) : 0u);
           if (x < rnd) {
             const long long slot = rrp + rd0 + x;
-            const int cj = fcol[slot];
+            const int cj = x < 64 ? cj_first : fcol[slot];
             sc[idx] = (unsigned short)((unsigned)spos[cj - blo] | flags);
             fdst[slot] = (int)(idx - base * 64);  // block-relative: the stream as a whole may exceed 2^31 entries
             // Gauss-Seidel mode: the stream values are A's own entries (L part scaled by the column's pivot)
@@ -713,6 +722,14 @@ __global__ __launch_bounds__(1024, 8) void k_ilu_schedule(int n, int B, const lo
             sv[idx] = 0.0;
           }
         }
+      };
+      // two rows per trip, their requests in two registers that take turns (a copy of a requested value would wait for it)
+      int cja = colreq(0), cjb;
+      for (int src = 0; src < 64; src += 2) {
+        cjb = colreq(src + 1);
+        emit(src, cja);
+        cja = colreq(src + 2);
+        emit(src + 1, cjb);
       }
     }
     used += s_nch;
