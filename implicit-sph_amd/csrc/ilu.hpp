@@ -468,6 +468,9 @@ __global__ __launch_bounds__(1024) void k_ilu_exact_offsets(int nblocks, const i
 
 // (second launch bound: eight waves per SIMD.  The kernel needed 106 SGPRs -- seven waves per SIMD, THREE 512-thread blocks per
 //  CU -- with 17 of them spilled to VGPR lanes it has four like its LDS allows: 1.60 -> 1.34 ms at 100^3)
+// NARROW: no row of the matrix has more than 128 entries beside its diagonal (the host knows the longest row), so a row's
+// dependencies in a direction fit two loads per lane: the level walk then has nothing conditional around its loads.
+template <bool NARROW>
 __global__ __launch_bounds__(1024, 8) void k_ilu_schedule(int n, int B, const long long *__restrict__ boff,
                                                        const long long *__restrict__ frp,
                                                        const int *__restrict__ fcol, const int *__restrict__ flen,
@@ -538,6 +541,42 @@ __global__ __launch_bounds__(1024, 8) void k_ilu_schedule(int n, int B, const lo
       int *lv = wdir == 0 ? levL : levU;
       const int step = wdir == 0 ? 1 : -1;
       const int r = wdir == 0 ? 0 : m - 1;
+      if constexpr (NARROW) {
+        // every request reads for every lane (a lane without a dependency, a request outside the block: the row's first
+        // entry, ignored): the compiler's s_waitcnt pass can count loads that are always issued, and only those
+        // (k_ilu_factor has the story); eight rows ahead, two columns per lane and row
+        constexpr int kA = 8;
+        int ca[kA], cb[kA];
+        auto req = [&](int row, int &c0, int &c1) {
+          const int rr = row < 0 ? 0 : (row >= m ? m - 1 : row);
+          const int dgr = sdg[rr], lnr = slen[rr];
+          const int d0r = wdir == 0 ? 0 : dgr + 1, nd = row == rr ? (wdir == 0 ? dgr : lnr - dgr - 1) : 0;
+          const long long b0r = srp[rr];
+          c0 = fcol[b0r + (lane < nd ? d0r + lane : 0)];
+          c1 = fcol[b0r + (lane + 64 < nd ? d0r + lane + 64 : 0)];
+        };
+        if (m > 0) {
+#pragma unroll
+          for (int u = 0; u < kA; ++u) req(r + u * step, ca[u], cb[u]);
+          for (int k0 = 0; k0 < m; k0 += kA) {
+#pragma unroll
+            for (int u = 0; u < kA; ++u) {
+              const int row = r + (k0 + u) * step;
+              if (k0 + u < m) {
+                const int nd = wdir == 0 ? sdg[row] : slen[row] - sdg[row] - 1;
+                int nl = lane < nd ? lv[ca[u] - blo] + 1 : 0;
+                if (lane + 64 < nd) nl = max(nl, lv[cb[u] - blo] + 1);
+                nl = wave_max_i32(nl);
+                if (lane == 0) lv[row] = nl;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+              }
+              req(row + kA * step, ca[u], cb[u]);
+            }
+          }
+        }
+        continue;
+      }
       int cq[kLevAhead];
       auto request = [&](int row, int &c) {
         c = -1;
@@ -1267,7 +1306,9 @@ inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int
     const size_t lds_s = sizeof(int) * (14 * (size_t)block_size + 10) + sizeof(long long) * (size_t)block_size;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_extract), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_e) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_s) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_schedule<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_s) != hipSuccess)
       rc = fail("LDS attribute failed", __FILE__, __LINE__);
   }
@@ -1300,10 +1341,16 @@ inline void ilu_launch_schedule(isph_ctx *ctx, isph_ilu *F, const Sell &S, int b
   const size_t Bz = (size_t)F->B;
   const size_t lds_s = sizeof(int) * (14 * Bz + 10) + sizeof(long long) * Bz;
   ProfScope prof(ctx, PROF_ILU_SCHEDULE, st);
-  hipLaunchKernelGGL(k_ilu_schedule, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->stream_off(), F->frp.p, F->fcol.p,
-                     F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p, F->blkinfo.p, F->llev.p, F->capf,
-                     F->slack, F->err.p, sgs ? (const double *)F->fval.p : (const double *)nullptr,
-                     sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0, count_only ? 1 : 0, F->blocks());
+  if (F->wmax <= 129)   // a row of at most 129 entries has at most 128 dependencies
+    hipLaunchKernelGGL(k_ilu_schedule<true>, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->stream_off(), F->frp.p, F->fcol.p,
+                       F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p, F->blkinfo.p, F->llev.p, F->capf,
+                       F->slack, F->err.p, sgs ? (const double *)F->fval.p : (const double *)nullptr,
+                       sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0, count_only ? 1 : 0, F->blocks());
+  else
+    hipLaunchKernelGGL(k_ilu_schedule<false>, dim3(nb), dim3(F->B), lds_s, st ? st : ctx->stream, S.nrow, F->B, F->stream_off(), F->frp.p, F->fcol.p,
+                       F->flen.p, F->fdiag.p, F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->fdst.p, F->blkinfo.p, F->llev.p, F->capf,
+                       F->slack, F->err.p, sgs ? (const double *)F->fval.p : (const double *)nullptr,
+                       sgs ? (const double *)F->dinv.p : (const double *)nullptr, b0, count_only ? 1 : 0, F->blocks());
 }
 
 // err_dev != nullptr: the kernel itself skips its blocks when the set-up so far has raised an error (ranged launches)
