@@ -111,7 +111,7 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
     for (int k0 = 0; k0 < len; k0 += kExtAhead) {   // the loads of kExtAhead slots first, then the dependent counting
       int cq[kExtAhead];
 #pragma unroll
-      for (int u = 0; u < kExtAhead; ++u) cq[u] = k0 + u < len ? scol[sell_pos(off, lane, k0 + u)] : -1;
+      for (int u = 0; u < kExtAhead; ++u) cq[u] = scol[sell_pos(off, lane, k0 + u < len ? k0 + u : 0)];   // every slot loads: countable
 #pragma unroll
       for (int u = 0; u < kExtAhead; ++u) {
         const int c = cq[u];
@@ -160,10 +160,9 @@ __global__ __launch_bounds__(1024) void k_ilu_extract(int n, int B, const int *_
                      // the block travel in vain: 4 of 10 on the bench matrix, against a load per slot that waited for its column)
 #pragma unroll
       for (int u = 0; u < kExtAhead; ++u) {
-        const bool in = k + u < len;
-        const long long p = sell_pos(off, lane, in ? k + u : 0);
-        cq[u] = in ? scol[p] : -1;
-        vq[u] = in ? sval[p] : 0.0;
+        const long long p = sell_pos(off, lane, k + u < len ? k + u : 0);   // every slot loads (a slot behind the row: its first)
+        cq[u] = scol[p];
+        vq[u] = sval[p];
       }
     }
     int c = -1;
