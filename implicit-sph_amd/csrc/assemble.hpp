@@ -54,10 +54,15 @@ __device__ __forceinline__ int neigh_at(const AsmTables &T, int i, int k) {
 }
 
 // numneigh per row (for the slice widths of the transposed list)
+// rowsrc (may be NULL): row i of the layout is the list of the caller's particle rowsrc[i] (order.hpp: the library's own
+// row numbering); idmap (may be NULL): the particle index a list entry j stands for in that numbering
 template <class OFF>
-__global__ void k_numneigh(int n, const OFF *__restrict__ nptr, int *__restrict__ len) {
+__global__ void k_numneigh(int n, const OFF *__restrict__ nptr, int *__restrict__ len, const int *__restrict__ rowsrc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) len[i] = (int)(nptr[i + 1] - nptr[i]);
+  if (i < n) {
+    const int s = rowsrc ? rowsrc[i] : i;
+    len[i] = (int)(nptr[s + 1] - nptr[s]);
+  }
 }
 
 // Orders every row's neighbour ids by their matrix column (stable: equal columns -- periodic images -- keep their
@@ -66,15 +71,22 @@ __global__ void k_numneigh(int n, const OFF *__restrict__ nptr, int *__restrict_
 // ranked by counting (two keys per 16-B LDS broadcast read), a long one goes through a bitonic network.
 constexpr int kNeighSortCap = 1024;
 template <class OFF>
-__global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restrict__ nptr, const int *__restrict__ nidx,
-                                                       const int *__restrict__ colmap, int *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restrict__ nptr, const int *__restrict__ nidx_in,
+                                                       const int *__restrict__ colmap, int *__restrict__ out,
+                                                       const int *__restrict__ rowsrc, const int *__restrict__ idmap) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[kBlock / 64][kNeighSortCap + 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kBlock / 64) + wave;
   if (row >= n) return;
-  const OFF jb = nptr[row];
-  const int len = (int)(nptr[row + 1] - jb);
+  const int srow = rowsrc ? rowsrc[row] : row;
+  const OFF jb = nptr[srow];
+  const int len = (int)(nptr[srow + 1] - jb);
   unsigned long long *kw = keys[wave];
+  // the list entries in the numbering of the layout (the output keeps the offsets of the source row)
+  struct Ids {
+    const int *p, *m;
+    __device__ __forceinline__ int operator[](long long k) const { const int j = p[k]; return m ? m[j] : j; }
+  } nidx{nidx_in, idmap};
   for (int k = lane; k < len; k += 64) kw[k] = ((unsigned long long)(unsigned)colmap[nidx[jb + k]] << 10) | (unsigned)k;
   if (lane < 2) kw[len + lane] = ~0ull;  // pad: the pair reads below may run one key past the end
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -126,7 +138,8 @@ __global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restr
 template <class OFF>
 __global__ __launch_bounds__(kBlock) void k_neigh_transpose(int n, const OFF *__restrict__ nptr,
                                                             const int *__restrict__ nidx,
-                                                            const long long *__restrict__ noff, int *__restrict__ nt) {
+                                                            const long long *__restrict__ noff, int *__restrict__ nt,
+                                                            const int *__restrict__ rowsrc, const int *__restrict__ idmap) {
   __shared__ int lds[kBlock / 64][64 * 17];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slice = blockIdx.x * (kBlock / 64) + wave;
@@ -134,7 +147,8 @@ __global__ __launch_bounds__(kBlock) void k_neigh_transpose(int n, const OFF *__
   if (slice >= nslices) return;
   int *wl = lds[wave];
   const int row = slice * 64 + lane;
-  const long long jb = row < n ? (long long)nptr[row] : 0, je = row < n ? (long long)nptr[row + 1] : 0;
+  const int srow = row < n ? (rowsrc ? rowsrc[row] : row) : 0;
+  const long long jb = row < n ? (long long)nptr[srow] : 0, je = row < n ? (long long)nptr[srow + 1] : 0;
   const long long off = noff[slice];
   const int w = (int)((noff[slice + 1] - off) >> 6);
   for (int c0 = 0; c0 < w; c0 += 16) {
@@ -143,7 +157,9 @@ __global__ __launch_bounds__(kBlock) void k_neigh_transpose(int n, const OFF *__
       const int r = s * 4 + (lane >> 4), t = lane & 15;
       const long long rb = __shfl(jb, r, 64), re = __shfl(je, r, 64);
       const long long p = rb + c0 + t;
-      wl[r * 17 + t] = p < re ? nidx[p] : 0;
+      int j = p < re ? nidx[p] : 0;
+      if (idmap && p < re) j = idmap[j];
+      wl[r * 17 + t] = j;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -501,9 +517,16 @@ __global__ void k_asm_count(AsmTables T, int nlocal, const double *__restrict__ 
   rowlen[i] = cnt;
 }
 
-__global__ void k_first_fluid(int nlocal, const int *__restrict__ type, const int *__restrict__ kind, int *first) {
+// the row modifySingularMatrix touches is the first fluid particle in the CALLER's atom order (pair_isph.cpp:493-520):
+// with the library's own row numbering (rowsrc = internal row -> caller's row) the minimum is taken over the caller's
+// indices and translated back afterwards
+__global__ void k_first_fluid(int nlocal, const int *__restrict__ type, const int *__restrict__ kind, int *first,
+                              const int *__restrict__ rowsrc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nlocal && kind[type[i]] != KIND_SOLID) atomicMin(first, i);
+  if (i < nlocal && kind[type[i]] != KIND_SOLID) atomicMin(first, rowsrc ? rowsrc[i] : i);
+}
+__global__ void k_first_to_internal(int nlocal, const int *__restrict__ iperm, int *first) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *first >= 0 && *first < nlocal) *first = iperm[*first];
 }
 
 struct PoissonArgs {
@@ -1069,8 +1092,14 @@ inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *
                              const int *dcolmap) {
   const int nslices = (n + kSlice - 1) / kSlice;
   // a held list (isph_ctx_hold_neighbours): the layout of an earlier call with the same arrays is still good
+  // the library's own row numbering (order.hpp; set by the ordered assembly entry points around this call): rows are
+  // read through rowsrc, list entries through idmap, dcolmap is the column map IN that numbering -- a temporary, so the
+  // held layout is keyed by the caller's column map and the order object instead
+  const int *rowsrc = ctx->nmap.rowsrc, *idmap = ctx->nmap.idmap;
+  const int *const colmap_key = ctx->nmap.order ? (dcolmap ? ctx->nmap.colmap_key : nullptr) : dcolmap;
   isph_neigh_layout *slot = (ctx->neigh_hold && n > 0) ? &ctx->neigh_cache[dcolmap ? 1 : 0] : nullptr;
-  if (slot && slot->n == n && slot->nptr == (const void *)dnptr && slot->nidx == dnidx && slot->colmap == dcolmap) {
+  if (slot && slot->n == n && slot->nptr == (const void *)dnptr && slot->nidx == dnidx && slot->colmap == colmap_key &&
+      slot->order == ctx->nmap.order) {
     T.nlen = slot->len.p; T.noff = slot->off.p; T.nt = slot->idx.p; T.sorted = slot->is_sorted;
     return ISPH_SUCCESS;
   }
@@ -1080,7 +1109,7 @@ inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *
   T.nlen = E.len.p;
   if (n == 0) { T.noff = E.off.p; T.nt = nullptr; return ISPH_SUCCESS; }
   const int grid = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_numneigh<OFF>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, dnptr, E.len.p);
+  hipLaunchKernelGGL(k_numneigh<OFF>, dim3(grid), dim3(kBlock), 0, ctx->stream, n, dnptr, E.len.p, rowsrc);
   hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, E.len.p, E.off.p);
   hipLaunchKernelGGL(k_exclusive_scan_ll, dim3(1), dim3(1024), 0, ctx->stream, nslices, E.off.p, E.off.p);
   // ONE host round trip for the sizes: the slice offsets (their last entry is the total) when the lists will be ordered
@@ -1102,19 +1131,22 @@ inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *
     for (int s = 0; s < nslices; ++s) wmax = std::max(wmax, (so[(size_t)s + 1] - so[(size_t)s]) >> 6);
     if (wmax <= kNeighSortCap) {
       ISPH_CHECK(E.sorted.reserve((size_t)(total > 0 ? total : 1)));
-      hipLaunchKernelGGL(k_neigh_sort<OFF>, dim3((n + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, dcolmap, E.sorted.p);
+      hipLaunchKernelGGL(k_neigh_sort<OFF>, dim3((n + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, dcolmap, E.sorted.p,
+                         rowsrc, idmap);
       dnidx = E.sorted.p;
+      idmap = nullptr;  // the sorted copy holds mapped entries already
       T.sorted = 1;
     }
   }
   hipLaunchKernelGGL(k_neigh_transpose<OFF>, dim3((nslices + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, E.off.p,
-                     E.idx.p);
+                     E.idx.p, rowsrc, idmap);
   ISPH_CHECK_HIP(hipGetLastError());
   T.noff = E.off.p;
   T.nt = E.idx.p;
   if (slot) {   // the buffers move into the context (T keeps pointing at them); E takes the slot's old ones and frees them
     std::swap(slot->off, E.off); std::swap(slot->idx, E.idx); std::swap(slot->len, E.len); std::swap(slot->sorted, E.sorted);
-    slot->n = n; slot->nptr = (const void *)dnptr; slot->nidx = nidx_key; slot->colmap = dcolmap; slot->is_sorted = T.sorted;
+    slot->n = n; slot->nptr = (const void *)dnptr; slot->nidx = nidx_key; slot->colmap = colmap_key; slot->is_sorted = T.sorted;
+    slot->order = ctx->nmap.order;
   }
   return ISPH_SUCCESS;
 }
@@ -1309,8 +1341,12 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
         const int big = 0x7fffffff;
         if (hipMemcpyAsync(S.first.p, &big, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
           rc = fail("copy failed", __FILE__, __LINE__);
-        if (a.pin_enabled)
-          hipLaunchKernelGGL(k_first_fluid, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a.type, T.kind, S.first.p);
+        if (a.pin_enabled) {
+          const RowOrder *ord = static_cast<const RowOrder *>(ctx->nmap.order);
+          hipLaunchKernelGGL(k_first_fluid, dim3(grid), dim3(kBlock), 0, ctx->stream, n, a.type, T.kind, S.first.p,
+                             ord ? (const int *)ord->perm.p : (const int *)nullptr);
+          if (ord) hipLaunchKernelGGL(k_first_to_internal, dim3(1), dim3(64), 0, ctx->stream, n, (const int *)ord->iperm.p, S.first.p);
+        }
         a.first_fluid = S.first.p;
       }
     }

@@ -1,6 +1,7 @@
 // core.hpp -- context / matrix / preconditioner objects behind the C ABI.
 #pragma once
 #include "common.hpp"
+#include "order.hpp"
 #include "sell.hpp"
 
 namespace isph { struct HostStager; }  // ingress.hpp: pinned ring of the host CSR ingress
@@ -10,10 +11,18 @@ namespace isph { struct HostStager; }  // ingress.hpp: pinned ring of the host C
 struct isph_neigh_layout {
   const void *nptr = nullptr;
   const int *nidx = nullptr, *colmap = nullptr;
+  const void *order = nullptr;  // the RowOrder the layout was built in (NULL: the caller's numbering)
   int n = -1, is_sorted = 0;
   isph::DevBuf<long long> off;
   isph::DevBuf<int> idx, len, sorted;
-  void release() { off.release(); idx.release(); len.release(); sorted.release(); nptr = nullptr; nidx = colmap = nullptr; n = -1; is_sorted = 0; }
+  void release() { off.release(); idx.release(); len.release(); sorted.release(); nptr = nullptr; nidx = colmap = nullptr; order = nullptr; n = -1; is_sorted = 0; }
+};
+
+// What an ordered assembly (isph_capi.hip: OrderedAssembly) tells the neighbour-layout builder of assemble.hpp for the
+// duration of one call: the list rows are read through rowsrc, the entries through idmap (order.hpp).
+struct isph_neigh_map {
+  const int *rowsrc = nullptr, *idmap = nullptr, *colmap_key = nullptr;
+  const void *order = nullptr;
 };
 
 struct isph_ctx {
@@ -35,7 +44,8 @@ struct isph_ctx {
   size_t hscal_cap = 0;
   // Krylov workspaces (grow-only, reused across solves)
   isph::DevBuf<double> V, Z, wv, tv, rv, pv, nvec, xext, sendbuf, bdev, xdev;
-  isph::DevBuf<int> imask;
+  isph::DevBuf<double> bint, xint;  // b / x of a solve in the matrix' own row numbering (order.hpp)
+  isph::DevBuf<int> imask, imask2;
   // profiling events
   std::vector<hipEvent_t> ev;     // pairs (begin, end) of profile mode
   std::vector<int> ev_class;      // class of every pair (isph::ProfClass)
@@ -51,6 +61,14 @@ struct isph_ctx {
   isph::HostStager *stager = nullptr;  // created by the first host-side isph_mat_create_csr
   bool neigh_hold = false;             // isph_ctx_hold_neighbours
   isph_neigh_layout neigh_cache[2];    // [0] list order, [1] ordered by matrix column
+  // row numbering of the matrices the assembly entry points build (isph_ctx_set_ordering): 1 = the library's bricks
+  // (order.hpp, default), 0 = the caller's atom order
+  int ordering = 1;
+  isph_neigh_map nmap;                 // set around one ordered assembly call
+  // while the neighbour list is held the row order of the first matrix assembly serves the following ones (LAMMPS'
+  // atom order -- the reference's row map -- does not change between two re-neighbourings either)
+  isph::RowOrderPtr held_order;
+  const void *held_key[2] = {nullptr, nullptr};  // neigh_idx / neigh_ptr of the caller
 };
 
 namespace isph {
@@ -95,6 +113,9 @@ struct isph_halo {
 struct isph_mat {
   isph::Sell S;
   isph_halo halo;
+  // the library's own row numbering (order.hpp) when the matrix was assembled in it: rows and owned columns are
+  // internal, vectors cross the C ABI in the caller's numbering (gathered / scattered there)
+  isph::RowOrderPtr order;
   bool local = false;  // rectangular operator on rank-local vectors (AMG transfer operators): no ghost columns
   bool aux = false;    // a level operator of the AMG hierarchy with its own halo plan: not in the caller's SpMV statistics
 };
@@ -113,4 +134,5 @@ struct isph_prec {
   isph_amg *amg = nullptr;
   isph_schwarz *schwarz = nullptr;
   isph_overlap *ovl = nullptr;
+  isph::RowOrderPtr order;  // the numbering of the matrix it was built from (isph_prec_apply takes the caller's)
 };

@@ -1284,8 +1284,11 @@ inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int
       return fail("copy of the subdomain table failed", __FILE__, __LINE__);
     }
   }
-  F->total = S.stored;
-  const size_t stored = (size_t)(S.stored > 0 ? S.stored : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
+  // caller-defined subdomains: a block's factor region is its in-block entry count rounded up to 64 (k_ilu_count_inblock),
+  // so the regions of all blocks together may exceed A's stored entries by up to 63 per block (a table of 1-row blocks on
+  // a banded matrix does); the arrays and the stream are sized for that bound
+  F->total = S.stored + (nblocks_tab > 0 ? 64LL * nblocks_tab : 0);
+  const size_t stored = (size_t)(F->total > 0 ? F->total : 1), n1 = (size_t)(S.nrow > 0 ? S.nrow : 1);
   F->capf = kCapFactor; F->slack = 2 * block_size;
   int rc = defer_factor_arrays ? ISPH_SUCCESS : F->fcol.reserve(stored);
   if (rc == ISPH_SUCCESS && !defer_factor_arrays) rc = F->fval.reserve(stored);

@@ -190,6 +190,143 @@ int sell_sort_rows(isph_ctx *ctx, Sell &S) {
   return ISPH_SUCCESS;
 }
 
+// ---- the library's own row numbering around one assembly call (order.hpp) ---------------------------------------
+// Builds (or, while the neighbour list is held, reuses) the brick order of the owned particles, hands the assembly a
+// device view of the particle arrays in that numbering -- owned particles permuted, ghosts in place, matrix columns and
+// the wall / correction tensors following their particles -- and tells the neighbour-layout builder (ctx->nmap) to read
+// the caller's list through the permutation.  The assembled right-hand side goes back in the caller's numbering.
+struct OrderedAssembly {
+  isph_ctx *ctx;
+  const isph_particles *P;
+  int on_device;
+  RowOrderPtr O;
+  isph_particles Q;
+  std::vector<DevBuf<char> *> bufs;
+  DevBuf<int> idmap, colmap;
+  OrderedAssembly(isph_ctx *c, const isph_particles *p, int dev) : ctx(c), P(p), on_device(dev) { Q = *p; }
+  OrderedAssembly(const OrderedAssembly &) = delete;
+  ~OrderedAssembly() {
+    ctx->nmap = isph_neigh_map();
+    for (DevBuf<char> *b : bufs) { b->release(); delete b; }
+    idmap.release(); colmap.release();
+  }
+  template <class T>
+  int alloc(size_t count, T **out) {
+    DevBuf<char> *b = new DevBuf<char>();
+    bufs.push_back(b);
+    ISPH_CHECK(b->reserve((count > 0 ? count : 1) * sizeof(T)));
+    *out = reinterpret_cast<T *>(b->p);
+    return ISPH_SUCCESS;
+  }
+  // device copy of a caller array as it is (host arrays are staged; device arrays pass through)
+  template <class T>
+  int on_dev(const T *src, size_t count, const T **out) {
+    if (!src) { *out = nullptr; return ISPH_SUCCESS; }
+    if (on_device) { *out = src; return ISPH_SUCCESS; }
+    ISPH_REQUIRE(!is_device_pointer(src), "device pointer passed with on_device = 0");
+    T *d = nullptr;
+    ISPH_CHECK(alloc(count, &d));
+    if (count > 0) ISPH_CHECK_HIP(hipMemcpyAsync(d, src, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream));
+    *out = d;
+    return ISPH_SUCCESS;
+  }
+  // a per-particle field [rows][ncomp] in the internal numbering: rows = nlocal (owned only) or nall (ghosts in place)
+  template <class T>
+  int field(const T *src, int ncomp, bool with_ghosts, const T **out) {
+    if (!src) { *out = nullptr; return ISPH_SUCCESS; }
+    const long long rows = with_ghosts ? P->nall : P->nlocal;
+    const T *d = nullptr;
+    ISPH_CHECK(on_dev(src, (size_t)rows * ncomp, &d));
+    T *q = nullptr;
+    ISPH_CHECK(alloc((size_t)rows * ncomp, &q));
+    if (rows > 0)
+      hipLaunchKernelGGL((k_perm_gather<T>), dim3(perm_grid(rows * ncomp)), dim3(kBlock), 0, ctx->stream, rows, P->nlocal, ncomp,
+                         (const int *)O->perm.p, d, q);
+    *out = q;
+    return ISPH_SUCCESS;
+  }
+  int begin(int ncol) {
+    const int n = P->nlocal, nall = P->nall, dim = P->dim, dL = dim * (dim + 1) / 2;
+    ISPH_REQUIRE(P->x && P->type && (P->neigh_ptr || P->neigh_ptr64) && P->neigh_idx && P->colmap, "particle arrays missing");
+    ISPH_REQUIRE(n >= 0 && nall >= n, "need 0 <= nlocal <= nall");
+    // neighbour list: stays the caller's (read through the permutation), on the device
+    long long nnb = 0;
+    if (P->neigh_ptr64) {
+      ISPH_CHECK(on_dev(P->neigh_ptr64, (size_t)n + 1, &Q.neigh_ptr64));
+      Q.neigh_ptr = nullptr;
+      if (!on_device) nnb = P->neigh_ptr64[n];
+    } else {
+      ISPH_CHECK(on_dev(P->neigh_ptr, (size_t)n + 1, &Q.neigh_ptr));
+      if (!on_device) nnb = P->neigh_ptr[n];
+    }
+    if (!on_device) {  // host-side shape checks before any kernel indexes with these (the assembly only sees device arrays)
+      ISPH_REQUIRE(nnb >= 0, "negative neighbour count");
+      for (long long k = 0; k < nnb; ++k) ISPH_REQUIRE(P->neigh_idx[k] >= 0 && P->neigh_idx[k] < nall, "neighbour index out of range");
+      for (int j = 0; j < nall; ++j) ISPH_REQUIRE(P->colmap[j] >= 0 && P->colmap[j] < ncol, "colmap entry out of range");
+      ISPH_CHECK(on_dev(P->neigh_idx, (size_t)nnb, &Q.neigh_idx));
+    }
+    const double *dx = nullptr;
+    ISPH_CHECK(on_dev(P->x, (size_t)nall * 3, &dx));
+    // the order: reused while the caller holds the neighbour list
+    const void *k0 = (const void *)P->neigh_idx, *k1 = P->neigh_ptr64 ? (const void *)P->neigh_ptr64 : (const void *)P->neigh_ptr;
+    if (ctx->neigh_hold && ctx->held_order && ctx->held_order->n == n && ctx->held_key[0] == k0 && ctx->held_key[1] == k1) {
+      O = ctx->held_order;
+    } else {
+      ISPH_CHECK(order_build(ctx->stream, dim, n, dx, O));
+      if (ctx->neigh_hold) { ctx->held_order = O; ctx->held_key[0] = k0; ctx->held_key[1] = k1; }
+    }
+    const int *perm = O->perm.p, *iperm = O->iperm.p;
+    // particle arrays in the internal numbering
+    Q.x = nullptr;
+    {
+      double *q = nullptr;
+      ISPH_CHECK(alloc((size_t)nall * 3, &q));
+      if (nall > 0)
+        hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid((long long)nall * 3)), dim3(kBlock), 0, ctx->stream, (long long)nall, n, 3, perm, dx, q);
+      Q.x = q;
+    }
+    ISPH_CHECK(field(P->type, 1, true, &Q.type));
+    ISPH_CHECK(field(P->vfrac, 1, true, &Q.vfrac));
+    ISPH_CHECK(field(P->pnd, 1, true, &Q.pnd));
+    ISPH_CHECK(field(P->normal, 3, true, &Q.normal));
+    ISPH_CHECK(field(P->Gc, dim * dim, false, &Q.Gc));
+    ISPH_CHECK(field(P->Lc, dL, false, &Q.Lc));
+    const int *dcm = nullptr;
+    ISPH_CHECK(on_dev(P->colmap, (size_t)nall, &dcm));
+    ISPH_CHECK(colmap.reserve((size_t)(nall > 0 ? nall : 1)));
+    ISPH_CHECK(idmap.reserve((size_t)(nall > 0 ? nall : 1)));
+    if (nall > 0) {
+      hipLaunchKernelGGL(k_perm_colmap, dim3((nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nall, n, perm, iperm, dcm, colmap.p);
+      hipLaunchKernelGGL(k_perm_idmap, dim3((nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nall, n, iperm, idmap.p);
+    }
+    Q.colmap = colmap.p;
+    ctx->nmap.rowsrc = perm;
+    ctx->nmap.idmap = idmap.p;
+    ctx->nmap.colmap_key = P->colmap;
+    ctx->nmap.order = O.get();
+    ISPH_CHECK_HIP(hipGetLastError());
+    return ISPH_SUCCESS;
+  }
+  // the assembled right-hand side, internal [n x ncols] contiguous -> the caller's [lda x ncols], host or device
+  int rhs_out(const double *internal, double *out, int ncols, int lda) {
+    const int n = P->nlocal;
+    if (n == 0) return ISPH_SUCCESS;
+    double *d = out;
+    if (!on_device) ISPH_CHECK(alloc((size_t)lda * ncols, &d));
+    for (int c = 0; c < ncols; ++c)
+      hipLaunchKernelGGL((k_perm_scatter<double>), dim3(perm_grid(n)), dim3(kBlock), 0, ctx->stream, n, (const int *)O->perm.p,
+                         internal + (size_t)c * n, d + (size_t)c * lda);
+    if (!on_device) {
+      // rows lda > n of a column are not the library's to write: copy column by column
+      for (int c = 0; c < ncols; ++c)
+        ISPH_CHECK_HIP(hipMemcpyAsync(out + (size_t)c * lda, d + (size_t)c * lda, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ISPH_CHECK_HIP(hipGetLastError());
+    return ISPH_SUCCESS;
+  }
+};
+
 }  // namespace isph
 
 using namespace isph;
@@ -291,7 +428,47 @@ int isph_ctx_set_profile(isph_ctx *ctx, int on) {
 int isph_ctx_hold_neighbours(isph_ctx *ctx, int on) {
   ISPH_REQUIRE(ctx, "ctx is NULL");
   for (auto &c : ctx->neigh_cache) c.release();   // either way: what was kept belongs to the list of before
+  ctx->held_order.reset();
+  ctx->held_key[0] = ctx->held_key[1] = nullptr;
   ctx->neigh_hold = on != 0;
+  return ISPH_SUCCESS;
+}
+
+int isph_ctx_set_ordering(isph_ctx *ctx, int mode) {
+  ISPH_REQUIRE(ctx && (mode == ISPH_ORDER_CALLER || mode == ISPH_ORDER_BRICKS), "bad ordering mode");
+  ctx->ordering = mode;
+  ctx->held_order.reset();
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_ordering_info(const isph_mat *A, long long info[3], isph_order_geometry *geom) {
+  ISPH_REQUIRE(A && info, "NULL argument");
+  info[0] = A->order ? 1 : 0;
+  info[1] = A->S.nrow;
+  info[2] = A->order ? A->order->nblocks() : 0;
+  if (geom) {
+    memset(geom, 0, sizeof(*geom));
+    if (A->order) {
+      const OrderGeom &g = A->order->g;
+      geom->dim = g.dim;
+      for (int a = 0; a < 3; ++a) {
+        geom->lo[a] = g.lo[a]; geom->inv_cell[a] = g.inv_cell[a]; geom->ncell[a] = g.ncell[a];
+        geom->cells_per_brick[a] = g.cpb[a]; geom->nbrick[a] = g.nbrick[a];
+      }
+    }
+  }
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_ordering(isph_ctx *ctx, const isph_mat *A, int *perm, int *block_ptr) {
+  ISPH_REQUIRE(ctx && A, "NULL argument");
+  ISPH_REQUIRE(A->order, "the matrix is in the caller's row numbering");
+  const RowOrder &O = *A->order;
+  if (perm && O.n > 0) {
+    ISPH_CHECK_HIP(hipMemcpyAsync(perm, O.perm.p, sizeof(int) * (size_t)O.n, hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (block_ptr) memcpy(block_ptr, O.block_ptr.data(), sizeof(int) * O.block_ptr.size());
   return ISPH_SUCCESS;
 }
 
@@ -365,6 +542,8 @@ void isph_ctx_destroy(isph_ctx *c) {
   c->partial.release(); c->dscal.release(); c->V.release(); c->Z.release(); c->wv.release(); c->tv.release();
   c->rv.release(); c->pv.release(); c->nvec.release(); c->xext.release(); c->sendbuf.release();
   c->bdev.release(); c->xdev.release(); c->imask.release();
+  c->bint.release(); c->xint.release(); c->imask2.release();
+  c->held_order.reset();
   if (c->hscal) (void)hipHostFree(c->hscal);
   delete c->stager;
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -569,6 +748,14 @@ int isph_mat_set_halo(isph_ctx *ctx, isph_mat *A, int npeers, const int *peer_ra
   ISPH_CHECK(H.send_idx.reserve((size_t)(H.nsend > 0 ? H.nsend : 1)));
   if (H.nsend > 0) {
     ISPH_CHECK_HIP(hipMemcpyAsync(H.send_idx.p, send_idx, sizeof(int) * (size_t)H.nsend, hipMemcpyHostToDevice, ctx->stream));
+    if (A->order) {  // the caller lists its own rows; the packed values are read from vectors in the matrix' numbering
+      DevTmp<int> t;
+      ISPH_CHECK(t.reserve((size_t)H.nsend));
+      ISPH_CHECK_HIP(hipMemcpyAsync(t.p, H.send_idx.p, sizeof(int) * (size_t)H.nsend, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_perm_map_indices, dim3(perm_grid(H.nsend)), dim3(kBlock), 0, ctx->stream, H.nsend, A->S.nrow,
+                         (const int *)A->order->iperm.p, (const int *)t.p, H.send_idx.p);
+      ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   // interior / boundary slices: the interior ones (no ghost column) run while the exchange is in flight
@@ -607,6 +794,33 @@ int isph_mat_export_rows(isph_ctx *ctx, const isph_mat *A, int row_begin, int nr
   ISPH_REQUIRE(ctx && A && rowptr && colidx && val, "NULL argument");
   const Sell &S = A->S;
   ISPH_REQUIRE(row_begin >= 0 && nrows >= 0 && (long long)row_begin + nrows <= S.nrow, "row range outside the matrix");
+  if (A->order && nrows > 0) {
+    // the caller's rows are scattered in the matrix: one row at a time through the ranged kernel, columns translated
+    // back and sorted (a host-side check of a few thousand rows)
+    std::vector<int> hperm((size_t)S.nrow), hiperm((size_t)S.nrow);
+    ISPH_CHECK_HIP(hipMemcpyAsync(hperm.data(), A->order->perm.p, sizeof(int) * hperm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipMemcpyAsync(hiperm.data(), A->order->iperm.p, sizeof(int) * hiperm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    isph_mat plain;           // the same storage without the numbering: borrowed, never released
+    plain.S = S;
+    rowptr[0] = 0;
+    std::vector<int> ord;
+    std::vector<int> tc;
+    std::vector<double> tv;
+    for (int i = 0; i < nrows; ++i) {
+      const int r = hiperm[(size_t)(row_begin + i)];
+      long long rp1[2];
+      const long long room = capacity - rowptr[i];
+      ISPH_CHECK(isph_mat_export_rows(ctx, &plain, r, 1, rp1, colidx + rowptr[i], val + rowptr[i], room));
+      const long long len1 = rp1[1];
+      ord.resize((size_t)len1); tc.assign(colidx + rowptr[i], colidx + rowptr[i] + len1); tv.assign(val + rowptr[i], val + rowptr[i] + len1);
+      for (long long k = 0; k < len1; ++k) { if (tc[(size_t)k] < S.nrow) tc[(size_t)k] = hperm[(size_t)tc[(size_t)k]]; ord[(size_t)k] = (int)k; }
+      std::sort(ord.begin(), ord.end(), [&](int a, int c) { return tc[(size_t)a] < tc[(size_t)c]; });
+      for (long long k = 0; k < len1; ++k) { colidx[rowptr[i] + k] = tc[(size_t)ord[(size_t)k]]; val[rowptr[i] + k] = tv[(size_t)ord[(size_t)k]]; }
+      rowptr[i + 1] = rowptr[i] + len1;
+    }
+    return ISPH_SUCCESS;
+  }
   std::vector<int> len((size_t)(nrows > 0 ? nrows : 1));
   if (nrows > 0) ISPH_CHECK_HIP(hipMemcpyAsync(len.data(), S.rowlen.p + row_begin, sizeof(int) * (size_t)nrows, hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -658,18 +872,30 @@ int isph_mat_export_csr(isph_ctx *ctx, const isph_mat *A, int *rowptr, int *coli
   ISPH_CHECK_HIP(hipMemcpyAsync(v.data(), dv.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   drp.release(); dci.release(); dv.release();
+  // the library's own row numbering: the caller sees its rows and columns (ghost columns are not renumbered)
+  std::vector<int> hperm, hiperm;
+  if (A->order && S.nrow > 0) {
+    hperm.resize((size_t)S.nrow); hiperm.resize((size_t)S.nrow);
+    ISPH_CHECK_HIP(hipMemcpyAsync(hperm.data(), A->order->perm.p, sizeof(int) * hperm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipMemcpyAsync(hiperm.data(), A->order->iperm.p, sizeof(int) * hiperm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (long long k = 0; k < nnz; ++k)
+      if (ci[(size_t)k] < S.nrow) ci[(size_t)k] = hperm[(size_t)ci[(size_t)k]];
+  }
   // sort columns inside each row (Epetra OptimizeStorage order)
   std::vector<int> perm;
+  long long q = 0;
   for (int i = 0; i < S.nrow; ++i) {
-    const long long b = rp[(size_t)i], e = rp[(size_t)i + 1];
+    const int r = hiperm.empty() ? i : hiperm[(size_t)i];
+    const long long b = rp[(size_t)r], e = rp[(size_t)r + 1];
     perm.resize((size_t)(e - b));
     std::iota(perm.begin(), perm.end(), 0);
     std::sort(perm.begin(), perm.end(), [&](int a, int c) { return ci[(size_t)(b + a)] < ci[(size_t)(b + c)]; });
-    for (long long k = b; k < e; ++k) {
-      colidx[k] = ci[(size_t)(b + perm[(size_t)(k - b)])];
-      val[k] = v[(size_t)(b + perm[(size_t)(k - b)])];
+    rowptr[i] = (int)q;
+    for (long long k = b; k < e; ++k, ++q) {
+      colidx[q] = ci[(size_t)(b + perm[(size_t)(k - b)])];
+      val[q] = v[(size_t)(b + perm[(size_t)(k - b)])];
     }
-    rowptr[i] = (int)b;
   }
   rowptr[S.nrow] = (int)nnz;
   return ISPH_SUCCESS;
@@ -687,11 +913,42 @@ void isph_mat_destroy(isph_mat *A) {
 int isph_spmv(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, int on_device) {
   ISPH_REQUIRE(ctx && A && x && y, "NULL argument");
   const Sell &S = A->S;
+  const size_t nx = (S.ncol > S.nrow && A->halo.npeers == 0) ? (size_t)S.ncol : (size_t)S.nrow;
+  if (A->order) {
+    // x and y are the caller's: x into the matrix' numbering (ghost entries, when the caller supplies them, in place),
+    // the product back out
+    DevTmp<double> xc, xi, yi;
+    const double *dxc = x;
+    if (!on_device) {
+      ISPH_CHECK(xc.reserve(nx));
+      ISPH_CHECK_HIP(hipMemcpyAsync(xc.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
+      dxc = xc.p;
+    }
+    ISPH_CHECK(xi.reserve((size_t)S.ncol + 64));
+    ISPH_CHECK(yi.reserve((size_t)S.nrow + 64));
+    hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid((long long)nx)), dim3(kBlock), 0, ctx->stream, (long long)nx, S.nrow, 1,
+                       (const int *)A->order->perm.p, dxc, xi.p);
+    if (S.ncol > S.nrow && A->halo.npeers == 0) {
+      int nbp = 0;
+      const int grid = spmv_grid(S.nslices, &nbp);
+      hipLaunchKernelGGL((k_sell_spmv<8, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, S.nslices, nbp,
+                         S.slice_off.p, S.col.p, S.val.p, (const double *)xi.p, yi.p, (const double *)nullptr, (double *)nullptr);
+    } else {
+      ISPH_CHECK(spmv_dev(ctx, A, xi.p, yi.p, nullptr));
+    }
+    double *dy = y;
+    if (!on_device) { ISPH_CHECK(xc.reserve((size_t)S.nrow)); dy = xc.p; }
+    hipLaunchKernelGGL((k_perm_scatter<double>), dim3(perm_grid(S.nrow)), dim3(kBlock), 0, ctx->stream, S.nrow,
+                       (const int *)A->order->perm.p, (const double *)yi.p, dy);
+    if (!on_device) ISPH_CHECK_HIP(hipMemcpyAsync(y, dy, sizeof(double) * (size_t)S.nrow, hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // the temporaries go back to the pool
+    ISPH_CHECK_HIP(hipGetLastError());
+    return ISPH_SUCCESS;
+  }
   if (on_device) {
     ISPH_CHECK(spmv_dev(ctx, A, x, y, nullptr));
     return ISPH_SUCCESS;
   }
-  const size_t nx = (S.ncol > S.nrow && A->halo.npeers == 0) ? (size_t)S.ncol : (size_t)S.nrow;
   ISPH_CHECK(ctx->xdev.reserve((size_t)S.ncol));
   ISPH_CHECK(ctx->bdev.reserve((size_t)(S.nrow > 0 ? S.nrow : 1)));
   ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
@@ -759,6 +1016,9 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
 int isph_prec_create_blocks(isph_ctx *ctx, const isph_mat *A, int nblocks, const int *block_ptr, isph_prec **Mout) {
   ISPH_REQUIRE(ctx && A && Mout && nblocks > 0 && block_ptr, "NULL argument or no subdomains");
   ISPH_REQUIRE(!is_device_pointer(block_ptr), "block_ptr must be a host array");
+  ISPH_REQUIRE(!A->order, "the matrix was assembled in the library's own row numbering: its subdomains are the library's "
+                          "bricks (isph_prec_create with block_size 0); a table over the caller's rows needs "
+                          "isph_ctx_set_ordering(ctx, 0) before the assembly");
   int cap = 64;
   for (int b = 0; b < nblocks; ++b) cap = std::max(cap, block_ptr[b + 1] - block_ptr[b]);
   cap = (cap + 63) / 64 * 64;
@@ -790,7 +1050,21 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
   } else if (!strncmp(type, "bjacobi-ilu", 11) && type[11] >= '0' && type[11] <= '8' && type[12] == 0) {
     // "bjacobi-ilu<k>": "fact: level-of-fill" = k (precond_ifpack.h:35)
     M->type = 2;
-    rc = ilu_create(ctx, A, block_size, &M->ilu, /*sgs=*/false, /*fill=*/type[11] - '0');
+    if (block_size <= 0) {
+      // the matrix' own subdomains: the bricks the assembly sorted the particles into (order.hpp)
+      if (!A->order) {
+        rc = fail("block_size 0 selects the library's own subdomains: the matrix must come from an assembly entry point "
+                  "with isph_ctx_set_ordering(ctx, 1)", __FILE__, __LINE__);
+      } else {
+        const std::vector<int> &bp = A->order->block_ptr;
+        int cap = 64;
+        for (size_t b = 0; b + 1 < bp.size(); ++b) cap = std::max(cap, bp[b + 1] - bp[b]);
+        cap = (cap + 63) / 64 * 64;
+        rc = ilu_create(ctx, A, cap, &M->ilu, /*sgs=*/false, /*fill=*/type[11] - '0', (int)bp.size() - 1, bp.data());
+      }
+    } else {
+      rc = ilu_create(ctx, A, block_size, &M->ilu, /*sgs=*/false, /*fill=*/type[11] - '0');
+    }
   } else if (!strncmp(type, "ilu", 3) && type[3] >= '0' && type[3] <= '8' && type[4] == 0) {
     // "ilu<k>": ILU(k) of the whole local matrix -- what Ifpack factors on one MPI rank (the overlap is a no-op there)
     M->type = 4;
@@ -807,12 +1081,35 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
     rc = fail("unknown preconditioner type (none|jacobi|bjacobi-ilu<k>|ilu<k>, k = 0..8|sa-amg)", __FILE__, __LINE__);
   }
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
+  M->order = A->order;
   *Mout = M;
   return ISPH_SUCCESS;
 }
 
 int isph_prec_apply(isph_ctx *ctx, const isph_prec *M, const double *r, double *z, int on_device) {
   ISPH_REQUIRE(ctx && M && r && z, "NULL argument");
+  if (M->order && M->n > 0) {  // r and z are the caller's; the preconditioner lives in the numbering of its matrix
+    const size_t n = (size_t)M->n;
+    DevTmp<double> rc, ri, zi;
+    const double *drc = r;
+    if (!on_device) {
+      ISPH_CHECK(rc.reserve(n));
+      ISPH_CHECK_HIP(hipMemcpyAsync(rc.p, r, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+      drc = rc.p;
+    }
+    ISPH_CHECK(ri.reserve(n + 64));
+    ISPH_CHECK(zi.reserve(n + 64));
+    hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid((long long)n)), dim3(kBlock), 0, ctx->stream, (long long)n, M->n, 1,
+                       (const int *)M->order->perm.p, drc, ri.p);
+    ISPH_CHECK(prec_apply_dev(ctx, M, ri.p, zi.p));
+    double *dz = on_device ? z : rc.p;
+    hipLaunchKernelGGL((k_perm_scatter<double>), dim3(perm_grid(M->n)), dim3(kBlock), 0, ctx->stream, M->n,
+                       (const int *)M->order->perm.p, (const double *)zi.p, dz);
+    if (!on_device) ISPH_CHECK_HIP(hipMemcpyAsync(z, dz, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ISPH_CHECK_HIP(hipGetLastError());
+    return prec_health(ctx, M);
+  }
   if (on_device) return prec_apply_dev(ctx, M, r, z);
   const size_t n = (size_t)M->n;
   ISPH_CHECK(ctx->xdev.reserve(n > 0 ? n : 1));
@@ -871,6 +1168,7 @@ int isph_prec_create_schwarz(isph_ctx *ctx, const isph_mat *A, const isph_schwar
   const int rc = schwarz_create(ctx, A, prm->level_of_fill, prm->block_size, prm->overlap, prm->combine, &M->schwarz,
                                 /*syncfree=*/prm->level_launches == 0);
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
+  M->order = A->order;
   *Mout = M;
   return ISPH_SUCCESS;
 }
@@ -949,11 +1247,20 @@ int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params
   isph_prec *M = new isph_prec();
   M->n = A->S.nrow;
   M->type = 3;
-  DevTmp<double> tn;
+  DevTmp<double> tn, tp;
   const double *dn = nullptr;
   int rc = nullvec ? stage_in(ctx, nullvec, (size_t)M->n, on_device, tn, &dn) : ISPH_SUCCESS;
+  if (rc == ISPH_SUCCESS && dn && A->order && M->n > 0) {  // the caller's null vector in the matrix' numbering
+    rc = tp.reserve((size_t)M->n);
+    if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid(M->n)), dim3(kBlock), 0, ctx->stream, (long long)M->n, M->n, 1,
+                         (const int *)A->order->perm.p, dn, tp.p);
+      dn = tp.p;
+    }
+  }
   if (rc == ISPH_SUCCESS) rc = amg_create(ctx, A, prm, dn, &M->amg);
-  tn.release();
+  M->order = A->order;
+  tn.release(); tp.release();
   if (comm_active(ctx) && ctx->nranks > 1) {
     // Every level exchanges halos inside the cycle, and how often depends on the depth of the hierarchy and on the coarse
     // solver.  amg_create agrees on both between the ranks while it builds (amg.hpp); this is the last word on the outcome:
@@ -1083,6 +1390,22 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
     db = ctx->bdev.p;
     dx = ctx->xdev.p;
   }
+  // b and x are the caller's vectors, in the caller's numbering.  A matrix in the library's own row numbering
+  // (order.hpp) solves on copies in its numbering; the results are scattered back before they leave.
+  double *const cb = db, *const cx = dx;  // device, caller's numbering
+  const RowOrder *ord = A->order.get();
+  if (ord && n > 0) {
+    ISPH_CHECK(ctx->bint.reserve(tot + 64));
+    ISPH_CHECK(ctx->xint.reserve(tot + 64));
+    for (int c = 0; c < nvec; ++c) {
+      hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid(n)), dim3(kBlock), 0, st, (long long)n, n, 1, (const int *)ord->perm.p,
+                         (const double *)cb + (size_t)c * lda, ctx->bint.p + (size_t)c * lda);
+      hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid(n)), dim3(kBlock), 0, st, (long long)n, n, 1, (const int *)ord->perm.p,
+                         (const double *)cx + (size_t)c * lda, ctx->xint.p + (size_t)c * lda);
+    }
+    db = ctx->bint.p;
+    dx = ctx->xint.p;
+  }
   const int sg = stream_grid(n);
   const double *nv = nullptr;
   if (is_singular) {
@@ -1096,7 +1419,14 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
       } else {
         ISPH_CHECK_HIP(hipMemcpyAsync(ctx->imask.p, null_mask, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
       }
-      hipLaunchKernelGGL(k_mask_to_double, dim3(sg), dim3(kBlock), 0, st, n, ctx->imask.p, ctx->nvec.p);
+      if (ord && n > 0) {  // the caller's mask follows its rows
+        ISPH_CHECK(ctx->imask2.reserve((size_t)n));
+        hipLaunchKernelGGL((k_perm_gather<int>), dim3(perm_grid(n)), dim3(kBlock), 0, st, (long long)n, n, 1, (const int *)ord->perm.p,
+                           (const int *)ctx->imask.p, ctx->imask2.p);
+        hipLaunchKernelGGL(k_mask_to_double, dim3(sg), dim3(kBlock), 0, st, n, ctx->imask2.p, ctx->nvec.p);
+      } else {
+        hipLaunchKernelGGL(k_mask_to_double, dim3(sg), dim3(kBlock), 0, st, n, ctx->imask.p, ctx->nvec.p);
+      }
     } else {
       hipLaunchKernelGGL(k_fill, dim3(sg), dim3(kBlock), 0, st, n, ctx->nvec.p, 1.0);
     }
@@ -1148,6 +1478,16 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
       if (ci.converged) printf(">> isph::Status - Passed! (%d iterations)\n", ci.iters);
       else printf(">> isph::Status - Failed to converge! ||r|| / ||b|| = %6.4e\n", ci.rel_res_explicit);
     }
+  }
+  if (ord && n > 0) {  // back into the caller's numbering (b holds its projection when the system is singular)
+    for (int c = 0; c < nvec; ++c) {
+      hipLaunchKernelGGL((k_perm_scatter<double>), dim3(perm_grid(n)), dim3(kBlock), 0, st, n, (const int *)ord->perm.p,
+                         (const double *)dx + (size_t)c * lda, cx + (size_t)c * lda);
+      hipLaunchKernelGGL((k_perm_scatter<double>), dim3(perm_grid(n)), dim3(kBlock), 0, st, n, (const int *)ord->perm.p,
+                         (const double *)db + (size_t)c * lda, cb + (size_t)c * lda);
+    }
+    db = cb;
+    dx = cx;
   }
   if (!on_device && ring) {  // x first (the caller's result), b's copy-out overlaps nothing but is half the pageable time
     ISPH_CHECK_HIP(hipMemcpyAsync(ring_slot(0), dx, sizeof(double) * tot, hipMemcpyDeviceToHost, st));
@@ -1215,7 +1555,27 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
   ISPH_CHECK(ctx->xdev.reserve(nt + 64));
   const hipMemcpyKind in = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   const hipMemcpyKind out = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  // blocks assembled in the library's own row numbering (all of them share it): the components are gathered on the way
+  // in and scattered on the way out
+  const RowOrder *ord = blocks[0]->order.get();
+  for (int k = 0; k < dim * dim; ++k)
+    if (blocks[k]) ISPH_REQUIRE(blocks[k]->order.get() == ord, "blocks must share one row numbering");
+  DevTmp<double> stg;
+  if (ord && n > 0) ISPH_CHECK(stg.reserve(2 * nt));
   for (int k = 0; k < dim; ++k) {
+    if (ord && n > 0) {
+      const double *sb = b + (size_t)k * lda, *sx = x + (size_t)k * lda;
+      if (!on_device) {
+        ISPH_CHECK_HIP(hipMemcpyAsync(stg.p + (size_t)k * n, sb, sizeof(double) * (size_t)n, in, st));
+        ISPH_CHECK_HIP(hipMemcpyAsync(stg.p + nt + (size_t)k * n, sx, sizeof(double) * (size_t)n, in, st));
+        sb = stg.p + (size_t)k * n; sx = stg.p + nt + (size_t)k * n;
+      }
+      hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid(n)), dim3(kBlock), 0, st, (long long)n, n, 1, (const int *)ord->perm.p,
+                         sb, ctx->bdev.p + (size_t)k * n);
+      hipLaunchKernelGGL((k_perm_gather<double>), dim3(perm_grid(n)), dim3(kBlock), 0, st, (long long)n, n, 1, (const int *)ord->perm.p,
+                         sx, ctx->xdev.p + (size_t)k * n);
+      continue;
+    }
     ISPH_CHECK_HIP(hipMemcpyAsync(ctx->bdev.p + (size_t)k * n, b + (size_t)k * lda, sizeof(double) * (size_t)n, in, st));
     ISPH_CHECK_HIP(hipMemcpyAsync(ctx->xdev.p + (size_t)k * n, x + (size_t)k * lda, sizeof(double) * (size_t)n, in, st));
   }
@@ -1239,8 +1599,16 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
   ISPH_CHECK(rc);
   const double bn = std::sqrt(ctx->hscal[SC_MISC + 17]);
   ci.rel_res_explicit = std::sqrt(ctx->hscal[SC_MISC + 16]) / (bn == 0.0 ? 1.0 : bn);
-  for (int k = 0; k < dim; ++k)
+  for (int k = 0; k < dim; ++k) {
+    if (ord && n > 0) {
+      double *dst = on_device ? x + (size_t)k * lda : stg.p + (size_t)k * n;
+      hipLaunchKernelGGL((k_perm_scatter<double>), dim3(perm_grid(n)), dim3(kBlock), 0, st, n, (const int *)ord->perm.p,
+                         (const double *)ctx->xdev.p + (size_t)k * n, dst);
+      if (!on_device) ISPH_CHECK_HIP(hipMemcpyAsync(x + (size_t)k * lda, dst, sizeof(double) * (size_t)n, out, st));
+      continue;
+    }
     ISPH_CHECK_HIP(hipMemcpyAsync(x + (size_t)k * lda, ctx->xdev.p + (size_t)k * n, sizeof(double) * (size_t)n, out, st));
+  }
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev1, st));
   ISPH_CHECK_HIP(hipEventSynchronize(ctx->ev1));
   float ms = 0.f;
@@ -1261,31 +1629,84 @@ int isph_assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym, d
                           const double *vstar, int singular_mode, int is_rank0, int ncol, isph_mat **A_out,
                           double *b_out, int on_device) {
   ISPH_REQUIRE(ctx && P && rho && vstar && A_out && b_out, "NULL argument");
-  return assemble_poisson(ctx, P, antisym, dt, rho, vstar, singular_mode, is_rank0, ncol, A_out, b_out, on_device);
+  if (!ctx->ordering || P->nlocal <= 0)
+    return assemble_poisson(ctx, P, antisym, dt, rho, vstar, singular_mode, is_rank0, ncol, A_out, b_out, on_device);
+  OrderedAssembly W(ctx, P, on_device);
+  ISPH_CHECK(W.begin(ncol));
+  const double *drho = nullptr, *dvs = nullptr;
+  ISPH_CHECK(W.field(rho, 1, true, &drho));
+  ISPH_CHECK(W.field(vstar, 3, true, &dvs));
+  double *bint = nullptr;
+  ISPH_CHECK(W.alloc((size_t)P->nlocal, &bint));
+  isph_mat *A = nullptr;
+  ISPH_CHECK(assemble_poisson(ctx, &W.Q, antisym, dt, drho, dvs, singular_mode, is_rank0, ncol, &A, bint, 1));
+  A->order = W.O;
+  const int rc = W.rhs_out(bint, b_out, 1, P->nlocal);
+  if (rc != ISPH_SUCCESS) { isph_mat_destroy(A); return rc; }
+  *A_out = A;
+  return ISPH_SUCCESS;
 }
+
+}  // extern "C"
+
+// the three callers of assemble_helmholtz (velocity Helmholtz, solute transport, applied potential) in the library's
+// own row numbering: fields permuted, b returned in the caller's numbering
+static int assemble_helmholtz_ordered(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
+                                      const double *nu, const double *rho, const double *pres, const double *force,
+                                      const double *g, int incremental, const double *v, int ncol, isph_mat **A_out,
+                                      double *b_out, int lda, int on_device, int mode, const double *field, const double *material) {
+  if (!ctx->ordering || P->nlocal <= 0)
+    return assemble_helmholtz(ctx, P, antisym, dt, theta, nu, rho, pres, force, g, incremental, v, ncol, A_out, b_out, lda,
+                              on_device, mode, field, material);
+  ISPH_REQUIRE(lda >= P->nlocal, "need lda >= nlocal");
+  OrderedAssembly W(ctx, P, on_device);
+  ISPH_CHECK(W.begin(ncol));
+  const double *dnu = nullptr, *drho = nullptr, *dp = nullptr, *df = nullptr, *dv = nullptr, *dfield = nullptr, *dmat = nullptr;
+  ISPH_CHECK(W.field(nu, 1, true, &dnu));
+  ISPH_CHECK(W.field(rho, 1, true, &drho));
+  ISPH_CHECK(W.field(pres, 1, true, &dp));
+  ISPH_CHECK(W.field(force, 3, true, &df));
+  ISPH_CHECK(W.field(v, 3, true, &dv));
+  ISPH_CHECK(W.field(field, 1, true, &dfield));
+  ISPH_CHECK(W.field(material, 1, true, &dmat));
+  const int n = P->nlocal, nrhs = mode ? 1 : P->dim;
+  double *bint = nullptr;
+  ISPH_CHECK(W.alloc((size_t)n * nrhs, &bint));
+  isph_mat *A = nullptr;
+  ISPH_CHECK(assemble_helmholtz(ctx, &W.Q, antisym, dt, theta, dnu, drho, dp, df, g, incremental, dv, ncol, A_out ? &A : nullptr,
+                                bint, n, 1, mode, dfield, dmat));
+  if (A) A->order = W.O;
+  const int rc = W.rhs_out(bint, b_out, nrhs, lda);
+  if (rc != ISPH_SUCCESS) { if (A) isph_mat_destroy(A); return rc; }
+  if (A_out) *A_out = A;
+  return ISPH_SUCCESS;
+}
+
+extern "C" {
+
 
 int isph_assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
                             const double *nu, const double *rho, const double *pres, const double *force,
                             const double *g, int incremental_pressure, const double *v, int ncol, isph_mat **A_out,
                             double *b_out, int lda, int on_device) {
   ISPH_REQUIRE(ctx && P && nu && rho && pres && force && v && b_out, "NULL argument");  // A_out may be NULL: b only
-  return assemble_helmholtz(ctx, P, antisym, dt, theta, nu, rho, pres, force, g, incremental_pressure, v, ncol, A_out,
-                            b_out, lda, on_device);
+  return assemble_helmholtz_ordered(ctx, P, antisym, dt, theta, nu, rho, pres, force, g, incremental_pressure, v, ncol, A_out,
+                                    b_out, lda, on_device, 0, nullptr, nullptr);
 }
 
 int isph_assemble_solute_transport(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
                                    double dcoeff, const double *conc, int ncol, isph_mat **A_out, double *b_out,
                                    int on_device) {
   ISPH_REQUIRE(ctx && P && conc && A_out && b_out, "NULL argument");
-  return assemble_helmholtz(ctx, P, antisym, dt * dcoeff, theta, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, ncol,
-                            A_out, b_out, P->nlocal, on_device, 1, conc, nullptr);
+  return assemble_helmholtz_ordered(ctx, P, antisym, dt * dcoeff, theta, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                                    ncol, A_out, b_out, P->nlocal, on_device, 1, conc, nullptr);
 }
 
 int isph_assemble_applied_potential(isph_ctx *ctx, const isph_particles *P, int antisym, const double *sigma,
                                     const double *phi, int ncol, isph_mat **A_out, double *b_out, int on_device) {
   ISPH_REQUIRE(ctx && P && phi && A_out && b_out, "NULL argument");
-  return assemble_helmholtz(ctx, P, antisym, -1.0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, ncol, A_out,
-                            b_out, P->nlocal, on_device, 2, phi, sigma);
+  return assemble_helmholtz_ordered(ctx, P, antisym, -1.0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, ncol,
+                                    A_out, b_out, P->nlocal, on_device, 2, phi, sigma);
 }
 
 int isph_assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisym, double dt, double theta,
@@ -1294,8 +1715,34 @@ int isph_assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int an
                                   const double *normal, int ncol, isph_mat **blocks_out, double *b_out, int lda,
                                   int on_device) {
   ISPH_REQUIRE(ctx && P && nu && rho && pres && force && v && blocks_out && b_out, "NULL argument");
-  return assemble_block_helmholtz(ctx, P, ncol, antisym, dt, theta, beta, nu, rho, pres, force, g, incremental_pressure, v,
-                                  normal, lda, blocks_out, b_out, on_device);
+  if (!ctx->ordering || P->nlocal <= 0)
+    return assemble_block_helmholtz(ctx, P, ncol, antisym, dt, theta, beta, nu, rho, pres, force, g, incremental_pressure, v,
+                                    normal, lda, blocks_out, b_out, on_device);
+  ISPH_REQUIRE(lda >= P->nlocal, "need lda >= nlocal");
+  OrderedAssembly W(ctx, P, on_device);
+  ISPH_CHECK(W.begin(ncol));
+  const double *dnu = nullptr, *drho = nullptr, *dp = nullptr, *df = nullptr, *dv = nullptr, *dn = nullptr;
+  ISPH_CHECK(W.field(nu, 1, true, &dnu));
+  ISPH_CHECK(W.field(rho, 1, true, &drho));
+  ISPH_CHECK(W.field(pres, 1, true, &dp));
+  ISPH_CHECK(W.field(force, 3, true, &df));
+  ISPH_CHECK(W.field(v, 3, true, &dv));
+  ISPH_CHECK(W.field(normal, 3, true, &dn));
+  const int n = P->nlocal, dim = P->dim;
+  double *bint = nullptr;
+  ISPH_CHECK(W.alloc((size_t)n * dim, &bint));
+  isph_mat *blk[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  ISPH_CHECK(assemble_block_helmholtz(ctx, &W.Q, ncol, antisym, dt, theta, beta, dnu, drho, dp, df, g, incremental_pressure, dv, dn,
+                                      n, blk, bint, 1));
+  for (int q = 0; q < dim * dim; ++q)
+    if (blk[q]) blk[q]->order = W.O;
+  const int rc = W.rhs_out(bint, b_out, dim, lda);
+  if (rc != ISPH_SUCCESS) {
+    for (int q = 0; q < dim * dim; ++q) isph_mat_destroy(blk[q]);
+    return rc;
+  }
+  for (int q = 0; q < dim * dim; ++q) blocks_out[q] = blk[q];
+  return ISPH_SUCCESS;
 }
 
 int isph_compute_volumes(isph_ctx *ctx, const isph_particles *P, double *vfrac_out, int on_device) {

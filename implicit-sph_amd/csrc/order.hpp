@@ -1,0 +1,276 @@
+// order.hpp -- the row numbering the library owns.
+//
+// The reference numbers matrix rows by LAMMPS' atom order (the Epetra map is built from atom->tag[0..nlocal),
+// ref: pair_isph.cpp:1258-1259) and Ifpack's subdomains are the bricks of LAMMPS' spatial decomposition (one per MPI rank,
+// ref: precond_ifpack.h:60-74).  Both are the CALLER's: an atom order that is lexicographic, sorted by LAMMPS' sort bins
+// or arbitrary after migration, and as many bricks as there are ranks.  The block-Jacobi ILU of this library wants
+// subdomains of <= 1024 rows that are compact in space, and the sliced-ELL SpMV wants the 64 rows of a slice to share
+// their x window -- so the assembly sorts the owned particles into bricks itself:
+//
+//   bounding box of the owned particles -> mean spacing d -> fine cells of edge ~ d -> bricks of kTarget cells
+//   (10 x 10 x 5 in 3-D, what profiles/r04_ilu_order.txt found best; 22 x 22 in 2-D)
+//   key(i) = brick(i) * cells_per_brick + cell inside the brick (x fastest), sorted stably: ties keep the caller's order
+//
+// The permutation lives in the matrix (isph_mat::order).  Everything that crosses the C ABI stays in the caller's
+// numbering: b / x / null mask of isph_solve, x / y of isph_spmv, r / z of isph_prec_apply, the send list of
+// isph_mat_set_halo and the CSR export are gathered / scattered at the boundary (8 MB each way at 10^6 rows).  The brick
+// table (over-full bricks split, empty ones dropped) is the subdomain table of "bjacobi-ilu<k>" with block_size 0.
+// isph_mat_ordering exports permutation, table and geometry, so that a checker can restate all of it.
+#pragma once
+#include <rocprim/rocprim.hpp>
+
+#include <cmath>
+#include <memory>
+
+#include "common.hpp"
+
+namespace isph {
+
+constexpr int kOrderBlockCap = 1024;  // rows per subdomain the block stream takes (ilu.hpp)
+
+struct OrderGeom {
+  int dim;
+  double lo[3], inv_cell[3];
+  int ncell[3];   // fine cells per axis
+  int cpb[3];     // fine cells per brick and axis
+  int nbrick[3];  // bricks per axis
+};
+
+struct RowOrder {
+  int n = 0;
+  OrderGeom g;
+  DevBuf<int> perm;    // internal row r holds the caller's row perm[r]
+  DevBuf<int> iperm;   // the caller's row i is internal row iperm[i]
+  std::vector<int> block_ptr;  // subdomains: consecutive internal rows, each 1 .. kOrderBlockCap
+  RowOrder() { memset(&g, 0, sizeof(g)); }
+  RowOrder(const RowOrder &) = delete;
+  RowOrder &operator=(const RowOrder &) = delete;
+  ~RowOrder() { perm.release(); iperm.release(); }
+  int nblocks() const { return (int)block_ptr.size() - 1; }
+};
+using RowOrderPtr = std::shared_ptr<RowOrder>;
+
+// ---- gather / scatter at the boundary ----------------------------------------------------------------------------
+// out[r][c] = in[perm[r]][c] for r < nperm, out[r][c] = in[r][c] for nperm <= r < ntotal (ghost particles keep their place)
+template <class T>
+__global__ void k_perm_gather(long long ntotal, int nperm, int ncomp, const int *__restrict__ perm, const T *__restrict__ in,
+                              T *__restrict__ out) {
+  const long long total = ntotal * ncomp;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / ncomp;
+    const int c = (int)(e - r * ncomp);
+    const long long s = r < nperm ? (long long)perm[r] : r;
+    out[e] = in[s * ncomp + c];
+  }
+}
+// out[perm[r]] = in[r], r < n
+template <class T>
+__global__ void k_perm_scatter(int n, const int *__restrict__ perm, const T *__restrict__ in, T *__restrict__ out) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) out[perm[r]] = in[r];
+}
+// matrix column of a particle in the internal numbering: owned columns move, ghost columns (>= nlocal) stay
+__global__ void k_perm_colmap(int nall, int nlocal, const int *__restrict__ perm, const int *__restrict__ iperm,
+                              const int *__restrict__ colmap, int *__restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nall) return;
+  const int c = colmap[r < nlocal ? perm[r] : r];
+  out[r] = c < nlocal ? iperm[c] : c;
+}
+// the particle index map of the neighbour lists: owned j -> iperm[j], ghosts keep their index
+__global__ void k_perm_idmap(int nall, int nlocal, const int *__restrict__ iperm, int *__restrict__ idmap) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nall) idmap[j] = j < nlocal ? iperm[j] : j;
+}
+__global__ void k_perm_map_indices(int n, int nlocal, const int *__restrict__ iperm, const int *__restrict__ in, int *__restrict__ out) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const int i = in[k];
+    out[k] = i < nlocal ? iperm[i] : i;
+  }
+}
+
+inline int perm_grid(long long n) {
+  const long long g = (n + kBlock - 1) / kBlock;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// ---- the brick sort ----------------------------------------------------------------------------------------------
+// per-workgroup bounding box of x[0..n)[0..3): part[block][0..3) = min, [3..6) = max
+__global__ __launch_bounds__(kBlock) void k_order_bbox(int n, const double *__restrict__ x, double *__restrict__ part) {
+  __shared__ double red[kBlock / 64][6];
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int a = 0; a < 3; ++a) {
+      const double v = x[3 * (size_t)i + a];
+      mn[a] = fmin(mn[a], v);
+      mx[a] = fmax(mx[a], v);
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = fmin(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = fmax(mx[a], __shfl_xor(mx[a], o, 64));
+    }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; ++a) { red[wave][a] = mn[a]; red[wave][3 + a] = mx[a]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = red[0][threadIdx.x];
+    for (int w = 1; w < kBlock / 64; ++w) v = threadIdx.x < 3 ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
+    part[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+// key = brick * cells_per_brick + cell inside the brick; (x - lo) * inv_cell is a subtraction followed by a
+// multiplication -- nothing a compiler can contract -- so a host restatement reaches the same cell bit for bit
+__device__ __host__ inline unsigned long long order_key(const OrderGeom &g, const double *xi) {
+  int b[3] = {0, 0, 0}, c[3] = {0, 0, 0};
+  for (int a = 0; a < g.dim; ++a) {
+    const double t = (xi[a] - g.lo[a]) * g.inv_cell[a];
+    int q = (int)floor(t);
+    q = q < 0 ? 0 : (q >= g.ncell[a] ? g.ncell[a] - 1 : q);
+    b[a] = q / g.cpb[a];
+    c[a] = q - b[a] * g.cpb[a];
+  }
+  const unsigned long long brick = ((unsigned long long)b[2] * g.nbrick[1] + b[1]) * g.nbrick[0] + b[0];
+  const unsigned long long cell = ((unsigned long long)c[2] * g.cpb[1] + c[1]) * g.cpb[0] + c[0];
+  return brick * ((unsigned long long)g.cpb[0] * g.cpb[1] * g.cpb[2]) + cell;
+}
+
+__global__ void k_order_keys(int n, OrderGeom g, const double *__restrict__ x, unsigned long long *__restrict__ key,
+                             int *__restrict__ val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double xi[3] = {x[3 * (size_t)i], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]};
+  key[i] = order_key(g, xi);
+  val[i] = i;
+}
+
+// inverse permutation + first internal row of every brick that holds particles (brick_start prefilled with -1)
+__global__ void k_order_finish(int n, unsigned long long cells_per_brick, const unsigned long long *__restrict__ skey,
+                               const int *__restrict__ perm, int *__restrict__ iperm, int *__restrict__ brick_start) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  iperm[perm[r]] = r;
+  const unsigned long long b = skey[r] / cells_per_brick;
+  if (r == 0 || skey[r - 1] / cells_per_brick != b) brick_start[b] = r;
+}
+
+// Brick geometry from the bounding box of the owned particles.  d solves d^dim = prod(extent_a + d) / n (the particles
+// of a lattice sit at the cell centres of a box half a spacing wider than their bounding box on every side); every axis
+// then gets round((extent + d) / d) fine cells and ceil(cells / target - 0.2) bricks of equally many cells.
+inline void order_geometry(int dim, int n, const double mn[3], const double mx[3], OrderGeom &g) {
+  static const int target3[3] = {10, 10, 5}, target2[3] = {22, 22, 1};
+  const int *target = dim == 3 ? target3 : target2;
+  memset(&g, 0, sizeof(g));
+  g.dim = dim;
+  double ext[3] = {0, 0, 0};
+  double scale = 0.0;
+  for (int a = 0; a < dim; ++a) { ext[a] = mx[a] - mn[a]; if (!(ext[a] >= 0.0)) ext[a] = 0.0; scale = std::max(scale, ext[a]); }
+  // all particles in one point / on one line: any positive spacing serves
+  if (!(scale > 0.0)) scale = 1.0;
+  double d = scale / std::max(1.0, std::pow((double)n, 1.0 / dim));
+  for (int it = 0; it < 32; ++it) {
+    double vol = 1.0;
+    for (int a = 0; a < dim; ++a) vol *= ext[a] + d;
+    const double dn = std::pow(vol / (double)(n > 0 ? n : 1), 1.0 / dim);
+    if (std::fabs(dn - d) <= 1e-14 * d) { d = dn; break; }
+    d = dn;
+  }
+  for (int a = 0; a < 3; ++a) {
+    g.lo[a] = 0.0; g.inv_cell[a] = 0.0; g.ncell[a] = 1; g.cpb[a] = 1; g.nbrick[a] = 1;
+  }
+  for (int a = 0; a < dim; ++a) {
+    const double len = ext[a] + d;
+    long long cells = std::llround(len / d);
+    if (cells < 1) cells = 1;
+    if (cells > (1LL << 20)) cells = 1LL << 20;
+    long long nb = (long long)std::ceil((double)cells / target[a] - 0.2);
+    if (nb < 1) nb = 1;
+    const long long cpb = (cells + nb - 1) / nb;
+    g.ncell[a] = (int)cells;
+    g.cpb[a] = (int)cpb;
+    g.nbrick[a] = (int)((cells + cpb - 1) / cpb);
+    g.lo[a] = mn[a] - 0.5 * d;
+    g.inv_cell[a] = (double)cells / len;
+  }
+}
+
+// Subdomain table from the first rows of the occupied bricks: a brick above the capacity is cut into equal consecutive
+// pieces (its rows are ordered z-slowest, so the pieces are slabs), bricks without particles have no entry.
+inline void order_block_table(int n, const std::vector<int> &brick_start, std::vector<int> &block_ptr) {
+  block_ptr.clear();
+  block_ptr.push_back(0);
+  int prev = -1;
+  auto close = [&](int lo, int hi) {
+    const int cnt = hi - lo;
+    if (cnt <= 0) return;
+    const int pieces = (cnt + kOrderBlockCap - 1) / kOrderBlockCap;
+    const int each = (cnt + pieces - 1) / pieces;
+    for (int s = lo; s < hi; s += each) block_ptr.push_back(std::min(hi, s + each));
+  };
+  for (size_t b = 0; b < brick_start.size(); ++b) {
+    const int s = brick_start[b];
+    if (s < 0) continue;
+    if (prev >= 0) close(prev, s);
+    prev = s;
+  }
+  if (prev >= 0) close(prev, n);
+}
+
+// x: device [>= n][3] positions of the owned particles in the caller's order.  Two host round trips (bounding box, brick
+// starts); everything else is queued on `st`.
+inline int order_build(hipStream_t st, int dim, int n, const double *x, RowOrderPtr &out) {
+  ISPH_REQUIRE(dim == 2 || dim == 3, "dim must be 2 or 3");
+  RowOrderPtr O = std::make_shared<RowOrder>();
+  O->n = n;
+  O->block_ptr.assign(1, 0);
+  if (n == 0) { order_geometry(dim, 0, (const double[3]){0, 0, 0}, (const double[3]){0, 0, 0}, O->g); out = O; return ISPH_SUCCESS; }
+  ISPH_CHECK(O->perm.reserve((size_t)n));
+  ISPH_CHECK(O->iperm.reserve((size_t)n));
+  // 1. bounding box
+  const int gb = std::min(256, (n + kBlock - 1) / kBlock);
+  DevTmp<double> part;
+  ISPH_CHECK(part.reserve((size_t)gb * 6));
+  hipLaunchKernelGGL(k_order_bbox, dim3(gb), dim3(kBlock), 0, st, n, x, part.p);
+  std::vector<double> hp((size_t)gb * 6);
+  ISPH_CHECK_HIP(hipMemcpyAsync(hp.data(), part.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, st));
+  ISPH_CHECK_HIP(hipStreamSynchronize(st));
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (int b = 0; b < gb; ++b)
+    for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], hp[(size_t)b * 6 + a]); mx[a] = std::max(mx[a], hp[(size_t)b * 6 + 3 + a]); }
+  for (int a = 0; a < 3; ++a) ISPH_REQUIRE(std::isfinite(mn[a]) && std::isfinite(mx[a]), "particle positions are not finite");
+  order_geometry(dim, n, mn, mx, O->g);
+  const OrderGeom &g = O->g;
+  const unsigned long long cpbt = (unsigned long long)g.cpb[0] * g.cpb[1] * g.cpb[2];
+  const unsigned long long nbricks = (unsigned long long)g.nbrick[0] * g.nbrick[1] * g.nbrick[2];
+  ISPH_REQUIRE(nbricks < (1ull << 31), "too many bricks");
+  // 2. keys, stable radix sort over the bits in use
+  DevTmp<unsigned long long> k0, k1;
+  DevTmp<int> v0, bstart;
+  DevTmp<char> tmp;
+  ISPH_CHECK(k0.reserve((size_t)n));
+  ISPH_CHECK(k1.reserve((size_t)n));
+  ISPH_CHECK(v0.reserve((size_t)n));
+  ISPH_CHECK(bstart.reserve((size_t)nbricks));
+  hipLaunchKernelGGL(k_order_keys, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, g, x, k0.p, v0.p);
+  unsigned bits = 1;
+  while (bits < 64 && ((nbricks * cpbt) >> bits) != 0) ++bits;
+  size_t bytes = 0;
+  ISPH_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, k0.p, k1.p, v0.p, O->perm.p, (size_t)n, 0u, bits, st));
+  ISPH_CHECK(tmp.reserve(bytes > 0 ? bytes : 1));
+  ISPH_CHECK_HIP(rocprim::radix_sort_pairs(tmp.p, bytes, k0.p, k1.p, v0.p, O->perm.p, (size_t)n, 0u, bits, st));
+  // 3. inverse permutation, brick starts -> subdomain table
+  ISPH_CHECK_HIP(hipMemsetAsync(bstart.p, 0xff, sizeof(int) * (size_t)nbricks, st));
+  hipLaunchKernelGGL(k_order_finish, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, cpbt, (const unsigned long long *)k1.p,
+                     (const int *)O->perm.p, O->iperm.p, bstart.p);
+  std::vector<int> hs((size_t)nbricks);
+  ISPH_CHECK_HIP(hipMemcpyAsync(hs.data(), bstart.p, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, st));
+  ISPH_CHECK_HIP(hipStreamSynchronize(st));
+  ISPH_CHECK_HIP(hipGetLastError());
+  order_block_table(n, hs, O->block_ptr);
+  ISPH_REQUIRE(O->block_ptr.back() == n, "brick table does not cover the rows");
+  out = O;
+  return ISPH_SUCCESS;
+}
+
+}  // namespace isph

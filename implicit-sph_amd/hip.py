@@ -21,7 +21,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_mat_ordering_info", "isph_mat_ordering", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
@@ -59,6 +59,19 @@ class SolveInfo(C.Structure):
                 ("rel_res_implicit", C.c_double), ("rel_res_explicit", C.c_double),
                 ("prec_setup_ms", C.c_double), ("solve_ms", C.c_double), ("spmv_ms", C.c_double),
                 ("spmv_calls", C.c_int), ("reorth", C.c_int)]
+
+
+class OrderGeometry(C.Structure):
+    """isph_order_geometry: what the library's brick sort of the owned particles was made with (isph_mat_ordering_info)."""
+    _fields_ = [("dim", C.c_int), ("lo", C.c_double * 3), ("inv_cell", C.c_double * 3), ("ncell", C.c_int * 3),
+                ("cells_per_brick", C.c_int * 3), ("nbrick", C.c_int * 3)]
+
+
+ORDERINGS = {"caller": 0, "bricks": 1}
+# Row numbering of the contexts this binding creates when the caller does not say: None = the library's default
+# (ISPH_ORDER_BRICKS: the assembly sorts the owned particles into bricks itself).  tests/conftest.py sets "caller" for the
+# suites that compare internals (ILU factors, AMG aggregates) row by row with the oracle in the generator's numbering.
+DEFAULT_ORDERING = None
 
 
 class _Particles(C.Structure):
@@ -116,6 +129,9 @@ def lib():
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.isph_ctx_hold_neighbours.argtypes = [C.c_void_p, C.c_int]
         L.isph_ctx_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_ctx_set_ordering.argtypes = [C.c_void_p, C.c_int]
+        L.isph_mat_ordering_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_mat_ordering.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_create_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]
         L.isph_mat_create_csr_bjacobi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -275,7 +291,9 @@ class Context:
     """isph_ctx: device + stream (+ RCCL communicator when nranks > 1, or the host-staged transport `transport`, a
     HostTransport whose callbacks outlive the context, for ranks that share a device)."""
 
-    def __init__(self, device=0, stream=None, rank=0, nranks=1, uid=None, transport=None):
+    def __init__(self, device=0, stream=None, rank=0, nranks=1, uid=None, transport=None, ordering=None):
+        """ordering: "bricks" (the library numbers the matrix rows itself, isph_ctx_set_ordering) | "caller" | None =
+        DEFAULT_ORDERING, else the library's default (bricks)"""
         self.h = C.c_void_p()
         self.rank, self.nranks = rank, nranks
         if stream is None and "torch" in sys.modules:
@@ -293,6 +311,15 @@ class Context:
             _check(lib().isph_ctx_create_dist(device, sp, rank, nranks, uid, C.byref(self.h)))
         else:
             _check(lib().isph_ctx_create(device, sp, C.byref(self.h)))
+        ordering = DEFAULT_ORDERING if ordering is None else ordering
+        self.ordering = "bricks" if ordering is None else ordering
+        if ordering is not None:
+            self.set_ordering(ordering)
+
+    def set_ordering(self, mode):
+        """isph_ctx_set_ordering: "bricks" | "caller" for the matrices assembled from now on"""
+        _check(lib().isph_ctx_set_ordering(self.h, ORDERINGS[mode]))
+        self.ordering = mode
 
     @staticmethod
     def unique_id():
@@ -419,6 +446,19 @@ class Matrix:
         _check(lib().isph_mat_info(self.h, a))
         return dict(nrow=a[0], ncol=a[1], nnz=a[2], nslices=a[3], stored=a[4], sell_bytes=a[5])
 
+    def ordering(self):
+        """None for a matrix in the caller's row numbering; else dict(perm [nrow]: the caller's row held by internal row r,
+        block_ptr: the library's subdomains over internal rows, geom: OrderGeometry) -- isph_mat_ordering(_info)."""
+        a = (C.c_longlong * 3)()
+        g = OrderGeometry()
+        _check(lib().isph_mat_ordering_info(self.h, a, C.byref(g)))
+        if not a[0]:
+            return None
+        perm = np.zeros(int(a[1]), dtype=np.int32)
+        bp = np.zeros(int(a[2]) + 1, dtype=np.int32)
+        _check(lib().isph_mat_ordering(self.ctx.h, self.h, _ptr(perm), _ptr(bp)))
+        return dict(perm=perm, block_ptr=bp, geom=g)
+
     def export_csr(self):
         i = self.info()
         rp = np.zeros(i["nrow"] + 1, dtype=np.int32)
@@ -492,7 +532,8 @@ class Precond:
 
     def __init__(self, ctx, A, kind="bjacobi-ilu0", block_size=512, block_ptr=None):
         """block_ptr: the caller's subdomains (isph_prec_create_blocks; kind must be "bjacobi-ilu0"): ascending row
-        offsets from 0 to nrow, at most 1024 rows per subdomain"""
+        offsets from 0 to nrow, at most 1024 rows per subdomain.  block_size 0: the matrix' own subdomains (the bricks of
+        the library's row numbering)"""
         self.ctx, self.n = ctx, A.info()["nrow"]
         self.h = C.c_void_p()
         if block_ptr is not None:

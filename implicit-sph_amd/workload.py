@@ -297,3 +297,31 @@ def make_porous_cylinder(nc, wall=5, nbeads=12, rbead_cells=3.0, seed=7, brick=(
     p.update(type=typ, v=v, part=part, kinds=[FLUID_KIND, FLUID_KIND, SOLID_KIND, SOLID_KIND],
              g=np.array([0.0, 1.06, 0.0]), dt=0.1 * spec.h / umax, radius=R)
     return p
+
+
+def renumber(parts, order):
+    """The same particles in another atom order, as LAMMPS would hold them after sorting / migration: new owned particle
+    k is the old owned particle order[k]; ghosts keep their slots (their owner_index follows).  Every per-particle array
+    of the dict, the neighbour list (rows moved, entries renamed) and the tags follow.  Single rank only (the images'
+    owners are renumbered with the same permutation)."""
+    n, nall = int(parts["nlocal"]), int(parts["nall"])
+    order = np.asarray(order, dtype=np.int64)
+    assert order.shape == (n,) and np.array_equal(np.sort(order), np.arange(n))
+    assert np.all(parts["owner_rank"] == parts["owner_rank"][0]), "renumber: single rank only"
+    inv = np.empty(n, dtype=np.int64)
+    inv[order] = np.arange(n)
+    full = np.r_[order, np.arange(n, nall)]                   # gather index over all particles
+    idmap = np.r_[inv, np.arange(n, nall)]                    # old particle index -> new
+    out = dict(parts)
+    for k, a in parts.items():
+        if isinstance(a, np.ndarray) and a.ndim >= 1 and a.shape[0] == nall and k not in ("neigh_idx",):
+            out[k] = np.ascontiguousarray(a[full])
+    out["owner_index"] = idmap[parts["owner_index"][full]].astype(parts["owner_index"].dtype)
+    nptr = parts["neigh_ptr"].astype(np.int64)
+    lens = (nptr[1:] - nptr[:-1])[order]
+    nptr2 = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=nptr2[1:])
+    src = np.repeat(nptr[:-1][order] - nptr2[:-1], lens) + np.arange(int(nptr2[-1]), dtype=np.int64)
+    out["neigh_idx"] = idmap[parts["neigh_idx"][src]].astype(np.int32)
+    out["neigh_ptr"] = nptr2.astype(parts["neigh_ptr"].dtype)
+    return out

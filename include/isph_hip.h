@@ -176,6 +176,8 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
  *   "sa-amg"        PrecondWrapper_ML::create() with its default parameters and no null vector
  *                   (isph_prec_create_amg takes the parameters and the null vector of a singular system)
  * Rebuilt every solve in the reference (solver_lin_belos.h:153,190). */
+/* block_size 0 ("bjacobi-ilu<k>" only): the matrix' own subdomains, i.e. the bricks the assembly sorted the particles
+ * into (isph_ctx_set_ordering); fails for a matrix in the caller's numbering. */
 int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int block_size,
                      isph_prec **M);
 /* "bjacobi-ilu0" on the CALLER'S subdomains: block b = rows block_ptr[b] .. block_ptr[b+1] (host array of nblocks + 1
@@ -298,6 +300,39 @@ int isph_ctx_set_profile(isph_ctx *ctx, int on);
  * Either call drops what was kept.  Without it every call is self-contained. */
 int isph_ctx_hold_neighbours(isph_ctx *ctx, int on);
 int isph_ctx_profile_read(isph_ctx *ctx, double ms[8], int calls[8]);
+
+/* ---- row numbering ----------------------------------------------------- */
+
+/* The reference's matrix rows follow LAMMPS' atom order (the Epetra map is atom->tag[0..nlocal), ref:
+ * pair_isph.cpp:1258-1259) and Ifpack's subdomains are the bricks of the MPI decomposition (ref: precond_ifpack.h:60-74).
+ * ISPH_ORDER_BRICKS (the default): every assembly entry point (isph_assemble_poisson / _helmholtz / _block_helmholtz and
+ * the scalar callers) sorts the rank's owned particles into bricks of about 500 particles by their coordinates
+ * (10 x 10 x 5 mean spacings in 3-D, 22 x 22 in 2-D; x fastest inside a brick; over-full bricks split) and builds the
+ * matrix in that numbering -- whatever order the caller's atoms are in.  Nothing of it is visible at this boundary: b, x
+ * and the null mask of isph_solve, x / y of isph_spmv, r / z of isph_prec_apply, the null vector of isph_prec_create_amg,
+ * the send list of isph_mat_set_halo and the exports isph_mat_export_csr / _rows are in the caller's numbering (ghost
+ * columns are never renumbered).  The bricks are the subdomains of "bjacobi-ilu<k>" when isph_prec_create is called with
+ * block_size 0.  While the neighbour list is held (isph_ctx_hold_neighbours) the order of the first assembly serves the
+ * following ones.  Internals exported for tests (isph_prec_export_ilu, isph_prec_amg_*) are in the matrix' numbering;
+ * isph_mat_ordering gives the permutation.
+ * ISPH_ORDER_CALLER: rows stay in the caller's atom order (rounds 1-4; subdomains then are `block_size` consecutive rows
+ * or the caller's table, isph_prec_create_blocks).  Matrices from isph_mat_create_csr are always in the caller's order. */
+#define ISPH_ORDER_CALLER 0
+#define ISPH_ORDER_BRICKS 1
+int isph_ctx_set_ordering(isph_ctx *ctx, int mode);
+/* what the sort was made with: cell(a) = clamp(floor((x_a - lo[a]) * inv_cell[a]), 0, ncell[a] - 1), brick(a) = cell(a) /
+ * cells_per_brick[a]; key = (brick_z * nbrick[1] + brick_y) * nbrick[0] + brick_x) * (cells per brick) + (cz' * cpb[1] +
+ * cy') * cpb[0] + cx' with c' = cell mod cells_per_brick; rows ascend by key, ties in the caller's order */
+typedef struct {
+  int dim;
+  double lo[3], inv_cell[3];
+  int ncell[3], cells_per_brick[3], nbrick[3];
+} isph_order_geometry;
+/* info: [0] 1 when A carries the library's numbering (0: the caller's) [1] rows [2] subdomains; geom may be NULL */
+int isph_mat_ordering_info(const isph_mat *A, long long info[3], isph_order_geometry *geom);
+/* perm[r] = the caller's row held by internal row r ([nrow], may be NULL); block_ptr [subdomains + 1] (may be NULL).
+ * Fails for a matrix in the caller's numbering. */
+int isph_mat_ordering(isph_ctx *ctx, const isph_mat *A, int *perm, int *block_ptr);
 
 /* ---- assembly --------------------------------------------------------- */
 

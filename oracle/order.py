@@ -1,0 +1,112 @@
+"""TEST INFRASTRUCTURE -- never imported by the product.
+
+numpy restatement of the row numbering the library owns (implicit-sph_amd/csrc/order.hpp): the brick sort of a rank's
+owned particles, the subdomain table, and the symmetric permutation of a CSR system, so that parity stays device vs
+oracle when the device numbers its rows itself.  The reference has no counterpart: its rows follow LAMMPS' atom order
+(pair_isph.cpp:1258-1259) and its subdomains are the MPI bricks (precond_ifpack.h:60-74); the oracle is handed the same
+permutation and the same table explicitly and solves P A P^T (P x) = P b with block ILU on that table.
+
+  keys(x, geom)          the sort key of every owned particle from the geometry the library reports (isph_order_geometry)
+  order(x, geom)         perm: internal row r holds the caller's row perm[r] (stable sort of the keys)
+  block_table(...)       the subdomains (over-full bricks split into equal consecutive pieces, empty ones dropped)
+  geometry(x, dim, n)    the geometry rule itself (bounding box -> spacing -> cells -> bricks)
+  permute_system(...)    P A P^T, P b with sorted columns
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+
+BLOCK_CAP = 1024           # kOrderBlockCap
+TARGET = {3: (10, 10, 5), 2: (22, 22, 1)}
+
+
+def _geom(g):
+    """accepts the ctypes isph_order_geometry or anything with the same attributes"""
+    return SimpleNamespace(dim=int(g.dim), lo=np.array(list(g.lo), dtype=np.float64), inv_cell=np.array(list(g.inv_cell), dtype=np.float64),
+                           ncell=np.array(list(g.ncell), dtype=np.int64), cpb=np.array(list(g.cells_per_brick), dtype=np.int64),
+                           nbrick=np.array(list(g.nbrick), dtype=np.int64))
+
+
+def keys(x, geom):
+    """order.hpp order_key: cell = clamp(floor((x - lo) * inv_cell)), brick = cell // cpb, key = brick-major, x fastest"""
+    g = _geom(geom)
+    x = np.asarray(x, dtype=np.float64)
+    b = np.zeros((len(x), 3), dtype=np.int64)
+    c = np.zeros((len(x), 3), dtype=np.int64)
+    for a in range(g.dim):
+        t = (x[:, a] - g.lo[a]) * g.inv_cell[a]            # one subtraction, one multiplication: nothing to contract
+        q = np.clip(np.floor(t).astype(np.int64), 0, g.ncell[a] - 1)
+        b[:, a] = q // g.cpb[a]
+        c[:, a] = q - b[:, a] * g.cpb[a]
+    brick = (b[:, 2] * g.nbrick[1] + b[:, 1]) * g.nbrick[0] + b[:, 0]
+    cell = (c[:, 2] * g.cpb[1] + c[:, 1]) * g.cpb[0] + c[:, 0]
+    return brick * int(g.cpb[0] * g.cpb[1] * g.cpb[2]) + cell, brick
+
+
+def order(x, geom):
+    k, _ = keys(x, geom)
+    return np.argsort(k, kind="stable").astype(np.int32)
+
+
+def block_table(x, geom, perm=None):
+    """order.hpp order_block_table from the sorted brick numbers"""
+    _, brick = keys(x, geom)
+    if perm is None:
+        perm = order(x, geom)
+    sb = brick[perm]
+    n = len(sb)
+    starts = np.flatnonzero(np.r_[True, sb[1:] != sb[:-1]]) if n else np.zeros(0, dtype=np.int64)
+    ends = np.r_[starts[1:], n]
+    bp = [0]
+    for lo, hi in zip(starts, ends):
+        cnt = hi - lo
+        pieces = (cnt + BLOCK_CAP - 1) // BLOCK_CAP
+        each = (cnt + pieces - 1) // pieces
+        s = lo
+        while s < hi:
+            bp.append(min(hi, s + each))
+            s += each
+    return np.asarray(bp, dtype=np.int32)
+
+
+def geometry(x, dim):
+    """order.hpp order_geometry, for checks of the rule (the tests feed keys() the geometry the library REPORTS, so a last-bit
+    difference of pow() between two C libraries cannot move a particle across a cell face)"""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    mn, mx = x.min(axis=0), x.max(axis=0)
+    ext = np.maximum(mx - mn, 0.0)[:dim]
+    scale = ext.max() if ext.max() > 0 else 1.0
+    d = scale / max(1.0, n ** (1.0 / dim))
+    for _ in range(32):
+        dn = (np.prod(ext + d) / max(n, 1)) ** (1.0 / dim)
+        done = abs(dn - d) <= 1e-14 * d
+        d = dn
+        if done:
+            break
+    out = SimpleNamespace(dim=dim, lo=[0.0] * 3, inv_cell=[0.0] * 3, ncell=[1] * 3, cells_per_brick=[1] * 3, nbrick=[1] * 3, spacing=d)
+    for a in range(dim):
+        ln = ext[a] + d
+        cells = min(max(int(math.floor(ln / d + 0.5)), 1), 1 << 20)
+        nb = max(int(math.ceil(cells / TARGET[dim][a] - 0.2)), 1)
+        cpb = (cells + nb - 1) // nb
+        out.ncell[a], out.cells_per_brick[a], out.nbrick[a] = cells, cpb, (cells + cpb - 1) // cpb
+        out.lo[a] = mn[a] - 0.5 * d
+        out.inv_cell[a] = cells / ln
+    return out
+
+
+def permute_system(rp, ci, val, b, perm, nghost_cols=0):
+    """(P A P^T, P b) as CSR with ascending columns: internal row r = the caller's row perm[r]; columns >= nrow (ghost
+    columns) keep their number"""
+    import scipy.sparse as sps
+    n = len(rp) - 1
+    ncol = n + nghost_cols
+    A = sps.csr_matrix((val, ci, rp), shape=(n, ncol))
+    perm = np.asarray(perm, dtype=np.int64)
+    colperm = np.r_[perm, np.arange(n, ncol)]
+    Ap = A[perm][:, colperm].tocsr()
+    Ap.sort_indices()
+    bp = None if b is None else np.asarray(b)[perm]
+    return Ap.indptr.astype(np.int32), Ap.indices.astype(np.int32), Ap.data.copy(), bp

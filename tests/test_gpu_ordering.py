@@ -1,0 +1,236 @@
+"""-m gpu: the row numbering the library owns (csrc/order.hpp, isph_ctx_set_ordering(ISPH_ORDER_BRICKS), the default).
+
+The reference's rows follow LAMMPS' atom order (pair_isph.cpp:1258-1259); the library sorts a rank's owned particles into
+bricks itself and shows none of it at the C ABI.  Checked here, for the SAME particles handed over in three atom orders
+(the generator's 8^3 bricks, lexicographic = what create_atoms gives, shuffled = after migration):
+  * the exported matrix and b are the oracle's for THAT atom order: pattern bit for bit, values <= 1e-12 max|A|;
+  * the permutation is the stable sort of the documented key (oracle/order.py restates it from the reported geometry), the
+    subdomain table covers the rows with blocks of 1..1024, and the internal matrix is the same for all three orders;
+  * block ILU(0) on the library's bricks (isph_prec_create block_size 0): factor = orc.ILU on P A P^T with the same
+    table (pattern exact, values 1e-10), FGMRES iterations +-1 and x <= 1e-6 against the oracle solving the permuted
+    system, and the same iteration count whatever the atom order;
+  * isph_spmv / isph_prec_apply / isph_solve take and return vectors in the caller's numbering;
+  * PinZero / DoubleDiag modify the caller's first fluid row (modifySingularMatrix, pair_isph.cpp:493-520)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from isph_amd import hip, workload
+import oracle as orc
+import order as oorder
+from problems import Problem, tgv_spec, wall_types
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def octx():
+    ctx = hip.Context(0, ordering="bricks")
+    yield ctx
+    ctx.close()
+
+
+def _three_orders(spec):
+    """the same particle set in three atom orders: (name, parts)"""
+    base = workload.make_tgv(spec)
+    n = base["nlocal"]
+    tag0 = base["tag"][:n].astype(np.int64) - 1
+    lex = np.argsort(tag0, kind="stable")                       # tag = lattice site, x fastest: create_atoms order
+    shuf = np.random.default_rng(7).permutation(n)
+    return [("generator", base), ("lexicographic", workload.renumber(base, lex)), ("shuffled", workload.renumber(base, shuf))]
+
+
+def _oracle_system(parts, spec, singular=orc.NULLSPACE, kinds=None):
+    P = orc.Particles(parts, workload.single_rank_colmap(parts), kernel=spec.kernel, kinds=kinds).precompute(corrections=False)
+    return P, P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True, singular=singular)
+
+
+def _assemble(ctx, parts, spec, P, singular=hip.NULLSPACE, kinds=None):
+    colmap = workload.single_rank_colmap(parts)
+    return hip.assemble_poisson(ctx, parts, colmap, spec.dt, parts["rho"], np.ascontiguousarray(parts["v"]), vfrac=P.vfrac,
+                                singular=singular, kinds=kinds)
+
+
+@pytest.mark.parametrize("dim,n", [(3, 20), (2, 48)])
+def test_matrix_in_the_callers_numbering_whatever_the_atom_order(octx, dim, n):
+    spec = tgv_spec(dim=dim, n=n, mode=workload.JITTER)
+    internal = []
+    for name, parts in _three_orders(spec):
+        P, (rp, ci, val, b) = _oracle_system(parts, spec)
+        A, bg = _assemble(octx, parts, spec, P)
+        rp2, ci2, v2 = A.export_csr()
+        assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci), name
+        assert np.max(np.abs(v2 - val)) <= 1e-12 * np.abs(val).max(), name
+        assert np.max(np.abs(bg - b)) <= 1e-12 * np.abs(b).max(), name
+        o = A.ordering()
+        assert o is not None
+        nl = parts["nlocal"]
+        # the permutation is the stable sort of the documented key; the table covers the rows
+        perm = oorder.order(parts["x"][:nl], o["geom"])
+        assert np.array_equal(perm, o["perm"]), name
+        bp = oorder.block_table(parts["x"][:nl], o["geom"], perm)
+        assert np.array_equal(bp, o["block_ptr"]), name
+        sizes = np.diff(bp)
+        assert bp[0] == 0 and bp[-1] == nl and sizes.min() >= 1 and sizes.max() <= 1024
+        # the geometry follows the rule (spacing of the lattice, bricks of 10 x 10 x 5 / 22 x 22 cells at most 20 % over)
+        g = oorder.geometry(parts["x"][:nl], dim)
+        assert list(g.ncell[:dim]) == [n] * dim == list(o["geom"].ncell)[:dim]
+        assert list(g.cells_per_brick) == list(o["geom"].cells_per_brick) and list(g.nbrick) == list(o["geom"].nbrick)
+        assert np.allclose(g.lo[:dim], list(o["geom"].lo)[:dim], rtol=0, atol=1e-12)
+        # rows by position: the internal matrix does not depend on the atom order it was handed in
+        rpi, cii, vi, _ = oorder.permute_system(rp, ci, val, None, o["perm"])
+        internal.append((name, rpi, cii, vi, parts["x"][:nl][o["perm"]]))
+        # x / y of isph_spmv are the caller's
+        xv = np.random.default_rng(3).standard_normal(nl)
+        yo = sps.csr_matrix((val, ci, rp), shape=(nl, nl)) @ xv
+        assert np.max(np.abs(A.spmv(xv) - yo)) <= 1e-12 * np.abs(yo).max(), name
+        A.close()
+    for name, rpi, cii, vi, xi in internal[1:]:
+        assert np.array_equal(xi, internal[0][4]), name                   # same particles on the same internal rows
+        assert np.array_equal(rpi, internal[0][1]) and np.array_equal(cii, internal[0][2]), name
+        assert np.max(np.abs(vi - internal[0][3])) <= 1e-12 * np.abs(vi).max(), name
+
+
+def test_block_ilu_on_the_librarys_bricks_matches_the_oracle(octx):
+    spec = tgv_spec(dim=3, n=20, mode=workload.JITTER)
+    its = {}
+    for name, parts in _three_orders(spec):
+        P, (rp, ci, val, b) = _oracle_system(parts, spec)
+        nl = parts["nlocal"]
+        A, bg = _assemble(octx, parts, spec, P)
+        o = A.ordering()
+        M = hip.Precond(octx, A, "bjacobi-ilu0", 0)                       # block_size 0: the matrix' own subdomains
+        assert M.info()["nblocks"] == len(o["block_ptr"]) - 1
+        # the oracle gets the same permutation and the same table explicitly
+        rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
+        ref = orc.ILU(rpi, cii, vi, 0, o["block_ptr"])
+        frp, fci, fv = ref.export()
+        grp, gci, gv = M.export_ilu()                                      # internals: the matrix' numbering
+        assert np.array_equal(grp, frp) and np.array_equal(gci, fci), name
+        assert np.max(np.abs(gv - fv) / np.maximum(np.abs(fv), 1e-10 * np.abs(fv).max())) < 1e-10, name
+        # r / z of isph_prec_apply are the caller's
+        r = np.random.default_rng(5).standard_normal(nl)
+        zo = np.empty(nl)
+        zo[o["perm"]] = ref.apply(r[o["perm"]])
+        z = M.apply(r)
+        assert np.linalg.norm(z - zo) / np.linalg.norm(zo) < 1e-11, name
+        # b, x of isph_solve are the caller's; the oracle solves the permuted system
+        xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, prec="ilu", ilu=ref)
+        xo = np.empty(nl)
+        xo[o["perm"]] = xoi
+        bb, xg = bg.copy(), np.zeros(nl)
+        info = hip.solve(octx, A, bb, xg, prec=M, singular=True)
+        assert info.converged == 1 and abs(info.iters - io.iters) <= 1, (name, info.iters, io.iters)
+        assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6, name
+        assert abs(xg.sum()) <= 1e-10 * np.abs(xg).sum()                   # x . n = 0
+        # b comes back projected, in the caller's numbering
+        assert np.max(np.abs(bb - (b - b.mean()))) <= 1e-12 * np.abs(b).max(), name
+        its[name] = info.iters
+        M.close(); A.close()
+    assert len(set(its.values())) == 1, its                                # the atom order does not reach the solver
+
+
+def test_device_operands_and_null_mask_follow_the_callers_rows(octx):
+    import torch
+    dev = torch.device("cuda", 0)
+    spec = tgv_spec(dim=3, n=16, mode=workload.JITTER)
+    name, parts = _three_orders(spec)[2]                                   # shuffled
+    kinds = [99, 12]
+    parts = dict(parts)
+    parts["type"] = wall_types(parts)
+    P, (rp, ci, val, b) = _oracle_system(parts, spec, kinds=kinds)
+    nl = parts["nlocal"]
+    mask = (parts["type"][:nl] == 1).astype(np.int32)
+    A, bg = _assemble(octx, parts, spec, P, kinds=kinds)
+    o = A.ordering()
+    M = hip.Precond(octx, A, "bjacobi-ilu0", 0)
+    rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
+    ref = orc.ILU(rpi, cii, vi, 0, o["block_ptr"])
+    xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, null_mask=mask[o["perm"]], prec="ilu", ilu=ref)
+    xo = np.empty(nl)
+    xo[o["perm"]] = xoi
+    bd = torch.from_numpy(bg.copy()).to(dev)
+    xd = torch.zeros(nl, dtype=torch.float64, device=dev)
+    info = hip.solve(octx, A, bd, xd, prec=M, singular=True, null_mask=mask)
+    assert info.converged == 1 and abs(info.iters - io.iters) <= 1, (info.iters, io.iters)
+    xg = xd.cpu().numpy()
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+    assert abs(xg[mask == 1].sum()) <= 1e-10 * np.abs(xg).sum()
+    # device spmv / apply in the caller's numbering
+    xv = torch.from_numpy(np.random.default_rng(9).standard_normal(nl)).to(dev)
+    yo = sps.csr_matrix((val, ci, rp), shape=(nl, nl)) @ xv.cpu().numpy()
+    assert np.max(np.abs(A.spmv(xv).cpu().numpy() - yo)) <= 1e-12 * np.abs(yo).max()
+    zo = np.empty(nl)
+    zo[o["perm"]] = ref.apply(xv.cpu().numpy()[o["perm"]])
+    assert np.linalg.norm(M.apply(xv).cpu().numpy() - zo) / np.linalg.norm(zo) < 1e-11
+    M.close(); A.close()
+
+
+@pytest.mark.parametrize("mode", ["pinzero", "doublediag"])
+def test_singular_modes_modify_the_callers_first_fluid_row(octx, mode):
+    spec = tgv_spec(dim=3, n=12, mode=workload.JITTER)
+    for name, parts in _three_orders(spec)[1:]:
+        smode_o = {"pinzero": orc.PINZERO, "doublediag": orc.DOUBLEDIAG}[mode]
+        smode_g = {"pinzero": hip.PINZERO, "doublediag": hip.DOUBLEDIAG}[mode]
+        P, (rp, ci, val, b) = _oracle_system(parts, spec, singular=smode_o)
+        A, bg = _assemble(octx, parts, spec, P, singular=smode_g)
+        rp2, ci2, v2 = A.export_csr()
+        assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci), name
+        assert np.max(np.abs(v2 - val)) <= 1e-12 * np.abs(val).max(), name
+        assert np.max(np.abs(bg - b)) <= 1e-12 * np.abs(b).max(), name
+        A.close()
+
+
+def test_caller_tables_and_the_librarys_numbering_do_not_mix(octx, gpu_ctx):
+    spec = tgv_spec(dim=3, n=12)
+    parts = workload.make_tgv(spec)
+    P, _ = _oracle_system(parts, spec)
+    A, _ = _assemble(octx, parts, spec, P)
+    nl = parts["nlocal"]
+    with pytest.raises(hip.IsphError):                                     # a table over the caller's rows means nothing here
+        hip.Precond(octx, A, "bjacobi-ilu0", block_ptr=np.asarray([0, nl], dtype=np.int32) if nl <= 1024 else np.arange(0, nl + 512, 512).clip(0, nl).astype(np.int32))
+    A.close()
+    A2, _ = _assemble(gpu_ctx, parts, spec, P)                             # the caller's numbering: no bricks to use
+    assert A2.ordering() is None
+    with pytest.raises(hip.IsphError):
+        hip.Precond(gpu_ctx, A2, "bjacobi-ilu0", 0)
+    A2.close()
+
+
+def test_clustered_cloud_splits_over_full_bricks(octx):
+    """a cloud with a dense clump: the bricks of the clump hold more than 1024 particles and are cut into consecutive
+    pieces; every subdomain stays within 1..1024 rows and the solve converges like the oracle's on the same table"""
+    rng = np.random.default_rng(2)
+    spec = tgv_spec(dim=3, n=16, mode=workload.JITTER)
+    base = workload.make_tgv(spec)
+    nl = base["nlocal"]
+    L = 2 * np.pi
+    x = base["x"][:nl].copy()
+    sel = rng.choice(nl, size=nl // 2, replace=False)                      # half of the particles pulled into one octant
+    x[sel] = (x[sel] % L) * 0.5
+    parts = workload.make_cloud(x, (L, L, L), spec.h, spec.cut, like=base)
+    parts["v"] = np.zeros((parts["nall"], 3))
+    parts["v"][:, 0] = np.sin(parts["x"][:, 0])
+    P = orc.Particles(parts, parts["owner_index"].astype(np.int32), kernel=spec.kernel).precompute(corrections=False)
+    rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True)
+    A, bg = hip.assemble_poisson(octx, parts, parts["owner_index"].astype(np.int32), spec.dt, parts["rho"],
+                                 np.ascontiguousarray(parts["v"]), vfrac=P.vfrac)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(ci2, ci) and np.max(np.abs(v2 - val)) <= 1e-12 * np.abs(val).max()
+    o = A.ordering()
+    sizes = np.diff(o["block_ptr"])
+    assert sizes.min() >= 1 and sizes.max() <= 1024 and o["block_ptr"][-1] == nl
+    _, brick = oorder.keys(parts["x"][:nl], o["geom"])
+    assert np.bincount(brick).max() > 1024                                 # the rule met an over-full brick ...
+    assert len(sizes) > len(np.unique(brick))                              # ... and cut it
+    M = hip.Precond(octx, A, "bjacobi-ilu0", 0)
+    rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
+    ref = orc.ILU(rpi, cii, vi, 0, o["block_ptr"])
+    xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, prec="ilu", ilu=ref)
+    bb, xg = bg.copy(), np.zeros(nl)
+    info = hip.solve(octx, A, bb, xg, prec=M, singular=True)
+    assert info.converged == io.converged == 1 and abs(info.iters - io.iters) <= 1, (info.iters, io.iters)
+    xo = np.empty(nl)
+    xo[o["perm"]] = xoi
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+    M.close(); A.close()
