@@ -121,6 +121,17 @@ def parse():
                          "bricks tile the lattice and hold <= 1024 particles they are the block-Jacobi subdomains "
                          "(isph_prec_create_blocks), like the bricks of LAMMPS' decomposition are Ifpack's; otherwise "
                          "subdomains are --block consecutive rows")
+    ap.add_argument("--order", default="lexicographic", choices=["bricks", "lexicographic", "sortbin", "shuffled"],
+                    help="the atom order the particles are handed over in (pair_isph.cpp:1258-1259: the reference's rows "
+                         "follow LAMMPS' atom order): lexicographic = create_atoms on the lattice, x fastest (default); sortbin "
+                         "= LAMMPS' atom sorting, bins of half the neighbour cutoff (atom_modify sort); shuffled = a random "
+                         "permutation (after migration); bricks = --brick cells, brick by brick (the numbering of round 4)")
+    ap.add_argument("--library-order", default="on", choices=["on", "off"],
+                    help="on (default): the library numbers the matrix rows itself (isph_ctx_set_ordering BRICKS) and its "
+                         "bricks are the block-Jacobi subdomains; off: rows in the caller's atom order, subdomains = the "
+                         "generator's bricks when --order bricks tiles the lattice, else --block consecutive rows")
+    ap.add_argument("--no-orders", action="store_true", help="skip the table of the other atom orders beside the headline")
+    ap.add_argument("--no-step", action="store_true", help="skip the 3-step time-step leg beside the headline")
     ap.add_argument("--colour", type=int, default=0,
                     help="numbering inside a brick: 0 lexicographic, c > 1 multi-colour with period c (isph_workload.h)")
     ap.add_argument("--kernel", default="wendland", choices=["wendland", "quintic"])
@@ -158,11 +169,38 @@ METRIC_NAME = {
 }
 
 
+def make_particles(args, world, rank, order):
+    """One rank's brick of the 3-D TGV lattice, handed over in the atom order `order` (see --order)."""
+    from isph_amd import workload
+    pg = pgrid_for(world)
+    n = args.ncell
+    mode = {"advect": workload.ADVECT, "jitter": workload.JITTER, "lattice": workload.LATTICE}[args.mode]
+    brick = tuple(int(t) for t in args.brick.split(",")) if order == "bricks" else (n, n, n)   # (n, n, n): x fastest over the rank's lattice
+    spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=brick,
+                            colour_period=args.colour if order == "bricks" else 0, mode=mode, kernel=args.kernel,
+                            cut_over_h=2.0 if args.kernel == "wendland" else 3.0)
+    parts = workload.make_tgv(spec)
+    if order in ("sortbin", "shuffled"):
+        assert world == 1, "--order %s renumbers a single rank's particles" % order
+        nl = parts["nlocal"]
+        if order == "shuffled":
+            q = np.random.default_rng(20251005).permutation(nl)
+        else:
+            # LAMMPS' atom sorting (Atom::sort / setup_sort_bins): bins of half the neighbour cutoff over the sub-domain box,
+            # x fastest; atoms bin by bin, inside a bin in their previous order
+            L = 2.0 * np.pi
+            nb = max(1, int(L / (0.5 * spec.cut)))
+            ib = np.minimum((np.mod(parts["x"][:nl], L) * (nb / L)).astype(np.int64), nb - 1)
+            q = np.argsort((ib[:, 2] * nb + ib[:, 1]) * nb + ib[:, 0], kind="stable")
+        parts = workload.renumber(parts, q)
+    return spec, parts, brick
+
+
 def pgrid_for(n):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
 
 
-def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False, bptr=None):
+def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False, bptr=None, keep_x=None):
     """Oracle (CPU restatement of Belos FGMRES + Ifpack ILU(k) / ML SA-AMG) timed on the host cores, every variant run
     to convergence (preconditioner set-up + the whole solve, nothing extrapolated):
       same_blocks     the GPU's own subdomains (`block` rows each), all threads
@@ -172,7 +210,8 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False,
       ifpack_1rank    the reference on one MPI rank: ILU(1) of the whole matrix, one thread (precond_ifpack.h:35,43;
                       overlap is a no-op on one rank).  Minutes of CPU time -> only with --cpu-ifpack-1rank (the record
                       contains nothing this run did not measure).
-    `value` = the fastest all-thread variant."""
+    `value` = the fastest all-thread variant.  keep_x (a list): receives the solution of the same_blocks variant, so
+    that the record can state ||x_gpu - x_cpu|| / ||x_cpu|| on the benchmark's own system."""
     import oracle as orc
     n = len(rp) - 1
     threads = orc.num_threads()
@@ -187,8 +226,10 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False,
         t_setup = time.perf_counter() - t0
         pk = "ilu" if ilu is not None else {"none": "none", "jacobi": "jacobi", "sa-amg": "amg"}[prec]
         t0 = time.perf_counter()
-        _, info, _ = orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, amg=amg)
+        xs, info, _ = orc.solve(rp, ci, val, b, singular=True, prec=pk, ilu=ilu, amg=amg)
         t_solve = time.perf_counter() - t0
+        if keep_x is not None and not keep_x:
+            keep_x.append(xs)                      # the first variant (same_blocks, all threads): the parity record
         return dict(seconds_per_solve=t_setup + t_solve, setup_s=t_setup, solve_s=t_solve, iterations=int(info.iters),
                     converged=int(info.converged), cores=orc.num_threads(), config=label, measured=True)
 
@@ -253,7 +294,7 @@ def dropin_leg(A, b, repeat=5, sub_rows=0):
     return rec, xd
 
 
-def step_workload(args, json_fd):
+def step_workload(args, json_fd=None, ctx=None, steps=None, warmup=None, quiet=False):
     """The reference's benchmark protocol as a measured record: `run 20` of
     bench-script/hopper/tgv/1728/tgv-3d-p24.lmp with tgv.xml -- 3-D TGV on a simple-cubic lattice, Quintic kernel cut 3h
     (--kernel quintic; wendland = the sph-script), theta 0.5, "Singular Poisson" DoubleDiag, dt = h/8 (.lmp:130), fixes
@@ -267,12 +308,19 @@ def step_workload(args, json_fd):
     import isph_amd  # noqa: F401
     from isph_amd import hip, workload
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = torch.device("cuda", 0)
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    ctx = hip.Context(0, stream=tstream.cuda_stream)
+    own_ctx = ctx is None
+    if own_ctx:
+        dev = torch.device("cuda", 0)
+        tstream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(tstream)
+        ctx = hip.Context(0, stream=tstream.cuda_stream, ordering="bricks" if args.library_order == "on" else "caller")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nsteps = args.steps if steps is None else steps
+    nwarm = args.warmup if warmup is None else warmup
+    lib_order = ctx.ordering == "bricks"
     n = args.ncell
-    brick = tuple(int(t) for t in args.brick.split(","))
+    # the atom order of the particles: the generator's bricks only when the caller's order is what the matrix keeps
+    brick = tuple(int(t) for t in args.brick.split(",")) if (not lib_order or args.order == "bricks") else (n, n, n)
     coh = 2.0 if args.kernel == "wendland" else 3.0
     spec = workload.TGVSpec(dim=3, ncell=(n, n, n), brick=brick, mode=workload.LATTICE, kernel=args.kernel, cut_over_h=coh)
     parts0 = workload.make_tgv(spec)
@@ -280,7 +328,7 @@ def step_workload(args, json_fd):
     L = 2.0 * np.pi
     dt = 0.125 * spec.h                                   # timestep of the bench script (tgv-3d-p24.lmp:130 = h/8)
     brows = brick[0] * brick[1] * brick[2]
-    bptr = np.arange(0, N + brows, brows).clip(0, N).astype(np.int32) if all(n % k == 0 for k in brick) and brows <= 1024 else None
+    bptr = np.arange(0, N + brows, brows).clip(0, N).astype(np.int32) if (not lib_order and all(n % k == 0 for k in brick) and brows <= 1024) else None
     smode = {"nullspace": hip.NULLSPACE, "pinzero": hip.PINZERO, "doublediag": hip.DOUBLEDIAG}[args.singular]
     x = torch.from_numpy(np.ascontiguousarray(parts0["x"][:N])).to(dev)
     v = torch.from_numpy(np.ascontiguousarray(parts0["v"][:N])).to(dev)
@@ -299,13 +347,15 @@ def step_workload(args, json_fd):
         if args.prec == "sa-amg":                            # ml.xml: max levels 10, Gauss-Seidel 4 sweeps pre and post
             nv = torch.full((N,), 1.0 / np.sqrt(float(N)), dtype=torch.float64, device=dev) if singular else None
             return hip.PrecondAMG(ctx, A, nullvec=nv, params=hip.AmgParams(max_levels=8, sweeps=4, block=args.block, theta=args.amg_theta))  # ml.xml asks for 10; the library's hierarchy holds 8 (4 are reached at 10^6 rows)
+        if args.prec.startswith("bjacobi-ilu") and lib_order:
+            return hip.Precond(ctx, A, args.prec, 0)                       # the library's bricks
         if args.prec == "bjacobi-ilu0" and bptr is not None:
             return hip.Precond(ctx, A, args.prec, block_ptr=bptr)
         return hip.Precond(ctx, A, args.prec, args.block)
 
-    total = args.warmup + args.steps
+    total = nwarm + nsteps
     for step in range(total):
-        timed = step >= args.warmup
+        timed = step >= nwarm
         t0 = time.perf_counter()
         cloud = workload.make_cloud(x.cpu().numpy(), (L, L, L), spec.h, spec.cut, like=parts0)
         t1 = time.perf_counter()
@@ -374,23 +424,25 @@ def step_workload(args, json_fd):
         if timed:
             for k, d in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6, t8 - t7, t9 - t8)):
                 acc[k] += d
-        sys.stderr.write("step %d: pre %.1f  helm asm %.1f solve %.1f [%s its]  poisson asm %.1f solve %.1f [%d its]  corr+adv %.1f  shift %.1f  | host neighbours %.0f ms\n"
+        if not quiet:
+          sys.stderr.write("step %d: pre %.1f  helm asm %.1f solve %.1f [%s its]  poisson asm %.1f solve %.1f [%d its]  corr+adv %.1f  shift %.1f  | host neighbours %.0f ms\n"
                          % (step, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, its["helmholtz"][-1] if its["helmholtz"] else "-",
                             (t6 - t5) * 1e3, (t7 - t6) * 1e3, ip.iters, (t8 - t7) * 1e3, (t9 - t8) * 1e3, (t1 - t0) * 1e3))
-    K = args.steps
+    K = nsteps
     dev_s = sum(acc[k] for k in stages[2:])
     # sanity of the physics: the kinetic energy of the decaying vortex only goes down, the velocity stays finite
     ke = float((v * v).sum().item()) * 0.5
     out = {
         "metric": "ISPH time steps/sec (3D TGV, %d^3 particles, %s cut %gh, theta %g, %s, GMRES(50)+%s; PairISPH::compute + fix isph + fix isph/shift per step)"
                   % (n, args.kernel, coh, args.theta, args.singular, args.prec),
-        "value": K / dev_s, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
+        "value": K / dev_s, "unit": "steps/s", "n_gpus": 1, "steps": K, "warmup": nwarm,
         "ms_per_step": dev_s / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "reference benchmark protocol bench-script/hopper/tgv/1728 (tgv.xml, tgv-3d-p24.lmp: run 20), one GPU",
                    "rows": N, "kernel": args.kernel, "cut_over_h": coh, "theta": args.theta, "singular": args.singular, "precond": args.prec,
-                   "dt": dt, "subdomains": ("%dx%dx%d bricks" % brick) if bptr is not None else "%d rows" % args.block,
-                   "iterations_poisson": its["poisson"][args.warmup:], "iterations_helmholtz_3rhs_total": its["helmholtz"][args.warmup:],
+                   "dt": dt, "library_row_order": "bricks" if lib_order else "caller",
+                   "subdomains": "the library's bricks" if lib_order else (("%dx%dx%d bricks" % brick) if bptr is not None else "%d rows" % args.block),
+                   "iterations_poisson": its["poisson"][nwarm:], "iterations_helmholtz_3rhs_total": its["helmholtz"][nwarm:],
                    "kinetic_energy_sum_end": ke},
         "stages_ms_per_step": {k: acc[k] / K * 1e3 for k in stages},
         "split": {"ISPH: computePre": acc["computePre"] / K * 1e3,
@@ -401,8 +453,11 @@ def step_workload(args, json_fd):
         "host_lammps_side_ms_per_step": {"neighbour_list_and_ghosts": acc["neighbour_host"] / K * 1e3, "upload": acc["upload"] / K * 1e3,
                                          "note": "what LAMMPS does between compute() calls; not in `value`"},
     }
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
-    ctx.close()
+    if json_fd is not None:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if own_ctx:
+        ctx.close()
+    return out
 
 
 def self_launch(args):
@@ -434,6 +489,156 @@ def self_launch(args):
                 for q in live:
                     q.kill()                      # exact children of this process, by handle
     sys.exit(rc)
+
+
+class Case:
+    """The resident system of one run: this rank's particles in one atom order, the assembled matrix (twice: the first
+    pass pays the one-time device allocations, the second is the steady state a time step sees), and step() = one pass of
+    `ISPH: solvePoisson` (preconditioner build + FGMRES + projections)."""
+
+    def __init__(self, env, order, lib_order):
+        import torch
+        from isph_amd import hip, dist
+        self.env, self.order, self.lib_order = env, order, lib_order
+        ctx, dev, args, td, world, rank = (env[k] for k in ("ctx", "dev", "args", "td", "world", "rank"))
+        ctx.set_ordering("bricks" if lib_order else "caller")
+        t0 = time.perf_counter()
+        self.spec, parts, self.brick = make_particles(args, world, rank, order)
+        if world > 1:
+            parts = dist.prune_ghosts(parts)                  # ghost columns = the referenced tags only (Epetra's column map)
+        if args.force_rccl and world == 1:
+            plan = dist.make_self_halo_plan(parts)
+        else:
+            plan = dist.make_plan(parts, td)                  # column map + halo lists (trivial on 1 rank)
+        self.parts, self.plan = parts, plan
+        self.host_generate_s = time.perf_counter() - t0
+        nlocal = self.nlocal = parts["nlocal"]
+        n, brick = args.ncell, self.brick
+        # rows in the caller's order: block-Jacobi subdomains = the generator's bricks when they tile this rank's lattice
+        brows = brick[0] * brick[1] * brick[2]
+        self.bptr = None
+        if (not lib_order and order == "bricks" and all(n % k == 0 for k in brick) and brows <= 1024 and args.prec == "bjacobi-ilu0"):
+            assert nlocal % brows == 0, "the generator's bricks must tile the rank's rows"
+            self.bptr = np.arange(0, nlocal + brows, brows).clip(0, nlocal).astype(np.int32)
+        dparts = dict(parts)
+        for k in ("x", "type", "neigh_ptr", "neigh_idx"):
+            dparts[k] = torch.from_numpy(np.ascontiguousarray(parts[k])).to(dev)
+        self.dparts = dparts
+        self.colmap = torch.from_numpy(plan.colmap).to(dev)
+        self.rho = torch.from_numpy(parts["rho"]).to(dev)
+        self.vstar = torch.from_numpy(np.ascontiguousarray(parts["v"])).to(dev)
+        self.own = torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)
+        # computePre (volumes on the GPU + forward comm of ghost volumes) and the Poisson assembly
+        self.fwd = hip.HaloForward(ctx, nlocal, plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr) if plan.npeers else None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.A, self.b = self.assemble()
+        torch.cuda.synchronize()
+        self.assemble_first_ms = (time.perf_counter() - t0) * 1e3
+        self.A.close()
+        t0 = time.perf_counter()
+        self.A, self.b = self.assemble()
+        torch.cuda.synchronize()
+        self.assemble_ms = (time.perf_counter() - t0) * 1e3
+        self.x = torch.zeros(nlocal, dtype=torch.float64, device=dev)
+        self.bwork = torch.empty_like(self.b)
+        self.prm = hip.SolverParams()
+        self.pinfo = {}
+        self.nullvec = torch.full((nlocal,), 1.0 / np.sqrt(float(nlocal * world)), dtype=torch.float64, device=dev)
+
+    def assemble(self):
+        from isph_amd import hip, dist
+        env, args = self.env, self.env["args"]
+        ctx = env["ctx"]
+        vf = hip.compute_volumes(ctx, self.dparts, self.colmap, kernel=args.kernel)
+        if self.fwd is None:
+            vfrac = vf[self.own].contiguous()
+        else:
+            vfrac = dist.forward_scalar_rccl(self.fwd, self.plan, vf)   # forward_comm_pair of Vfrac over the library's RCCL comm
+        A, b = hip.assemble_poisson(ctx, self.dparts, self.colmap, self.spec.dt, self.rho, self.vstar, vfrac=vfrac,
+                                    ncol=self.plan.ncol, kernel=args.kernel, rank0=(env["rank"] == 0))
+        if self.plan.npeers:
+            A.set_halo(self.plan.peers, self.plan.send_ptr, self.plan.send_idx, self.plan.recv_ptr)
+        return A, b
+
+    def subdomains(self):
+        """what the block-Jacobi preconditioner of this case is built on, for the record"""
+        if self.lib_order:
+            o = self.A.ordering()
+            sz = np.diff(o["block_ptr"])
+            g = o["geom"]
+            return dict(kind="the library's bricks (isph_ctx_set_ordering BRICKS): %dx%dx%d cells of the mean spacing" % tuple(g.cells_per_brick),
+                        count=int(len(sz)), rows_min=int(sz.min()), rows_max=int(sz.max()), rows_mean=float(sz.mean()))
+        if self.bptr is not None:
+            return dict(kind="%dx%dx%d-cell bricks of the generator's numbering (isph_prec_create_blocks)" % self.brick,
+                        count=int(len(self.bptr) - 1), rows_min=int(np.diff(self.bptr).min()), rows_max=int(np.diff(self.bptr).max()))
+        return dict(kind="%d consecutive rows of the caller's atom order" % self.env["args"].block)
+
+    def make_prec(self, prec):
+        from isph_amd import hip, dist
+        env, args, A, pinfo = self.env, self.env["args"], self.A, self.pinfo
+        ctx = env["ctx"]
+        if prec == "sa-amg":
+            M = hip.PrecondAMG(ctx, A, nullvec=self.nullvec, params=hip.AmgParams(block=args.block, theta=args.amg_theta))
+            if not pinfo:
+                pinfo.update(levels=[M.level_info(l) for l in range(M.levels)])
+        elif prec.startswith("schwarz-ilu"):
+            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(prec[-1]), overlap=args.overlap, combine=args.combine,
+                                   block_size=args.block)
+            if not pinfo:
+                pinfo.update(M.schwarz_info())
+            pinfo["create_ms"] = M.create_timing()          # of the last create
+        elif prec in ("ilu0", "ilu1"):
+            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(prec[-1]), overlap=0, block_size=0)
+            if not pinfo:
+                pinfo.update(M.schwarz_info())
+        elif prec.startswith("overlap-ilu"):
+            # Ifpack on N ranks with "Overlap Level" 1: this rank's rows + the rows of its ghost columns, one ILU(k) block
+            plan = self.plan
+            assert plan.npeers, "overlap-ilu<k> needs ghost columns (--gpus > 1 or --force-rccl)"
+            rpl, cil, vall = A.export_csr()
+            rpe, cie, ve = dist.extend_rows(plan, rpl, cil, vall, env["td"])
+            Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
+            M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=int(prec[-1]), combine=args.combine)
+            Aext.close()
+            if not pinfo:
+                pinfo.update(extended_rows=len(rpe) - 1, extended_nnz=int(rpe[-1]))
+        elif prec.startswith("bjacobi-ilu") and self.lib_order:
+            M = hip.Precond(ctx, A, prec, 0)                # the library's bricks
+        elif prec == "bjacobi-ilu0" and self.bptr is not None:
+            M = hip.Precond(ctx, A, prec, block_ptr=self.bptr)
+        else:
+            M = hip.Precond(ctx, A, prec, args.block)
+        if not pinfo and prec == args.prec and prec.startswith("bjacobi-ilu"):
+            pinfo.update(M.info(), factor_nnz_exact=int(M.info()["factor_nnz"]))
+        return M
+
+    def step(self, prec=None):
+        from isph_amd import hip
+        prec = prec or self.env["args"].prec
+        self.bwork.copy_(self.b)
+        self.x.zero_()
+        M = self.make_prec(prec)
+        inf = hip.solve(self.env["ctx"], self.A, self.bwork, self.x, prec=M, singular=True, params=self.prm)
+        M.close()
+        return inf
+
+    def timed(self, steps, warmup, prec=None):
+        """ms per step() over `steps` after `warmup` (single rank: no barrier)"""
+        import torch
+        for _ in range(warmup):
+            inf = self.step(prec)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            inf = self.step(prec)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, inf
+
+    def close(self):
+        self.A.close()
+        if self.fwd is not None:
+            self.fwd.close()
 
 
 def main():
@@ -488,107 +693,21 @@ def main():
         td = None
         ctx = hip.Context(local_rank, stream=stream)
 
-    # ---- synthetic input: one brick of ncell^3 particles per GPU (weak scaling)
-    pg = pgrid_for(world)
-    n = args.ncell
-    mode = {"advect": workload.ADVECT, "jitter": workload.JITTER, "lattice": workload.LATTICE}[args.mode]
-    brick = tuple(int(t) for t in args.brick.split(","))
-    spec = workload.TGVSpec(dim=3, ncell=(n * pg[0], n * pg[1], n * pg[2]), pgrid=pg, rank=rank, brick=brick, colour_period=args.colour,
-                            mode=mode, kernel=args.kernel, cut_over_h=2.0 if args.kernel == "wendland" else 3.0)
-    parts = workload.make_tgv(spec)
-    if world > 1:
-        parts = dist.prune_ghosts(parts)                  # ghost columns = the referenced tags only (Epetra's column map)
-    if args.force_rccl and world == 1:
-        plan = dist.make_self_halo_plan(parts)
-    else:
-        plan = dist.make_plan(parts, td)                  # column map + halo lists (trivial on 1 rank)
-    nlocal = parts["nlocal"]
-    # block-Jacobi subdomains = the bricks of the numbering when they tile this rank's lattice
+    lib_order = args.library_order == "on"
+    if args.prec.startswith("overlap-ilu"):
+        lib_order = False                                 # the extended matrix is built from the exported rows (caller's numbering)
+    ctx.set_ordering("bricks" if lib_order else "caller")
+    env = dict(ctx=ctx, dev=dev, args=args, td=td, world=world, rank=rank)
+    case = Case(env, args.order, lib_order)
+    spec, parts, plan, nlocal, brick, bptr = case.spec, case.parts, case.plan, case.nlocal, case.brick, case.bptr
     brows = brick[0] * brick[1] * brick[2]
-    bptr = None
-    if all(n % k == 0 for k in brick) and brows <= 1024 and args.prec == "bjacobi-ilu0":
-        bptr = np.arange(0, nlocal + brows, brows).clip(0, nlocal).astype(np.int32)
-
-    # device-resident particle arrays
-    dparts = dict(parts)
-    for k in ("x", "type", "neigh_ptr", "neigh_idx"):
-        dparts[k] = torch.from_numpy(np.ascontiguousarray(parts[k])).to(dev)
-    colmap = torch.from_numpy(plan.colmap).to(dev)
-    rho = torch.from_numpy(parts["rho"]).to(dev)
-    vstar = torch.from_numpy(np.ascontiguousarray(parts["v"])).to(dev)
-
-    # computePre (volumes on the GPU + forward comm of ghost volumes) and the Poisson assembly.  Done twice: the first
-    # pass pays the one-time device allocations, the second is the steady state a time step sees
-    fwd = hip.HaloForward(ctx, nlocal, plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr) if plan.npeers else None
-
-    def assemble():
-        vf = hip.compute_volumes(ctx, dparts, colmap, kernel=args.kernel)
-        if fwd is None:
-            vfrac = vf[torch.from_numpy(parts["owner_index"].astype(np.int64)).to(dev)].contiguous()
-        else:
-            vfrac = dist.forward_scalar_rccl(fwd, plan, vf)   # forward_comm_pair of Vfrac over the library's RCCL comm
-        A, b = hip.assemble_poisson(ctx, dparts, colmap, spec.dt, rho, vstar, vfrac=vfrac, ncol=plan.ncol,
-                                    kernel=args.kernel, rank0=(rank == 0))
-        if plan.npeers:
-            A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
-        return A, b
-
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    A, b = assemble()
-    torch.cuda.synchronize()
-    assemble_first_ms = (time.perf_counter() - t0) * 1e3
-    A.close()
-    t0 = time.perf_counter()
-    A, b = assemble()
-    torch.cuda.synchronize()
-    assemble_ms = (time.perf_counter() - t0) * 1e3
+    n = args.ncell
+    pg = pgrid_for(world)
+    A, b = case.A, case.b
+    assemble_first_ms, assemble_ms = case.assemble_first_ms, case.assemble_ms
     info_m = A.info()
-
-    x = torch.zeros(nlocal, dtype=torch.float64, device=dev)
-    bwork = torch.empty_like(b)
-    prm = hip.SolverParams()
-
-    pinfo = {}
-    nullvec = torch.full((nlocal,), 1.0 / np.sqrt(float(nlocal * world)), dtype=torch.float64, device=dev)
-
-    def step(prec=None):
-        prec = prec or args.prec
-        bwork.copy_(b)
-        x.zero_()
-        if prec == "sa-amg":
-            M = hip.PrecondAMG(ctx, A, nullvec=nullvec, params=hip.AmgParams(block=args.block, theta=args.amg_theta))
-            if not pinfo:
-                pinfo.update(levels=[M.level_info(l) for l in range(M.levels)])
-        elif prec.startswith("schwarz-ilu"):
-            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(prec[-1]), overlap=args.overlap, combine=args.combine,
-                                   block_size=args.block)
-            if not pinfo:
-                pinfo.update(M.schwarz_info())
-            pinfo["create_ms"] = M.create_timing()          # of the last create
-        elif prec in ("ilu0", "ilu1"):
-            M = hip.PrecondSchwarz(ctx, A, level_of_fill=int(prec[-1]), overlap=0, block_size=0)
-            if not pinfo:
-                pinfo.update(M.schwarz_info())
-        elif prec.startswith("overlap-ilu"):
-            # Ifpack on N ranks with "Overlap Level" 1: this rank's rows + the rows of its ghost columns, one ILU(k) block
-            assert plan.npeers, "overlap-ilu<k> needs ghost columns (--gpus > 1 or --force-rccl)"
-            rpl, cil, vall = A.export_csr()
-            rpe, cie, ve = dist.extend_rows(plan, rpl, cil, vall, td)
-            Aext = hip.Matrix.from_csr(ctx, rpe, cie, ve)
-            M = hip.PrecondOverlap(ctx, Aext, plan, level_of_fill=int(prec[-1]), combine=args.combine)
-            Aext.close()
-            if not pinfo:
-                pinfo.update(extended_rows=len(rpe) - 1, extended_nnz=int(rpe[-1]))
-        elif prec == "bjacobi-ilu0" and bptr is not None:
-            M = hip.Precond(ctx, A, prec, block_ptr=bptr)
-        else:
-            M = hip.Precond(ctx, A, prec, args.block)
-        if not pinfo and prec == args.prec and prec.startswith("bjacobi-ilu"):
-            pinfo.update(M.info(), factor_nnz_exact=int(M.info()["factor_nnz"]))
-        inf = hip.solve(ctx, A, bwork, x, prec=M, singular=True, params=prm)
-        M.close()
-        return inf
+    x, prm, pinfo = case.x, case.prm, case.pinfo
+    step = case.step
 
     def barrier():
         if td is not None:
@@ -614,6 +733,7 @@ def main():
         spmv_calls += infp.spmv_calls
     barrier()
     prof = ctx.profile_read()          # {class: (ms, launches)} over the nprof untimed passes (set-up + solve)
+    halo_prof = ctx.halo_profile_read() if world > 1 else None
     x_headline = x.clone()             # the headline configuration's solution (the alt runs below reuse x)
     if td is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
@@ -644,6 +764,57 @@ def main():
     nslices = (info_m["nrow"] + 63) // 64
     moved_model = 10 * info_m["stored"] + 64 * 4 * nslices + 16 * info_m["nrow"]
 
+    # ---- N > 1: a record that validates itself (every rank takes part; rank 0 prints)
+    multi = None
+    if world > 1:
+        ctx.set_profile(False)
+        cpu_side = args.share_gpu                      # gloo reduces host tensors
+        red = lambda t, op: (td.all_reduce(t, op=op), t)[1]
+        tdev = "cpu" if cpu_side else dev
+        # explicit residual of the GLOBAL system from the distributed product: b (projected by the solve) - A x, with the
+        # halo exchange of the production SpMV; A 1 = 0 across every rank boundary; the scale of a row from A s, s = +-1
+        r = case.bwork - A.spmv(x_headline)
+        sums = red(torch.stack([(r * r).sum(), (case.bwork * case.bwork).sum(), x_headline.sum(), r.sum()]).to(tdev), td.ReduceOp.SUM)
+        # the operator of the singular solve is y = A x - (A x . n) n (PoissonProjection::Apply, solver_lin.h:131-140): the
+        # residual that converges is the one with its component along n = 1/sqrt(N) removed
+        rr_proj = max(sums[0].item() - sums[3].item() ** 2 / float(nlocal * world), 0.0)
+        ones = torch.ones(nlocal, dtype=torch.float64, device=dev)
+        sgn = torch.where(torch.rand(nlocal, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank)) < 0.5, -1.0, 1.0).to(torch.float64)
+        mx = red(torch.stack([A.spmv(ones).abs().max(), A.spmv(sgn).abs().max()]).to(tdev), td.ReduceOp.MAX)
+        mine = dict(rank=rank, comm=ctx.comm_info(), peers=int(plan.npeers), ghost_cols=int(plan.ncol - nlocal),
+                    halo_bytes_per_spmv=int(8 * (int(plan.send_ptr[-1]) + int(plan.recv_ptr[-1]))) if plan.npeers else 0,
+                    rows=int(nlocal), iterations=int(inf.iters), converged=int(inf.converged), subdomains=case.subdomains().get("count"),
+                    halo_profile=halo_prof and dict(products=halo_prof["products"],
+                                                    exchange_us=halo_prof["exchange_ms"] / max(halo_prof["products"], 1) * 1e3,
+                                                    interior_us=halo_prof["interior_ms"] / max(halo_prof["products"], 1) * 1e3,
+                                                    exposed_us=halo_prof["exposed_ms"] / max(halo_prof["products"], 1) * 1e3))
+        allr = [None] * world
+        td.all_gather_object(allr, mine)
+        its_all = [q["iterations"] for q in allr]
+        assert len(set(its_all)) == 1, "ranks report different iteration counts: %s" % its_all
+        assert all(q["comm"]["ranks"] == world for q in allr), "a rank's communicator does not span the job: %s" % [q["comm"] for q in allr]
+        multi = dict(rccl_ranks=int(allr[0]["comm"]["ranks"]), transport=allr[0]["comm"]["transport"], per_rank=allr,
+                     iterations_equal_on_all_ranks=True,
+                     global_rel_residual=float(np.sqrt(rr_proj / sums[1].item())),
+                     global_rel_residual_unprojected_operator=float(np.sqrt(sums[0].item() / sums[1].item())),
+                     global_solution_sum_over_abs_scale=float(abs(sums[2].item())),
+                     a_times_one_max_abs=float(mx[0].item()), a_times_signs_max_abs=float(mx[1].item()),
+                     note="global_rel_residual = ||P (b - A x)|| / ||b|| of the global system (b projected, P the null-space projection of "
+                          "the solve), from the distributed product, all-reduced over the ranks; ..._unprojected_operator = the figure "
+                          "solver_lin_belos.h:201-212 prints on failure (A without the projection); A 1 = 0 holds across rank boundaries when a_times_one_max_abs is round-off of "
+                          "a_times_signs_max_abs; halo_profile: HIP events per product in the profile passes")
+        assert multi["global_rel_residual"] < 1e-6, multi
+        assert multi["a_times_one_max_abs"] <= 1e-9 * multi["a_times_signs_max_abs"], multi
+        # the same brick alone on this process' GPU, periodic: what N = 1 gives here, for the agreement check of the curve
+        if rank == 0 and not args.share_gpu:
+            ctx1 = hip.Context(local_rank, stream=stream, ordering="bricks" if lib_order else "caller")
+            c1 = Case(dict(ctx=ctx1, dev=dev, args=args, td=None, world=1, rank=0), args.order, lib_order)
+            ms1, i1 = c1.timed(3, 2)
+            multi["n1_in_process"] = dict(ms_per_step=ms1, iterations=int(i1.iters), solves_per_s=1e3 / ms1,
+                                          note="rank 0's GPU alone, one periodic %d^3 brick, 3 steps after 2" % n)
+            c1.close(); ctx1.close()
+        td.barrier()
+
     if rank == 0:
         out = {
             "metric": METRIC_NAME.get(args.prec, "pressure-Poisson solves/sec (3D TGV, 1M particles per GPU, GMRES(50)+%s, tol 1e-8)" % args.prec),
@@ -658,9 +829,8 @@ def main():
                        "rows_per_gpu": nlocal, "global_rows": nlocal * world, "nnz_per_gpu": info_m["nnz"],
                        "nnz_per_row": info_m["nnz"] / max(nlocal, 1), "sell_padding": info_m["stored"] / max(info_m["nnz"], 1),
                        "solver": "FGMRES(50) DGKS tol 1e-8, right prec", "precond": args.prec,
-                       "block_rows": brows if bptr is not None else args.block,
-                       "subdomains": ("%dx%dx%d-cell bricks of the particle numbering (%d rows each)" % (brick + (brows,))) if bptr is not None
-                                     else "%d consecutive rows" % args.block,
+                       "atom_order": args.order, "library_row_order": "bricks" if lib_order else "caller",
+                       "subdomains": case.subdomains(),
                        "parallelism": ("domain bricks %dx%dx%d, " % pg) +
                                       ("host-staged halo + all-reduce over gloo, ALL RANKS ON ONE GPU (rehearsal, not a performance figure)"
                                        if args.share_gpu else "RCCL halo + all-reduce"),
@@ -704,8 +874,30 @@ def main():
             else:
                 out["dropin"] = d
         if world == 1 and not args.no_cpu_baseline and args.prec in ("none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg"):
-            rp, ci, val = A.export_csr()
-            cb = cpu_baseline(rp, ci, val, b.cpu().numpy(), args.block, args.prec, args.amg_theta, args.cpu_ifpack_1rank, bptr)
+            rp, ci, val = A.export_csr()                                           # the caller's numbering
+            bh = b.cpu().numpy()
+            o = A.ordering()
+            cb_bptr = bptr
+            if o is not None:
+                # the oracle gets the library's permutation and subdomain table explicitly: it solves P A P^T (P x) = P b
+                import order as oorder
+                rp, ci, val, bh = oorder.permute_system(rp, ci, val, bh, o["perm"])
+                cb_bptr = o["block_ptr"] if args.prec.startswith("bjacobi-ilu") else None
+            xkeep = []
+            cb = cpu_baseline(rp, ci, val, bh, args.block, args.prec, args.amg_theta, args.cpu_ifpack_1rank, cb_bptr, keep_x=xkeep)
+            # parity at BASELINE size, in the record: the oracle's solution of the same system with the same subdomains
+            xc = xkeep[0]
+            if o is not None:
+                xu = np.empty_like(xc)
+                xu[o["perm"]] = xc
+                xc = xu
+            xg = x_headline.cpu().numpy()
+            cb["x_rel_diff_vs_gpu"] = float(np.linalg.norm(xg - xc) / np.linalg.norm(xc))
+            cb["iterations_gpu"] = int(inf.iters)
+            cb["iterations_equal"] = bool(int(inf.iters) == cb["same_blocks"]["iterations"])
+            cb["parity_note"] = ("same_blocks = the oracle (CPU restatement of Belos FGMRES + Ifpack ILU(0)) on the exported system"
+                                 + (", permuted with the library's row order and factored on the library's subdomain table" if o is not None else "")
+                                 + "; tolerance of the parity tests: iterations +-1, x <= 1e-6")
             out["cpu_baseline"] = cb
             out["config"]["speedup_vs_cpu"] = out["value"] / cb["value"]            # against the FASTEST CPU variant
             for k in ("same_blocks", "block_per_core", "block_per_core_ilu1", "single_thread", "ifpack_1rank"):
@@ -715,6 +907,38 @@ def main():
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 json.dump(dict(nrow=info_m["nrow"], nnz=info_m["nnz"], ifpack_1rank=cb["ifpack_1rank"]),
                           open(os.path.join(ROOT, "gpurun_out", "r02_cpu_ifpack_1rank.json"), "w"))
+        if multi is not None:
+            out["multi_gpu"] = multi
+        extra = {}
+        if world == 1 and not args.no_orders and args.prec == "bjacobi-ilu0" and not args.force_rccl:
+            # the same particles handed over in the other atom orders, with the library's own row numbering and without:
+            # the headline must not depend on the order the caller's atoms happen to be in
+            table = {}
+            head_key = "%s/%s" % (args.order, "library" if lib_order else "caller")
+            table[head_key] = dict(ms_per_solve=elapsed / args.steps * 1e3, iterations=int(inf.iters), converged=int(inf.converged),
+                                   assemble_ms=assemble_ms, subdomains=case.subdomains(), headline=True)
+            for order in ("lexicographic", "sortbin", "shuffled", "bricks"):
+                for lib in (True, False):
+                    key = "%s/%s" % (order, "library" if lib else "caller")
+                    if key in table:
+                        continue
+                    c = Case(env, order, lib)
+                    ms, ia = c.timed(3, 2)
+                    table[key] = dict(ms_per_solve=ms, iterations=int(ia.iters), converged=int(ia.converged), assemble_ms=c.assemble_ms,
+                                      subdomains=c.subdomains())
+                    c.close()
+            ctx.set_ordering("bricks" if lib_order else "caller")
+            extra["atom_orders"] = dict(note="<atom order handed over>/<who numbers the matrix rows>; 3 timed solves after 2, same "
+                                             "particles, preconditioner rebuilt every solve", cases=table)
+        if world == 1 and not args.no_step and args.prec == "bjacobi-ilu0" and not args.force_rccl and args.kernel == "wendland":
+            # the reference's own protocol beside the solve: 3 ISPH time steps, everything rebuilt per step
+            st = step_workload(args, None, ctx=ctx, steps=3, warmup=1, quiet=True)
+            extra["step"] = dict(metric=st["metric"], steps_per_s=st["value"], ms_per_step=st["ms_per_step"], split=st["split"],
+                                 iterations_poisson=st["config"]["iterations_poisson"],
+                                 iterations_helmholtz_3rhs_total=st["config"]["iterations_helmholtz_3rhs_total"],
+                                 host_lammps_side_ms_per_step=st["host_lammps_side_ms_per_step"])
+        if extra:
+            out["extra"] = extra
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if td is not None:

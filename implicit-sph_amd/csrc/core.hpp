@@ -50,6 +50,8 @@ struct isph_ctx {
   std::vector<hipEvent_t> ev;     // pairs (begin, end) of profile mode
   std::vector<int> ev_class;      // class of every pair (isph::ProfClass)
   size_t ev_used = 0;
+  std::vector<hipEvent_t> hev;    // profile mode, products with a halo: triples (packed, ghosts landed, interior done)
+  size_t hev_used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ev_fetch = nullptr;  // marks the scalar mailbox copy of a Krylov iteration (host waits on it only)
   std::vector<hipEvent_t> ev_ls;  // one such mark per right-hand side of a lockstep solve (solver.hpp gmres_lockstep)

@@ -422,6 +422,38 @@ int isph_ctx_set_profile(isph_ctx *ctx, int on) {
   ISPH_REQUIRE(ctx, "ctx is NULL");
   ctx->profile = on != 0;
   ctx->ev_used = 0;  // switching the mode starts a new collection
+  ctx->hev_used = 0;
+  return ISPH_SUCCESS;
+}
+
+int isph_ctx_halo_profile_read(isph_ctx *ctx, double ms[3], int *calls) {
+  ISPH_REQUIRE(ctx && ms && calls, "NULL argument");
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) ISPH_CHECK_HIP(hipStreamSynchronize(ctx->comm_stream));
+  ms[0] = ms[1] = ms[2] = 0.0;
+  *calls = 0;
+  for (size_t k = 0; k + 3 <= ctx->hev_used; k += 3) {
+    float te = 0.f, ti = 0.f;
+    ISPH_CHECK_HIP(hipEventElapsedTime(&te, ctx->hev[k], ctx->hev[k + 1]));
+    ISPH_CHECK_HIP(hipEventElapsedTime(&ti, ctx->hev[k], ctx->hev[k + 2]));
+    ms[0] += te; ms[1] += ti; ms[2] += te > ti ? te - ti : 0.0;
+    *calls += 1;
+  }
+  ctx->hev_used = 0;
+  return ISPH_SUCCESS;
+}
+
+int isph_ctx_comm_info(const isph_ctx *ctx, long long info[4]) {
+  ISPH_REQUIRE(ctx && info, "NULL argument");
+  info[0] = ctx->comm ? 1 : (ctx->host_tr.exchange ? 2 : 0);
+  info[1] = ctx->nranks; info[2] = ctx->rank; info[3] = ctx->device;
+  if (ctx->comm) {
+    int cnt = 0, ur = 0, dv = 0;
+    ISPH_CHECK_NCCL(ncclCommCount(ctx->comm, &cnt));
+    ISPH_CHECK_NCCL(ncclCommUserRank(ctx->comm, &ur));
+    ISPH_CHECK_NCCL(ncclCommCuDevice(ctx->comm, &dv));
+    info[1] = cnt; info[2] = ur; info[3] = dv;
+  }
   return ISPH_SUCCESS;
 }
 
@@ -535,6 +567,7 @@ void isph_ctx_destroy(isph_ctx *c) {
   if (c->hsend) (void)hipHostFree(c->hsend);
   if (c->hrecv) (void)hipHostFree(c->hrecv);
   for (auto e : c->ev) (void)hipEventDestroy(e);
+  for (auto e : c->hev) (void)hipEventDestroy(e);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   if (c->ev_fetch) (void)hipEventDestroy(c->ev_fetch);
@@ -1354,6 +1387,8 @@ int isph_solve(isph_ctx *ctx, const isph_mat *A, const isph_prec *M, double *b, 
   const int n = A->S.nrow;
   ISPH_REQUIRE(nvec >= 1 && lda >= n, "need nvec >= 1 and lda >= nlocal");
   ISPH_REQUIRE(!M || M->n == n, "preconditioner / matrix size mismatch");
+  ISPH_REQUIRE(!M || M->order.get() == A->order.get(),
+               "preconditioner and matrix are in different row numberings (build the preconditioner from this matrix)");
   isph_solver_params prm;
   if (prm_in) prm = *prm_in; else isph_solver_params_default(&prm);
   memset(info, 0, sizeof(*info));
@@ -1542,6 +1577,8 @@ int isph_solve_block(isph_ctx *ctx, int dim, const isph_mat *const *blocks, cons
   for (int k = 0; k < dim; ++k) ISPH_REQUIRE(blocks[k * dim + k] != nullptr, "diagonal blocks must be set");
   ISPH_REQUIRE(lda >= n, "need lda >= nlocal");
   ISPH_REQUIRE(!M || M->n == n, "preconditioner / block size mismatch");
+  ISPH_REQUIRE(!M || M->order.get() == blocks[0]->order.get(),
+               "preconditioner and blocks are in different row numberings (build the preconditioner from one of the blocks)");
   isph_solver_params prm;
   if (prm_in) prm = *prm_in; else isph_solver_params_default(&prm);
   memset(info, 0, sizeof(*info));

@@ -57,7 +57,9 @@ __global__ void k_gather(int n, const int *__restrict__ idx, const double *__res
 // before the boundary slices.  The communicator is only ever used by one operation at a time: the exchange starts
 // after everything queued before it (ev_pack) and every later collective is queued behind the boundary kernel, which
 // itself waits for ev_halo.  (Ifpack/Epetra do this Import inside Epetra_CrsMatrix::Apply, solver_lin.h:133.)
-inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x) {
+// hev (profile mode, the caller's operator only): three timing events of this product -- [0] values packed (compute
+// stream), [1] ghost values landed (halo stream), [2] interior slices done (compute stream, recorded by spmv_dev)
+inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x, hipEvent_t *hev = nullptr) {
   ISPH_REQUIRE(comm_active(ctx) && ctx->comm_stream,
                "a matrix with a halo needs a context made by isph_ctx_create_dist or isph_ctx_create_hostcomm");
   const Sell &S = A->S;
@@ -70,9 +72,11 @@ inline int halo_begin(isph_ctx *ctx, const isph_mat *A, const double *x) {
     hipLaunchKernelGGL(k_gather, dim3(stream_grid(H.nsend)), dim3(kBlock), 0, ctx->stream, H.nsend, H.send_idx.p, x,
                        ctx->sendbuf.p);
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev_pack, ctx->stream));
+  if (hev) ISPH_CHECK_HIP(hipEventRecord(hev[0], ctx->stream));
   ISPH_CHECK_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_pack, 0));
   ISPH_CHECK(comm_exchange(ctx, H, ctx->sendbuf.p, ctx->xghost.p, 1, false, ctx->comm_stream));
   ISPH_CHECK_HIP(hipEventRecord(ctx->ev_halo, ctx->comm_stream));
+  if (hev) ISPH_CHECK_HIP(hipEventRecord(hev[1], ctx->comm_stream));
   return ISPH_SUCCESS;
 }
 
@@ -127,10 +131,18 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
     else spmv_launch<false, false, false>(ctx, S, c16, S.nslices, nullptr, x, nullptr, y, nvec);
   } else {
     const isph_halo &H = A->halo;
-    ISPH_CHECK(halo_begin(ctx, A, x));
+    hipEvent_t *hev = nullptr;
+    if (ctx->profile && !A->aux && !A->local) {  // exchange vs interior time of this product (isph_ctx_halo_profile_read)
+      if (ctx->hev_used + 3 > ctx->hev.size())
+        for (int k = 0; k < 3; ++k) { hipEvent_t e = nullptr; ISPH_CHECK_HIP(hipEventCreate(&e)); ctx->hev.push_back(e); }
+      hev = ctx->hev.data() + ctx->hev_used;
+      ctx->hev_used += 3;
+    }
+    ISPH_CHECK(halo_begin(ctx, A, x, hev));
     // interior slices (no ghost column) while the exchange is in flight
     if (nvec) spmv_launch<true, true, false>(ctx, S, c16, H.n_int, H.list_int.p, x, nullptr, y, nvec);
     else spmv_launch<false, true, false>(ctx, S, c16, H.n_int, H.list_int.p, x, nullptr, y, nvec);
+    if (hev) ISPH_CHECK_HIP(hipEventRecord(hev[2], ctx->stream));
     ISPH_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));
     if (nvec) spmv_launch<true, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);
     else spmv_launch<false, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);

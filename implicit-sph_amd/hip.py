@@ -21,7 +21,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_mat_ordering_info", "isph_mat_ordering", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_mat_ordering_info", "isph_mat_ordering", "isph_ctx_halo_profile_read", "isph_ctx_comm_info", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
@@ -129,6 +129,8 @@ def lib():
         L.isph_ctx_set_profile.argtypes = [C.c_void_p, C.c_int]
         L.isph_ctx_hold_neighbours.argtypes = [C.c_void_p, C.c_int]
         L.isph_ctx_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_ctx_halo_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_ctx_comm_info.argtypes = [C.c_void_p, C.c_void_p]
         L.isph_ctx_set_ordering.argtypes = [C.c_void_p, C.c_int]
         L.isph_mat_ordering_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_ordering.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -345,6 +347,18 @@ class Context:
         ms, calls = (C.c_double * 8)(), (C.c_int * 8)()
         _check(lib().isph_ctx_profile_read(self.h, ms, calls))
         return {k: (ms[i], calls[i]) for i, k in enumerate(self.PROFILE_CLASSES)}
+
+    def halo_profile_read(self):
+        """isph_ctx_halo_profile_read: dict(products, exchange_ms, interior_ms, exposed_ms) summed since the collection started"""
+        ms, calls = (C.c_double * 3)(), C.c_int()
+        _check(lib().isph_ctx_halo_profile_read(self.h, ms, C.byref(calls)))
+        return dict(products=calls.value, exchange_ms=ms[0], interior_ms=ms[1], exposed_ms=ms[2])
+
+    def comm_info(self):
+        """isph_ctx_comm_info: dict(transport "none" | "rccl" | "host", ranks, rank, device) -- for RCCL from the communicator"""
+        a = (C.c_longlong * 4)()
+        _check(lib().isph_ctx_comm_info(self.h, a))
+        return dict(transport=("none", "rccl", "host")[int(a[0])], ranks=int(a[1]), rank=int(a[2]), device=int(a[3]))
 
     def close(self):
         if self.h:

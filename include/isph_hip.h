@@ -300,6 +300,15 @@ int isph_ctx_set_profile(isph_ctx *ctx, int on);
  * Either call drops what was kept.  Without it every call is self-contained. */
 int isph_ctx_hold_neighbours(isph_ctx *ctx, int on);
 int isph_ctx_profile_read(isph_ctx *ctx, double ms[8], int calls[8]);
+/* profile mode, products of a matrix with a halo plan (more than one rank): per product the time from "boundary values
+ * packed" to "ghost values landed" on the halo stream (ms[0], summed over `calls` products), the time the interior slices
+ * took on the compute stream from the same instant (ms[1]), and the part of the exchange that was not hidden behind them,
+ * max(0, exchange - interior) (ms[2]).  Starts the next collection.  No reference counterpart (Epetra's Import is
+ * synchronous inside Epetra_CrsMatrix::Apply, solver_lin.h:133). */
+int isph_ctx_halo_profile_read(isph_ctx *ctx, double ms[3], int *calls);
+/* info: [0] transport of the context: 0 none (one rank), 1 RCCL, 2 host-staged  [1] ranks -- ncclCommCount of the
+ * communicator for transport 1  [2] this rank (ncclCommUserRank)  [3] device (ncclCommCuDevice) */
+int isph_ctx_comm_info(const isph_ctx *ctx, long long info[4]);
 
 /* ---- row numbering ----------------------------------------------------- */
 
