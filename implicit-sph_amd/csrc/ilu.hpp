@@ -247,7 +247,8 @@ __global__ __launch_bounds__(kSymWaves * 64) void k_iluk_merge(
     const unsigned char *__restrict__ flev, const int *__restrict__ flen, const int *__restrict__ fdiag,
     const double *__restrict__ fval, int *__restrict__ nlen, int *__restrict__ inoff, int *__restrict__ blktot,
     int *__restrict__ maxlen, const long long *__restrict__ boff, long long *__restrict__ nrp,
-    int *__restrict__ ncol, unsigned char *__restrict__ nlev, int *__restrict__ ndiag, double *__restrict__ nval) {
+    int *__restrict__ ncol, unsigned char *__restrict__ nlev, int *__restrict__ ndiag, double *__restrict__ nval,
+    const int *__restrict__ bptr) {
   extern __shared__ double lds_m[];
   long long *rpL = reinterpret_cast<long long *>(lds_m);       // [B]
   double *dvals = lds_m + B;                                   // [waves][B] values of the row, by local column
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(kSymWaves * 64) void k_iluk_merge(
   int *dlev = cntL + B;                                        // [waves][B] level of the row's entry, by local column
   unsigned short *mcol = reinterpret_cast<unsigned short *>(dlev + kSymWaves * B);  // [waves][B] the row's columns
   unsigned char *mlev = reinterpret_cast<unsigned char *>(mcol + kSymWaves * B);    // [waves][B] ... and levels
-  const int b = blockIdx.x, blo = b * B, bhi = min(blo + B, n), m = bhi - blo;
+  const int b = blockIdx.x;
+  int blo, bhi;
+  ilu_block_rows(bptr, b, B, n, blo, bhi);  // B rows each, or the caller's table (B is then the capacity)
+  const int m = bhi - blo;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int t = threadIdx.x; t < m; t += blockDim.x) {
     rpL[t] = frp[blo + t];
@@ -1197,7 +1201,7 @@ inline int ilu_symbolic(isph_ctx *ctx, isph_ilu *F, int K) {
     hipLaunchKernelGGL((k_iluk_merge<false>), dim3(nb), dim3(kSymWaves * 64), lds, ctx->stream, n, B, K, F->frp.p, F->fcol.p,
                        F->flev.p, F->flen.p, F->fdiag.p, F->fval.p, nlen.p, inoff.p, blktot.p, meta.p,
                        (const long long *)nullptr, (long long *)nullptr, (int *)nullptr, (unsigned char *)nullptr,
-                       (int *)nullptr, (double *)nullptr);
+                       (int *)nullptr, (double *)nullptr, F->blocks());
     hipLaunchKernelGGL(k_iluk_block_offsets, dim3(1), dim3(1024), 0, ctx->stream, nb, blktot.p, F->boff.p);
     long long total = 0;
     int wmax = 0, herr = 0;
@@ -1223,7 +1227,7 @@ inline int ilu_symbolic(isph_ctx *ctx, isph_ilu *F, int K) {
     if (rc == ISPH_SUCCESS) {
       hipLaunchKernelGGL((k_iluk_merge<true>), dim3(nb), dim3(kSymWaves * 64), lds, ctx->stream, n, B, K, F->frp.p, F->fcol.p,
                          F->flev.p, F->flen.p, F->fdiag.p, F->fval.p, nlen.p, inoff.p, blktot.p, meta.p,
-                         (const long long *)F->boff.p, nrp.p, ncol.p, nlev.p, ndiag.p, nval.p);
+                         (const long long *)F->boff.p, nrp.p, ncol.p, nlev.p, ndiag.p, nval.p, F->blocks());
       if (hipGetLastError() != hipSuccess) rc = fail("ILU(k) symbolic fill failed", __FILE__, __LINE__);
     }
     if (rc != ISPH_SUCCESS) { nrp.release(); ncol.release(); ndiag.release(); nlev.release(); nval.release(); break; }
@@ -1272,7 +1276,7 @@ inline int ilu_begin(isph_ctx *ctx, const Sell &S, int block_size, bool sgs, int
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
                "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
   ISPH_REQUIRE(fill >= 0 && fill <= 8 && !(sgs && fill), "level of fill must be in [0,8]");
-  ISPH_REQUIRE(nblocks_tab == 0 || (host_bptr && fill == 0), "a table of subdomains needs level of fill 0");
+  ISPH_REQUIRE(nblocks_tab == 0 || host_bptr, "a table of subdomains without its offsets");
   isph_ilu *F = new isph_ilu();
   F->n = S.nrow; F->B = block_size; F->wmax = S.wmax; F->fill = fill;
   F->nblocks = nblocks_tab > 0 ? nblocks_tab : (S.nrow + block_size - 1) / block_size;
@@ -1454,13 +1458,17 @@ inline int ilu_create(isph_ctx *ctx, const isph_mat *A, int block_size, isph_ilu
                          (const int *)S.rowlen.p, (const long long *)S.slice_off.p, (const int *)S.col.p, blktot.p, F->blocks());
       hipLaunchKernelGGL(k_iluk_block_offsets, dim3(1), dim3(1024), 0, ctx->stream, F->nblocks, (const int *)blktot.p, F->boff.p);
       F->compact = true;
-      rc = F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1));
     }
-    if (rc == ISPH_SUCCESS) rc = ilu_size_stream(F);
     if (rc == ISPH_SUCCESS) {
       ilu_launch_extract(ctx, F, S, 0, F->nblocks);
-      rc = ilu_schedule_and_factor(ctx, F, S, sgs);
+      if (fill > 0) {  // "fact: level-of-fill" > 0 on the table's blocks: the symbolic sweeps re-lay the factor out
+        rc = ilu_symbolic(ctx, F, fill);
+        F->exact = ilu_wants_exact_stream(F);
+      }
     }
+    if (rc == ISPH_SUCCESS) rc = F->fdst.reserve((size_t)(F->total > 0 ? F->total : 1));
+    if (rc == ISPH_SUCCESS && !F->exact) rc = ilu_size_stream(F);
+    if (rc == ISPH_SUCCESS) rc = ilu_schedule_and_factor(ctx, F, S, sgs);
     blktot.release();
   } else if (big) {
     DevTmp<int> blktot;

@@ -412,6 +412,15 @@ int isph_ctx_create_hostcomm(int device, void *stream, int rank, int nranks, con
   return ISPH_SUCCESS;
 }
 
+int isph_device_identity(int device, char id[ISPH_DEVICE_ID_BYTES]) {
+  ISPH_REQUIRE(id, "NULL argument");
+  memset(id, 0, ISPH_DEVICE_ID_BYTES);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail("device index out of range", __FILE__, __LINE__);
+  ISPH_CHECK_HIP(hipDeviceGetPCIBusId(id, ISPH_DEVICE_ID_BYTES - 1, device));
+  return ISPH_SUCCESS;
+}
+
 int isph_ctx_sync(isph_ctx *ctx) {
   ISPH_REQUIRE(ctx, "ctx is NULL");
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -643,6 +652,8 @@ int isph_mat_create_csr_blocks(isph_ctx *ctx, int nrow, int ncol, const int *row
                                int nblocks, const int *block_ptr, isph_mat **Aout, isph_prec **Mout) {
   ISPH_REQUIRE(ctx && Aout && Mout && rowptr && colidx && val && nblocks > 0 && block_ptr, "NULL argument or no subdomains");
   ISPH_REQUIRE(nrow >= 0 && ncol >= nrow, "need 0 <= nrow <= ncol");
+  ISPH_REQUIRE(!is_device_pointer(block_ptr), "block_ptr must be a host array");
+  ISPH_REQUIRE(block_ptr[0] == 0 && block_ptr[nblocks] == nrow, "subdomain table must run from 0 to the number of rows");
   int cap = 64;
   for (int b = 0; b < nblocks; ++b) cap = std::max(cap, block_ptr[b + 1] - block_ptr[b]);
   cap = (cap + 63) / 64 * 64;
@@ -1047,7 +1058,13 @@ int isph_spmv_time(isph_ctx *ctx, const isph_mat *A, const double *x_dev, double
 /* ---- preconditioner --------------------------------------------------- */
 
 int isph_prec_create_blocks(isph_ctx *ctx, const isph_mat *A, int nblocks, const int *block_ptr, isph_prec **Mout) {
+  return isph_prec_create_blocks_fill(ctx, A, nblocks, block_ptr, 0, Mout);
+}
+
+int isph_prec_create_blocks_fill(isph_ctx *ctx, const isph_mat *A, int nblocks, const int *block_ptr, int level_of_fill,
+                                 isph_prec **Mout) {
   ISPH_REQUIRE(ctx && A && Mout && nblocks > 0 && block_ptr, "NULL argument or no subdomains");
+  ISPH_REQUIRE(level_of_fill >= 0 && level_of_fill <= 8, "level of fill must be in [0,8]");
   ISPH_REQUIRE(!is_device_pointer(block_ptr), "block_ptr must be a host array");
   ISPH_REQUIRE(!A->order, "the matrix was assembled in the library's own row numbering: its subdomains are the library's "
                           "bricks (isph_prec_create with block_size 0); a table over the caller's rows needs "
@@ -1059,7 +1076,7 @@ int isph_prec_create_blocks(isph_ctx *ctx, const isph_mat *A, int nblocks, const
   isph_prec *M = new isph_prec();
   M->n = A->S.nrow;
   M->type = 2;
-  const int rc = ilu_create(ctx, A, cap, &M->ilu, /*sgs=*/false, /*fill=*/0, nblocks, block_ptr);
+  const int rc = ilu_create(ctx, A, cap, &M->ilu, /*sgs=*/false, level_of_fill, nblocks, block_ptr);
   if (rc != ISPH_SUCCESS) { isph_prec_destroy(M); return rc; }
   *Mout = M;
   return ISPH_SUCCESS;

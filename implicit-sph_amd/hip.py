@@ -19,9 +19,9 @@ KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 EXPORTS = [
     "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_create_hostcomm", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_pool_info", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
-    "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_apply",
+    "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_create_blocks_fill", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_mat_ordering_info", "isph_mat_ordering", "isph_ctx_halo_profile_read", "isph_ctx_comm_info", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_mat_ordering_info", "isph_mat_ordering", "isph_ctx_halo_profile_read", "isph_ctx_comm_info", "isph_device_identity", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
@@ -131,6 +131,7 @@ def lib():
         L.isph_ctx_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_ctx_halo_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_ctx_comm_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.isph_device_identity.argtypes = [C.c_int, C.c_char_p]
         L.isph_ctx_set_ordering.argtypes = [C.c_void_p, C.c_int]
         L.isph_mat_ordering_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_ordering.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -150,6 +151,7 @@ def lib():
         L.isph_spmv_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.isph_prec_create.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
         L.isph_prec_create_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.isph_prec_create_blocks_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.isph_prec_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.isph_prec_export_ilu.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_prec_destroy.argtypes = [C.c_void_p]
@@ -244,6 +246,13 @@ def _f64(a):
         assert str(a.dtype) == "torch.float64", "float64 tensor expected, got %s" % a.dtype
         return a
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_identity(device=0):
+    """isph_device_identity: the PCI bus id of HIP device `device` as this process sees it"""
+    buf = C.create_string_buffer(64)
+    _check(lib().isph_device_identity(int(device), buf))
+    return buf.value.decode()
 
 
 def pool_trim():
@@ -551,9 +560,9 @@ class Precond:
         self.ctx, self.n = ctx, A.info()["nrow"]
         self.h = C.c_void_p()
         if block_ptr is not None:
-            assert kind == "bjacobi-ilu0"
+            assert kind.startswith("bjacobi-ilu") and kind[11:].isdigit()
             bp = np.ascontiguousarray(block_ptr, dtype=np.int32)
-            _check(lib().isph_prec_create_blocks(ctx.h, A.h, len(bp) - 1, _ptr(bp), C.byref(self.h)))
+            _check(lib().isph_prec_create_blocks_fill(ctx.h, A.h, len(bp) - 1, _ptr(bp), int(kind[11:]), C.byref(self.h)))
         else:
             _check(lib().isph_prec_create(ctx.h, A.h, kind.encode(), block_size, C.byref(self.h)))
 

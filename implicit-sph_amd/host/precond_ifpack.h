@@ -37,8 +37,8 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
   // Device-side extension (not a reference method): the additive-Schwarz subdomains INSIDE this rank as consecutive row
   // ranges, block b = rows block_ptr[b] .. block_ptr[b+1] (at most 1024 rows each).  The reference has one subdomain per
   // rank, a brick of LAMMPS' decomposition; an adapter that numbers the rank's particles brick by brick passes the brick
-  // boundaries here and gets compact subdomains instead of a cut every "isph: block rows" rows.  Level of fill 0,
-  // overlap 0 (isph_prec_create_blocks).  nblocks = 0 clears the table.
+  // boundaries here and gets compact subdomains instead of a cut every "isph: block rows" rows.  Any level of fill,
+  // overlap 0 (isph_prec_create_blocks_fill).  nblocks = 0 clears the table.
   void setSubdomains(int nblocks, const int *block_ptr) {
     _bptr.clear();
     if (nblocks > 0 && block_ptr != NULL) _bptr.assign(block_ptr, block_ptr + nblocks + 1);
@@ -50,18 +50,34 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     setParameters(_param.get());
     const int block = _param->get("isph: block rows", 512);
     if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0) return 0;
-    if (!_bptr.empty()) {
+    if (tableUsable()) {
       int cap = 64;
       for (size_t b = 0; b + 1 < _bptr.size(); ++b) cap = std::max(cap, _bptr[b + 1] - _bptr[b]);
       noticeOnce(0, cap, _param->get("Overlap Level", 1));
-      return cap <= 1024 ? (cap + 63) / 64 * 64 : 0;
+      return (cap + 63) / 64 * 64;
     }
     if (block < 64 || block > 1024 || block % 64 != 0) return 0;
     noticeOnce(0, block, _param->get("Overlap Level", 1));
     return block;
   }
-  virtual bool fusedIngressSubdomains(int &nblocks, const int *&bptr) {
+  // A table that does not fit the matrix at hand -- left over from a matrix with another row count, a subdomain above
+  // the 1024 rows of the block stream, offsets that do not ascend -- is set aside with a notice and the solve goes on
+  // with "isph: block rows" consecutive rows; it never fails the solve.
+  bool tableUsable() {
     if (_bptr.empty()) return false;
+    const int nrows = _A.get() != NULL ? _A->NumMyRows() : -1;
+    bool ok = _bptr.front() == 0 && (nrows < 0 || _bptr.back() == nrows);
+    for (size_t b = 0; ok && b + 1 < _bptr.size(); ++b) ok = _bptr[b + 1] > _bptr[b] && _bptr[b + 1] - _bptr[b] <= 1024;
+    if (!ok && _comm.MyPID() == 0 && !_warned_table) {
+      std::printf(">> PrecondWrapper_Ifpack(HIP): the subdomain table of setSubdomains does not fit this matrix (rows %d, table "
+                  "ends at %d, blocks of 1..1024 rows required): ignored, subdomains are \"isph: block rows\" consecutive rows\n",
+                  nrows, _bptr.back());
+      _warned_table = true;
+    }
+    return ok;
+  }
+  virtual bool fusedIngressSubdomains(int &nblocks, const int *&bptr) {
+    if (!tableUsable()) return false;
     nblocks = (int)_bptr.size() - 1;
     bptr = _bptr.data();
     return true;
@@ -134,9 +150,9 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
       isph_mat_destroy(Aext);
       return ierr;
     }
-    if (!_bptr.empty() && fill == 0) {  // the caller's subdomains (setSubdomains)
+    if (tableUsable()) {  // the caller's subdomains (setSubdomains), any level of fill
       noticeOnce(fill, 0, overlap);
-      return isph_prec_create_blocks(ctx, A, (int)_bptr.size() - 1, _bptr.data(), &_M);
+      return isph_prec_create_blocks_fill(ctx, A, (int)_bptr.size() - 1, _bptr.data(), fill, &_M);
     }
     if (block == 0 || block > 1024) {
       isph_schwarz_params sp;
@@ -154,7 +170,7 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     const std::string kind = "bjacobi-ilu" + std::to_string(fill);
     return isph_prec_create(ctx, A, kind.c_str(), block, &_M);
   }
-  bool _warned = false;
+  bool _warned = false, _warned_table = false;
   std::vector<int> _bptr;  // setSubdomains
 };
 

@@ -227,7 +227,7 @@ class SolverLin_HIP : public SolverLin {
 #ifdef ISPH_HAVE_MPI
     // Which transport: RCCL needs one device per rank.  Ranks that share a device (several MPI ranks of a LAMMPS run
     // per GPU) exchange through the caller's MPI communicator instead, staged through pinned memory (csrc/comm.hpp).
-    // "auto": every rank gathers the device indices of the ranks on its node; one shared device anywhere => MPI
+    // "auto": every rank gathers the PCI bus ids of the devices of the ranks on its node; one shared device anywhere => MPI
     // everywhere (the choice must be the same on all ranks).  ISPH_TRANSPORT=rccl|mpi overrides.
     if (useMpiTransport()) {
       _mpi.comm = _comm.Comm();
@@ -264,9 +264,16 @@ class SolverLin_HIP : public SolverLin {
         int nn = 1, me = 0;
         MPI_Comm_size(node, &nn);
         MPI_Comm_rank(node, &me);
-        std::vector<int> dev((size_t)nn, 0);
-        MPI_Allgather(&_device, 1, MPI_INT, dev.data(), 1, MPI_INT, node);
-        for (int r = 0; r < nn; ++r) shared = shared || (r != me && dev[(size_t)r] == _device);
+        // the PHYSICAL device, not the ordinal: in the usual one-GPU-per-rank launch every rank runs under its own
+        // ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES mask and sees "device 0" -- ordinals would call that sharing and
+        // put every exchange on the host; the PCI bus id of the device the ordinal maps to tells them apart
+        char mine[ISPH_DEVICE_ID_BYTES];
+        std::memset(mine, 0, sizeof(mine));
+        if (isph_device_identity(_device, mine) != ISPH_SUCCESS) std::snprintf(mine, sizeof(mine), "ordinal-%d", _device);
+        std::vector<char> ids((size_t)nn * ISPH_DEVICE_ID_BYTES, 0);
+        MPI_Allgather(mine, ISPH_DEVICE_ID_BYTES, MPI_CHAR, ids.data(), ISPH_DEVICE_ID_BYTES, MPI_CHAR, node);
+        for (int r = 0; r < nn; ++r)
+          shared = shared || (r != me && std::memcmp(ids.data() + (size_t)r * ISPH_DEVICE_ID_BYTES, mine, ISPH_DEVICE_ID_BYTES) == 0);
         MPI_Comm_free(&node);
       }
       choice = _comm.MaxAll(shared);

@@ -62,6 +62,11 @@ typedef struct {
 } isph_host_transport;
 int isph_ctx_create_hostcomm(int device, void *stream, int rank, int nranks, const isph_host_transport *transport,
                              isph_ctx **ctx);
+/* Physical identity of HIP device `device` as this process sees it: its PCI bus id ("0000:c1:00.0"), zero-padded to
+ * ISPH_DEVICE_ID_BYTES.  Two ranks share a GPU exactly when their strings are equal -- their ordinals say nothing when
+ * every rank runs under its own ROCR_VISIBLE_DEVICES mask (host/solver_lin_hip.h picks the transport by it). */
+#define ISPH_DEVICE_ID_BYTES 64
+int isph_device_identity(int device, char id[ISPH_DEVICE_ID_BYTES]);
 int isph_ctx_sync(isph_ctx *ctx);
 void isph_ctx_destroy(isph_ctx *ctx);
 /* Device buffers released by the library are kept for the next set-up (the reference rebuilds matrix and preconditioner
@@ -188,6 +193,11 @@ int isph_prec_create(isph_ctx *ctx, const isph_mat *A, const char *type, int blo
  * subdomain of its own shape and not the two halves of its neighbours.  Same kernels and data layout as
  * isph_prec_create("bjacobi-ilu0"). */
 int isph_prec_create_blocks(isph_ctx *ctx, const isph_mat *A, int nblocks, const int *block_ptr, isph_prec **M);
+/* The same with "fact: level-of-fill" = level_of_fill in 0..8 (ref: precond_ifpack.h:35, the reference's default is 1): the
+ * level-of-fill pattern of every subdomain (Ifpack_IlukGraph's rule) is formed on the device by level_of_fill sweeps of
+ * the merge kernel, whatever the lengths of the subdomains. */
+int isph_prec_create_blocks_fill(isph_ctx *ctx, const isph_mat *A, int nblocks, const int *block_ptr, int level_of_fill,
+                                 isph_prec **M);
 /* Ifpack_AdditiveSchwarz<Ifpack_ILU> with the parameters PrecondWrapper_Ifpack sets (ref: precond_ifpack.h:30-45,
  * 60-74): "fact: level-of-fill" (default 1), "Overlap Level" (default 1), "schwarz: combine mode" (default "Add" = 0;
  * 1 = "Zero", restricted additive Schwarz).  block_size = 0: one subdomain = the whole local matrix, which is what

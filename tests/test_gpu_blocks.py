@@ -57,6 +57,63 @@ def test_ilu0_on_caller_subdomains_matches_oracle(gpu_ctx, kind):
     M.close(); A.close()
 
 
+@pytest.mark.parametrize("kind,fill", [("bricks500", 1), ("ragged", 1), ("ragged", 2), ("uniform512", 1)])
+def test_iluk_on_caller_subdomains_matches_oracle(gpu_ctx, kind, fill):
+    """"fact: level-of-fill" k > 0 (precond_ifpack.h:35; the reference's default is 1) on the caller's subdomains of any
+    length: the level-of-fill pattern of every block exact against orc.ILU(rp, ci, val, k, bp) (Ifpack_IlukGraph's rule
+    restated), values 1e-10, application 1e-11, FGMRES iterations +-1; the table form of uniform blocks is the built-in
+    "bjacobi-ilu<k>" object bit for bit."""
+    spec = workload.TGVSpec(dim=3, ncell=(20, 20, 20), brick=(10, 10, 5), mode=workload.JITTER)
+    pr = Problem(spec)
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    bp = _tables(n, kind)
+    ref = orc.ILU(rp, ci, val, fill, bp)
+    frp, fci, fv = ref.export()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu%d" % fill, block_ptr=bp)
+    grp, gci, gv = M.export_ilu()
+    assert np.array_equal(grp, frp) and np.array_equal(gci, fci)
+    assert len(fci) > len(ci) * 0.5                                        # the pattern did fill in
+    assert np.max(np.abs(gv - fv) / np.maximum(np.abs(fv), 1e-10 * np.abs(fv).max())) < 1e-10
+    r = np.random.default_rng(5).standard_normal(n)
+    z, zo = M.apply(r), ref.apply(r)
+    assert np.linalg.norm(z - zo) / np.linalg.norm(zo) < 1e-11
+    if kind == "uniform512":
+        M2 = hip.Precond(gpu_ctx, A, "bjacobi-ilu%d" % fill, 512)
+        assert np.array_equal(M2.apply(r), z)
+        M2.close()
+    xo, io, _ = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=ref)
+    bg, xg = b.copy(), np.zeros(n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=True)
+    assert info.converged == 1 and abs(info.iters - io.iters) <= 1, (info.iters, io.iters)
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+    M.close(); A.close()
+
+
+def test_tables_of_tiny_blocks_do_not_overrun_the_factor_arrays(gpu_ctx):
+    """a table of 1-row and few-row blocks on a banded matrix: every block's factor region is rounded up to 64 entries,
+    so the regions together exceed the matrix' stored entries -- the arrays are sized for that; factor and
+    application against the oracle (1-row blocks: M = diag(A))"""
+    n = 3000
+    main = 4.0 + np.arange(n) * 1e-3
+    import scipy.sparse as sps
+    T = sps.diags([-1.0 * np.ones(n - 1), main, -1.2 * np.ones(n - 1)], [-1, 0, 1], format="csr")
+    rp, ci, val = T.indptr.astype(np.int32), T.indices.astype(np.int32), T.data.copy()
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    for bp in (np.arange(n + 1, dtype=np.int32), np.arange(0, n + 10, 10).clip(0, n).astype(np.int32),
+               np.unique(np.r_[0, np.arange(1, n, 3), n]).astype(np.int32)):
+        ref = orc.ILU(rp, ci, val, 0, bp)
+        M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", block_ptr=bp)
+        f1, f2 = M.export_ilu(), ref.export()
+        assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
+        assert np.max(np.abs(f1[2] - f2[2])) <= 1e-12 * np.abs(f2[2]).max()
+        r = np.random.default_rng(1).standard_normal(n)
+        assert np.linalg.norm(M.apply(r) - ref.apply(r)) <= 1e-12 * np.linalg.norm(r)
+        M.close()
+    A.close()
+
+
 def test_caller_subdomains_are_validated(gpu_ctx):
     pr = Problem(tgv_spec(dim=3, n=12))
     rp, ci, val, b = pr.poisson()

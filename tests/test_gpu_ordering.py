@@ -130,6 +130,31 @@ def test_block_ilu_on_the_librarys_bricks_matches_the_oracle(octx):
     assert len(set(its.values())) == 1, its                                # the atom order does not reach the solver
 
 
+def test_iluk_on_the_librarys_bricks(octx):
+    """"bjacobi-ilu1" with block_size 0: the reference's default level of fill (precond_ifpack.h:35) on the library's bricks"""
+    spec = tgv_spec(dim=3, n=20, mode=workload.JITTER)
+    name, parts = _three_orders(spec)[1]
+    P, (rp, ci, val, b) = _oracle_system(parts, spec)
+    nl = parts["nlocal"]
+    A, bg = _assemble(octx, parts, spec, P)
+    o = A.ordering()
+    M = hip.Precond(octx, A, "bjacobi-ilu1", 0)
+    rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
+    ref = orc.ILU(rpi, cii, vi, 1, o["block_ptr"])
+    frp, fci, fv = ref.export()
+    grp, gci, gv = M.export_ilu()
+    assert np.array_equal(grp, frp) and np.array_equal(gci, fci)
+    assert np.max(np.abs(gv - fv) / np.maximum(np.abs(fv), 1e-10 * np.abs(fv).max())) < 1e-10
+    xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, prec="ilu", ilu=ref)
+    bb, xg = bg.copy(), np.zeros(nl)
+    info = hip.solve(octx, A, bb, xg, prec=M, singular=True)
+    xo = np.empty(nl)
+    xo[o["perm"]] = xoi
+    assert info.converged == 1 and abs(info.iters - io.iters) <= 1, (info.iters, io.iters)
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+    M.close(); A.close()
+
+
 def test_device_operands_and_null_mask_follow_the_callers_rows(octx):
     import torch
     dev = torch.device("cuda", 0)

@@ -260,28 +260,58 @@ def test_full_size_properties(gpu_ctx):
     assert abs(x.mean()) < 1e-12 * np.abs(x).max()
 
 
-def test_config1_full_size_100cubed(gpu_ctx):
-    """BASELINE configs[1] at its full size inside the test suite (not only in bench.py): 3-D TGV, 100^3 = 1 M rows,
-    assembled and solved on the GPU with FGMRES(50) + block-Jacobi ILU(0) (512-row blocks).  Size-independent
-    properties: zero row sums, b orthogonal to the null vector after projection, x . n = 0, the residual re-computed
-    on the host with an independent CSR product <= 2e-8, the iteration count bench.py reports (116 +- 2), and the
-    same solution from the Jacobi-preconditioned solve (two different Krylov paths agree to 1e-6)."""
-    sp = tgv_spec(dim=3, n=100, mode=workload.ADVECT)
+def test_config1_full_size_100cubed(gpu_ctx_bricks):
+    """BASELINE configs[1] at its full size and in bench.py's own configuration: 3-D TGV, 100^3 = 1 M particles handed over
+    in lexicographic atom order (create_atoms on the lattice), the library numbering the rows itself (its 10 x 10 x 5
+    bricks = the block-Jacobi subdomains), FGMRES(50) + block ILU(0) rebuilt per solve -- against the ORACLE on the same
+    system (solver_lin_belos.h:130-222): the oracle is handed the library's permutation and subdomain table, factors and
+    solves P A P^T (1-2 s on the host cores): iterations +-1, ||x_gpu - x_cpu|| / ||x_cpu|| <= 1e-6, the ILU factor of
+    200 sampled subdomains <= 1e-10 with the pattern exact.  Kept from the earlier rounds, the size-independent properties:
+    zero row sums, b orthogonal to the null vector after projection, x . n = 0, the residual re-computed on the host with
+    an independent CSR product <= 2e-8, and the same solution from the Jacobi-preconditioned solve (two different Krylov
+    paths agree to 1e-6)."""
+    import order as oorder
+    ctx = gpu_ctx_bricks
+    sp = workload.TGVSpec(dim=3, ncell=(100, 100, 100), brick=(100, 100, 100), mode=workload.ADVECT)
     p = workload.make_tgv(sp)
     colmap = workload.single_rank_colmap(p)
     n = p["nlocal"]
     assert n == 10 ** 6
-    vf = hip.compute_volumes(gpu_ctx, p, colmap)
+    vf = hip.compute_volumes(ctx, p, colmap)
     vfrac = np.ascontiguousarray(vf[p["owner_index"]])
-    A, b = hip.assemble_poisson(gpu_ctx, p, colmap, sp.dt, p["rho"], np.ascontiguousarray(p["v"]), vfrac=vfrac)
+    A, b = hip.assemble_poisson(ctx, p, colmap, sp.dt, p["rho"], np.ascontiguousarray(p["v"]), vfrac=vfrac)
     info_m = A.info()
     assert info_m["nrow"] == n and 100 < info_m["nnz"] / n < 108
-    rp, ci, v = A.export_csr()
+    rp, ci, v = A.export_csr()                                          # the caller's numbering
     assert np.max(np.abs(A.spmv(np.ones(n)))) < 1e-11 * np.abs(v).max()
-    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 512)
+    o = A.ordering()
+    sizes = np.diff(o["block_ptr"])
+    assert len(sizes) == 2000 and sizes.min() == sizes.max() == 500     # 10 x 10 x 5 bricks tile the lattice
+    assert np.array_equal(o["perm"], oorder.order(p["x"][:n], o["geom"]))
+    M = hip.Precond(ctx, A, "bjacobi-ilu0", 0)
     x, bb = np.zeros(n), b.copy()
-    info = hip.solve(gpu_ctx, A, bb, x, prec=M, singular=True)
-    assert info.converged == 1 and abs(info.iters - 116) <= 2, info.iters
+    info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
+    assert info.converged == 1
+    # ---- the oracle on the same system with the same subdomains
+    rpi, cii, vi, bi = oorder.permute_system(rp, ci, v, b, o["perm"])
+    ref = orc.ILU(rpi, cii, vi, 0, o["block_ptr"])
+    xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, prec="ilu", ilu=ref)
+    assert io.converged == 1 and abs(info.iters - io.iters) <= 1, (info.iters, io.iters)
+    assert abs(info.iters - 71) <= 2, info.iters                        # the figure bench.py reports
+    xo = np.empty(n)
+    xo[o["perm"]] = xoi
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    frp, fci, fv = ref.export()
+    grp, gci, gv = M.export_ilu()                                       # the matrix' own numbering, like the oracle's copy
+    assert np.array_equal(grp, frp)
+    pick = np.sort(np.random.default_rng(4).choice(len(sizes), size=200, replace=False))
+    for bk in pick:
+        lo, hi = frp[o["block_ptr"][bk]], frp[o["block_ptr"][bk + 1]]
+        assert np.array_equal(gci[lo:hi], fci[lo:hi]), bk
+        fb = fv[lo:hi]
+        assert np.max(np.abs(gv[lo:hi] - fb) / np.maximum(np.abs(fb), 1e-10 * np.abs(fb).max())) < 1e-10, bk
+    M.close()
+    # ---- size-independent properties
     assert abs(bb.sum()) < 1e-10 * np.abs(bb).sum()                     # b was projected in place
     assert abs(x.mean()) < 1e-12 * np.abs(x).max()
     Ah = _csr(rp, ci, v, n)
@@ -289,9 +319,10 @@ def test_config1_full_size_100cubed(gpu_ctx):
     r -= r.mean()
     assert np.linalg.norm(r) / np.linalg.norm(bb) < 2e-8
     xj, bj = np.zeros(n), b.copy()
-    ij = hip.solve(gpu_ctx, A, bj, xj, prec=hip.Precond(gpu_ctx, A, "jacobi", 0), singular=True)
+    ij = hip.solve(ctx, A, bj, xj, prec=hip.Precond(ctx, A, "jacobi", 0), singular=True)
     assert ij.converged == 1
     assert np.linalg.norm(x - xj) / np.linalg.norm(xj) < 1e-6
+    A.close()
 
 
 def test_neigh_ptr64_gives_the_same_system(gpu_ctx):
