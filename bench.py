@@ -260,7 +260,7 @@ def cpu_baseline(rp, ci, val, b, block, prec, amg_theta=0.0, ifpack_1rank=False,
     return out
 
 
-def dropin_leg(A, b, repeat=5, sub_rows=0):
+def dropin_leg(A, b, repeat=5, sub_rows=0, coords=None):
     """The path `north_star` names, unchanged: the matrix as a HOST Epetra CSR handed to SolverLin_Belos::solveProblem
     (pair_isph.cpp:924-926,988-1011 -> host/solver_lin_hip.h) with PrecondWrapper_Ifpack (fill 0, overlap 0, 512-row
     subdomains = the headline preconditioner).  The C++ driver of the mirror classes (tests/cpp/test_solver_lin.cpp, mode
@@ -280,7 +280,12 @@ def dropin_leg(A, b, repeat=5, sub_rows=0):
             np.array([n, len(val)], np.int32).tofile(f)
             rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
             val.tofile(f); bh.tofile(f)
-        r = subprocess.run([exe, fin, fout, "1", "timed", str(repeat), str(int(sub_rows))], capture_output=True, text=True, timeout=600)
+        cmd = [exe, fin, fout, "1", "timed", str(repeat), str(int(sub_rows))]
+        if coords is not None:                      # PrecondWrapper_Ifpack::setCoordinates: x[n], y[n], z[n]
+            fc = os.path.join(td_, "coords.bin")
+            np.ascontiguousarray(np.asarray(coords)[:n, :3].T).tofile(fc)
+            cmd.append(fc)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:
             return {"error": (r.stdout + r.stderr)[-400:]}
         rec = None
@@ -290,7 +295,9 @@ def dropin_leg(A, b, repeat=5, sub_rows=0):
         if rec is None:
             return {"error": "no record from the driver: " + r.stdout[-300:]}
         xd = np.fromfile(fout)[:n]
-    rec["path"] = "SolverLin_Belos::solveProblem(PrecondWrapper_Ifpack) on a host CSR, C++ mirror, median of %d calls" % repeat
+    rec["path"] = ("SolverLin_Belos::solveProblem(PrecondWrapper_Ifpack) on a host CSR in the caller's atom order, C++ mirror, median of %d calls%s"
+                   % (repeat, "; the adapter called PrecondWrapper_Ifpack::setCoordinates (INTEGRATION.md): rows numbered by the library" if coords is not None
+                      else "; pair_isph.cpp unchanged: subdomains = 512 consecutive rows of the atom order" if not sub_rows else ""))
     return rec, xd
 
 
@@ -863,16 +870,22 @@ def main():
             out["alt"] = alt
         if world == 1 and not args.no_dropin and not args.force_rccl and args.prec == "bjacobi-ilu0" and (args.block == 512 or bptr is not None):
             # the unchanged SolverLin drop-in (host CSR in, host x out) beside the device-resident figure above
-            d = dropin_leg(A, b, sub_rows=brows if bptr is not None else 0)
-            if isinstance(d, tuple):
-                rec, xd = d
-                xr = x_headline.cpu().numpy()
-                rec["x_rel_diff_vs_device_resident"] = float(np.linalg.norm(xd - xr) / np.linalg.norm(xr))
-                rec["iterations_device_resident"] = inf.iters
-                rec["ratio_to_device_resident"] = rec["ms_per_solve"] / (elapsed / args.steps * 1e3)
-                out["dropin"] = rec
-            else:
-                out["dropin"] = d
+            # with the three-line adapter call that hands the wrapper the coordinates (the library numbers the rows), and
+            # without it (pair_isph.cpp unchanged: the rows keep the atom order, 512 consecutive rows per subdomain)
+            for key, kw in (("dropin", dict(coords=parts["x"]) if lib_order else dict(sub_rows=brows if bptr is not None else 0)),
+                            ("dropin_unchanged_adapter", dict(sub_rows=0))):
+                if key == "dropin_unchanged_adapter" and not lib_order:
+                    continue
+                d = dropin_leg(A, b, **kw)
+                if isinstance(d, tuple):
+                    rec, xd = d
+                    xr = x_headline.cpu().numpy()
+                    rec["x_rel_diff_vs_device_resident"] = float(np.linalg.norm(xd - xr) / np.linalg.norm(xr))
+                    rec["iterations_device_resident"] = inf.iters
+                    rec["ratio_to_device_resident"] = rec["ms_per_solve"] / (elapsed / args.steps * 1e3)
+                    out[key] = rec
+                else:
+                    out[key] = d
         if world == 1 and not args.no_cpu_baseline and args.prec in ("none", "jacobi", "bjacobi-ilu0", "bjacobi-ilu1", "bjacobi-ilu2", "sa-amg"):
             rp, ci, val = A.export_csr()                                           # the caller's numbering
             bh = b.cpu().numpy()

@@ -327,6 +327,33 @@ struct OrderedAssembly {
   }
 };
 
+// S0 (the caller's numbering) -> S (the numbering of O): rows perm[.], owned columns through iperm, rows column-sorted
+int sell_permute(isph_ctx *ctx, const Sell &S0, const RowOrder &O, Sell &S) {
+  S.nrow = S0.nrow; S.ncol = S0.ncol; S.nnz = S0.nnz; S.nslices = S0.nslices; S.wmax = S0.wmax;
+  const int n = S.nrow;
+  ISPH_CHECK(S.rowlen.reserve((size_t)(n > 0 ? n : 1)));
+  ISPH_CHECK(S.slice_off.reserve((size_t)S.nslices + 1));
+  if (n == 0) return ISPH_SUCCESS;
+  const int grid = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL((k_perm_gather<int>), dim3(perm_grid(n)), dim3(kBlock), 0, ctx->stream, (long long)n, n, 1, (const int *)O.perm.p,
+                     (const int *)S0.rowlen.p, S.rowlen.p);
+  hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, (const int *)S.rowlen.p, S.slice_off.p);
+  ISPH_CHECK(sell_finalize_offsets(ctx, S));
+  const int wmax = S.wmax;
+  if (wmax == 0) return ISPH_SUCCESS;
+  const int Ws = wmax | 1;
+  int R = 64;
+  while (R > 1 && (size_t)R * Ws * 24 > 48 * 1024) R >>= 1;
+  ISPH_REQUIRE((size_t)R * Ws * 24 <= 150 * 1024, "row too long for the LDS row sort");
+  const size_t lds = (size_t)R * Ws * 24;
+  ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sell_permute_sort), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sell_permute_sort, dim3(S.nslices), dim3(kBlock), lds, ctx->stream, n, S.nslices, R, Ws, (const int *)O.perm.p,
+                     (const int *)O.iperm.p, (const int *)S0.rowlen.p, (const long long *)S0.slice_off.p, (const int *)S0.col.p,
+                     (const double *)S0.val.p, (const int *)S.rowlen.p, (const long long *)S.slice_off.p, S.col.p, S.val.p);
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;
+}
+
 }  // namespace isph
 
 using namespace isph;
@@ -644,6 +671,40 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, co
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   isph_mat *A = nullptr;
   ISPH_CHECK(mat_from_device_csr(ctx, nrow, ncol, rowptr, colidx, val, (long long)last, &A));
+  *Aout = A;
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_create_csr_coords(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
+                               int dim, const double *x, const double *y, const double *z, isph_mat **Aout) {
+  ISPH_REQUIRE(ctx && Aout && rowptr && colidx && val && x && y, "NULL argument");
+  ISPH_REQUIRE(nrow >= 0 && ncol >= nrow, "need 0 <= nrow <= ncol");
+  ISPH_REQUIRE((dim == 2) || (dim == 3 && z), "dim must be 2, or 3 with z");
+  ISPH_REQUIRE(!is_device_pointer(x) && !is_device_pointer(y) && !is_device_pointer(z), "coordinates must be host arrays");
+  if (nrow == 0) return isph_mat_create_csr(ctx, nrow, ncol, rowptr, colidx, val, 0, Aout);
+  // 1. the row order from the coordinates (0.5 ms at 10^6 rows; the matrix is not needed for it)
+  RowOrderPtr O;
+  {
+    DevTmp<double> soa, aos;
+    ISPH_CHECK(soa.reserve((size_t)3 * nrow));
+    ISPH_CHECK(aos.reserve((size_t)3 * nrow));
+    ISPH_CHECK_HIP(hipMemcpyAsync(soa.p, x, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
+    ISPH_CHECK_HIP(hipMemcpyAsync(soa.p + nrow, y, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
+    if (dim == 3) ISPH_CHECK_HIP(hipMemcpyAsync(soa.p + 2 * (size_t)nrow, z, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_order_soa_to_aos, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, (const double *)soa.p,
+                       (const double *)soa.p + nrow, dim == 3 ? (const double *)soa.p + 2 * (size_t)nrow : (const double *)nullptr, aos.p);
+    ISPH_CHECK(order_build(ctx->stream, dim, nrow, aos.p, O));
+  }
+  // 2. the matrix over the link as it is (the pipelined ingress: conversion hidden behind the copies)
+  isph_mat *A0 = nullptr;
+  ISPH_CHECK(csr_ingress_host(ctx, nrow, ncol, rowptr, colidx, val, &A0));
+  // 3. one pass on the device: rows gathered in the new order, columns renamed, rows sorted
+  isph_mat *A = new isph_mat();
+  int rc = sell_permute(ctx, A0->S, *O, A->S);
+  if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("permutation of the matrix failed", __FILE__, __LINE__);
+  isph_mat_destroy(A0);
+  if (rc != ISPH_SUCCESS) { isph_mat_destroy(A); return rc; }
+  A->order = O;
   *Aout = A;
   return ISPH_SUCCESS;
 }

@@ -94,6 +94,16 @@ inline int perm_grid(long long n) {
 }
 
 // ---- the brick sort ----------------------------------------------------------------------------------------------
+// three coordinate arrays (PrecondWrapper_ML::setCoordinates hands them over like this, precond_ml.h:63-94) -> [n][3]
+__global__ void k_order_soa_to_aos(int n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                   double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[3 * (size_t)i] = x[i];
+  out[3 * (size_t)i + 1] = y[i];
+  out[3 * (size_t)i + 2] = z ? z[i] : 0.0;
+}
+
 // per-workgroup bounding box of x[0..n)[0..3): part[block][0..3) = min, [3..6) = max
 __global__ __launch_bounds__(kBlock) void k_order_bbox(int n, const double *__restrict__ x, double *__restrict__ part) {
   __shared__ double red[kBlock / 64][6];

@@ -257,6 +257,84 @@ __global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int nrow, int nslices
   }
 }
 
+// The same sort fused with a symmetric permutation of the matrix (order.hpp: the library's own row numbering for a
+// matrix that arrived as a host CSR in the caller's atom order): slice s of the result holds the rows perm[64 s ..] of the
+// source, their owned columns renamed through iperm (ghost columns >= nrow keep their number), every row sorted by its
+// new columns.  The load phase gathers from the source rows (12 B per entry wherever they lie), the rest is
+// k_sell_sort_rows; one pass over both matrices instead of a copy and a sort.
+__global__ __launch_bounds__(kBlock) void k_sell_permute_sort(int nrow, int nslices, int R, int Ws,
+                                                              const int *__restrict__ perm, const int *__restrict__ iperm,
+                                                              const int *__restrict__ rowlen0,
+                                                              const long long *__restrict__ slice_off0,
+                                                              const int *__restrict__ scol0, const double *__restrict__ sval0,
+                                                              const int *__restrict__ rowlen,
+                                                              const long long *__restrict__ slice_off,
+                                                              int *__restrict__ scol, double *__restrict__ sval) {
+  extern __shared__ double lds_raw[];
+  __shared__ long long s_off0[kSlice];
+  __shared__ int s_lane0[kSlice], s_len[kSlice];
+  const int slice = blockIdx.x;
+  if (slice >= nslices) return;
+  double *valA = lds_raw;                 // [R][Ws]
+  double *valB = valA + (size_t)R * Ws;   // [R][Ws]
+  int *colA = reinterpret_cast<int *>(valB + (size_t)R * Ws);
+  int *colB = colA + (size_t)R * Ws;
+  const long long off = slice_off[slice];
+  const int w = (int)((slice_off[slice + 1] - off) >> 6);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < kSlice) {
+    const int row = slice * kSlice + threadIdx.x;
+    const int src = row < nrow ? perm[row] : 0;
+    s_off0[threadIdx.x] = slice_off0[src >> 6];
+    s_lane0[threadIdx.x] = src & 63;
+    s_len[threadIdx.x] = row < nrow ? rowlen0[src] : 0;
+  }
+  __syncthreads();
+  for (int r0 = 0; r0 < kSlice; r0 += R) {
+    const int total = R * w;  // w is even
+    for (int e = threadIdx.x; e < total; e += kBlock) {
+      const int kk = e & 1, r = (e >> 1) % R, kp = (e >> 1) / R;
+      const int k = 2 * kp + kk, row = slice * kSlice + r0 + r;
+      int c = row < nrow ? row : 0;        // padding: the row's own column, value 0
+      double v = 0.0;
+      if (k < s_len[r0 + r]) {
+        const long long g0 = sell_pos(s_off0[r0 + r], s_lane0[r0 + r], k);
+        c = scol0[g0];
+        v = sval0[g0];
+        if (c < nrow) c = iperm[c];
+      }
+      colA[r * Ws + k] = c;
+      valA[r * Ws + k] = v;
+    }
+    __syncthreads();
+    for (int r = wave; r < R; r += kBlock / kWave) {
+      const int len = s_len[r0 + r];
+      for (int k = lane; k < w; k += kWave) {
+        int dst = k;  // padding keeps its slot
+        if (k < len) {
+          const int c = colA[r * Ws + k];
+          int rank = 0;
+          for (int q = 0; q < len; ++q) {
+            const int cq = colA[r * Ws + q];
+            rank += (cq < c) || (cq == c && q < k);
+          }
+          dst = rank;
+        }
+        colB[r * Ws + dst] = colA[r * Ws + k];
+        valB[r * Ws + dst] = valA[r * Ws + k];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < total; e += kBlock) {
+      const int kk = e & 1, r = (e >> 1) % R, kp = (e >> 1) / R;
+      const long long g = off + (long long)kp * 128 + (r0 + r) * 2 + kk;
+      scol[g] = colB[r * Ws + 2 * kp + kk];
+      sval[g] = valB[r * Ws + 2 * kp + kk];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- SELL -> CSR (export for tests; unsorted within the row) -------------
 __global__ void k_sell_to_csr(int nrow, const int *__restrict__ rowlen, const long long *__restrict__ slice_off,
                               const int *__restrict__ scol, const double *__restrict__ sval,

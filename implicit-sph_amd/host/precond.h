@@ -28,6 +28,21 @@ class PrecondWrapper {
   // the wrapper's own table of subdomains for that fused set-up (isph_mat_create_csr_blocks), if it has one
   virtual bool fusedIngressSubdomains(int &, const int *&) { return false; }
   void adoptDevice(isph_prec *M) { free(); _M = M; }
+  // Coordinates of the rows, as PrecondWrapper_ML::setCoordinates receives them (ref: precond_ml.h:63-94; borrowed
+  // pointers into the adapter's Epetra_MultiVector, pair_isph.cpp:1290-1303).  When a wrapper has them, SolverLin_HIP
+  // brings the host matrix in through isph_mat_create_csr_coords: the library then numbers the rows itself (bricks of
+  // about 500 particles) instead of keeping LAMMPS' atom order.
+  int _cdim = 0;
+  const double *_cx = nullptr, *_cy = nullptr, *_cz = nullptr;
+  void storeCoordinates(int dim, const double *x, const double *y, const double *z) {
+    const bool ok = x != NULL && y != NULL && (dim == 2 || (dim == 3 && z != NULL));
+    _cdim = ok ? dim : 0; _cx = ok ? x : nullptr; _cy = ok ? y : nullptr; _cz = ok ? z : nullptr;
+  }
+  virtual bool ingressCoordinates(int &dim, const double *&x, const double *&y, const double *&z) {
+    if (_cx == nullptr) return false;
+    dim = _cdim; x = _cx; y = _cy; z = _cz;
+    return true;
+  }
 
  public:
   PrecondWrapper(MPI_Comm comm) : _comm(comm) {}

@@ -44,10 +44,19 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     if (nblocks > 0 && block_ptr != NULL) _bptr.assign(block_ptr, block_ptr + nblocks + 1);
   }
 
+  // Device-side extension with the signature of PrecondWrapper_ML::setCoordinates (ref: precond_ml.h:25,63-94): the
+  // coordinates of the rank's rows (three arrays of NumMyRows doubles, borrowed until the solve; z unused in 2-D).  The
+  // reference hands coordinates to ML only (pair_isph.cpp:1290-1303); an adapter that makes the same three-line call for
+  // this wrapper gets the library's own row numbering for the host matrix: subdomains = compact bricks of about 500
+  // particles, whatever the atom order (on the 100^3 TGV system in create_atoms order 71 iterations instead of 164).
+  // INTEGRATION.md shows the call.  NULL pointers clear them.
+  void setCoordinates(const int dim, double *x, double *y, double *z) { storeCoordinates(dim, x, y, z); }
+
  protected:
   // the throughput path (block-Jacobi ILU(0), overlap 0 inside the rank) can be built during the matrix ingress
   virtual int fusedIngressBlockRows() {
     setParameters(_param.get());
+    if (_cx != nullptr) return 0;  // coordinates: the ingress permutes the matrix first, the set-up follows (createOnDevice)
     const int block = _param->get("isph: block rows", 512);
     if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0) return 0;
     if (tableUsable()) {
@@ -84,9 +93,14 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
   }
   void noticeOnce(int fill, int block, int overlap) {
     if (_comm.MyPID() == 0 && !_warned) {
-      std::printf(">> PrecondWrapper_Ifpack(HIP): block-Jacobi ILU(%d) on %d-row subdomains, overlap 0 (reference: one "
-                  "subdomain per rank, Overlap Level %d); set \"isph: block rows\" = 0 for the reference's decomposition\n",
-                  fill, block, overlap);
+      if (block < 0)
+        std::printf(">> PrecondWrapper_Ifpack(HIP): block-Jacobi ILU(%d) on the library's bricks of about 500 particles (rows "
+                    "numbered by the coordinates of setCoordinates), overlap 0 (reference: one subdomain per rank, Overlap Level %d)\n",
+                    fill, overlap);
+      else
+        std::printf(">> PrecondWrapper_Ifpack(HIP): block-Jacobi ILU(%d) on %d-row subdomains, overlap 0 (reference: one "
+                    "subdomain per rank, Overlap Level %d); set \"isph: block rows\" = 0 for the reference's decomposition\n",
+                    fill, block, overlap);
       _warned = true;
     }
   }
@@ -162,6 +176,14 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
       sp.overlap = block == 0 ? 0 : overlap;    // subdomains inside one rank are extended by schwarz.hpp itself
       sp.combine = (mode == "Zero") ? 1 : 0;
       return isph_prec_create_schwarz(ctx, A, &sp, &_M);
+    }
+    {  // a matrix the library numbered itself (setCoordinates): its bricks are the subdomains
+      long long oi[3] = {0, 0, 0};
+      if (isph_mat_ordering_info(A, oi, NULL) == ISPH_SUCCESS && oi[0] == 1) {
+        noticeOnce(fill, -1, overlap);
+        const std::string kind = "bjacobi-ilu" + std::to_string(fill);
+        return isph_prec_create(ctx, A, kind.c_str(), 0, &_M);
+      }
     }
     // default: the throughput path -- block-Jacobi ILU(fill) on subdomains of `block` rows inside the rank, overlap 0.
     // This is NOT what the reference factors (one subdomain per rank, overlap 1): iteration counts differ (on the 100^3

@@ -36,8 +36,11 @@ class PrecondWrapper_ML : public PrecondWrapper {
     return _param.get();
   }
 
-  // ref: precond_ml.h:62-94 -- coordinates only feed ML's Zoltan repartitioning, which has no device counterpart
-  virtual void setCoordinates(const int, double *, double *, double *) { return; }
+  // ref: precond_ml.h:62-94.  In the reference the coordinates feed ML's Zoltan repartitioning of the coarse rows, which
+  // has no device counterpart; here they let the library number the matrix rows by position (precond.h
+  // ingressCoordinates): the sliced-ELL slices and the Gauss-Seidel blocks of the smoother are then compact in space
+  // whatever LAMMPS' atom order is.  NULL pointers clear them.
+  virtual void setCoordinates(const int dim, double *x, double *y, double *z) { storeCoordinates(dim, x, y, z); }
 
   // ref: precond_ml.h:97-127 -- one pre-computed null-space vector; the smoother becomes the coarse solver
   virtual void setNullVector(double *n) { _null = n; }

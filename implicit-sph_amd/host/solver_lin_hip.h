@@ -87,7 +87,12 @@ class SolverLin_HIP : public SolverLin {
     int nsub = 0;
     const int *subptr = nullptr;
     const bool table = fused > 0 && prec->fusedIngressSubdomains(nsub, subptr);
-    if ((table ? isph_mat_create_csr_blocks(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, nsub, subptr, &A, &Mfused)
+    // a wrapper that was given the coordinates of the rows (setCoordinates): the library numbers the rows itself
+    int cdim = 0;
+    const double *cx = nullptr, *cy = nullptr, *cz = nullptr;
+    const bool ordered = prec != NULL && prec->ingressCoordinates(cdim, cx, cy, cz);
+    if ((ordered ? isph_mat_create_csr_coords(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, cdim, cx, cy, cz, &A)
+         : table ? isph_mat_create_csr_blocks(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, nsub, subptr, &A, &Mfused)
          : fused > 0 ? isph_mat_create_csr_bjacobi(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, fused, &A, &Mfused)
                      : isph_mat_create_csr(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, 0, &A)) != ISPH_SUCCESS)
       return report_failure();

@@ -117,6 +117,16 @@ int isph_mat_create_csr_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *ro
 int isph_mat_create_csr_blocks(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h]*/, const int *colidx /*[h]*/,
                                const double *val /*[h]*/, int nblocks, const int *block_ptr /*[h]*/, isph_mat **A,
                                isph_prec **M);
+/* The same ingress INTO THE LIBRARY'S OWN ROW NUMBERING (isph_ctx_set_ordering), for the drop-in path, where the matrix
+ * arrives assembled in LAMMPS' atom order and no particle array comes with it: the caller hands over the coordinates of
+ * its rows the way PrecondWrapper_ML::setCoordinates receives them (ref: precond_ml.h:63-94 -- three host arrays of nrow
+ * doubles cut from atom->x, pair_isph.cpp:1290-1303; z may be NULL when dim == 2).  The rows are sorted into the bricks
+ * of order.hpp from the coordinates, the matrix crosses the link as it is and is permuted on the device in one pass
+ * (rows, owned columns, column order inside the rows).  The result behaves like a matrix from isph_assemble_poisson:
+ * every vector at this boundary stays in the caller's numbering, isph_prec_create(.., block_size 0) uses the bricks. */
+int isph_mat_create_csr_coords(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h]*/, const int *colidx /*[h]*/,
+                               const double *val /*[h]*/, int dim, const double *x /*[h]*/, const double *y /*[h]*/,
+                               const double *z /*[h]*/, isph_mat **A);
 /* Diagnostics of the last host-side ingress on this context (milliseconds since its start):
  * [0] staging threads started, device buffers reserved  [1] all chunks queued on the copy stream
  * [2] copy stream drained  [3] compute stream drained (conversion + fused set-up)  [4] end

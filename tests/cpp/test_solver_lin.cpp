@@ -295,6 +295,19 @@ static int run(int argc, char **argv) {
     prec_ifpack.setSubdomains((int)subptr.size() - 1, subptr.data());
   }
 
+  // argv[7] = file with the coordinates of the rows, three arrays of n doubles (x, y, z) one after the other: the adapter's
+  // three-line call of INTEGRATION.md, PrecondWrapper_Ifpack::setCoordinates / PrecondWrapper_ML::setCoordinates
+  // (pair_isph.cpp:1290-1303 makes it for ML) -- the library then numbers the rows itself
+  std::vector<double> coords;
+  if (argc > 7 && std::string(argv[7]) != "-") {
+    FILE *fc = std::fopen(argv[7], "rb");
+    coords.resize((size_t)3 * n);
+    if (!fc || std::fread(coords.data(), 8, coords.size(), fc) != coords.size()) { std::fprintf(stderr, "cannot read the coordinates\n"); return 2; }
+    std::fclose(fc);
+    if (use_ml) prec_ml.setCoordinates(3, coords.data(), coords.data() + n, coords.data() + 2 * (size_t)n);
+    else prec_ifpack.setCoordinates(3, coords.data(), coords.data() + n, coords.data() + 2 * (size_t)n);
+  }
+
   SolverLin_Belos li_solver(world);
   li_solver.setParameters();
   Teuchos::ParameterList cgp;

@@ -259,3 +259,66 @@ def test_clustered_cloud_splits_over_full_bricks(octx):
     xo[o["perm"]] = xoi
     assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
     M.close(); A.close()
+
+
+def test_host_csr_with_coordinates_gets_the_librarys_numbering(octx, gpu_ctx):
+    """isph_mat_create_csr_coords: the drop-in path.  The host CSR in the caller's atom order + the coordinates of its rows
+    (what PrecondWrapper_ML::setCoordinates receives, precond_ml.h:63-94) give the matrix the device assembly builds from
+    the particles: same permutation, same subdomain table, export in the caller's numbering bit for bit, and the solve of
+    the oracle on the permuted system -- for a lexicographic and a shuffled atom order."""
+    spec = tgv_spec(dim=3, n=20, mode=workload.JITTER)
+    for name, parts in _three_orders(spec)[1:]:
+        P, (rp, ci, val, b) = _oracle_system(parts, spec)
+        nl = parts["nlocal"]
+        A = hip.Matrix.from_host_csr_with_coords(gpu_ctx, rp, ci, val, parts["x"][:nl])   # any context: the call asks for it
+        Ad, _ = _assemble(octx, parts, spec, P)
+        o, od = A.ordering(), Ad.ordering()
+        assert o is not None and np.array_equal(o["perm"], od["perm"]) and np.array_equal(o["block_ptr"], od["block_ptr"]), name
+        rp2, ci2, v2 = A.export_csr()
+        assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2, val), name
+        xv = np.random.default_rng(3).standard_normal(nl)
+        yo = sps.csr_matrix((val, ci, rp), shape=(nl, nl)) @ xv
+        assert np.max(np.abs(A.spmv(xv) - yo)) <= 1e-12 * np.abs(yo).max(), name
+        M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 0)
+        rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
+        ref = orc.ILU(rpi, cii, vi, 0, o["block_ptr"])
+        xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, prec="ilu", ilu=ref)
+        bb, xg = b.copy(), np.zeros(nl)
+        info = hip.solve(gpu_ctx, A, bb, xg, prec=M, singular=True)
+        xo = np.empty(nl)
+        xo[o["perm"]] = xoi
+        assert info.converged == 1 and abs(info.iters - io.iters) <= 1, (name, info.iters, io.iters)
+        assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6, name
+        M.close(); A.close(); Ad.close()
+
+
+def test_cpp_mirror_with_coordinates(gpu_ctx, tmp_path):
+    """PrecondWrapper_Ifpack::setCoordinates through SolverLin_Belos::solveProblem (tests/cpp/test_solver_lin.cpp, the
+    adapter's three-line call of INTEGRATION.md): a shuffled atom order solves in the iterations of the library's bricks
+    (the oracle on the permuted system), not in those of 512 consecutive rows of the atom order."""
+    import subprocess
+    from isph_amd import build
+    spec = tgv_spec(dim=3, n=20, mode=workload.JITTER)
+    name, parts = _three_orders(spec)[2]
+    P, (rp, ci, val, b) = _oracle_system(parts, spec)
+    nl = parts["nlocal"]
+    exe = build.build_cpp_test()
+    fin, fout, fc = tmp_path / "sys.bin", tmp_path / "x.bin", tmp_path / "coords.bin"
+    with open(fin, "wb") as f:
+        np.array([nl, len(val)], np.int32).tofile(f)
+        rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f); val.tofile(f); b.tofile(f)
+    np.ascontiguousarray(parts["x"][:nl].T).tofile(fc)
+    r = subprocess.run([exe, str(fin), str(fout), "1", "timed", "2", "0", str(fc)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    x = np.fromfile(fout)[:nl]
+    A = hip.Matrix.from_host_csr_with_coords(gpu_ctx, rp, ci, val, parts["x"][:nl])
+    o = A.ordering()
+    A.close()
+    rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
+    xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, prec="ilu", ilu=orc.ILU(rpi, cii, vi, 0, o["block_ptr"]))
+    xo = np.empty(nl)
+    xo[o["perm"]] = xoi
+    its = [int(t.split(":")[1].split(",")[0]) for t in r.stdout.split('"iterations"')[1:2]]
+    assert abs(its[0] - io.iters) <= 1, (its, io.iters)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    assert "library's bricks" in r.stdout
