@@ -73,21 +73,26 @@ constexpr int kNeighSortCap = 1024;
 template <class OFF>
 __global__ __launch_bounds__(kBlock) void k_neigh_sort(int n, const OFF *__restrict__ nptr, const int *__restrict__ nidx_in,
                                                        const int *__restrict__ colmap, int *__restrict__ out,
-                                                       const int *__restrict__ rowsrc, const int *__restrict__ idmap) {
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[kBlock / 64][kNeighSortCap + 2];
+                                                       const int *__restrict__ rowsrc, const int *__restrict__ idmap,
+                                                       int stride) {
+  // keys of kBlock / 64 rows, `stride` (even, >= longest row + 2) per row: sized by the launch for the lists at hand -- a
+  // fixed buffer for the longest row the kernel can take (1024 neighbours) left five workgroups per CU in flight for
+  // rows of ~100 neighbours, whose time is the latency of their gathers
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys_dyn[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kBlock / 64) + wave;
   if (row >= n) return;
   const int srow = rowsrc ? rowsrc[row] : row;
   const OFF jb = nptr[srow];
   const int len = (int)(nptr[srow + 1] - jb);
-  unsigned long long *kw = keys[wave];
-  // the list entries in the numbering of the layout (the output keeps the offsets of the source row)
+  unsigned long long *kw = keys_dyn + (size_t)wave * stride;
+  // the list entries in the numbering of the layout (the output keeps the offsets of the source row); with idmap the
+  // column map is indexed by the CALLER's particle (one gather per key, the renamed entry is only needed for the store)
   struct Ids {
     const int *p, *m;
     __device__ __forceinline__ int operator[](long long k) const { const int j = p[k]; return m ? m[j] : j; }
   } nidx{nidx_in, idmap};
-  for (int k = lane; k < len; k += 64) kw[k] = ((unsigned long long)(unsigned)colmap[nidx[jb + k]] << 10) | (unsigned)k;
+  for (int k = lane; k < len; k += 64) kw[k] = ((unsigned long long)(unsigned)colmap[nidx_in[jb + k]] << 10) | (unsigned)k;
   if (lane < 2) kw[len + lane] = ~0ull;  // pad: the pair reads below may run one key past the end
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -520,6 +525,27 @@ __global__ void k_asm_count(AsmTables T, int nlocal, const double *__restrict__ 
 // the row modifySingularMatrix touches is the first fluid particle in the CALLER's atom order (pair_isph.cpp:493-520):
 // with the library's own row numbering (rowsrc = internal row -> caller's row) the minimum is taken over the caller's
 // indices and translated back afterwards
+// the same count from the packed particle records of the row kernels (one 32-B load per neighbour instead of three
+// 8-B loads of x and one of type); the arithmetic of r^2 is the fill kernel's (rsq_nofma on copies of the same numbers)
+__global__ void k_asm_count_packed(AsmTables T, int nlocal, const double4 *__restrict__ r1, const int2 *__restrict__ r3,
+                                   int *__restrict__ rowlen) {
+  const int i = xcd_block() * blockDim.x + threadIdx.x;
+  if (i >= nlocal) return;
+  const int nt1 = T.ntypes + 1, it = r3[i].x;
+  const double4 qi = r1[i];
+  const double xi[3] = {qi.x, qi.y, qi.z};
+  int cnt = 1;
+  for (int jj = 0, nn_i = T.nlen[i]; jj < nn_i; ++jj) {
+    const int j = neigh_at(T, i, jj);
+    const double4 qj = r1[j];
+    const double xj[3] = {qj.x, qj.y, qj.z};
+    double rij[3];
+    const double rsq = rsq_nofma(T.dim, xi, xj, rij);
+    if (rsq < T.cutsq[it * nt1 + r3[j].x]) ++cnt;
+  }
+  rowlen[i] = cnt;
+}
+
 __global__ void k_first_fluid(int nlocal, const int *__restrict__ type, const int *__restrict__ kind, int *first,
                               const int *__restrict__ rowsrc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -544,10 +570,13 @@ struct PoissonArgs {
 __global__ void k_pack_particles(int nall, const double *__restrict__ x, const double *__restrict__ vfrac,
                                  const double *__restrict__ invrho, const double *__restrict__ vstar,
                                  const int *__restrict__ type, const int *__restrict__ colmap, double4 *__restrict__ r1,
-                                 double4 *__restrict__ r2, int2 *__restrict__ r3) {
+                                 double4 *__restrict__ r2, int2 *__restrict__ r3, int root_of_volume) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nall) return;
-  r1[j] = make_double4(x[3 * (size_t)j], x[3 * (size_t)j + 1], x[3 * (size_t)j + 2], vfrac[j]);
+  // root_of_volume (the 3-D AntiSymmetric instantiation): the pair volume sqrt(V_i V_j) is formed as sqrt(V_i) sqrt(V_j)
+  // from per-particle roots -- one square root per particle instead of one per pair and sweep (2 x 10^8 at 100^3); the
+  // product differs from the reference's sqrt(V_i V_j) (functor_laplacian_matrix.h:156) in the last bit at most
+  r1[j] = make_double4(x[3 * (size_t)j], x[3 * (size_t)j + 1], x[3 * (size_t)j + 2], root_of_volume ? sqrt(vfrac[j]) : vfrac[j]);
   r2[j] = make_double4(invrho[j], vstar[3 * (size_t)j], vstar[3 * (size_t)j + 1], vstar[3 * (size_t)j + 2]);
   r3[j] = make_int2(type[j], colmap[j]);
 }
@@ -637,6 +666,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       for (int k = 0; k < dL; ++k) L[k] = a.Lc[(size_t)i * dL + k];
     }
     const double vi = a.vfrac[i];
+    const double svi = sqrt(vi);
     double grad_m[3] = {0, 0, 0}, ci[3] = {0, 0, 0};
     double diag1 = 0.0, div = 0.0;
     // ---- sweep 1: grad m_i, c_i, diag, divergence (:127-201, functor_divergence.h:79-117)
@@ -661,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
       for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
-      const double vfrac = antisym ? sqrt(vi * q1.w) : q1.w;
+      const double vfrac = FAM == 1 ? svi * q1.w : (antisym ? sqrt(vi * q1.w) : q1.w);  // FAM == 1: r1.w holds sqrt(V_j)
       const double vjtmp = dwdr * vfrac;
       for (int k2 = 0; k2 < dim; ++k2) {
         double gitmp = 0.0;
@@ -714,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_poisson(AsmTables T, PoissonArgs
       const double dwdr = kernel_dval(T.kernel, r, T.hinv[it * nt1 + jt], T.kdnorm[it * nt1 + jt]);
       double e[3] = {0, 0, 0};
       for (int k = 0; k < dim; ++k) e[k] = rij[k] * rinv;
-      const double vfrac = antisym ? sqrt(vi * q1.w) : q1.w;
+      const double vfrac = FAM == 1 ? svi * q1.w : (antisym ? sqrt(vi * q1.w) : q1.w);  // FAM == 1: r1.w holds sqrt(V_j)
       const double vjtmp = dwdr * vfrac;
       double aij = 0.0;
       if (antisym) {  // L = I: only the squares survive, summed in the same order
@@ -1061,6 +1091,28 @@ __global__ void k_sell_merge_duplicates(int nrow, const int *__restrict__ rowlen
   newlen[row] = out;
 }
 
+// nnz = sum of the row lengths, reduced on the device (the 4 MB copy of a million row lengths and the host loop over
+// them cost 0.4 ms per assembly)
+__global__ __launch_bounds__(kBlock) void k_sum_rowlen(int n, const int *__restrict__ len, unsigned long long *__restrict__ out) {
+  unsigned long long s = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += (unsigned long long)len[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+inline int sell_sum_rowlen(isph_ctx *ctx, const Sell &S, long long *nnz) {
+  DevTmp<unsigned long long> acc;
+  ISPH_CHECK(acc.reserve(1));
+  ISPH_CHECK_HIP(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), ctx->stream));
+  if (S.nrow > 0)
+    hipLaunchKernelGGL(k_sum_rowlen, dim3(std::min(256, (S.nrow + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, S.nrow,
+                       (const int *)S.rowlen.p, acc.p);
+  unsigned long long h = 0;
+  ISPH_CHECK_HIP(hipMemcpyAsync(&h, acc.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  *nnz = (long long)h;
+  return ISPH_SUCCESS;
+}
+
 struct StagedParticles {
   DevBuf<double> x, vfrac, Gc, Lc, h, cutsq, rho, vstar, pnd, hinv, knorm, kdnorm, invrho, normal;
   DevBuf<int> type, kind, nptr, nidx, colmap, first;
@@ -1131,8 +1183,19 @@ inline int build_neigh_ell_t(isph_ctx *ctx, int n, const OFF *dnptr, const int *
     for (int s = 0; s < nslices; ++s) wmax = std::max(wmax, (so[(size_t)s + 1] - so[(size_t)s]) >> 6);
     if (wmax <= kNeighSortCap) {
       ISPH_CHECK(E.sorted.reserve((size_t)(total > 0 ? total : 1)));
-      hipLaunchKernelGGL(k_neigh_sort<OFF>, dim3((n + 3) / 4), dim3(kBlock), 0, ctx->stream, n, dnptr, dnidx, dcolmap, E.sorted.p,
-                         rowsrc, idmap);
+      // with the library's own numbering the keys come from the column map indexed by the caller's particle
+      const int *keymap = ctx->nmap.order ? ctx->nmap.colkey : dcolmap;
+      long long need = wmax + 2;  // two pad keys behind the longest row (pair reads of the rank loop)
+      if (wmax > 128) {           // long rows go through a bitonic network over the next power of two (>= 256)
+        long long p2 = 256;
+        while (p2 < wmax) p2 <<= 1;
+        need = std::max(need, p2);
+      }
+      const int stride = (int)((need + 1) & ~1LL);
+      const size_t lds = sizeof(unsigned long long) * (size_t)stride * (kBlock / 64);
+      ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_neigh_sort<OFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_neigh_sort<OFF>, dim3((n + 3) / 4), dim3(kBlock), lds, ctx->stream, n, dnptr, dnidx, keymap, E.sorted.p,
+                         rowsrc, idmap, stride);
       dnidx = E.sorted.p;
       idmap = nullptr;  // the sorted copy holds mapped entries already
       T.sorted = 1;
@@ -1320,19 +1383,28 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
   if (rc == ISPH_SUCCESS && !on_device) { rc = bdev.reserve((size_t)(n > 0 ? n : 1)); db = bdev.p; }
   if (rc == ISPH_SUCCESS && n > 0) {
     const int grid = (n + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_asm_count, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, a.x, a.type, a.nptr, a.nidx, M.rowlen.p);
-    hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
-    rc = sell_finalize_offsets(ctx, M);
+    // the particle records of the row kernels first: the row-length count reads them too
+    DevBuf<double4> pk1, pk2;
+    DevBuf<int2> pk3;
+    struct PackRelease { DevBuf<double4> &a, &b; DevBuf<int2> &c; ~PackRelease() { a.release(); b.release(); c.release(); } } pack_release{pk1, pk2, pk3};
+    a.nlocal = n; a.antisym = antisym; a.singular_mode = singular_mode; a.dt = dt;
+    a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
+    a.solid_normal_diag = P->solid_normal_diag;
+    rc = S.invrho.reserve((size_t)P->nall);
+    if (rc == ISPH_SUCCESS) rc = pk1.reserve((size_t)P->nall);
+    if (rc == ISPH_SUCCESS) rc = pk2.reserve((size_t)P->nall);
+    if (rc == ISPH_SUCCESS) rc = pk3.reserve((size_t)P->nall);
     if (rc == ISPH_SUCCESS) {
-      a.nlocal = n; a.antisym = antisym; a.singular_mode = singular_mode; a.dt = dt;
-      a.morris = P->morris_holmes ? 1 : 0; a.safe = P->morris_safe_coeff;
-      a.solid_normal_diag = P->solid_normal_diag;
-      rc = S.invrho.reserve((size_t)P->nall);
-      if (rc == ISPH_SUCCESS) {
-        hipLaunchKernelGGL(k_reciprocal, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall, a.rho,
-                           S.invrho.p);
-        a.invrho = S.invrho.p;
-      }
+      hipLaunchKernelGGL(k_reciprocal, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall, a.rho,
+                         S.invrho.p);
+      a.invrho = S.invrho.p;
+      hipLaunchKernelGGL(k_pack_particles, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall, a.x,
+                         a.vfrac, a.invrho, a.vstar, a.type, a.colmap, pk1.p, pk2.p, pk3.p, (T.dim == 3 && a.antisym) ? 1 : 0);
+      a.r1 = pk1.p; a.r2 = pk2.p; a.r3 = pk3.p;
+      hipLaunchKernelGGL(k_asm_count_packed, dim3(xcd_grid(grid)), dim3(kBlock), 0, ctx->stream, T, n, (const double4 *)pk1.p,
+                         (const int2 *)pk3.p, M.rowlen.p);
+      hipLaunchKernelGGL(k_slicew_from_rowlen, dim3(grid), dim3(kBlock), 0, ctx->stream, n, M.rowlen.p, M.slice_off.p);
+      rc = sell_finalize_offsets(ctx, M);
     }
     if (rc == ISPH_SUCCESS) {
       a.pin_enabled = (is_rank0 && singular_mode >= 2) ? 1 : 0;
@@ -1350,17 +1422,6 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
         a.first_fluid = S.first.p;
       }
     }
-    DevBuf<double4> pk1, pk2;
-    DevBuf<int2> pk3;
-    if (rc == ISPH_SUCCESS) rc = pk1.reserve((size_t)P->nall);
-    if (rc == ISPH_SUCCESS) rc = pk2.reserve((size_t)P->nall);
-    if (rc == ISPH_SUCCESS) rc = pk3.reserve((size_t)P->nall);
-    if (rc == ISPH_SUCCESS) {
-      hipLaunchKernelGGL(k_pack_particles, dim3((P->nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P->nall, a.x,
-                         a.vfrac, a.invrho, a.vstar, a.type, a.colmap, pk1.p, pk2.p, pk3.p);
-      a.r1 = pk1.p; a.r2 = pk2.p; a.r3 = pk3.p;
-    }
-    struct PackRelease { DevBuf<double4> &a, &b; DevBuf<int2> &c; ~PackRelease() { a.release(); b.release(); c.release(); } } pack_release{pk1, pk2, pk3};
     if (rc == ISPH_SUCCESS) {
       const int gridp = M.nslices * kSlice / kBlock + ((M.nslices * kSlice) % kBlock ? 1 : 0);
       if (T.dim == 3 && a.antisym)
@@ -1387,13 +1448,7 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
         rc = fail("assembly kernel failed", __FILE__, __LINE__);
     }
     if (rc == ISPH_SUCCESS) {
-      // nnz = sum of row lengths (after merge)
-      std::vector<int> len((size_t)n);
-      if (hipMemcpy(len.data(), M.rowlen.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail("copy failed", __FILE__, __LINE__);
-      long long s = 0;
-      for (int v : len) s += v;
-      M.nnz = s;
+      rc = sell_sum_rowlen(ctx, M, &M.nnz);  // nnz = sum of row lengths (after merge)
     }
   }
   S.release();
@@ -1534,12 +1589,7 @@ inline int assemble_helmholtz(isph_ctx *ctx, const isph_particles *P, int antisy
         rc = fail("assembly kernel failed", __FILE__, __LINE__);
     }
     if (rc == ISPH_SUCCESS && !rhs_only) {
-      std::vector<int> len((size_t)n);
-      if (hipMemcpy(len.data(), M.rowlen.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail("copy failed", __FILE__, __LINE__);
-      long long tot = 0;
-      for (int v : len) tot += v;
-      M.nnz = tot;
+      rc = sell_sum_rowlen(ctx, M, &M.nnz);
     }
   }
   S.release(); E.release(); snu.release(); sp.release(); sf.release(); sv.release();

@@ -408,11 +408,8 @@ inline int assemble_block_helmholtz(isph_ctx *ctx, const isph_particles *P, int 
         rc = fail("block assembly kernel failed", __FILE__, __LINE__);
     }
     if (rc == ISPH_SUCCESS) {
-      std::vector<int> len((size_t)n);
-      if (hipMemcpy(len.data(), A0->S.rowlen.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail("copy failed", __FILE__, __LINE__);
       long long tot = 0;
-      for (int v : len) tot += v;
+      rc = sell_sum_rowlen(ctx, A0->S, &tot);
       for (int q = 0; q < d2; ++q)
         if (blk[q]) blk[q]->S.nnz = tot;
     }

@@ -22,6 +22,7 @@ struct isph_neigh_layout {
 // duration of one call: the list rows are read through rowsrc, the entries through idmap (order.hpp).
 struct isph_neigh_map {
   const int *rowsrc = nullptr, *idmap = nullptr, *colmap_key = nullptr;
+  const int *colkey = nullptr;  // internal matrix column of the CALLER's particle j (sort key of its list entries)
   const void *order = nullptr;
 };
 

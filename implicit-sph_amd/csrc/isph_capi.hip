@@ -202,13 +202,13 @@ struct OrderedAssembly {
   RowOrderPtr O;
   isph_particles Q;
   std::vector<DevBuf<char> *> bufs;
-  DevBuf<int> idmap, colmap;
+  DevBuf<int> idmap, colmap, colkey;
   OrderedAssembly(isph_ctx *c, const isph_particles *p, int dev) : ctx(c), P(p), on_device(dev) { Q = *p; }
   OrderedAssembly(const OrderedAssembly &) = delete;
   ~OrderedAssembly() {
     ctx->nmap = isph_neigh_map();
     for (DevBuf<char> *b : bufs) { b->release(); delete b; }
-    idmap.release(); colmap.release();
+    idmap.release(); colmap.release(); colkey.release();
   }
   template <class T>
   int alloc(size_t count, T **out) {
@@ -295,7 +295,9 @@ struct OrderedAssembly {
     ISPH_CHECK(on_dev(P->colmap, (size_t)nall, &dcm));
     ISPH_CHECK(colmap.reserve((size_t)(nall > 0 ? nall : 1)));
     ISPH_CHECK(idmap.reserve((size_t)(nall > 0 ? nall : 1)));
+    ISPH_CHECK(colkey.reserve((size_t)(nall > 0 ? nall : 1)));
     if (nall > 0) {
+      hipLaunchKernelGGL(k_perm_colkey, dim3((nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nall, n, iperm, dcm, colkey.p);
       hipLaunchKernelGGL(k_perm_colmap, dim3((nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nall, n, perm, iperm, dcm, colmap.p);
       hipLaunchKernelGGL(k_perm_idmap, dim3((nall + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nall, n, iperm, idmap.p);
     }
@@ -303,6 +305,7 @@ struct OrderedAssembly {
     ctx->nmap.rowsrc = perm;
     ctx->nmap.idmap = idmap.p;
     ctx->nmap.colmap_key = P->colmap;
+    ctx->nmap.colkey = colkey.p;
     ctx->nmap.order = O.get();
     ISPH_CHECK_HIP(hipGetLastError());
     return ISPH_SUCCESS;

@@ -76,6 +76,13 @@ __global__ void k_perm_colmap(int nall, int nlocal, const int *__restrict__ perm
   const int c = colmap[r < nlocal ? perm[r] : r];
   out[r] = c < nlocal ? iperm[c] : c;
 }
+// the same indexed by the CALLER's particle j: the sort key of a neighbour-list entry without going through idmap first
+__global__ void k_perm_colkey(int nall, int nlocal, const int *__restrict__ iperm, const int *__restrict__ colmap, int *__restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nall) return;
+  const int c = colmap[j];
+  out[j] = c < nlocal ? iperm[c] : c;
+}
 // the particle index map of the neighbour lists: owned j -> iperm[j], ghosts keep their index
 __global__ void k_perm_idmap(int nall, int nlocal, const int *__restrict__ iperm, int *__restrict__ idmap) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
