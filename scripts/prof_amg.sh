@@ -4,7 +4,7 @@ set -o pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_amg -- python3 $GRAFT_REPO_ROOT/bench.py --prec sa-amg --steps 3 --warmup 1 --no-cpu-baseline --no-dropin --no-alt > $OUT/prof_amg.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_amg -- python3 $GRAFT_REPO_ROOT/bench.py --prec sa-amg --steps 3 --warmup 1 --no-cpu-baseline --no-dropin --no-alt --no-orders --no-step > $OUT/prof_amg.log 2>&1 || exit 1
 F=$(ls $OUT/prof_amg/*/*kernel_stats.csv | head -1)
 python3 - "$F" <<'PY' > $OUT/prof_amg_summary.txt
 import csv, sys
