@@ -859,6 +859,11 @@ __global__ __launch_bounds__(WAVES * 64, WIDE ? 1 : 8) void k_ilu_factor(int n, 
   int *mc = wcol + wave * W;
   unsigned short *mp = pos + wave * B;
   const int nlev = s_nlev;
+  // first entry of the block's factor region (its rows lie back to back from there), as a wave-uniform value
+  const long long rp_block = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rpL[0] >> 32)) << 32) |
+                                         (unsigned)__builtin_amdgcn_readfirstlane((int)rpL[0]));
+  const int *__restrict__ fcol_b = fcol + rp_block;
+  const double *__restrict__ fval_b = fval + rp_block;
   for (int l = 0; l < nlev; ++l) {
     for (int q = lstart[l] + wave; q < lstart[l + 1]; q += WAVES) {
       const int r = order[q];
@@ -905,17 +910,20 @@ __global__ __launch_bounds__(WAVES * 64, WIDE ? 1 : 8) void k_ilu_factor(int n, 
       // in the ISA where vmcnt(2 (kPF - 1)) belongs -- and the queue drains.  The other rows take the plain loop below.
       const bool narrow_row = !WIDE && dg <= 64 && __ballot(lane < dg && pcnt > 64) == 0;   // wave-uniform
       if (narrow_row) {
+        // the loads of a request are addressed as (uniform base of the block's factor region) + (32-bit offset): the
+        // region of a block holds some 10^4 entries, and a 64-bit position per lane cost six vector instructions per
+        // request where two do (r5: the kernel issues vector instructions 68 % of the time, profiles/r05_pmc_ilu_setup.txt)
+        const unsigned prel = (unsigned)(pbase - rp_block);   // this lane's pivot row, relative to the block's first entry
+        const unsigned rprel = (unsigned)(rp - rp_block);
         auto request1 = [&](int s, int &pc, double &pvv, double &pdv, int &pn) {
           const int sl = s < dg ? s : 0;   // (dg >= 1 here: the loop below does not run otherwise)
-          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)pbase, sl);
-          const int hi = __builtin_amdgcn_readlane((int)(pbase >> 32), sl);
-          const long long p0 = (long long)(((unsigned long long)(unsigned)hi << 32) | lo);
+          const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)prel, sl);
           const int cnt = s < dg ? __builtin_amdgcn_readlane(pcnt, sl) : 0;
           pdv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pdk), sl), __builtin_amdgcn_readlane(__double2loint(pdk), sl));
           pn = cnt;
-          const long long p = lane < cnt ? p0 + lane : rp;
-          pc = fcol[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
-          pvv = fval[p];
+          const unsigned p = lane < cnt ? p0 + (unsigned)lane : rprel;
+          pc = fcol_b[p];  // raw column: no arithmetic on the loaded value here, or the wait moves up to the request
+          pvv = fval_b[p];
         };
         if (dg > 0) {
 #pragma unroll
