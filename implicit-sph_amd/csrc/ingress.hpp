@@ -146,6 +146,20 @@ inline int stager_get(isph_ctx *ctx, HostStager **out) {
 
 int sell_sort_rows(isph_ctx *ctx, Sell &S);  // isph_capi.hip
 
+// The host CSR in ANOTHER ROW ORDER than it lies in memory (the library's own numbering for the drop-in with coordinates,
+// order.hpp): the `rowptr` csr_ingress_host is given is then the row pointer of the PERMUTED matrix, row r of which is
+// row perm[r] of the caller's arrays (src_rowptr = the caller's own row pointers); the staging threads gather the row
+// segments (1.2 KB each on the bench matrix) instead of copying one flat range, the columns travel in the caller's
+// numbering (16-bit differences still work: they are taken inside a source row) and the conversion kernel renames the
+// owned ones (colren, a DEVICE array: the caller's row -> its new number).  The rows arrive unsorted by their new
+// columns: the `slices` hook sorts each converted range before anything else looks at it.
+struct IngressGather {
+  const int *perm = nullptr;        // host [nrow]
+  const int *src_rowptr = nullptr;  // host [nrow + 1]
+  const int *colren = nullptr;      // device [nren]
+  int nren = 0;
+};
+
 struct IngressHooks {
   // the matrix has its shape, its buffers and (stream-ordered) its slice offsets and row lengths; no entries yet
   std::function<int(isph_mat *)> begin;
@@ -156,7 +170,8 @@ struct IngressHooks {
 // host CSR -> isph_mat.  The caller's arrays are only read while this function runs.  was_unsorted: the rows had to be
 // column-sorted after the conversion (what the hooks queued for the unsorted image is then void).
 inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
-                            isph_mat **Aout, const IngressHooks *hooks = nullptr, bool *was_unsorted = nullptr) {
+                            isph_mat **Aout, const IngressHooks *hooks = nullptr, bool *was_unsorted = nullptr,
+                            const IngressGather *gat = nullptr) {
   ISPH_REQUIRE(!is_device_pointer(rowptr) && !is_device_pointer(colidx) && !is_device_pointer(val),
                "device pointer passed with on_device = 0");
   ISPH_REQUIRE(rowptr[0] == 0 && rowptr[nrow] >= 0, "rowptr must start at 0 (Epetra's ExtractCrsDataPointers does) and be monotone");
@@ -236,7 +251,39 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
       auto cut = [&](int k) { return k >= P ? p1 : std::min(p1, p0 + (((long long)cnt * k / P) & ~31LL)); };
       const long long q_lo = cut(part), q_hi = cut(part + 1);
       unsigned over = 0;
-      if (q_hi > q_lo) {
+      if (q_hi > q_lo && gat) {
+        // gathered rows: the part's entries are the segments [max(rowptr[r], q_lo), min(rowptr[r + 1], q_hi)) of the permuted
+        // rows r, each a contiguous piece of source row perm[r]
+        int r = (int)(std::upper_bound(rowptr, rowptr + nrow + 1, (int)q_lo) - rowptr) - 1;
+        unsigned nw = 0, ov = 0;
+        unsigned short *d16 = reinterpret_cast<unsigned short *>(base + 8 * cnt);
+        int *dc32 = reinterpret_cast<int *>(base + 8 * cnt);
+        for (; r < nrow && (long long)rowptr[r] < q_hi; ++r) {
+          const long long a = std::max<long long>(rowptr[r], q_lo), b = std::min<long long>(rowptr[r + 1], q_hi);
+          if (b <= a) continue;
+          const long long sq = (long long)gat->src_rowptr[gat->perm[r]] + (a - rowptr[r]);
+          const size_t m = (size_t)(b - a);
+          stage_copy(base + 8 * (size_t)(a - p0), val + sq, sizeof(double) * m);
+          const int *src = colidx + sq;
+          if (try16) {
+            unsigned short *dst = d16 + (a - p0);
+            size_t k0 = 0;
+            if (a == (long long)rowptr[r]) { dst[0] = 0; ov |= (unsigned)((unsigned)src[0] >= (unsigned)ncol); k0 = 1; }  // row start: its column travels in the table
+            for (size_t k = k0; k < m; ++k) {
+              const int cc = src[k];
+              const unsigned diff = (unsigned)(cc - src[(ptrdiff_t)k - 1]);   // the previous entry of the same source row
+              nw += diff > 65535u;
+              ov |= (unsigned)((unsigned)cc >= (unsigned)ncol);
+              dst[k] = (unsigned short)diff;
+            }
+          } else {
+            int *dc = dc32 + (a - p0);
+            for (size_t k = 0; k < m; ++k) { const int cc = src[k]; ov |= (unsigned)((unsigned)cc >= (unsigned)ncol); dc[k] = cc; }
+          }
+        }
+        over |= ov;
+        if (try16) nwide_sum[(size_t)c].fetch_add((long long)nw);
+      } else if (q_hi > q_lo) {
         stage_copy(base + 8 * (size_t)(q_lo - p0), val + q_lo, sizeof(double) * (size_t)(q_hi - q_lo));
         if (try16) {
           // flat pass (vectorises, runs at copy speed): range check and the 16-bit difference to the previous entry, row
@@ -283,15 +330,23 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
         long long nwide = nwide_sum[(size_t)c].load();
         for (int r = r0; r < r1; ++r) {
           const long long rs = rowptr[r];
-          rowfirst[r - r0] = rs < nnz ? colidx[rs] : 0;  // (rows without entries: never read)
+          const long long rsrc = gat ? (long long)gat->src_rowptr[gat->perm[r]] : rs;   // where the row starts in the caller's arrays
+          rowfirst[r - r0] = rs < nnz ? colidx[rsrc] : 0;  // (rows without entries: never read)
           if (rowptr[r + 1] == rs) continue;
           d16[rs - p0] = 0;
-          if (rs > 0 && (unsigned)(colidx[rs] - colidx[rs - 1]) > 65535u) --nwide;
+          if (!gat && rs > 0 && (unsigned)(colidx[rs] - colidx[rs - 1]) > 65535u) --nwide;   // (the gathered pass does not count row starts)
         }
         if (nwide > 0) {  // not this chunk: its columns once more, plain (this thread alone; rare after chunk 0)
           pack16 = false;
           int *dc = reinterpret_cast<int *>(base + 8 * cnt);
-          if (stage_have_avx2() && ncol > 0) (void)stage_cols_avx2(dc, colidx + p0, cnt, (unsigned)ncol);
+          if (gat) {
+            int r = (int)(std::upper_bound(rowptr, rowptr + nrow + 1, (int)p0) - rowptr) - 1;
+            for (; r < nrow && (long long)rowptr[r] < p1; ++r) {
+              const long long a = std::max<long long>(rowptr[r], p0), b = std::min<long long>(rowptr[r + 1], p1);
+              const long long sq = (long long)gat->src_rowptr[gat->perm[r]] + (a - rowptr[r]);
+              for (long long k = 0; k < b - a; ++k) dc[a - p0 + k] = colidx[sq + k];
+            }
+          } else if (stage_have_avx2() && ncol > 0) (void)stage_cols_avx2(dc, colidx + p0, cnt, (unsigned)ncol);
           else for (size_t k = 0; k < cnt; ++k) dc[k] = colidx[p0 + (long long)k];
         }
       }
@@ -388,7 +443,8 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
       const int cnt = lo - slices_done;
       hipLaunchKernelGGL(k_csr_to_sell<int>, dim3((cnt + 3) / 4), dim3(kBlock), 0, ctx->stream, nrow, (const int *)g.drp.p,
                          (const int *)nullptr, (const double *)nullptr, (const long long *)S.slice_off.p, S.col.p, S.val.p,
-                         slices_done, lo, H->flag.p, ck);
+                         slices_done, lo, gat ? (int *)nullptr : H->flag.p, ck, gat ? gat->colren : (const int *)nullptr,
+                         gat ? gat->nren : 0);
       const int s0 = slices_done;
       slices_done = lo;
       if (hooks && hooks->slices && rc == ISPH_SUCCESS) rc = hooks->slices(g.A, s0, lo);
@@ -472,7 +528,7 @@ constexpr int kBatchDiv = 12;
 // from the row pointers before the first entry has crossed the link.
 inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
                                     int block_size, isph_mat **Aout, isph_ilu **Fout, int nblocks_tab = 0,
-                                    const int *bptr = nullptr) {
+                                    const int *bptr = nullptr, const IngressGather *gat = nullptr) {
   ISPH_REQUIRE(block_size >= 64 && block_size <= 1024 && block_size % 64 == 0,
                "block-Jacobi ILU block size must be a multiple of 64 in [64,1024]");
   const bool var = nblocks_tab > 0;
@@ -527,6 +583,17 @@ inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int
     const int ready = blocks_ready(s1, S.nslices);
     const int batch = std::max(1, F->nblocks / kBatchDiv);
     const bool fire = ready > blocks_done && (ready - blocks_done >= batch || s1 == S.nslices);
+    if (gat && s1 > s0) {
+      // gathered rows carry renamed columns: every row of the range is sorted by them first (k_sell_sort_rows, ranged)
+      const int Ws = S.wmax | 1;
+      int R = 64;
+      while (R > 1 && (size_t)R * Ws * 24 > 48 * 1024) R >>= 1;
+      ISPH_REQUIRE((size_t)R * Ws * 24 <= 150 * 1024, "row too long for the LDS row sort");
+      const size_t lds = (size_t)R * Ws * 24;
+      ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sell_sort_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_sell_sort_rows, dim3(s1 - s0), dim3(kBlock), lds, ctx->stream, S.nrow, S.nslices, R, Ws, (const int *)S.rowlen.p,
+                         (const long long *)S.slice_off.p, S.col.p, S.val.p, s0);
+    }
     if (fire) ISPH_CHECK_HIP(hipEventRecord(H->ev_conv, ctx->stream));  // behind the conversion, in front of the column windows
     hipLaunchKernelGGL(k_sell_compress_cols, dim3((s1 - s0 + 3) / 4), dim3(kBlock), 0, ctx->stream, s0, s1,
                        (const long long *)S.slice_off.p, (const int *)S.col.p, S.col16.p, S.wtab.p, H->flag.p + 1);
@@ -551,7 +618,7 @@ inline int csr_ingress_host_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int
   };
   isph_mat *A = nullptr;
   bool unsorted = false;
-  int rc = csr_ingress_host(ctx, nrow, ncol, rowptr, colidx, val, &A, &hooks, &unsorted);
+  int rc = csr_ingress_host(ctx, nrow, ncol, rowptr, colidx, val, &A, &hooks, &unsorted, gat);
   bool redo = unsorted;
   if (rc == ISPH_SUCCESS && F && !unsorted && nrow > 0) {
     bool overflow = false;

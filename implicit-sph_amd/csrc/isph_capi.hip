@@ -678,6 +678,8 @@ int isph_mat_create_csr(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, co
   return ISPH_SUCCESS;
 }
 
+static int order_from_host_coords(isph_ctx *ctx, int nrow, int dim, const double *x, const double *y, const double *z, RowOrderPtr &O);
+
 int isph_mat_create_csr_coords(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
                                int dim, const double *x, const double *y, const double *z, isph_mat **Aout) {
   ISPH_REQUIRE(ctx && Aout && rowptr && colidx && val && x && y, "NULL argument");
@@ -687,17 +689,7 @@ int isph_mat_create_csr_coords(isph_ctx *ctx, int nrow, int ncol, const int *row
   if (nrow == 0) return isph_mat_create_csr(ctx, nrow, ncol, rowptr, colidx, val, 0, Aout);
   // 1. the row order from the coordinates (0.5 ms at 10^6 rows; the matrix is not needed for it)
   RowOrderPtr O;
-  {
-    DevTmp<double> soa, aos;
-    ISPH_CHECK(soa.reserve((size_t)3 * nrow));
-    ISPH_CHECK(aos.reserve((size_t)3 * nrow));
-    ISPH_CHECK_HIP(hipMemcpyAsync(soa.p, x, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
-    ISPH_CHECK_HIP(hipMemcpyAsync(soa.p + nrow, y, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
-    if (dim == 3) ISPH_CHECK_HIP(hipMemcpyAsync(soa.p + 2 * (size_t)nrow, z, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_order_soa_to_aos, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, (const double *)soa.p,
-                       (const double *)soa.p + nrow, dim == 3 ? (const double *)soa.p + 2 * (size_t)nrow : (const double *)nullptr, aos.p);
-    ISPH_CHECK(order_build(ctx->stream, dim, nrow, aos.p, O));
-  }
+  ISPH_CHECK(order_from_host_coords(ctx, nrow, dim, x, y, z, O));
   // 2. the matrix over the link as it is (the pipelined ingress: conversion hidden behind the copies)
   isph_mat *A0 = nullptr;
   ISPH_CHECK(csr_ingress_host(ctx, nrow, ncol, rowptr, colidx, val, &A0));
@@ -709,6 +701,74 @@ int isph_mat_create_csr_coords(isph_ctx *ctx, int nrow, int ncol, const int *row
   if (rc != ISPH_SUCCESS) { isph_mat_destroy(A); return rc; }
   A->order = O;
   *Aout = A;
+  return ISPH_SUCCESS;
+}
+
+// the row order of a host CSR from the coordinates of its rows (three host arrays, PrecondWrapper_ML::setCoordinates' layout)
+static int order_from_host_coords(isph_ctx *ctx, int nrow, int dim, const double *x, const double *y, const double *z, RowOrderPtr &O) {
+  DevTmp<double> soa, aos;
+  ISPH_CHECK(soa.reserve((size_t)3 * nrow));
+  ISPH_CHECK(aos.reserve((size_t)3 * nrow));
+  ISPH_CHECK_HIP(hipMemcpyAsync(soa.p, x, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
+  ISPH_CHECK_HIP(hipMemcpyAsync(soa.p + nrow, y, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
+  if (dim == 3) ISPH_CHECK_HIP(hipMemcpyAsync(soa.p + 2 * (size_t)nrow, z, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_order_soa_to_aos, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, (const double *)soa.p,
+                     (const double *)soa.p + nrow, dim == 3 ? (const double *)soa.p + 2 * (size_t)nrow : (const double *)nullptr, aos.p);
+  return order_build(ctx->stream, dim, nrow, aos.p, O);
+}
+
+int isph_mat_create_csr_coords_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,
+                                       int dim, const double *x, const double *y, const double *z, isph_mat **Aout, isph_prec **Mout) {
+  ISPH_REQUIRE(ctx && Aout && Mout && rowptr && colidx && val && x && y, "NULL argument");
+  ISPH_REQUIRE(nrow > 0 && ncol >= nrow, "need 0 < nrow <= ncol");
+  ISPH_REQUIRE((dim == 2) || (dim == 3 && z), "dim must be 2, or 3 with z");
+  ISPH_REQUIRE(!is_device_pointer(x) && !is_device_pointer(y) && !is_device_pointer(z), "coordinates must be host arrays");
+  ISPH_REQUIRE(rowptr[0] == 0, "rowptr must start at 0");
+  RowOrderPtr O;
+  ISPH_CHECK(order_from_host_coords(ctx, nrow, dim, x, y, z, O));
+  // the permuted row pointers on the host (the staging threads walk the rows in the new order): four threads gather the
+  // row lengths, the prefix sum is one pass
+  std::vector<int> hperm((size_t)nrow), rp2((size_t)nrow + 1);
+  ISPH_CHECK_HIP(hipMemcpyAsync(hperm.data(), O->perm.p, sizeof(int) * (size_t)nrow, hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    const int T = 4;
+    std::vector<std::thread> th;
+    std::vector<int> bad((size_t)T, 0);
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t]() {
+        const size_t a = (size_t)nrow * t / T, b = (size_t)nrow * (t + 1) / T;
+        for (size_t r = a; r < b; ++r) {
+          const int sr = hperm[r];
+          const int len = rowptr[sr + 1] - rowptr[sr];
+          if (len < 0) bad[(size_t)t] = 1;
+          rp2[r + 1] = len;
+        }
+      });
+    for (auto &q : th) q.join();
+    for (int t = 0; t < T; ++t) ISPH_REQUIRE(!bad[(size_t)t], "rowptr not monotone");
+    rp2[0] = 0;
+    long long run = 0;
+    for (int r = 0; r < nrow; ++r) { run += rp2[(size_t)r + 1]; ISPH_REQUIRE(run <= 2147483647LL, "more than 2^31 entries"); rp2[(size_t)r + 1] = (int)run; }
+    ISPH_REQUIRE(run == (long long)rowptr[nrow], "row pointers and entry count disagree");
+  }
+  const std::vector<int> &bp = O->block_ptr;
+  int cap = 64;
+  for (size_t b = 0; b + 1 < bp.size(); ++b) cap = std::max(cap, bp[b + 1] - bp[b]);
+  cap = (cap + 63) / 64 * 64;
+  IngressGather gat;
+  gat.perm = hperm.data(); gat.src_rowptr = rowptr; gat.colren = O->iperm.p; gat.nren = nrow;
+  isph_mat *A = nullptr;
+  isph_ilu *F = nullptr;
+  ISPH_CHECK(csr_ingress_host_bjacobi(ctx, nrow, ncol, rp2.data(), colidx, val, cap, &A, &F, (int)bp.size() - 1, bp.data(), &gat));
+  A->order = O;
+  isph_prec *M = new isph_prec();
+  M->n = nrow;
+  M->type = 2;
+  M->ilu = F;
+  M->order = O;
+  *Aout = A;
+  *Mout = M;
   return ISPH_SUCCESS;
 }
 

@@ -138,7 +138,10 @@ template <class OFF>
 __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const int *__restrict__ colidx,
                               const double *__restrict__ cval, const long long *__restrict__ slice_off,
                               int *__restrict__ scol, double *__restrict__ sval, int slice_begin, int slice_end,
-                              int *__restrict__ unsorted, CsrChunks ck) {
+                              int *__restrict__ unsorted, CsrChunks ck, const int *__restrict__ colren = nullptr, int nren = 0) {
+  // colren (may be NULL): columns < nren are stored as colren[c] -- the library's own row numbering for a host CSR whose
+  // rows arrive in that numbering but whose columns still carry the caller's (ingress.hpp, IngressGather); the rows then
+  // come out unsorted and the caller sorts the slice range afterwards
   const int slice = slice_begin + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int row = slice * kSlice + lane;
@@ -169,6 +172,8 @@ __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const in
       padcol = colidx[beg];
     }
   }
+  const int first_col = padcol;            // the row's first column as it was sent (16-bit mode adds differences to it)
+  if (colren && padcol < nren) padcol = colren[padcol];
   int prev = -1;
   bool desc = false;
   for (int k = 0; k < w; ++k) {
@@ -185,12 +190,12 @@ __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const in
         const long long e = q - cv.cbase;
         v = cv.vals[e];
         if (!cv.m16) c = cv.c32[e];
-        else if (k == 0) c = padcol;
+        else if (k == 0) c = first_col;
         else c = prev + (int)cv.d16[e];
       }
       desc = desc || c < prev;
       prev = c;
-      scol[p] = c;
+      scol[p] = (colren && c < nren) ? colren[c] : c;
       sval[p] = v;
     } else {
       scol[p] = padcol;
@@ -208,9 +213,9 @@ __global__ void k_csr_to_sell(int nrow, const OFF *__restrict__ rowptr, const in
 __global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int nrow, int nslices, int R, int Ws,
                                                            const int *__restrict__ rowlen,
                                                            const long long *__restrict__ slice_off,
-                                                           int *__restrict__ scol, double *__restrict__ sval) {
+                                                           int *__restrict__ scol, double *__restrict__ sval, int slice0 = 0) {
   extern __shared__ double lds_raw[];
-  const int slice = blockIdx.x;
+  const int slice = slice0 + blockIdx.x;   // a ranged launch sorts slices [slice0, slice0 + gridDim.x)
   if (slice >= nslices) return;
   double *valA = lds_raw;                 // [R][Ws]
   double *valB = valA + (size_t)R * Ws;   // [R][Ws]

@@ -18,7 +18,7 @@ KERNELS = {"wendland": 0, "quintic": 1, "cubic": 2}
 
 EXPORTS = [
     "isph_ctx_create", "isph_comm_unique_id", "isph_ctx_create_dist", "isph_ctx_create_hostcomm", "isph_ctx_sync", "isph_ctx_destroy", "isph_pool_trim", "isph_pool_set_cap", "isph_set_exact_stream_threshold", "isph_pool_cached_bytes", "isph_pool_info", "isph_halo_create", "isph_halo_forward", "isph_halo_destroy", "isph_prec_create_overlap",
-    "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_mat_create_csr_coords", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
+    "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_mat_create_csr_coords", "isph_mat_create_csr_coords_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_create_blocks_fill", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
     "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_mat_ordering_info", "isph_mat_ordering", "isph_ctx_halo_profile_read", "isph_ctx_comm_info", "isph_device_identity", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
@@ -143,6 +143,8 @@ def lib():
                                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_create_csr_coords.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_mat_create_csr_coords_bjacobi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
         L.isph_mat_info.argtypes = [C.c_void_p, C.c_void_p]
@@ -439,13 +441,22 @@ class Matrix:
         return m
 
     @classmethod
-    def from_host_csr_with_coords(cls, ctx, rowptr, colidx, val, coords, dim=3, ncol=None):
+    def from_host_csr_with_coords(cls, ctx, rowptr, colidx, val, coords, dim=3, ncol=None, with_bjacobi=False):
         """isph_mat_create_csr_coords: host CSR in the caller's atom order + the coordinates of its rows ([nrow, >= dim]) ->
-        a matrix in the library's own row numbering (the drop-in path with PrecondWrapper_Ifpack::setCoordinates)"""
+        a matrix in the library's own row numbering (the drop-in path with PrecondWrapper_Ifpack::setCoordinates).
+        with_bjacobi: isph_mat_create_csr_coords_bjacobi, returns (Matrix, Precond) with the ILU(0) set-up of the library's
+        bricks fused with the ingress"""
         rowptr, colidx, val = _i32(rowptr), _i32(colidx), _f64(val)
         nrow = int(rowptr.shape[0]) - 1
         xs = [np.ascontiguousarray(coords[:nrow, a], dtype=np.float64) for a in range(dim)]
         m = cls(ctx)
+        if with_bjacobi:
+            M = Precond.__new__(Precond)
+            M.ctx, M.n, M.h = ctx, nrow, C.c_void_p()
+            _check(lib().isph_mat_create_csr_coords_bjacobi(ctx.h, nrow, nrow if ncol is None else ncol, _ptr(rowptr), _ptr(colidx),
+                                                            _ptr(val), int(dim), _ptr(xs[0]), _ptr(xs[1]),
+                                                            _ptr(xs[2]) if dim == 3 else None, C.byref(m.h), C.byref(M.h)))
+            return m, M
         _check(lib().isph_mat_create_csr_coords(ctx.h, nrow, nrow if ncol is None else ncol, _ptr(rowptr), _ptr(colidx), _ptr(val),
                                                 int(dim), _ptr(xs[0]), _ptr(xs[1]), _ptr(xs[2]) if dim == 3 else None, C.byref(m.h)))
         return m

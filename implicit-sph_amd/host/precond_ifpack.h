@@ -56,8 +56,12 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
   // the throughput path (block-Jacobi ILU(0), overlap 0 inside the rank) can be built during the matrix ingress
   virtual int fusedIngressBlockRows() {
     setParameters(_param.get());
-    if (_cx != nullptr) return 0;  // coordinates: the ingress permutes the matrix first, the set-up follows (createOnDevice)
     const int block = _param->get("isph: block rows", 512);
+    if (_cx != nullptr) {  // coordinates: the library's bricks are the subdomains; fused with the ingress when fill is 0
+      if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0 || block == 0 || block > 1024) return 0;
+      noticeOnce(0, -1, _param->get("Overlap Level", 1));
+      return 512;
+    }
     if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0) return 0;
     if (tableUsable()) {
       int cap = 64;
@@ -86,7 +90,7 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
     return ok;
   }
   virtual bool fusedIngressSubdomains(int &nblocks, const int *&bptr) {
-    if (!tableUsable()) return false;
+    if (_cx != nullptr || !tableUsable()) return false;   // with coordinates the library's own bricks win over a table
     nblocks = (int)_bptr.size() - 1;
     bptr = _bptr.data();
     return true;

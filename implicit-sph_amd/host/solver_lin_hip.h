@@ -91,7 +91,9 @@ class SolverLin_HIP : public SolverLin {
     int cdim = 0;
     const double *cx = nullptr, *cy = nullptr, *cz = nullptr;
     const bool ordered = prec != NULL && prec->ingressCoordinates(cdim, cx, cy, cz);
-    if ((ordered ? isph_mat_create_csr_coords(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, cdim, cx, cy, cz, &A)
+    if ((ordered && fused > 0 && _A->NumMyRows() > 0
+             ? isph_mat_create_csr_coords_bjacobi(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, cdim, cx, cy, cz, &A, &Mfused)
+         : ordered ? isph_mat_create_csr_coords(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, cdim, cx, cy, cz, &A)
          : table ? isph_mat_create_csr_blocks(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, nsub, subptr, &A, &Mfused)
          : fused > 0 ? isph_mat_create_csr_bjacobi(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, fused, &A, &Mfused)
                      : isph_mat_create_csr(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, 0, &A)) != ISPH_SUCCESS)

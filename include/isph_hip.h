@@ -127,6 +127,14 @@ int isph_mat_create_csr_blocks(isph_ctx *ctx, int nrow, int ncol, const int *row
 int isph_mat_create_csr_coords(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h]*/, const int *colidx /*[h]*/,
                                const double *val /*[h]*/, int dim, const double *x /*[h]*/, const double *y /*[h]*/,
                                const double *z /*[h]*/, isph_mat **A);
+/* The same fused with the set-up of "bjacobi-ilu0" on the library's bricks: the staging threads gather the caller's rows
+ * in the NEW order (the permutation is known before the first entry leaves the host), the conversion kernel renames the
+ * columns and a ranged row sort follows it, so that -- as in isph_mat_create_csr_blocks -- the 16-bit column windows and
+ * the ILU(0) extraction / schedule / factorisation of the bricks whose rows have arrived run while the rest of the matrix
+ * is still on the link.  Result: the matrix of isph_mat_create_csr_coords and isph_prec_create(A, "bjacobi-ilu0", 0). */
+int isph_mat_create_csr_coords_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr /*[h]*/, const int *colidx /*[h]*/,
+                                       const double *val /*[h]*/, int dim, const double *x /*[h]*/, const double *y /*[h]*/,
+                                       const double *z /*[h]*/, isph_mat **A, isph_prec **M);
 /* Diagnostics of the last host-side ingress on this context (milliseconds since its start):
  * [0] staging threads started, device buffers reserved  [1] all chunks queued on the copy stream
  * [2] copy stream drained  [3] compute stream drained (conversion + fused set-up)  [4] end

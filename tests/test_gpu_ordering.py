@@ -289,7 +289,40 @@ def test_host_csr_with_coordinates_gets_the_librarys_numbering(octx, gpu_ctx):
         xo[o["perm"]] = xoi
         assert info.converged == 1 and abs(info.iters - io.iters) <= 1, (name, info.iters, io.iters)
         assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6, name
+        # the fused form (rows staged in the new order, set-up behind the link) is the two-step result bit for bit
+        A2, M2 = hip.Matrix.from_host_csr_with_coords(gpu_ctx, rp, ci, val, parts["x"][:nl], with_bjacobi=True)
+        o2 = A2.ordering()
+        assert np.array_equal(o2["perm"], o["perm"]) and np.array_equal(o2["block_ptr"], o["block_ptr"]), name
+        assert all(np.array_equal(a, c) for a, c in zip(A2.export_csr(), (rp, ci, val))), name
+        assert np.array_equal(A2.spmv(xv), A.spmv(xv)), name
+        assert all(np.array_equal(a, c) for a, c in zip(M2.export_ilu(), M.export_ilu())), name
+        assert np.array_equal(M2.apply(xv), M.apply(xv)), name
+        M2.close(); A2.close()
         M.close(); A.close(); Ad.close()
+
+
+def test_fused_ordered_ingress_on_a_larger_matrix(gpu_ctx):
+    """isph_mat_create_csr_coords_bjacobi at a size where the matrix crosses the link in several chunks and the set-up
+    runs in batches behind it (40^3, shuffled atom order -- every staged row comes from somewhere else): the two-step
+    result bit for bit"""
+    spec = tgv_spec(dim=3, n=40, mode=workload.ADVECT)
+    name, parts = _three_orders(spec)[2]
+    P, (rp, ci, val, b) = _oracle_system(parts, spec)
+    nl = parts["nlocal"]
+    A = hip.Matrix.from_host_csr_with_coords(gpu_ctx, rp, ci, val, parts["x"][:nl])
+    M = hip.Precond(gpu_ctx, A, "bjacobi-ilu0", 0)
+    A2, M2 = hip.Matrix.from_host_csr_with_coords(gpu_ctx, rp, ci, val, parts["x"][:nl], with_bjacobi=True)
+    xv = np.random.default_rng(3).standard_normal(nl)
+    assert np.array_equal(A2.spmv(xv), A.spmv(xv))
+    assert all(np.array_equal(a, c) for a, c in zip(M2.export_ilu(), M.export_ilu()))
+    assert np.array_equal(M2.apply(xv), M.apply(xv))
+    bb, xg = b.copy(), np.zeros(nl)
+    info = hip.solve(gpu_ctx, A2, bb, xg, prec=M2, singular=True)
+    bb1, xg1 = b.copy(), np.zeros(nl)
+    info1 = hip.solve(gpu_ctx, A, bb1, xg1, prec=M, singular=True)
+    assert info.converged == 1 and info.iters == info1.iters and np.array_equal(xg, xg1)
+    for o in (M, M2, A, A2):
+        o.close()
 
 
 def test_cpp_mirror_with_coordinates(gpu_ctx, tmp_path):
