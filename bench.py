@@ -292,6 +292,8 @@ def dropin_leg(A, b, repeat=5, sub_rows=0, coords=None):
         for line in r.stdout.splitlines():
             if line.startswith('{"dropin"'):
                 rec = json.loads(line)["dropin"]
+            if line.startswith('{"ingress_last_call"') and rec is not None:
+                rec["ingress_last_call"] = json.loads(line)["ingress_last_call"]
         if rec is None:
             return {"error": "no record from the driver: " + r.stdout[-300:]}
         xd = np.fromfile(fout)[:n]

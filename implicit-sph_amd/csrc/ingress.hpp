@@ -87,6 +87,33 @@ inline unsigned stage_cols_avx2(int *, const int *, size_t, unsigned) { return 0
 inline void stage_copy(void *dst, const void *src, size_t bytes) {
   if (stage_have_avx2()) stage_copy_avx2(dst, src, bytes); else memcpy(dst, src, bytes);
 }
+// A row segment of the gathered ingress: a few hundred bytes, both pointers 4-byte aligned (8 for values).  Plain moves
+// up to the next 32-byte boundary of the destination, streaming stores of 32 bytes, plain moves for the rest; no fence
+// (the chunk's finisher fences once).  stage_copy's byte-wise head and tail (up to 158 bytes per call) cost more than
+// the copy itself at this size.
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void stage_copy_row_avx2(void *dst, const void *src, size_t bytes) {
+  char *d = static_cast<char *>(dst);
+  const char *s = static_cast<const char *>(src);
+  size_t k = 0;
+  while (k + 4 <= bytes && (reinterpret_cast<uintptr_t>(d + k) & 31)) { memcpy(d + k, s + k, 4); k += 4; }
+  for (; k + 32 <= bytes; k += 32)
+    _mm256_stream_si256(reinterpret_cast<__m256i *>(d + k), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + k)));
+  for (; k + 4 <= bytes; k += 4) memcpy(d + k, s + k, 4);
+  for (; k < bytes; ++k) d[k] = s[k];
+}
+#endif
+inline void stage_copy_row(void *dst, const void *src, size_t bytes) {
+#if defined(__x86_64__)
+  if (stage_have_avx2()) { stage_copy_row_avx2(dst, src, bytes); return; }
+#endif
+  memcpy(dst, src, bytes);
+}
+inline void stage_fence() {
+#if defined(__x86_64__)
+  _mm_sfence();
+#endif
+}
 
 struct HostStager {
   static constexpr size_t kChunk = (size_t)4 << 20;  // entries per ring slot; a slot is 12 bytes per entry = 48 MiB
@@ -263,10 +290,15 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
           if (b <= a) continue;
           const long long sq = (long long)gat->src_rowptr[gat->perm[r]] + (a - rowptr[r]);
           const size_t m = (size_t)(b - a);
-          stage_copy(base + 8 * (size_t)(a - p0), val + sq, sizeof(double) * m);
-          const int *src = colidx + sq;
+          if (r + 3 < nrow) {  // the rows three ahead start somewhere else in the caller's arrays: ask for their first lines now
+            const long long nq = gat->src_rowptr[gat->perm[r + 3]];
+            __builtin_prefetch(val + nq); __builtin_prefetch(val + nq + 8); __builtin_prefetch(val + nq + 16); __builtin_prefetch(val + nq + 24);
+            __builtin_prefetch(colidx + nq); __builtin_prefetch(colidx + nq + 16);
+          }
+          stage_copy_row(base + 8 * (size_t)(a - p0), val + sq, sizeof(double) * m);
+          const int *__restrict__ src = colidx + sq;
           if (try16) {
-            unsigned short *dst = d16 + (a - p0);
+            unsigned short *__restrict__ dst = d16 + (a - p0);
             size_t k0 = 0;
             if (a == (long long)rowptr[r]) { dst[0] = 0; ov |= (unsigned)((unsigned)src[0] >= (unsigned)ncol); k0 = 1; }  // row start: its column travels in the table
             for (size_t k = k0; k < m; ++k) {
@@ -278,9 +310,13 @@ inline int csr_ingress_host(isph_ctx *ctx, int nrow, int ncol, const int *rowptr
             }
           } else {
             int *dc = dc32 + (a - p0);
-            for (size_t k = 0; k < m; ++k) { const int cc = src[k]; ov |= (unsigned)((unsigned)cc >= (unsigned)ncol); dc[k] = cc; }
+            unsigned o2 = 0;
+            for (size_t k = 0; k < m; ++k) o2 |= (unsigned)((unsigned)src[k] >= (unsigned)ncol);
+            ov |= o2;
+            stage_copy_row(dc, src, sizeof(int) * m);
           }
         }
+        stage_fence();
         over |= ov;
         if (try16) nwide_sum[(size_t)c].fetch_add((long long)nw);
       } else if (q_hi > q_lo) {

@@ -38,6 +38,9 @@ class PrecondWrapper {
     const bool ok = x != NULL && y != NULL && (dim == 2 || (dim == 3 && z != NULL));
     _cdim = ok ? dim : 0; _cx = ok ? x : nullptr; _cy = ok ? y : nullptr; _cz = ok ? z : nullptr;
   }
+  // true when this wrapper's device object is the block ILU(0) on the library's bricks (fill 0), which
+  // isph_mat_create_csr_coords_bjacobi can set up during the ordered ingress
+  virtual bool orderedIngressFusable() { return false; }
   virtual bool ingressCoordinates(int &dim, const double *&x, const double *&y, const double *&z) {
     if (_cx == nullptr) return false;
     dim = _cdim; x = _cx; y = _cy; z = _cz;

@@ -57,11 +57,11 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
   virtual int fusedIngressBlockRows() {
     setParameters(_param.get());
     const int block = _param->get("isph: block rows", 512);
-    if (_cx != nullptr) {  // coordinates: the library's bricks are the subdomains; fused with the ingress when fill is 0
-      if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0 || block == 0 || block > 1024) return 0;
-      noticeOnce(0, -1, _param->get("Overlap Level", 1));
-      return 512;
-    }
+    // coordinates: the matrix crosses the link as it lies in the caller's memory and is permuted on the device; the set-up
+    // follows in createOnDevice.  (isph_mat_create_csr_coords_bjacobi stages the rows in the new order on the host and
+    // runs the set-up behind the link; on the 16-core share of the GPU box the gathered staging reaches 35 GB/s where
+    // the flat copy reaches 54, so the fused form loses 5-10 ms against this one: profiles/r05_dropin.txt)
+    if (_cx != nullptr) return 0;
     if (_param->get("Precond Type", "ILU") != "ILU" || _param->get("fact: level-of-fill", 1) != 0) return 0;
     if (tableUsable()) {
       int cap = 64;
@@ -88,6 +88,11 @@ class PrecondWrapper_Ifpack : public PrecondWrapper {
       _warned_table = true;
     }
     return ok;
+  }
+  virtual bool orderedIngressFusable() {
+    setParameters(_param.get());
+    const int block = _param->get("isph: block rows", 512);
+    return _param->get("Precond Type", "ILU") == "ILU" && _param->get("fact: level-of-fill", 1) == 0 && block > 0 && block <= 1024;
   }
   virtual bool fusedIngressSubdomains(int &nblocks, const int *&bptr) {
     if (_cx != nullptr || !tableUsable()) return false;   // with coordinates the library's own bricks win over a table

@@ -91,7 +91,9 @@ class SolverLin_HIP : public SolverLin {
     int cdim = 0;
     const double *cx = nullptr, *cy = nullptr, *cz = nullptr;
     const bool ordered = prec != NULL && prec->ingressCoordinates(cdim, cx, cy, cz);
-    if ((ordered && fused > 0 && _A->NumMyRows() > 0
+    const char *fuse_env = std::getenv("ISPH_DROPIN_FUSED_ORDER");   // "1": the fused form of the ordered ingress (see precond_ifpack.h)
+    const bool fuse_ordered = ordered && fuse_env && fuse_env[0] == '1' && _A->NumMyRows() > 0 && prec->orderedIngressFusable();
+    if ((fuse_ordered
              ? isph_mat_create_csr_coords_bjacobi(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, cdim, cx, cy, cz, &A, &Mfused)
          : ordered ? isph_mat_create_csr_coords(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, cdim, cx, cy, cz, &A)
          : table ? isph_mat_create_csr_blocks(_ctx, _A->NumMyRows(), _A->NumMyCols(), rp, ci, v, nsub, subptr, &A, &Mfused)
@@ -108,7 +110,7 @@ class SolverLin_HIP : public SolverLin {
     if (prec != NULL) {
       if (_is_singular && prec->usesNullVector()) { createNullVector(); prec->setNullVector(_n->Values()); }  // :149-151
       prec->create();
-      if (fused > 0) prec->adoptDevice(Mfused);
+      if (fused > 0 || fuse_ordered) prec->adoptDevice(Mfused);
       else rc = prec->createOnDevice(_ctx, A);  // Ifpack Initialize+Compute happen here (:153)
     }
     if (_timing && rc == ISPH_SUCCESS) rc = isph_ctx_sync(_ctx);  // only to attribute the set-up; the solve queues behind it anyway
