@@ -327,6 +327,7 @@ def step_workload(args, json_fd=None, ctx=None, steps=None, warmup=None, quiet=F
     nsteps = args.steps if steps is None else steps
     nwarm = args.warmup if warmup is None else warmup
     lib_order = ctx.ordering == "bricks"
+    ctx.set_periodic_box((0.0, 0.0, 0.0), (2 * np.pi,) * 3, (1, 1, 1))     # domain->boxlo / boxhi / periodicity of the script's box
     n = args.ncell
     # the atom order of the particles: the generator's bricks only when the caller's order is what the matrix keeps
     brick = tuple(int(t) for t in args.brick.split(",")) if (not lib_order or args.order == "bricks") else (n, n, n)
@@ -347,6 +348,7 @@ def step_workload(args, json_fd=None, ctx=None, steps=None, warmup=None, quiet=F
               "correct_advance", "shift")
     acc = {k: 0.0 for k in stages}
     its = {"helmholtz": [], "poisson": []}
+    substats = []
 
     def sync():
         torch.cuda.synchronize()
@@ -409,10 +411,15 @@ def step_workload(args, json_fd=None, ctx=None, steps=None, warmup=None, quiet=F
         M = make_prec(A, smode == hip.NULLSPACE)
         dpv = torch.zeros(N, dtype=torch.float64, device=dev)
         ip = hip.solve(ctx, A, b, dpv, prec=M, singular=(smode == hip.NULLSPACE))
-        M.close(); A.close()
+        M.close()
+        sub = A.subdomains() if (lib_order and timed) else None           # (a 8 KB table; inside the Poisson bracket like the close)
+        A.close()
         its["poisson"].append(int(ip.iters))
         dpv -= dpv.mean()                                                  # computeZeroMeanPressure
         t7 = sync()
+        if sub is not None:
+            sz = np.diff(sub)
+            substats.append((int(len(sz)), int(sz.min()), float(sz.mean()), int(sz.max())))
         # ---- correction + advanceTime (pair_isph.cpp:1030-1031, pair_isph_corrected.cpp:1172-1199)
         dp_all = dpv[own].contiguous()
         hip.correct_velocity_pressure(ctx, dp, colmap, dt, rho, dp_all, vstar_all, pall, vfrac, kernel=args.kernel)
@@ -452,6 +459,7 @@ def step_workload(args, json_fd=None, ctx=None, steps=None, warmup=None, quiet=F
                    "dt": dt, "library_row_order": "bricks" if lib_order else "caller",
                    "subdomains": "the library's bricks" if lib_order else (("%dx%dx%d bricks" % brick) if bptr is not None else "%d rows" % args.block),
                    "iterations_poisson": its["poisson"][nwarm:], "iterations_helmholtz_3rhs_total": its["helmholtz"][nwarm:],
+                   "subdomains_per_step_count_min_mean_max": substats,
                    "kinetic_energy_sum_end": ke},
         "stages_ms_per_step": {k: acc[k] / K * 1e3 for k in stages},
         "split": {"ISPH: computePre": acc["computePre"] / K * 1e3,
@@ -511,6 +519,10 @@ class Case:
         self.env, self.order, self.lib_order = env, order, lib_order
         ctx, dev, args, td, world, rank = (env[k] for k in ("ctx", "dev", "args", "td", "world", "rank"))
         ctx.set_ordering("bricks" if lib_order else "caller")
+        # the periodic box, as a LAMMPS adapter knows it (domain->boxlo / boxhi / periodicity): periodic along the axes this
+        # rank's brick spans alone
+        pgb = pgrid_for(world)
+        ctx.set_periodic_box((0.0, 0.0, 0.0), (2 * np.pi,) * 3, tuple(int(g == 1) for g in pgb))
         t0 = time.perf_counter()
         self.spec, parts, self.brick = make_particles(args, world, rank, order)
         if world > 1:

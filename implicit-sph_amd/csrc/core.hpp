@@ -67,6 +67,7 @@ struct isph_ctx {
   // row numbering of the matrices the assembly entry points build (isph_ctx_set_ordering): 1 = the library's bricks
   // (order.hpp, default), 0 = the caller's atom order
   int ordering = 1;
+  isph::OrderBox box;                  // isph_ctx_set_periodic_box: what the caller said about its periodic box (for the brick sort)
   isph_neigh_map nmap;                 // set around one ordered assembly call
   // while the neighbour list is held the row order of the first matrix assembly serves the following ones (LAMMPS'
   // atom order -- the reference's row map -- does not change between two re-neighbourings either)

@@ -272,7 +272,7 @@ struct OrderedAssembly {
     if (ctx->neigh_hold && ctx->held_order && ctx->held_order->n == n && ctx->held_key[0] == k0 && ctx->held_key[1] == k1) {
       O = ctx->held_order;
     } else {
-      ISPH_CHECK(order_build(ctx->stream, dim, n, dx, O));
+      ISPH_CHECK(order_build(ctx->stream, dim, n, dx, O, &ctx->box));
       if (ctx->neigh_hold) { ctx->held_order = O; ctx->held_key[0] = k0; ctx->held_key[1] = k1; }
     }
     const int *perm = O->perm.p, *iperm = O->iperm.p;
@@ -512,6 +512,15 @@ int isph_ctx_set_ordering(isph_ctx *ctx, int mode) {
   return ISPH_SUCCESS;
 }
 
+int isph_ctx_set_periodic_box(isph_ctx *ctx, const double lo[3], const double hi[3], const int periodic[3]) {
+  ISPH_REQUIRE(ctx, "ctx is NULL");
+  ctx->box = OrderBox();
+  if (lo && hi && periodic)
+    for (int a = 0; a < 3; ++a) { ctx->box.lo[a] = lo[a]; ctx->box.hi[a] = hi[a]; ctx->box.periodic[a] = periodic[a] ? 1 : 0; }
+  ctx->held_order.reset();
+  return ISPH_SUCCESS;
+}
+
 int isph_mat_ordering_info(const isph_mat *A, long long info[3], isph_order_geometry *geom) {
   ISPH_REQUIRE(A && info, "NULL argument");
   info[0] = A->order ? 1 : 0;
@@ -523,11 +532,20 @@ int isph_mat_ordering_info(const isph_mat *A, long long info[3], isph_order_geom
       const OrderGeom &g = A->order->g;
       geom->dim = g.dim;
       for (int a = 0; a < 3; ++a) {
-        geom->lo[a] = g.lo[a]; geom->inv_cell[a] = g.inv_cell[a]; geom->ncell[a] = g.ncell[a];
+        geom->lo[a] = g.lo[a]; geom->inv_bin[a] = g.inv_bin[a]; geom->nbins[a] = g.nbins[a]; geom->ncell[a] = g.ncell[a];
         geom->cells_per_brick[a] = g.cpb[a]; geom->nbrick[a] = g.nbrick[a];
+        geom->shift[a] = g.shift[a]; geom->period[a] = g.period[a];
       }
     }
   }
+  return ISPH_SUCCESS;
+}
+
+int isph_mat_ordering_faces(const isph_mat *A, int axis, double *faces) {
+  ISPH_REQUIRE(A && faces && axis >= 0 && axis < 3, "bad argument");
+  ISPH_REQUIRE(A->order, "the matrix is in the caller's row numbering");
+  const std::vector<double> &f = A->order->hface[axis];
+  if (!f.empty()) memcpy(faces, f.data(), sizeof(double) * f.size());
   return ISPH_SUCCESS;
 }
 
@@ -714,7 +732,7 @@ static int order_from_host_coords(isph_ctx *ctx, int nrow, int dim, const double
   if (dim == 3) ISPH_CHECK_HIP(hipMemcpyAsync(soa.p + 2 * (size_t)nrow, z, sizeof(double) * (size_t)nrow, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_order_soa_to_aos, dim3((nrow + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nrow, (const double *)soa.p,
                      (const double *)soa.p + nrow, dim == 3 ? (const double *)soa.p + 2 * (size_t)nrow : (const double *)nullptr, aos.p);
-  return order_build(ctx->stream, dim, nrow, aos.p, O);
+  return order_build(ctx->stream, dim, nrow, aos.p, O, &ctx->box);
 }
 
 int isph_mat_create_csr_coords_bjacobi(isph_ctx *ctx, int nrow, int ncol, const int *rowptr, const int *colidx, const double *val,

@@ -21,7 +21,7 @@ EXPORTS = [
     "isph_last_error", "isph_mat_create_csr", "isph_mat_create_csr_bjacobi", "isph_mat_create_csr_blocks", "isph_mat_create_csr_coords", "isph_mat_create_csr_coords_bjacobi", "isph_ingress_info", "isph_mat_set_halo", "isph_mat_info", "isph_mat_export_csr", "isph_mat_export_rows",
     "isph_mat_destroy", "isph_spmv", "isph_spmv_time", "isph_prec_create", "isph_prec_create_blocks", "isph_prec_create_blocks_fill", "isph_prec_apply",
     "isph_prec_export_ilu", "isph_prec_nnz", "isph_prec_info", "isph_prec_destroy", "isph_solver_params_default", "isph_solve",
-    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_mat_ordering_info", "isph_mat_ordering", "isph_ctx_halo_profile_read", "isph_ctx_comm_info", "isph_device_identity", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
+    "isph_ctx_set_profile", "isph_ctx_hold_neighbours", "isph_ctx_profile_read", "isph_ctx_set_ordering", "isph_ctx_set_periodic_box", "isph_mat_ordering_info", "isph_mat_ordering", "isph_mat_ordering_faces", "isph_ctx_halo_profile_read", "isph_ctx_comm_info", "isph_device_identity", "isph_assemble_poisson", "isph_assemble_helmholtz", "isph_assemble_solute_transport", "isph_assemble_applied_potential", "isph_compute_volumes", "isph_compute_pnd", "isph_compute_corrections", "isph_gradient", "isph_divergence", "isph_correct_velocity_pressure",
     "isph_advance_begin", "isph_advance_end", "isph_compute_shift", "isph_apply_shift", "isph_shift_particles",
     "isph_solve_block", "isph_assemble_block_helmholtz", "isph_amg_params_default", "isph_prec_create_amg", "isph_prec_amg_levels", "isph_prec_amg_info",
     "isph_prec_amg_export", "isph_prec_amg_aggregates",
@@ -63,8 +63,8 @@ class SolveInfo(C.Structure):
 
 class OrderGeometry(C.Structure):
     """isph_order_geometry: what the library's brick sort of the owned particles was made with (isph_mat_ordering_info)."""
-    _fields_ = [("dim", C.c_int), ("lo", C.c_double * 3), ("inv_cell", C.c_double * 3), ("ncell", C.c_int * 3),
-                ("cells_per_brick", C.c_int * 3), ("nbrick", C.c_int * 3)]
+    _fields_ = [("dim", C.c_int), ("lo", C.c_double * 3), ("inv_bin", C.c_double * 3), ("nbins", C.c_int * 3), ("ncell", C.c_int * 3),
+                ("cells_per_brick", C.c_int * 3), ("nbrick", C.c_int * 3), ("shift", C.c_double * 3), ("period", C.c_double * 3)]
 
 
 ORDERINGS = {"caller": 0, "bricks": 1}
@@ -133,8 +133,10 @@ def lib():
         L.isph_ctx_comm_info.argtypes = [C.c_void_p, C.c_void_p]
         L.isph_device_identity.argtypes = [C.c_int, C.c_char_p]
         L.isph_ctx_set_ordering.argtypes = [C.c_void_p, C.c_int]
+        L.isph_ctx_set_periodic_box.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_ordering_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.isph_mat_ordering.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.isph_mat_ordering_faces.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.isph_mat_create_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]
         L.isph_mat_create_csr_bjacobi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -336,6 +338,16 @@ class Context:
         _check(lib().isph_ctx_set_ordering(self.h, ORDERINGS[mode]))
         self.ordering = mode
 
+    def set_periodic_box(self, lo=None, hi=None, periodic=None):
+        """isph_ctx_set_periodic_box: the caller's periodic box for the brick sort (None forgets it)"""
+        if lo is None:
+            _check(lib().isph_ctx_set_periodic_box(self.h, None, None, None))
+            return
+        a = (C.c_double * 3)(*[float(v) for v in (list(lo) + [0.0] * 3)[:3]])
+        b = (C.c_double * 3)(*[float(v) for v in (list(hi) + [0.0] * 3)[:3]])
+        p = (C.c_int * 3)(*[int(v) for v in (list(periodic) + [0] * 3)[:3]])
+        _check(lib().isph_ctx_set_periodic_box(self.h, a, b, p))
+
     @staticmethod
     def unique_id():
         buf = C.create_string_buffer(UID_BYTES)
@@ -496,7 +508,8 @@ class Matrix:
 
     def ordering(self):
         """None for a matrix in the caller's row numbering; else dict(perm [nrow]: the caller's row held by internal row r,
-        block_ptr: the library's subdomains over internal rows, geom: OrderGeometry) -- isph_mat_ordering(_info)."""
+        block_ptr: the library's subdomains over internal rows, geom: OrderGeometry, faces: the cell faces of the three axes)
+        -- isph_mat_ordering(_info), isph_mat_ordering_faces."""
         a = (C.c_longlong * 3)()
         g = OrderGeometry()
         _check(lib().isph_mat_ordering_info(self.h, a, C.byref(g)))
@@ -505,7 +518,23 @@ class Matrix:
         perm = np.zeros(int(a[1]), dtype=np.int32)
         bp = np.zeros(int(a[2]) + 1, dtype=np.int32)
         _check(lib().isph_mat_ordering(self.ctx.h, self.h, _ptr(perm), _ptr(bp)))
-        return dict(perm=perm, block_ptr=bp, geom=g)
+        faces = []
+        for ax in range(3):
+            f = np.zeros(max(int(g.ncell[ax]) - 1, 0))
+            if ax < g.dim and len(f):
+                _check(lib().isph_mat_ordering_faces(self.h, ax, _ptr(f)))
+            faces.append(f)
+        return dict(perm=perm, block_ptr=bp, geom=g, faces=faces)
+
+    def subdomains(self):
+        """the library's subdomain table alone (no copy of the permutation); None for a matrix in the caller's numbering"""
+        a = (C.c_longlong * 3)()
+        _check(lib().isph_mat_ordering_info(self.h, a, None))
+        if not a[0]:
+            return None
+        bp = np.zeros(int(a[2]) + 1, dtype=np.int32)
+        _check(lib().isph_mat_ordering(self.ctx.h, self.h, None, _ptr(bp)))
+        return bp
 
     def export_csr(self):
         i = self.info()

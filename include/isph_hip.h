@@ -357,19 +357,33 @@ int isph_ctx_comm_info(const isph_ctx *ctx, long long info[4]);
 #define ISPH_ORDER_CALLER 0
 #define ISPH_ORDER_BRICKS 1
 int isph_ctx_set_ordering(isph_ctx *ctx, int mode);
-/* what the sort was made with: cell(a) = clamp(floor((x_a - lo[a]) * inv_cell[a]), 0, ncell[a] - 1), brick(a) = cell(a) /
- * cells_per_brick[a]; key = (brick_z * nbrick[1] + brick_y) * nbrick[0] + brick_x) * (cells per brick) + (cz' * cpb[1] +
- * cy') * cpb[0] + cx' with c' = cell mod cells_per_brick; rows ascend by key, ties in the caller's order */
+/* Optional, for ISPH_ORDER_BRICKS: the caller's periodic box (LAMMPS: domain->boxlo / boxhi / periodicity; on more than one
+ * rank set periodic[a] only for axes the rank's sub-domain spans alone).  Atoms that have just wrapped around a periodic
+ * box end sit at the other end of the coordinate range -- half a lattice plane at x = L - eps, the other half at +eps --,
+ * which stretches the bounding box the bricks are cut from by a spacing and leaves bricks of 9 ... 11 planes per axis
+ * instead of 10 (all subdomains then pay for the largest one's LDS).  With the box the sort takes coordinates relative to a
+ * point in the widest empty stretch of each periodic axis, modulo the period.  NULL arguments forget the box.  Without the
+ * call everything works, with uneven bricks in that situation.  No reference counterpart. */
+int isph_ctx_set_periodic_box(isph_ctx *ctx, const double lo[3], const double hi[3], const int periodic[3]);
+/* what the sort was made with: cell(a) = number of faces of axis a that are <= x_a (isph_mat_ordering_faces: ncell[a] - 1
+ * ascending doubles), brick(a) = cell(a) / cells_per_brick[a]; key = ((brick_z * nbrick[1] + brick_y) * nbrick[0] +
+ * brick_x) * (cells per brick) + (cz' * cpb[1] + cy') * cpb[0] + cx' with c' = cell mod cells_per_brick; rows ascend by
+ * key, ties in the caller's order.  The faces are quantiles of the owned particles' coordinates: face k of an axis is the
+ * upper edge lo + (j + 1) / inv_bin of the first bin j of the histogram bin(x) = clamp(floor((x - lo) * inv_bin), 0,
+ * nbins - 1) at which the cumulative count reaches ceil(k n / ncell). */
 typedef struct {
   int dim;
-  double lo[3], inv_cell[3];
-  int ncell[3], cells_per_brick[3], nbrick[3];
+  double lo[3], inv_bin[3];
+  int nbins[3], ncell[3], cells_per_brick[3], nbrick[3];
+  double shift[3], period[3]; /* every coordinate enters as t = x - shift, + period when t < 0 (isph_ctx_set_periodic_box; period 0: as is) */
 } isph_order_geometry;
 /* info: [0] 1 when A carries the library's numbering (0: the caller's) [1] rows [2] subdomains; geom may be NULL */
 int isph_mat_ordering_info(const isph_mat *A, long long info[3], isph_order_geometry *geom);
 /* perm[r] = the caller's row held by internal row r ([nrow], may be NULL); block_ptr [subdomains + 1] (may be NULL).
  * Fails for a matrix in the caller's numbering. */
 int isph_mat_ordering(isph_ctx *ctx, const isph_mat *A, int *perm, int *block_ptr);
+/* faces[0 .. ncell[axis] - 2] of one axis (host array of the caller) */
+int isph_mat_ordering_faces(const isph_mat *A, int axis, double *faces);
 
 /* ---- assembly --------------------------------------------------------- */
 

@@ -6,10 +6,11 @@ oracle when the device numbers its rows itself.  The reference has no counterpar
 (pair_isph.cpp:1258-1259) and its subdomains are the MPI bricks (precond_ifpack.h:60-74); the oracle is handed the same
 permutation and the same table explicitly and solves P A P^T (P x) = P b with block ILU on that table.
 
-  keys(x, geom)          the sort key of every owned particle from the geometry the library reports (isph_order_geometry)
-  order(x, geom)         perm: internal row r holds the caller's row perm[r] (stable sort of the keys)
+  keys(x, geom, faces)   the sort key of every owned particle from the geometry and the cell faces the library reports
+                         (isph_order_geometry, isph_mat_ordering_faces)
+  order(x, geom, faces)  perm: internal row r holds the caller's row perm[r] (stable sort of the keys)
   block_table(...)       the subdomains (over-full bricks split into equal consecutive pieces, empty ones dropped)
-  geometry(x, dim, n)    the geometry rule itself (bounding box -> spacing -> cells -> bricks)
+  geometry(x, dim)       the geometry rule itself (bounding box -> spacing -> cells -> histogram -> quantile faces -> bricks)
   permute_system(...)    P A P^T, P b with sorted columns
 """
 import math
@@ -23,20 +24,33 @@ TARGET = {3: (10, 10, 5), 2: (22, 22, 1)}
 
 def _geom(g):
     """accepts the ctypes isph_order_geometry or anything with the same attributes"""
-    return SimpleNamespace(dim=int(g.dim), lo=np.array(list(g.lo), dtype=np.float64), inv_cell=np.array(list(g.inv_cell), dtype=np.float64),
+    return SimpleNamespace(dim=int(g.dim), lo=np.array(list(g.lo), dtype=np.float64), inv_bin=np.array(list(g.inv_bin), dtype=np.float64),
+                           nbins=np.array(list(g.nbins), dtype=np.int64),
                            ncell=np.array(list(g.ncell), dtype=np.int64), cpb=np.array(list(g.cells_per_brick), dtype=np.int64),
                            nbrick=np.array(list(g.nbrick), dtype=np.int64))
 
 
-def keys(x, geom):
-    """order.hpp order_key: cell = clamp(floor((x - lo) * inv_cell)), brick = cell // cpb, key = brick-major, x fastest"""
+def coords(x, geom):
+    """order.hpp order_coord: t = x - shift, + period when negative, on the axes the caller declared periodic"""
+    x = np.array(x, dtype=np.float64, copy=True)
+    sh, pe = list(getattr(geom, "shift", [0.0] * 3)), list(getattr(geom, "period", [0.0] * 3))
+    for a in range(min(3, x.shape[1])):
+        t = x[:, a] - sh[a]
+        if pe[a] > 0.0:
+            t = np.where(t < 0.0, t + pe[a], t)
+        x[:, a] = t
+    return x
+
+
+def keys(x, geom, faces):
+    """order.hpp order_key: cell(a) = number of faces of axis a that are <= x_a, brick = cell // cpb, key = brick-major,
+    x fastest"""
     g = _geom(geom)
-    x = np.asarray(x, dtype=np.float64)
+    x = coords(x, geom)
     b = np.zeros((len(x), 3), dtype=np.int64)
     c = np.zeros((len(x), 3), dtype=np.int64)
     for a in range(g.dim):
-        t = (x[:, a] - g.lo[a]) * g.inv_cell[a]            # one subtraction, one multiplication: nothing to contract
-        q = np.clip(np.floor(t).astype(np.int64), 0, g.ncell[a] - 1)
+        q = np.searchsorted(np.asarray(faces[a], dtype=np.float64), x[:, a], side="right").astype(np.int64)
         b[:, a] = q // g.cpb[a]
         c[:, a] = q - b[:, a] * g.cpb[a]
     brick = (b[:, 2] * g.nbrick[1] + b[:, 1]) * g.nbrick[0] + b[:, 0]
@@ -44,16 +58,38 @@ def keys(x, geom):
     return brick * int(g.cpb[0] * g.cpb[1] * g.cpb[2]) + cell, brick
 
 
-def order(x, geom):
-    k, _ = keys(x, geom)
+def order(x, geom, faces):
+    k, _ = keys(x, geom, faces)
     return np.argsort(k, kind="stable").astype(np.int32)
 
 
-def block_table(x, geom, perm=None):
+def faces_from_histogram(x, geom):
+    """order.hpp order_faces: per axis the histogram bin(x) = clamp(floor((x - lo) * inv_bin)), and face k = upper edge of
+    the first bin at which the cumulative count reaches ceil(k n / ncell)"""
+    g = _geom(geom)
+    x = coords(x, geom)
+    n = len(x)
+    out = []
+    for a in range(3):
+        if a >= g.dim or g.ncell[a] <= 1:
+            out.append(np.zeros(0))
+            continue
+        t = (x[:, a] - g.lo[a]) * g.inv_bin[a]             # one subtraction, one multiplication: nothing to contract
+        bins = np.clip(np.floor(t).astype(np.int64), 0, g.nbins[a] - 1)
+        cum = np.cumsum(np.bincount(bins, minlength=int(g.nbins[a])))
+        nc = int(g.ncell[a])
+        targets = (np.arange(1, nc, dtype=np.int64) * n + nc - 1) // nc
+        j = np.searchsorted(cum, targets, side="left")       # first bin with cum >= target
+        j = np.minimum(j, g.nbins[a] - 1)
+        out.append(g.lo[a] + (j + 1).astype(np.float64) / g.inv_bin[a])
+    return out
+
+
+def block_table(x, geom, faces, perm=None):
     """order.hpp order_block_table from the sorted brick numbers"""
-    _, brick = keys(x, geom)
+    _, brick = keys(x, geom, faces)
     if perm is None:
-        perm = order(x, geom)
+        perm = order(x, geom, faces)
     sb = brick[perm]
     n = len(sb)
     starts = np.flatnonzero(np.r_[True, sb[1:] != sb[:-1]]) if n else np.zeros(0, dtype=np.int64)
@@ -73,7 +109,7 @@ def block_table(x, geom, perm=None):
 def geometry(x, dim):
     """order.hpp order_geometry, for checks of the rule (the tests feed keys() the geometry the library REPORTS, so a last-bit
     difference of pow() between two C libraries cannot move a particle across a cell face)"""
-    x = np.asarray(x, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)                      # (callers pass coords(x, geom) when a periodic box was declared)
     n = len(x)
     mn, mx = x.min(axis=0), x.max(axis=0)
     ext = np.maximum(mx - mn, 0.0)[:dim]
@@ -85,7 +121,7 @@ def geometry(x, dim):
         d = dn
         if done:
             break
-    out = SimpleNamespace(dim=dim, lo=[0.0] * 3, inv_cell=[0.0] * 3, ncell=[1] * 3, cells_per_brick=[1] * 3, nbrick=[1] * 3, spacing=d)
+    out = SimpleNamespace(dim=dim, lo=[0.0] * 3, inv_bin=[0.0] * 3, nbins=[1] * 3, ncell=[1] * 3, cells_per_brick=[1] * 3, nbrick=[1] * 3, spacing=d)
     for a in range(dim):
         ln = ext[a] + d
         cells = min(max(int(math.floor(ln / d + 0.5)), 1), 1 << 20)
@@ -93,7 +129,8 @@ def geometry(x, dim):
         cpb = (cells + nb - 1) // nb
         out.ncell[a], out.cells_per_brick[a], out.nbrick[a] = cells, cpb, (cells + cpb - 1) // cpb
         out.lo[a] = mn[a] - 0.5 * d
-        out.inv_cell[a] = cells / ln
+        out.nbins[a] = min(64 * cells, 1 << 20)
+        out.inv_bin[a] = out.nbins[a] / ln
     return out
 
 

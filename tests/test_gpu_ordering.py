@@ -66,9 +66,9 @@ def test_matrix_in_the_callers_numbering_whatever_the_atom_order(octx, dim, n):
         assert o is not None
         nl = parts["nlocal"]
         # the permutation is the stable sort of the documented key; the table covers the rows
-        perm = oorder.order(parts["x"][:nl], o["geom"])
+        perm = oorder.order(parts["x"][:nl], o["geom"], o["faces"])
         assert np.array_equal(perm, o["perm"]), name
-        bp = oorder.block_table(parts["x"][:nl], o["geom"], perm)
+        bp = oorder.block_table(parts["x"][:nl], o["geom"], o["faces"], perm)
         assert np.array_equal(bp, o["block_ptr"]), name
         sizes = np.diff(bp)
         assert bp[0] == 0 and bp[-1] == nl and sizes.min() >= 1 and sizes.max() <= 1024
@@ -77,6 +77,11 @@ def test_matrix_in_the_callers_numbering_whatever_the_atom_order(octx, dim, n):
         assert list(g.ncell[:dim]) == [n] * dim == list(o["geom"].ncell)[:dim]
         assert list(g.cells_per_brick) == list(o["geom"].cells_per_brick) and list(g.nbrick) == list(o["geom"].nbrick)
         assert np.allclose(g.lo[:dim], list(o["geom"].lo)[:dim], rtol=0, atol=1e-12)
+        # the cell faces are the quantile rule applied to the histogram of the reported grid
+        fr = oorder.faces_from_histogram(parts["x"][:nl], o["geom"])
+        for a in range(dim):
+            assert np.array_equal(fr[a], o["faces"][a]), (name, a)
+            assert np.all(np.diff(o["faces"][a]) >= 0)
         # rows by position: the internal matrix does not depend on the atom order it was handed in
         rpi, cii, vi, _ = oorder.permute_system(rp, ci, val, None, o["perm"])
         internal.append((name, rpi, cii, vi, parts["x"][:nl][o["perm"]]))
@@ -222,9 +227,97 @@ def test_caller_tables_and_the_librarys_numbering_do_not_mix(octx, gpu_ctx):
     A2.close()
 
 
-def test_clustered_cloud_splits_over_full_bricks(octx):
-    """a cloud with a dense clump: the bricks of the clump hold more than 1024 particles and are cut into consecutive
-    pieces; every subdomain stays within 1..1024 rows and the solve converges like the oracle's on the same table"""
+def test_periodic_box_reunites_planes_that_wrapped_around(octx):
+    """isph_ctx_set_periodic_box.  A lattice whose particles have moved a little and been wrapped into [0, L), as LAMMPS
+    does at every re-neighbouring: half of plane 0 sits at +eps, the other half at L - eps.  Without the box the bounding
+    box grows by a spacing and the bricks hold 10.5 planes at the ends of every axis (uneven subdomains, all of which pay
+    for the largest one's LDS); with it the cut goes into an empty stretch and every brick is 10 x 10 x 5 again.  Matrix
+    and permutation stay exact either way."""
+    spec = tgv_spec(dim=3, n=20, mode=workload.LATTICE)
+    base = workload.make_tgv(spec)
+    nl = base["nlocal"]
+    L = 2 * np.pi
+    rng = np.random.default_rng(5)
+    x = base["x"][:nl] + rng.uniform(-0.02, 0.02, size=(nl, 3)) * spec.dx
+    parts = workload.make_cloud(x, (L, L, L), spec.h, spec.cut, like=base)          # wraps into [0, L)
+    assert parts["x"][:nl, 0].max() > L - 0.03 * spec.dx and parts["x"][:nl, 0].min() < 0.03 * spec.dx
+    parts["v"] = np.zeros((parts["nall"], 3))
+    parts["v"][:, 0] = np.sin(parts["x"][:, 0])
+    colmap = parts["owner_index"].astype(np.int32)
+    P = orc.Particles(parts, colmap, kernel=spec.kernel).precompute(corrections=False)
+    rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True)
+    sizes = {}
+    try:
+        for label, box in (("without", None), ("with", ((0, 0, 0), (L, L, L), (1, 1, 1)))):
+            if box is None:
+                octx.set_periodic_box()
+            else:
+                octx.set_periodic_box(*box)
+            A, bg = hip.assemble_poisson(octx, parts, colmap, spec.dt, parts["rho"], np.ascontiguousarray(parts["v"]), vfrac=P.vfrac)
+            rp2, ci2, v2 = A.export_csr()
+            assert np.array_equal(ci2, ci) and np.max(np.abs(v2 - val)) <= 1e-12 * np.abs(val).max(), label
+            o = A.ordering()
+            assert np.array_equal(o["perm"], oorder.order(parts["x"][:nl], o["geom"], o["faces"])), label
+            fr = oorder.faces_from_histogram(parts["x"][:nl], o["geom"])
+            assert all(np.array_equal(fr[a], o["faces"][a]) for a in range(3)), label
+            sizes[label] = np.diff(o["block_ptr"])
+            A.close()
+    finally:
+        octx.set_periodic_box()
+    assert sizes["with"].min() == sizes["with"].max() == 500 and len(sizes["with"]) == 16
+    assert sizes["without"].max() > 500
+
+
+def test_correlated_cloud_splits_over_full_bricks(octx):
+    """a 2-D band along the diagonal of the box: every axis sees a uniform distribution, so the quantile faces cannot thin
+    the diagonal bricks out -- they hold more than 1024 particles and are cut into consecutive pieces (the table keeps
+    1..1024 rows per subdomain); matrix exact, solve like the oracle's on the same table"""
+    nlat, band = 128, 16
+    L = 2 * np.pi
+    dx = L / nlat
+    ii, jj = np.meshgrid(np.arange(nlat), np.arange(nlat), indexing="ij")
+    keep = (np.abs(((ii - jj + nlat // 2) % nlat) - nlat // 2) <= band).ravel()
+    x = np.zeros((int(keep.sum()), 3))
+    x[:, 0] = (ii.ravel()[keep] + 0.5) * dx
+    x[:, 1] = (jj.ravel()[keep] + 0.5) * dx
+    x[:, :2] += np.random.default_rng(3).uniform(-0.05, 0.05, size=(len(x), 2)) * dx
+    spec = tgv_spec(dim=2, n=nlat, mode=workload.LATTICE)
+    like = workload.make_tgv(tgv_spec(dim=2, n=16, mode=workload.LATTICE))
+    parts = workload.make_cloud(x, (L, L), spec.h, spec.cut, dim=2)
+    nl = parts["nlocal"]
+    parts.update(spec=spec, rho=np.ones(parts["nall"]), nu=np.full(parts["nall"], 0.1), dt=spec.dt)
+    parts["v"] = np.zeros((parts["nall"], 3))
+    parts["v"][:, 0] = np.sin(parts["x"][:, 0]) * np.cos(parts["x"][:, 1])
+    colmap = parts["owner_index"].astype(np.int32)
+    P = orc.Particles(parts, colmap, kernel=spec.kernel).precompute(corrections=False)
+    rp, ci, val, b = P.poisson(spec.dt, parts["rho"], parts["v"], antisym=True)
+    A, bg = hip.assemble_poisson(octx, parts, colmap, spec.dt, parts["rho"], np.ascontiguousarray(parts["v"]), vfrac=P.vfrac)
+    rp2, ci2, v2 = A.export_csr()
+    assert np.array_equal(ci2, ci) and np.max(np.abs(v2 - val)) <= 1e-12 * np.abs(val).max()
+    o = A.ordering()
+    sizes = np.diff(o["block_ptr"])
+    assert sizes.min() >= 1 and sizes.max() <= 1024 and o["block_ptr"][-1] == nl
+    _, brick = oorder.keys(parts["x"][:nl], o["geom"], o["faces"])
+    assert np.bincount(brick).max() > 1024                                 # the rule met an over-full brick ...
+    assert len(sizes) > len(np.unique(brick))                              # ... and cut it
+    assert np.array_equal(o["block_ptr"], oorder.block_table(parts["x"][:nl], o["geom"], o["faces"], o["perm"]))
+    M = hip.Precond(octx, A, "bjacobi-ilu0", 0)
+    rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
+    ref = orc.ILU(rpi, cii, vi, 0, o["block_ptr"])
+    xoi, io, _ = orc.solve(rpi, cii, vi, bi, singular=True, prec="ilu", ilu=ref)
+    bb, xg = bg.copy(), np.zeros(nl)
+    info = hip.solve(octx, A, bb, xg, prec=M, singular=True)
+    assert info.converged == io.converged == 1 and abs(info.iters - io.iters) <= 1, (info.iters, io.iters)
+    xo = np.empty(nl)
+    xo[o["perm"]] = xoi
+    assert np.linalg.norm(xg - xo) / np.linalg.norm(xo) <= 1e-6
+    M.close(); A.close()
+
+
+def test_clustered_cloud_keeps_subdomains_within_bounds(octx):
+    """a cloud with a dense clump: the quantile faces thin the bricks of the clump out along every axis; whatever is left
+    above 1024 particles is cut into consecutive pieces; every subdomain stays within 1..1024 rows and the solve converges
+    like the oracle's on the same table"""
     rng = np.random.default_rng(2)
     spec = tgv_spec(dim=3, n=16, mode=workload.JITTER)
     base = workload.make_tgv(spec)
@@ -245,9 +338,7 @@ def test_clustered_cloud_splits_over_full_bricks(octx):
     o = A.ordering()
     sizes = np.diff(o["block_ptr"])
     assert sizes.min() >= 1 and sizes.max() <= 1024 and o["block_ptr"][-1] == nl
-    _, brick = oorder.keys(parts["x"][:nl], o["geom"])
-    assert np.bincount(brick).max() > 1024                                 # the rule met an over-full brick ...
-    assert len(sizes) > len(np.unique(brick))                              # ... and cut it
+    assert np.array_equal(o["block_ptr"], oorder.block_table(parts["x"][:nl], o["geom"], o["faces"], o["perm"]))
     M = hip.Precond(octx, A, "bjacobi-ilu0", 0)
     rpi, cii, vi, bi = oorder.permute_system(rp, ci, val, b, o["perm"])
     ref = orc.ILU(rpi, cii, vi, 0, o["block_ptr"])

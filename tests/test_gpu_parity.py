@@ -287,7 +287,7 @@ def test_config1_full_size_100cubed(gpu_ctx_bricks):
     o = A.ordering()
     sizes = np.diff(o["block_ptr"])
     assert len(sizes) == 2000 and sizes.min() == sizes.max() == 500     # 10 x 10 x 5 bricks tile the lattice
-    assert np.array_equal(o["perm"], oorder.order(p["x"][:n], o["geom"]))
+    assert np.array_equal(o["perm"], oorder.order(p["x"][:n], o["geom"], o["faces"]))
     M = hip.Precond(ctx, A, "bjacobi-ilu0", 0)
     x, bb = np.zeros(n), b.copy()
     info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
