@@ -39,8 +39,8 @@ class RankGroup:
         self._ranks.append((h, t))
         return t
 
-    def context(self, rank, device=0):
-        return hip.Context(device, rank=rank, nranks=self.n, transport=self.transport(rank))
+    def context(self, rank, device=0, ordering=None):
+        return hip.Context(device, rank=rank, nranks=self.n, transport=self.transport(rank), ordering=ordering)
 
     def td(self, rank):
         """the two torch.distributed calls isph_amd.dist uses at plan time, between the rank threads"""

@@ -31,7 +31,7 @@ def _spec(dim, pgrid, n, rank=None):
     return workload.TGVSpec(**kw)
 
 
-def _rank_setup(rank, G, dim, pgrid, n, singular):
+def _rank_setup(rank, G, dim, pgrid, n, singular, ordering=None):
     """particles, plan, context, volumes with forward comm, assembled Poisson system of one rank"""
     nreal = int(np.prod(pgrid[:dim]))
     if rank < nreal:
@@ -41,7 +41,7 @@ def _rank_setup(rank, G, dim, pgrid, n, singular):
         spec = _spec(dim, pgrid, n, 0)
         parts = empty_parts(spec, rank)
     plan = dist.make_plan(parts, G.td(rank))
-    ctx = G.context(rank)
+    ctx = G.context(rank, ordering=ordering)
     nl = int(parts["nlocal"])
     fwd = hip.HaloForward(ctx, nl, plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
     vf = hip.compute_volumes(ctx, parts, plan.colmap)
@@ -154,6 +154,59 @@ def test_distributed_fgmres_bjacobi_ilu0_matches_the_single_rank_oracle(dim, pgr
     assert cnt["exchanges"] > world * iters and cnt["allreduces"] > world * iters
     print("ranks %d grid %s: iterations %d (oracle %d), %d exchanges, %d all-reduces" % (world, pgrid, iters, io.iters,
                                                                                          cnt["exchanges"], cnt["allreduces"]))
+
+
+def _solve_on_library_bricks(rank, G, dim, pgrid, n):
+    st = _rank_setup(rank, G, dim, pgrid, n, orc.NULLSPACE, ordering="bricks")
+    ctx, A = st["ctx"], st["A"]
+    try:
+        o = A.ordering()
+        M = hip.Precond(ctx, A, "bjacobi-ilu0", 0)             # every rank's own bricks
+        x, bb = np.zeros(st["nl"]), st["b"].copy()
+        info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
+        y = A.spmv(x)
+        M.close()
+        return dict(st, x=x, y=y, bproj=bb, perm=o["perm"], bptr=o["block_ptr"], info=(info.converged, info.iters), ctx=None, A=None, parts=None)
+    finally:
+        A.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("pgrid,n", [((2, 1, 1), 10), ((2, 2, 1), 10)])
+def test_distributed_solve_in_the_librarys_row_numbering(pgrid, n):
+    """isph_ctx_set_ordering(BRICKS) on more than one rank: every rank sorts ITS particles into bricks, ghost columns keep the
+    numbering of the halo plan and isph_mat_set_halo translates the send list.  Rows exported in the caller's numbering =
+    the single-rank oracle's; the oracle is handed every rank's permutation and subdomain table (block-diagonal P over the
+    rank-concatenated system) and must need the same iterations and give the same pressure."""
+    dim = 3
+    world = int(np.prod(pgrid))
+    G = RankGroup(world)
+    try:
+        res = G.run(_solve_on_library_bricks, dim, pgrid, n)
+    finally:
+        G.close()
+    O = GlobalOracle(dim, pgrid, n, orc.NULLSPACE, [r["rtag"] for r in res])
+    O.check_rows(res)                                             # exported in the caller's numbering, ghost columns by tag
+    gperm = np.concatenate([O.off[r] + res[r]["perm"].astype(np.int64) for r in range(world)])
+    gbp = np.concatenate([[0]] + [O.off[r] + res[r]["bptr"][1:].astype(np.int64) for r in range(world)]).astype(np.int32)
+    assert all(np.diff(res[r]["bptr"]).max() <= 1024 for r in range(world))
+    App = O.Ap[gperm][:, gperm].tocsr()
+    App.sort_indices()
+    ilu = orc.ILU(App.indptr, App.indices, App.data, 0, gbp)
+    xoi, io, _ = orc.solve(App.indptr, App.indices, App.data, O.bp[gperm], singular=True, prec="ilu", ilu=ilu)
+    xo = np.empty(O.N)
+    xo[gperm] = xoi
+    infos = {r["info"] for r in res}
+    assert len(infos) == 1, infos
+    conv, iters = infos.pop()
+    assert conv == 1 and io.converged == 1 and abs(iters - io.iters) <= 1, (iters, io.iters)
+    x = np.concatenate([r["x"] for r in res])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-6
+    y = np.concatenate([r["y"] for r in res])
+    assert np.max(np.abs(y - O.Ap @ x)) <= 1e-11 * O.scale * np.abs(x).max()     # halo SpMV in the caller's numbering == global operator
+    bb = np.concatenate([r["bproj"] for r in res])
+    rres = bb - (y - y.mean())
+    assert np.linalg.norm(rres) / np.linalg.norm(bb) < 2e-8
 
 
 @pytest.mark.parametrize("mode", [orc.PINZERO, orc.DOUBLEDIAG])
