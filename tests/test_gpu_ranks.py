@@ -428,8 +428,8 @@ def test_cpp_mirror_on_mpi_ranks_sharing_one_gpu(tmp_path, pgrid, mode):
 AMG_KW = dict(theta=0.02, block=256, coarse_max=64)
 
 
-def _solve_amg(rank, G, dim, pgrid, n, mode, sweeps, kw=None):
-    st = _rank_setup(rank, G, dim, pgrid, n, mode)
+def _solve_amg(rank, G, dim, pgrid, n, mode, sweeps, kw=None, ordering=None):
+    st = _rank_setup(rank, G, dim, pgrid, n, mode, ordering=ordering)
     ctx, A = st["ctx"], st["A"]
     try:
         nullvec = None
@@ -564,16 +564,18 @@ def test_amg_coarse_levels_across_ranks(mode, sweeps):
     print("AMG with coarse levels across 4 ranks: iterations %d (block-Jacobi ILU(0): %d)" % (iters, io.iters))
 
 
-@pytest.mark.parametrize("mode", [orc.DOUBLEDIAG, orc.NULLSPACE])
-def test_amg_deeper_hierarchy_across_eight_ranks(mode):
+@pytest.mark.parametrize("mode,ordering", [(orc.DOUBLEDIAG, "caller"), (orc.NULLSPACE, "caller"), (orc.NULLSPACE, "bricks")])
+def test_amg_deeper_hierarchy_across_eight_ranks(mode, ordering):
     """2x2x2 ranks, every rank with seven different peers, coarse_max small enough for three or more levels: every level
     below the fine one has its own halo plan, derived from the level above.  All ranks report the same depth, iteration
-    count and convergence; the solution is the single-rank oracle's (ILU-preconditioned) to 1e-6."""
+    count and convergence; the solution is the single-rank oracle's (ILU-preconditioned) to 1e-6.  ordering "bricks": the
+    hierarchy is built on matrices in the library's own row numbering (every rank sorts its particles; the null vector and
+    the vectors of the solve cross the C ABI in the caller's numbering)."""
     dim, pgrid, n = 3, (2, 2, 2), 16
     kw = dict(theta=0.02, block=256, coarse_max=8)
     G = RankGroup(8)
     try:
-        res = G.run(_solve_amg, dim, pgrid, n, mode, 1, kw)
+        res = G.run(_solve_amg, dim, pgrid, n, mode, 1, kw, ordering)
     finally:
         G.close()
     O = GlobalOracle(dim, pgrid, n, mode, [q["rtag"] for q in res])
@@ -617,10 +619,11 @@ def test_amg_with_a_rank_that_cannot_coarsen():
 # ------------------------------------------------------------------ BASELINE configs[2] at its own size, on one GPU
 def _config2_rank(rank, G, n, pgrid=(2, 2, 2), prec="bjacobi-ilu0"):
     import time
-    spec = workload.TGVSpec(dim=3, ncell=tuple(n * g for g in pgrid), pgrid=pgrid, rank=rank, brick=(10, 10, 5), mode=workload.ADVECT)
+    # atoms in lexicographic order over the rank's brick (create_atoms); the library numbers the rows (the product default)
+    spec = workload.TGVSpec(dim=3, ncell=tuple(n * g for g in pgrid), pgrid=pgrid, rank=rank, brick=(n, n, n), mode=workload.ADVECT)
     parts = dist.prune_ghosts(workload.make_tgv(spec))
     plan = dist.make_plan(parts, G.td(rank))
-    ctx = G.context(rank)
+    ctx = G.context(rank, ordering="bricks")
     nl = int(parts["nlocal"])
     try:
         fwd = hip.HaloForward(ctx, nl, plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
@@ -630,13 +633,14 @@ def _config2_rank(rank, G, n, pgrid=(2, 2, 2), prec="bjacobi-ilu0"):
         A, b = hip.assemble_poisson(ctx, parts, plan.colmap, spec.dt, parts["rho"], np.ascontiguousarray(parts["v"]), vfrac=vfrac,
                                     ncol=plan.ncol, rank0=(rank == 0))
         A.set_halo(plan.peers, plan.send_ptr, plan.send_idx, plan.recv_ptr)
-        bp = np.arange(0, nl + 500, 500).clip(0, nl).astype(np.int32)
+        sub = np.diff(A.subdomains())
+        assert len(sub) == nl // 500 and sub.min() == sub.max() == 500     # 10 x 10 x 5 bricks tile every rank's 100^3
         x, bb = np.zeros(nl), b.copy()
         t0 = time.perf_counter()
         if prec == "sa-amg":                                # setNullVector: the normalised mask of all ranks
             M = hip.PrecondAMG(ctx, A, nullvec=np.full(nl, 1.0 / np.sqrt(float(nl) * float(np.prod(pgrid)))))
         else:
-            M = hip.Precond(ctx, A, "bjacobi-ilu0", block_ptr=bp)
+            M = hip.Precond(ctx, A, "bjacobi-ilu0", 0)
         info = hip.solve(ctx, A, bb, x, prec=M, singular=True)
         wall = time.perf_counter() - t0
         y = A.spmv(x)                                  # distributed product for the explicit residual of the global system
