@@ -561,21 +561,41 @@ class Case:
         self.A, self.b = self.assemble()
         torch.cuda.synchronize()
         self.assemble_ms = (time.perf_counter() - t0) * 1e3
+        # the same once more with a synchronisation between computePre's volumes and the matrix assembly, for the split
+        self.A.close()
+        self.A, self.b = self.assemble(split=True)
         self.x = torch.zeros(nlocal, dtype=torch.float64, device=dev)
         self.bwork = torch.empty_like(self.b)
         self.prm = hip.SolverParams()
         self.pinfo = {}
         self.nullvec = torch.full((nlocal,), 1.0 / np.sqrt(float(nlocal * world)), dtype=torch.float64, device=dev)
 
-    def assemble(self):
+    def assemble(self, split=False):
+        import torch
         from isph_amd import hip, dist
         env, args = self.env, self.env["args"]
         ctx = env["ctx"]
+        if split:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         vf = hip.compute_volumes(ctx, self.dparts, self.colmap, kernel=args.kernel)
         if self.fwd is None:
             vfrac = vf[self.own].contiguous()
         else:
             vfrac = dist.forward_scalar_rccl(self.fwd, self.plan, vf)   # forward_comm_pair of Vfrac over the library's RCCL comm
+        if split:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            A, b = self._assemble_matrix(vfrac)
+            torch.cuda.synchronize()
+            self.assemble_split_ms = {"compute_volumes_and_forward": (t1 - t0) * 1e3, "assemble_poisson": (time.perf_counter() - t1) * 1e3}
+            return A, b
+        return self._assemble_matrix(vfrac)
+
+    def _assemble_matrix(self, vfrac):
+        from isph_amd import hip
+        env, args = self.env, self.env["args"]
+        ctx = env["ctx"]
         A, b = hip.assemble_poisson(ctx, self.dparts, self.colmap, self.spec.dt, self.rho, self.vstar, vfrac=vfrac,
                                     ncol=self.plan.ncol, kernel=args.kernel, rank0=(env["rank"] == 0))
         if self.plan.npeers:
@@ -857,6 +877,7 @@ def main():
                                        if args.share_gpu else "RCCL halo + all-reduce"),
                        "iterations": inf.iters, "restarts": inf.restarts, "converged": inf.converged,
                        "rel_res": inf.rel_res_implicit, "assemble_ms": assemble_ms, "assemble_first_call_ms": assemble_first_ms,
+                       "assemble_split_ms": case.assemble_split_ms,
                        "spmv_isolated_ms": iso_ms, ("amg" if args.prec == "sa-amg" else "ilu"): pinfo},
             "roofline": {"bound": "hbm", "kernel": "k_sell_spmv16<8,false> (SELL-64, 16-bit window columns)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -943,7 +964,7 @@ def main():
             table = {}
             head_key = "%s/%s" % (args.order, "library" if lib_order else "caller")
             table[head_key] = dict(ms_per_solve=elapsed / args.steps * 1e3, iterations=int(inf.iters), converged=int(inf.converged),
-                                   assemble_ms=assemble_ms, subdomains=case.subdomains(), headline=True)
+                                   assemble_ms=assemble_ms, assemble_split_ms=case.assemble_split_ms, subdomains=case.subdomains(), headline=True)
             for order in ("lexicographic", "sortbin", "shuffled", "bricks"):
                 for lib in (True, False):
                     key = "%s/%s" % (order, "library" if lib else "caller")
@@ -952,7 +973,7 @@ def main():
                     c = Case(env, order, lib)
                     ms, ia = c.timed(3, 2)
                     table[key] = dict(ms_per_solve=ms, iterations=int(ia.iters), converged=int(ia.converged), assemble_ms=c.assemble_ms,
-                                      subdomains=c.subdomains())
+                                      assemble_split_ms=c.assemble_split_ms, subdomains=c.subdomains())
                     c.close()
             ctx.set_ordering("bricks" if lib_order else "caller")
             extra["atom_orders"] = dict(note="<atom order handed over>/<who numbers the matrix rows>; 3 timed solves after 2, same "
