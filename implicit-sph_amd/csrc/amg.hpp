@@ -115,7 +115,7 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 
 // SELL -> CSR, one wave per slice: a lane reads its own row (coalesced across the wave), kCsrChunk entries per
 // round are staged in LDS and kCsrChunk consecutive lanes write one row's piece of the row-major destination
-constexpr int kCsrChunk = 8;
+constexpr int kCsrChunk = 16;  // (8 until r5: 64-byte row pieces; 16 gives 128-byte value pieces per row: 1.17 -> see docs/kernels_detail.md)
 __global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__restrict__ rowlen,
                                                          const long long *__restrict__ slice_off,
                                                          const int *__restrict__ scol, const double *__restrict__ sval,
