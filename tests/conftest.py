@@ -49,3 +49,10 @@ def gpu_ctx_bricks():
     ctx = hip.Context(0, ordering="bricks")
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(params=["caller", "bricks"])
+def gpu_ctx_both(request, gpu_ctx, gpu_ctx_bricks):
+    """the same test in the caller's row numbering and in the library's own (everything these tests look at crosses the
+    C ABI in the caller's numbering: exported matrices, right-hand sides, solutions)"""
+    return gpu_ctx if request.param == "caller" else gpu_ctx_bricks

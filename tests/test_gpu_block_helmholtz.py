@@ -42,7 +42,8 @@ def _inputs(pr):
 @pytest.mark.parametrize("dim,n", [(2, 24), (3, 12)])
 @pytest.mark.parametrize("antisym", [True, False])
 @pytest.mark.parametrize("morris", [False, True])
-def test_block_helmholtz_matches_oracle(gpu_ctx, dim, n, antisym, morris):
+def test_block_helmholtz_matches_oracle(gpu_ctx_both, dim, n, antisym, morris):
+    gpu_ctx = gpu_ctx_both
     kinds = [orc.FLUID, orc.SOLID]
     pr = Problem(tgv_spec(dim=dim, n=n, mode=workload.JITTER, brick=4), antisym=antisym, kinds=kinds, types=wall_types,
                  pnd=fake_pnd if morris else None, normal=lambda parts: band_normals(parts, dim))
@@ -77,7 +78,8 @@ def test_block_helmholtz_matches_oracle(gpu_ctx, dim, n, antisym, morris):
     assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
 
 
-def test_block_helmholtz_without_normals_is_block_diagonal(gpu_ctx):
+def test_block_helmholtz_without_normals_is_block_diagonal(gpu_ctx_both):
+    gpu_ctx = gpu_ctx_both
     """no wall normals: off-diagonal blocks are not created and the (Fluid,Solid) rows go to block (0,0) only,
     as the reference writes it (functor_laplacian_matrix.h:269-271)."""
     kinds = [orc.FLUID, orc.SOLID]

@@ -708,7 +708,8 @@ def test_cpp_ifpack_overlap_level_one_through_the_importer(tmp_path):
                                   dict(dim=2, n=4, mode=workload.JITTER, brick=0)])
 @pytest.mark.parametrize("antisym", [True, False])
 @pytest.mark.parametrize("theta", [0.0, 0.5, 1.0])
-def test_gpu_helmholtz_matches_oracle(gpu_ctx, case, antisym, theta):
+def test_gpu_helmholtz_matches_oracle(gpu_ctx_both, case, antisym, theta):
+    gpu_ctx = gpu_ctx_both
     pr = Problem(tgv_spec(**case), antisym=antisym)
     p = pr.parts
     x, nall = p["x"], p["nall"]
@@ -734,7 +735,8 @@ def test_gpu_helmholtz_matches_oracle(gpu_ctx, case, antisym, theta):
     assert A0 is None and np.max(np.abs(b0 - bg)) <= 1e-13 * np.abs(bg).max()   # unsorted neighbour sums: round-off only
 
 
-def test_helmholtz_solve_three_rhs(gpu_ctx):
+def test_helmholtz_solve_three_rhs(gpu_ctx_both):
+    gpu_ctx = gpu_ctx_both
     """computeHelmholtz + solveProblem("Helmholtz") with x0 = v^n (pair_isph.cpp:932-971), theta = 0.5."""
     pr = Problem(tgv_spec(dim=3, n=12, mode=workload.JITTER))
     p = pr.parts

@@ -118,7 +118,8 @@ def test_oracle_applied_potential_is_what_the_functor_promises(antisym):
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("antisym", [True, False])
 @pytest.mark.parametrize("theta", [0.0, 0.5, 1.0])
-def test_gpu_solute_transport_rows_match_oracle(gpu_ctx, case, antisym, theta):
+def test_gpu_solute_transport_rows_match_oracle(gpu_ctx_both, case, antisym, theta):
+    gpu_ctx = gpu_ctx_both
     from isph_amd import hip
     pr = Problem(tgv_spec(**case), antisym=antisym, kinds=KINDS, types=zone_types)
     p, n = pr.parts, pr.n
@@ -138,7 +139,8 @@ def test_gpu_solute_transport_rows_match_oracle(gpu_ctx, case, antisym, theta):
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("antisym", [True, False])
 @pytest.mark.parametrize("with_sigma", [True, False])
-def test_gpu_applied_potential_rows_match_oracle(gpu_ctx, case, antisym, with_sigma):
+def test_gpu_applied_potential_rows_match_oracle(gpu_ctx_both, case, antisym, with_sigma):
+    gpu_ctx = gpu_ctx_both
     from isph_amd import hip
     pr = Problem(tgv_spec(**case), antisym=antisym, kinds=KINDS, types=zone_types)
     p, n = pr.parts, pr.n
@@ -181,7 +183,8 @@ def test_gpu_applied_potential_between_two_buffers_is_linear(gpu_ctx, dim, n):
 
 
 @pytest.mark.gpu
-def test_gpu_solute_transport_step_matches_oracle_solve_and_conserves_a_uniform_field(gpu_ctx):
+def test_gpu_solute_transport_step_matches_oracle_solve_and_conserves_a_uniform_field(gpu_ctx_both):
+    gpu_ctx = gpu_ctx_both
     """computeSoluteTransport: one theta = 0.5 step.  The solve equals the oracle's solve of the oracle's rows; a uniform
     concentration is a fixed point (zero row sums of the Laplacian on the Fluid rows, unit rows elsewhere)."""
     from isph_amd import hip
