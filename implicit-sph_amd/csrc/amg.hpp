@@ -52,6 +52,7 @@ struct AmgLevel {
   isph_mat *APm = nullptr;   // A P of the set-up, kept when the level has no halo: residual update after the coarse correction
   DCsr R;                    // restriction P^T in CSR: its rows are hundreds of entries long, one wave per row
   isph_ilu *sgs = nullptr;   // block-local symmetric Gauss-Seidel in stream form
+  DevBuf<double> wsgs;       // small coarse levels: the same smoother as dense 64 x 64 inverses (k_sgs_dense_build)
   DevBuf<int> agg;
   DevBuf<double> nv, x, b, r, z;
 };
@@ -182,6 +183,35 @@ __global__ void k_strong_cols(int n, const rp_t *__restrict__ rp, const int *__r
     const int j = ci[p];
     sc[p] = AMG_STRONG(v[p], i, j) ? j : -1;
   }
+}
+
+// threshold 0 (the wrapper's default): ONE sweep over A instead of four -- the diagonal (k_amg_diag), the strong
+// columns (k_strong_cols), the first MIS keys (k_mis_init) and rho (k_amg_rho), each with the arithmetic of the kernel
+// it stands for
+__global__ __launch_bounds__(256) void k_amg_prepare(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
+                                                     const double *__restrict__ v, double *__restrict__ dg, int *__restrict__ sc,
+                                                     unsigned long long *__restrict__ key, volatile unsigned long long *rho_bits) {
+  const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n) return;
+  double d = 0.0, s = 0.0;
+  bool found = false, strong = false;
+  for (rp_t p = rp[i] + lane; p < rp[i + 1]; p += 64) {
+    const int j = ci[p];
+    const double a = v[p];
+    if (j == i && !found) { d = a; found = true; }
+    const bool st = j < n && j != i && a != 0.0;
+    sc[p] = st ? j : -1;
+    strong |= st;
+    if (j < n) s += fabs(a);
+  }
+  const unsigned long long any = __ballot(found);
+  d = any ? __shfl(d, __ffsll((long long)any) - 1, 64) : 1.0;
+  const bool any_strong = __ballot(strong) != 0;
+  if (lane == 0) { dg[i] = d; key[i] = amg_key(any_strong ? AMG_UNDECIDED : AMG_COVERED, i); }
+  if (d == 0.0) return;  // wave-uniform
+  s = wave_sum(s) / fabs(d);
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+  if (lane == 0 && bits > *rho_bits) atomicMax(const_cast<unsigned long long *>(rho_bits), bits);
 }
 
 __global__ __launch_bounds__(256) void k_mis_init(int n, const rp_t *__restrict__ rp, const int *__restrict__ sc,
@@ -401,17 +431,19 @@ __global__ void k_segment_starts(int n, int nagg, const unsigned long long *__re
   if (p == n - 1) start[nagg] = n;
 }
 
-// nvc[a] = |nv restricted to aggregate a|, members summed in index order (reproducible, equals the CPU order)
-__global__ void k_agg_norm(int nagg, const int *__restrict__ start, const unsigned long long *__restrict__ keys,
-                           const double *__restrict__ nv, double *__restrict__ nvc) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+// nvc[a] = |nv restricted to aggregate a|: one wave per aggregate (a hundred members on the fine level), lane l sums
+// members l, l + 64, .. in index order and the lanes are added in a fixed order (reproducible)
+__global__ __launch_bounds__(256) void k_agg_norm(int nagg, const int *__restrict__ start, const unsigned long long *__restrict__ keys,
+                                                  const double *__restrict__ nv, double *__restrict__ nvc) {
+  const int a = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (a >= nagg) return;
   double s = 0.0;
-  for (int p = start[a]; p < start[a + 1]; ++p) {
+  for (int p = start[a] + lane; p < start[a + 1]; p += 64) {
     const double x = nv[(unsigned)(keys[p] & 0xffffffffu)];
     s += x * x;
   }
-  nvc[a] = sqrt(s);
+  s = wave_sum(s);
+  if (lane == 0) nvc[a] = sqrt(s);
 }
 
 __global__ void k_ptent(int n, const int *__restrict__ agg, const double *__restrict__ nv, const double *__restrict__ nvc,
@@ -442,7 +474,100 @@ __global__ __launch_bounds__(256) void k_amg_rho(int n, const rp_t *__restrict__
 // fixed-order wave sum and merged into the table, so the result does not depend on scheduling.  FILL = false only counts.
 constexpr int kProlongSlots = 8;
 
-template <bool FILL>
+// MODE 0 counts, MODE 1 fills the CSR rows behind prp (the two passes of rounds 2-4: rows of more than kProlongCap
+// aggregates, and ISPH_AMG_PROLONG_TWO_PASS=1)
+constexpr int kProlongCap = 64;
+
+// The same row in ONE pass, for rows of at most kProlongCap aggregates: a per-wave LDS table (key = aggregate, open
+// addressing) takes the row's terms as they are read; the row goes, columns ascending, to a scratch row of kProlongCap
+// slots and its length to pcnt (k_rows_compact packs the rows).  A longer row raises err bit 8 and the caller falls back
+// to the two passes.  The terms of one aggregate are added in the order the lanes reach the table (like the products of
+// the SpGEMM that consumes P): the last bits of P are not reproducible from run to run, those of the two-pass kernel are.
+__global__ __launch_bounds__(256) void k_prolong_rows(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
+                                                      const double *__restrict__ v, const double *__restrict__ dg,
+                                                      const int *__restrict__ agg, const double *__restrict__ pt, double damp,
+                                                      int *__restrict__ pcnt, int *__restrict__ tci, double *__restrict__ tcv,
+                                                      int *__restrict__ err) {
+  constexpr int TABLE = 2 * kProlongCap, NT = TABLE / 64;
+  __shared__ int tk[kAmgWaves][TABLE];
+  __shared__ double tv[kAmgWaves][TABLE];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * kAmgWaves + w;
+  if (i >= n) return;   // wave-uniform; no workgroup barrier below
+  for (int s = lane; s < TABLE; s += 64) { tk[w][s] = -1; tv[w][s] = 0.0; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  bool over = false;
+  auto insert = [&](int c, double val) {
+    int slot = (int)(amg_hash32((unsigned)c) & (TABLE - 1));
+    for (int tries = 0;; ++tries) {
+      const int old = atomicCAS(&tk[w][slot], -1, c);
+      if (old == -1 || old == c) break;
+      slot = (slot + 1) & (TABLE - 1);
+      if (tries >= TABLE) { over = true; slot = -1; break; }
+    }
+    if (slot >= 0) atomicAdd(&tv[w][slot], val);
+  };
+  const int ai = agg[i];
+  if (ai >= 0 && lane == 0) insert(ai, pt[i]);
+  const double f = dg[i] != 0.0 ? damp / dg[i] : 0.0;
+  const rp_t lo = rp[i], hi = rp[i + 1];
+  for (rp_t p0 = lo; p0 < hi; p0 += 128) {   // two rounds of loads at a time
+    int a[2];
+    double term[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const rp_t p = p0 + 64 * u + lane;
+      a[u] = -1;
+      term[u] = 0.0;
+      if (p < hi) {
+        const int j = ci[p];
+        if (j < n) {
+          const int aj = agg[j];
+          if (aj >= 0) { a[u] = aj; term[u] = -(f * v[p] * pt[j]); }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (a[u] >= 0) insert(a[u], term[u]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int kt[NT], rank[NT], cnt = 0;
+  unsigned long long occ[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    kt[t] = tk[w][lane + 64 * t];
+    rank[t] = 0;
+    occ[t] = __ballot(kt[t] >= 0);
+    cnt += __popcll(occ[t]);
+  }
+  if (__ballot(over) != 0 || cnt > kProlongCap) {
+    if (lane == 0) { atomicOr(err, 8); pcnt[i] = 0; }
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    unsigned long long m = occ[u];
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      const int ks = __builtin_amdgcn_readlane(kt[u], src);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) rank[t] += ks < kt[t];
+      m &= m - 1;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (kt[t] >= 0) {
+      tci[(size_t)i * kProlongCap + rank[t]] = kt[t];
+      tcv[(size_t)i * kProlongCap + rank[t]] = tv[w][lane + 64 * t];
+    }
+  if (lane == 0) pcnt[i] = cnt;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void k_prolong(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ v, const double *__restrict__ dg,
                                                  const int *__restrict__ agg, const double *__restrict__ pt, double damp,
@@ -495,7 +620,8 @@ __global__ __launch_bounds__(256) void k_prolong(int n, const rp_t *__restrict__
       live &= ~__ballot(mine);
     }
   }
-  if (!FILL) { if (lane == 0) pcnt[i] = cnt; return; }
+  if (MODE == 0) { if (lane == 0) pcnt[i] = cnt; return; }
+  const rp_t obeg = prp[i];
   // rank sort by aggregate id (ascending columns)
   int rank[kProlongSlots];
 #pragma unroll
@@ -510,12 +636,18 @@ __global__ __launch_bounds__(256) void k_prolong(int n, const rp_t *__restrict__
   }
 #pragma unroll
   for (int t = 0; t < kProlongSlots; ++t)
-    if (lane + 64 * t < cnt) { pci[prp[i] + rank[t]] = tkey[t]; pv[prp[i] + rank[t]] = tval[t]; }
+    if (lane + 64 * t < cnt) { pci[obeg + rank[t]] = tkey[t]; pv[obeg + rank[t]] = tval[t]; }
 }
 
-__global__ void k_count_cols(long long nnz, const int *__restrict__ ci, int *__restrict__ cnt) {
+// row pointers of the transpose from the sorted (column, row) keys: position p opens every column after its
+// predecessor's up to its own (empty columns included); the last position closes the rest
+__global__ void k_transpose_rowptr(long long nnz, int ncol, const unsigned long long *__restrict__ keys, rp_t *__restrict__ rp) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < nnz) atomicAdd(&cnt[ci[p]], 1);
+  if (p >= nnz) return;
+  const int c = (int)(keys[p] >> 32), cprev = p > 0 ? (int)(keys[p - 1] >> 32) : -1;
+  for (int cc = cprev + 1; cc <= c; ++cc) rp[cc] = p;
+  if (p == nnz - 1)
+    for (int cc = c + 1; cc <= ncol; ++cc) rp[cc] = nnz;
 }
 __global__ void k_transpose_keys(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                  unsigned long long *__restrict__ keys) {
@@ -585,6 +717,145 @@ __global__ __launch_bounds__(BS) void k_spgemm(int n, int ycols, int yrows, cons
       cci[beg + pos] = tk[s];
       cv[beg + pos] = tv[s];
     }
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: Hillis-Steele inside a row of 16, then the row totals are passed on)
+__device__ __forceinline__ int wave_scan_incl_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1 (a lane without a source adds 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// C = X * Y for rows of X around a hundred entries and short rows of Y (A * P: ~8 entries): ONE pass, one wave per row of C.
+// The products of 64 entries of X's row are laid out flat (prefix sum of the Y row lengths; own[] names the X entry behind
+// every product), so a lane takes products x, x + 64, .. whatever the lengths of the Y rows are, and the loads of one
+// round do not depend on the round before.  Accumulation in a per-wave LDS hash table of 2 CAP slots; a row of C is
+// written to a scratch row of CAP slots with ascending columns (k_rows_compact packs the rows once their lengths are
+// scanned).  A row with more than CAP distinct columns raises err bit 2: the caller repeats with a larger CAP.
+// (The two-pass kernel below it replaces walked every Y row with one thread, count pass and fill pass: 2.2 + 4.5 ms
+// per set-up at 100^3.)
+constexpr int kOwnCap = 2048;
+template <int CAP>
+__global__ __launch_bounds__(256) void k_spgemm_rows(int n, int yrows, const rp_t *__restrict__ xrp, const int *__restrict__ xci,
+                                                     const double *__restrict__ xv, const rp_t *__restrict__ yrp,
+                                                     const int *__restrict__ yci, const double *__restrict__ yv,
+                                                     int *__restrict__ ccnt, int *__restrict__ tci, double *__restrict__ tcv,
+                                                     int *__restrict__ err) {
+  constexpr int TABLE = 2 * CAP, NT = TABLE / 64;
+  __shared__ int tk[4][TABLE];
+  __shared__ double tv[4][TABLE];
+  __shared__ unsigned char own[4][kOwnCap];
+  __shared__ rp_t sbase[4][64];
+  __shared__ double sxa[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= n) return;   // wave-uniform; the kernel has no workgroup barrier
+  for (int s = lane; s < TABLE; s += 64) { tk[w][s] = -1; tv[w][s] = 0.0; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  bool over = false;
+  auto insert = [&](int c, double val) {
+    int slot = (int)(amg_hash32((unsigned)c) & (TABLE - 1));
+    for (int tries = 0;; ++tries) {
+      const int old = atomicCAS(&tk[w][slot], -1, c);
+      if (old == -1 || old == c) break;
+      slot = (slot + 1) & (TABLE - 1);
+      if (tries >= TABLE) { over = true; slot = -1; break; }
+    }
+    if (slot >= 0) atomicAdd(&tv[w][slot], val);
+  };
+  const rp_t x0 = xrp[i], x1 = xrp[i + 1];
+  for (rp_t p0 = x0; p0 < x1; p0 += 64) {
+    const rp_t p = p0 + lane;
+    int len = 0;
+    rp_t qb = 0;
+    double xa = 0.0;
+    if (p < x1) {
+      const int k = xci[p];
+      if (k < yrows) { qb = yrp[k]; len = (int)(yrp[k + 1] - qb); xa = xv[p]; }
+    }
+    const int incl = wave_scan_incl_i32(len);
+    const int T = __builtin_amdgcn_readlane(incl, 63), start = incl - len;
+    if (T <= kOwnCap) {
+      for (int t = 0; t < len; ++t) own[w][start + t] = (unsigned char)lane;
+      sbase[w][lane] = qb - start;
+      sxa[w][lane] = xa;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // four rounds of loads are issued before the first insertion waits on its table slot (the compiler keeps loads
+      // behind the LDS atomics of the round before when the loop is written round by round)
+      for (int x0 = 0; x0 < T; x0 += 256) {
+        int c[4];
+        double pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int x = x0 + 64 * u + lane;
+          c[u] = -1;
+          pv[u] = 0.0;
+          if (x < T) {
+            const int e = own[w][x];
+            const rp_t q = sbase[w][e] + x;
+            c[u] = yci[q];
+            pv[u] = sxa[w][e] * yv[q];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c[u] >= 0) insert(c[u], pv[u]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {   // Y rows of hundreds of entries: every lane walks its own
+      for (int t = 0; t < len; ++t) insert(yci[qb + t], xa * yv[qb + t]);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int kt[NT], rank[NT], cnt = 0;
+  unsigned long long occ[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    kt[t] = tk[w][lane + 64 * t];
+    rank[t] = 0;
+    occ[t] = __ballot(kt[t] >= 0);
+    cnt += __popcll(occ[t]);
+  }
+  if (__ballot(over) != 0 || cnt > CAP) {
+    if (lane == 0) { atomicOr(err, 2); ccnt[i] = 0; }
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    unsigned long long m = occ[u];
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      const int ks = __builtin_amdgcn_readlane(kt[u], src);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) rank[t] += ks < kt[t];
+      m &= m - 1;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (kt[t] >= 0) {
+      tci[(size_t)i * CAP + rank[t]] = kt[t];
+      tcv[(size_t)i * CAP + rank[t]] = tv[w][lane + 64 * t];
+    }
+  if (lane == 0) ccnt[i] = cnt;
+}
+
+// scratch rows of `cap` slots (a power of two) -> CSR
+__global__ void k_rows_compact(int n, int cap_shift, const rp_t *__restrict__ rp, const int *__restrict__ tci,
+                               const double *__restrict__ tcv, int *__restrict__ ci, double *__restrict__ v) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = (int)(idx >> cap_shift), s = (int)(idx & ((1 << cap_shift) - 1));
+  if (r >= n) return;
+  const rp_t b = rp[r];
+  if (s < (int)(rp[r + 1] - b)) { ci[b + s] = tci[idx]; v[b + s] = tcv[idx]; }
 }
 
 // y = R x for a CSR matrix with long rows: one wave per row, coalesced reads of the row, fixed-order wave sum
@@ -663,6 +934,66 @@ __global__ __launch_bounds__(256) void k_dense_apply(int n, const double *__rest
   if (lane == 0) x[i] = s;
 }
 
+// ---- the smoother of small coarse levels as dense block inverses ---------------------------------------------------
+// On a level of a few thousand rows the chunk-stream sweeps are one wave per 64-row block walking 64 dependent rows twice
+// (37 us per application at 4 014 rows, 16 us at 24 rows -- 140 us of every V cycle on levels that hold 0.3 % of the
+// entries).  The smoother is linear: M_B^-1 = (D+U_B)^-1 D (D+L_B)^-1 of one block is a dense 64 x 64 matrix, built once
+// per set-up (thread t solves for column t: forward sweep, scaling, backward sweep, with the conventions of
+// k_sgs_pivots: a zero pivot keeps its unknown at zero) and applied as 64 multiply-adds per row.
+constexpr int kSgsDenseMaxRows = 32768;   // 16 MB of inverses at most
+__global__ __launch_bounds__(64) void k_sgs_dense_build(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
+                                                        const double *__restrict__ v, double *__restrict__ W) {
+  __shared__ double Bm[64][65];   // the block's entries, row i at Bm[i][.]
+  __shared__ double Y[64][65];    // Y[i][t]: unknown i of thread t's column
+  const int t = threadIdx.x, r0 = blockIdx.x * 64;
+  const int m = min(64, n - r0);
+  for (int j = 0; j < 64; ++j) Bm[t][j] = 0.0;
+  if (t < m)
+    for (rp_t p = rp[r0 + t]; p < rp[r0 + t + 1]; ++p) {
+      const int j = ci[p] - r0;
+      if (j >= 0 && j < m) Bm[t][j] = v[p];
+    }
+  __syncthreads();
+  // w = (D + L)^-1 e_t, then y = D w
+  for (int i = 0; i < m; ++i) {
+    double s = i == t ? 1.0 : 0.0;
+    for (int j = 0; j < i; ++j) s -= Bm[i][j] * Y[j][t];
+    const double d = Bm[i][i];
+    Y[i][t] = d != 0.0 ? s / d : 0.0;
+  }
+  for (int i = 0; i < m; ++i) Y[i][t] *= Bm[i][i];
+  // x = (D + U)^-1 y
+  for (int i = m - 1; i >= 0; --i) {
+    double s = Y[i][t];
+    for (int j = i + 1; j < m; ++j) s -= Bm[i][j] * Y[j][t];
+    const double d = Bm[i][i];
+    Y[i][t] = d != 0.0 ? s / d : 0.0;
+  }
+  __syncthreads();
+  // column-major: W[t * 64 + i] = (M^-1)[i][t]; thread t writes row t of every column (coalesced)
+  double *Wb = W + (size_t)blockIdx.x * 4096;
+  for (int c = 0; c < 64; ++c) Wb[c * 64 + t] = (t < m && c < m) ? Y[t][c] : 0.0;
+}
+
+// z = M_B^-1 r (ACC: z += M_B^-1 r), one wave per block: lane i adds column t times r[t] for t = 0..63
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_sgs_dense_apply(int n, const double *__restrict__ W, const double *__restrict__ r,
+                                                         double *__restrict__ z) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b * 64 >= n) return;
+  const int row = b * 64 + lane;
+  const double rv = row < n ? r[row] : 0.0;
+  const int lo = __double2loint(rv), hi = __double2hiint(rv);
+  const double *Wb = W + (size_t)b * 4096 + lane;
+  double acc = 0.0;
+#pragma unroll
+  for (int t = 0; t < 64; ++t) {
+    const double rt = __hiloint2double(__builtin_amdgcn_readlane(hi, t), __builtin_amdgcn_readlane(lo, t));
+    acc = fma(Wb[t * 64], rt, acc);
+  }
+  if (row < n) z[row] = ACC ? z[row] + acc : acc;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 inline int amg_scan(isph_ctx *ctx, const int *in, rp_t *out, int n, DevBuf<char> &tmp) {
   size_t bytes = 0;
@@ -723,29 +1054,32 @@ inline int amg_transpose(isph_ctx *ctx, const DCsr &P, DCsr &R, DevBuf<char> &tm
   ISPH_CHECK(R.ci.reserve(nnz1));
   ISPH_CHECK(R.v.reserve(nnz1));
   DevTmp<unsigned long long> k0, k1;
-  DevTmp<int> cnt;
   int rc = k0.reserve(nnz1);
   if (rc == ISPH_SUCCESS) rc = k1.reserve(nnz1);
-  if (rc == ISPH_SUCCESS) rc = cnt.reserve((size_t)R.n + 1);
-  if (rc == ISPH_SUCCESS && hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)R.n + 1), ctx->stream) != hipSuccess)
-    rc = fail("memset failed", __FILE__, __LINE__);
   if (rc == ISPH_SUCCESS && P.nnz > 0) {
     const int gn = (int)((P.nnz + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_count_cols, dim3(gn), dim3(kBlock), 0, ctx->stream, P.nnz, (const int *)P.ci.p, cnt.p);
     hipLaunchKernelGGL(k_transpose_keys, dim3((P.n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, P.n,
                        (const rp_t *)P.rp.p, (const int *)P.ci.p, k0.p);
+    // the keys are written row by row, so a STABLE sort by the column bits alone leaves every column's rows ascending
+    int cbits = 1;
+    while (cbits < 31 && (1ll << cbits) < (long long)R.n) ++cbits;
+    const unsigned b0 = 32, b1 = 32 + (unsigned)cbits;
     size_t bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, k0.p, k1.p, P.v.p, R.v.p, (size_t)P.nnz, 0, 64, ctx->stream) != hipSuccess)
+    if (rocprim::radix_sort_pairs(nullptr, bytes, k0.p, k1.p, P.v.p, R.v.p, (size_t)P.nnz, b0, b1, ctx->stream) != hipSuccess)
       rc = fail("radix sort sizing failed", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) rc = tmp.reserve(bytes > 0 ? bytes : 1);
     if (rc == ISPH_SUCCESS &&
-        rocprim::radix_sort_pairs(tmp.p, bytes, k0.p, k1.p, P.v.p, R.v.p, (size_t)P.nnz, 0, 64, ctx->stream) != hipSuccess)
+        rocprim::radix_sort_pairs(tmp.p, bytes, k0.p, k1.p, P.v.p, R.v.p, (size_t)P.nnz, b0, b1, ctx->stream) != hipSuccess)
       rc = fail("radix sort failed", __FILE__, __LINE__);
-    if (rc == ISPH_SUCCESS) hipLaunchKernelGGL(k_low32, dim3(gn), dim3(kBlock), 0, ctx->stream, P.nnz, (const unsigned long long *)k1.p, R.ci.p);
+    if (rc == ISPH_SUCCESS) {
+      hipLaunchKernelGGL(k_low32, dim3(gn), dim3(kBlock), 0, ctx->stream, P.nnz, (const unsigned long long *)k1.p, R.ci.p);
+      hipLaunchKernelGGL(k_transpose_rowptr, dim3(gn), dim3(kBlock), 0, ctx->stream, P.nnz, R.n, (const unsigned long long *)k1.p, R.rp.p);
+    }
+  } else if (rc == ISPH_SUCCESS) {
+    if (hipMemsetAsync(R.rp.p, 0, sizeof(rp_t) * ((size_t)R.n + 1), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
   }
-  if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, R.rp.p, R.n + 1, tmp);
   if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("transpose failed", __FILE__, __LINE__);
-  k0.release(); k1.release(); cnt.release();
+  k0.release(); k1.release();
   return rc;
 }
 
@@ -792,8 +1126,59 @@ inline int amg_spgemm_try(isph_ctx *ctx, const DCsr &A, const DCsr &P, DCsr &AP,
   }
   return ISPH_SUCCESS;
 }
+// the one-pass kernel with scratch rows of CAP slots; *overflow: a row has more distinct columns (nothing is kept)
+template <int CAP>
+inline int amg_spgemm_rows(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C, DevBuf<char> &tmp, int *derr, bool *overflow) {
+  constexpr int SHIFT = CAP == 64 ? 6 : 8;
+  static_assert(CAP == 64 || CAP == 256, "scratch rows of 64 or 256 slots");
+  static_assert(kProlongCap == 64, "k_rows_compact is called with shift 6 for the prolongator");
+  *overflow = false;
+  C.n = X.n; C.m = Y.m;
+  ISPH_CHECK(C.rp.reserve((size_t)C.n + 1));
+  DevTmp<int> cnt, tci;
+  DevTmp<double> tcv;
+  const size_t slots = (size_t)(C.n > 0 ? C.n : 1) * CAP;
+  ISPH_CHECK(cnt.reserve((size_t)C.n + 1));
+  ISPH_CHECK(tci.reserve(slots));
+  ISPH_CHECK(tcv.reserve(slots));
+  ISPH_CHECK_HIP(hipMemsetAsync(cnt.p + C.n, 0, sizeof(int), ctx->stream));
+  if (C.n > 0)
+    hipLaunchKernelGGL((k_spgemm_rows<CAP>), dim3((C.n + 3) / 4), dim3(256), 0, ctx->stream, X.n, Y.n, (const rp_t *)X.rp.p,
+                       (const int *)X.ci.p, (const double *)X.v.p, (const rp_t *)Y.rp.p, (const int *)Y.ci.p,
+                       (const double *)Y.v.p, cnt.p, tci.p, tcv.p, derr);
+  ISPH_CHECK(amg_scan(ctx, cnt.p, C.rp.p, C.n + 1, tmp));
+  long long nnz = 0;
+  int herr = 0;
+  ISPH_CHECK_HIP(hipMemcpyAsync(&nnz, C.rp.p + C.n, sizeof(rp_t), hipMemcpyDeviceToHost, ctx->stream));
+  ISPH_CHECK(amg_read_int(ctx, derr, &herr));
+  if (herr & 2) {
+    herr &= ~2;
+    ISPH_CHECK_HIP(hipMemcpyAsync(derr, &herr, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    C.release();
+    *overflow = true;
+    return ISPH_SUCCESS;
+  }
+  C.nnz = nnz;
+  ISPH_CHECK(C.ci.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  ISPH_CHECK(C.v.reserve((size_t)(nnz > 0 ? nnz : 1)));
+  if (C.n > 0) {
+    const long long total = (long long)C.n << SHIFT;
+    hipLaunchKernelGGL(k_rows_compact, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, C.n, SHIFT,
+                       (const rp_t *)C.rp.p, (const int *)tci.p, (const double *)tcv.p, C.ci.p, C.v.p);
+  }
+  return ISPH_SUCCESS;   // (the scratch rows go back to the pool, which hands a block out again only after a device synchronisation)
+}
+
 inline int amg_spgemm_ap(isph_ctx *ctx, const DCsr &A, const DCsr &P, DCsr &AP, DevBuf<char> &tmp, int *derr) {
   bool overflow = false;
+  const char *two = getenv("ISPH_AMG_SPGEMM_TWO_PASS");   // the kernels of rounds 2-4, kept for comparisons
+  if (!(two && two[0] == '1')) {
+    ISPH_CHECK(amg_spgemm_rows<64>(ctx, A, P, AP, tmp, derr, &overflow));
+    if (!overflow) return ISPH_SUCCESS;
+    ISPH_CHECK(amg_spgemm_rows<256>(ctx, A, P, AP, tmp, derr, &overflow));
+    if (!overflow) return ISPH_SUCCESS;
+  }
   ISPH_CHECK(amg_spgemm_try<256>(ctx, A, P, AP, tmp, derr, &overflow));
   if (!overflow) return ISPH_SUCCESS;
   ISPH_CHECK(amg_spgemm_try<1024>(ctx, A, P, AP, tmp, derr, &overflow));
@@ -808,6 +1193,7 @@ inline void amg_level_destroy(AmgLevel *L) {
   if (L->Pm) isph_mat_destroy(L->Pm);
   if (L->APm) isph_mat_destroy(L->APm);
   if (L->sgs) ilu_destroy(L->sgs);
+  L->wsgs.release();
   L->agg.release(); L->nv.release(); L->x.release(); L->b.release(); L->r.release(); L->z.release();
   delete L;
 }
@@ -820,7 +1206,8 @@ inline void amg_destroy(isph_amg *G) {
 }
 
 // aggregates of level L (sets L->agg) ; returns the number of aggregates in *nagg_out
-inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double theta, DevBuf<char> &tmp, int *nagg_out) {
+// theta == 0: also fills dg and *rho (k_amg_prepare); otherwise dg is read and rho is left to amg_prolongator
+inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, double *dg, unsigned long long *rho, double theta, DevBuf<char> &tmp, int *nagg_out) {
   const DCsr &A = L->A;
   const int n = A.n;
   const double th2 = theta * theta;
@@ -846,8 +1233,13 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
   const int *ci = A.ci.p;
   const double *v = A.v.p;
   if (rc == ISPH_SUCCESS) {
-    hipLaunchKernelGGL(k_strong_cols, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, th2, scb.p);
-    hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p, key.p);
+    if (th2 == 0.0) {
+      if (hipMemsetAsync(rho, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+      hipLaunchKernelGGL(k_amg_prepare, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, scb.p, key.p, rho);
+    } else {
+      hipLaunchKernelGGL(k_strong_cols, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, (const double *)dg, th2, scb.p);
+      hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p, key.p);
+    }
     // rounds: t1 = max over the strong neighbourhood, t2 = max of t1 (distance 2), decide.  From the second round on
     // the sweeps run over work lists (see k_mis_mark)
     int und = n, cur = 0;
@@ -909,43 +1301,49 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, const double *dg, double th
 }
 
 // P = (I - omega/rho D^-1 A) P_tent and the coarse null vector
-inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, int nagg, double omega, DevBuf<double> &nvc,
-                           DevBuf<char> &tmp, int *derr) {
+// rho_ready: the device word already holds rho (amg_aggregate with threshold 0)
+inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, unsigned long long *rho_dev, bool rho_ready, int nagg, double omega,
+                           DevBuf<double> &nvc, DevBuf<char> &tmp, int *derr) {
   const DCsr &A = L->A;
   const int n = A.n;
   DevTmp<unsigned long long> k0, k1;
   DevTmp<int> start, cnt;
   DevTmp<double> pt;
-  DevTmp<unsigned long long> rho;
   int rc = k0.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = k1.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = start.reserve((size_t)nagg + 1);
   if (rc == ISPH_SUCCESS) rc = cnt.reserve((size_t)n + 1);
   if (rc == ISPH_SUCCESS) rc = pt.reserve((size_t)n);
-  if (rc == ISPH_SUCCESS) rc = rho.reserve(1);
   if (rc == ISPH_SUCCESS) rc = nvc.reserve((size_t)nagg);
   const int gw = amg_wave_grid(n), gt = (n + kBlock - 1) / kBlock;
   if (rc == ISPH_SUCCESS) {
     hipLaunchKernelGGL(k_member_keys, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const int *)L->agg.p, k0.p);
+    // keys are made in index order: a STABLE sort by the aggregate bits alone leaves the members of an aggregate ascending
+    // (nodes outside every aggregate carry all ones there: one value more than the aggregates need)
+    int abits = 1;
+    while (abits < 32 && (1ll << abits) <= (long long)nagg) ++abits;
+    const unsigned b0 = 32, b1 = 32 + (unsigned)abits;
     size_t bytes = 0;
-    if (rocprim::radix_sort_keys(nullptr, bytes, k0.p, k1.p, (size_t)n, 0, 64, ctx->stream) != hipSuccess)
+    if (rocprim::radix_sort_keys(nullptr, bytes, k0.p, k1.p, (size_t)n, b0, b1, ctx->stream) != hipSuccess)
       rc = fail("radix sort sizing failed", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) rc = tmp.reserve(bytes > 0 ? bytes : 1);
-    if (rc == ISPH_SUCCESS && rocprim::radix_sort_keys(tmp.p, bytes, k0.p, k1.p, (size_t)n, 0, 64, ctx->stream) != hipSuccess)
+    if (rc == ISPH_SUCCESS && rocprim::radix_sort_keys(tmp.p, bytes, k0.p, k1.p, (size_t)n, b0, b1, ctx->stream) != hipSuccess)
       rc = fail("radix sort failed", __FILE__, __LINE__);
   }
   double rho_h = 0.0;
   if (rc == ISPH_SUCCESS) {
     hipLaunchKernelGGL(k_segment_starts, dim3(gt), dim3(kBlock), 0, ctx->stream, n, nagg, (const unsigned long long *)k1.p, start.p);
-    hipLaunchKernelGGL(k_agg_norm, dim3((nagg + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, nagg, (const int *)start.p,
+    hipLaunchKernelGGL(k_agg_norm, dim3(amg_wave_grid(nagg)), dim3(256), 0, ctx->stream, nagg, (const int *)start.p,
                        (const unsigned long long *)k1.p, (const double *)L->nv.p, nvc.p);
     hipLaunchKernelGGL(k_ptent, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const int *)L->agg.p, (const double *)L->nv.p,
                        (const double *)nvc.p, pt.p);
-    if (hipMemsetAsync(rho.p, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
-    hipLaunchKernelGGL(k_amg_rho, dim3(gw), dim3(256), 0, ctx->stream, n, (const rp_t *)A.rp.p, (const int *)A.ci.p,
-                       (const double *)A.v.p, dg, rho.p);
+    if (!rho_ready) {
+      if (hipMemsetAsync(rho_dev, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+      hipLaunchKernelGGL(k_amg_rho, dim3(gw), dim3(256), 0, ctx->stream, n, (const rp_t *)A.rp.p, (const int *)A.ci.p,
+                         (const double *)A.v.p, dg, rho_dev);
+    }
     if (rc == ISPH_SUCCESS &&
-        (hipMemcpyAsync(&rho_h, rho.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        (hipMemcpyAsync(&rho_h, rho_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
          hipStreamSynchronize(ctx->stream) != hipSuccess))
       rc = fail("rho read-back failed", __FILE__, __LINE__);
   }
@@ -953,24 +1351,60 @@ inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, int nag
   DCsr &P = L->P;
   P.n = n; P.m = nagg;
   if (rc == ISPH_SUCCESS) rc = P.rp.reserve((size_t)n + 1);
-  if (rc == ISPH_SUCCESS) {
-    if (hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)n + 1), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
-    hipLaunchKernelGGL((k_prolong<false>), dim3(gw), dim3(256), 0, ctx->stream, n, (const rp_t *)A.rp.p, (const int *)A.ci.p,
-                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, cnt.p, (const rp_t *)nullptr,
-                       (int *)nullptr, (double *)nullptr, derr);
-  }
-  if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, P.rp.p, n + 1, tmp);
+  const rp_t *arp = A.rp.p;
+  const int *aci = A.ci.p;
+  const double *av = A.v.p;
+  const int *agg = L->agg.p;
   long long nnz = 0;
-  if (rc == ISPH_SUCCESS) rc = amg_read_off(ctx, P.rp.p + n, &nnz);
-  P.nnz = nnz;
-  if (rc == ISPH_SUCCESS) rc = P.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
-  if (rc == ISPH_SUCCESS) rc = P.v.reserve((size_t)(nnz > 0 ? nnz : 1));
-  if (rc == ISPH_SUCCESS)
-    hipLaunchKernelGGL((k_prolong<true>), dim3(gw), dim3(256), 0, ctx->stream, n, (const rp_t *)A.rp.p, (const int *)A.ci.p,
-                       (const double *)A.v.p, dg, (const int *)L->agg.p, (const double *)pt.p, damp, (int *)nullptr, (const rp_t *)P.rp.p,
-                       P.ci.p, P.v.p, derr);
+  bool one_pass = false;
+  const char *two = getenv("ISPH_AMG_PROLONG_TWO_PASS");
+  if (!(two && two[0] == '1')) {   // one pass into scratch rows of kProlongCap slots
+    DevTmp<int> tci;
+    DevTmp<double> tcv;
+    int herr = 0;
+    if (rc == ISPH_SUCCESS) rc = tci.reserve((size_t)n * kProlongCap);
+    if (rc == ISPH_SUCCESS) rc = tcv.reserve((size_t)n * kProlongCap);
+    if (rc == ISPH_SUCCESS) {
+      if (hipMemsetAsync(cnt.p + n, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+      hipLaunchKernelGGL(k_prolong_rows, dim3(gw), dim3(256), 0, ctx->stream, n, arp, aci, av, dg, agg, (const double *)pt.p, damp,
+                         cnt.p, tci.p, tcv.p, derr);
+    }
+    if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, P.rp.p, n + 1, tmp);
+    if (rc == ISPH_SUCCESS && hipMemcpyAsync(&nnz, P.rp.p + n, sizeof(rp_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      rc = fail("copy failed", __FILE__, __LINE__);
+    if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, derr, &herr);
+    if (rc == ISPH_SUCCESS && (herr & 8)) {   // a row longer than the scratch rows: the two passes below
+      herr &= ~8;
+      if (hipMemcpyAsync(derr, &herr, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = fail("copy failed", __FILE__, __LINE__);
+    } else if (rc == ISPH_SUCCESS) {
+      one_pass = true;
+      P.nnz = nnz;
+      rc = P.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
+      if (rc == ISPH_SUCCESS) rc = P.v.reserve((size_t)(nnz > 0 ? nnz : 1));
+      if (rc == ISPH_SUCCESS && n > 0) {
+        const long long total = (long long)n * kProlongCap;
+        hipLaunchKernelGGL(k_rows_compact, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, 6,
+                           (const rp_t *)P.rp.p, (const int *)tci.p, (const double *)tcv.p, P.ci.p, P.v.p);
+      }
+    }
+  }
+  if (rc == ISPH_SUCCESS && !one_pass) {
+    if (hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)n + 1), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+    hipLaunchKernelGGL((k_prolong<0>), dim3(gw), dim3(256), 0, ctx->stream, n, arp, aci, av, dg, agg, (const double *)pt.p, damp,
+                       cnt.p, (const rp_t *)nullptr, (int *)nullptr, (double *)nullptr, derr);
+    if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, P.rp.p, n + 1, tmp);
+    if (rc == ISPH_SUCCESS) rc = amg_read_off(ctx, P.rp.p + n, &nnz);
+    P.nnz = nnz;
+    if (rc == ISPH_SUCCESS) rc = P.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
+    if (rc == ISPH_SUCCESS) rc = P.v.reserve((size_t)(nnz > 0 ? nnz : 1));
+    if (rc == ISPH_SUCCESS)
+      hipLaunchKernelGGL((k_prolong<1>), dim3(gw), dim3(256), 0, ctx->stream, n, arp, aci, av, dg, agg, (const double *)pt.p, damp,
+                         (int *)nullptr, (const rp_t *)P.rp.p, P.ci.p, P.v.p, derr);
+  }
   if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("prolongator kernels failed", __FILE__, __LINE__);
-  k0.release(); k1.release(); start.release(); cnt.release(); pt.release(); rho.release();
+  k0.release(); k1.release(); start.release(); cnt.release(); pt.release();
   return rc;
 }
 
@@ -1197,7 +1631,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   DevTmp<char> tmp;
   DevTmp<int> derr;
   DevTmp<double> dg;
+  DevTmp<unsigned long long> rho;
   int rc = derr.reserve(1);
+  if (rc == ISPH_SUCCESS) rc = rho.reserve(1);
   if (rc == ISPH_SUCCESS && hipMemsetAsync(derr.p, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
   AmgLevel *L0 = new AmgLevel();
   G->L.push_back(L0);
@@ -1233,9 +1669,10 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc != ISPH_SUCCESS && !dist) break;
     int nagg = 0;
     if (rc == ISPH_SUCCESS && n > 0) {
-      hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const rp_t *)L->A.rp.p,
-                         (const int *)L->A.ci.p, (const double *)L->A.v.p, dg.p);
-      rc = amg_aggregate(ctx, L, dg.p, prm->theta, tmp, &nagg);
+      if (prm->theta != 0.0)
+        hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const rp_t *)L->A.rp.p,
+                           (const int *)L->A.ci.p, (const double *)L->A.v.p, dg.p);
+      rc = amg_aggregate(ctx, L, dg.p, rho.p, prm->theta, tmp, &nagg);
     }
     if (rc != ISPH_SUCCESS && !dist) break;
     // no coarsening, or a coarse space too small to carry anything but the null vector: stop here
@@ -1251,7 +1688,7 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (stop) { L->agg.release(); break; }
     AmgLevel *Lc = new AmgLevel();
     if (identity) { nagg = n; rc = amg_identity_prolongator(ctx, L, Lc->nv); }
-    else rc = amg_prolongator(ctx, L, dg.p, nagg, prm->omega, Lc->nv, tmp, derr.p);
+    else rc = amg_prolongator(ctx, L, dg.p, rho.p, prm->theta == 0.0, nagg, prm->omega, Lc->nv, tmp, derr.p);
     DCsr AP, Pext;
     DCsr &R = L->R;
     const isph_halo &H = L->Am->halo;
@@ -1327,8 +1764,18 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     rc = amg_level_buffers(L);
     const bool last = l == G->nlev - 1;
     // coarse levels are small: 64-row blocks keep enough waves busy (an 8-block level ran its sweeps on 8 waves)
-    if (rc == ISPH_SUCCESS && (!last || G->coarse_smooth))
-      rc = ilu_create(ctx, L->Am, l == 0 ? G->block : kAmgCoarseBlock, &L->sgs, /*sgs=*/true);
+    if (rc == ISPH_SUCCESS && (!last || G->coarse_smooth)) {
+      const char *env_stream = getenv("ISPH_AMG_COARSE_STREAM");   // the chunk-stream sweeps on every level (rounds 2-4)
+      if (l > 0 && L->A.n > 0 && L->A.n <= kSgsDenseMaxRows && kAmgCoarseBlock == 64 && !(env_stream && env_stream[0] == '1')) {
+        const int nb = (L->A.n + 63) / 64;
+        rc = L->wsgs.reserve((size_t)nb * 4096);
+        if (rc == ISPH_SUCCESS)
+          hipLaunchKernelGGL(k_sgs_dense_build, dim3(nb), dim3(64), 0, ctx->stream, L->A.n, (const rp_t *)L->A.rp.p,
+                             (const int *)L->A.ci.p, (const double *)L->A.v.p, L->wsgs.p);
+      } else {
+        rc = ilu_create(ctx, L->Am, l == 0 ? G->block : kAmgCoarseBlock, &L->sgs, /*sgs=*/true);
+      }
+    }
   }
   if (dist) {   // the smoothers are built per rank: a failure there must keep every rank out of the collective steps below
     double h = rc == ISPH_SUCCESS ? 0.0 : 1.0;
@@ -1391,17 +1838,31 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   return ISPH_SUCCESS;
 }
 
+// z = M_B^-1 r of level L (accumulate: z += M_B^-1 r)
+inline int amg_sgs_apply(isph_ctx *ctx, AmgLevel *L, const double *r, double *z, bool accumulate) {
+  const int n = L->A.n;
+  if (L->wsgs.p) {
+    const int grid = ((n + 63) / 64 + 3) / 4;
+    if (n <= 0) return ISPH_SUCCESS;
+    if (accumulate) hipLaunchKernelGGL((k_sgs_dense_apply<true>), dim3(grid), dim3(256), 0, ctx->stream, n, (const double *)L->wsgs.p, r, z);
+    else hipLaunchKernelGGL((k_sgs_dense_apply<false>), dim3(grid), dim3(256), 0, ctx->stream, n, (const double *)L->wsgs.p, r, z);
+    return ISPH_SUCCESS;
+  }
+  if (!accumulate) return ilu_apply(ctx, L->sgs, r, z);
+  ISPH_CHECK(ilu_apply(ctx, L->sgs, r, L->z.p));
+  hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
+                     (const double *)L->z.p, z);
+  return ISPH_SUCCESS;
+}
+
 // x += M_B^-1 (b - A x); zero_guess: x = M_B^-1 b
 inline int amg_smooth(isph_ctx *ctx, const isph_amg *G, int l, const double *b, double *x, bool zero_guess) {
   AmgLevel *L = G->L[(size_t)l];
   const int n = L->A.n;
-  if (zero_guess) return ilu_apply(ctx, L->sgs, b, x);
+  if (zero_guess) return amg_sgs_apply(ctx, L, b, x, false);
   ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
   hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
-  ISPH_CHECK(ilu_apply(ctx, L->sgs, L->r.p, L->z.p));
-  hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
-                     (const double *)L->z.p, x);
-  return ISPH_SUCCESS;
+  return amg_sgs_apply(ctx, L, L->r.p, x, true);
 }
 
 inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, double *x) {
@@ -1445,9 +1906,7 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
     ISPH_CHECK(spmv_dev(ctx, L->APm, Lc->x.p, L->z.p, nullptr));
     hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, -1.0, (const double *)nullptr,
                        (const double *)L->z.p, L->r.p);
-    ISPH_CHECK(ilu_apply(ctx, L->sgs, L->r.p, L->z.p));
-    hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
-                       (const double *)L->z.p, x);
+    ISPH_CHECK(amg_sgs_apply(ctx, L, L->r.p, x, true));
     first = 1;
   }
   for (int s = first; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
