@@ -117,11 +117,17 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 // SELL -> CSR, one wave per slice: a lane reads its own row (coalesced across the wave), kCsrChunk entries per
 // round are staged in LDS and kCsrChunk consecutive lanes write one row's piece of the row-major destination
 constexpr int kCsrChunk = 16;  // (8 until r5: 64-byte row pieces; 16 gives 128-byte value pieces per row: 1.17 -> see docs/kernels_detail.md)
+// PREP (aggregation threshold 0): the sweep also leaves what k_amg_prepare would compute from the copy -- diagonal,
+// strong columns, first MIS keys, rho -- the lane that owns a row sees its entries go by (the row sum of rho is added in
+// entry order here, across lanes first there: the last bit of rho may differ between the two)
+template <bool PREP>
 __global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__restrict__ rowlen,
                                                          const long long *__restrict__ slice_off,
                                                          const int *__restrict__ scol, const double *__restrict__ sval,
                                                          const rp_t *__restrict__ rowptr, int *__restrict__ colidx,
-                                                         double *__restrict__ cval) {
+                                                         double *__restrict__ cval, double *__restrict__ dg = nullptr,
+                                                         int *__restrict__ sc = nullptr, unsigned long long *__restrict__ key = nullptr,
+                                                         volatile unsigned long long *rho_bits = nullptr) {
   __shared__ int stc[4][64][kCsrChunk];
   __shared__ double stv[4][64][kCsrChunk];
   __shared__ int slen[4][64];
@@ -135,14 +141,23 @@ __global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__
   slen[wv][lane] = len;
   sbeg[wv][lane] = row < nrow ? rowptr[row] : 0;
   const int rounds = (wave_max_i32(len) + kCsrChunk - 1) / kCsrChunk;
+  double pd = 0.0, ps = 0.0;
+  bool pfound = false, pstrong = false;
   for (int r = 0; r < rounds; ++r) {
 #pragma unroll
     for (int u = 0; u < kCsrChunk; ++u) {
       const int k = r * kCsrChunk + u;
       if (k < len) {
         const long long p = sell_pos(off, lane, k);
-        stc[wv][lane][u] = scol[p];
-        stv[wv][lane][u] = sval[p];
+        const int c = scol[p];
+        const double a = sval[p];
+        stc[wv][lane][u] = c;
+        stv[wv][lane][u] = a;
+        if (PREP) {
+          if (c == row && !pfound) { pd = a; pfound = true; }
+          pstrong |= c < nrow && c != row && a != 0.0;
+          if (c < nrow) ps += fabs(a);
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -151,12 +166,22 @@ __global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__
     for (int it = 0; it < kCsrChunk; ++it) {
       const int e = lane + 64 * it, rr = e / kCsrChunk, u = e % kCsrChunk, k = r * kCsrChunk + u;
       if (k < slen[wv][rr]) {
-        colidx[sbeg[wv][rr] + k] = stc[wv][rr][u];
-        cval[sbeg[wv][rr] + k] = stv[wv][rr][u];
+        const int c = stc[wv][rr][u];
+        const double a = stv[wv][rr][u];
+        colidx[sbeg[wv][rr] + k] = c;
+        cval[sbeg[wv][rr] + k] = a;
+        if (PREP) sc[sbeg[wv][rr] + k] = (c < nrow && c != slice * 64 + rr && a != 0.0) ? c : -1;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+  if (PREP) {
+    const double d = pfound ? pd : 1.0;
+    if (row < nrow) { dg[row] = d; key[row] = amg_key(pstrong ? AMG_UNDECIDED : AMG_COVERED, row); }
+    const double q = (row < nrow && d != 0.0) ? ps / fabs(d) : 0.0;
+    unsigned long long bits = wave_max_u64((unsigned long long)__double_as_longlong(q));
+    if (lane == 0 && bits > *rho_bits) atomicMax(const_cast<unsigned long long *>(rho_bits), bits);
   }
 }
 
@@ -478,95 +503,90 @@ constexpr int kProlongSlots = 8;
 // aggregates, and ISPH_AMG_PROLONG_TWO_PASS=1)
 constexpr int kProlongCap = 64;
 
-// The same row in ONE pass, for rows of at most kProlongCap aggregates: a per-wave LDS table (key = aggregate, open
-// addressing) takes the row's terms as they are read; the row goes, columns ascending, to a scratch row of kProlongCap
-// slots and its length to pcnt (k_rows_compact packs the rows).  A longer row raises err bit 8 and the caller falls back
-// to the two passes.  The terms of one aggregate are added in the order the lanes reach the table (like the products of
-// the SpGEMM that consumes P): the last bits of P are not reproducible from run to run, those of the two-pass kernel are.
+// The same row in ONE pass: LPR lanes per row (16: four rows per wave -- the chain row offsets -> columns -> aggregates ->
+// table is four dependent round trips whatever the row holds, so four rows in flight per wave finish in the time of one),
+// a per-row LDS table of 2 LPR slots (key = aggregate, open addressing) takes the terms as they are read, and the row
+// goes, columns ascending, to a scratch row of LPR slots and its length to pcnt (k_rows_compact packs the rows).  A row of more than LPR aggregates raises err bit 8: the caller
+// repeats with LPR = 64 and then falls back to the two passes.  The terms of one aggregate are added in the order the
+// lanes reach the table (like the products of the SpGEMM that consumes P): the last bits of P are not reproducible from
+// run to run, those of the two-pass kernel are.
+template <int LPR>
 __global__ __launch_bounds__(256) void k_prolong_rows(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                                       const double *__restrict__ v, const double *__restrict__ dg,
                                                       const int *__restrict__ agg, const double *__restrict__ pt, double damp,
                                                       int *__restrict__ pcnt, int *__restrict__ tci, double *__restrict__ tcv,
                                                       int *__restrict__ err) {
-  constexpr int TABLE = 2 * kProlongCap, NT = TABLE / 64;
-  __shared__ int tk[kAmgWaves][TABLE];
-  __shared__ double tv[kAmgWaves][TABLE];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * kAmgWaves + w;
-  if (i >= n) return;   // wave-uniform; no workgroup barrier below
-  for (int s = lane; s < TABLE; s += 64) { tk[w][s] = -1; tv[w][s] = 0.0; }
+  constexpr int RPW = 64 / LPR, TABLE = 2 * LPR;
+  __shared__ int tk[kAmgWaves * RPW][TABLE];
+  __shared__ double tv[kAmgWaves * RPW][TABLE];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / LPR, sub = lane % LPR;
+  const int tr = w * RPW + g;
+  const int i = (blockIdx.x * kAmgWaves + w) * RPW + g;
+  const bool live = i < n;   // the lanes of a row past the end walk along: the wave barriers below are for all 64
+  tk[tr][sub] = -1; tk[tr][sub + LPR] = -1;
+  tv[tr][sub] = 0.0; tv[tr][sub + LPR] = 0.0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   bool over = false;
   auto insert = [&](int c, double val) {
     int slot = (int)(amg_hash32((unsigned)c) & (TABLE - 1));
     for (int tries = 0;; ++tries) {
-      const int old = atomicCAS(&tk[w][slot], -1, c);
-      if (old == -1 || old == c) break;
+      int cur = __atomic_load_n(&tk[tr][slot], __ATOMIC_RELAXED);
+      if (cur == -1) cur = atomicCAS(&tk[tr][slot], -1, c);
+      if (cur == -1 || cur == c) break;
       slot = (slot + 1) & (TABLE - 1);
       if (tries >= TABLE) { over = true; slot = -1; break; }
     }
-    if (slot >= 0) atomicAdd(&tv[w][slot], val);
+    if (slot >= 0) atomicAdd(&tv[tr][slot], val);
   };
-  const int ai = agg[i];
-  if (ai >= 0 && lane == 0) insert(ai, pt[i]);
-  const double f = dg[i] != 0.0 ? damp / dg[i] : 0.0;
-  const rp_t lo = rp[i], hi = rp[i + 1];
-  for (rp_t p0 = lo; p0 < hi; p0 += 128) {   // two rounds of loads at a time
-    int a[2];
-    double term[2];
+  if (live) {
+    const int ai = agg[i];
+    if (ai >= 0 && sub == 0) insert(ai, pt[i]);
+    const double f = dg[i] != 0.0 ? damp / dg[i] : 0.0;
+    const rp_t lo = rp[i], hi = rp[i + 1];
+    constexpr int U = LPR == 64 ? 2 : 4;   // rounds of loads in flight
+    for (rp_t p0 = lo; p0 < hi; p0 += U * LPR) {
+      int a[U];
+      double term[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const rp_t p = p0 + 64 * u + lane;
-      a[u] = -1;
-      term[u] = 0.0;
-      if (p < hi) {
-        const int j = ci[p];
-        if (j < n) {
-          const int aj = agg[j];
-          if (aj >= 0) { a[u] = aj; term[u] = -(f * v[p] * pt[j]); }
+      for (int u = 0; u < U; ++u) {
+        const rp_t p = p0 + LPR * u + sub;
+        a[u] = -1;
+        term[u] = 0.0;
+        if (p < hi) {
+          const int j = ci[p];
+          if (j < n) {
+            const int aj = agg[j];
+            if (aj >= 0) { a[u] = aj; term[u] = -(f * v[p] * pt[j]); }
+          }
         }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (a[u] >= 0) insert(a[u], term[u]);
+      for (int u = 0; u < U; ++u)
+        if (a[u] >= 0) insert(a[u], term[u]);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  int kt[NT], rank[NT], cnt = 0;
-  unsigned long long occ[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    kt[t] = tk[w][lane + 64 * t];
-    rank[t] = 0;
-    occ[t] = __ballot(kt[t] >= 0);
-    cnt += __popcll(occ[t]);
+  const int k0 = tk[tr][sub], k1 = tk[tr][sub + LPR];
+  int r0 = 0, r1 = 0, cnt = 0;
+  bool bad = over;
+  for (int s2 = 0; s2 < TABLE; ++s2) {
+    const int ks = tk[tr][s2];   // the same address for the lanes of a row
+    if (ks >= 0) { ++cnt; r0 += ks < k0; r1 += ks < k1; }
   }
-  if (__ballot(over) != 0 || cnt > kProlongCap) {
-    if (lane == 0) { atomicOr(err, 8); pcnt[i] = 0; }
-    return;
-  }
-#pragma unroll
-  for (int u = 0; u < NT; ++u) {
-    unsigned long long m = occ[u];
-    while (m) {
-      const int src = __ffsll((long long)m) - 1;
-      const int ks = __builtin_amdgcn_readlane(kt[u], src);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) rank[t] += ks < kt[t];
-      m &= m - 1;
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-    if (kt[t] >= 0) {
-      tci[(size_t)i * kProlongCap + rank[t]] = kt[t];
-      tcv[(size_t)i * kProlongCap + rank[t]] = tv[w][lane + 64 * t];
-    }
-  if (lane == 0) pcnt[i] = cnt;
+  // a lane that met a full table: the row's other lanes learn it from the vote
+  unsigned long long votes = __ballot(over);
+  if (LPR < 64) votes = (votes >> (g * LPR)) & ((1ull << (LPR & 63)) - 1ull);
+  bad = votes != 0 || cnt > LPR;
+  if (!live) return;
+  if (bad) { if (sub == 0) { atomicOr(err, 8); pcnt[i] = 0; } return; }
+  if (k0 >= 0) { tci[(size_t)i * LPR + r0] = k0; tcv[(size_t)i * LPR + r0] = tv[tr][sub]; }
+  if (k1 >= 0) { tci[(size_t)i * LPR + r1] = k1; tcv[(size_t)i * LPR + r1] = tv[tr][sub + LPR]; }
+  if (sub == 0) pcnt[i] = cnt;
 }
 
+// the two-pass kernel (see above)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_prolong(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ v, const double *__restrict__ dg,
@@ -761,56 +781,75 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int n, int yrows, const rp_
   auto insert = [&](int c, double val) {
     int slot = (int)(amg_hash32((unsigned)c) & (TABLE - 1));
     for (int tries = 0;; ++tries) {
-      const int old = atomicCAS(&tk[w][slot], -1, c);
-      if (old == -1 || old == c) break;
+      // most products meet a slot that holds their column already: a plain read (one broadcast for all the lanes of an
+      // address) settles those, the compare-and-swap -- serialised lane by lane on one address -- only runs on an empty slot
+      int cur = __atomic_load_n(&tk[w][slot], __ATOMIC_RELAXED);
+      if (cur == -1) cur = atomicCAS(&tk[w][slot], -1, c);
+      if (cur == -1 || cur == c) break;
       slot = (slot + 1) & (TABLE - 1);
       if (tries >= TABLE) { over = true; slot = -1; break; }
     }
     if (slot >= 0) atomicAdd(&tv[w][slot], val);
   };
   const rp_t x0 = xrp[i], x1 = xrp[i + 1];
-  for (rp_t p0 = x0; p0 < x1; p0 += 64) {
-    const rp_t p = p0 + lane;
-    int len = 0;
-    rp_t qb = 0;
-    double xa = 0.0;
-    if (p < x1) {
-      const int k = xci[p];
-      if (k < yrows) { qb = yrp[k]; len = (int)(yrp[k + 1] - qb); xa = xv[p]; }
+  for (rp_t pp = x0; pp < x1; pp += 128) {
+    // the X entries and Y row extents of two rounds of 64 are requested together (one dependent chain for both)
+    int kk[2], len2[2];
+    rp_t qb2[2];
+    double xa2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const rp_t p = pp + 64 * h + lane;
+      kk[h] = -1;
+      xa2[h] = 0.0;
+      if (p < x1) { const int k = xci[p]; if (k < yrows) { kk[h] = k; xa2[h] = xv[p]; } }
     }
-    const int incl = wave_scan_incl_i32(len);
-    const int T = __builtin_amdgcn_readlane(incl, 63), start = incl - len;
-    if (T <= kOwnCap) {
-      for (int t = 0; t < len; ++t) own[w][start + t] = (unsigned char)lane;
-      sbase[w][lane] = qb - start;
-      sxa[w][lane] = xa;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // four rounds of loads are issued before the first insertion waits on its table slot (the compiler keeps loads
-      // behind the LDS atomics of the round before when the loop is written round by round)
-      for (int x0 = 0; x0 < T; x0 += 256) {
-        int c[4];
-        double pv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int x = x0 + 64 * u + lane;
-          c[u] = -1;
-          pv[u] = 0.0;
-          if (x < T) {
-            const int e = own[w][x];
-            const rp_t q = sbase[w][e] + x;
-            c[u] = yci[q];
-            pv[u] = sxa[w][e] * yv[q];
+    for (int h = 0; h < 2; ++h) {
+      len2[h] = 0;
+      qb2[h] = 0;
+      if (kk[h] >= 0) { qb2[h] = yrp[kk[h]]; len2[h] = (int)(yrp[kk[h] + 1] - qb2[h]); }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (pp + 64 * h >= x1) break;   // wave-uniform
+      const int len = len2[h];
+      const rp_t qb = qb2[h];
+      const double xa = xa2[h];
+      const int incl = wave_scan_incl_i32(len);
+      const int T = __builtin_amdgcn_readlane(incl, 63), start = incl - len;
+      if (T <= kOwnCap) {
+        for (int t = 0; t < len; ++t) own[w][start + t] = (unsigned char)lane;
+        sbase[w][lane] = qb - start;
+        sxa[w][lane] = xa;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // four rounds of loads are issued before the first insertion waits on its table slot (the compiler keeps loads
+        // behind the LDS atomics of the round before when the loop is written round by round)
+        for (int xx = 0; xx < T; xx += 256) {
+          int c[4];
+          double pv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int x = xx + 64 * u + lane;
+            c[u] = -1;
+            pv[u] = 0.0;
+            if (x < T) {
+              const int e = own[w][x];
+              const rp_t q = sbase[w][e] + x;
+              c[u] = yci[q];
+              pv[u] = sxa[w][e] * yv[q];
+            }
           }
-        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (c[u] >= 0) insert(c[u], pv[u]);
+          for (int u = 0; u < 4; ++u)
+            if (c[u] >= 0) insert(c[u], pv[u]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      } else {   // Y rows of hundreds of entries: every lane walks its own
+        for (int t = 0; t < len; ++t) insert(yci[qb + t], xa * yv[qb + t]);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    } else {   // Y rows of hundreds of entries: every lane walks its own
-      for (int t = 0; t < len; ++t) insert(yci[qb + t], xa * yv[qb + t]);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -848,14 +887,16 @@ __global__ __launch_bounds__(256) void k_spgemm_rows(int n, int yrows, const rp_
   if (lane == 0) ccnt[i] = cnt;
 }
 
-// scratch rows of `cap` slots (a power of two) -> CSR
+// scratch rows of 1 << cap_shift slots -> CSR, sixteen lanes per row
 __global__ void k_rows_compact(int n, int cap_shift, const rp_t *__restrict__ rp, const int *__restrict__ tci,
                                const double *__restrict__ tcv, int *__restrict__ ci, double *__restrict__ v) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = (int)(idx >> cap_shift), s = (int)(idx & ((1 << cap_shift) - 1));
+  const int r = (int)(idx >> 4), s0 = (int)(idx & 15);
   if (r >= n) return;
   const rp_t b = rp[r];
-  if (s < (int)(rp[r + 1] - b)) { ci[b + s] = tci[idx]; v[b + s] = tcv[idx]; }
+  const int len = (int)(rp[r + 1] - b);
+  const size_t src = (size_t)r << cap_shift;
+  for (int s2 = s0; s2 < len; s2 += 16) { ci[b + s2] = tci[src + s2]; v[b + s2] = tcv[src + s2]; }
 }
 
 // y = R x for a CSR matrix with long rows: one wave per row, coalesced reads of the row, fixed-order wave sum
@@ -1027,7 +1068,9 @@ inline int amg_read_off(isph_ctx *ctx, const rp_t *dev, long long *host) {
 inline int amg_wave_grid(int n) { return (n + kAmgWaves - 1) / kAmgWaves; }
 
 // device CSR copy of a SELL matrix (rows stay column-sorted)
-inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char> &tmp) {
+// prep (dg, sc, key, rho all given): see k_sell_to_csr_i32<true>
+inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char> &tmp, double *dg = nullptr, int *sc = nullptr,
+                             unsigned long long *key = nullptr, unsigned long long *rho = nullptr) {
   A.n = S.nrow; A.m = S.ncol; A.nnz = S.nnz;
   ISPH_CHECK(A.rp.reserve((size_t)S.nrow + 1));
   ISPH_CHECK(A.ci.reserve((size_t)(S.nnz > 0 ? S.nnz : 1)));
@@ -1038,9 +1081,16 @@ inline int amg_csr_from_sell(isph_ctx *ctx, const Sell &S, DCsr &A, DevBuf<char>
   ISPH_CHECK_HIP(hipMemcpyAsync(len1.p, S.rowlen.p, sizeof(int) * (size_t)S.nrow, hipMemcpyDeviceToDevice, ctx->stream));
   ISPH_CHECK_HIP(hipMemsetAsync(len1.p + S.nrow, 0, sizeof(int), ctx->stream));
   int rc = amg_scan(ctx, len1.p, A.rp.p, S.nrow + 1, tmp);
-  if (rc == ISPH_SUCCESS && S.nrow > 0)
-    hipLaunchKernelGGL(k_sell_to_csr_i32, dim3((S.nslices + 3) / 4), dim3(256), 0, ctx->stream, S.nrow,
-                       S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, (const rp_t *)A.rp.p, A.ci.p, A.v.p);
+  if (rc == ISPH_SUCCESS && S.nrow > 0) {
+    if (dg && sc && key && rho) {
+      if (hipMemsetAsync(rho, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+      hipLaunchKernelGGL((k_sell_to_csr_i32<true>), dim3((S.nslices + 3) / 4), dim3(256), 0, ctx->stream, S.nrow,
+                         S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, (const rp_t *)A.rp.p, A.ci.p, A.v.p, dg, sc, key, rho);
+    } else {
+      hipLaunchKernelGGL((k_sell_to_csr_i32<false>), dim3((S.nslices + 3) / 4), dim3(256), 0, ctx->stream, S.nrow,
+                         S.rowlen.p, S.slice_off.p, S.col.p, S.val.p, (const rp_t *)A.rp.p, A.ci.p, A.v.p);
+    }
+  }
   if (rc == ISPH_SUCCESS && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail("SELL->CSR failed", __FILE__, __LINE__);
   len1.release();
   return rc;
@@ -1163,7 +1213,7 @@ inline int amg_spgemm_rows(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C,
   ISPH_CHECK(C.ci.reserve((size_t)(nnz > 0 ? nnz : 1)));
   ISPH_CHECK(C.v.reserve((size_t)(nnz > 0 ? nnz : 1)));
   if (C.n > 0) {
-    const long long total = (long long)C.n << SHIFT;
+    const long long total = (long long)C.n * 16;
     hipLaunchKernelGGL(k_rows_compact, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, C.n, SHIFT,
                        (const rp_t *)C.rp.p, (const int *)tci.p, (const double *)tcv.p, C.ci.p, C.v.p);
   }
@@ -1207,20 +1257,25 @@ inline void amg_destroy(isph_amg *G) {
 
 // aggregates of level L (sets L->agg) ; returns the number of aggregates in *nagg_out
 // theta == 0: also fills dg and *rho (k_amg_prepare); otherwise dg is read and rho is left to amg_prolongator
-inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, double *dg, unsigned long long *rho, double theta, DevBuf<char> &tmp, int *nagg_out) {
+// prep_sc / prep_key: the strong columns and first keys are already there (amg_csr_from_sell with its prep outputs)
+inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, double *dg, unsigned long long *rho, double theta, DevBuf<char> &tmp, int *nagg_out,
+                         int *prep_sc = nullptr, unsigned long long *prep_key = nullptr) {
   const DCsr &A = L->A;
   const int n = A.n;
   const double th2 = theta * theta;
-  DevTmp<unsigned long long> key, t1, t2;
-  DevTmp<int> flag, id, a1, cnt, scb, listA, listB, list1, stamp;
-  int rc = key.reserve((size_t)n);
+  const bool prepared = prep_sc != nullptr && prep_key != nullptr;
+  DevTmp<unsigned long long> key_own, t1, t2;
+  DevTmp<int> flag, id, a1, cnt, scb_own, listA, listB, list1, stamp;
+  int rc = prepared ? ISPH_SUCCESS : key_own.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = listA.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = listB.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = list1.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = stamp.reserve((size_t)n);
   if (rc == ISPH_SUCCESS && hipMemsetAsync(stamp.p, 0, sizeof(int) * (size_t)n, ctx->stream) != hipSuccess)
     rc = fail("memset failed", __FILE__, __LINE__);
-  if (rc == ISPH_SUCCESS) rc = scb.reserve((size_t)(A.nnz > 0 ? A.nnz : 1));
+  if (rc == ISPH_SUCCESS && !prepared) rc = scb_own.reserve((size_t)(A.nnz > 0 ? A.nnz : 1));
+  unsigned long long *const keyp = prepared ? prep_key : key_own.p;
+  int *const scp = prepared ? prep_sc : scb_own.p;
   if (rc == ISPH_SUCCESS) rc = t1.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = t2.reserve((size_t)n);
   if (rc == ISPH_SUCCESS) rc = flag.reserve((size_t)n + 1);
@@ -1233,12 +1288,13 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, double *dg, unsigned long l
   const int *ci = A.ci.p;
   const double *v = A.v.p;
   if (rc == ISPH_SUCCESS) {
-    if (th2 == 0.0) {
+    if (prepared) {
+    } else if (th2 == 0.0) {
       if (hipMemsetAsync(rho, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
-      hipLaunchKernelGGL(k_amg_prepare, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, scb.p, key.p, rho);
+      hipLaunchKernelGGL(k_amg_prepare, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, dg, scp, keyp, rho);
     } else {
-      hipLaunchKernelGGL(k_strong_cols, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, (const double *)dg, th2, scb.p);
-      hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p, key.p);
+      hipLaunchKernelGGL(k_strong_cols, dim3(gw), dim3(256), 0, ctx->stream, n, rp, ci, v, (const double *)dg, th2, scp);
+      hipLaunchKernelGGL(k_mis_init, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scp, keyp);
     }
     // rounds: t1 = max over the strong neighbourhood, t2 = max of t1 (distance 2), decide.  From the second round on
     // the sweeps run over work lists (see k_mis_mark)
@@ -1251,23 +1307,23 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, double *dg, unsigned long l
       if (clist && (long long)und * 4 <= n) {
         if (hipMemsetAsync(cnt.p + 2, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
         hipLaunchKernelGGL(k_mis_mark, dim3(std::min(kMisGrid, (und + 31) / 32)), dim3(256), 0, ctx->stream, ccnt, clist, rp,
-                           (const int *)scb.p, stamp.p, round, list1.p, cnt.p + 2);
+                           (const int *)scp, stamp.p, round, list1.p, cnt.p + 2);
         hipLaunchKernelGGL(k_mis_max_list, dim3(kMisGrid), dim3(256), 0, ctx->stream, (const int *)(cnt.p + 2),
-                           (const int *)list1.p, rp, (const int *)scb.p, (const unsigned long long *)key.p, t1.p);
+                           (const int *)list1.p, rp, (const int *)scp, (const unsigned long long *)keyp, t1.p);
       } else {
-        hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
-                           (const unsigned long long *)key.p, t1.p, (const unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scp,
+                           (const unsigned long long *)keyp, t1.p, (const unsigned long long *)nullptr);
       }
       if (clist)
         hipLaunchKernelGGL(k_mis_max_list, dim3(std::min(kMisGrid, amg_wave_grid(und))), dim3(256), 0, ctx->stream, ccnt, clist,
-                           rp, (const int *)scb.p, (const unsigned long long *)t1.p, t2.p);
+                           rp, (const int *)scp, (const unsigned long long *)t1.p, t2.p);
       else
-        hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
-                           (const unsigned long long *)t1.p, t2.p, (const unsigned long long *)key.p);
+        hipLaunchKernelGGL(k_mis_max, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scp,
+                           (const unsigned long long *)t1.p, t2.p, (const unsigned long long *)keyp);
       if (hipMemsetAsync(ncnt, 0, sizeof(int), ctx->stream) != hipSuccess) { rc = fail("memset failed", __FILE__, __LINE__); break; }
       const int nd = clist ? und : n;
       hipLaunchKernelGGL(k_mis_decide_list, dim3(std::min(kMisGrid, (nd + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
-                         ccnt, clist, n, key.p, (const unsigned long long *)t2.p, nlist, ncnt);
+                         ccnt, clist, n, keyp, (const unsigned long long *)t2.p, nlist, ncnt);
       rc = amg_read_int(ctx, ncnt, &und);
       if (round > 0) cur = 1 - cur;
       if (und == 0) break;
@@ -1276,15 +1332,15 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, double *dg, unsigned long l
   }
   int nroot = 0, nleft = 0, last = 0;
   if (rc == ISPH_SUCCESS) {
-    hipLaunchKernelGGL(k_flag_roots, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const unsigned long long *)key.p, flag.p);
+    hipLaunchKernelGGL(k_flag_roots, dim3(gt), dim3(kBlock), 0, ctx->stream, n, (const unsigned long long *)keyp, flag.p);
     if (hipMemsetAsync(flag.p + n, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
   }
   if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, flag.p, id.p, n + 1, tmp);
   if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, id.p + n, &nroot);
   if (rc == ISPH_SUCCESS) {
-    hipLaunchKernelGGL(k_agg_pass1, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p,
-                       (const unsigned long long *)key.p, (const int *)id.p, a1.p);
-    hipLaunchKernelGGL(k_agg_pass2, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scb.p, v, (const int *)a1.p,
+    hipLaunchKernelGGL(k_agg_pass1, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scp,
+                       (const unsigned long long *)keyp, (const int *)id.p, a1.p);
+    hipLaunchKernelGGL(k_agg_pass2, dim3(gw), dim3(256), 0, ctx->stream, n, rp, (const int *)scp, v, (const int *)a1.p,
                        L->agg.p, flag.p);
     rc = amg_scan(ctx, flag.p, id.p, n + 1, tmp);
   }
@@ -1295,7 +1351,7 @@ inline int amg_aggregate(isph_ctx *ctx, AmgLevel *L, double *dg, unsigned long l
                        L->agg.p);
   if (rc == ISPH_SUCCESS && hipGetLastError() != hipSuccess) rc = fail("aggregation kernels failed", __FILE__, __LINE__);
   *nagg_out = nroot + nleft;
-  key.release(); t1.release(); t2.release(); flag.release(); id.release(); a1.release(); cnt.release(); scb.release();
+  key_own.release(); t1.release(); t2.release(); flag.release(); id.release(); a1.release(); cnt.release(); scb_own.release();
   listA.release(); listB.release(); list1.release(); stamp.release();
   return rc;
 }
@@ -1358,22 +1414,28 @@ inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, unsigne
   long long nnz = 0;
   bool one_pass = false;
   const char *two = getenv("ISPH_AMG_PROLONG_TWO_PASS");
-  if (!(two && two[0] == '1')) {   // one pass into scratch rows of kProlongCap slots
-    DevTmp<int> tci;
-    DevTmp<double> tcv;
+  for (int attempt = 0; attempt < 2 && rc == ISPH_SUCCESS && !one_pass && !(two && two[0] == '1'); ++attempt) {
+    // one pass into scratch rows of 16 slots (four rows per wave), then of 64 (one row per wave)
+    const int shift = attempt == 0 ? 4 : 6, lpr = 1 << shift;
     int herr = 0;
-    if (rc == ISPH_SUCCESS) rc = tci.reserve((size_t)n * kProlongCap);
-    if (rc == ISPH_SUCCESS) rc = tcv.reserve((size_t)n * kProlongCap);
-    if (rc == ISPH_SUCCESS) {
-      if (hipMemsetAsync(cnt.p + n, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
-      hipLaunchKernelGGL(k_prolong_rows, dim3(gw), dim3(256), 0, ctx->stream, n, arp, aci, av, dg, agg, (const double *)pt.p, damp,
-                         cnt.p, tci.p, tcv.p, derr);
-    }
+    DevTmp<int> ps_ci;
+    DevTmp<double> ps_v;
+    rc = ps_ci.reserve((size_t)n << shift);
+    if (rc == ISPH_SUCCESS) rc = ps_v.reserve((size_t)n << shift);
+    if (rc != ISPH_SUCCESS) break;
+    if (hipMemsetAsync(cnt.p + n, 0, sizeof(int), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+    const int rows_wg = kAmgWaves * (64 / lpr), grid = (n + rows_wg - 1) / rows_wg;
+    if (attempt == 0)
+      hipLaunchKernelGGL((k_prolong_rows<16>), dim3(grid), dim3(256), 0, ctx->stream, n, arp, aci, av, dg, agg, (const double *)pt.p, damp,
+                         cnt.p, ps_ci.p, ps_v.p, derr);
+    else
+      hipLaunchKernelGGL((k_prolong_rows<64>), dim3(grid), dim3(256), 0, ctx->stream, n, arp, aci, av, dg, agg, (const double *)pt.p, damp,
+                         cnt.p, ps_ci.p, ps_v.p, derr);
     if (rc == ISPH_SUCCESS) rc = amg_scan(ctx, cnt.p, P.rp.p, n + 1, tmp);
     if (rc == ISPH_SUCCESS && hipMemcpyAsync(&nnz, P.rp.p + n, sizeof(rp_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = fail("copy failed", __FILE__, __LINE__);
     if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, derr, &herr);
-    if (rc == ISPH_SUCCESS && (herr & 8)) {   // a row longer than the scratch rows: the two passes below
+    if (rc == ISPH_SUCCESS && (herr & 8)) {   // a row longer than the scratch rows
       herr &= ~8;
       if (hipMemcpyAsync(derr, &herr, sizeof(int), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
           hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -1384,9 +1446,9 @@ inline int amg_prolongator(isph_ctx *ctx, AmgLevel *L, const double *dg, unsigne
       rc = P.ci.reserve((size_t)(nnz > 0 ? nnz : 1));
       if (rc == ISPH_SUCCESS) rc = P.v.reserve((size_t)(nnz > 0 ? nnz : 1));
       if (rc == ISPH_SUCCESS && n > 0) {
-        const long long total = (long long)n * kProlongCap;
-        hipLaunchKernelGGL(k_rows_compact, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, 6,
-                           (const rp_t *)P.rp.p, (const int *)tci.p, (const double *)tcv.p, P.ci.p, P.v.p);
+        const long long total = (long long)n * 16;
+        hipLaunchKernelGGL(k_rows_compact, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n, shift,
+                           (const rp_t *)P.rp.p, (const int *)ps_ci.p, (const double *)ps_v.p, P.ci.p, P.v.p);
       }
     }
   }
@@ -1640,7 +1702,16 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   G->nlev = 1;
   L0->Am = Am;
   const int n0 = Am->S.nrow;
-  if (rc == ISPH_SUCCESS) rc = amg_csr_from_sell(ctx, Am->S, L0->A, tmp);
+  // threshold 0: the SELL -> CSR sweep of the fine level prepares the aggregation on the way (k_sell_to_csr_i32<true>)
+  DevTmp<int> sc0;
+  DevTmp<unsigned long long> key0;
+  bool prep0 = prm->theta == 0.0 && n0 > 0 && prm->max_levels > 1 && n0 > prm->coarse_max && !(getenv("ISPH_AMG_NO_FUSED_PREP") != nullptr);
+  if (rc == ISPH_SUCCESS && prep0) {
+    rc = sc0.reserve((size_t)(Am->S.nnz > 0 ? Am->S.nnz : 1));
+    if (rc == ISPH_SUCCESS) rc = key0.reserve((size_t)n0);
+    if (rc == ISPH_SUCCESS) rc = dg.reserve((size_t)n0);
+  }
+  if (rc == ISPH_SUCCESS) rc = prep0 ? amg_csr_from_sell(ctx, Am->S, L0->A, tmp, dg.p, sc0.p, key0.p, rho.p) : amg_csr_from_sell(ctx, Am->S, L0->A, tmp);
   if (rc == ISPH_SUCCESS) rc = L0->nv.reserve((size_t)(n0 > 0 ? n0 : 1));
   if (rc == ISPH_SUCCESS) {
     if (nullvec_dev) {
@@ -1672,7 +1743,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
       if (prm->theta != 0.0)
         hipLaunchKernelGGL(k_amg_diag, dim3(amg_wave_grid(n)), dim3(256), 0, ctx->stream, n, (const rp_t *)L->A.rp.p,
                            (const int *)L->A.ci.p, (const double *)L->A.v.p, dg.p);
-      rc = amg_aggregate(ctx, L, dg.p, rho.p, prm->theta, tmp, &nagg);
+      const bool use_prep = prep0 && L == L0;
+      rc = amg_aggregate(ctx, L, dg.p, rho.p, prm->theta, tmp, &nagg, use_prep ? sc0.p : nullptr, use_prep ? key0.p : nullptr);
+      if (use_prep) { sc0.release(); key0.release(); }
     }
     if (rc != ISPH_SUCCESS && !dist) break;
     // no coarsening, or a coarse space too small to carry anything but the null vector: stop here
@@ -1860,8 +1933,7 @@ inline int amg_smooth(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   AmgLevel *L = G->L[(size_t)l];
   const int n = L->A.n;
   if (zero_guess) return amg_sgs_apply(ctx, L, b, x, false);
-  ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
-  hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
+  ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr, b, -1.0));   // r = b - A x
   return amg_sgs_apply(ctx, L, L->r.p, x, true);
 }
 
@@ -1891,21 +1963,16 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   AmgLevel *Lc = G->L[(size_t)l + 1];
   ISPH_CHECK(amg_smooth(ctx, G, l, b, x, true));
   for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
-  ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr));
-  hipLaunchKernelGGL(k_residual, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, b, L->r.p);
+  ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr, b, -1.0));   // r = b - A x
   if (L->R.n > 0)   // (a rank without rows still walks the cycle: its neighbours' exchanges and the all-reduces count on it)
     hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const rp_t *)L->R.rp.p,
                        (const int *)L->R.ci.p, (const double *)L->R.v.p, (const double *)L->r.p, Lc->b.p);
   ISPH_CHECK(amg_vcycle(ctx, G, l + 1, Lc->b.p, Lc->x.p));
-  ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, L->z.p, nullptr));
-  hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
-                     (const double *)L->z.p, x);
+  ISPH_CHECK(spmv_dev(ctx, L->Pm, Lc->x.p, x, nullptr, x, 1.0));   // x += P e
   int first = 0;
   if (L->APm) {
     // r still holds b - A x of before the correction: r -= (A P) e, then the first post-smoothing sweep uses it
-    ISPH_CHECK(spmv_dev(ctx, L->APm, Lc->x.p, L->z.p, nullptr));
-    hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, -1.0, (const double *)nullptr,
-                       (const double *)L->z.p, L->r.p);
+    ISPH_CHECK(spmv_dev(ctx, L->APm, Lc->x.p, L->r.p, nullptr, L->r.p, -1.0));
     ISPH_CHECK(amg_sgs_apply(ctx, L, L->r.p, x, true));
     first = 1;
   }

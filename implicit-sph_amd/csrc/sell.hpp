@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int
                                                       const double *__restrict__ nvec,
                                                       double *__restrict__ dot_partial,
                                                       const int *__restrict__ slice_list = nullptr,
-                                                      const double *__restrict__ xg = nullptr) {
+                                                      const double *__restrict__ xg = nullptr,
+                                                      const double *badd = nullptr, double alpha = 1.0) {
   const int b = xcd_remap(blockIdx.x, nblocks_padded);
   int slice = b * (kBlock / kWave) + (threadIdx.x >> 6);
   if (slice >= nslices) return;
@@ -450,7 +451,11 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv(int nrow, int nslices, int
     acc1 = fma(vv.y, x_at<GHOST>(x, xg, nrow, cc.y), acc1);
   }
   const int row = slice * kSlice + lane;
-  const double r = acc0 + acc1;
+  double r = acc0 + acc1;
+  // epilogue of the AMG cycle: y = badd + alpha (A x) -- residual b - A x, corrections x += P e, r -= (A P) e -- with the
+  // bits of the product followed by the vector kernel it replaces (badd may be y itself)
+  if (alpha != 1.0) r *= alpha;
+  if (badd != nullptr && row < nrow) r += badd[row];
   if (row < nrow) y[row] = r;
   if (DOT) {
     const double d = wave_sum(row < nrow ? r * nvec[row] : 0.0);
@@ -512,7 +517,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, i
                                                         const double *__restrict__ nvec,
                                                         double *__restrict__ dot_partial,
                                                         const int *__restrict__ slice_list = nullptr,
-                                                        const double *__restrict__ xg = nullptr) {
+                                                        const double *__restrict__ xg = nullptr,
+                                                        const double *badd = nullptr, double alpha = 1.0) {
   __shared__ int tab[kBlock / kWave][64];
   const int b = xcd_remap(blockIdx.x, nblocks_padded);
   const int wave = threadIdx.x >> 6;
@@ -560,7 +566,11 @@ __global__ __launch_bounds__(kBlock) void k_sell_spmv16(int nrow, int nslices, i
     acc1 = fma(vv.y, x_at<GHOST>(x, xg, nrow, tw[hi >> 10] | (int)(hi & 1023u)), acc1);
   }
   const int row = slice * kSlice + lane;
-  const double r = acc0 + acc1;
+  double r = acc0 + acc1;
+  // epilogue of the AMG cycle: y = badd + alpha (A x) -- residual b - A x, corrections x += P e, r -= (A P) e -- with the
+  // bits of the product followed by the vector kernel it replaces (badd may be y itself)
+  if (alpha != 1.0) r *= alpha;
+  if (badd != nullptr && row < nrow) r += badd[row];
   if (row < nrow) y[row] = r;
   if (DOT) {
     const double d = wave_sum(row < nrow ? r * nvec[row] : 0.0);

@@ -103,32 +103,34 @@ inline bool sell_cols16(isph_ctx *ctx, const Sell &S) {
 
 template <bool DOT, bool LIST, bool GHOST>
 inline void spmv_launch(isph_ctx *ctx, const Sell &S, bool c16, int nsl, const int *list, const double *x, const double *xg,
-                        double *y, const double *nvec) {
+                        double *y, const double *nvec, const double *badd = nullptr, double alpha = 1.0) {
   if (nsl <= 0) return;
   int nbp = 0;
   const int grid = spmv_grid(nsl, &nbp);
   double *part = DOT ? ctx->partial.p : nullptr;
   if (c16)
     hipLaunchKernelGGL((k_sell_spmv16<8, DOT, LIST, GHOST>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, nsl, nbp,
-                       S.slice_off.p, S.col16.p, S.wtab.p, S.val.p, x, y, nvec, part, list, xg);
+                       S.slice_off.p, S.col16.p, S.wtab.p, S.val.p, x, y, nvec, part, list, xg, badd, alpha);
   else
     hipLaunchKernelGGL((k_sell_spmv<8, DOT, true, LIST, GHOST>), dim3(grid), dim3(kBlock), 0, ctx->stream, S.nrow, nsl, nbp,
-                       S.slice_off.p, S.col.p, S.val.p, x, y, nvec, part, list, xg);
+                       S.slice_off.p, S.col.p, S.val.p, x, y, nvec, part, list, xg, badd, alpha);
 }
 
-// y = A x ; if nvec: also SC_MISC+0 = y.nvec (all-reduced)
-inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, const double *nvec) {
+// y = A x ; if nvec: also SC_MISC+0 = y.nvec (all-reduced).  badd / alpha (without nvec): y = badd + alpha (A x), badd may be y
+inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y, const double *nvec, const double *badd = nullptr,
+                    double alpha = 1.0) {
   const Sell &S = A->S;
   // (a rank whose own rows reference no ghost column still sends what its neighbours' rows reference)
   const bool halo = !A->local && (S.ncol != S.nrow || A->halo.nsend > 0);
   // AMG transfer / coarse operators are small or have very long rows: the window tables do not pay there
   const bool c16 = !A->local && !A->aux && sell_cols16(ctx, S);
+  ISPH_REQUIRE(nvec == nullptr || (badd == nullptr && alpha == 1.0), "spmv: the dot epilogue takes the plain product");
   ProfScope prof((A->local || A->aux) ? nullptr : ctx, PROF_SPMV);  // the SpMV statistics are those of the caller's operator only
   if (nvec)
     ISPH_CHECK(ctx->partial.reserve((size_t)S.nslices > (size_t)kMaxRedBlocks * 66 ? (size_t)S.nslices : (size_t)kMaxRedBlocks * 66));
   if (!halo) {
     if (nvec) spmv_launch<true, false, false>(ctx, S, c16, S.nslices, nullptr, x, nullptr, y, nvec);
-    else spmv_launch<false, false, false>(ctx, S, c16, S.nslices, nullptr, x, nullptr, y, nvec);
+    else spmv_launch<false, false, false>(ctx, S, c16, S.nslices, nullptr, x, nullptr, y, nvec, badd, alpha);
   } else {
     const isph_halo &H = A->halo;
     hipEvent_t *hev = nullptr;
@@ -141,11 +143,11 @@ inline int spmv_dev(isph_ctx *ctx, const isph_mat *A, const double *x, double *y
     ISPH_CHECK(halo_begin(ctx, A, x, hev));
     // interior slices (no ghost column) while the exchange is in flight
     if (nvec) spmv_launch<true, true, false>(ctx, S, c16, H.n_int, H.list_int.p, x, nullptr, y, nvec);
-    else spmv_launch<false, true, false>(ctx, S, c16, H.n_int, H.list_int.p, x, nullptr, y, nvec);
+    else spmv_launch<false, true, false>(ctx, S, c16, H.n_int, H.list_int.p, x, nullptr, y, nvec, badd, alpha);
     if (hev) ISPH_CHECK_HIP(hipEventRecord(hev[2], ctx->stream));
     ISPH_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));
     if (nvec) spmv_launch<true, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);
-    else spmv_launch<false, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec);
+    else spmv_launch<false, true, true>(ctx, S, c16, H.n_bnd, H.list_bnd.p, x, ctx->xghost.p, y, nvec, badd, alpha);
   }
   prof.end();
   if (nvec) {
