@@ -1209,54 +1209,59 @@ inline int stage(isph_ctx *ctx, const T *src, size_t n, int on_device, DevBuf<T>
   return ISPH_SUCCESS;
 }
 
-// stages the neighbour-list offsets (neigh_ptr64 wins over neigh_ptr) and returns the number of list entries
+// stages the neighbour-list offsets (neigh_ptr64 wins over neigh_ptr) and returns the number of list entries of a HOST list
 struct StagedParticles;
 inline int stage_neigh_ptr(isph_ctx *ctx, const isph_particles *P, int n, int on_device, DevBuf<int> &b32,
                            DevBuf<long long> &b64, NeighPtr &np, long long *nnb) {
   ISPH_REQUIRE(P->neigh_ptr || P->neigh_ptr64, "neighbour list offsets missing");
   if (P->neigh_ptr64) {
     ISPH_CHECK(stage(ctx, P->neigh_ptr64, (size_t)n + 1, on_device, b64, &np.p64));
-    if (on_device) {
-      ISPH_CHECK_HIP(hipMemcpyAsync(nnb, P->neigh_ptr64 + n, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-      ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    } else {
-      *nnb = P->neigh_ptr64[n];
-    }
+    // (device lists: the count is only needed to stage a host list, and the layout builder reads its own sizes --
+    // no host round trip here)
+    *nnb = on_device ? 0 : P->neigh_ptr64[n];
   } else {
     ISPH_CHECK(stage(ctx, P->neigh_ptr, (size_t)n + 1, on_device, b32, &np.p32));
-    int last = 0;
-    if (on_device) {
-      ISPH_CHECK_HIP(hipMemcpyAsync(&last, P->neigh_ptr + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    } else {
-      last = P->neigh_ptr[n];
-    }
-    *nnb = last;
+    *nnb = on_device ? 0 : P->neigh_ptr[n];
   }
   ISPH_REQUIRE(*nnb >= 0, "negative neighbour count");
   return ISPH_SUCCESS;
 }
 
 inline int stage_tables(isph_ctx *ctx, const isph_particles *P, StagedParticles &S, AsmTables &T) {
+  (void)S;
   const size_t nt1 = (size_t)P->ntypes + 1;
   ISPH_REQUIRE(P->kind && P->h && P->cutsq, "kind/h/cutsq tables are required (host pointers)");
-  const int *dk; const double *dh, *dc;
-  ISPH_CHECK(stage(ctx, P->kind, nt1, 0, S.kind, &dk));
-  ISPH_CHECK(stage(ctx, P->h, nt1 * nt1, 0, S.h, &dh));
-  ISPH_CHECK(stage(ctx, P->cutsq, nt1 * nt1, 0, S.cutsq, &dc));
-  T.kind = dk; T.h = dh; T.cutsq = dc; T.ntypes = P->ntypes; T.kernel = P->kernel; T.dim = P->dim;
+  T.ntypes = P->ntypes; T.kernel = P->kernel; T.dim = P->dim;
   T.noff = nullptr; T.nt = nullptr; T.sorted = 0;
-  std::vector<double> hi(nt1 * nt1), kn(nt1 * nt1), kd(nt1 * nt1);
-  for (size_t k = 0; k < nt1 * nt1; ++k) {
-    const double hh = P->h[k];
-    hi[k] = hh != 0.0 ? 1.0 / hh : 0.0;
-    kn[k] = hh != 0.0 ? kernel_norm(P->kernel, P->dim, hh) : 0.0;
-    kd[k] = hh != 0.0 ? kn[k] / hh : 0.0;
+  isph_table_cache &C = ctx->tables;
+  const bool same = C.ntypes == P->ntypes && C.kernel == P->kernel && C.dim == P->dim && C.kind.size() == nt1 &&
+                    memcmp(C.kind.data(), P->kind, sizeof(int) * nt1) == 0 &&
+                    memcmp(C.h.data(), P->h, sizeof(double) * nt1 * nt1) == 0 &&
+                    memcmp(C.cutsq.data(), P->cutsq, sizeof(double) * nt1 * nt1) == 0;
+  if (!same) {   // the tables of the context (isph_table_cache): staged when they change, which a run does not do
+    C.ntypes = -1;
+    const int *dk; const double *dh, *dc, *d1, *d2, *d3;
+    ISPH_CHECK(stage(ctx, P->kind, nt1, 0, C.dkind, &dk));
+    ISPH_CHECK(stage(ctx, P->h, nt1 * nt1, 0, C.dh, &dh));
+    ISPH_CHECK(stage(ctx, P->cutsq, nt1 * nt1, 0, C.dcutsq, &dc));
+    std::vector<double> hi(nt1 * nt1), kn(nt1 * nt1), kd(nt1 * nt1);
+    for (size_t k = 0; k < nt1 * nt1; ++k) {
+      const double hh = P->h[k];
+      hi[k] = hh != 0.0 ? 1.0 / hh : 0.0;
+      kn[k] = hh != 0.0 ? kernel_norm(P->kernel, P->dim, hh) : 0.0;
+      kd[k] = hh != 0.0 ? kn[k] / hh : 0.0;
+    }
+    ISPH_CHECK(stage(ctx, hi.data(), nt1 * nt1, 0, C.dhinv, &d1));
+    ISPH_CHECK(stage(ctx, kn.data(), nt1 * nt1, 0, C.dknorm, &d2));
+    ISPH_CHECK(stage(ctx, kd.data(), nt1 * nt1, 0, C.dkdnorm, &d3));
+    ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // hi/kn/kd are stack-lived
+    C.kind.assign(P->kind, P->kind + nt1);
+    C.h.assign(P->h, P->h + nt1 * nt1);
+    C.cutsq.assign(P->cutsq, P->cutsq + nt1 * nt1);
+    C.ntypes = P->ntypes; C.kernel = P->kernel; C.dim = P->dim;
   }
-  ISPH_CHECK(stage(ctx, hi.data(), nt1 * nt1, 0, S.hinv, &T.hinv));
-  ISPH_CHECK(stage(ctx, kn.data(), nt1 * nt1, 0, S.knorm, &T.knorm));
-  ISPH_CHECK(stage(ctx, kd.data(), nt1 * nt1, 0, S.kdnorm, &T.kdnorm));
-  ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // hi/kn/kd are stack-lived
+  T.kind = C.dkind.p; T.h = C.dh.p; T.cutsq = C.dcutsq.p;
+  T.hinv = C.dhinv.p; T.knorm = C.dknorm.p; T.kdnorm = C.dkdnorm.p;
   return ISPH_SUCCESS;
 }
 
@@ -1418,15 +1423,24 @@ inline int assemble_poisson(isph_ctx *ctx, const isph_particles *P, int antisym,
         }
       }
       // rows come out column-sorted when the neighbour lists were ordered; merged duplicates break that order
-      if (rc == ISPH_SUCCESS) rc = (T.sorted && n > 32768) ? sell_set_wmax(ctx, M) : sell_sort_rows(ctx, M);  // columns ascending, like Epetra after FillComplete
+      // (sorted lists, no merge: the widest slice is known since sell_finalize_offsets)
+      if (rc == ISPH_SUCCESS && !(T.sorted && n > 32768)) rc = sell_sort_rows(ctx, M);  // columns ascending, like Epetra after FillComplete
       if (rc == ISPH_SUCCESS && !on_device &&
           hipMemcpyAsync(b_out, db, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         rc = fail("copy failed", __FILE__, __LINE__);
+      // nnz = sum of the row lengths (after the merge), read back with the synchronisation that ends the assembly
+      DevTmp<unsigned long long> acc;
+      unsigned long long hacc = 0;
+      if (rc == ISPH_SUCCESS) rc = acc.reserve(1);
+      if (rc == ISPH_SUCCESS) {
+        if (hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), ctx->stream) != hipSuccess) rc = fail("memset failed", __FILE__, __LINE__);
+        hipLaunchKernelGGL(k_sum_rowlen, dim3(std::min(256, (n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, n,
+                           (const int *)M.rowlen.p, acc.p);
+        if (hipMemcpyAsync(&hacc, acc.p, sizeof(hacc), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail("copy failed", __FILE__, __LINE__);
+      }
       if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         rc = fail("assembly kernel failed", __FILE__, __LINE__);
-    }
-    if (rc == ISPH_SUCCESS) {
-      rc = sell_sum_rowlen(ctx, M, &M.nnz);  // nnz = sum of row lengths (after merge)
+      M.nnz = (long long)hacc;
     }
   }
   S.release();

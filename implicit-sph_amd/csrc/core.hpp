@@ -26,6 +26,18 @@ struct isph_neigh_map {
   const void *order = nullptr;
 };
 
+// The per-type-pair tables of the row kernels (kind, h, cutsq and what is derived from them) as they were staged last:
+// a time step calls half a dozen operators with the same tables, each staging used to cost six small copies and a
+// host synchronisation.
+struct isph_table_cache {
+  int ntypes = -1, kernel = -1, dim = -1;
+  std::vector<int> kind;
+  std::vector<double> h, cutsq;
+  isph::DevBuf<int> dkind;
+  isph::DevBuf<double> dh, dcutsq, dhinv, dknorm, dkdnorm;
+  void release() { dkind.release(); dh.release(); dcutsq.release(); dhinv.release(); dknorm.release(); dkdnorm.release(); ntypes = -1; }
+};
+
 struct isph_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -64,6 +76,7 @@ struct isph_ctx {
   isph::HostStager *stager = nullptr;  // created by the first host-side isph_mat_create_csr
   bool neigh_hold = false;             // isph_ctx_hold_neighbours
   isph_neigh_layout neigh_cache[2];    // [0] list order, [1] ordered by matrix column
+  isph_table_cache tables;             // assemble.hpp stage_tables
   // row numbering of the matrices the assembly entry points build (isph_ctx_set_ordering): 1 = the library's bricks
   // (order.hpp, default), 0 = the caller's atom order
   int ordering = 1;

@@ -145,9 +145,14 @@ int stage_in(isph_ctx *ctx, const T *src, size_t n, int on_device, DevBuf<T> &tm
 int sell_finalize_offsets(isph_ctx *ctx, Sell &S) {
   // slice_off currently holds per-slice entry counts in [0,nslices)
   hipLaunchKernelGGL(k_exclusive_scan_ll, dim3(1), dim3(1024), 0, ctx->stream, S.nslices, S.slice_off.p, S.slice_off.p);
-  long long total = 0;
-  ISPH_CHECK_HIP(hipMemcpyAsync(&total, S.slice_off.p + S.nslices, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  // the whole offset array comes back (8 B per slice): its last entry sizes the arrays, its differences give the
+  // widest slice, which callers with sorted rows would otherwise fetch in a round trip of their own (sell_set_wmax)
+  std::vector<long long> so((size_t)S.nslices + 1, 0);
+  ISPH_CHECK_HIP(hipMemcpyAsync(so.data(), S.slice_off.p, sizeof(long long) * so.size(), hipMemcpyDeviceToHost, ctx->stream));
   ISPH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  const long long total = so[(size_t)S.nslices];
+  S.wmax = 0;
+  for (int s2 = 0; s2 < S.nslices; ++s2) S.wmax = std::max(S.wmax, (int)((so[(size_t)s2 + 1] - so[(size_t)s2]) >> 6));
   S.stored = total;
   ISPH_CHECK(S.col.reserve((size_t)(total > 0 ? total : 1)));
   ISPH_CHECK(S.val.reserve((size_t)(total > 0 ? total : 1)));
@@ -620,6 +625,7 @@ void isph_ctx_destroy(isph_ctx *c) {
   if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   c->xghost.release();
   for (auto &nc : c->neigh_cache) nc.release();
+  c->tables.release();
   if (c->comm) (void)ncclCommDestroy(c->comm);
   if (c->hsend) (void)hipHostFree(c->hsend);
   if (c->hrecv) (void)hipHostFree(c->hrecv);

@@ -180,17 +180,47 @@ __global__ void k_order_hist(int n, OrderGeom g, const double *__restrict__ x, i
   if (g.dim == 3) atomicAdd(&h2[order_bin(g, 2, order_coord(g, 2, x[3 * (size_t)i + 2]))], 1);
 }
 
+// The same histogram through a workgroup-private copy in LDS: particles in lattice order hand a wave 64 times the same
+// y and z bin, and a million global atomics on a few thousand words ran 0.46 ms; here a workgroup of 1024 threads counts
+// its share of the particles in LDS and adds its non-zero bins to the global histogram once.  h = the three axes'
+// histograms one behind the other (o1, o2: where axes 1 and 2 begin), nb_all ints of dynamic LDS.
+constexpr int kHistGroups = 128;
+__global__ __launch_bounds__(1024) void k_order_hist_lds(int n, OrderGeom g, const double *__restrict__ x, int *__restrict__ h,
+                                                         int nb_all, int o1, int o2) {
+  extern __shared__ int order_lh[];
+  for (int s = threadIdx.x; s < nb_all; s += 1024) order_lh[s] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+    atomicAdd(&order_lh[order_bin(g, 0, order_coord(g, 0, x[3 * (size_t)i]))], 1);
+    atomicAdd(&order_lh[o1 + order_bin(g, 1, order_coord(g, 1, x[3 * (size_t)i + 1]))], 1);
+    if (g.dim == 3) atomicAdd(&order_lh[o2 + order_bin(g, 2, order_coord(g, 2, x[3 * (size_t)i + 2]))], 1);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < nb_all; s += 1024) {
+    const int v = order_lh[s];
+    if (v) atomicAdd(&h[s], v);
+  }
+}
+
 // occupancy of the caller's periodic box along its periodic axes, kCutBins bins per axis: bin = clamp(floor((x - lo) * inv))
 constexpr int kCutBins = 4096;
-__global__ void k_order_cut_hist(int n, int dim, OrderBox bx, const double *__restrict__ x, int *__restrict__ h) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for (int a = 0; a < dim; ++a) {
-    if (!bx.periodic[a]) continue;
-    const double inv = (double)kCutBins / (bx.hi[a] - bx.lo[a]);
-    int q = (int)floor((x[3 * (size_t)i + a] - bx.lo[a]) * inv);
-    q = q < 0 ? 0 : (q >= kCutBins ? kCutBins - 1 : q);
-    atomicAdd(&h[a * kCutBins + q], 1);
+// (workgroup-private LDS copy, like k_order_hist_lds)
+__global__ __launch_bounds__(1024) void k_order_cut_hist(int n, int dim, OrderBox bx, const double *__restrict__ x, int *__restrict__ h) {
+  __shared__ int lh[3 * kCutBins];
+  for (int s = threadIdx.x; s < 3 * kCutBins; s += 1024) lh[s] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024)
+    for (int a = 0; a < dim; ++a) {
+      if (!bx.periodic[a]) continue;
+      const double inv = (double)kCutBins / (bx.hi[a] - bx.lo[a]);
+      int q = (int)floor((x[3 * (size_t)i + a] - bx.lo[a]) * inv);
+      q = q < 0 ? 0 : (q >= kCutBins ? kCutBins - 1 : q);
+      atomicAdd(&lh[a * kCutBins + q], 1);
+    }
+  __syncthreads();
+  for (int s = threadIdx.x; s < 3 * kCutBins; s += 1024) {
+    const int v = lh[s];
+    if (v) atomicAdd(&h[s], v);
   }
 }
 
@@ -332,7 +362,7 @@ inline int order_build(hipStream_t st, int dim, int n, const double *x, RowOrder
     ISPH_CHECK_HIP(hipMemsetAsync(ch.p, 0, sizeof(int) * 3 * kCutBins, st));
     OrderBox bx = *box;
     for (int a = 0; a < 3; ++a) if (a >= dim || !(bx.hi[a] > bx.lo[a])) bx.periodic[a] = 0;
-    hipLaunchKernelGGL(k_order_cut_hist, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, dim, bx, x, ch.p);
+    hipLaunchKernelGGL(k_order_cut_hist, dim3(std::min(kHistGroups, (n + 1023) / 1024)), dim3(1024), 0, st, n, dim, bx, x, ch.p);
     std::vector<int> hc((size_t)3 * kCutBins);
     ISPH_CHECK_HIP(hipMemcpyAsync(hc.data(), ch.p, sizeof(int) * hc.size(), hipMemcpyDeviceToHost, st));
     ISPH_CHECK_HIP(hipStreamSynchronize(st));
@@ -376,8 +406,15 @@ inline int order_build(hipStream_t st, int dim, int n, const double *x, RowOrder
     DevTmp<int> hist;
     ISPH_CHECK(hist.reserve(nb_all));
     ISPH_CHECK_HIP(hipMemsetAsync(hist.p, 0, sizeof(int) * nb_all, st));
-    hipLaunchKernelGGL(k_order_hist, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, gw, x, hist.p, hist.p + gw.nbins[0],
-                       hist.p + gw.nbins[0] + gw.nbins[1]);
+    if (nb_all * sizeof(int) <= (size_t)150 * 1024) {
+      const size_t lds = nb_all * sizeof(int);
+      ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_order_hist_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_order_hist_lds, dim3(std::min(kHistGroups, (n + 1023) / 1024)), dim3(1024), lds, st, n, gw, x, hist.p, (int)nb_all,
+                         gw.nbins[0], gw.nbins[0] + gw.nbins[1]);
+    } else {
+      hipLaunchKernelGGL(k_order_hist, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, gw, x, hist.p, hist.p + gw.nbins[0],
+                         hist.p + gw.nbins[0] + gw.nbins[1]);
+    }
     std::vector<int> hh(nb_all);
     ISPH_CHECK_HIP(hipMemcpyAsync(hh.data(), hist.p, sizeof(int) * nb_all, hipMemcpyDeviceToHost, st));
     ISPH_CHECK_HIP(hipStreamSynchronize(st));

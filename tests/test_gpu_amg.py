@@ -133,3 +133,72 @@ def test_cg_with_amg_on_an_spd_system(gpu_ctx):
     info = hip.solve(gpu_ctx, A, b.copy(), xg, prec=hip.PrecondAMG(gpu_ctx, A, params=hip.AmgParams(**kw)), params=prm_g)
     assert info.converged == 1 and io_.converged == 1 and abs(info.iters - io_.iters) <= 1
     assert np.linalg.norm(xg - xo) <= 1e-6 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("env", ["ISPH_AMG_PROLONG_TWO_PASS", "ISPH_AMG_SPGEMM_TWO_PASS", "ISPH_AMG_COARSE_STREAM", "ISPH_AMG_NO_FUSED_PREP"])
+@pytest.mark.parametrize("theta", [0.0, 0.05])
+def test_amg_fallback_kernels_build_the_same_hierarchy(gpu_ctx, monkeypatch, env, theta):
+    """The set-up has a fast path and the kernels it falls back to (rows with more aggregates / columns than the scratch
+    rows hold, levels too large for dense smoother blocks, a non-zero threshold): each fallback, forced by its switch,
+    gives the hierarchy of the default path -- same patterns, values to round-off, the same V cycle."""
+    pr = Problem(tgv_spec(dim=3, n=18, mode=workload.JITTER, brick=6))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    nv = np.ones(n) / np.sqrt(n)
+    kw = dict(theta=theta, block=256, coarse_max=64)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M0 = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(**kw))
+    monkeypatch.setenv(env, "1")
+    M1 = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(**kw))
+    monkeypatch.delenv(env)
+    assert M0.levels == M1.levels >= 2
+    # with a threshold the strength test of level 1 sits on values that differ in their last bits between the two paths, and
+    # a coupling on the edge may fall either way: below the first coarse operator only the unthresholded hierarchy is compared
+    deep = M0.levels if theta == 0.0 else 2
+    for l in range(deep):
+        whats = ("A", "P") if (l < M0.levels - 1 and (theta == 0.0 or l == 0)) else ("A",)
+        for what in whats:
+            r0, c0, v0 = M0.export(l, what)
+            r1, c1, v1 = M1.export(l, what)
+            assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+            assert np.max(np.abs(v0 - v1)) <= 1e-12 * np.abs(v0).max()
+    if theta == 0.0:
+        for l in range(M0.levels):
+            assert M0.level_info(l) == M1.level_info(l)
+        r = np.random.default_rng(5).standard_normal(n)
+        z0, z1 = M0.apply(r), M1.apply(r)
+        assert np.linalg.norm(z0 - z1) <= 1e-10 * np.linalg.norm(z0)
+    M0.close(); M1.close(); A.close()
+
+
+@pytest.mark.parametrize("case,theta,wider_than", [
+    (dict(dim=3, n=18, mode=workload.JITTER, brick=6), 0.05, 16),                                  # 64 lanes per row
+    (dict(dim=3, n=14, mode=workload.JITTER, kernel="quintic", cut_over_h=3.0, brick=7), 0.03, 64),   # the two passes
+])
+def test_amg_rows_with_many_aggregates_take_the_wider_scratch_rows(gpu_ctx, case, theta, wider_than):
+    """A thresholded graph leaves small aggregates, so a row of the smoothed prolongator meets more of them than the
+    16-slot scratch rows of the fast path hold: the set-up repeats the row kernel with 64 lanes per row, then with the two
+    passes (and the product A P with wider scratch rows when it must) -- the hierarchy is still the oracle's."""
+    pr = Problem(tgv_spec(**case))
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    nv = np.ones(n) / np.sqrt(n)
+    kw = dict(theta=theta, block=256, coarse_max=64)
+    G = orc.AMG(rp, ci, val, nullvec=nv, **kw)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(**kw))
+    assert M.levels == G.levels >= 2
+    rP, cP, vP = M.export(0, "P")
+    assert np.diff(rP).max() > wider_than, np.diff(rP).max()      # the premise
+    for l in range(G.levels):
+        assert G.level_info(l) == M.level_info(l)
+        ro, co, vo = G.export(l, "A")
+        rg, cg, vg = M.export(l, "A")
+        assert np.array_equal(ro, rg) and np.array_equal(co, cg)
+        assert np.max(np.abs(vo - vg)) <= 1e-11 * np.abs(vo).max()
+        if l < G.levels - 1:
+            ro, co, vo = G.export(l, "P")
+            rg, cg, vg = M.export(l, "P")
+            assert np.array_equal(ro, rg) and np.array_equal(co, cg)
+            assert np.max(np.abs(vo - vg)) <= 1e-12 * np.abs(vo).max()
+    M.close(); A.close()
