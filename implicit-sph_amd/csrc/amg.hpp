@@ -66,7 +66,7 @@ struct isph_amg {
   std::vector<isph::AmgLevel *> L;
   isph::DevBuf<double> cinv;  // dense inverse of the coarsest operator (non-singular case)
   int nc = 0;
-  // more than one rank (coarse levels across ranks, see amg_extend_prolongator): the coarsest operator of ALL ranks is
+  // more than one rank (coarse levels across ranks, see amg_extend_pack / amg_extend_finish): the coarsest operator of ALL ranks is
   // inverted on every rank (nc = its global size, rows nc_off .. nc_off + nc_loc are this rank's)
   int dist = 0, nc_off = 0, nc_loc = 0;
   isph::DevBuf<double> bglob;
@@ -1552,12 +1552,20 @@ inline int amg_host_allreduce(isph_ctx *ctx, double *h, int count, int op) {
 
 // P (n x nagg, this rank's rows) -> Pext ((n + ghosts of A) x (nagg + ghosts of the coarse level)) and the coarse halo
 // lists.  K: longest P row on any send list of any rank (agreed by the caller).
-inline int amg_extend_prolongator(isph_ctx *ctx, const isph_halo &H, const DCsr &P, int K, DCsr &Pext, std::vector<int> &csend_ptr,
-                                  std::vector<int> &csend_idx, std::vector<int> &crecv_ptr, DevBuf<char> &tmp) {
-  const int n = P.n, nagg = P.m, np = H.npeers, nsend = H.nsend, nrecv = H.nrecv;
-  const size_t rec = 2 + 2 * (size_t)K;
+// Two halves, so that the ranks can agree between them: everything of the first half that can fail on one rank alone
+// (allocations, scans, read-backs) happens BEFORE any rank enters the point-to-point exchange of the second half -- a rank
+// that returned early from a single function left its peers waiting in that exchange for ever (amg_create holds a
+// consensus all-reduce between the halves).
+struct AmgExtendState {
   DevTmp<double> sbuf, rbuf;
-  DevTmp<int> flag, pos, list, slot0, len;
+  DevTmp<int> flag, pos, list;
+};
+inline int amg_extend_pack(isph_ctx *ctx, const isph_halo &H, const DCsr &P, int K, AmgExtendState &St, std::vector<int> &csend_ptr,
+                           std::vector<int> &csend_idx, DevBuf<char> &tmp) {
+  const int nagg = P.m, np = H.npeers, nsend = H.nsend, nrecv = H.nrecv;
+  const size_t rec = 2 + 2 * (size_t)K;
+  DevTmp<double> &sbuf = St.sbuf, &rbuf = St.rbuf;
+  DevTmp<int> &flag = St.flag, &pos = St.pos, &list = St.list;
   ISPH_CHECK(sbuf.reserve(std::max<size_t>((size_t)nsend * rec, 1)));
   ISPH_CHECK(rbuf.reserve(std::max<size_t>((size_t)nrecv * rec, 1)));
   ISPH_CHECK(flag.reserve((size_t)nagg + 1));
@@ -1588,6 +1596,14 @@ inline int amg_extend_prolongator(isph_ctx *ctx, const isph_halo &H, const DCsr 
     }
     csend_ptr[(size_t)p + 1] = csend_ptr[(size_t)p] + count;
   }
+  return ISPH_SUCCESS;
+}
+inline int amg_extend_finish(isph_ctx *ctx, const isph_halo &H, const DCsr &P, int K, AmgExtendState &St, DCsr &Pext,
+                             std::vector<int> &crecv_ptr, DevBuf<char> &tmp) {
+  const int n = P.n, nagg = P.m, np = H.npeers, nrecv = H.nrecv;
+  const size_t rec = 2 + 2 * (size_t)K;
+  DevTmp<double> &sbuf = St.sbuf, &rbuf = St.rbuf;
+  DevTmp<int> slot0, len;
   ISPH_CHECK(comm_exchange(ctx, H, sbuf.p, rbuf.p, (int)rec, false, ctx->stream));
   // what every peer will send from now on: announced in each of its records
   crecv_ptr.assign((size_t)np + 1, 0);
@@ -1768,7 +1784,7 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     std::vector<int> cs_ptr, cs_idx, cr_ptr;
     bool extended = false;
     if (dist) {
-      // the P rows behind A's ghost columns (amg_extend_prolongator); K is agreed first, by all ranks
+      // the P rows behind A's ghost columns (amg_extend_pack / amg_extend_finish); K is agreed first, by all ranks
       DevTmp<int> kmax;
       int hk = 0;
       if (rc == ISPH_SUCCESS) rc = kmax.reserve(1);
@@ -1780,8 +1796,15 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
       double h[2] = {(double)hk, rc == ISPH_SUCCESS ? 0.0 : 1.0};
       if (amg_host_allreduce(ctx, h, 2, 1) != ISPH_SUCCESS) { rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__); amg_level_destroy(Lc); break; }
       if (h[1] != 0.0) { if (rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__); amg_level_destroy(Lc); break; }
-      if (H.npeers > 0) {   // (a rank without ghost columns of its own still owes its neighbours their rows)
-        rc = amg_extend_prolongator(ctx, H, L->P, std::max((int)h[0], 1), Pext, cs_ptr, cs_idx, cr_ptr, tmp);
+      AmgExtendState est;
+      const int Kx = std::max((int)h[0], 1);
+      // (a rank without ghost columns of its own still owes its neighbours their rows)
+      if (H.npeers > 0) rc = amg_extend_pack(ctx, H, L->P, Kx, est, cs_ptr, cs_idx, tmp);
+      double h2 = rc == ISPH_SUCCESS ? 0.0 : 1.0;   // nobody enters the exchange unless everybody can
+      if (amg_host_allreduce(ctx, &h2, 1, 1) != ISPH_SUCCESS) { rc = fail("AMG: consensus between the ranks failed", __FILE__, __LINE__); amg_level_destroy(Lc); break; }
+      if (h2 != 0.0) { if (rc == ISPH_SUCCESS) rc = fail("AMG: set-up failed on another rank", __FILE__, __LINE__); amg_level_destroy(Lc); break; }
+      if (H.npeers > 0) {
+        rc = amg_extend_finish(ctx, H, L->P, Kx, est, Pext, cr_ptr, tmp);
         extended = rc == ISPH_SUCCESS;
       }
     }
@@ -1803,7 +1826,7 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
       if (rc == ISPH_SUCCESS) L->APm->local = true;
     }
     AP.release();
-    if (rc == ISPH_SUCCESS && extended) {   // the coarse operator exchanges with the same peers (lists: amg_extend_prolongator)
+    if (rc == ISPH_SUCCESS && extended) {   // the coarse operator exchanges with the same peers (lists: amg_extend_pack / amg_extend_finish)
       rc = isph_mat_set_halo(ctx, Lc->Aown, H.npeers, H.peer.data(), cs_ptr.data(), cs_idx.empty() ? nullptr : cs_idx.data(), cr_ptr.data());
       if (rc == ISPH_SUCCESS) Lc->Aown->aux = true;
     }
