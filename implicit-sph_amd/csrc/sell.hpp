@@ -485,25 +485,49 @@ __global__ __launch_bounds__(kBlock) void k_sell_compress_cols(int slice_begin, 
   const long long off = slice_off[slice];
   const long long nent = slice_off[slice + 1] - off;
   bool bad = false;
-  for (long long e = lane; e < nent; e += 64) {
-    const int win = scol[off + e] >> 10;
-    int slot = (int)(amg_like_hash(win) & 63u);
-    for (int tries = 0; tries < 64; ++tries) {
-      const int old = atomicCAS(&tab[wave][slot], -1, win);
-      if (old == -1 || old == win) break;
-      slot = (slot + 1) & 63;
-      if (tries == 63) bad = true;
+  // Position e of a slice belongs to row (e % 128) / 2 (pair-interleaved layout), so a lane that walks e = lane, lane + 64,
+  // .. alternates between TWO rows and sees every second entry of each, in ascending column order: the window of an
+  // entry is nearly always the window of the lane's entry two trips earlier.  The lane remembers one (window, slot) per
+  // row; the table in LDS (compare-and-swap while it is built, probing when it is read) is only asked when the window
+  // changes (0.53 -> see docs/kernels_detail.md; the table and the codes are what they were).
+  int last_win[2] = {-2, -2}, last_slot[2] = {0, 0};
+  for (long long e0 = lane; e0 < nent; e0 += 128) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long e = e0 + 64 * h;
+      if (e >= nent) break;
+      const int win = scol[off + e] >> 10;
+      if (win == last_win[h]) continue;
+      int slot = (int)(amg_like_hash(win) & 63u);
+      for (int tries = 0; tries < 64; ++tries) {
+        int old = __atomic_load_n(&tab[wave][slot], __ATOMIC_RELAXED);
+        if (old == -1) old = atomicCAS(&tab[wave][slot], -1, win);
+        if (old == -1 || old == win) break;
+        slot = (slot + 1) & 63;
+        if (tries == 63) bad = true;
+      }
+      last_win[h] = win;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   if (__ballot(bad)) { if (lane == 0) atomicOr(fail, 1); return; }
   wtab[(long long)slice * 64 + lane] = tab[wave][lane];
-  for (long long e = lane; e < nent; e += 64) {
-    const int c = scol[off + e], win = c >> 10;
-    int slot = (int)(amg_like_hash(win) & 63u);
-    while (tab[wave][slot] != win) slot = (slot + 1) & 63;
-    c16[off + e] = (unsigned short)((slot << 10) | (c & 1023));
+  last_win[0] = last_win[1] = -2;
+  for (long long e0 = lane; e0 < nent; e0 += 128) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long e = e0 + 64 * h;
+      if (e >= nent) break;
+      const int c = scol[off + e], win = c >> 10;
+      if (win != last_win[h]) {
+        int slot = (int)(amg_like_hash(win) & 63u);
+        while (tab[wave][slot] != win) slot = (slot + 1) & 63;
+        last_win[h] = win;
+        last_slot[h] = slot;
+      }
+      c16[off + e] = (unsigned short)((last_slot[h] << 10) | (c & 1023));
+    }
   }
 }
 
