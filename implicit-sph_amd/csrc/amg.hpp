@@ -922,22 +922,40 @@ __global__ void k_dense_from_csr(int n, const rp_t *__restrict__ rp, const int *
   for (rp_t p = rp[i] + threadIdx.x; p < rp[i + 1]; p += blockDim.x)
     if (ci[p] < n) aug[(size_t)i * 2 * n + ci[p]] = v[p];
 }
-// Gauss-Jordan with partial pivoting (first maximal row), one elimination step per launch pair; the right half of
-// aug ends as A^-1.  k_gj_pivot: pivot search, row swap, scaling of the pivot row, copy of column k.
-__global__ __launch_bounds__(1024) void k_gj_pivot(int n, int k, double *__restrict__ aug, double *__restrict__ colk,
-                                                   int *__restrict__ err) {
-  __shared__ double sval[1024];
-  __shared__ int sidx[1024];
-  const int t = threadIdx.x, w = 2 * n;
+// Gauss-Jordan with partial pivoting, ONE launch per elimination step (a level of ~10^3 rows took 2 x 10^3 launches of
+// 7 us with a pivot kernel and an elimination kernel per step -- 14 ms of every set-up of the reference's benchmark
+// protocol, tgv.xml: Quintic kernel, ML, DoubleDiag).  What makes one launch enough:
+//   * every workgroup (= matrix row) finds the pivot itself, from a compact copy of the pivot column that the step
+//     before left behind (cur / next take turns);
+//   * rows are not swapped and the pivot row is not scaled: pivrow[k] names the row that served column k, and the
+//     elimination stored_r -= (stored_r[k] / stored_p[k]) stored_p is the same whether p was scaled or not.  Nobody writes
+//     what another workgroup of the same launch reads (the pivot row stays as it is; column k itself is left alone, it is
+//     never read again; columns < k of the pivot row are zero);
+//   * k_gj_finish divides row pivrow[k] of the right half by its pivot and stores it as row k of the LEFT half, which is
+//     where the application kernels read the inverse.
+// usedat[r] = the step row r served as pivot (-1: not yet); a value >= k read during step k still means "not yet".
+__global__ void k_gj_init(int n, const double *__restrict__ aug, double *__restrict__ col0, int *__restrict__ usedat) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) { col0[r] = aug[(size_t)r * 2 * n]; usedat[r] = -1; }
+}
+__global__ __launch_bounds__(256) void k_gj_step(int n, int k, double *__restrict__ aug, const double *__restrict__ cur,
+                                                 double *__restrict__ next, int *__restrict__ usedat, int *__restrict__ pivrow,
+                                                 int *__restrict__ err) {
+  __shared__ double sval[256];
+  __shared__ int sidx[256];
+  const int r = blockIdx.x, t = threadIdx.x, w = 2 * n;
+  if (*err & 4) return;
   double best = -1.0;
   int bi = 0x7fffffff;
-  for (int r = k + t; r < n; r += blockDim.x) {
-    const double a = fabs(aug[(size_t)r * w + k]);
-    if (a > best) { best = a; bi = r; }
+  for (int q = t; q < n; q += 256) {
+    const int u = usedat[q];
+    if (u >= 0 && u < k) continue;
+    const double a = fabs(cur[q]);
+    if (a > best) { best = a; bi = q; }   // ascending q per thread: the first maximal row of the thread's share
   }
   sval[t] = best; sidx[t] = bi;
   __syncthreads();
-  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if (t < o) {
       const double a = sval[t + o];
       const int ai = sidx[t + o];
@@ -946,31 +964,36 @@ __global__ __launch_bounds__(1024) void k_gj_pivot(int n, int k, double *__restr
     __syncthreads();
   }
   const int piv = sidx[0];
-  if (!(sval[0] > 0.0)) { if (t == 0) atomicOr(err, 4); return; }  // singular coarse operator
-  const double d = 1.0 / aug[(size_t)piv * w + k];
-  __syncthreads();
-  for (int c = t; c < w; c += blockDim.x) {
-    const double a = aug[(size_t)piv * w + c];
-    if (piv != k) aug[(size_t)piv * w + c] = aug[(size_t)k * w + c];
-    aug[(size_t)k * w + c] = a * d;
+  if (!(sval[0] > 0.0)) { if (t == 0 && r == 0) atomicOr(err, 4); return; }  // singular coarse operator (every row sees it)
+  double *row = aug + (size_t)r * w;
+  if (r == piv) {
+    if (t == 0) { usedat[r] = k; pivrow[k] = r; if (k + 1 < n) next[r] = row[k + 1]; }
+    return;
   }
+  const double *prow = aug + (size_t)piv * w;
+  const double f = cur[r] / cur[piv];
+  if (f != 0.0)
+    for (int c = k + 1 + t; c < w; c += 256) row[c] -= f * prow[c];
   __syncthreads();
-  for (int r = t; r < n; r += blockDim.x) colk[r] = aug[(size_t)r * w + k];
+  if (t == 0 && k + 1 < n) next[r] = row[k + 1];
 }
-__global__ __launch_bounds__(256) void k_gj_elim(int n, int k, double *__restrict__ aug, const double *__restrict__ colk,
-                                                 const int *__restrict__ err) {
-  const int r = blockIdx.x, w = 2 * n;
-  if (r == k || (*err & 4)) return;
-  const double f = colk[r];
-  if (f == 0.0) return;
-  for (int c = threadIdx.x; c < w; c += blockDim.x) aug[(size_t)r * w + c] -= f * aug[(size_t)k * w + c];
+__global__ void k_gj_pivots(int n, const double *__restrict__ aug, const int *__restrict__ pivrow, double *__restrict__ pv) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) pv[k] = aug[(size_t)pivrow[k] * 2 * n + k];
+}
+__global__ __launch_bounds__(256) void k_gj_finish(int n, double *__restrict__ aug, const int *__restrict__ pivrow,
+                                                   const double *__restrict__ pv) {
+  const int k = blockIdx.x, w = 2 * n;
+  const double *src = aug + (size_t)pivrow[k] * w + n;
+  const double d = 1.0 / pv[k];
+  for (int c = threadIdx.x; c < n; c += 256) aug[(size_t)k * w + c] = src[c] * d;
 }
 __global__ __launch_bounds__(256) void k_dense_apply(int n, const double *__restrict__ aug, const double *__restrict__ b,
                                                      double *__restrict__ x) {
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   double s = 0.0;
-  for (int c = lane; c < n; c += 64) s += aug[(size_t)i * 2 * n + n + c] * b[c];
+  for (int c = lane; c < n; c += 64) s += aug[(size_t)i * 2 * n + c] * b[c];   // the inverse: left half (k_gj_finish)
   s = wave_sum(s);
   if (lane == 0) x[i] = s;
 }
@@ -1661,7 +1684,7 @@ __global__ __launch_bounds__(256) void k_dense_apply_rows(int nloc, int N, int o
   const int i = blockIdx.x * kAmgWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= nloc) return;
   double s = 0.0;
-  for (int c = lane; c < N; c += 64) s += aug[(size_t)(off + i) * 2 * N + N + c] * b[c];
+  for (int c = lane; c < N; c += 64) s += aug[(size_t)(off + i) * 2 * N + c] * b[c];   // the inverse: left half (k_gj_finish)
   s = wave_sum(s);
   if (lane == 0) x[i] = s;
 }
@@ -1688,6 +1711,25 @@ inline int amg_identity_prolongator(isph_ctx *ctx, AmgLevel *L, DevBuf<double> &
                      (const double *)L->nv.p, nvc.p);
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;
+}
+
+// aug = [A | I] (n x 2n, row-major) -> its left half holds A^-1; err bit 4: singular
+inline int amg_dense_invert(isph_ctx *ctx, double *aug, int n, int *derr) {
+  if (n <= 0) return ISPH_SUCCESS;
+  DevTmp<double> col;
+  DevTmp<int> idx;
+  ISPH_CHECK(col.reserve((size_t)3 * n));
+  ISPH_CHECK(idx.reserve((size_t)2 * n));
+  double *c0 = col.p, *c1 = col.p + n, *pv = col.p + 2 * (size_t)n;
+  int *usedat = idx.p, *pivrow = idx.p + n;
+  hipLaunchKernelGGL(k_gj_init, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, (const double *)aug, c0, usedat);
+  for (int k = 0; k < n; ++k)
+    hipLaunchKernelGGL(k_gj_step, dim3(n), dim3(256), 0, ctx->stream, n, k, aug, (const double *)((k & 1) ? c1 : c0), (k & 1) ? c0 : c1,
+                       usedat, pivrow, derr);
+  hipLaunchKernelGGL(k_gj_pivots, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, (const double *)aug, (const int *)pivrow, pv);
+  hipLaunchKernelGGL(k_gj_finish, dim3(n), dim3(256), 0, ctx->stream, n, aug, (const int *)pivrow, (const double *)pv);
+  ISPH_CHECK_HIP(hipGetLastError());
+  return ISPH_SUCCESS;   // (col / idx go back to the pool, which hands them out again only after a device synchronisation)
 }
 
 inline int amg_level_buffers(AmgLevel *L) {
@@ -1897,13 +1939,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
                          (const int *)L->A.ci.p, (const double *)L->A.v.p, (const double *)gr.p, G->cinv.p);
     if (rc == ISPH_SUCCESS) rc = comm_allreduce(ctx, G->cinv.p, 2 * N * N, 0, ctx->stream);
     if (rc == ISPH_SUCCESS && N > 0) {
-      double *colk = G->cinv.p + (size_t)2 * N * N;
-      for (int k = 0; k < N; ++k) {
-        hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, ctx->stream, N, k, G->cinv.p, colk, derr.p);
-        hipLaunchKernelGGL(k_gj_elim, dim3(N), dim3(256), 0, ctx->stream, N, k, G->cinv.p, (const double *)colk, (const int *)derr.p);
-      }
+      rc = amg_dense_invert(ctx, G->cinv.p, N, derr.p);
       int herr = 0;
-      rc = amg_read_int(ctx, derr.p, &herr);
+      if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, derr.p, &herr);
       if (rc == ISPH_SUCCESS && (herr & 4)) rc = fail("AMG: coarsest operator is singular (pass the null vector)", __FILE__, __LINE__);
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == ISPH_SUCCESS) rc = fail("AMG setup failed", __FILE__, __LINE__);   // gs, gr leave scope
@@ -1915,14 +1953,9 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
     if (rc == ISPH_SUCCESS && nc > 0) {
       hipLaunchKernelGGL(k_dense_from_csr, dim3(nc), dim3(kBlock), 0, ctx->stream, nc, (const rp_t *)L->A.rp.p,
                          (const int *)L->A.ci.p, (const double *)L->A.v.p, G->cinv.p);
-      double *colk = G->cinv.p + (size_t)2 * nc * nc;
-      for (int k = 0; k < nc; ++k) {
-        hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, ctx->stream, nc, k, G->cinv.p, colk, derr.p);
-        hipLaunchKernelGGL(k_gj_elim, dim3(nc), dim3(256), 0, ctx->stream, nc, k, G->cinv.p, (const double *)colk,
-                           (const int *)derr.p);
-      }
+      rc = amg_dense_invert(ctx, G->cinv.p, nc, derr.p);
       int herr = 0;
-      rc = amg_read_int(ctx, derr.p, &herr);
+      if (rc == ISPH_SUCCESS) rc = amg_read_int(ctx, derr.p, &herr);
       if (rc == ISPH_SUCCESS && (herr & 4)) rc = fail("AMG: coarsest operator is singular (pass the null vector)", __FILE__, __LINE__);
     }
   }
