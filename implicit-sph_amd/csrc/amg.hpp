@@ -128,8 +128,9 @@ __global__ __launch_bounds__(256) void k_sell_to_csr_i32(int nrow, const int *__
                                                          double *__restrict__ cval, double *__restrict__ dg = nullptr,
                                                          int *__restrict__ sc = nullptr, unsigned long long *__restrict__ key = nullptr,
                                                          volatile unsigned long long *rho_bits = nullptr) {
-  __shared__ int stc[4][64][kCsrChunk];
-  __shared__ double stv[4][64][kCsrChunk];
+  // (+1: a lane writes its row's piece, rows kCsrChunk words apart would all fall on two LDS banks)
+  __shared__ int stc[4][64][kCsrChunk + 1];
+  __shared__ double stv[4][64][kCsrChunk + 1];
   __shared__ int slen[4][64];
   __shared__ rp_t sbeg[4][64];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -943,8 +944,11 @@ __global__ __launch_bounds__(256) void k_gj_step(int n, int k, double *__restric
                                                  int *__restrict__ err) {
   __shared__ double sval[256];
   __shared__ int sidx[256];
+  __shared__ int s_err;
   const int r = blockIdx.x, t = threadIdx.x, w = 2 * n;
-  if (*err & 4) return;
+  if (t == 0) s_err = *err;   // read once per workgroup: the exit below is uniform whatever another row raises meanwhile
+  __syncthreads();
+  if (s_err & 4) return;
   double best = -1.0;
   int bi = 0x7fffffff;
   for (int q = t; q < n; q += 256) {
