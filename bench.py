@@ -115,6 +115,9 @@ def parse():
     ap.add_argument("--overlap", type=int, default=1, help='schwarz-ilu<k>: "Overlap Level" (precond_ifpack.h:43)')
     ap.add_argument("--combine", default="add", choices=["add", "zero"], help='schwarz-ilu<k>: "schwarz: combine mode"')
     ap.add_argument("--amg-theta", type=float, default=0.0, help='"aggregation: threshold" of the sa-amg variant (ML default 0)')
+    ap.add_argument("--amg-smoother", default="ml.xml", choices=["ml.xml", "symmetric"],
+                    help='step workload with --prec sa-amg: "ml.xml" = Gauss-Seidel, efficient symmetric (forward sweeps before, backward sweeps '
+                         'after the coarse correction: bench-script/hopper/tgv/1728/ml.xml); "symmetric" = symmetric sweeps on both sides')
     ap.add_argument("--block", type=int, default=512)
     ap.add_argument("--brick", default="10,10,5",
                     help="particle numbering: bricks of this many lattice cells, brick by brick (x fastest inside).  When the "
@@ -357,7 +360,11 @@ def step_workload(args, json_fd=None, ctx=None, steps=None, warmup=None, quiet=F
     def make_prec(A, singular):
         if args.prec == "sa-amg":                            # ml.xml: max levels 10, Gauss-Seidel 4 sweeps pre and post
             nv = torch.full((N,), 1.0 / np.sqrt(float(N)), dtype=torch.float64, device=dev) if singular else None
-            return hip.PrecondAMG(ctx, A, nullvec=nv, params=hip.AmgParams(max_levels=8, sweeps=4, block=args.block, theta=args.amg_theta))  # ml.xml asks for 10; the library's hierarchy holds 8 (4 are reached at 10^6 rows)
+            # ml.xml: "ML Gauss-Seidel" with "efficient symmetric", 4 sweeps: forward before, backward after the coarse correction
+            # (--amg-smoother symmetric: 4 symmetric sweeps on both sides, what rounds 2-4 ran); max levels: ml.xml asks for 10,
+            # the library's hierarchy holds 8 (4 are reached at 10^6 rows)
+            return hip.PrecondAMG(ctx, A, nullvec=nv, params=hip.AmgParams(max_levels=8, sweeps=4, block=args.block, theta=args.amg_theta,
+                                                                             smoother=0 if args.amg_smoother == "symmetric" else 1))
         if args.prec.startswith("bjacobi-ilu") and lib_order:
             return hip.Precond(ctx, A, args.prec, 0)                       # the library's bricks
         if args.prec == "bjacobi-ilu0" and bptr is not None:

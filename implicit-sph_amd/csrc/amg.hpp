@@ -53,6 +53,7 @@ struct AmgLevel {
   DCsr R;                    // restriction P^T in CSR: its rows are hundreds of entries long, one wave per row
   isph_ilu *sgs = nullptr;   // block-local symmetric Gauss-Seidel in stream form
   DevBuf<double> wsgs;       // small coarse levels: the same smoother as dense 64 x 64 inverses (k_sgs_dense_build)
+  DevBuf<double> wfwd, wbwd; // ... of the forward / backward sweep alone (isph_amg::gs_eff)
   DevBuf<int> agg;
   DevBuf<double> nv, x, b, r, z;
 };
@@ -61,6 +62,7 @@ struct AmgLevel {
 
 struct isph_amg {
   int nlev = 0, block = 512, sweeps = 1, singular = 0;
+  int gs_eff = 0;         // isph_amg_params::smoother == 1: forward sweeps before, backward sweeps after the coarse correction
   int coarse_smooth = 0;  // coarsest level solved by the smoother: singular system (precond_ml.h:97-127) or a level too
                           // large for the dense inverse (no coarsening possible: isolated / Dirichlet rows dominate)
   std::vector<isph::AmgLevel *> L;
@@ -1009,8 +1011,9 @@ __global__ __launch_bounds__(256) void k_dense_apply(int n, const double *__rest
 // per set-up (thread t solves for column t: forward sweep, scaling, backward sweep, with the conventions of
 // k_sgs_pivots: a zero pivot keeps its unknown at zero) and applied as 64 multiply-adds per row.
 constexpr int kSgsDenseMaxRows = 32768;   // 16 MB of inverses at most
+// mode 0: the symmetric sweep; 1: the forward sweep alone, (D+L_B)^-1; 2: the backward sweep alone, (D+U_B)^-1
 __global__ __launch_bounds__(64) void k_sgs_dense_build(int n, const rp_t *__restrict__ rp, const int *__restrict__ ci,
-                                                        const double *__restrict__ v, double *__restrict__ W) {
+                                                        const double *__restrict__ v, double *__restrict__ W, int mode) {
   __shared__ double Bm[64][65];   // the block's entries, row i at Bm[i][.]
   __shared__ double Y[64][65];    // Y[i][t]: unknown i of thread t's column
   const int t = threadIdx.x, r0 = blockIdx.x * 64;
@@ -1022,20 +1025,27 @@ __global__ __launch_bounds__(64) void k_sgs_dense_build(int n, const rp_t *__res
       if (j >= 0 && j < m) Bm[t][j] = v[p];
     }
   __syncthreads();
-  // w = (D + L)^-1 e_t, then y = D w
-  for (int i = 0; i < m; ++i) {
-    double s = i == t ? 1.0 : 0.0;
-    for (int j = 0; j < i; ++j) s -= Bm[i][j] * Y[j][t];
-    const double d = Bm[i][i];
-    Y[i][t] = d != 0.0 ? s / d : 0.0;
+  if (mode == 2) {
+    for (int i = 0; i < m; ++i) Y[i][t] = i == t ? 1.0 : 0.0;
+  } else {
+    // w = (D + L)^-1 e_t, then y = D w
+    for (int i = 0; i < m; ++i) {
+      double s = i == t ? 1.0 : 0.0;
+      for (int j = 0; j < i; ++j) s -= Bm[i][j] * Y[j][t];
+      const double d = Bm[i][i];
+      Y[i][t] = d != 0.0 ? s / d : 0.0;
+    }
+    if (mode == 0)
+      for (int i = 0; i < m; ++i) Y[i][t] *= Bm[i][i];
   }
-  for (int i = 0; i < m; ++i) Y[i][t] *= Bm[i][i];
-  // x = (D + U)^-1 y
-  for (int i = m - 1; i >= 0; --i) {
-    double s = Y[i][t];
-    for (int j = i + 1; j < m; ++j) s -= Bm[i][j] * Y[j][t];
-    const double d = Bm[i][i];
-    Y[i][t] = d != 0.0 ? s / d : 0.0;
+  if (mode != 1) {
+    // x = (D + U)^-1 y
+    for (int i = m - 1; i >= 0; --i) {
+      double s = Y[i][t];
+      for (int j = i + 1; j < m; ++j) s -= Bm[i][j] * Y[j][t];
+      const double d = Bm[i][i];
+      Y[i][t] = d != 0.0 ? s / d : 0.0;
+    }
   }
   __syncthreads();
   // column-major: W[t * 64 + i] = (M^-1)[i][t]; thread t writes row t of every column (coalesced)
@@ -1270,7 +1280,7 @@ inline void amg_level_destroy(AmgLevel *L) {
   if (L->Pm) isph_mat_destroy(L->Pm);
   if (L->APm) isph_mat_destroy(L->APm);
   if (L->sgs) ilu_destroy(L->sgs);
-  L->wsgs.release();
+  L->wsgs.release(); L->wfwd.release(); L->wbwd.release();
   L->agg.release(); L->nv.release(); L->x.release(); L->b.release(); L->r.release(); L->z.release();
   delete L;
 }
@@ -1752,6 +1762,8 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   ISPH_REQUIRE(prm->sweeps >= 1, "smoother sweeps must be >= 1");
   isph_amg *G = new isph_amg();
   G->block = prm->block; G->sweeps = prm->sweeps; G->singular = nullvec_dev != nullptr;
+  ISPH_REQUIRE(prm->smoother == 0 || prm->smoother == 1, "smoother must be 0 (symmetric Gauss-Seidel) or 1 (Gauss-Seidel, efficient symmetric)");
+  G->gs_eff = prm->smoother == 1;
   DevTmp<char> tmp;
   DevTmp<int> derr;
   DevTmp<double> dg;
@@ -1910,10 +1922,18 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
       const char *env_stream = getenv("ISPH_AMG_COARSE_STREAM");   // the chunk-stream sweeps on every level (rounds 2-4)
       if (l > 0 && L->A.n > 0 && L->A.n <= kSgsDenseMaxRows && kAmgCoarseBlock == 64 && !(env_stream && env_stream[0] == '1')) {
         const int nb = (L->A.n + 63) / 64;
-        rc = L->wsgs.reserve((size_t)nb * 4096);
-        if (rc == ISPH_SUCCESS)
-          hipLaunchKernelGGL(k_sgs_dense_build, dim3(nb), dim3(64), 0, ctx->stream, L->A.n, (const rp_t *)L->A.rp.p,
-                             (const int *)L->A.ci.p, (const double *)L->A.v.p, L->wsgs.p);
+        // symmetric sweeps: always on a coarsest level the smoother solves, otherwise unless the cycle uses the one-directional sweeps
+        const bool need_sym = last || !G->gs_eff, need_dir = G->gs_eff && !last;
+        auto build = [&](DevBuf<double> &W, int mode) {
+          int r2 = W.reserve((size_t)nb * 4096);
+          if (r2 == ISPH_SUCCESS)
+            hipLaunchKernelGGL(k_sgs_dense_build, dim3(nb), dim3(64), 0, ctx->stream, L->A.n, (const rp_t *)L->A.rp.p,
+                               (const int *)L->A.ci.p, (const double *)L->A.v.p, W.p, mode);
+          return r2;
+        };
+        if (need_sym) rc = build(L->wsgs, 0);
+        if (rc == ISPH_SUCCESS && need_dir) rc = build(L->wfwd, 1);
+        if (rc == ISPH_SUCCESS && need_dir) rc = build(L->wbwd, 2);
       } else {
         rc = ilu_create(ctx, L->Am, l == 0 ? G->block : kAmgCoarseBlock, &L->sgs, /*sgs=*/true);
       }
@@ -1971,30 +1991,31 @@ inline int amg_create(isph_ctx *ctx, const isph_mat *Am, const isph_amg_params *
   return ISPH_SUCCESS;
 }
 
-// z = M_B^-1 r of level L (accumulate: z += M_B^-1 r)
-inline int amg_sgs_apply(isph_ctx *ctx, AmgLevel *L, const double *r, double *z, bool accumulate) {
+// z = M_B^-1 r of level L (accumulate: z += M_B^-1 r).  part: 0 = the symmetric sweep, 1 = forward alone, 2 = backward alone
+inline int amg_sgs_apply(isph_ctx *ctx, AmgLevel *L, const double *r, double *z, bool accumulate, int part = 0) {
   const int n = L->A.n;
-  if (L->wsgs.p) {
+  const double *W = part == 0 ? L->wsgs.p : (part == 1 ? L->wfwd.p : L->wbwd.p);
+  if (W) {
     const int grid = ((n + 63) / 64 + 3) / 4;
     if (n <= 0) return ISPH_SUCCESS;
-    if (accumulate) hipLaunchKernelGGL((k_sgs_dense_apply<true>), dim3(grid), dim3(256), 0, ctx->stream, n, (const double *)L->wsgs.p, r, z);
-    else hipLaunchKernelGGL((k_sgs_dense_apply<false>), dim3(grid), dim3(256), 0, ctx->stream, n, (const double *)L->wsgs.p, r, z);
+    if (accumulate) hipLaunchKernelGGL((k_sgs_dense_apply<true>), dim3(grid), dim3(256), 0, ctx->stream, n, W, r, z);
+    else hipLaunchKernelGGL((k_sgs_dense_apply<false>), dim3(grid), dim3(256), 0, ctx->stream, n, W, r, z);
     return ISPH_SUCCESS;
   }
-  if (!accumulate) return ilu_apply(ctx, L->sgs, r, z);
-  ISPH_CHECK(ilu_apply(ctx, L->sgs, r, L->z.p));
+  ISPH_REQUIRE(L->sgs != nullptr, "AMG level without a smoother");
+  if (!accumulate) return ilu_apply(ctx, L->sgs, r, z, part);
+  ISPH_CHECK(ilu_apply(ctx, L->sgs, r, L->z.p, part));
   hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
                      (const double *)L->z.p, z);
   return ISPH_SUCCESS;
 }
 
 // x += M_B^-1 (b - A x); zero_guess: x = M_B^-1 b
-inline int amg_smooth(isph_ctx *ctx, const isph_amg *G, int l, const double *b, double *x, bool zero_guess) {
+inline int amg_smooth(isph_ctx *ctx, const isph_amg *G, int l, const double *b, double *x, bool zero_guess, int part = 0) {
   AmgLevel *L = G->L[(size_t)l];
-  const int n = L->A.n;
-  if (zero_guess) return amg_sgs_apply(ctx, L, b, x, false);
+  if (zero_guess) return amg_sgs_apply(ctx, L, b, x, false, part);
   ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr, b, -1.0));   // r = b - A x
-  return amg_sgs_apply(ctx, L, L->r.p, x, true);
+  return amg_sgs_apply(ctx, L, L->r.p, x, true, part);
 }
 
 inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, double *x) {
@@ -2021,8 +2042,9 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
     return ISPH_SUCCESS;
   }
   AmgLevel *Lc = G->L[(size_t)l + 1];
-  ISPH_CHECK(amg_smooth(ctx, G, l, b, x, true));
-  for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
+  const int pre = G->gs_eff ? 1 : 0, post = G->gs_eff ? 2 : 0;
+  ISPH_CHECK(amg_smooth(ctx, G, l, b, x, true, pre));
+  for (int s = 1; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false, pre));
   ISPH_CHECK(spmv_dev(ctx, L->Am, x, L->r.p, nullptr, b, -1.0));   // r = b - A x
   if (L->R.n > 0)   // (a rank without rows still walks the cycle: its neighbours' exchanges and the all-reduces count on it)
     hipLaunchKernelGGL(k_csr_spmv_wave, dim3(amg_wave_grid(L->R.n)), dim3(256), 0, ctx->stream, L->R.n, (const rp_t *)L->R.rp.p,
@@ -2033,10 +2055,10 @@ inline int amg_vcycle(isph_ctx *ctx, const isph_amg *G, int l, const double *b, 
   if (L->APm) {
     // r still holds b - A x of before the correction: r -= (A P) e, then the first post-smoothing sweep uses it
     ISPH_CHECK(spmv_dev(ctx, L->APm, Lc->x.p, L->r.p, nullptr, L->r.p, -1.0));
-    ISPH_CHECK(amg_sgs_apply(ctx, L, L->r.p, x, true));
+    ISPH_CHECK(amg_sgs_apply(ctx, L, L->r.p, x, true, post));
     first = 1;
   }
-  for (int s = first; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false));
+  for (int s = first; s < G->sweeps; ++s) ISPH_CHECK(amg_smooth(ctx, G, l, b, x, false, post));
   return ISPH_SUCCESS;
 }
 

@@ -1045,7 +1045,10 @@ __global__ void k_sgs_pivots(int n, const long long *__restrict__ frp, const dou
 // ---------------------------------------------------------------------------
 // z = U^-1 D^-1 L^-1 r : one wave per block streams the block's chunk list.
 // LDS per wave: y[B] and the block's reciprocal pivots.  kPrefetch chunks (values + words) are kept in flight.
-template <int WAVES, int PF>
+// PART (Gauss-Seidel streams only, amg.hpp): 0 = both directions; 1 = the L part alone, z = (D+L_B)^-1 r (the stream
+// leaves y = D (D+L_B)^-1 r, scaled on the way out); 2 = the U part alone on r, z = (D+U_B)^-1 r -- the forward and the
+// backward sweep of ML's "Gauss-Seidel, efficient symmetric".  The instantiation the ILU preconditioner uses is PART 0.
+template <int WAVES, int PF, int PART = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, int nblocks,
                                                                  const long long *__restrict__ boff,
                                                                  const double *__restrict__ sv,
@@ -1074,8 +1077,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
     yl[posl[t]] = r[blo + t];
     dv[posu[t]] = dinv[blo + t];
   }
-  const long long base = ilu_base_chunk(boff, b, capf, slack);
-  const int nL = __builtin_amdgcn_readfirstlane(blkinfo[4 * b]), nU = __builtin_amdgcn_readfirstlane(blkinfo[4 * b + 1]);
+  const int nL0 = __builtin_amdgcn_readfirstlane(blkinfo[4 * b]), nU0 = __builtin_amdgcn_readfirstlane(blkinfo[4 * b + 1]);
+  // PART 2 starts behind the L chunks and sees a stream without them; PART 1 ends before the U chunks
+  const long long base = ilu_base_chunk(boff, b, capf, slack) + (PART == 2 ? nL0 : 0);
+  const int nL = PART == 2 ? 0 : nL0, nU = PART == 1 ? 0 : nU0;
   const int nsU = __builtin_amdgcn_readfirstlane(blkinfo[4 * b + 3]);  // rows the U stream completes
   const double *__restrict__ pv = sv + base * 64 + lane;
   const unsigned short *__restrict__ pc = sc + base * 64 + lane;
@@ -1153,6 +1158,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
         }
       }
     }
+  }
+  if (PART == 1) {  // forward sweep alone: y = D (D+L_B)^-1 r sits in the L order
+    for (int t = lane; t < m; t += 64) z[blo + t] = yl[posl[t]] * dinv[blo + t];
+    return;
   }
   if (!upper) to_upper();  // no U chunks at all (or an empty stream)
   for (int t = lane; t < m; t += 64) z[blo + t] = yu[posu[t]];
@@ -1665,7 +1674,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream_multi(int n, in
 }
 
 // z_k = U^-1 D^-1 L^-1 r_k for K = 2..4 vectors in one sweep of the factor stream (falls back to K sweeps otherwise)
-inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z);
+inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z, int part = 0);
 inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double *const *rs, double *const *zs) {
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
   if (F->n == 0) return ISPH_SUCCESS;
@@ -1700,25 +1709,28 @@ inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double
   return ISPH_SUCCESS;
 }
 
-inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z) {
+inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z, int part) {
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
+  ISPH_REQUIRE(part >= 0 && part <= 2, "ilu_apply: part must be 0 (both sweeps), 1 (lower) or 2 (upper)");
   if (F->n == 0) return ISPH_SUCCESS;
   constexpr int WV = 4;
   const size_t lds = sizeof(double) * 3 * (size_t)F->B * WV;
   constexpr int pf = kPrefetch;
-#define ISPH_ILU_LAUNCH(PF)                                                                                             \
+#define ISPH_ILU_LAUNCH(PF, PART)                                                                                       \
   do {                                                                                                                   \
     if (lds > 48 * 1024)                                                                                                 \
-      ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_solve_stream<WV, PF>),                     \
+      ISPH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ilu_solve_stream<WV, PF, PART>),               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
-    hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, \
+    hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF, PART>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, \
                        F->n, F->B, F->nblocks, F->stream_off(), F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->blkinfo.p,          \
                        F->dinv.p, r, z, F->capf, F->slack, F->blocks());                                                \
   } while (0)
-  if (pf == 12) ISPH_ILU_LAUNCH(12);
-  else if (pf == 16) ISPH_ILU_LAUNCH(16);
-  else if (pf == 24) ISPH_ILU_LAUNCH(24);
-  else ISPH_ILU_LAUNCH(8);
+  if (part == 1) ISPH_ILU_LAUNCH(16, 1);
+  else if (part == 2) ISPH_ILU_LAUNCH(16, 2);
+  else if (pf == 12) ISPH_ILU_LAUNCH(12, 0);
+  else if (pf == 16) ISPH_ILU_LAUNCH(16, 0);
+  else if (pf == 24) ISPH_ILU_LAUNCH(24, 0);
+  else ISPH_ILU_LAUNCH(8, 0);
 #undef ISPH_ILU_LAUNCH
   ISPH_CHECK_HIP(hipGetLastError());
   return ISPH_SUCCESS;

@@ -1434,6 +1434,7 @@ int isph_prec_create_overlap(isph_ctx *ctx, const isph_mat *Aext, int nlocal, in
 void isph_amg_params_default(isph_amg_params *p) {
   // PrecondWrapper_ML::setParameters(NULL), ref: precond_ml.h:44-55, plus ML's own defaults
   p->max_levels = 5; p->coarse_max = 128; p->omega = 4.0 / 3.0; p->block = 512; p->sweeps = 1; p->theta = 0.0;
+  p->smoother = 0;
 }
 
 int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params *prm, const double *nullvec,

@@ -32,7 +32,7 @@ EXPORTS = [
 class AmgParams(C.Structure):
     """Mirror of isph_amg_params == the keys PrecondWrapper_ML::setParameters sets (precond_ml.h:44-55)."""
     _fields_ = [("max_levels", C.c_int), ("coarse_max", C.c_int), ("omega", C.c_double), ("block", C.c_int),
-                ("sweeps", C.c_int), ("theta", C.c_double)]
+                ("sweeps", C.c_int), ("theta", C.c_double), ("smoother", C.c_int)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -541,6 +541,12 @@ typedef struct {
   double omega;
   int block, sweeps;
   double theta;
+  /* "smoother: type": 0 = symmetric Gauss-Seidel, `sweeps` symmetric sweeps before and after the coarse correction
+   * (the wrapper's default, precond_ml.h:50-52); 1 = "ML Gauss-Seidel" / "Gauss-Seidel" with "smoother: Gauss-Seidel
+   * efficient symmetric" (the ml.xml of the reference's benchmark protocol, bench-script/hopper/tgv/1728/ml.xml):
+   * `sweeps` FORWARD sweeps before the coarse correction, `sweeps` BACKWARD sweeps after it.  (With a null vector the
+   * coarsest level is still solved by symmetric sweeps.) */
+  int smoother;
 } isph_amg_params;
 void isph_amg_params_default(isph_amg_params *p);
 int isph_prec_create_amg(isph_ctx *ctx, const isph_mat *A, const isph_amg_params *prm, const double *nullvec,

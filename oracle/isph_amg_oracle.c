@@ -41,6 +41,8 @@ typedef struct { int n, m; int *rp, *ci; double *v; } csr_t; /* n rows, m column
 
 struct orc_amg {
   int nlev, block, sweeps, singular;
+  int gs_eff; /* 1: "ML Gauss-Seidel" with "smoother: Gauss-Seidel efficient symmetric" (bench-script ml.xml): forward sweeps before the
+                 coarse correction, backward sweeps after it, instead of symmetric sweeps on both sides */
   int coarse_smooth; /* coarsest level solved by the smoother: singular, or larger than AMG_DENSE_MAX rows */
   int whole_sgs; /* 1: Gauss-Seidel over the whole level (= ML's processor-local sweep on one rank) */
   csr_t A[AMG_MAXLEV], P[AMG_MAXLEV], R[AMG_MAXLEV];
@@ -344,6 +346,53 @@ static void sgs_solve(const csr_t *A, const double *dinv, int block, const doubl
   }
 }
 
+/* one direction only: dir > 0: z = (D+L_B)^-1 r (as y = D (D+L_B)^-1 r, then z = D^-1 y: the order the device works in),
+ * dir < 0: z = (D+U_B)^-1 r */
+static void gs_solve(const csr_t *A, const double *dinv, int block, const double *r, double *z, int dir) {
+  const int n = A->n, nb = (n + block - 1) / block;
+#pragma omp parallel for schedule(dynamic, 4) if (n > 16384)
+  for (int b = 0; b < nb; ++b) {
+    const int lo = b * block, hi = lo + block < n ? lo + block : n;
+    if (dir > 0) {
+      for (int i = lo; i < hi; ++i) {
+        double s = r[i];
+        for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) {
+          const int j = A->ci[p];
+          if (j >= lo && j < i) s -= A->v[p] * dinv[j] * z[j];
+        }
+        z[i] = s;
+      }
+      for (int i = lo; i < hi; ++i) z[i] *= dinv[i];
+    } else {
+      for (int i = hi - 1; i >= lo; --i) {
+        double s = r[i];
+        for (int p = A->rp[i]; p < A->rp[i + 1]; ++p) {
+          const int j = A->ci[p];
+          if (j > i && j < hi) s -= A->v[p] * z[j];
+        }
+        z[i] = s * dinv[i];
+      }
+    }
+  }
+}
+
+/* x += M_B^-1 (b - A x); zero_guess: x = M_B^-1 b.  dir: 0 symmetric sweep, +1 forward only, -1 backward only */
+static void smooth_dir(const orc_amg *G, int l, const double *b, double *x, int zero_guess, int dir) {
+  const csr_t *A = &G->A[l];
+  double *r = G->r[l];
+  const int blk = G->whole_sgs ? (A->n > 0 ? A->n : 1) : (l == 0 ? G->block : AMG_COARSE_BLOCK);
+  if (zero_guess) {
+    if (dir == 0) sgs_solve(A, G->dinv[l], blk, b, x); else gs_solve(A, G->dinv[l], blk, b, x, dir);
+    return;
+  }
+  spmv(A, x, r);
+  for (int i = 0; i < A->n; ++i) r[i] = b[i] - r[i];
+  double *z = (double *)malloc(sizeof(double) * (size_t)A->n);
+  if (dir == 0) sgs_solve(A, G->dinv[l], blk, r, z); else gs_solve(A, G->dinv[l], blk, r, z, dir);
+  for (int i = 0; i < A->n; ++i) x[i] += z[i];
+  free(z);
+}
+
 /* x += M_B^-1 (b - A x); zero_guess: x = M_B^-1 b */
 static void smooth(const orc_amg *G, int l, const double *b, double *x, int zero_guess) {
   const csr_t *A = &G->A[l];
@@ -458,8 +507,9 @@ static void vcycle(const orc_amg *G, int l, const double *b, double *x) {
     }
     return;
   }
-  smooth(G, l, b, x, 1);
-  for (int s = 1; s < G->sweeps; ++s) smooth(G, l, b, x, 0);
+  const int pre = G->gs_eff ? 1 : 0, post = G->gs_eff ? -1 : 0;
+  smooth_dir(G, l, b, x, 1, pre);
+  for (int s = 1; s < G->sweeps; ++s) smooth_dir(G, l, b, x, 0, pre);
   double *r = G->r[l];
   spmv(A, x, r);
   for (int i = 0; i < A->n; ++i) r[i] = b[i] - r[i];
@@ -467,8 +517,12 @@ static void vcycle(const orc_amg *G, int l, const double *b, double *x) {
   vcycle(G, l + 1, G->b[l + 1], G->x[l + 1]);
   spmv(&G->P[l], G->x[l + 1], r);
   for (int i = 0; i < A->n; ++i) x[i] += r[i];
-  for (int s = 0; s < G->sweeps; ++s) smooth(G, l, b, x, 0);
+  for (int s = 0; s < G->sweeps; ++s) smooth_dir(G, l, b, x, 0, post);
 }
+
+/* kind: 0 = symmetric Gauss-Seidel sweeps before and after the coarse correction (precond_ml.h:50), 1 = Gauss-Seidel,
+ * "efficient symmetric" (ml.xml of the benchmark protocol) */
+void orc_amg_set_smoother(orc_amg *G, int kind) { G->gs_eff = kind == 1; }
 
 void orc_amg_apply(const orc_amg *G, const double *r, double *z) { vcycle(G, 0, r, z); }
 

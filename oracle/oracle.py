@@ -77,6 +77,7 @@ def lib():
         L.orc_amg_create_ex.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
         L.orc_amg_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_amg_set_smoother.argtypes = [C.c_void_p, C.c_int]
         L.orc_amg_levels.argtypes = [C.c_void_p]
         L.orc_amg_level_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_amg_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -415,7 +416,7 @@ class AMG:
     """Smoothed-aggregation AMG standing in for PrecondWrapper_ML (isph_amg_oracle.c)."""
 
     def __init__(self, rowptr, colidx, val, nullvec=None, max_levels=5, coarse_max=128, omega=4.0 / 3.0, block=512,
-                 sweeps=1, theta=0.0, aggregation="mis2", whole_sgs=False):
+                 sweeps=1, theta=0.0, aggregation="mis2", whole_sgs=False, smoother=0):
         """aggregation "mis2" = the device algorithm, "ml" = ML's sequential Uncoupled sweep; whole_sgs = Gauss-Seidel
         over the whole level (ML on one rank) instead of block-local"""
         self.n = len(rowptr) - 1
@@ -423,6 +424,8 @@ class AMG:
         self.h = lib().orc_amg_create_ex(self.n, _p(self._keep[0]), _p(self._keep[1]), _p(self._keep[2]),
                                          _p(self._keep[3]), max_levels, coarse_max, omega, block, sweeps, theta,
                                          {"mis2": 0, "ml": 1}[aggregation], int(whole_sgs))
+        if smoother:                      # 1 = "ML Gauss-Seidel", efficient symmetric (ml.xml of the benchmark protocol)
+            lib().orc_amg_set_smoother(self.h, int(smoother))
 
     @property
     def levels(self):

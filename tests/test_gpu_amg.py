@@ -204,3 +204,39 @@ def test_amg_rows_with_many_aggregates_take_the_wider_scratch_rows(gpu_ctx, case
     assert np.array_equal(ro, rg) and np.array_equal(co, cg)
     assert np.max(np.abs(vo - vg)) <= 1e-12 * np.abs(vo).max()
     M.close(); A.close()
+
+
+@pytest.mark.parametrize("case,singular,sweeps,block", [
+    (dict(dim=3, n=16, mode=workload.ADVECT, brick=8), True, 1, 256),
+    (dict(dim=3, n=18, mode=workload.JITTER, brick=6), True, 4, 512),     # ml.xml: 4 sweeps
+    (dict(dim=2, n=40, mode=workload.JITTER, brick=8), False, 2, 256),    # direct coarse solve
+])
+def test_amg_gauss_seidel_efficient_symmetric_matches_oracle(gpu_ctx, case, singular, sweeps, block):
+    """isph_amg_params::smoother = 1 -- "ML Gauss-Seidel" with "smoother: Gauss-Seidel efficient symmetric", the ml.xml of the
+    reference's benchmark protocol: forward sweeps before the coarse correction, backward sweeps after it (block-local like
+    the symmetric sweeps; the L part / the U part of the same chunk stream, dense (D+L_B)^-1 / (D+U_B)^-1 on the small
+    levels).  One V cycle and the preconditioned solve against the oracle's restatement; the cycle differs from the
+    symmetric one."""
+    if singular:
+        pr = Problem(tgv_spec(**case))
+    else:
+        pr = Problem(tgv_spec(**case), singular=orc.NOT_SINGULAR, kinds=[orc.FLUID, orc.SOLID], types=wall_types)
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    nv = np.ones(n) / np.sqrt(n) if singular else None
+    kw = dict(theta=0.0, block=block, coarse_max=64, sweeps=sweeps)
+    G = orc.AMG(rp, ci, val, nullvec=nv, smoother=1, **kw)
+    A = hip.Matrix.from_csr(gpu_ctx, rp, ci, val)
+    M = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(smoother=1, **kw))
+    Ms = hip.PrecondAMG(gpu_ctx, A, nullvec=nv, params=hip.AmgParams(smoother=0, **kw))
+    assert M.levels == G.levels >= 2
+    r = np.random.default_rng(6).standard_normal(n)
+    zo, zg, zs = G.apply(r), M.apply(r), Ms.apply(r)
+    assert np.linalg.norm(zg - zo) <= 1e-9 * np.linalg.norm(zo)
+    assert np.linalg.norm(zg - zs) > 1e-3 * np.linalg.norm(zs)          # not the symmetric cycle
+    xo, io_, _ = orc.solve(rp, ci, val, b, singular=singular, prec="amg", amg=G)
+    bg, xg = b.copy(), np.zeros(n)
+    info = hip.solve(gpu_ctx, A, bg, xg, prec=M, singular=singular)
+    assert info.converged == 1 and io_.converged == 1 and abs(info.iters - io_.iters) <= 1
+    assert np.linalg.norm(xg - xo) <= 1e-6 * np.linalg.norm(xo)
+    M.close(); Ms.close(); A.close()
