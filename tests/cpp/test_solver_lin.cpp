@@ -267,7 +267,9 @@ static int run(int argc, char **argv) {
   Epetra_Map nodalmap(-1, n, gid.data(), 1, Epetra_MpiComm(world));
   Epetra_CrsMatrix AA(n, n, rp.data(), ci.data(), val.data());
 
-  const bool use_ml = argc > 4 && std::string(argv[4]) == "ml";
+  // "ml-xml": PrecondWrapper_ML with the keys of the benchmark protocol's ml.xml (bench-script/hopper/tgv/1728/ml.xml)
+  const bool ml_xml = argc > 4 && std::string(argv[4]) == "ml-xml";
+  const bool use_ml = (argc > 4 && std::string(argv[4]) == "ml") || ml_xml;
   const bool use_cg = argc > 4 && std::string(argv[4]) == "cg";
   const bool ifpack_defaults = argc > 4 && std::string(argv[4]) == "ifpack-defaults";  // level-of-fill 1, overlap 1
   const bool ifpack_reference = argc > 4 && std::string(argv[4]) == "ifpack-reference";  // + one subdomain = the whole matrix
@@ -279,7 +281,14 @@ static int run(int argc, char **argv) {
   Teuchos::ParameterList *pp = prec.setParameters();
   if (use_ml) {  // the keys of precond_ml.h:44-55 are already set; shrink the hierarchy to the test size
     pp->set("coarse: max size", 64);
-    pp->set("aggregation: threshold", 0.02);
+    if (ml_xml) {
+      pp->set("max levels", 10);
+      pp->set("smoother: type", "ML Gauss-Seidel");
+      pp->set("smoother: Gauss-Seidel efficient symmetric", true);
+      pp->set("smoother: sweeps", 4);
+    } else {
+      pp->set("aggregation: threshold", 0.02);
+    }
   } else if (!ifpack_defaults && !ifpack_reference) {
     pp->set("fact: level-of-fill", 0);
     pp->set("Overlap Level", 0);

@@ -579,7 +579,7 @@ def test_rccl_forward_comm_of_per_atom_fields(gpu_ctx):
 
 
 # ---------------------------------------------------------------- C++ mirror of the reference interface
-@pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml"), (1, "ifpack-defaults"), (1, "ifpack-reference"),
+@pytest.mark.parametrize("singular,cg", [(1, False), (0, True), (1, "ml"), (1, "ml-xml"), (1, "ifpack-defaults"), (1, "ifpack-reference"),
                                          (1, "recycling")])
 def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     """SolverLin_Belos / PrecondWrapper_Ifpack (implicit-sph_amd/host/*.h) driven
@@ -600,7 +600,8 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
         np.array([pr.n, len(val)], np.int32).tofile(f)
         rp.astype(np.int32).tofile(f); ci.astype(np.int32).tofile(f)
         val.tofile(f); b.tofile(f)
-    ml = cg == "ml"
+    ml = cg in ("ml", "ml-xml")
+    ml_xml = cg == "ml-xml"
     mode = cg if isinstance(cg, str) else None
     fill = 1 if mode in ("ifpack-defaults", "ifpack-reference") else 0   # PrecondWrapper_Ifpack's own defaults: fill 1
     cg = bool(cg) and mode is None
@@ -613,7 +614,9 @@ def test_cpp_solver_lin_mirror(tmp_path, singular, cg):
     bp = np.arange(0, pr.n + 256, 256).clip(0, pr.n).astype(np.int32)
     prm = orc.SolverParams(solver_type=1, tol=1e-8) if cg else orc.SolverParams()
     if ml:   # PrecondWrapper_ML mirror: setNullVector reaches the AMG through solveProblem (solver_lin_belos.h:149-151)
-        G = orc.AMG(rp, ci, val, nullvec=np.full(pr.n, 1.0 / np.sqrt(pr.n)), coarse_max=64, theta=0.02, block=256)
+        # ("ml-xml": the keys of the benchmark protocol's ml.xml -- Gauss-Seidel, efficient symmetric, 4 sweeps, 10 levels asked)
+        kw = dict(theta=0.0, sweeps=4, smoother=1, max_levels=8) if ml_xml else dict(theta=0.02)
+        G = orc.AMG(rp, ci, val, nullvec=np.full(pr.n, 1.0 / np.sqrt(pr.n)), coarse_max=64, block=256, **kw)
         xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="amg", amg=G, params=prm)
     elif mode == "ifpack-reference":   # "isph: block rows" = 0: ILU(1) of the whole matrix, the reference on one rank
         xo, io, bo = orc.solve(rp, ci, val, b, singular=True, prec="ilu", ilu=orc.ILU(rp, ci, val, 1), params=prm)
