@@ -2003,11 +2003,7 @@ inline int amg_sgs_apply(isph_ctx *ctx, AmgLevel *L, const double *r, double *z,
     return ISPH_SUCCESS;
   }
   ISPH_REQUIRE(L->sgs != nullptr, "AMG level without a smoother");
-  if (!accumulate) return ilu_apply(ctx, L->sgs, r, z, part);
-  ISPH_CHECK(ilu_apply(ctx, L->sgs, r, L->z.p, part));
-  hipLaunchKernelGGL(k_axpy_dev, dim3(stream_grid(n)), dim3(kBlock), 0, ctx->stream, n, 1.0, (const double *)nullptr,
-                     (const double *)L->z.p, z);
-  return ISPH_SUCCESS;
+  return ilu_apply(ctx, L->sgs, r, z, part, accumulate);   // (accumulate: the stream kernel adds into z on its way out)
 }
 
 // x += M_B^-1 (b - A x); zero_guess: x = M_B^-1 b

@@ -1058,7 +1058,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
                                                                  const int *__restrict__ blkinfo,
                                                                  const double *__restrict__ dinv,
                                                                  const double *__restrict__ r, double *__restrict__ z,
-                                                                 int capf, int slack, const int *__restrict__ bptr) {
+                                                                 int capf, int slack, const int *__restrict__ bptr,
+                                                                 int accumulate = 0) {
+  // accumulate: z += M^-1 r instead of z = M^-1 r (the smoother's x += M_B^-1 (b - A x): no vector kernel behind the sweep)
   extern __shared__ double lds_y[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES + wave);  // wave-uniform: keep what follows scalar
@@ -1160,11 +1162,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream(int n, int B, i
     }
   }
   if (PART == 1) {  // forward sweep alone: y = D (D+L_B)^-1 r sits in the L order
-    for (int t = lane; t < m; t += 64) z[blo + t] = yl[posl[t]] * dinv[blo + t];
+    for (int t = lane; t < m; t += 64) {
+      const double v = yl[posl[t]] * dinv[blo + t];
+      z[blo + t] = accumulate ? z[blo + t] + v : v;
+    }
     return;
   }
   if (!upper) to_upper();  // no U chunks at all (or an empty stream)
-  for (int t = lane; t < m; t += 64) z[blo + t] = yu[posu[t]];
+  if (accumulate) {
+    for (int t = lane; t < m; t += 64) z[blo + t] += yu[posu[t]];
+  } else {
+    for (int t = lane; t < m; t += 64) z[blo + t] = yu[posu[t]];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1674,7 +1683,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ilu_solve_stream_multi(int n, in
 }
 
 // z_k = U^-1 D^-1 L^-1 r_k for K = 2..4 vectors in one sweep of the factor stream (falls back to K sweeps otherwise)
-inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z, int part = 0);
+inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z, int part = 0, bool accumulate = false);
 inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double *const *rs, double *const *zs) {
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
   if (F->n == 0) return ISPH_SUCCESS;
@@ -1709,7 +1718,7 @@ inline int ilu_apply_multi(isph_ctx *ctx, const isph_ilu *F, int K, const double
   return ISPH_SUCCESS;
 }
 
-inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z, int part) {
+inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *z, int part, bool accumulate) {
   ISPH_REQUIRE(F != nullptr, "ILU factor is NULL");
   ISPH_REQUIRE(part >= 0 && part <= 2, "ilu_apply: part must be 0 (both sweeps), 1 (lower) or 2 (upper)");
   if (F->n == 0) return ISPH_SUCCESS;
@@ -1723,7 +1732,7 @@ inline int ilu_apply(isph_ctx *ctx, const isph_ilu *F, const double *r, double *
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                         \
     hipLaunchKernelGGL((k_ilu_solve_stream<WV, PF, PART>), dim3((F->nblocks + WV - 1) / WV), dim3(WV * 64), lds, ctx->stream, \
                        F->n, F->B, F->nblocks, F->stream_off(), F->sv.p, F->sc.p, F->si.p, F->sperm.p, F->blkinfo.p,          \
-                       F->dinv.p, r, z, F->capf, F->slack, F->blocks());                                                \
+                       F->dinv.p, r, z, F->capf, F->slack, F->blocks(), accumulate ? 1 : 0);                            \
   } while (0)
   if (part == 1) ISPH_ILU_LAUNCH(16, 1);
   else if (part == 2) ISPH_ILU_LAUNCH(16, 2);
