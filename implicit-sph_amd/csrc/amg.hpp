@@ -502,9 +502,8 @@ __global__ __launch_bounds__(256) void k_amg_rho(int n, const rp_t *__restrict__
 // fixed-order wave sum and merged into the table, so the result does not depend on scheduling.  FILL = false only counts.
 constexpr int kProlongSlots = 8;
 
-// MODE 0 counts, MODE 1 fills the CSR rows behind prp (the two passes of rounds 2-4: rows of more than kProlongCap
+// MODE 0 counts, MODE 1 fills the CSR rows behind prp (the two passes of rounds 2-4: rows of more than 64
 // aggregates, and ISPH_AMG_PROLONG_TWO_PASS=1)
-constexpr int kProlongCap = 64;
 
 // The same row in ONE pass: LPR lanes per row (16: four rows per wave -- the chain row offsets -> columns -> aggregates ->
 // table is four dependent round trips whatever the row holds, so four rows in flight per wave finish in the time of one),
@@ -1218,7 +1217,6 @@ template <int CAP>
 inline int amg_spgemm_rows(isph_ctx *ctx, const DCsr &X, const DCsr &Y, DCsr &C, DevBuf<char> &tmp, int *derr, bool *overflow) {
   constexpr int SHIFT = CAP == 64 ? 6 : 8;
   static_assert(CAP == 64 || CAP == 256, "scratch rows of 64 or 256 slots");
-  static_assert(kProlongCap == 64, "k_rows_compact is called with shift 6 for the prolongator");
   *overflow = false;
   C.n = X.n; C.m = Y.m;
   ISPH_CHECK(C.rp.reserve((size_t)C.n + 1));
