@@ -576,3 +576,47 @@ def test_oracle_kernels_equal_the_reference_kernel_classes():
                 assert np.max(np.abs(dwo - dw)) <= 4e-16 * scale_d, (name, dim, h)
                 out = np.abs(r / h) >= support                     # the ratio the kernels themselves form
                 assert np.all(w[out] == 0.0) and np.all(wo[out] == 0.0) and out.sum() > 5
+
+
+def test_amg_gauss_seidel_efficient_symmetric_cycle_is_what_it_says():
+    """The oracle's restatement of ml.xml's smoother ("ML Gauss-Seidel" with "smoother: Gauss-Seidel efficient symmetric",
+    bench-script/hopper/tgv/1728/ml.xml) against an independent two-level V cycle written with SciPy: `sweeps` block-local
+    FORWARD sweeps x += (D+L_B)^-1 (b - A x), the coarse correction through the exported P and coarse operator, `sweeps`
+    block-local BACKWARD sweeps x += (D+U_B)^-1 (b - A x)."""
+    import scipy.sparse.linalg as spla
+    from problems import wall_types
+    pr = Problem(tgv_spec(dim=2, n=32, mode=workload.JITTER, brick=8), singular=orc.NOT_SINGULAR,
+                 kinds=[orc.FLUID, orc.SOLID], types=wall_types)
+    rp, ci, val, b = pr.poisson()
+    n = pr.n
+    block, sweeps = 256, 3
+    G = orc.AMG(rp, ci, val, nullvec=None, coarse_max=256, block=block, sweeps=sweeps, smoother=1)
+    assert G.levels == 2
+    A = sps.csr_matrix((val, ci, rp), shape=(n, n))
+    prp, pci, pv = G.export(0, "P")
+    r1, c1, v1 = G.export(1, "A")
+    nc = G.level_info(1)["rows"]
+    P = sps.csr_matrix((pv, pci, prp), shape=(n, nc))
+    Ac = sps.csr_matrix((v1, c1, r1), shape=(nc, nc))
+    # block-diagonal lower / upper triangles (diagonal included)
+    rows, cols = A.nonzero()
+    same = (rows // block) == (cols // block)
+    Ab = sps.csr_matrix((np.asarray(A[rows[same], cols[same]]).ravel(), (rows[same], cols[same])), shape=(n, n))
+    Lb, Ub = sps.tril(Ab, format="csr"), sps.triu(Ab, format="csr")
+
+    def cycle(r):
+        x = np.zeros(n)
+        for _ in range(sweeps):
+            x = x + spla.spsolve_triangular(Lb, r - A @ x, lower=True)
+        xc = spla.spsolve(Ac.tocsc(), P.T @ (r - A @ x))
+        x = x + P @ xc
+        for _ in range(sweeps):
+            x = x + spla.spsolve_triangular(Ub, r - A @ x, lower=False)
+        return x
+
+    r = np.random.default_rng(11).standard_normal(n)
+    zo, zs = G.apply(r), cycle(r)
+    assert np.linalg.norm(zo - zs) <= 1e-11 * np.linalg.norm(zs)
+    # and it is a different cycle from the symmetric-sweep one
+    Gs = orc.AMG(rp, ci, val, nullvec=None, coarse_max=256, block=block, sweeps=sweeps, smoother=0)
+    assert np.linalg.norm(Gs.apply(r) - zo) > 1e-3 * np.linalg.norm(zo)
